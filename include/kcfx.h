@@ -1,0 +1,149 @@
+/*
+ * kcfx.h -- C ABI of the MI355X-native `getVariations` engine (libkcfx.so).
+ *
+ * The reference (sivasubramanics/kcftools v0.4.0, pure Java) has no FFI / plugin ABI; "plugin"
+ * means a picocli sub-command class.  The seam this ABI replaces is Java-internal
+ * (paths relative to src/main/java/nl/wur/bis/kcftools/):
+ *
+ *   new KMC(prefix, inMemory)                      Data/KMC.java:56-78         -> kcfx_db_open
+ *   KMC getters used for the KCF header            Data/KMC.java:403-410, Plugins/GetVariants.java:96,103
+ *                                                                               -> kcfx_db_info
+ *   KMC.getCount(Kmer)                             Data/KMC.java:292-326       -> kcfx_db_lookup (batched)
+ *   kmc.close()                                    Data/KMC.java:412-420       -> kcfx_db_close
+ *   getWindows() "window" case                     Plugins/GetVariants.java:293-320 -> kcfx_windows
+ *   thread-pool fan-out + getFasta + processWindow Plugins/GetVariants.java:129-159,188-261
+ *                                                                               -> kcfx_ref_create + kcfx_screen_ref
+ *                                                                                  (or the one-shot kcfx_screen)
+ *   Window.addTotalKmers/setEffLength/addData args Plugins/GetVariants.java:254-258 -> kcfx_result
+ *   Data.update / Data.computeScore                Data/Data.java:70-107       -> kcfx_score
+ *   Logger.error -> System.exit(1)                 Utils/Logger.java:29-31     -> int32 status + kcfx_last_error
+ *
+ * Conventions
+ *   - every entry point returns 0 on success, non-zero on failure; the library never exits or aborts;
+ *     kcfx_last_error() returns a thread-local message for the last failure on the calling thread.
+ *   - the caller owns every input and output buffer; the library owns only the opaque handles.
+ *   - a handle may be used from one thread at a time; distinct handles (one per GPU) may be used concurrently.
+ *   - plain pointers and sizes only; no torch / C++ types.  "device" pointers are HIP device pointers.
+ *   - k-mers cross the ABI as the reference's Kmer.kmerLong word (Kmer.java:232-252): base i in bits
+ *     [63-2i, 62-2i], A=0 C=1 G=2 T=3, left-aligned; k <= 32.
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails.
+ */
+#ifndef KCFX_H
+#define KCFX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KCFX_OK 0
+#define KCFX_ERR_ARG 1       /* bad argument */
+#define KCFX_ERR_IO 2        /* file missing / truncated */
+#define KCFX_ERR_FORMAT 3    /* not a KMC 0x200 database, unsupported k / prefix length */
+#define KCFX_ERR_DEVICE 4    /* HIP error (no device, out of memory, launch failure) */
+#define KCFX_ERR_WEIGHTS 5   /* wi + wt + wr != 1.0 (Data.java:101-103; the reference exits) */
+
+typedef struct kcfx_db kcfx_db;     /* one KMC database re-indexed into an HBM-resident table on one GPU */
+typedef struct kcfx_ref kcfx_ref;   /* reference text + window list resident in HBM on one GPU */
+
+/* Per (window, sample) integers: exactly the arguments of Window.addTotalKmers(int), Window.setEffLength(int)
+ * and Window.addData(sample, obs, var, inner, left, right, kmerCount, ...)  (GetVariants.java:254-258). 40 bytes. */
+typedef struct {
+    int32_t total_kmers;     /* valid k-mers in the window (Fasta.java:90-127)                */
+    int32_t eff_length;      /* Fasta.getEffectiveATGCCount (Fasta.java:140-167)              */
+    int32_t obs;             /* k-mers with count >= min_count (GetVariants.java:224-227)     */
+    int32_t var;             /* maximal miss-runs (GetVariants.java:228-230,248-249)          */
+    int32_t inner;           /* sum of getDistance over inner gaps (GetVariants.java:237,267) */
+    int32_t left;            /* leading miss-run length, in k-mers (GetVariants.java:232-234) */
+    int32_t right;           /* trailing miss-run length, in k-mers (GetVariants.java:248-251)*/
+    int32_t _pad;
+    int64_t kmer_count_sum;  /* sum of counts over observed k-mers (GetVariants.java:226)     */
+} kcfx_result;
+
+/* Header fields of the database (KMC.java:124-139) plus the derived sizes. */
+typedef struct {
+    int32_t kmer_length, mode, counter_size, lut_prefix_length, signature_length;
+    int32_t min_count, max_count;
+    int32_t both_strands;    /* 1 = canonical k-mers (header byte == 0, KMC.java:133) */
+    int32_t version;         /* 0x200 */
+    int32_t n_bins;          /* numPrefixArrays (KMC.java:156) */
+    int64_t total_kmers;
+    int64_t table_bytes;     /* HBM bytes of the re-indexed table */
+    int64_t table_lines;     /* number of 64-byte lines */
+    int32_t slots_per_line;
+    int32_t device;
+    double  load_seconds;    /* file read + upload + table build */
+} kcfx_db_info_t;
+
+/* ---- database ------------------------------------------------------------------------------------ */
+
+/* Parse <kmc_prefix>.kmc_pre / .kmc_suf (layout: KMC.java:107-189) and build the HBM table on `device`.
+ * Fails with KCFX_ERR_FORMAT unless version == 0x200, 1 <= k <= 32 and (k - lut_prefix_length) % 4 == 0. */
+int32_t kcfx_db_open(const char* kmc_prefix, int32_t device, kcfx_db** out);
+
+/* Build the same table from host arrays of distinct k-mer words and counts (no files). `counter_size` in
+ * 0..4 selects the stored counter width exactly like the KMC header field. */
+int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, int32_t kmer_length,
+                      int32_t counter_size, int32_t both_strands, int32_t device, kcfx_db** out);
+
+int32_t kcfx_db_info(const kcfx_db* db, kcfx_db_info_t* info);
+
+/* Batched KMC.getCount (KMC.java:292-326): counts_out[i] = stored counter of kmers[i] or 0.  The words are looked
+ * up as given (canonicalise first for a both-strands database, as Kmer(Kmer, bothStrands) does, Kmer.java:57-65).
+ * Counts are Java ints: a 4-byte counter with the top bit set is negative. Host pointers. */
+int32_t kcfx_db_lookup(kcfx_db* db, const uint64_t* kmers, int64_t n, int32_t* counts_out);
+
+void kcfx_db_close(kcfx_db* db);
+
+/* ---- reference text + windows ---------------------------------------------------------------------- */
+
+/* Upload newline-free, case-preserved text and a window list: window w is text[win_begin[w], win_begin[w]+win_len[w]).
+ * Windows may overlap (tiling windows share k-1 bases) and gene-mode windows are pre-spliced by the caller.
+ * `kmer_length` fixes the tile plan; use the database's. Host pointers; they are not retained. */
+int32_t kcfx_ref_create(int32_t device, int32_t kmer_length, const uint8_t* text, int64_t text_len,
+                        const int64_t* win_begin, const int32_t* win_len, int32_t n_windows, kcfx_ref** out);
+int32_t kcfx_ref_n_windows(const kcfx_ref* ref);
+int64_t kcfx_ref_n_kmer_slots(const kcfx_ref* ref);   /* sum over windows of max(0, len - k + 1) */
+void kcfx_ref_destroy(kcfx_ref* ref);
+
+/* ---- the hot path ----------------------------------------------------------------------------------- */
+
+/* Screen every window of `ref` against `db`; out[w] (host, n_windows entries) receives the integers.
+ * Replaces GetVariants.java:129-159. Synchronous. db and ref must live on the same device. */
+int32_t kcfx_screen_ref(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count, kcfx_result* out);
+
+/* Same, asynchronous on `hip_stream` (a hipStream_t, NULL = default stream) with the results left in device
+ * memory `out_device` (n_windows * sizeof(kcfx_result) bytes). No host synchronisation, no allocation. */
+int32_t kcfx_screen_ref_async(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count, void* out_device, void* hip_stream);
+
+/* One-shot convenience: kcfx_ref_create + kcfx_screen_ref + kcfx_ref_destroy. */
+int32_t kcfx_screen(kcfx_db* db, const uint8_t* text, int64_t text_len, const int64_t* win_begin,
+                    const int32_t* win_len, int32_t n_windows, int32_t min_kmer_count, kcfx_result* out);
+
+/* Data.update + Data.computeScore (Data.java:87,95-107), strict IEEE double, no FMA; runs on the host.
+ * score/mean_count may be NULL. Returns KCFX_ERR_WEIGHTS if wi + wt + wr != 1.0 (values are still written). */
+int32_t kcfx_score(const kcfx_result* res, int64_t n, double wi, double wt, double wr, double* score, double* mean_count);
+
+/* GetVariants.getWindows "window" case (GetVariants.java:293-320). step <= 0: tiling. Writes up to `cap` windows,
+ * *n_out = number of windows. window <= k-1 in tiling mode (the reference loops forever) is KCFX_ERR_ARG. */
+int32_t kcfx_windows(int32_t seq_len, int32_t window, int32_t step, int32_t kmer_length,
+                     int32_t* starts, int32_t* ends, int64_t cap, int64_t* n_out);
+
+/* ---- measurement ------------------------------------------------------------------------------------ */
+
+/* When enabled, kcfx_screen_ref_async brackets its dominant kernel (screen_tiles) with HIP events on the launch
+ * stream; kcfx_prof_read synchronises those events and returns the summed kernel time and launch count since the
+ * last reset. Used by bench.py for roofline.achieved. */
+int32_t kcfx_prof_enable(kcfx_ref* ref, int32_t enable);
+int32_t kcfx_prof_read(kcfx_ref* ref, double* kernel_ms_sum, int64_t* launches, int32_t reset);
+
+/* ---- misc --------------------------------------------------------------------------------------------- */
+const char* kcfx_last_error(void);
+int32_t kcfx_device_count(int32_t* n);
+const char* kcfx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KCFX_H */

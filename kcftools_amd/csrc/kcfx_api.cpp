@@ -1,0 +1,640 @@
+// kcfx_api.cpp -- host side of libkcfx.so: the C ABI of include/kcfx.h.
+//
+// Handles mirror the reference's objects: kcfx_db <-> `KMC` (Data/KMC.java), kcfx_ref <-> the window list plus the
+// FastaIndex-backed window text (Plugins/GetVariants.java:117-121,188-197). There is no CPU compute path here:
+// every compute entry point launches the HIP kernels of kcfx_kernels.hip or fails.
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kcfx_internal.h"
+
+namespace kcfx {
+
+static thread_local std::string g_error;
+void set_error(const std::string& msg) { g_error = msg; }
+int32_t hip_fail(hipError_t e, const char* what) {
+    g_error = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what;
+    (void)hipGetLastError();
+    return KCFX_ERR_DEVICE;
+}
+static int32_t fail(int32_t code, const std::string& msg) {
+    g_error = msg;
+    return code;
+}
+
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// KMC files (layout: KMC.java:107-189)
+// ------------------------------------------------------------------------------------------------------
+struct KmcHeader {
+    int32_t k = 0, mode = 0, counter_size = 0, p = 0, sig_len = 0, min_count = 0, max_count = 0, both = 0, version = 0;
+    int32_t n_bins = 0;
+    int64_t total = 0;
+    int32_t suffix_bytes = 0, record_size = 0;
+    std::vector<uint64_t> lut;   // n_bins * 4^p global record indices
+};
+
+static uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+
+static int32_t read_whole(const std::string& path, std::vector<uint8_t>& out) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return fail(KCFX_ERR_IO, "Error reading prefix file " + path);
+    fseeko(f, 0, SEEK_END);
+    const off_t n = ftello(f);
+    fseeko(f, 0, SEEK_SET);
+    out.resize((size_t)n);
+    if (n > 0 && fread(out.data(), 1, (size_t)n, f) != (size_t)n) {
+        fclose(f);
+        return fail(KCFX_ERR_IO, "short read on " + path);
+    }
+    fclose(f);
+    return KCFX_OK;
+}
+
+// KMC.java:107-168 readPrefixFile
+static int32_t parse_prefix_file(const std::string& path, KmcHeader& h) {
+    std::vector<uint8_t> pre;
+    if (int32_t rc = read_whole(path, pre)) return rc;
+    const int64_t size = (int64_t)pre.size();
+    if (size < 4 + 8 + 68 + 8) return fail(KCFX_ERR_FORMAT, "prefix file too small: " + path);
+    if (memcmp(pre.data(), "KMCP", 4) != 0 || memcmp(pre.data() + size - 4, "KMCP", 4) != 0)
+        return fail(KCFX_ERR_FORMAT, "missing KMCP markers in " + path);
+    const int64_t header_offset = rd32(pre.data() + size - 8);             // :117-118
+    const int64_t pos = size - header_offset - 8;                          // :121
+    if (header_offset < 68 || pos < 4 + 8) return fail(KCFX_ERR_FORMAT, "bad header offset in " + path);
+    const uint8_t* q = pre.data() + pos;
+    h.k = (int32_t)rd32(q + 0);                                            // :124
+    h.mode = (int32_t)rd32(q + 4);
+    h.counter_size = (int32_t)rd32(q + 8);
+    h.p = (int32_t)rd32(q + 12);
+    h.sig_len = (int32_t)rd32(q + 16);
+    h.min_count = (int32_t)rd32(q + 20);
+    h.max_count = (int32_t)rd32(q + 24);
+    h.total = (int64_t)rd64(q + 28);
+    h.both = (q[36] == 0) ? 1 : 0;                                         // :133 (inverted flag)
+    h.version = (int32_t)rd32(q + 64);                                     // :139
+    if (h.version != 0x200) return fail(KCFX_ERR_FORMAT, "KMC version is not 0x200");   // :140-142
+    if (h.k < 1 || h.k > 32) return fail(KCFX_ERR_FORMAT, "unsupported k-mer length " + std::to_string(h.k) + " (1..32)");
+    if (h.p < 0 || h.p > 15 || h.p > h.k || (h.k - h.p) % 4 != 0)
+        return fail(KCFX_ERR_FORMAT, "unsupported LUT prefix length " + std::to_string(h.p) + " for k=" + std::to_string(h.k));
+    if (h.counter_size < 0 || h.counter_size > 4) return fail(KCFX_ERR_FORMAT, "unsupported counter size");
+    if (h.sig_len < 1 || h.sig_len > 14) return fail(KCFX_ERR_FORMAT, "unsupported signature length");
+    if (h.total < 0) return fail(KCFX_ERR_FORMAT, "negative k-mer total");
+    const int64_t map_size = (1ll << (2 * h.sig_len)) + 1;                 // :145
+    const int64_t map_start = size - header_offset - 8 - map_size * 4;     // :146
+    const int64_t lut_size = 1ll << (2 * h.p);                             // :154
+    if (map_start < 4 + 8) return fail(KCFX_ERR_FORMAT, "prefix file too small for its signature map");
+    h.n_bins = (int32_t)((map_start - 8 - 4) / (lut_size * 8));            // :156
+    const int64_t entries = (int64_t)h.n_bins * lut_size;                  // :160
+    h.lut.resize((size_t)entries);
+    if (entries) memcpy(h.lut.data(), pre.data() + 4, (size_t)entries * 8);   // :153,:161-163
+    for (int64_t i = 1; i < entries; ++i)
+        if (h.lut[i] < h.lut[i - 1]) return fail(KCFX_ERR_FORMAT, "LUT is not monotonic");
+    if (entries && h.lut[entries - 1] > (uint64_t)h.total) return fail(KCFX_ERR_FORMAT, "LUT points past total_kmers");
+    if (h.total > 0 && (entries == 0 || h.lut[0] != 0)) return fail(KCFX_ERR_FORMAT, "LUT does not start at record 0");
+    h.suffix_bytes = (h.k - h.p) / 4;
+    h.record_size = h.counter_size + h.suffix_bytes;                       // :61
+    return KCFX_OK;
+}
+
+}  // namespace kcfx
+
+using namespace kcfx;
+
+// ------------------------------------------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------------------------------------------
+struct kcfx_db {
+    int32_t device = 0;
+    kcfx_db_info_t info{};
+    uint8_t* d_lines = nullptr;
+    uint32_t n_lines = 0;
+    int32_t wide = 0;
+    hipStream_t stream = nullptr;
+    TableView view() const { return TableView{d_lines, n_lines, wide}; }
+};
+
+struct kcfx_ref {
+    int32_t device = 0;
+    int32_t k = 0;
+    int32_t n_windows = 0;
+    int32_t n_tiles = 0;
+    int64_t n_slots = 0;
+    uint8_t* d_text = nullptr;
+    TileDesc* d_tiles = nullptr;
+    int32_t* d_win_tile0 = nullptr;
+    TileSummary* d_summ = nullptr;
+    kcfx_result* d_res = nullptr;      // used by the synchronous entry point
+    hipStream_t stream = nullptr;
+    // measurement
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int32_t check_device(int32_t device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(KCFX_ERR_DEVICE, "no HIP device available (libkcfx has no CPU fallback)");
+    }
+    if (device < 0 || device >= n) return fail(KCFX_ERR_ARG, "device index out of range");
+    return KCFX_OK;
+}
+
+double table_load_factor() {
+    const char* s = getenv("KCFX_TABLE_LOAD");
+    double a = s ? atof(s) : 0.5;
+    if (!(a >= 0.05 && a <= 0.9)) a = 0.5;
+    return a;
+}
+
+int32_t table_alloc(kcfx_db* db, int64_t n_keys, int32_t counter_size) {
+    db->wide = counter_size > 2 ? 1 : 0;
+    const int slots = db->wide ? SLOTS_U32 : SLOTS_U16;
+    double want = (double)n_keys / (slots * table_load_factor());
+    if (want < 64) want = 64;
+    if (want > 4294967295.0) return fail(KCFX_ERR_ARG, "database too large for a 32-bit line index");
+    db->n_lines = (uint32_t)want + 1;
+    KCFX_HIP(hipMalloc(&db->d_lines, (size_t)db->n_lines * LINE_BYTES));
+    KCFX_HIP(launch_table_clear(db->d_lines, db->n_lines, db->stream));
+    db->info.table_bytes = (int64_t)db->n_lines * LINE_BYTES;
+    db->info.table_lines = db->n_lines;
+    db->info.slots_per_line = slots;
+    return KCFX_OK;
+}
+
+void db_free(kcfx_db* db) {
+    if (!db) return;
+    DeviceGuard g(db->device);
+    if (db->d_lines) (void)hipFree(db->d_lines);
+    if (db->stream) (void)hipStreamDestroy(db->stream);
+    delete db;
+}
+
+void ref_free(kcfx_ref* r) {
+    if (!r) return;
+    DeviceGuard g(r->device);
+    for (auto& ev : r->events) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    if (r->d_text) (void)hipFree(r->d_text);
+    if (r->d_tiles) (void)hipFree(r->d_tiles);
+    if (r->d_win_tile0) (void)hipFree(r->d_win_tile0);
+    if (r->d_summ) (void)hipFree(r->d_summ);
+    if (r->d_res) (void)hipFree(r->d_res);
+    if (r->stream) (void)hipStreamDestroy(r->stream);
+    delete r;
+}
+
+// stream the .kmc_suf records through the GPU: upload -> decode_records -> table_insert
+int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& h) {
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return fail(KCFX_ERR_IO, "Error reading suffix buffers from file " + path);
+    struct stat st;
+    if (fstat(fd, &st) != 0 || (int64_t)st.st_size < 4 + h.total * h.record_size) {
+        close(fd);
+        return fail(KCFX_ERR_IO, "suffix file shorter than total_kmers * record_size: " + path);
+    }
+    char marker[4];
+    if (pread(fd, marker, 4, 0) != 4 || memcmp(marker, "KMCS", 4) != 0) {
+        close(fd);
+        return fail(KCFX_ERR_FORMAT, "missing KMCS marker in " + path);
+    }
+    const int64_t CH = 16ll << 20;   // records per chunk
+    const int64_t chunk_bytes = CH * h.record_size;
+    uint8_t* h_buf[2] = {nullptr, nullptr};
+    uint8_t* d_rec = nullptr;
+    uint64_t* d_lut = nullptr;
+    uint64_t* d_keys = nullptr;
+    uint32_t* d_counts = nullptr;
+    hipEvent_t done[2] = {nullptr, nullptr};
+    int32_t rc = KCFX_OK;
+    auto cleanup = [&]() {
+        for (int i = 0; i < 2; ++i) {
+            if (h_buf[i]) (void)hipHostFree(h_buf[i]);
+            if (done[i]) (void)hipEventDestroy(done[i]);
+        }
+        if (d_rec) (void)hipFree(d_rec);
+        if (d_lut) (void)hipFree(d_lut);
+        if (d_keys) (void)hipFree(d_keys);
+        if (d_counts) (void)hipFree(d_counts);
+        close(fd);
+    };
+#define LOAD_HIP(call)                                  \
+    do {                                                \
+        hipError_t e__ = (call);                        \
+        if (e__ != hipSuccess) {                        \
+            rc = hip_fail(e__, #call);                  \
+            cleanup();                                  \
+            return rc;                                  \
+        }                                               \
+    } while (0)
+    const int64_t n_chunk_max = std::min<int64_t>(CH, std::max<int64_t>(h.total, 1));
+    for (int i = 0; i < 2; ++i) {
+        LOAD_HIP(hipHostMalloc(&h_buf[i], (size_t)std::min(chunk_bytes, std::max<int64_t>(h.total * h.record_size, 16)), hipHostMallocDefault));
+        LOAD_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+    }
+    LOAD_HIP(hipMalloc(&d_rec, (size_t)n_chunk_max * h.record_size + 16));
+    LOAD_HIP(hipMalloc(&d_lut, std::max<size_t>(h.lut.size(), 1) * 8));
+    LOAD_HIP(hipMalloc(&d_keys, (size_t)n_chunk_max * 8));
+    LOAD_HIP(hipMalloc(&d_counts, (size_t)n_chunk_max * 4));
+    if (!h.lut.empty()) LOAD_HIP(hipMemcpyAsync(d_lut, h.lut.data(), h.lut.size() * 8, hipMemcpyHostToDevice, db->stream));
+    int64_t first = 0;
+    int turn = 0;
+    bool used[2] = {false, false};
+    while (first < h.total) {
+        const int64_t n = std::min(CH, h.total - first);
+        const int64_t bytes = n * h.record_size;
+        if (used[turn]) LOAD_HIP(hipEventSynchronize(done[turn]));
+        int64_t got = 0;
+        while (got < bytes) {
+            const ssize_t r = pread(fd, h_buf[turn] + got, (size_t)(bytes - got), 4 + first * h.record_size + got);
+            if (r <= 0) {
+                cleanup();
+                return fail(KCFX_ERR_IO, "short read on " + path);
+            }
+            got += r;
+        }
+        // d_rec is reused by every chunk: stream order (copy -> decode -> insert -> next copy) keeps it safe
+        LOAD_HIP(hipMemcpyAsync(d_rec, h_buf[turn], (size_t)bytes, hipMemcpyHostToDevice, db->stream));
+        LOAD_HIP(hipEventRecord(done[turn], db->stream));
+        used[turn] = true;
+        LOAD_HIP(launch_decode_records(d_rec, first, n, h.record_size, h.suffix_bytes, h.counter_size, h.p, d_lut,
+                                       (int64_t)h.lut.size(), d_keys, d_counts, db->stream));
+        LOAD_HIP(launch_table_insert(db->d_lines, db->n_lines, db->wide, d_keys, d_counts, n, db->stream));
+        first += n;
+        turn ^= 1;
+    }
+    LOAD_HIP(hipStreamSynchronize(db->stream));
+#undef LOAD_HIP
+    cleanup();
+    return KCFX_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* kcfx_last_error(void) { return g_error.c_str(); }
+const char* kcfx_version(void) { return "kcfx 0.1.0 (gfx950)"; }
+
+int32_t kcfx_device_count(int32_t* n) {
+    if (!n) return fail(KCFX_ERR_ARG, "null argument");
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) {
+        (void)hipGetLastError();
+        c = 0;
+    }
+    *n = c;
+    return KCFX_OK;
+}
+
+int32_t kcfx_db_open(const char* kmc_prefix, int32_t device, kcfx_db** out) {
+    if (!kmc_prefix || !out) return fail(KCFX_ERR_ARG, "null argument");
+    *out = nullptr;
+    const double t0 = now_s();
+    KmcHeader h;
+    if (int32_t rc = parse_prefix_file(std::string(kmc_prefix) + ".kmc_pre", h)) return rc;
+    if (int32_t rc = check_device(device)) return rc;
+    DeviceGuard g(device);
+    if (!g.ok) return fail(KCFX_ERR_DEVICE, "hipSetDevice failed");
+    kcfx_db* db = new kcfx_db();
+    db->device = device;
+    db->info.kmer_length = h.k;
+    db->info.mode = h.mode;
+    db->info.counter_size = h.counter_size;
+    db->info.lut_prefix_length = h.p;
+    db->info.signature_length = h.sig_len;
+    db->info.min_count = h.min_count;
+    db->info.max_count = h.max_count;
+    db->info.both_strands = h.both;
+    db->info.version = h.version;
+    db->info.n_bins = h.n_bins;
+    db->info.total_kmers = h.total;
+    db->info.device = device;
+    hipError_t e = hipStreamCreateWithFlags(&db->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { db_free(db); return hip_fail(e, "hipStreamCreate"); }
+    int32_t rc = table_alloc(db, h.total, h.counter_size);
+    if (!rc) rc = load_suffix_file(db, std::string(kmc_prefix) + ".kmc_suf", h);
+    if (!rc) {
+        e = launch_table_finalize(db->d_lines, db->n_lines, db->wide, db->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(db->stream);
+        if (e != hipSuccess) rc = hip_fail(e, "table_finalize");
+    }
+    if (rc) { db_free(db); return rc; }
+    db->info.load_seconds = now_s() - t0;
+    *out = db;
+    return KCFX_OK;
+}
+
+int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, int32_t kmer_length,
+                      int32_t counter_size, int32_t both_strands, int32_t device, kcfx_db** out) {
+    if (!out || n < 0 || (n > 0 && (!kmers || !counts))) return fail(KCFX_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (kmer_length < 1 || kmer_length > 32) return fail(KCFX_ERR_FORMAT, "unsupported k-mer length (1..32)");
+    if (counter_size < 0 || counter_size > 4) return fail(KCFX_ERR_FORMAT, "unsupported counter size");
+    const double t0 = now_s();
+    if (int32_t rc = check_device(device)) return rc;
+    DeviceGuard g(device);
+    if (!g.ok) return fail(KCFX_ERR_DEVICE, "hipSetDevice failed");
+    kcfx_db* db = new kcfx_db();
+    db->device = device;
+    db->info.kmer_length = kmer_length;
+    db->info.counter_size = counter_size;
+    db->info.both_strands = both_strands ? 1 : 0;
+    db->info.version = 0x200;
+    db->info.total_kmers = n;
+    db->info.device = device;
+    uint64_t* d_keys = nullptr;
+    uint32_t* d_counts = nullptr;
+    int32_t rc = KCFX_OK;
+    hipError_t e = hipStreamCreateWithFlags(&db->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) rc = hip_fail(e, "hipStreamCreate");
+    if (!rc) rc = table_alloc(db, n, counter_size);
+    if (!rc && n > 0) {
+        // the stored counter is counter_size bytes wide (KMC.java:395-401)
+        std::vector<uint32_t> masked;
+        const uint32_t* src = counts;
+        if (counter_size < 4) {
+            const uint32_t mask = counter_size ? ((1u << (8 * counter_size)) - 1u) : 0u;
+            masked.resize((size_t)n);
+            for (int64_t i = 0; i < n; ++i) masked[(size_t)i] = counts[i] & mask;
+            src = masked.data();
+        }
+        if ((e = hipMalloc(&d_keys, (size_t)n * 8)) != hipSuccess || (e = hipMalloc(&d_counts, (size_t)n * 4)) != hipSuccess ||
+            (e = hipMemcpyAsync(d_keys, kmers, (size_t)n * 8, hipMemcpyHostToDevice, db->stream)) != hipSuccess ||
+            (e = hipMemcpyAsync(d_counts, src, (size_t)n * 4, hipMemcpyHostToDevice, db->stream)) != hipSuccess ||
+            (e = launch_table_insert(db->d_lines, db->n_lines, db->wide, d_keys, d_counts, n, db->stream)) != hipSuccess ||
+            (e = hipStreamSynchronize(db->stream)) != hipSuccess)
+            rc = hip_fail(e, "kcfx_db_build upload/insert");
+    }
+    if (!rc) {
+        e = launch_table_finalize(db->d_lines, db->n_lines, db->wide, db->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(db->stream);
+        if (e != hipSuccess) rc = hip_fail(e, "table_finalize");
+    }
+    if (d_keys) (void)hipFree(d_keys);
+    if (d_counts) (void)hipFree(d_counts);
+    if (rc) { db_free(db); return rc; }
+    db->info.load_seconds = now_s() - t0;
+    *out = db;
+    return KCFX_OK;
+}
+
+int32_t kcfx_db_info(const kcfx_db* db, kcfx_db_info_t* info) {
+    if (!db || !info) return fail(KCFX_ERR_ARG, "null argument");
+    *info = db->info;
+    return KCFX_OK;
+}
+
+int32_t kcfx_db_lookup(kcfx_db* db, const uint64_t* kmers, int64_t n, int32_t* counts_out) {
+    if (!db || n < 0 || (n > 0 && (!kmers || !counts_out))) return fail(KCFX_ERR_ARG, "null argument");
+    if (n == 0) return KCFX_OK;
+    DeviceGuard g(db->device);
+    uint64_t* d_k = nullptr;
+    int32_t* d_c = nullptr;
+    hipError_t e;
+    int32_t rc = KCFX_OK;
+    if ((e = hipMalloc(&d_k, (size_t)n * 8)) != hipSuccess || (e = hipMalloc(&d_c, (size_t)n * 4)) != hipSuccess ||
+        (e = hipMemcpyAsync(d_k, kmers, (size_t)n * 8, hipMemcpyHostToDevice, db->stream)) != hipSuccess ||
+        (e = launch_lookup(db->view(), d_k, n, d_c, db->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(counts_out, d_c, (size_t)n * 4, hipMemcpyDeviceToHost, db->stream)) != hipSuccess ||
+        (e = hipStreamSynchronize(db->stream)) != hipSuccess)
+        rc = hip_fail(e, "kcfx_db_lookup");
+    if (d_k) (void)hipFree(d_k);
+    if (d_c) (void)hipFree(d_c);
+    return rc;
+}
+
+void kcfx_db_close(kcfx_db* db) { db_free(db); }
+
+int32_t kcfx_ref_create(int32_t device, int32_t kmer_length, const uint8_t* text, int64_t text_len,
+                        const int64_t* win_begin, const int32_t* win_len, int32_t n_windows, kcfx_ref** out) {
+    if (!out || text_len < 0 || n_windows < 0 || (text_len > 0 && !text) || (n_windows > 0 && (!win_begin || !win_len)))
+        return fail(KCFX_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (kmer_length < 1 || kmer_length > 32) return fail(KCFX_ERR_FORMAT, "unsupported k-mer length (1..32)");
+    const int32_t k = kmer_length;
+    // tile plan: every window is cut into near-equal tiles of <= TILE_K k-mer start positions (multiples of 64)
+    std::vector<TileDesc> tiles;
+    std::vector<int32_t> win_tile0((size_t)n_windows + 1, 0);
+    int64_t n_slots = 0;
+    for (int32_t w = 0; w < n_windows; ++w) {
+        if (win_begin[w] < 0 || win_len[w] < 0 || win_begin[w] + (int64_t)win_len[w] > text_len)
+            return fail(KCFX_ERR_ARG, "window " + std::to_string(w) + " lies outside the text");   // FastaIndex.java:131-134
+        win_tile0[(size_t)w] = (int32_t)tiles.size();
+        const int64_t nk = (int64_t)win_len[w] - k + 1;
+        if (nk <= 0) continue;
+        n_slots += nk;
+        const int64_t nt = (nk + TILE_K - 1) / TILE_K;
+        int64_t per = (nk + nt - 1) / nt;
+        per = std::min<int64_t>(TILE_K, (per + 63) / 64 * 64);
+        for (int64_t s = 0; s < nk; s += per) {
+            TileDesc t;
+            t.text_off = win_begin[w] + s;
+            t.n_kmers = (int32_t)std::min<int64_t>(per, nk - s);
+            t.window = w;
+            tiles.push_back(t);
+        }
+        if (tiles.size() > 0x7FFFFFF0u) return fail(KCFX_ERR_ARG, "too many tiles");
+    }
+    win_tile0[(size_t)n_windows] = (int32_t)tiles.size();
+
+    if (int32_t rc = check_device(device)) return rc;
+    DeviceGuard g(device);
+    if (!g.ok) return fail(KCFX_ERR_DEVICE, "hipSetDevice failed");
+    kcfx_ref* r = new kcfx_ref();
+    r->device = device;
+    r->k = k;
+    r->n_windows = n_windows;
+    r->n_tiles = (int32_t)tiles.size();
+    r->n_slots = n_slots;
+    const size_t text_alloc = (size_t)text_len + 128;   // the pack phase reads whole 32-byte chunks
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipMalloc(&r->d_text, text_alloc)) != hipSuccess ||
+        (e = hipMemsetAsync(r->d_text + text_len, 0, 128, r->stream)) != hipSuccess ||
+        (text_len > 0 && (e = hipMemcpyAsync(r->d_text, text, (size_t)text_len, hipMemcpyHostToDevice, r->stream)) != hipSuccess) ||
+        (e = hipMalloc(&r->d_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(TileDesc))) != hipSuccess ||
+        (e = hipMalloc(&r->d_win_tile0, win_tile0.size() * 4)) != hipSuccess ||
+        (e = hipMalloc(&r->d_summ, std::max<size_t>(tiles.size(), 1) * sizeof(TileSummary))) != hipSuccess ||
+        (e = hipMalloc(&r->d_res, std::max<size_t>((size_t)n_windows, 1) * sizeof(kcfx_result))) != hipSuccess ||
+        (!tiles.empty() && (e = hipMemcpyAsync(r->d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, r->stream)) != hipSuccess) ||
+        (e = hipMemcpyAsync(r->d_win_tile0, win_tile0.data(), win_tile0.size() * 4, hipMemcpyHostToDevice, r->stream)) != hipSuccess ||
+        (e = hipStreamSynchronize(r->stream)) != hipSuccess) {
+        ref_free(r);
+        return hip_fail(e, "kcfx_ref_create");
+    }
+    *out = r;
+    return KCFX_OK;
+}
+
+int32_t kcfx_ref_n_windows(const kcfx_ref* ref) { return ref ? ref->n_windows : 0; }
+int64_t kcfx_ref_n_kmer_slots(const kcfx_ref* ref) { return ref ? ref->n_slots : 0; }
+void kcfx_ref_destroy(kcfx_ref* ref) { ref_free(ref); }
+
+int32_t kcfx_screen_ref_async(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count, void* out_device, void* hip_stream) {
+    if (!db || !ref || !out_device) return fail(KCFX_ERR_ARG, "null argument");
+    if (db->device != ref->device) return fail(KCFX_ERR_ARG, "database and reference live on different devices");
+    if (db->info.kmer_length != ref->k) return fail(KCFX_ERR_ARG, "reference was planned for a different k-mer length");
+    if (min_kmer_count < 1) return fail(KCFX_ERR_ARG, "Minimum kmer count should be at least 1");   // GetVariants.java:383-385
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    DeviceGuard g(db->device);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (ref->prof) {
+        if (ref->events_used == ref->events.size()) {
+            hipEvent_t a, b;
+            KCFX_HIP(hipEventCreate(&a));
+            KCFX_HIP(hipEventCreate(&b));
+            ref->events.emplace_back(a, b);
+        }
+        ev0 = ref->events[ref->events_used].first;
+        ev1 = ref->events[ref->events_used].second;
+        ref->events_used++;
+        KCFX_HIP(hipEventRecord(ev0, st));
+    }
+    KCFX_HIP(launch_screen_tiles(ref->d_text, ref->d_tiles, ref->n_tiles, db->view(), ref->k, db->info.both_strands,
+                                 min_kmer_count, ref->d_summ, st));
+    if (ev1) KCFX_HIP(hipEventRecord(ev1, st));
+    KCFX_HIP(launch_finalize_windows(ref->d_summ, ref->d_win_tile0, ref->n_windows, ref->k,
+                                     reinterpret_cast<kcfx_result*>(out_device), st));
+    return KCFX_OK;
+}
+
+int32_t kcfx_screen_ref(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count, kcfx_result* out) {
+    if (!db || !ref || (!out && ref->n_windows > 0)) return fail(KCFX_ERR_ARG, "null argument");
+    if (ref->n_windows == 0) return KCFX_OK;
+    if (int32_t rc = kcfx_screen_ref_async(db, ref, min_kmer_count, ref->d_res, ref->stream)) return rc;
+    DeviceGuard g(db->device);
+    KCFX_HIP(hipMemcpyAsync(out, ref->d_res, (size_t)ref->n_windows * sizeof(kcfx_result), hipMemcpyDeviceToHost, ref->stream));
+    KCFX_HIP(hipStreamSynchronize(ref->stream));
+    return KCFX_OK;
+}
+
+int32_t kcfx_screen(kcfx_db* db, const uint8_t* text, int64_t text_len, const int64_t* win_begin,
+                    const int32_t* win_len, int32_t n_windows, int32_t min_kmer_count, kcfx_result* out) {
+    if (!db) return fail(KCFX_ERR_ARG, "null argument");
+    kcfx_ref* ref = nullptr;
+    if (int32_t rc = kcfx_ref_create(db->device, db->info.kmer_length, text, text_len, win_begin, win_len, n_windows, &ref))
+        return rc;
+    const int32_t rc = kcfx_screen_ref(db, ref, min_kmer_count, out);
+    kcfx_ref_destroy(ref);
+    return rc;
+}
+
+// Data.java:87 and :95-107. Separate statements + -ffp-contract=off: strict left-to-right IEEE double, no FMA.
+int32_t kcfx_score(const kcfx_result* res, int64_t n, double wi, double wt, double wr, double* score, double* mean_count) {
+    if (n < 0 || (n > 0 && !res)) return fail(KCFX_ERR_ARG, "null argument");
+    const double weights[3] = {wi, wt, wr};                                 // GetVariants.java:388-390
+    const bool bad = (weights[0] + weights[1] + weights[2] != 1.0);         // Data.java:101
+    for (int64_t i = 0; i < n; ++i) {
+        const kcfx_result& r = res[i];
+        if (mean_count) mean_count[i] = (r.obs > 0) ? (double)r.kmer_count_sum / r.obs : 0.00;   // :87
+        if (!score) continue;
+        if (r.obs == 0 || r.total_kmers == 0 || r.eff_length == 0) {      // :96-98
+            score[i] = 0;
+            continue;
+        }
+        const int32_t tail = r.left + r.right;                              // :170-172
+        const double a = weights[2] * ((double)r.obs / r.total_kmers);
+        const double b = weights[0] * (1.0f - ((double)r.inner / r.eff_length));
+        const double c = weights[1] * (1.0f - ((double)tail / r.eff_length));
+        double s = a + b;
+        s = s + c;
+        s = s * 100.0f;
+        score[i] = s;
+    }
+    if (bad) return fail(KCFX_ERR_WEIGHTS, "Weights should sum to 1.0");
+    return KCFX_OK;
+}
+
+// GetVariants.java:293-320
+int32_t kcfx_windows(int32_t seq_len, int32_t window, int32_t step, int32_t kmer_length, int32_t* starts, int32_t* ends,
+                     int64_t cap, int64_t* n_out) {
+    if (!n_out || kmer_length < 1) return fail(KCFX_ERR_ARG, "null argument");
+    if (window <= 0) return fail(KCFX_ERR_ARG, "Window size is required for window model");   // GetVariants.java:360-362
+    const int32_t k = kmer_length;
+    int64_t n = 0;
+    auto emit = [&](int64_t s, int64_t e) {
+        if (n < cap) {
+            if (starts) starts[n] = (int32_t)s;
+            if (ends) ends[n] = (int32_t)e;
+        }
+        ++n;
+    };
+    if (step > 0) {
+        for (int64_t pos = 0; pos < seq_len; pos += step) {
+            const int64_t e = std::min<int64_t>(pos + window, seq_len);
+            if (e - pos >= k) emit(pos, e);
+        }
+    } else {
+        if (window <= k - 1) return fail(KCFX_ERR_ARG, "window size must exceed k-1 in tiling mode (the reference never terminates)");
+        int64_t last_end = 0;
+        while (last_end < seq_len) {
+            const int64_t s = std::max<int64_t>(0, last_end - k + 1);
+            const int64_t e = std::min<int64_t>(s + window, seq_len);
+            if (e - s >= k) emit(s, e);
+            last_end = e;
+        }
+    }
+    *n_out = n;
+    return KCFX_OK;
+}
+
+int32_t kcfx_prof_enable(kcfx_ref* ref, int32_t enable) {
+    if (!ref) return fail(KCFX_ERR_ARG, "null argument");
+    ref->prof = enable != 0;
+    return KCFX_OK;
+}
+
+int32_t kcfx_prof_read(kcfx_ref* ref, double* kernel_ms_sum, int64_t* launches, int32_t reset) {
+    if (!ref) return fail(KCFX_ERR_ARG, "null argument");
+    DeviceGuard g(ref->device);
+    double sum = 0;
+    for (size_t i = 0; i < ref->events_used; ++i) {
+        KCFX_HIP(hipEventSynchronize(ref->events[i].second));
+        float ms = 0;
+        KCFX_HIP(hipEventElapsedTime(&ms, ref->events[i].first, ref->events[i].second));
+        sum += ms;
+    }
+    if (kernel_ms_sum) *kernel_ms_sum = sum;
+    if (launches) *launches = (int64_t)ref->events_used;
+    if (reset) ref->events_used = 0;
+    return KCFX_OK;
+}
+
+}  // extern "C"

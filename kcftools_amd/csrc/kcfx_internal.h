@@ -1,0 +1,158 @@
+// kcfx_internal.h -- structures shared by the host side and the HIP kernels of libkcfx.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/kcfx.h"
+
+namespace kcfx {
+
+// ----------------------------------------------------------------------------------------------------
+// HBM table: open addressing at 64-byte line granularity (one line = one memory transaction per probe).
+//
+//   LAYOUT_U16 (counter_size <= 2): 6 x u64 key | 6 x u16 count | u32 meta      = 48 + 12 + 4
+//   LAYOUT_U32 (counter_size 3, 4): 5 x u64 key | 5 x u32 count | u32 meta      = 40 + 20 + 4
+//   meta: bits 0..7 = occupied slots, bit 8 = overflow (some key whose home is this line or earlier was
+//   pushed to the next line) => a probe that does not find its key continues with the next line iff bit 8.
+//
+// A key's home line is umulhi(hash32(key), n_lines).  Keys are the reference's left-aligned k-mer words.
+// ----------------------------------------------------------------------------------------------------
+constexpr int LINE_BYTES = 64;
+constexpr int SLOTS_U16 = 6;
+constexpr int SLOTS_U32 = 5;
+constexpr uint32_t META_OVERFLOW = 0x100u;
+
+struct TableView {
+    const uint8_t* lines;
+    uint32_t n_lines;
+    int32_t wide;        // 0: LAYOUT_U16, 1: LAYOUT_U32
+};
+
+// ----------------------------------------------------------------------------------------------------
+// Tile plan: every window is cut into tiles of at most TILE_K consecutive k-mer start positions; one
+// workgroup screens one tile and emits one TileSummary; finalize_windows folds a window's tiles in order.
+// ----------------------------------------------------------------------------------------------------
+constexpr int BLOCK = 256;            // 4 wavefronts
+constexpr int TILE_K = 4096;          // k-mer start positions per tile (multiple of 64)
+constexpr int TILE_MAX_BASES = TILE_K + 32 + 32;  // + (k-1) + alignment slack
+
+struct TileDesc {
+    int64_t text_off;    // offset of the tile's first base in the padded device text
+    int32_t n_kmers;     // k-mer start positions in this tile (1..TILE_K)
+    int32_t window;
+};
+
+// The gap monoid of SURVEY.md section 8 a-7 plus what EFFLEN needs (a-8): summarises a contiguous range of
+// k-mer start positions of one window.
+struct TileSummary {
+    int32_t n;           // valid k-mers
+    int32_t obs;         // hits
+    int32_t lead;        // misses before the first hit (== n when there is no hit)
+    int32_t trail;       // misses after the last hit  (== n when there is no hit)
+    int32_t var_in;      // interior miss-runs (between two hits of this range)
+    int32_t inner_in;    // sum of getDistance over them
+    int32_t runs;        // maximal runs of valid k-mer start positions
+    uint32_t flags;      // bit0 any hit, bit1 first position valid, bit2 last position valid, bit3 empty range
+    int64_t count_sum;   // sum of counts over hits
+};
+constexpr uint32_t F_ANY = 1u, F_FIRST = 2u, F_LAST = 4u, F_EMPTY = 8u;
+
+// GetVariants.java:267-273
+__host__ __device__ inline int32_t gap_distance(int32_t k, int32_t gap) {
+    int32_t d = gap - (k - 1);
+    if (d <= 0) {
+        d = d + 1;
+        d = d < 0 ? -d : d;
+    }
+    return d;
+}
+
+__host__ __device__ inline TileSummary summary_identity() {
+    TileSummary s;
+    s.n = s.obs = s.lead = s.trail = s.var_in = s.inner_in = s.runs = 0;
+    s.flags = F_EMPTY;
+    s.count_sum = 0;
+    return s;
+}
+
+// A followed by B (adjacent position ranges of the same window).
+__host__ __device__ inline TileSummary summary_combine(const TileSummary& a, const TileSummary& b, int32_t k) {
+    if (a.flags & F_EMPTY) return b;
+    if (b.flags & F_EMPTY) return a;
+    TileSummary c;
+    c.n = a.n + b.n;
+    c.obs = a.obs + b.obs;
+    c.count_sum = a.count_sum + b.count_sum;
+    c.runs = a.runs + b.runs - (((a.flags & F_LAST) && (b.flags & F_FIRST)) ? 1 : 0);
+    c.flags = (a.flags & F_FIRST) | (b.flags & F_LAST) | ((a.flags | b.flags) & F_ANY);
+    c.var_in = a.var_in + b.var_in;
+    c.inner_in = a.inner_in + b.inner_in;
+    const bool ha = a.flags & F_ANY, hb = b.flags & F_ANY;
+    if (ha && hb) {
+        int32_t g = a.trail + b.lead;
+        if (g > 0) {
+            c.var_in += 1;
+            c.inner_in += gap_distance(k, g);
+        }
+        c.lead = a.lead;
+        c.trail = b.trail;
+    } else if (ha) {
+        c.lead = a.lead;
+        c.trail = a.trail + b.n;
+    } else if (hb) {
+        c.lead = a.n + b.lead;
+        c.trail = b.trail;
+    } else {
+        c.lead = c.n;
+        c.trail = c.n;
+    }
+    return c;
+}
+
+__host__ __device__ inline kcfx_result summary_finalize(const TileSummary& s, int32_t k) {
+    kcfx_result r;
+    const bool any = s.flags & F_ANY;
+    r.total_kmers = s.n;
+    r.eff_length = s.n + (k - 1) * s.runs;       // sum over ACGT runs >= k of their length (Fasta.java:140-167)
+    r.obs = s.obs;
+    r.left = any ? s.lead : 0;
+    r.right = any ? s.trail : s.n;
+    r.var = s.var_in + ((any && s.lead > 0) ? 1 : 0) + (r.right > 0 ? 1 : 0);
+    r.inner = s.inner_in;
+    r._pad = 0;
+    r.kmer_count_sum = s.count_sum;
+    return r;
+}
+
+// ---- error plumbing ---------------------------------------------------------------------------------
+void set_error(const std::string& msg);
+int32_t hip_fail(hipError_t e, const char* what);
+
+#define KCFX_HIP(call)                                         \
+    do {                                                       \
+        hipError_t e__ = (call);                               \
+        if (e__ != hipSuccess) return kcfx::hip_fail(e__, #call); \
+    } while (0)
+
+// ---- kernel launchers (kcfx_kernels.hip) ------------------------------------------------------------
+// table build
+hipError_t launch_table_clear(uint8_t* lines, uint32_t n_lines, hipStream_t st);
+hipError_t launch_decode_records(const uint8_t* records, int64_t first_record, int64_t n, int32_t record_size,
+                                 int32_t suffix_bytes, int32_t counter_size, int32_t lut_prefix_length,
+                                 const uint64_t* lut, int64_t lut_entries, uint64_t* keys_out, uint32_t* counts_out,
+                                 hipStream_t st);
+hipError_t launch_table_insert(uint8_t* lines, uint32_t n_lines, int32_t wide, const uint64_t* keys,
+                               const uint32_t* counts, int64_t n, hipStream_t st);
+hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide, hipStream_t st);
+// lookup
+hipError_t launch_lookup(TableView tv, const uint64_t* keys, int64_t n, int32_t* counts_out, hipStream_t st);
+// screen
+hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32_t n_tiles, TableView tv, int32_t k,
+                               int32_t both_strands, int32_t min_count, TileSummary* out, hipStream_t st);
+hipError_t launch_finalize_windows(const TileSummary* tiles, const int32_t* win_tile0, int32_t n_windows, int32_t k,
+                                   kcfx_result* out, hipStream_t st);
+
+}  // namespace kcfx

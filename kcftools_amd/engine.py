@@ -1,0 +1,213 @@
+"""ctypes binding of libkcfx.so (include/kcfx.h) -- the only way Python reaches the engine.
+
+There is no Python or CPU implementation of the hot path here: if the HIP library is missing or no
+GPU is usable, construction of `KmcDb` / `Reference` raises.  The class / method names follow the
+reference's objects for this path: `KmcDb` <-> Data/KMC.java, `Reference` <-> the window list +
+FastaIndex-backed text of Plugins/GetVariants.java, `screen` <-> the processWindow fan-out.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkcfx.so")
+
+RESULT_DTYPE = np.dtype([("total_kmers", "<i4"), ("eff_length", "<i4"), ("obs", "<i4"), ("var", "<i4"),
+                         ("inner", "<i4"), ("left", "<i4"), ("right", "<i4"), ("_pad", "<i4"),
+                         ("kmer_count_sum", "<i8")])
+INT_FIELDS = ("total_kmers", "eff_length", "obs", "var", "inner", "left", "right", "kmer_count_sum")
+assert RESULT_DTYPE.itemsize == 40
+
+# every symbol include/kcfx.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = (
+    "kcfx_db_open", "kcfx_db_build", "kcfx_db_info", "kcfx_db_lookup", "kcfx_db_close",
+    "kcfx_ref_create", "kcfx_ref_n_windows", "kcfx_ref_n_kmer_slots", "kcfx_ref_destroy",
+    "kcfx_screen_ref", "kcfx_screen_ref_async", "kcfx_screen", "kcfx_score", "kcfx_windows",
+    "kcfx_prof_enable", "kcfx_prof_read", "kcfx_last_error", "kcfx_device_count", "kcfx_version",
+)
+
+
+class DbInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("kmer_length", "mode", "counter_size", "lut_prefix_length",
+                                          "signature_length", "min_count", "max_count", "both_strands",
+                                          "version", "n_bins")] + \
+               [("total_kmers", C.c_int64), ("table_bytes", C.c_int64), ("table_lines", C.c_int64),
+                ("slots_per_line", C.c_int32), ("device", C.c_int32), ("load_seconds", C.c_double)]
+
+
+class KcfxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"kcfx error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libkcfx.so; fail loudly if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: the HIP extension is not built "
+                              f"(run `python -c 'import __graft_entry__ as g; g.build()'`); there is no fallback")
+        L = C.CDLL(LIB_PATH)
+        vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+        L.kcfx_last_error.restype = C.c_char_p
+        L.kcfx_version.restype = C.c_char_p
+        L.kcfx_device_count.argtypes = [C.POINTER(i32)]
+        L.kcfx_db_open.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
+        L.kcfx_db_build.argtypes = [vp, vp, i64, i32, i32, i32, i32, C.POINTER(vp)]
+        L.kcfx_db_info.argtypes = [vp, C.POINTER(DbInfo)]
+        L.kcfx_db_lookup.argtypes = [vp, vp, i64, vp]
+        L.kcfx_db_close.argtypes = [vp]
+        L.kcfx_db_close.restype = None
+        L.kcfx_ref_create.argtypes = [i32, i32, vp, i64, vp, vp, i32, C.POINTER(vp)]
+        L.kcfx_ref_n_windows.argtypes = [vp]
+        L.kcfx_ref_n_kmer_slots.argtypes = [vp]
+        L.kcfx_ref_n_kmer_slots.restype = i64
+        L.kcfx_ref_destroy.argtypes = [vp]
+        L.kcfx_ref_destroy.restype = None
+        L.kcfx_screen_ref.argtypes = [vp, vp, i32, vp]
+        L.kcfx_screen_ref_async.argtypes = [vp, vp, i32, vp, vp]
+        L.kcfx_screen.argtypes = [vp, vp, i64, vp, vp, i32, i32, vp]
+        L.kcfx_score.argtypes = [vp, i64, dbl, dbl, dbl, vp, vp]
+        L.kcfx_windows.argtypes = [i32, i32, i32, i32, vp, vp, i64, C.POINTER(i64)]
+        L.kcfx_prof_enable.argtypes = [vp, i32]
+        L.kcfx_prof_read.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), i32]
+        _lib = L
+    return _lib
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise KcfxError(rc, lib().kcfx_last_error().decode(errors="replace"))
+
+
+def device_count() -> int:
+    n = C.c_int32(0)
+    _check(lib().kcfx_device_count(C.byref(n)))
+    return n.value
+
+
+class KmcDb:
+    """A KMC database re-indexed into an HBM-resident table (replaces `new KMC(prefix, inMemory)`, KMC.java:56)."""
+
+    def __init__(self, handle: C.c_void_p):
+        self._h = handle
+        self.info = DbInfo()
+        _check(lib().kcfx_db_info(self._h, C.byref(self.info)))
+
+    @classmethod
+    def open(cls, kmc_prefix: str, device: int = 0) -> "KmcDb":
+        h = C.c_void_p()
+        _check(lib().kcfx_db_open(os.fsencode(kmc_prefix), device, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def build(cls, kmers: np.ndarray, counts: np.ndarray, k: int, counter_size: int = 2,
+              both_strands: bool = True, device: int = 0) -> "KmcDb":
+        km = np.ascontiguousarray(kmers, dtype=np.uint64)
+        ct = np.ascontiguousarray(counts, dtype=np.uint32)
+        assert len(km) == len(ct)
+        h = C.c_void_p()
+        _check(lib().kcfx_db_build(km.ctypes.data, ct.ctypes.data, len(km), k, counter_size, int(both_strands), device, C.byref(h)))
+        return cls(h)
+
+    @property
+    def k(self) -> int:
+        return self.info.kmer_length
+
+    def lookup(self, kmers: np.ndarray) -> np.ndarray:
+        """Batched KMC.getCount (KMC.java:292-326)."""
+        km = np.ascontiguousarray(kmers, dtype=np.uint64)
+        out = np.zeros(len(km), dtype=np.int32)
+        _check(lib().kcfx_db_lookup(self._h, km.ctypes.data, len(km), out.ctypes.data))
+        return out
+
+    def screen(self, text: bytes, win_begin, win_len, min_count: int = 1) -> np.ndarray:
+        """One-shot kcfx_screen on host buffers."""
+        wb = np.ascontiguousarray(win_begin, dtype=np.int64)
+        wl = np.ascontiguousarray(win_len, dtype=np.int32)
+        buf = np.frombuffer(text, dtype=np.uint8)
+        out = np.zeros(len(wb), dtype=RESULT_DTYPE)
+        _check(lib().kcfx_screen(self._h, buf.ctypes.data if len(buf) else None, len(buf), wb.ctypes.data, wl.ctypes.data,
+                                 len(wb), min_count, out.ctypes.data))
+        return out
+
+    def close(self) -> None:
+        if self._h:
+            lib().kcfx_db_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Reference:
+    """Reference text + window list resident in HBM (GetVariants.java:117-121 windows, :188-197 window text)."""
+
+    def __init__(self, text: bytes, win_begin, win_len, k: int, device: int = 0):
+        wb = np.ascontiguousarray(win_begin, dtype=np.int64)
+        wl = np.ascontiguousarray(win_len, dtype=np.int32)
+        assert len(wb) == len(wl)
+        buf = np.frombuffer(text, dtype=np.uint8)
+        self._h = C.c_void_p()
+        _check(lib().kcfx_ref_create(device, k, buf.ctypes.data if len(buf) else None, len(buf), wb.ctypes.data,
+                                     wl.ctypes.data, len(wb), C.byref(self._h)))
+        self.n_windows = len(wb)
+        self.n_kmer_slots = lib().kcfx_ref_n_kmer_slots(self._h)
+        self.device = device
+
+    def screen(self, db: KmcDb, min_count: int = 1) -> np.ndarray:
+        out = np.zeros(self.n_windows, dtype=RESULT_DTYPE)
+        _check(lib().kcfx_screen_ref(db._h, self._h, min_count, out.ctypes.data))
+        return out
+
+    def screen_async(self, db: KmcDb, out_device_ptr: int, stream: int = 0, min_count: int = 1) -> None:
+        """Asynchronous launch on `stream` (a hipStream_t as int); results stay in device memory."""
+        _check(lib().kcfx_screen_ref_async(db._h, self._h, min_count, C.c_void_p(out_device_ptr), C.c_void_p(stream)))
+
+    def prof_enable(self, on: bool = True) -> None:
+        _check(lib().kcfx_prof_enable(self._h, int(on)))
+
+    def prof_read(self, reset: bool = True) -> tuple[float, int]:
+        ms, n = C.c_double(0), C.c_int64(0)
+        _check(lib().kcfx_prof_read(self._h, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
+    def close(self) -> None:
+        if self._h:
+            lib().kcfx_ref_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def score(res: np.ndarray, wi: float = 0.3, wt: float = 0.3, wr: float = 0.4) -> tuple[np.ndarray, np.ndarray]:
+    """Data.update + Data.computeScore (Data.java:87,95-107) through the C ABI. Raises on bad weights."""
+    r = np.ascontiguousarray(res, dtype=RESULT_DTYPE)
+    sc = np.zeros(len(r), dtype=np.float64)
+    md = np.zeros(len(r), dtype=np.float64)
+    _check(lib().kcfx_score(r.ctypes.data, len(r), wi, wt, wr, sc.ctypes.data, md.ctypes.data))
+    return sc, md
+
+
+def windows(seq_len: int, window: int, step: int, k: int) -> tuple[np.ndarray, np.ndarray]:
+    """GetVariants.getWindows, "window" case (GetVariants.java:293-320)."""
+    n = C.c_int64(0)
+    _check(lib().kcfx_windows(seq_len, window, step, k, None, None, 0, C.byref(n)))
+    s = np.zeros(n.value, dtype=np.int32)
+    e = np.zeros(n.value, dtype=np.int32)
+    _check(lib().kcfx_windows(seq_len, window, step, k, s.ctypes.data, e.ctypes.data, n.value, C.byref(n)))
+    return s, e

@@ -1,0 +1,146 @@
+// Lane-by-lane CPU emulation of screen_tiles_kernel built from the SAME __host__ __device__ helpers
+// (kcfx_device.h): base packing, k-mer extraction, ballot-style gap accounting, monoid combine.
+// TEST INFRASTRUCTURE ONLY: lets the bit logic be checked against the oracle without a GPU. The table probe is
+// replaced by a caller-provided count per position (the test computes it with the oracle).
+#include <cstring>
+#include <vector>
+
+#include "../../kcftools_amd/csrc/kcfx_device.h"
+
+using namespace kcfx;
+
+namespace kcfx {
+void set_error(const std::string&) {}
+int32_t hip_fail(hipError_t, const char*) { return 4; }
+}
+
+static constexpr int MAX_CHUNKS = (31 + TILE_K + 31 + 31) / 32 + 1;
+
+struct Packed {
+    std::vector<uint32_t> fw, cw, vb;
+    int off;
+};
+
+static Packed pack_tile(const uint8_t* text, int64_t text_off, int n_kmers, int k) {
+    Packed P;
+    P.fw.assign(2 * (MAX_CHUNKS + 2), 0xDEADBEEFu);
+    P.cw.assign(2 * (MAX_CHUNKS + 2), 0xDEADBEEFu);
+    P.vb.assign(MAX_CHUNKS + 2, 0xDEADBEEFu);
+    const int64_t a0 = text_off & ~(int64_t)31;
+    P.off = (int)(text_off - a0);
+    const int nbases = P.off + n_kmers + k - 1;
+    const int nchunks = (nbases + 31) >> 5;
+    for (int c = 0; c < nchunks + 2; ++c) {
+        uint32_t f0 = 0, f1 = 0, v0 = 0, v1 = 0;
+        if (c < nchunks) {
+            uint32_t x[8];
+            memcpy(x, text + a0 + 32 * (int64_t)c, 32);
+            pack16(x[0], x[1], x[2], x[3], f0, v0);
+            pack16(x[4], x[5], x[6], x[7], f1, v1);
+        }
+        P.fw[2 * c] = f0;
+        P.fw[2 * c + 1] = f1;
+        P.cw[2 * c] = comp_swap(f0);
+        P.cw[2 * c + 1] = comp_swap(f1);
+        P.vb[c] = (v0 << 16) | v1;
+    }
+    return P;
+}
+
+extern "C" {
+
+// per position of the tile: forward word, reverse-complement word, validity
+int harness_extract(const uint8_t* text, int64_t text_off, int n_kmers, int k, uint64_t* fwd, uint64_t* rc, uint8_t* valid) {
+    Packed P = pack_tile(text, text_off, n_kmers, k);
+    for (int j = 0; j < n_kmers; ++j) {
+        uint64_t f, r;
+        valid[j] = extract_kmer(P.fw.data(), P.cw.data(), P.vb.data(), P.off + j, k, f, r) ? 1 : 0;
+        fwd[j] = f;
+        rc[j] = r;
+    }
+    return 0;
+}
+
+// the screen_tiles_kernel control flow with counts[j] standing in for the probe result
+int harness_screen_tile(const uint8_t* text, int64_t text_off, int n_kmers, int k, const int32_t* counts,
+                        int min_count, TileSummary* out) {
+    Packed P = pack_tile(text, text_off, n_kmers, k);
+    const int n_words = (n_kmers + 63) >> 6;
+    const int waves = BLOCK / 64;
+    const int wpw = (n_words + waves - 1) / waves;
+    TileSummary sums[BLOCK / 64];
+    for (int wave = 0; wave < waves; ++wave) {
+        const int w_begin = std::min(wave * wpw, n_words), w_end = std::min(w_begin + wpw, n_words);
+        GapCarry carry{0, 0, false};
+        int32_t n_valid = 0, obs = 0, runs = 0, var_in = 0, inner_in = 0;
+        uint32_t prev_valid = 0, first_valid = 0;
+        uint64_t last_V = 0;
+        int64_t sum = 0;
+        for (int w = w_begin; w < w_end; ++w) {
+            uint64_t V = 0, H = 0;
+            int32_t cnt[64];
+            for (int lane = 0; lane < 64; ++lane) {
+                const int j = w * 64 + lane;
+                uint64_t f, r;
+                const int q = P.off + std::min(j, n_kmers - 1);
+                bool valid = extract_kmer(P.fw.data(), P.cw.data(), P.vb.data(), q, k, f, r) && j < n_kmers;
+                cnt[lane] = valid ? counts[j] : 0;
+                const bool hit = valid && cnt[lane] >= min_count;
+                if (valid) V |= 1ull << lane;
+                if (hit) H |= 1ull << lane;
+            }
+            const uint64_t M = V & ~H;
+            n_valid += __builtin_popcountll(V);
+            obs += __builtin_popcountll(H);
+            runs += __builtin_popcountll(V & ~((V << 1) | (uint64_t)prev_valid));
+            if (w == w_begin) first_valid = (uint32_t)(V & 1);
+            prev_valid = (uint32_t)(V >> 63);
+            last_V = V;
+            for (int lane = 0; lane < 64; ++lane) {
+                const bool hit = (H >> lane) & 1;
+                if (hit) sum += cnt[lane];
+                if (H) {
+                    if (M) {
+                        if (hit) {
+                            const int32_t g = gap_closed_by(H, M, lane, carry);
+                            if (g > 0) { var_in += 1; inner_in += gap_distance(k, g); }
+                        }
+                    } else if (carry.cany && carry.cg > 0 && lane == 0) {
+                        var_in += 1;
+                        inner_in += gap_distance(k, carry.cg);
+                    }
+                }
+            }
+            gap_advance(H, M, carry);
+        }
+        TileSummary s;
+        if (w_begin == w_end) {
+            s = summary_identity();
+        } else {
+            const int last_pos = std::min(w_end * 64, n_kmers) - 1;
+            s.n = n_valid; s.obs = obs;
+            s.lead = carry.cany ? carry.lead : n_valid;
+            s.trail = carry.cany ? carry.cg : n_valid;
+            s.var_in = var_in; s.inner_in = inner_in; s.runs = runs;
+            s.flags = (carry.cany ? F_ANY : 0u) | (first_valid ? F_FIRST : 0u) | (((last_V >> (last_pos & 63)) & 1) ? F_LAST : 0u);
+            s.count_sum = sum;
+        }
+        sums[wave] = s;
+    }
+    TileSummary acc = sums[0];
+    for (int i = 1; i < waves; ++i) acc = summary_combine(acc, sums[i], k);
+    *out = acc;
+    return 0;
+}
+
+void harness_combine(const TileSummary* a, const TileSummary* b, int k, TileSummary* out) { *out = summary_combine(*a, *b, k); }
+void harness_identity(TileSummary* out) { *out = summary_identity(); }
+void harness_finalize(const TileSummary* s, int k, kcfx_result* out) {
+    TileSummary t = *s;
+    if (t.flags & F_EMPTY) t.flags = 0;
+    *out = summary_finalize(t, k);
+}
+uint32_t harness_hash32(uint64_t key) { return hash32(key); }
+int harness_tile_k(void) { return TILE_K; }
+
+}

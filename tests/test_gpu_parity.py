@@ -1,0 +1,239 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (include/kcfx.h), against the CPU oracle.
+
+Bar (BASELINE.json north_star): every per-window integer bit-exact; identity score within 1e-6 (it is
+computed from the integers by the same IEEE operations, so it is in fact bit-identical).
+"""
+import numpy as np
+import pytest
+
+from kcftools_amd import engine, synth
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = engine.INT_FIELDS
+SCORE_TOL = 1e-6
+
+
+def assert_same(got: np.ndarray, want: np.ndarray, ctx=""):
+    assert len(got) == len(want)
+    for f in FIELDS:
+        bad = np.nonzero(got[f] != want[f])[0]
+        assert len(bad) == 0, f"{ctx}: field {f} differs at windows {bad[:8]}: got {got[f][bad[:8]]} want {want[f][bad[:8]]}"
+
+
+def assert_scores(oracle, got: np.ndarray, want: np.ndarray):
+    gs, gm = engine.score(got)
+    ws, wm = oracle.score_array(want)
+    assert np.max(np.abs(gs - ws), initial=0.0) <= SCORE_TOL
+    assert np.max(np.abs(gm - wm), initial=0.0) <= SCORE_TOL
+
+
+def make_db(tmp_path, name, ref, seed, k=31, p=3, cs=2, m=7, bins=8, both=True, noise=2000, **mut):
+    sample = synth.mutate_sample(ref, seed, **mut)
+    prm = synth.KmcParams(k=k, p=p, counter_size=cs, sig_len=m, n_bins=bins, both_strands=both,
+                          max_count=(1 << (8 * cs)) - 1 if cs else 0)
+    kmers, counts = synth.build_sample_db(sample, prm, seed + 1, noise_kmers=noise)
+    prefix = str(tmp_path / name)
+    synth.write_kmc(prefix, kmers, counts, prm)
+    return prefix, kmers, counts, prm
+
+
+CONFIGS = [
+    # k,  p, cs, m, bins, both
+    (31, 3, 2, 9, 16, True),
+    (31, 7, 1, 9, 4, True),
+    (31, 3, 4, 7, 5, False),
+    (31, 3, 3, 7, 3, True),
+    (23, 3, 2, 5, 7, True),
+    (15, 3, 1, 5, 3, False),
+    (32, 4, 2, 7, 4, True),
+]
+
+
+@pytest.mark.parametrize("k,p,cs,m,bins,both", CONFIGS)
+def test_lookup_matches_getcount(oracle, tmp_path, k, p, cs, m, bins, both):
+    ref = synth.random_reference(30_000, 3, n_run_every=7000, max_n_run=200)
+    prefix, kmers, counts, prm = make_db(tmp_path, "db", ref, 10, k, p, cs, m, bins, both)
+    db = engine.KmcDb.open(prefix)
+    odb = oracle.OracleDb(prefix)
+    i = db.info
+    assert (i.kmer_length, i.lut_prefix_length, i.counter_size, i.signature_length, i.n_bins) == (k, p, cs, m, bins)
+    assert bool(i.both_strands) == both and i.total_kmers == len(kmers) and i.version == 0x200
+    assert i.min_count == prm.min_count and i.max_count == prm.max_count
+    got = db.lookup(kmers)
+    assert np.array_equal(got, counts.astype(np.uint32).astype(np.int32))
+    rng = np.random.default_rng(1)
+    mask = np.uint64((0xFFFFFFFFFFFFFFFF << (64 - 2 * k)) & 0xFFFFFFFFFFFFFFFF)
+    q = rng.integers(0, np.iinfo(np.uint64).max, size=4000, dtype=np.uint64, endpoint=True) & mask
+    if both:
+        q = np.minimum(q, synth.revcomp(q, k))
+    q = np.concatenate([q, kmers[::7]])
+    got = db.lookup(q)
+    want = np.array([odb.get_count(int(x)) for x in q], dtype=np.int32)
+    assert np.array_equal(got, want)
+    # the table built from arrays is the same function
+    db2 = engine.KmcDb.build(kmers, counts, k, cs, both)
+    assert np.array_equal(db2.lookup(q), want)
+
+
+@pytest.mark.parametrize("k,p,cs,m,bins,both", CONFIGS)
+def test_screen_parity_small(oracle, tmp_path, k, p, cs, m, bins, both):
+    ref = synth.random_reference(120_000, 21 + k, n_run_every=9000, max_n_run=400, lower_frac=0.15, iupac_rate=5e-4)
+    prefix, *_ = make_db(tmp_path, "db", ref, 30, k, p, cs, m, bins, both,
+                         sub_rate=1e-2, indel_rate=1e-3, big_del_per_mb=40, big_del_len=4000)
+    db = engine.KmcDb.open(prefix)
+    odb = oracle.OracleDb(prefix)
+    for window, step in ((10_000, 0), (700, 0), (5_000, 1_250), (50_000, 0)):
+        s, e = engine.windows(len(ref), window, step, k)
+        for mc in (1, 3):
+            got = db.screen(ref, s, e - s, mc)
+            want = odb.screen(ref, s, e - s, mc, threads=4)
+            assert_same(got, want, f"w={window} step={step} c={mc}")
+            assert_scores(oracle, got, want)
+    # every k-mer of the contig belongs to exactly one tiling window
+    s, e = engine.windows(len(ref), 10_000, 0, k)
+    got = db.screen(ref, s, e - s, 1)
+    whole = db.screen(ref, [0], [len(ref)], 1)
+    assert int(got["total_kmers"].sum()) == int(whole["total_kmers"][0])
+    assert int(got["obs"].sum()) == int(whole["obs"][0])
+    assert int(got["kmer_count_sum"].sum()) == int(whole["kmer_count_sum"][0])
+
+
+def test_screen_irregular_windows(oracle, tmp_path):
+    """gene-model-like windows: 31 bp .. 60 kbp, overlapping, unsorted, at every alignment"""
+    k = 31
+    ref = synth.random_reference(200_000, 5, n_run_every=15_000, max_n_run=900, lower_frac=0.3, iupac_rate=1e-3)
+    prefix, *_ = make_db(tmp_path, "db", ref, 40)
+    db = engine.KmcDb.open(prefix)
+    odb = oracle.OracleDb(prefix)
+    rng = np.random.default_rng(11)
+    lens = np.concatenate([rng.integers(1, 200, 150), rng.integers(200, 15_000, 150), rng.integers(15_000, 60_000, 12),
+                           [31, 30, 32, 0, 1, 4126, 4127, 4128, 8222, 8223]])
+    begins = np.array([rng.integers(0, len(ref) - l + 1) for l in lens])
+    order = rng.permutation(len(lens))
+    lens, begins = lens[order], begins[order]
+    got = db.screen(ref, begins, lens, 1)
+    want = odb.screen(ref, begins, lens, 1, threads=4)
+    assert_same(got, want, "irregular")
+    assert_scores(oracle, got, want)
+    short = lens < k
+    assert np.all(got["total_kmers"][short] == 0) and np.all(got["var"][short] == 0) and np.all(got["eff_length"][short] == 0)
+
+
+def test_edge_cases(oracle, tmp_path):
+    k = 31
+    ref = synth.random_reference(20_000, 9, n_run_every=0, lower_frac=0.0, iupac_rate=0.0)
+    prefix, kmers, counts, _ = make_db(tmp_path, "db", ref, 50)
+    db = engine.KmcDb.open(prefix)
+    odb = oracle.OracleDb(prefix)
+    texts = [b"N" * 5000, b"ACGT" * 10, (b"ACGTTGCA" * 4)[:31], ref[:31] + b"N" + ref[32:64], b"acgtn" * 300,
+             b"RYKMSWBDHV" * 50, ref[:4126], ref[:4127], b"\x00\xff\x80" * 40 + ref[:200], ref[100:163].lower()]
+    for t in texts:
+        got = db.screen(t, [0], [len(t)], 1)
+        want = odb.screen(t, [0], [len(t)], 1)
+        assert_same(got, want, repr(t[:20]))
+    # no windows / empty text
+    assert len(db.screen(ref, [], [], 1)) == 0
+    z = db.screen(b"", [0], [0], 1)
+    assert all(int(z[f][0]) == 0 for f in FIELDS)
+    # windows touching the end of the text, and the same window many times
+    s = np.array([len(ref) - 31, len(ref) - 5000, 0, 0, 0, len(ref) - 1, len(ref)])
+    l = np.array([31, 5000, 20_000, 20_000, 31, 1, 0])
+    assert_same(db.screen(ref, s, l, 1), odb.screen(ref, s, l, 1), "end windows")
+    # argument errors are reported, never a crash
+    with pytest.raises(engine.KcfxError):
+        db.screen(ref, [len(ref) - 10], [11], 1)
+    with pytest.raises(engine.KcfxError):
+        db.screen(ref, [-1], [40], 1)
+    with pytest.raises(engine.KcfxError):
+        db.screen(ref, [0], [100], 0)          # -c must be >= 1 (GetVariants.java:383-385)
+
+
+def test_all_hit_all_miss_and_thresholds(oracle, tmp_path):
+    k = 31
+    ref = synth.random_reference(60_000, 13, n_run_every=20_000, max_n_run=100)
+    prm = synth.KmcParams(k=k, p=3, counter_size=2, sig_len=7, n_bins=4)
+    # database = exactly the reference's own k-mers => every valid k-mer is observed
+    kmers, counts = synth.build_sample_db(ref, prm, 1)
+    db = engine.KmcDb.build(kmers, counts, k, 2, True)
+    s, e = engine.windows(len(ref), 10_000, 0, k)
+    got = db.screen(ref, s, e - s, 1)
+    assert np.array_equal(got["obs"], got["total_kmers"]) and not got["var"].any() and not got["inner"].any()
+    sc, _ = engine.score(got)
+    assert np.allclose(sc[got["total_kmers"] > 0], 100.0, atol=1e-9)
+    # empty database => nothing observed: var = 1, right = total (GetVariants.java:248-251)
+    empty = engine.KmcDb.build(np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint32), k, 2, True)
+    got0 = empty.screen(ref, s, e - s, 1)
+    assert not got0["obs"].any() and np.array_equal(got0["right"], got0["total_kmers"])
+    assert np.array_equal(got0["var"], (got0["total_kmers"] > 0).astype(np.int32))
+    assert np.array_equal(got0["total_kmers"], got["total_kmers"]) and np.array_equal(got0["eff_length"], got["eff_length"])
+    # -c thresholds are monotone and match the oracle's reduction of the same counts
+    for c in (2, 5, 50):
+        gc = db.screen(ref, s, e - s, c)
+        assert np.all(gc["obs"] <= got["obs"])
+    # idempotent
+    assert_same(db.screen(ref, s, e - s, 1), got, "rerun")
+
+
+def test_java_int_counts(oracle, tmp_path):
+    """counter_size 4 with the top bit set is a negative Java int: never >= -c (KMC.java:395-401, GetVariants.java:224)"""
+    k = 31
+    ref = synth.random_reference(8_000, 17, n_run_every=0, lower_frac=0, iupac_rate=0)
+    prm = synth.KmcParams(k=k, p=3, counter_size=4, sig_len=5, n_bins=2, max_count=0xFFFFFFFF)
+    kmers = np.unique(synth.kmers_of_text(ref, k, True))
+    counts = np.where(np.arange(len(kmers)) % 3 == 0, 0x80000005, 7).astype(np.uint64)
+    prefix = str(tmp_path / "neg")
+    synth.write_kmc(prefix, kmers, counts, prm)
+    db = engine.KmcDb.open(prefix)
+    odb = oracle.OracleDb(prefix)
+    assert np.array_equal(db.lookup(kmers), counts.astype(np.uint32).astype(np.int32))
+    got = db.screen(ref, [0], [len(ref)], 1)
+    want = odb.screen(ref, [0], [len(ref)], 1)
+    assert_same(got, want, "negative counts")
+    assert 0 < int(got["obs"][0]) < int(got["total_kmers"][0])
+    # counter_size 0: every count reads 0, nothing is ever observed
+    prm0 = synth.KmcParams(k=k, p=3, counter_size=0, sig_len=5, n_bins=2, max_count=0)
+    prefix0 = str(tmp_path / "cs0")
+    synth.write_kmc(prefix0, kmers, np.zeros(len(kmers), dtype=np.uint64), prm0)
+    db0 = engine.KmcDb.open(prefix0)
+    assert_same(db0.screen(ref, [0], [len(ref)], 1), oracle.OracleDb(prefix0).screen(ref, [0], [len(ref)], 1), "cs0")
+
+
+def test_config1_scale(oracle, tmp_path):
+    """BASELINE.json configs[0]: synthetic 1 Mb FASTA, 1 KMC sample, k=31, 10 kb windows (101 windows), full compare"""
+    k = 31
+    ref = synth.random_reference(1_000_000, 1)
+    prefix, kmers, counts, prm = make_db(tmp_path, "cfg1", ref, 2, k=31, p=7, cs=2, m=9, bins=64, noise=100_000)
+    db = engine.KmcDb.open(prefix)
+    odb = oracle.OracleDb(prefix)
+    s, e = engine.windows(len(ref), 10_000, 0, k)
+    assert len(s) == 101 and (s[-1], e[-1]) == (997000, 1000000)
+    got = db.screen(ref, s, e - s, 1)
+    want = odb.screen(ref, s, e - s, 1, threads=8)
+    assert_same(got, want, "config 1")
+    assert_scores(oracle, got, want)
+    assert 0.5 < got["obs"].sum() / got["total_kmers"].sum() < 0.95     # realistic hit rate
+
+
+def test_async_device_output_on_torch_stream(oracle, tmp_path):
+    import torch
+    k = 31
+    ref = synth.random_reference(300_000, 23)
+    prefix, *_ = make_db(tmp_path, "db", ref, 60)
+    db = engine.KmcDb.open(prefix)
+    s, e = engine.windows(len(ref), 10_000, 0, k)
+    r = engine.Reference(ref, s, e - s, k)
+    want = r.screen(db, 1)
+    out = torch.zeros(len(s) * 10, dtype=torch.int32, device="cuda:0")
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        r.prof_enable(True)
+        for _ in range(3):
+            r.screen_async(db, out.data_ptr(), st.cuda_stream, 1)
+    st.synchronize()
+    ms, n = r.prof_read()
+    assert n == 3 and ms > 0
+    got = out.cpu().numpy().view(engine.RESULT_DTYPE)
+    assert_same(got, want, "async")
+    odb = oracle.OracleDb(prefix)
+    assert_same(got, odb.screen(ref, s, e - s, 1, threads=4), "async vs oracle")

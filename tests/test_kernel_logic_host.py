@@ -1,0 +1,169 @@
+"""CPU lane-by-lane emulation of screen_tiles_kernel (tests/host_harness) against the oracle.
+
+The harness is compiled from the same __host__ __device__ helpers the HIP kernel uses (kcfx_device.h,
+kcfx_internal.h): base packing, k-mer extraction, ballot-mask gap accounting, the tile monoid. Only the
+table probe is substituted (counts come from the oracle). This is a pre-GPU logic check, not a parity
+claim -- the parity tests proper are tests/test_gpu_parity.py.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from kcftools_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HDIR = os.path.join(HERE, "host_harness")
+
+SUMMARY = np.dtype([("n", "<i4"), ("obs", "<i4"), ("lead", "<i4"), ("trail", "<i4"), ("var_in", "<i4"),
+                    ("inner_in", "<i4"), ("runs", "<i4"), ("flags", "<u4"), ("count_sum", "<i8")])
+RESULT = np.dtype([("total_kmers", "<i4"), ("eff_length", "<i4"), ("obs", "<i4"), ("var", "<i4"), ("inner", "<i4"),
+                   ("left", "<i4"), ("right", "<i4"), ("_pad", "<i4"), ("kmer_count_sum", "<i8")])
+FIELDS = ("total_kmers", "eff_length", "obs", "var", "inner", "left", "right", "kmer_count_sum")
+
+
+@pytest.fixture(scope="module")
+def harness():
+    so = os.path.join(HDIR, "libharness.so")
+    src = os.path.join(HDIR, "harness.cpp")
+    deps = [src] + [os.path.join(HERE, "..", "kcftools_amd", "csrc", f) for f in ("kcfx_device.h", "kcfx_internal.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        hipcc = "/opt/rocm/bin/hipcc"
+        if not os.path.exists(hipcc):
+            pytest.skip("hipcc not available")
+        subprocess.run([hipcc, "-O1", "-std=c++17", "-fPIC", "-x", "hip", "--offload-arch=gfx950", "-shared", "-o", so, src],
+                       check=True, capture_output=True)
+    L = C.CDLL(so)
+    L.harness_extract.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.harness_screen_tile.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    L.harness_combine.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.harness_identity.argtypes = [C.c_void_p]
+    L.harness_finalize.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.harness_hash32.argtypes = [C.c_uint64]
+    L.harness_hash32.restype = C.c_uint32
+    return L
+
+
+def padded(text: bytes) -> np.ndarray:
+    return np.frombuffer(text + b"\0" * 128, dtype=np.uint8).copy()
+
+
+def plan(nk: int, tile_k: int):
+    if nk <= 0:
+        return []
+    nt = -(-nk // tile_k)
+    per = min(tile_k, -(-(-(-nk // nt)) // 64) * 64)
+    return [(s, min(per, nk - s)) for s in range(0, nk, per)]
+
+
+def emulate_window(L, buf, begin, length, k, both, count_of, min_count, cuts=None):
+    """fold the window's tiles through the harness; `cuts` overrides the tile plan (arbitrary split points)."""
+    nk = length - k + 1
+    acc = np.zeros(1, dtype=SUMMARY)
+    L.harness_identity(acc.ctypes.data)
+    tiles = plan(nk, L.harness_tile_k()) if cuts is None else cuts
+    for s, n in tiles:
+        fwd = np.zeros(n, dtype=np.uint64)
+        rc = np.zeros(n, dtype=np.uint64)
+        val = np.zeros(n, dtype=np.uint8)
+        L.harness_extract(buf.ctypes.data, begin + s, n, k, fwd.ctypes.data, rc.ctypes.data, val.ctypes.data)
+        key = np.minimum(fwd, rc) if both else fwd
+        counts = np.array([count_of(int(x)) if v else -99 for x, v in zip(key, val)], dtype=np.int32)
+        out = np.zeros(1, dtype=SUMMARY)
+        L.harness_screen_tile(buf.ctypes.data, begin + s, n, k, counts.ctypes.data, min_count, out.ctypes.data)
+        nxt = np.zeros(1, dtype=SUMMARY)
+        L.harness_combine(acc.ctypes.data, out.ctypes.data, k, nxt.ctypes.data)
+        acc = nxt
+    res = np.zeros(1, dtype=RESULT)
+    L.harness_finalize(acc.ctypes.data, k, res.ctypes.data)
+    return {f: int(res[f][0]) for f in FIELDS}
+
+
+def test_pack_and_extract_match_oracle(harness, oracle):
+    rng = np.random.default_rng(1)
+    alphabet = np.frombuffer(b"ACGTacgtNnRYKM-*\x00\xff@[`{AAAACCCCGGGGTTTT", dtype=np.uint8)
+    for k in (31, 32, 15, 7, 1):
+        text = alphabet[rng.integers(0, len(alphabet), 700)].tobytes()
+        # long valid stretches too
+        text = text[:200] + bytes(rng.choice(np.frombuffer(b"ACGTacgt", dtype=np.uint8), 300)) + text[200:]
+        buf = padded(text)
+        for begin in (0, 1, 17, 31, 32, 33, 95):
+            n = len(text) - begin - k + 1
+            fwd = np.zeros(n, dtype=np.uint64)
+            rc = np.zeros(n, dtype=np.uint64)
+            val = np.zeros(n, dtype=np.uint8)
+            harness.harness_extract(buf.ctypes.data, begin, n, k, fwd.ctypes.data, rc.ctypes.data, val.ctypes.data)
+            up = text.upper()
+            want_valid = np.array([all(c in b"ACGT" for c in up[begin + j:begin + j + k]) for j in range(n)])
+            assert np.array_equal(val.astype(bool), want_valid), (k, begin)
+            # the valid ones, in order, are Fasta.getKmersList (oracle)
+            lst = np.zeros(max(1, n), dtype=np.uint64)
+            m = oracle.lib().kcfo_kmers_list(text[begin:], len(text) - begin, k, lst.ctypes.data)
+            assert m == int(want_valid.sum())
+            assert np.array_equal(fwd[want_valid], lst[:m])
+            for j in np.nonzero(want_valid)[0][:60]:
+                assert int(rc[j]) == oracle.lib().kcfo_kmer_revcomp(int(fwd[j]), k)
+
+
+@pytest.mark.parametrize("k,both", [(31, True), (31, False), (15, True), (32, True)])
+def test_emulated_kernel_matches_oracle(harness, oracle, tmp_path, k, both):
+    p = 3 if (k - 3) % 4 == 0 else 4
+    ref = synth.random_reference(40_000, 77 + k, n_run_every=6000, max_n_run=300, lower_frac=0.2, iupac_rate=1e-3)
+    sample = synth.mutate_sample(ref, 5, sub_rate=1.2e-2, indel_rate=1e-3, big_del_per_mb=100, big_del_len=2500)
+    prm = synth.KmcParams(k=k, p=p, counter_size=2, sig_len=7, n_bins=8, both_strands=both)
+    kmers, counts = synth.build_sample_db(sample, prm, 9, noise_kmers=500)
+    prefix = str(tmp_path / "db")
+    synth.write_kmc(prefix, kmers, counts, prm)
+    db = oracle.OracleDb(prefix)
+    table = dict(zip((int(x) for x in kmers), (int(c) for c in counts)))
+    count_of = lambda w: table.get(w, 0)
+    buf = padded(ref)
+    wins = [(0, 10_000), (9_970, 10_000), (123, 4126), (5, 4127), (777, 31), (778, k), (800, k - 1 if k > 1 else 1),
+            (1000, 200), (20_001, 12_345), (39_000, 1000), (0, 40_000)]
+    for begin, length in wins:
+        for mc in (1, 4):
+            got = emulate_window(harness, buf, begin, length, k, both, count_of, mc)
+            want = db.process_window(ref[begin:begin + length], mc)
+            assert got == want, (begin, length, mc)
+    # arbitrary split points give the same answer as one pass (monoid associativity + carries across tiles)
+    rng = np.random.default_rng(4)
+    begin, length = 3_000, 9_000
+    nk = length - k + 1
+    want = db.process_window(ref[begin:begin + length], 1)
+    for _ in range(12):
+        pts = sorted(set(int(x) for x in rng.integers(1, nk, size=int(rng.integers(1, 9)))))
+        edges = [0] + pts + [nk]
+        cuts = [(a, b - a) for a, b in zip(edges[:-1], edges[1:]) if b - a <= 4096]
+        if sum(n for _, n in cuts) != nk:
+            continue
+        assert emulate_window(harness, buf, begin, length, k, both, count_of, 1, cuts=cuts) == want
+
+
+def test_emulated_kernel_extreme_patterns(harness, oracle):
+    """alternating hit/miss, all-miss, all-hit, N-separated runs: via a hand-made count function"""
+    k = 31
+    rng = np.random.default_rng(8)
+    text = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 9000))
+    text = text[:2500] + b"N" * 40 + text[2540:6000] + b"n" + text[6001:]
+    buf = padded(text)
+    lst = np.zeros(len(text), dtype=np.uint64)
+    m = oracle.lib().kcfo_kmers_list(text, len(text), k, lst.ctypes.data)
+    order = {int(w): i for i, w in enumerate(lst[:m])}       # random text: k-mers are distinct
+    assert len(order) == m
+    patterns = {
+        "alternate": lambda i: i % 2,
+        "all_miss": lambda i: 0,
+        "all_hit": lambda i: 3,
+        "blocks": lambda i: 0 if (i // 97) % 3 == 0 else 2,
+        "sparse_hits": lambda i: 1 if i % 641 == 5 else 0,
+        "gap29_30_31": lambda i: 0 if (i % 200) < 29 + (i // 200) % 3 else 1,
+    }
+    for name, fn in patterns.items():
+        count_of = lambda w, fn=fn: fn(order[w])
+        counts = np.array([fn(i) for i in range(m)], dtype=np.int32)
+        want = oracle.accumulate(counts, k, 1)
+        want["eff_length"] = oracle.lib().kcfo_eff_length(text, len(text), k)
+        got = emulate_window(harness, buf, 0, len(text), k, False, count_of, 1)
+        assert got == want, name
