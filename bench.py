@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py -- k-mers screened/s of the getVariations hot path on N MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch: every window of the reference screened against one
+sample's KMC database (kcfx_screen_ref_async: screen_tiles + finalize_windows), inputs resident in HBM.
+
+Workload at N=1 (BASELINE.json configs[1]): synthetic A. thaliana chr1-sized reference (30,427,671 bp, seeded),
+one synthetic KMC sample (k=31, counter_size 2, ~150 M k-mers = sample-genome k-mers + random noise k-mers),
+10 kb tiling windows (3,052 windows).  At N>1 the samples shard across ranks (configs[3] pattern): rank r screens
+the same reference against its own sample database r; per-GPU work is fixed ("weak"), and each step ends with the
+RCCL gather of the 40-byte per-window records to rank 0.  One process per GPU; launched for N>1 as
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+K = 31
+COUNTER_SIZE = 2
+B_ALG = 1 + 8 + COUNTER_SIZE   # algorithmic bytes per k-mer screened (SURVEY.md section 8 d)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def ensure_built():
+    from kcftools_amd import engine
+    synth_bin = os.path.join(ROOT, "kcftools_amd", "bin", "kcfx_synth")
+    if not os.path.exists(engine.LIB_PATH) or not os.path.exists(synth_bin):
+        import __graft_entry__ as g
+        g.build()
+    return synth_bin
+
+
+def make_dataset(synth_bin: str, workdir: str, ref_len: int, db_kmers: int, sample_seed: int, threads: int) -> tuple[str, dict]:
+    """Reference text + one sample's KMC database, written by the native generator (cached per parameter set)."""
+    os.makedirs(workdir, exist_ok=True)
+    prefix = os.path.join(workdir, f"r{ref_len}_d{db_kmers}_s{sample_seed}")
+    meta_path = prefix + ".meta.json"
+    if os.path.exists(meta_path):
+        return prefix, json.load(open(meta_path))
+    # the sample genome contributes ~0.88 * ref_len distinct k-mers; the rest is random noise k-mers
+    noise = max(0, db_kmers - int(0.885 * ref_len))
+    cmd = [synth_bin, "--out", prefix, "--ref-len", str(ref_len), "--seed", "1", "--sample-seed", str(sample_seed),
+           "--noise", str(noise), "--k", str(K), "--p", "7", "--cs", str(COUNTER_SIZE), "--bins", "512", "--threads", str(threads)]
+    t0 = time.time()
+    out = subprocess.run(cmd, check=True, capture_output=True, text=True).stdout
+    meta = json.loads(out.strip().splitlines()[-1])
+    meta["generate_seconds"] = time.time() - t0
+    meta["command"] = " ".join(cmd[1:])
+    json.dump(meta, open(meta_path, "w"))
+    return prefix, meta
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--ref-len", type=int, default=30_427_671)
+    ap.add_argument("--db-kmers", type=int, default=150_000_000)
+    ap.add_argument("--window", type=int, default=10_000)
+    ap.add_argument("--workdir", default=os.environ.get("KCFX_BENCH_DIR", "/tmp/kcfx_bench"))
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="target CPU work for the baseline leg (0 = skip)")
+    ap.add_argument("--min-count", type=int, default=1)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            log(f"bench.py: --gpus {args.gpus} needs torch.distributed.run (one process per GPU); see the module docstring")
+            sys.exit(2)
+        args.gpus = world
+
+    synth_bin = ensure_built()
+    import torch
+    import torch.distributed as dist
+    from kcftools_amd import engine
+
+    if not torch.cuda.is_available():
+        log("bench.py: no GPU visible; the engine has no CPU fallback")
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # ---- data: same reference on every rank, one sample database per rank -------------------------------
+    ncpu = os.cpu_count() or 8
+    t0 = time.time()
+    prefix, meta = make_dataset(synth_bin, args.workdir, args.ref_len, args.db_kmers, 2 + rank, max(1, ncpu // world))
+    text = np.fromfile(prefix + ".ref.txt", dtype=np.uint8).tobytes()
+    gen_s = time.time() - t0
+    starts, ends = engine.windows(len(text), args.window, 0, K)
+    win_begin = starts.astype(np.int64)
+    win_len = (ends - starts).astype(np.int32)
+
+    t0 = time.time()
+    db = engine.KmcDb.open(prefix, device=local_rank)
+    load_s = time.time() - t0
+    ref = engine.Reference(text, win_begin, win_len, K, device=local_rank)
+    n_win = len(win_begin)
+
+    out = torch.zeros(n_win * 10, dtype=torch.int32, device=f"cuda:{local_rank}")
+    gathered = [torch.zeros_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
+    stream = torch.cuda.current_stream()
+
+    def step():
+        ref.screen_async(db, out.data_ptr(), stream.cuda_stream, args.min_count)
+        if world > 1:
+            dist.gather(out, gathered, dst=0)      # RCCL over xGMI: 40 B per (window, sample)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    res = out.cpu().numpy().view(engine.RESULT_DTYPE).copy()
+    kmers_per_step = int(res["total_kmers"].sum())
+
+    # ---- timed region -----------------------------------------------------------------------------------------
+    ref.prof_enable(True)
+    ref.prof_read(reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = ref.prof_read(reset=True)
+    ref.prof_enable(False)
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+    tot = torch.tensor([kmers_per_step], dtype=torch.int64, device=f"cuda:{local_rank}")
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    kmers_all = int(tot.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    value = kmers_all * args.steps / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+    kern_avg_ms = kernel_ms / max(1, launches)
+    achieved_gbs = (kmers_per_step * B_ALG) / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("ref_len") == args.ref_len and tj.get("db_kmers") == args.db_kmers and tj.get("window") == args.window:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    # ---- CPU baseline: the oracle (C restatement of the reference path, probing the on-disk KMC layout) -----------
+    cpu = None
+    parity = None
+    if world == 1 and args.cpu_baseline_seconds > 0:
+        from oracle import binding as oracle
+        odb = oracle.OracleDb(prefix)
+        threads = min(ncpu, 256)
+        # calibrate on a few windows, single thread, then size the sample to ~cpu_baseline_seconds of CPU work
+        cal = min(n_win, 8)
+        t0 = time.perf_counter()
+        w1 = odb.screen(text, win_begin[:cal], win_len[:cal], args.min_count, threads=1)
+        t1 = time.perf_counter() - t0
+        rate1 = int(w1["total_kmers"].sum()) / t1
+        want_kmers = rate1 * args.cpu_baseline_seconds
+        n_s = int(min(n_win, max(threads, want_kmers / max(1, kmers_per_step / n_win))))
+        idx = np.linspace(0, n_win - 1, n_s).astype(np.int64)
+        t0 = time.perf_counter()
+        wN = odb.screen(text, win_begin[idx], win_len[idx], args.min_count, threads=threads)
+        tN = time.perf_counter() - t0
+        cpu_kmers = int(wN["total_kmers"].sum())
+        cpu = {"value": cpu_kmers / tN, "unit": "k-mers/s", "cores": threads, "kind": "port",
+               "sample": f"{n_s} of {n_win} windows ({cpu_kmers} k-mers), evenly spaced, same database files; "
+                         f"oracle/kcf_oracle.c (C restatement of the Java path, KMC on-disk layout, thread pool over windows)",
+               "value_1thread": rate1, "seconds": tN}
+        # the same windows from the GPU run must be bit-identical
+        ok = all(np.array_equal(res[f][idx], wN[f]) for f in engine.INT_FIELDS)
+        parity = {"windows_checked": int(n_s), "bit_exact": bool(ok)}
+        if not ok:
+            log("bench.py: GPU results differ from the oracle on the baseline sample")
+
+    line = {
+        "metric": "k-mers screened/sec, getVariations k=31",
+        "value": value,
+        "unit": "k-mers/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {"workload": f"getVariations: synthetic chr1-sized reference {args.ref_len} bp, 1 KMC sample per GPU "
+                               f"(k=31, counter_size {COUNTER_SIZE}, {meta['db_kmers']} k-mers), {args.window // 1000} kb tiling windows "
+                               f"({n_win} windows), -c {args.min_count}",
+                   "windows": n_win, "kmers_per_step_per_gpu": kmers_per_step, "db_kmers": meta["db_kmers"],
+                   "parallelism": f"sample-sharded x{world}, RCCL gather of 40 B records" if world > 1 else "single GPU",
+                   "table_bytes": int(db.info.table_bytes), "hit_rate": float(res["obs"].sum() / max(1, res["total_kmers"].sum()))},
+        "windows_per_s": n_win * world * args.steps / elapsed,
+        "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "screen_tiles_kernel", "kernel_avg_ms": kern_avg_ms, "launches_timed": int(launches),
+                     "algorithmic_bytes_per_kmer": B_ALG},
+        "cpu_baseline": cpu,
+        "parity": parity,
+        "setup_seconds": {"generate": gen_s, "db_open": load_s, "db_open_inner": float(db.info.load_seconds)},
+    }
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -47,6 +47,26 @@ class KcfxError(RuntimeError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """One HIP runtime per process.  The PyTorch wheel bundles its own libamdhip64.so (SONAME libamdhip64.so.7,
+    the same SONAME libkcfx.so needs).  If libkcfx.so were loaded first it would bind /opt/rocm's copy, a later
+    `import torch` would bring in the bundled copy as well, and the second runtime finds no GPU.  Pre-loading the
+    bundled copy (when PyTorch is installed) makes both bind the same runtime, whatever the import order."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib() -> C.CDLL:
     """Load libkcfx.so; fail loudly if it has not been built (python __graft_entry__.py build)."""
     global _lib
@@ -54,6 +74,7 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: the HIP extension is not built "
                               f"(run `python -c 'import __graft_entry__ as g; g.build()'`); there is no fallback")
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
         L.kcfx_last_error.restype = C.c_char_p

@@ -59,7 +59,7 @@ def test_lookup_matches_getcount(oracle, tmp_path, k, p, cs, m, bins, both):
     i = db.info
     assert (i.kmer_length, i.lut_prefix_length, i.counter_size, i.signature_length, i.n_bins) == (k, p, cs, m, bins)
     assert bool(i.both_strands) == both and i.total_kmers == len(kmers) and i.version == 0x200
-    assert i.min_count == prm.min_count and i.max_count == prm.max_count
+    assert i.min_count == prm.min_count and i.max_count == int(np.int32(np.uint32(prm.max_count)))   # Java int (KMC.java:131)
     got = db.lookup(kmers)
     assert np.array_equal(got, counts.astype(np.uint32).astype(np.int32))
     rng = np.random.default_rng(1)
