@@ -10,6 +10,8 @@
 //
 // Integer / index work, HBM-bound: no MFMA. Lane <-> consecutive k-mer start positions, so one __ballot is a
 // 64-position slice of the window's hit bitmap.
+#include <cstdlib>
+
 #include "kcfx_device.h"
 
 namespace kcfx {
@@ -96,41 +98,44 @@ __global__ void decode_records_kernel(const uint8_t* __restrict__ records, int64
 // ======================================================================================================
 // probe: one 64-byte line per step; a miss continues to the next line only while the overflow bit is set
 // ======================================================================================================
-template <bool WIDE>
+template <bool WIDE, bool SINGLE_ROUND = false>
 __device__ __forceinline__ bool probe(const TableView& tv, uint64_t key, int32_t& count) {
     uint32_t line = home_line(key, tv.n_lines);
     const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
     for (;;) {
         const uint4* p = reinterpret_cast<const uint4*>(tv.lines + (size_t)line * LINE_BYTES);
         const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+        // pin the count dwords here: without it LLVM sinks their load below the key compares, i.e. into a second,
+        // dependent memory round trip per probe
+        asm volatile("" ::"v"(q3.x), "v"(q3.y), "v"(q3.z), "v"(q3.w));
         const uint32_t meta = q3.w;
         const uint32_t ns = meta & 0xFFu;
-        bool found;
+        // Branch-free match: every loaded dword is consumed unconditionally, so the compiler keeps the four 16-byte
+        // loads of the line together in ONE memory round trip (with ?: chains it sinks the count loads into a
+        // second, dependent access after the key compares).
         uint32_t c;
+        uint32_t any;
+#define KCFX_EQ(lo, hi, i) (((((lo) ^ klo) | ((hi) ^ khi)) == 0u && ns > (i)) ? 0xFFFFFFFFu : 0u)
         if (!WIDE) {
-            const bool m0 = (ns > 0) & (q0.x == klo) & (q0.y == khi);
-            const bool m1 = (ns > 1) & (q0.z == klo) & (q0.w == khi);
-            const bool m2 = (ns > 2) & (q1.x == klo) & (q1.y == khi);
-            const bool m3 = (ns > 3) & (q1.z == klo) & (q1.w == khi);
-            const bool m4 = (ns > 4) & (q2.x == klo) & (q2.y == khi);
-            const bool m5 = (ns > 5) & (q2.z == klo) & (q2.w == khi);
-            found = m0 | m1 | m2 | m3 | m4 | m5;
-            const uint32_t cw = (m0 | m1) ? q3.x : ((m2 | m3) ? q3.y : q3.z);
-            c = (m1 | m3 | m5) ? (cw >> 16) : (cw & 0xFFFFu);
+            const uint32_t e0 = KCFX_EQ(q0.x, q0.y, 0), e1 = KCFX_EQ(q0.z, q0.w, 1), e2 = KCFX_EQ(q1.x, q1.y, 2);
+            const uint32_t e3 = KCFX_EQ(q1.z, q1.w, 3), e4 = KCFX_EQ(q2.x, q2.y, 4), e5 = KCFX_EQ(q2.z, q2.w, 5);
+            any = e0 | e1 | e2 | e3 | e4 | e5;
+            c = (q3.x & ((e0 & 0xFFFFu) | (e1 & 0xFFFF0000u))) | (q3.y & ((e2 & 0xFFFFu) | (e3 & 0xFFFF0000u))) |
+                (q3.z & ((e4 & 0xFFFFu) | (e5 & 0xFFFF0000u)));
+            c = (c & 0xFFFFu) | (c >> 16);
         } else {
-            const bool m0 = (ns > 0) & (q0.x == klo) & (q0.y == khi);
-            const bool m1 = (ns > 1) & (q0.z == klo) & (q0.w == khi);
-            const bool m2 = (ns > 2) & (q1.x == klo) & (q1.y == khi);
-            const bool m3 = (ns > 3) & (q1.z == klo) & (q1.w == khi);
-            const bool m4 = (ns > 4) & (q2.x == klo) & (q2.y == khi);
-            found = m0 | m1 | m2 | m3 | m4;
-            c = m0 ? q2.z : (m1 ? q2.w : (m2 ? q3.x : (m3 ? q3.y : q3.z)));
+            const uint32_t e0 = KCFX_EQ(q0.x, q0.y, 0), e1 = KCFX_EQ(q0.z, q0.w, 1), e2 = KCFX_EQ(q1.x, q1.y, 2);
+            const uint32_t e3 = KCFX_EQ(q1.z, q1.w, 3), e4 = KCFX_EQ(q2.x, q2.y, 4);
+            any = e0 | e1 | e2 | e3 | e4;
+            c = (q2.z & e0) | (q2.w & e1) | (q3.x & e2) | (q3.y & e3) | (q3.z & e4);
         }
+#undef KCFX_EQ
+        const bool found = any != 0u;
         if (found) {
             count = (int32_t)c;           // Java int (KMC.java:395-401)
             return true;
         }
-        if (!(meta & META_OVERFLOW)) {
+        if (SINGLE_ROUND || !(meta & META_OVERFLOW)) {
             count = 0;
             return false;
         }
@@ -165,7 +170,10 @@ __device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
     return v;
 }
 
-template <bool WIDE>
+// VAR != 0 only exists in the experiments build (-DKCFX_EXPERIMENTS, libkcfx_exp.so): timing ablations whose
+// results are deliberately wrong. 1: single probe round (ignore overflow)  2: no gap accounting
+// 3: no table probe  4: no k-mer extraction (synthetic keys)
+template <bool WIDE, int VAR>
 __global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __restrict__ text,
                                                              const TileDesc* __restrict__ tiles, TableView tv,
                                                              int32_t k, int32_t both_strands, int32_t min_count,
@@ -219,13 +227,25 @@ __global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __re
     for (int w = w_begin; w < w_end; ++w) {
         const int j = w * 64 + lane;
         uint64_t fwd, rc;
-        bool valid = extract_kmer(s_fw, s_cw, s_vb, off + j, k, fwd, rc);
+        bool valid;
+        if (VAR == 4) {
+            fwd = (uint64_t)hash32((uint64_t)(blockIdx.x * 4096u + j)) << 32 | hash32((uint64_t)j * 77u + blockIdx.x);
+            rc = ~fwd;
+            valid = true;
+        } else {
+            valid = extract_kmer(s_fw, s_cw, s_vb, off + min(j, td.n_kmers - 1), k, fwd, rc);
+        }
         valid = valid && (j < td.n_kmers);
         // Kmer(Kmer, bothStrands): canonical = min(fwd, revcomp) unsigned (Kmer.java:72-79,406-414)
         const uint64_t key = (both_strands && rc < fwd) ? rc : fwd;
         int32_t cnt = 0;
         bool found = false;
-        if (valid) found = probe<WIDE>(tv, key, cnt);
+        if (VAR == 3) {
+            cnt = (int32_t)(key >> 60);
+            found = (key & 0x300) != 0;
+        } else if (valid) {
+            found = probe<WIDE, VAR == 1>(tv, key, cnt);
+        }
         const bool hit = found && (cnt >= min_count);            // GetVariants.java:224
 
         const uint64_t V = __ballot(valid);
@@ -242,7 +262,9 @@ __global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __re
         last_V = V;
 
         // gap accounting (GetVariants.java:228-244)
-        if (H) {
+        if (VAR == 2) {
+            var_acc += (int32_t)(M >> lane) & 1;
+        } else if (H) {
             if (M) {
                 if (hit) {
                     const int32_t g = gap_closed_by(H, M, lane, carry);
@@ -367,10 +389,16 @@ hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32
                                int32_t both_strands, int32_t min_count, TileSummary* out, hipStream_t st) {
     if (n_tiles <= 0) return hipSuccess;
     const dim3 g(n_tiles), b(BLOCK);
+#ifdef KCFX_EXPERIMENTS
+    static const int var = getenv("KCFX_VARIANT") ? atoi(getenv("KCFX_VARIANT")) : 0;
+#define KCFX_VARIANT_CASE(V) \
+    if (var == V) { hipLaunchKernelGGL((screen_tiles_kernel<false, V>), g, b, 0, st, text, tiles, tv, k, both_strands, min_count, out); return hipGetLastError(); }
+    if (!tv.wide) { KCFX_VARIANT_CASE(1) KCFX_VARIANT_CASE(2) KCFX_VARIANT_CASE(3) KCFX_VARIANT_CASE(4) }
+#endif
     if (tv.wide)
-        hipLaunchKernelGGL(screen_tiles_kernel<true>, g, b, 0, st, text, tiles, tv, k, both_strands, min_count, out);
+        hipLaunchKernelGGL((screen_tiles_kernel<true, 0>), g, b, 0, st, text, tiles, tv, k, both_strands, min_count, out);
     else
-        hipLaunchKernelGGL(screen_tiles_kernel<false>, g, b, 0, st, text, tiles, tv, k, both_strands, min_count, out);
+        hipLaunchKernelGGL((screen_tiles_kernel<false, 0>), g, b, 0, st, text, tiles, tv, k, both_strands, min_count, out);
     return hipGetLastError();
 }
 

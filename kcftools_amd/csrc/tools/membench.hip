@@ -1,0 +1,114 @@
+// kcfx_membench -- random-access microbenchmarks that size the table design (not part of the product path).
+// Each lane reads BYTES contiguous bytes at a pseudo-random, BYTES-aligned (or LINE-aligned) offset of a big buffer.
+//   usage: kcfx_membench [table_GiB=3] [accesses_M=64]
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+__device__ __forceinline__ uint32_t h32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16; return x;
+}
+
+// per-lane gather: each lane reads VEC x 16 bytes from its own random LINE-byte-aligned line. ILP independent probes per lane.
+template <int VEC, int LINE, int ILP>
+__global__ __launch_bounds__(256) void gather_lane(const uint8_t* __restrict__ buf, uint32_t n_lines, uint64_t n_acc, uint32_t* out) {
+    uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    for (; i < n_acc; i += stride * ILP) {
+        uint4 v[ILP][VEC];
+#pragma unroll
+        for (int u = 0; u < ILP; ++u) {
+            const uint32_t line = __umulhi(h32((uint32_t)(i + u * stride) * 2654435761u + 12345u), n_lines);
+            const uint4* p = reinterpret_cast<const uint4*>(buf + (size_t)line * LINE);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v[u][j] = p[j];
+        }
+#pragma unroll
+        for (int u = 0; u < ILP; ++u)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc += v[u][j].x ^ v[u][j].y ^ v[u][j].z ^ v[u][j].w;
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+// cooperative gather: G lanes share one random line of G*16 bytes (one dwordx4 each); 64/G lines per wave-instruction
+template <int G, int ILP>
+__global__ __launch_bounds__(256) void gather_coop(const uint8_t* __restrict__ buf, uint32_t n_lines, uint64_t n_acc, uint32_t* out) {
+    const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    uint64_t i = tid / G;
+    const uint32_t sub = tid % G;
+    const uint64_t stride = ((uint64_t)gridDim.x * blockDim.x) / G;
+    uint32_t acc = 0;
+    for (; i < n_acc; i += stride * ILP) {
+        uint4 v[ILP];
+#pragma unroll
+        for (int u = 0; u < ILP; ++u) {
+            const uint32_t line = __umulhi(h32((uint32_t)(i + u * stride) * 2654435761u + 12345u), n_lines);
+            v[u] = reinterpret_cast<const uint4*>(buf + (size_t)line * (G * 16))[sub];
+        }
+#pragma unroll
+        for (int u = 0; u < ILP; ++u) acc += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+__global__ void stream_read(const uint4* __restrict__ buf, uint64_t n_vec, uint32_t* out) {
+    uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    for (; i < n_vec; i += stride) { uint4 v = buf[i]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+__global__ void fill(uint4* buf, uint64_t n_vec) {
+    uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n_vec; i += stride) buf[i] = make_uint4((uint32_t)i, 1, 2, 3);
+}
+
+template <typename F>
+static void timeit(const char* name, double accesses, double bytes_per_access, F launch) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    launch();
+    CK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int r = 0; r < 3; ++r) {
+        CK(hipEventRecord(a));
+        launch();
+        CK(hipEventRecord(b));
+        CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        if (ms < best) best = ms;
+    }
+    printf("%-34s %8.3f ms  %8.2f G acc/s  %8.1f GB/s (requested bytes)\n", name, best, accesses / best / 1e6, accesses * bytes_per_access / best / 1e6);
+}
+
+int main(int argc, char** argv) {
+    const double gib = argc > 1 ? atof(argv[1]) : 3.0;
+    const uint64_t n_acc = (uint64_t)((argc > 2 ? atof(argv[2]) : 64.0) * 1e6);
+    const size_t bytes = (size_t)(gib * (1ull << 30)) / 4096 * 4096;
+    uint8_t* buf; uint32_t* out;
+    CK(hipMalloc(&buf, bytes)); CK(hipMalloc(&out, 64));
+    hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, (uint4*)buf, bytes / 16);
+    CK(hipDeviceSynchronize());
+    printf("table %.2f GiB, %llu accesses per launch\n", gib, (unsigned long long)n_acc);
+    const dim3 g(256 * 8), b(256);
+    timeit("stream read 16B/lane", (double)bytes / 16, 16, [&] { hipLaunchKernelGGL(stream_read, g, b, 0, 0, (const uint4*)buf, bytes / 16, out); });
+#define LANE(V, L, I) timeit("lane " #V "x16B of " #L "B line, ILP " #I, (double)n_acc, V * 16, [&] { \
+        hipLaunchKernelGGL((gather_lane<V, L, I>), g, b, 0, 0, buf, (uint32_t)(bytes / L), n_acc, out); });
+    LANE(1, 16, 1) LANE(1, 32, 1) LANE(1, 64, 1) LANE(1, 128, 1)
+    LANE(2, 32, 1) LANE(2, 64, 1)
+    LANE(4, 64, 1) LANE(4, 64, 2) LANE(4, 64, 4)
+    LANE(4, 128, 1) LANE(8, 128, 1) LANE(8, 128, 2)
+    LANE(1, 64, 4) LANE(2, 32, 4)
+#define COOP(G, I) timeit("coop " #G " lanes x16B, ILP " #I, (double)n_acc, G * 16, [&] { \
+        hipLaunchKernelGGL((gather_coop<G, I>), g, b, 0, 0, buf, (uint32_t)(bytes / (G * 16)), n_acc, out); });
+    COOP(2, 1) COOP(2, 4) COOP(4, 1) COOP(4, 2) COOP(4, 4) COOP(4, 8) COOP(8, 1) COOP(8, 4) COOP(16, 1) COOP(16, 4)
+    return 0;
+}

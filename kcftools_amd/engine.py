@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkcfx.so")
+LIB_PATH = os.environ.get("KCFX_LIB") or os.path.join(_HERE, "libkcfx.so")   # KCFX_LIB: experiments build only
 
 RESULT_DTYPE = np.dtype([("total_kmers", "<i4"), ("eff_length", "<i4"), ("obs", "<i4"), ("var", "<i4"),
                          ("inner", "<i4"), ("left", "<i4"), ("right", "<i4"), ("_pad", "<i4"),
