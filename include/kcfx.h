@@ -70,10 +70,12 @@ typedef struct {
     int32_t n_bins;          /* numPrefixArrays (KMC.java:156) */
     int64_t total_kmers;
     int64_t table_bytes;     /* HBM bytes of the re-indexed table */
-    int64_t table_lines;     /* number of 64-byte lines */
+    int64_t table_lines;     /* number of 128-byte lines */
     int32_t slots_per_line;
     int32_t device;
     double  load_seconds;    /* file read + upload + table build */
+    int32_t table_mode;      /* 1 = minimizer-bucketed lines (default), 0 = per-k-mer hashing */
+    int32_t minimizer_length;/* M of the minimizer bucketing (0 in mode 0) */
 } kcfx_db_info_t;
 
 /* ---- database ------------------------------------------------------------------------------------ */

@@ -124,8 +124,10 @@ struct kcfx_db {
     uint8_t* d_lines = nullptr;
     uint32_t n_lines = 0;
     int32_t wide = 0;
+    int32_t mode = MODE_MINIMIZER;
+    int32_t mm_len = 0;
     hipStream_t stream = nullptr;
-    TableView view() const { return TableView{d_lines, n_lines, wide}; }
+    TableView view() const { return TableView{d_lines, n_lines, wide, mode, mm_len}; }
 };
 
 struct kcfx_ref {
@@ -178,15 +180,40 @@ double table_load_factor() {
     return a;
 }
 
+// KCFX_TABLE_MODE=keyhash selects per-k-mer hashing (A/B against the default minimizer bucketing)
+int32_t table_mode() {
+    const char* s = getenv("KCFX_TABLE_MODE");
+    return (s && (!strcmp(s, "keyhash") || !strcmp(s, "0"))) ? MODE_KEYHASH : MODE_MINIMIZER;
+}
+
+// Minimizer length M: long enough that distinct minimizers rarely share an M-mer by chance (4^M >> 16 x keys),
+// short enough to keep runs long (run length ~ (k - M + 2) / 2).
+int32_t minimizer_len(int32_t k, int64_t n_keys) {
+    const char* s = getenv("KCFX_MM_LEN");
+    int m;
+    if (s && atoi(s) > 0) {
+        m = atoi(s);
+    } else {
+        m = 11;
+        while (m < 20 && (double)(1ull << (2 * m)) < 16.0 * (double)std::max<int64_t>(n_keys, 1)) ++m;
+        if (k == 31 && m <= 16) m = 16;     // the compile-time-specialised kernel (k = 31, M = 16)
+    }
+    return std::max(1, std::min(m, std::min(k, 32)));
+}
+
 int32_t table_alloc(kcfx_db* db, int64_t n_keys, int32_t counter_size) {
     db->wide = counter_size > 2 ? 1 : 0;
+    db->mode = table_mode();
+    db->mm_len = minimizer_len(db->info.kmer_length, n_keys);
+    db->info.table_mode = db->mode;
+    db->info.minimizer_length = db->mode == MODE_MINIMIZER ? db->mm_len : 0;
     const int slots = db->wide ? SLOTS_U32 : SLOTS_U16;
     double want = (double)n_keys / (slots * table_load_factor());
     if (want < 64) want = 64;
     if (want > 4294967295.0) return fail(KCFX_ERR_ARG, "database too large for a 32-bit line index");
     db->n_lines = (uint32_t)want + 1;
     KCFX_HIP(hipMalloc(&db->d_lines, (size_t)db->n_lines * LINE_BYTES));
-    KCFX_HIP(launch_table_clear(db->d_lines, db->n_lines, db->stream));
+    KCFX_HIP(launch_table_clear(db->d_lines, db->n_lines, db->wide, db->stream));
     db->info.table_bytes = (int64_t)db->n_lines * LINE_BYTES;
     db->info.table_lines = db->n_lines;
     db->info.slots_per_line = slots;
@@ -292,7 +319,7 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
         used[turn] = true;
         LOAD_HIP(launch_decode_records(d_rec, first, n, h.record_size, h.suffix_bytes, h.counter_size, h.p, d_lut,
                                        (int64_t)h.lut.size(), d_keys, d_counts, db->stream));
-        LOAD_HIP(launch_table_insert(db->d_lines, db->n_lines, db->wide, d_keys, d_counts, n, db->stream));
+        LOAD_HIP(launch_table_insert(db->d_lines, db->view(), h.k, d_keys, d_counts, n, db->stream));
         first += n;
         turn ^= 1;
     }
@@ -398,7 +425,7 @@ int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, 
         if ((e = hipMalloc(&d_keys, (size_t)n * 8)) != hipSuccess || (e = hipMalloc(&d_counts, (size_t)n * 4)) != hipSuccess ||
             (e = hipMemcpyAsync(d_keys, kmers, (size_t)n * 8, hipMemcpyHostToDevice, db->stream)) != hipSuccess ||
             (e = hipMemcpyAsync(d_counts, src, (size_t)n * 4, hipMemcpyHostToDevice, db->stream)) != hipSuccess ||
-            (e = launch_table_insert(db->d_lines, db->n_lines, db->wide, d_keys, d_counts, n, db->stream)) != hipSuccess ||
+            (e = launch_table_insert(db->d_lines, db->view(), kmer_length, d_keys, d_counts, n, db->stream)) != hipSuccess ||
             (e = hipStreamSynchronize(db->stream)) != hipSuccess)
             rc = hip_fail(e, "kcfx_db_build upload/insert");
     }
@@ -431,7 +458,7 @@ int32_t kcfx_db_lookup(kcfx_db* db, const uint64_t* kmers, int64_t n, int32_t* c
     int32_t rc = KCFX_OK;
     if ((e = hipMalloc(&d_k, (size_t)n * 8)) != hipSuccess || (e = hipMalloc(&d_c, (size_t)n * 4)) != hipSuccess ||
         (e = hipMemcpyAsync(d_k, kmers, (size_t)n * 8, hipMemcpyHostToDevice, db->stream)) != hipSuccess ||
-        (e = launch_lookup(db->view(), d_k, n, d_c, db->stream)) != hipSuccess ||
+        (e = launch_lookup(db->view(), db->info.kmer_length, d_k, n, d_c, db->stream)) != hipSuccess ||
         (e = hipMemcpyAsync(counts_out, d_c, (size_t)n * 4, hipMemcpyDeviceToHost, db->stream)) != hipSuccess ||
         (e = hipStreamSynchronize(db->stream)) != hipSuccess)
         rc = hip_fail(e, "kcfx_db_lookup");

@@ -25,7 +25,16 @@ KCFX_HD uint32_t hash32(uint64_t key) {
     return h;
 }
 KCFX_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
-KCFX_HD uint32_t home_line(uint64_t key, uint32_t n_lines) { return mulhi32(hash32(key), n_lines); }
+// second bijective mix: the minimum of ~16 hashes is skewed towards 0, so it is re-spread before range reduction
+KCFX_HD uint32_t remix32(uint32_t x) {
+    x += 0x68E31DA4u;
+    x ^= x >> 15;
+    x *= 0x2C1B3C6Du;
+    x ^= x >> 12;
+    x *= 0x297A2D39u;
+    x ^= x >> 15;
+    return x;
+}
 
 // ---- base packing ------------------------------------------------------------------------------------
 // funnel shift left: high 32 bits of ((hi:lo) << s), s in 0..31 (lowers to v_alignbit_b32)
@@ -84,24 +93,113 @@ KCFX_HD uint32_t brev32(uint32_t x) {
 #endif
 }
 
-// The k-mer starting at packed base position q (forward array fw, complement-swapped array cw, validity
-// bits vb; all MSB-first). Returns validity (all k bases valid); fwd / rc are left-aligned words
-// (Kmer.java:232-252, :300-338).
-KCFX_HD bool extract_kmer(const uint32_t* fw, const uint32_t* cw, const uint32_t* vb, int q, int k, uint64_t& fwd,
-                          uint64_t& rc) {
+// `len` bases starting at packed base position q as left-aligned words: fwd (Kmer.java:232-252) and its reverse
+// complement (Kmer.java:300-338), from the forward code array fw and the complement-swapped array cw (MSB first).
+KCFX_HD void extract_pair(const uint32_t* fw, const uint32_t* cw, int q, int len, uint64_t& fwd, uint64_t& rc) {
     const int w = q >> 4;
     const uint32_t s = (uint32_t)(q & 15) * 2;
     const uint32_t f0 = fw[w], f1 = fw[w + 1], f2 = fw[w + 2];
     const uint32_t g0 = cw[w], g1 = cw[w + 1], g2 = cw[w + 2];
-    const uint64_t kmask = ~0ull << (64 - 2 * k);          // top 2k bits
-    fwd = ((((uint64_t)fshl(f0, f1, s)) << 32) | fshl(f1, f2, s)) & kmask;
-    const uint64_t y = ((((uint64_t)fshl(g0, g1, s)) << 32) | fshl(g1, g2, s)) & kmask;
+    const uint64_t mask = ~0ull << (64 - 2 * len);          // top 2*len bits
+    fwd = ((((uint64_t)fshl(f0, f1, s)) << 32) | fshl(f1, f2, s)) & mask;
+    const uint64_t y = ((((uint64_t)fshl(g0, g1, s)) << 32) | fshl(g1, g2, s)) & mask;
     // bit-reverse the 64-bit word: reverses the base order and swaps the bits of every pair back
     const uint64_t r = (((uint64_t)brev32((uint32_t)y)) << 32) | brev32((uint32_t)(y >> 32));
-    rc = r << (64 - 2 * k);
+    rc = r << (64 - 2 * len);
+}
+
+// all k bases starting at q are A/C/G/T (validity bits vb, MSB first)
+KCFX_HD bool kmer_valid(const uint32_t* vb, int q, int k) {
     const int w2 = q >> 5;
     const uint32_t v = fshl(vb[w2], vb[w2 + 1], (uint32_t)(q & 31));
     return (v >> (32 - k)) == (uint32_t)((1ull << k) - 1);
+}
+
+KCFX_HD bool extract_kmer(const uint32_t* fw, const uint32_t* cw, const uint32_t* vb, int q, int k, uint64_t& fwd,
+                          uint64_t& rc) {
+    extract_pair(fw, cw, q, k, fwd, rc);
+    return kmer_valid(vb, q, k);
+}
+
+// ---- minimizers ---------------------------------------------------------------------------------------
+// reverse complement of a left-aligned word of `len` bases (same bit trick as extract_pair)
+KCFX_HD uint64_t revcomp_word(uint64_t x, int len) {
+    const uint64_t z = ~(((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1));
+    const uint64_t y = z & (~0ull << (64 - 2 * len));
+    const uint64_t r = (((uint64_t)brev32((uint32_t)y)) << 32) | brev32((uint32_t)(y >> 32));
+    return r << (64 - 2 * len);
+}
+
+// hash of the canonical M-mer given its two strands as left-aligned words
+KCFX_HD uint32_t mmer_hash(uint64_t fwd, uint64_t rc) { return hash32(fwd < rc ? fwd : rc); }
+
+// Build side: minimizer of a stored k-mer word = min over its k-M+1 M-mers of mmer_hash. Strand-symmetric, so the
+// canonical and the forward form of a k-mer agree, and it equals what screen_tiles derives from the reference text
+// (min over s_h[p .. p+k-M]).
+KCFX_HD uint32_t minimizer_of_kmer(uint64_t x, int k, int M) {
+    const uint64_t y = revcomp_word(x, k);
+    const uint64_t mask = ~0ull << (64 - 2 * M);
+    uint32_t best = 0xFFFFFFFFu;
+    for (int j = 0; j + M <= k; ++j) {
+        const uint64_t f = (x << (2 * j)) & mask;
+        const uint64_t r = (y << (2 * (k - M - j))) & mask;
+        const uint32_t h = mmer_hash(f, r);
+        best = h < best ? h : best;
+    }
+    return best;
+}
+
+KCFX_HD uint32_t home_line(const TableView& tv, uint64_t key, int k) {
+    const uint32_t h = (tv.mode == MODE_MINIMIZER) ? remix32(minimizer_of_kmer(key, k, tv.mm_len)) : hash32(key);
+    return mulhi32(h, tv.n_lines);
+}
+
+// ---- one 128-byte line against one key ----------------------------------------------------------------
+// q[0..7] = the line as eight 16-byte pieces. Empty slots hold EMPTY_KEY (all ones), which no k-mer word with
+// k < 32 can equal (its low 2*(32-k) bits are zero); CHECK_NS additionally masks slots >= the occupied count and
+// is needed only for k == 32, where TT..T is the all-ones word. Returns true when the key is present.
+constexpr uint64_t EMPTY_KEY = ~0ull;
+
+KCFX_HD uint64_t u64_of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+
+template <bool WIDE, bool CHECK_NS>
+KCFX_HD bool match_line(const uint4 (&q)[8], uint64_t key, uint32_t& count, uint32_t& meta) {
+    meta = q[7].z;
+    const uint32_t ns = CHECK_NS ? (meta & 0xFFu) : 0xFFu;
+    const bool m0 = u64_of(q[0].x, q[0].y) == key && ns > 0, m1 = u64_of(q[0].z, q[0].w) == key && ns > 1;
+    const bool m2 = u64_of(q[1].x, q[1].y) == key && ns > 2, m3 = u64_of(q[1].z, q[1].w) == key && ns > 3;
+    const bool m4 = u64_of(q[2].x, q[2].y) == key && ns > 4, m5 = u64_of(q[2].z, q[2].w) == key && ns > 5;
+    const bool m6 = u64_of(q[3].x, q[3].y) == key && ns > 6, m7 = u64_of(q[3].z, q[3].w) == key && ns > 7;
+    const bool m8 = u64_of(q[4].x, q[4].y) == key && ns > 8, m9 = u64_of(q[4].z, q[4].w) == key && ns > 9;
+    uint32_t c = 0;
+    bool any;
+    if (!WIDE) {
+        const bool m10 = u64_of(q[5].x, q[5].y) == key && ns > 10, m11 = u64_of(q[5].z, q[5].w) == key && ns > 11;
+        // at most one slot matches: pick the dword holding its u16 count, then the half
+        c = (m0 | m1) ? q[6].x : c;
+        c = (m2 | m3) ? q[6].y : c;
+        c = (m4 | m5) ? q[6].z : c;
+        c = (m6 | m7) ? q[6].w : c;
+        c = (m8 | m9) ? q[7].x : c;
+        c = (m10 | m11) ? q[7].y : c;
+        const bool odd = m1 | m3 | m5 | m7 | m9 | m11;
+        c = odd ? (c >> 16) : (c & 0xFFFFu);
+        any = m0 | m1 | m2 | m3 | m4 | m5 | m6 | m7 | m8 | m9 | m10 | m11;
+    } else {
+        c = m0 ? q[5].x : c;
+        c = m1 ? q[5].y : c;
+        c = m2 ? q[5].z : c;
+        c = m3 ? q[5].w : c;
+        c = m4 ? q[6].x : c;
+        c = m5 ? q[6].y : c;
+        c = m6 ? q[6].z : c;
+        c = m7 ? q[6].w : c;
+        c = m8 ? q[7].x : c;
+        c = m9 ? q[7].y : c;
+        any = m0 | m1 | m2 | m3 | m4 | m5 | m6 | m7 | m8 | m9;
+    }
+    count = c;
+    return any;
 }
 
 // ---- gap accounting over one 64-position word ----------------------------------------------------------
@@ -115,6 +213,7 @@ struct GapCarry {
 };
 
 // contribution of the hit at `lane` (must be a set bit of H): does it close an interior gap, and how long?
+// (lane-parallel form; kept for the CPU emulation tests as the independent cross-check of gap_close_scalar)
 KCFX_HD int32_t gap_closed_by(uint64_t H, uint64_t M, int lane, const GapCarry& c) {
     const uint64_t below = (1ull << lane) - 1;
     const uint64_t hb = H & below;
@@ -122,6 +221,34 @@ KCFX_HD int32_t gap_closed_by(uint64_t H, uint64_t M, int lane, const GapCarry& 
     const int q = 63 - __builtin_clzll(hb);
     const uint64_t between = below & ~((2ull << q) - 1);
     return __builtin_popcountll(M & between);
+}
+
+// Wave-uniform form used by the kernel: all arguments are ballot masks / scalars, so this runs on the scalar unit.
+// V = valid positions. A hit closes a gap iff the nearest lower VALID position (looking through invalid ones, and
+// through the word boundary via the carry) is a miss. Those hits are found bit-parallel with an add that ripples a
+// "previous valid is a miss" bit through each run of invalid positions; the loop then runs once per closed gap
+// (typically 0-2 per word), adding interior gaps to var / inner (GetVariants.java:228-238).
+KCFX_HD void gap_close_scalar(uint64_t V, uint64_t H, uint64_t M, const GapCarry& c, int32_t k, int32_t& var_in,
+                              int32_t& inner_in) {
+    const uint64_t T = ~V;
+    const uint64_t B = (M << 1) | (c.cg > 0 ? 1ull : 0ull);
+    const uint64_t S = (B & V) | (((B & T) + T) & V);
+    uint64_t E = H & S;
+    uint64_t prev = 0;            // positions up to and including the previous gap-closing hit
+    bool use_carry = true;
+    while (E) {
+        const int e = __builtin_ctzll(E);
+        const uint64_t below = (1ull << e) - 1;
+        const int32_t g = __builtin_popcountll(M & below & ~prev) + (use_carry ? c.cg : 0);
+        const bool interior = c.cany || (H & below) != 0;
+        if (interior && g > 0) {
+            var_in += 1;
+            inner_in += gap_distance(k, g);
+        }
+        prev = below | (1ull << e);
+        use_carry = false;
+        E &= E - 1;
+    }
 }
 
 // advance the carry past the word

@@ -11,24 +11,36 @@
 namespace kcfx {
 
 // ----------------------------------------------------------------------------------------------------
-// HBM table: open addressing at 64-byte line granularity (one line = one memory transaction per probe).
+// HBM table: open addressing at 128-byte line granularity. Measured on MI355X (profiles/r01_membench*.log):
+// a random access costs the same for 16..128 contiguous bytes (~50 G lines/s at any footprint) provided ONE
+// wave instruction fetches the whole line (8 lanes x 16 B); per-lane multi-load probing collapses to ~19 G/s
+// once the table exceeds ~3 GiB. So a line is 128 B and is always fetched cooperatively.
 //
-//   LAYOUT_U16 (counter_size <= 2): 6 x u64 key | 6 x u16 count | u32 meta      = 48 + 12 + 4
-//   LAYOUT_U32 (counter_size 3, 4): 5 x u64 key | 5 x u32 count | u32 meta      = 40 + 20 + 4
-//   meta: bits 0..7 = occupied slots, bit 8 = overflow (some key whose home is this line or earlier was
-//   pushed to the next line) => a probe that does not find its key continues with the next line iff bit 8.
+//   LAYOUT_U16 (counter_size <= 2): 12 x u64 key | 12 x u16 count | u32 meta | u32 pad   = 96 + 24 + 4 + 4
+//   LAYOUT_U32 (counter_size 3, 4): 10 x u64 key | 10 x u32 count | u32 meta | u32 pad   = 80 + 40 + 4 + 4
+//   meta (dword 30): bits 0..7 = occupied slots, bit 8 = overflow (some key whose home is this line or an
+//   earlier one was pushed to the next line) => a probe that misses continues with the next line iff bit 8.
 //
-// A key's home line is umulhi(hash32(key), n_lines).  Keys are the reference's left-aligned k-mer words.
+// Home line of a key (k-mer word):
+//   MODE_KEYHASH   : umulhi(hash32(key), n_lines)                      -- every k-mer probes its own line
+//   MODE_MINIMIZER : umulhi(remix32(minimizer(key)), n_lines)          -- minimizer = min over the k-M+1 M-mers of
+//                    hash32(canonical M-mer): strand-symmetric, and consecutive reference k-mers share it in runs of
+//                    ~(k-M+2)/2, so ONE line fetch serves a whole run of k-mers.
+// Exactness never depends on the home function: the full 64-bit key is compared.
 // ----------------------------------------------------------------------------------------------------
-constexpr int LINE_BYTES = 64;
-constexpr int SLOTS_U16 = 6;
-constexpr int SLOTS_U32 = 5;
+constexpr int LINE_BYTES = 128;
+constexpr int SLOTS_U16 = 12;
+constexpr int SLOTS_U32 = 10;
+constexpr int META_DWORD = 30;
 constexpr uint32_t META_OVERFLOW = 0x100u;
+constexpr int MODE_KEYHASH = 0, MODE_MINIMIZER = 1;
 
 struct TableView {
     const uint8_t* lines;
     uint32_t n_lines;
     int32_t wide;        // 0: LAYOUT_U16, 1: LAYOUT_U32
+    int32_t mode;        // MODE_KEYHASH / MODE_MINIMIZER
+    int32_t mm_len;      // M (minimizer length, <= min(k, 32)); unused in MODE_KEYHASH
 };
 
 // ----------------------------------------------------------------------------------------------------
@@ -36,8 +48,7 @@ struct TableView {
 // workgroup screens one tile and emits one TileSummary; finalize_windows folds a window's tiles in order.
 // ----------------------------------------------------------------------------------------------------
 constexpr int BLOCK = 256;            // 4 wavefronts
-constexpr int TILE_K = 4096;          // k-mer start positions per tile (multiple of 64)
-constexpr int TILE_MAX_BASES = TILE_K + 32 + 32;  // + (k-1) + alignment slack
+constexpr int TILE_K = 2048;          // k-mer start positions per tile (multiple of 64)
 
 struct TileDesc {
     int64_t text_off;    // offset of the tile's first base in the padded device text
@@ -139,16 +150,16 @@ int32_t hip_fail(hipError_t e, const char* what);
 
 // ---- kernel launchers (kcfx_kernels.hip) ------------------------------------------------------------
 // table build
-hipError_t launch_table_clear(uint8_t* lines, uint32_t n_lines, hipStream_t st);
+hipError_t launch_table_clear(uint8_t* lines, uint32_t n_lines, int32_t wide, hipStream_t st);
 hipError_t launch_decode_records(const uint8_t* records, int64_t first_record, int64_t n, int32_t record_size,
                                  int32_t suffix_bytes, int32_t counter_size, int32_t lut_prefix_length,
                                  const uint64_t* lut, int64_t lut_entries, uint64_t* keys_out, uint32_t* counts_out,
                                  hipStream_t st);
-hipError_t launch_table_insert(uint8_t* lines, uint32_t n_lines, int32_t wide, const uint64_t* keys,
+hipError_t launch_table_insert(uint8_t* lines, TableView tv, int32_t k, const uint64_t* keys,
                                const uint32_t* counts, int64_t n, hipStream_t st);
 hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide, hipStream_t st);
 // lookup
-hipError_t launch_lookup(TableView tv, const uint64_t* keys, int64_t n, int32_t* counts_out, hipStream_t st);
+hipError_t launch_lookup(TableView tv, int32_t k, const uint64_t* keys, int64_t n, int32_t* counts_out, hipStream_t st);
 // screen
 hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32_t n_tiles, TableView tv, int32_t k,
                                int32_t both_strands, int32_t min_count, TileSummary* out, hipStream_t st);

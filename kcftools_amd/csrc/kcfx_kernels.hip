@@ -4,8 +4,8 @@
 //   decode_records   : KMC .kmc_suf records + LUT -> (k-mer word, count)         (load time; KMC.java:427-450)
 //   lookup           : batched KMC.getCount                                      (KMC.java:292-326)
 //   screen_tiles     : THE hot kernel. ASCII window text -> 2-bit pack in LDS -> per-lane canonical k-mer ->
-//                      one 64-byte line probe -> wave ballots -> gap monoid      (GetVariants.java:202-252,
-//                                                                                 Fasta.java:90-167, Kmer.java)
+//                      minimizer runs -> cooperative 128-byte line fetches -> wave ballots -> gap monoid
+//                                                     (GetVariants.java:202-252, Fasta.java:90-167, Kmer.java)
 //   finalize_windows : fold a window's tile summaries -> kcfx_result             (GetVariants.java:254-258)
 //
 // Integer / index work, HBM-bound: no MFMA. Lane <-> consecutive k-mer start positions, so one __ballot is a
@@ -19,16 +19,20 @@ namespace kcfx {
 // ======================================================================================================
 // table build
 // ======================================================================================================
-__global__ void table_clear_kernel(uint4* lines, uint64_t n_vec) {
+// every key slot = EMPTY_KEY (all ones), counts / meta = 0
+__global__ void table_clear_kernel(uint4* lines, uint64_t n_vec, int32_t key_pieces) {
     uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (; i < n_vec; i += stride) lines[i] = make_uint4(0, 0, 0, 0);
+    for (; i < n_vec; i += stride) {
+        const uint32_t v = ((int32_t)(i & 7) < key_pieces) ? 0xFFFFFFFFu : 0u;
+        lines[i] = make_uint4(v, v, v, v);
+    }
 }
 
-// During the build the meta word (byte 60) is a plain arrival counter; table_finalize turns it into
+// During the build the meta dword is a plain arrival counter; table_finalize turns it into
 // {occupied slots, overflow flag}.
 template <bool WIDE>
-__global__ void table_insert_kernel(uint8_t* lines, uint32_t n_lines, const uint64_t* __restrict__ keys,
+__global__ void table_insert_kernel(uint8_t* lines, TableView tv, int32_t k, const uint64_t* __restrict__ keys,
                                     const uint32_t* __restrict__ counts, int64_t n) {
     constexpr uint32_t S = WIDE ? SLOTS_U32 : SLOTS_U16;
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -36,19 +40,19 @@ __global__ void table_insert_kernel(uint8_t* lines, uint32_t n_lines, const uint
     for (; i < n; i += stride) {
         const uint64_t key = keys[i];
         const uint32_t c = counts[i];
-        uint32_t line = home_line(key, n_lines);
+        uint32_t line = home_line(tv, key, k);
         for (;;) {
             uint8_t* base = lines + (size_t)line * LINE_BYTES;
-            const uint32_t slot = atomicAdd(reinterpret_cast<uint32_t*>(base + 60), 1u);
+            const uint32_t slot = atomicAdd(reinterpret_cast<uint32_t*>(base) + META_DWORD, 1u);
             if (slot < S) {
                 reinterpret_cast<uint64_t*>(base)[slot] = key;
                 if (WIDE)
-                    reinterpret_cast<uint32_t*>(base + 40)[slot] = c;
+                    reinterpret_cast<uint32_t*>(base + 8 * SLOTS_U32)[slot] = c;
                 else
-                    reinterpret_cast<uint16_t*>(base + 48)[slot] = (uint16_t)c;
+                    reinterpret_cast<uint16_t*>(base + 8 * SLOTS_U16)[slot] = (uint16_t)c;
                 break;
             }
-            line = (line + 1 == n_lines) ? 0 : line + 1;
+            line = (line + 1 == tv.n_lines) ? 0 : line + 1;
         }
     }
 }
@@ -59,7 +63,7 @@ __global__ void table_finalize_kernel(uint8_t* lines, uint32_t n_lines) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t stride = gridDim.x * blockDim.x;
     for (; i < n_lines; i += stride) {
-        uint32_t* meta = reinterpret_cast<uint32_t*>(lines + (size_t)i * LINE_BYTES + 60);
+        uint32_t* meta = reinterpret_cast<uint32_t*>(lines + (size_t)i * LINE_BYTES) + META_DWORD;
         const uint32_t arrivals = *meta;
         *meta = (arrivals > S) ? (S | META_OVERFLOW) : arrivals;
     }
@@ -96,61 +100,40 @@ __global__ void decode_records_kernel(const uint8_t* __restrict__ records, int64
 }
 
 // ======================================================================================================
-// probe: one 64-byte line per step; a miss continues to the next line only while the overflow bit is set
+// lookup (batched KMC.getCount; not the hot path): 8 consecutive lanes share one key and fetch its line together
 // ======================================================================================================
-template <bool WIDE, bool SINGLE_ROUND = false>
-__device__ __forceinline__ bool probe(const TableView& tv, uint64_t key, int32_t& count) {
-    uint32_t line = home_line(key, tv.n_lines);
-    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
-    for (;;) {
-        const uint4* p = reinterpret_cast<const uint4*>(tv.lines + (size_t)line * LINE_BYTES);
-        const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-        // pin the count dwords here: without it LLVM sinks their load below the key compares, i.e. into a second,
-        // dependent memory round trip per probe
-        asm volatile("" ::"v"(q3.x), "v"(q3.y), "v"(q3.z), "v"(q3.w));
-        const uint32_t meta = q3.w;
-        const uint32_t ns = meta & 0xFFu;
-        // Branch-free match: every loaded dword is consumed unconditionally, so the compiler keeps the four 16-byte
-        // loads of the line together in ONE memory round trip (with ?: chains it sinks the count loads into a
-        // second, dependent access after the key compares).
-        uint32_t c;
-        uint32_t any;
-#define KCFX_EQ(lo, hi, i) (((((lo) ^ klo) | ((hi) ^ khi)) == 0u && ns > (i)) ? 0xFFFFFFFFu : 0u)
-        if (!WIDE) {
-            const uint32_t e0 = KCFX_EQ(q0.x, q0.y, 0), e1 = KCFX_EQ(q0.z, q0.w, 1), e2 = KCFX_EQ(q1.x, q1.y, 2);
-            const uint32_t e3 = KCFX_EQ(q1.z, q1.w, 3), e4 = KCFX_EQ(q2.x, q2.y, 4), e5 = KCFX_EQ(q2.z, q2.w, 5);
-            any = e0 | e1 | e2 | e3 | e4 | e5;
-            c = (q3.x & ((e0 & 0xFFFFu) | (e1 & 0xFFFF0000u))) | (q3.y & ((e2 & 0xFFFFu) | (e3 & 0xFFFF0000u))) |
-                (q3.z & ((e4 & 0xFFFFu) | (e5 & 0xFFFF0000u)));
-            c = (c & 0xFFFFu) | (c >> 16);
-        } else {
-            const uint32_t e0 = KCFX_EQ(q0.x, q0.y, 0), e1 = KCFX_EQ(q0.z, q0.w, 1), e2 = KCFX_EQ(q1.x, q1.y, 2);
-            const uint32_t e3 = KCFX_EQ(q1.z, q1.w, 3), e4 = KCFX_EQ(q2.x, q2.y, 4);
-            any = e0 | e1 | e2 | e3 | e4;
-            c = (q2.z & e0) | (q2.w & e1) | (q3.x & e2) | (q3.y & e3) | (q3.z & e4);
-        }
-#undef KCFX_EQ
-        const bool found = any != 0u;
-        if (found) {
-            count = (int32_t)c;           // Java int (KMC.java:395-401)
-            return true;
-        }
-        if (SINGLE_ROUND || !(meta & META_OVERFLOW)) {
-            count = 0;
-            return false;
-        }
-        line = (line + 1 == tv.n_lines) ? 0 : line + 1;
-    }
-}
-
 template <bool WIDE>
-__global__ void lookup_kernel(TableView tv, const uint64_t* __restrict__ keys, int64_t n, int32_t* __restrict__ out) {
-    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
-        int32_t c;
-        probe<WIDE>(tv, keys[i], c);
-        out[i] = c;
+__global__ __launch_bounds__(256) void lookup_kernel(TableView tv, int32_t k, const uint64_t* __restrict__ keys,
+                                                     int64_t n, int32_t* __restrict__ out) {
+    const int64_t gtid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 3;
+    const int piece = threadIdx.x & 7;
+    const int lane = threadIdx.x & 63;
+    for (int64_t i = gtid >> 3; i < n; i += stride) {     // (gtid >> 3) is uniform over each group of 8 lanes
+        const uint64_t key = keys[i];
+        uint32_t line = home_line(tv, key, k);
+        int32_t result = 0;
+        for (;;) {
+            const uint4 mine = reinterpret_cast<const uint4*>(tv.lines + (size_t)line * LINE_BYTES)[piece];
+            uint4 q[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int src = (lane & ~7) | s;
+                q[s].x = __shfl(mine.x, src, 64);
+                q[s].y = __shfl(mine.y, src, 64);
+                q[s].z = __shfl(mine.z, src, 64);
+                q[s].w = __shfl(mine.w, src, 64);
+            }
+            uint32_t c, meta;
+            const bool any = match_line<WIDE, true>(q, key, c, meta);
+            if (any) {
+                result = (int32_t)c;        // Java int (KMC.java:395-401)
+                break;
+            }
+            if (!(meta & META_OVERFLOW)) break;
+            line = (line + 1 == tv.n_lines) ? 0 : line + 1;
+        }
+        if (piece == 0) out[i] = result;
     }
 }
 
@@ -158,6 +141,8 @@ __global__ void lookup_kernel(TableView tv, const uint64_t* __restrict__ keys, i
 // screen_tiles
 // ======================================================================================================
 constexpr int MAX_CHUNKS = (31 + TILE_K + 31 + 31) / 32 + 1;   // 32-base chunks a tile can span
+constexpr int RUN_CHUNK = 16;                                  // line buffers per wave (2 load instructions)
+constexpr int WAVES = BLOCK / 64;
 
 __device__ __forceinline__ int32_t wave_sum_i32(int32_t v) {
 #pragma unroll
@@ -170,19 +155,36 @@ __device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
     return v;
 }
 
+// wave-private LDS hand-off: LDS operations of one wave execute in order, so only the compiler has to be kept
+// from moving accesses across this point
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // VAR != 0 only exists in the experiments build (-DKCFX_EXPERIMENTS, libkcfx_exp.so): timing ablations whose
-// results are deliberately wrong. 1: single probe round (ignore overflow)  2: no gap accounting
-// 3: no table probe  4: no k-mer extraction (synthetic keys)
-template <bool WIDE, int VAR>
+// results are deliberately wrong. 2: no gap accounting  3: no table probe
+//
+// KT = 31: k = 31 and M = 16 are compile-time constants (the BASELINE.json configuration); KT = 0: any k <= 32 / M.
+template <bool WIDE, int MODE, int KT, int VAR>
 __global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __restrict__ text,
                                                              const TileDesc* __restrict__ tiles, TableView tv,
-                                                             int32_t k, int32_t both_strands, int32_t min_count,
+                                                             int32_t k_rt, int32_t both_strands, int32_t min_count,
                                                              TileSummary* __restrict__ out) {
+    constexpr bool MINI = (MODE == MODE_MINIMIZER);
+    constexpr int HLEN = MINI ? TILE_K + 64 : 1;
     __shared__ uint32_t s_fw[2 * (MAX_CHUNKS + 2)];
     __shared__ uint32_t s_cw[2 * (MAX_CHUNKS + 2)];
     __shared__ uint32_t s_vb[MAX_CHUNKS + 2];
-    __shared__ TileSummary s_sum[BLOCK / 64];
+    __shared__ uint32_t s_ha[HLEN];                        // sliding-minimum ping
+    __shared__ __attribute__((aligned(16))) uint32_t s_hb[MINI ? HLEN : WAVES * RUN_CHUNK * 32];   // pong, then line buffers
+    __shared__ uint32_t s_runline[WAVES][64];              // line index of each run, per wave
+    __shared__ TileSummary s_sum[WAVES];
+    static_assert(HLEN == 1 || HLEN * 4 >= WAVES * RUN_CHUNK * 128, "line buffers alias the dead pong array");
 
+    const int k = KT ? KT : k_rt;
+    const int M = KT ? 16 : tv.mm_len;
+    const int wlen = k - M + 1;                            // M-mers per k-mer
     const TileDesc td = tiles[blockIdx.x];
     const int tid = threadIdx.x;
 
@@ -207,50 +209,127 @@ __global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __re
     }
     __syncthreads();
 
+    // ---- phase 1b (minimizer mode): h[p] = hash of the canonical M-mer at p, then a log-step sliding minimum:
+    //      after the steps F[p] = min h[p .. p+p2-1] (p2 = largest power of two <= wlen); a k-mer's minimizer is
+    //      min(F[j], F[j + wlen - p2]) -- two LDS reads in the main loop instead of wlen ------------------------
+    const uint32_t* s_fin = s_ha;                          // final sliding-minimum array
+    uint4* s_line = reinterpret_cast<uint4*>(s_hb);        // [WAVES][RUN_CHUNK][8] fetched lines
+    int p2 = 1;
+    if (MINI) {
+        const int n_m = td.n_kmers + wlen - 1;             // every M-mer of every k-mer of the tile
+        for (int p = tid; p < n_m; p += BLOCK) {
+            uint64_t f, r;
+            extract_pair(s_fw, s_cw, off + p, M, f, r);
+            s_ha[p] = mmer_hash(f, r);
+        }
+        __syncthreads();
+        uint32_t* src = s_ha;
+        uint32_t* dst = s_hb;
+        while (p2 * 2 <= wlen) {
+            for (int p = tid; p < n_m; p += BLOCK) dst[p] = min(src[p], src[min(p + p2, n_m - 1)]);
+            __syncthreads();
+            uint32_t* t = src;
+            src = dst;
+            dst = t;
+            p2 *= 2;
+        }
+        s_fin = src;
+        s_line = reinterpret_cast<uint4*>(dst);            // the other array is dead now
+    }
+
     // ---- phase 2: each wave walks a contiguous range of 64-position words ------------------------------
     const int lane = tid & 63, wave = tid >> 6;
     const int n_words = (td.n_kmers + 63) >> 6;
-    const int wpw = (n_words + (BLOCK / 64) - 1) / (BLOCK / 64);
+    const int wpw = (n_words + WAVES - 1) / WAVES;
     const int w_begin = min(wave * wpw, n_words);
     const int w_end = min(w_begin + wpw, n_words);
+    const uint64_t lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1);   // bits 0..lane
+    uint4* my_lines = s_line + wave * (RUN_CHUNK * 8);
 
     GapCarry carry;
     carry.cg = 0;
     carry.lead = 0;
     carry.cany = false;
-    int32_t n_valid = 0, obs = 0, runs = 0;
+    int32_t n_valid = 0, obs = 0, runs = 0, var_in = 0, inner_in = 0;     // wave-uniform
     uint32_t prev_valid = 0, first_valid = 0;
     uint64_t last_V = 0;
-    int32_t var_acc = 0, inner_acc = 0;
-    int64_t sum_acc = 0;
+    int64_t sum_acc = 0;                                                     // per lane
 
     for (int w = w_begin; w < w_end; ++w) {
         const int j = w * 64 + lane;
+        const int jc = min(j, td.n_kmers - 1);
         uint64_t fwd, rc;
-        bool valid;
-        if (VAR == 4) {
-            fwd = (uint64_t)hash32((uint64_t)(blockIdx.x * 4096u + j)) << 32 | hash32((uint64_t)j * 77u + blockIdx.x);
-            rc = ~fwd;
-            valid = true;
-        } else {
-            valid = extract_kmer(s_fw, s_cw, s_vb, off + min(j, td.n_kmers - 1), k, fwd, rc);
-        }
+        bool valid = extract_kmer(s_fw, s_cw, s_vb, off + jc, k, fwd, rc);
         valid = valid && (j < td.n_kmers);
         // Kmer(Kmer, bothStrands): canonical = min(fwd, revcomp) unsigned (Kmer.java:72-79,406-414)
         const uint64_t key = (both_strands && rc < fwd) ? rc : fwd;
+
+        // home line: shared by the whole minimizer run this k-mer belongs to
+        uint32_t tgt;
+        if (MINI) {
+            const uint32_t mz = min(s_fin[jc], s_fin[jc + wlen - p2]);
+            tgt = mulhi32(remix32(mz), tv.n_lines);
+        } else {
+            tgt = mulhi32(hash32(key), tv.n_lines);
+        }
+
         int32_t cnt = 0;
         bool found = false;
+        bool pending = valid;
         if (VAR == 3) {
-            cnt = (int32_t)(key >> 60);
+            cnt = (int32_t)(key >> 60) + (int32_t)(tgt & 1);
             found = (key & 0x300) != 0;
-        } else if (valid) {
-            found = probe<WIDE, VAR == 1>(tv, key, cnt);
+            pending = false;
+        }
+        // ---- cooperative probe rounds: each round fetches, for every run of adjacent pending lanes with the same
+        //      target line, that line ONCE (8 lanes x 16 B = one 128-byte request) into wave-private LDS -------------
+        for (;;) {
+            const uint64_t P = __ballot(pending);
+            if (!P) break;
+            const uint32_t prev_tgt = __shfl_up(tgt, 1, 64);
+            const bool prev_pending = lane > 0 && ((P >> (lane - 1)) & 1);
+            const bool head = pending && (!prev_pending || prev_tgt != tgt);
+            const uint64_t HM = __ballot(head);
+            const int nruns = __popcll(HM);
+            const int my_run = __popcll(HM & lane_le) - 1;
+            if (head) s_runline[wave][my_run] = tgt;
+            wave_lds_fence();
+            for (int c0 = 0; c0 < nruns; c0 += RUN_CHUNK) {
+                const int r0 = c0 + (lane >> 3), r1 = r0 + 8;
+                const int piece = lane & 7;
+                uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
+                if (r0 < nruns)
+                    a = reinterpret_cast<const uint4*>(tv.lines + (size_t)s_runline[wave][r0] * LINE_BYTES)[piece];
+                if (r1 < nruns)
+                    b = reinterpret_cast<const uint4*>(tv.lines + (size_t)s_runline[wave][r1] * LINE_BYTES)[piece];
+                my_lines[(lane >> 3) * 8 + piece] = a;
+                my_lines[(8 + (lane >> 3)) * 8 + piece] = b;
+                wave_lds_fence();
+                if (pending && my_run >= c0 && my_run < c0 + RUN_CHUNK) {
+                    uint4 q[8];
+                    const uint4* src = my_lines + (my_run - c0) * 8;
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) q[s] = src[s];
+                    uint32_t c, meta;
+                    const bool any = match_line<WIDE, KT == 0>(q, key, c, meta);
+                    if (any) {
+                        found = true;
+                        cnt = (int32_t)c;                   // Java int (KMC.java:395-401)
+                        pending = false;
+                    } else if (!(meta & META_OVERFLOW)) {
+                        pending = false;
+                    } else {
+                        tgt = (tgt + 1 == tv.n_lines) ? 0 : tgt + 1;
+                    }
+                }
+                wave_lds_fence();
+            }
         }
         const bool hit = found && (cnt >= min_count);            // GetVariants.java:224
 
         const uint64_t V = __ballot(valid);
         const uint64_t H = __ballot(hit);
-        const uint64_t M = V & ~H;
+        const uint64_t Mm = V & ~H;
         n_valid += __popcll(V);
         obs += __popcll(H);
         if (hit) sum_acc += (int64_t)cnt;                          // GetVariants.java:226
@@ -261,30 +340,12 @@ __global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __re
         prev_valid = (uint32_t)(V >> 63);
         last_V = V;
 
-        // gap accounting (GetVariants.java:228-244)
-        if (VAR == 2) {
-            var_acc += (int32_t)(M >> lane) & 1;
-        } else if (H) {
-            if (M) {
-                if (hit) {
-                    const int32_t g = gap_closed_by(H, M, lane, carry);
-                    if (g > 0) {
-                        var_acc += 1;
-                        inner_acc += gap_distance(k, g);
-                    }
-                }
-            } else if (carry.cany && carry.cg > 0 && lane == 0) {
-                // every valid position of this word hit: only its first hit can close a (carried) gap
-                var_acc += 1;
-                inner_acc += gap_distance(k, carry.cg);
-            }
-        }
-        gap_advance(H, M, carry);
+        // gap accounting (GetVariants.java:228-244), on the scalar unit
+        if (VAR != 2) gap_close_scalar(V, H, Mm, carry, k, var_in, inner_in);
+        gap_advance(H, Mm, carry);
     }
 
     // ---- wave summary --------------------------------------------------------------------------------
-    const int32_t var_in = wave_sum_i32(var_acc);
-    const int32_t inner_in = wave_sum_i32(inner_acc);
     const int64_t count_sum = wave_sum_i64(sum_acc);
     if (lane == 0) {
         TileSummary s;
@@ -309,7 +370,7 @@ __global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __re
     if (tid == 0) {
         TileSummary acc = s_sum[0];
 #pragma unroll
-        for (int i = 1; i < BLOCK / 64; ++i) acc = summary_combine(acc, s_sum[i], k);
+        for (int i = 1; i < WAVES; ++i) acc = summary_combine(acc, s_sum[i], k);
         out[blockIdx.x] = acc;
     }
 }
@@ -337,10 +398,10 @@ static inline int grid_for(int64_t n, int block, int cap = 256 * 8) {
     return (int)g;
 }
 
-hipError_t launch_table_clear(uint8_t* lines, uint32_t n_lines, hipStream_t st) {
+hipError_t launch_table_clear(uint8_t* lines, uint32_t n_lines, int32_t wide, hipStream_t st) {
     const uint64_t n_vec = (uint64_t)n_lines * (LINE_BYTES / 16);
     hipLaunchKernelGGL(table_clear_kernel, dim3(grid_for((int64_t)n_vec, 256)), dim3(256), 0, st,
-                       reinterpret_cast<uint4*>(lines), n_vec);
+                       reinterpret_cast<uint4*>(lines), n_vec, wide ? SLOTS_U32 / 2 : SLOTS_U16 / 2);
     return hipGetLastError();
 }
 
@@ -355,14 +416,14 @@ hipError_t launch_decode_records(const uint8_t* records, int64_t first_record, i
     return hipGetLastError();
 }
 
-hipError_t launch_table_insert(uint8_t* lines, uint32_t n_lines, int32_t wide, const uint64_t* keys,
-                               const uint32_t* counts, int64_t n, hipStream_t st) {
+hipError_t launch_table_insert(uint8_t* lines, TableView tv, int32_t k, const uint64_t* keys, const uint32_t* counts,
+                               int64_t n, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     const dim3 g(grid_for(n, 256, 256 * 16)), b(256);
-    if (wide)
-        hipLaunchKernelGGL(table_insert_kernel<true>, g, b, 0, st, lines, n_lines, keys, counts, n);
+    if (tv.wide)
+        hipLaunchKernelGGL(table_insert_kernel<true>, g, b, 0, st, lines, tv, k, keys, counts, n);
     else
-        hipLaunchKernelGGL(table_insert_kernel<false>, g, b, 0, st, lines, n_lines, keys, counts, n);
+        hipLaunchKernelGGL(table_insert_kernel<false>, g, b, 0, st, lines, tv, k, keys, counts, n);
     return hipGetLastError();
 }
 
@@ -375,13 +436,13 @@ hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide,
     return hipGetLastError();
 }
 
-hipError_t launch_lookup(TableView tv, const uint64_t* keys, int64_t n, int32_t* counts_out, hipStream_t st) {
+hipError_t launch_lookup(TableView tv, int32_t k, const uint64_t* keys, int64_t n, int32_t* counts_out, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    const dim3 g(grid_for(n, 256, 256 * 16)), b(256);
+    const dim3 g(grid_for(n * 8, 256, 256 * 16)), b(256);
     if (tv.wide)
-        hipLaunchKernelGGL(lookup_kernel<true>, g, b, 0, st, tv, keys, n, counts_out);
+        hipLaunchKernelGGL(lookup_kernel<true>, g, b, 0, st, tv, k, keys, n, counts_out);
     else
-        hipLaunchKernelGGL(lookup_kernel<false>, g, b, 0, st, tv, keys, n, counts_out);
+        hipLaunchKernelGGL(lookup_kernel<false>, g, b, 0, st, tv, k, keys, n, counts_out);
     return hipGetLastError();
 }
 
@@ -389,16 +450,24 @@ hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32
                                int32_t both_strands, int32_t min_count, TileSummary* out, hipStream_t st) {
     if (n_tiles <= 0) return hipSuccess;
     const dim3 g(n_tiles), b(BLOCK);
+#define KCFX_LAUNCH(W, MD, KT, V) \
+    hipLaunchKernelGGL((screen_tiles_kernel<W, MD, KT, V>), g, b, 0, st, text, tiles, tv, k, both_strands, min_count, out)
+    const bool spec = (k == 31) && (tv.mode == MODE_KEYHASH || tv.mm_len == 16);   // compile-time k / M
 #ifdef KCFX_EXPERIMENTS
     static const int var = getenv("KCFX_VARIANT") ? atoi(getenv("KCFX_VARIANT")) : 0;
-#define KCFX_VARIANT_CASE(V) \
-    if (var == V) { hipLaunchKernelGGL((screen_tiles_kernel<false, V>), g, b, 0, st, text, tiles, tv, k, both_strands, min_count, out); return hipGetLastError(); }
-    if (!tv.wide) { KCFX_VARIANT_CASE(1) KCFX_VARIANT_CASE(2) KCFX_VARIANT_CASE(3) KCFX_VARIANT_CASE(4) }
+    if (!tv.wide && spec && tv.mode == MODE_MINIMIZER && var == 2) { KCFX_LAUNCH(false, MODE_MINIMIZER, 31, 2); return hipGetLastError(); }
+    if (!tv.wide && spec && tv.mode == MODE_MINIMIZER && var == 3) { KCFX_LAUNCH(false, MODE_MINIMIZER, 31, 3); return hipGetLastError(); }
+    if (!tv.wide && spec && tv.mode == MODE_KEYHASH && var == 3) { KCFX_LAUNCH(false, MODE_KEYHASH, 31, 3); return hipGetLastError(); }
+    if (!tv.wide && tv.mode == MODE_MINIMIZER && var == 10) { KCFX_LAUNCH(false, MODE_MINIMIZER, 0, 0); return hipGetLastError(); }
 #endif
-    if (tv.wide)
-        hipLaunchKernelGGL((screen_tiles_kernel<true, 0>), g, b, 0, st, text, tiles, tv, k, both_strands, min_count, out);
-    else
-        hipLaunchKernelGGL((screen_tiles_kernel<false, 0>), g, b, 0, st, text, tiles, tv, k, both_strands, min_count, out);
+    if (tv.mode == MODE_MINIMIZER) {
+        if (spec) { if (tv.wide) KCFX_LAUNCH(true, MODE_MINIMIZER, 31, 0); else KCFX_LAUNCH(false, MODE_MINIMIZER, 31, 0); }
+        else      { if (tv.wide) KCFX_LAUNCH(true, MODE_MINIMIZER, 0, 0); else KCFX_LAUNCH(false, MODE_MINIMIZER, 0, 0); }
+    } else {
+        if (spec) { if (tv.wide) KCFX_LAUNCH(true, MODE_KEYHASH, 31, 0); else KCFX_LAUNCH(false, MODE_KEYHASH, 31, 0); }
+        else      { if (tv.wide) KCFX_LAUNCH(true, MODE_KEYHASH, 0, 0); else KCFX_LAUNCH(false, MODE_KEYHASH, 0, 0); }
+    }
+#undef KCFX_LAUNCH
     return hipGetLastError();
 }
 

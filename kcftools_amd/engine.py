@@ -35,7 +35,8 @@ class DbInfo(C.Structure):
                                           "signature_length", "min_count", "max_count", "both_strands",
                                           "version", "n_bins")] + \
                [("total_kmers", C.c_int64), ("table_bytes", C.c_int64), ("table_lines", C.c_int64),
-                ("slots_per_line", C.c_int32), ("device", C.c_int32), ("load_seconds", C.c_double)]
+                ("slots_per_line", C.c_int32), ("device", C.c_int32), ("load_seconds", C.c_double),
+                ("table_mode", C.c_int32), ("minimizer_length", C.c_int32)]
 
 
 class KcfxError(RuntimeError):

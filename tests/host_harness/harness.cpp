@@ -96,21 +96,9 @@ int harness_screen_tile(const uint8_t* text, int64_t text_off, int n_kmers, int 
             if (w == w_begin) first_valid = (uint32_t)(V & 1);
             prev_valid = (uint32_t)(V >> 63);
             last_V = V;
-            for (int lane = 0; lane < 64; ++lane) {
-                const bool hit = (H >> lane) & 1;
-                if (hit) sum += cnt[lane];
-                if (H) {
-                    if (M) {
-                        if (hit) {
-                            const int32_t g = gap_closed_by(H, M, lane, carry);
-                            if (g > 0) { var_in += 1; inner_in += gap_distance(k, g); }
-                        }
-                    } else if (carry.cany && carry.cg > 0 && lane == 0) {
-                        var_in += 1;
-                        inner_in += gap_distance(k, carry.cg);
-                    }
-                }
-            }
+            for (int lane = 0; lane < 64; ++lane)
+                if ((H >> lane) & 1) sum += cnt[lane];
+            gap_close_scalar(V, H, M, carry, k, var_in, inner_in);
             gap_advance(H, M, carry);
         }
         TileSummary s;
@@ -141,6 +129,50 @@ void harness_finalize(const TileSummary* s, int k, kcfx_result* out) {
     *out = summary_finalize(t, k);
 }
 uint32_t harness_hash32(uint64_t key) { return hash32(key); }
+
+// both formulations of the per-word gap accounting on the same masks: lane-parallel (gap_closed_by) and the
+// scalar loop the kernel uses (gap_close_scalar). out[0..1] = var, inner of the former; out[2..3] of the latter.
+void harness_gap_both(uint64_t V, uint64_t H, int cg, int cany, int k, int32_t* out) {
+    const uint64_t M = V & ~H;
+    GapCarry c{cg, 0, cany != 0};
+    int32_t v1 = 0, i1 = 0, v2 = 0, i2 = 0;
+    for (int lane = 0; lane < 64; ++lane) {
+        if (!((H >> lane) & 1)) continue;
+        if (M) {
+            const int32_t g = gap_closed_by(H, M, lane, c);
+            if (g > 0) { v1 += 1; i1 += gap_distance(k, g); }
+        } else if (c.cany && c.cg > 0 && lane == __builtin_ctzll(H)) {
+            v1 += 1; i1 += gap_distance(k, c.cg);
+        }
+    }
+    gap_close_scalar(V, H, M, c, k, v2, i2);
+    out[0] = v1; out[1] = i1; out[2] = v2; out[3] = i2;
+}
+
+// minimizer consistency: query side (hash of the canonical M-mer per text position, min over the k-mer's window -- what
+// screen_tiles_kernel does with s_h) versus build side (minimizer_of_kmer on the stored word, canonical or forward)
+int harness_minimizers(const uint8_t* text, int64_t text_off, int n_kmers, int k, int M, uint32_t* query_side,
+                       uint32_t* build_fwd, uint32_t* build_canon) {
+    Packed P = pack_tile(text, text_off, n_kmers, k);
+    const int wlen = k - M + 1;
+    std::vector<uint32_t> h(n_kmers + wlen);
+    for (int p = 0; p < n_kmers + wlen - 1; ++p) {
+        uint64_t f, r;
+        extract_pair(P.fw.data(), P.cw.data(), P.off + p, M, f, r);
+        h[p] = mmer_hash(f, r);
+    }
+    for (int j = 0; j < n_kmers; ++j) {
+        uint32_t mz = h[j];
+        for (int t = 1; t < wlen; ++t) mz = std::min(mz, h[j + t]);
+        query_side[j] = mz;
+        uint64_t f, r;
+        extract_pair(P.fw.data(), P.cw.data(), P.off + j, k, f, r);
+        build_fwd[j] = minimizer_of_kmer(f, k, M);
+        build_canon[j] = minimizer_of_kmer(f < r ? f : r, k, M);
+    }
+    return 0;
+}
+uint64_t harness_revcomp_word(uint64_t x, int len) { return revcomp_word(x, len); }
 int harness_tile_k(void) { return TILE_K; }
 
 }

@@ -43,6 +43,10 @@ def harness():
     L.harness_finalize.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.harness_hash32.argtypes = [C.c_uint64]
     L.harness_hash32.restype = C.c_uint32
+    L.harness_minimizers.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.harness_revcomp_word.argtypes = [C.c_uint64, C.c_int]
+    L.harness_revcomp_word.restype = C.c_uint64
+    L.harness_gap_both.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p]
     return L
 
 
@@ -133,9 +137,9 @@ def test_emulated_kernel_matches_oracle(harness, oracle, tmp_path, k, both):
     nk = length - k + 1
     want = db.process_window(ref[begin:begin + length], 1)
     for _ in range(12):
-        pts = sorted(set(int(x) for x in rng.integers(1, nk, size=int(rng.integers(1, 9)))))
+        pts = sorted(set(int(x) for x in rng.integers(1, nk, size=int(rng.integers(6, 14)))))
         edges = [0] + pts + [nk]
-        cuts = [(a, b - a) for a, b in zip(edges[:-1], edges[1:]) if b - a <= 4096]
+        cuts = [(a, b - a) for a, b in zip(edges[:-1], edges[1:]) if b - a <= harness.harness_tile_k()]
         if sum(n for _, n in cuts) != nk:
             continue
         assert emulate_window(harness, buf, begin, length, k, both, count_of, 1, cuts=cuts) == want
@@ -167,3 +171,51 @@ def test_emulated_kernel_extreme_patterns(harness, oracle):
         want["eff_length"] = oracle.lib().kcfo_eff_length(text, len(text), k)
         got = emulate_window(harness, buf, 0, len(text), k, False, count_of, 1)
         assert got == want, name
+
+
+def test_minimizer_build_side_equals_query_side(harness, oracle):
+    """The table is bucketed by minimizer_of_kmer(stored word); screen_tiles derives the bucket from the reference text.
+    They must agree for every valid k-mer, on either strand, or lookups would silently miss."""
+    rng = np.random.default_rng(21)
+    text = bytes(rng.choice(np.frombuffer(b"ACGTacgt", dtype=np.uint8), 3000))
+    text = text[:900] + b"AAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA" + b"ATATATATATATATATATATATATATATATATATATATAT" + text[990:]
+    buf = padded(text)
+    for k, M in ((31, 16), (31, 13), (31, 20), (31, 31), (32, 16), (23, 12), (15, 11), (15, 15), (31, 1)):
+        for begin in (0, 5, 33):
+            n = min(2048, len(text) - begin - k + 1)
+            q = np.zeros(n, dtype=np.uint32)
+            bf = np.zeros(n, dtype=np.uint32)
+            bc = np.zeros(n, dtype=np.uint32)
+            harness.harness_minimizers(buf.ctypes.data, begin, n, k, M, q.ctypes.data, bf.ctypes.data, bc.ctypes.data)
+            assert np.array_equal(q, bf), (k, M, begin)
+            assert np.array_equal(q, bc), (k, M, begin)
+    # consecutive k-mers share their minimizer in runs: mean run length ~ (w + 1) / 2
+    n = 2048
+    q = np.zeros(n, dtype=np.uint32)
+    harness.harness_minimizers(buf.ctypes.data, 1000, n, 31, 16, q.ctypes.data, np.zeros(n, dtype=np.uint32).ctypes.data,
+                               np.zeros(n, dtype=np.uint32).ctypes.data)
+    runs = 1 + int((q[1:] != q[:-1]).sum())
+    assert 6.0 < n / runs < 12.0
+    for w in (0x1B00000000000000, 0xFFFFFFFFFFFFFFFC, 0x123456789ABCDEF0 & ~3):
+        assert harness.harness_revcomp_word(w, 31) == oracle.lib().kcfo_kmer_revcomp(w, 31)
+
+
+def test_scalar_gap_loop_equals_lane_parallel_form(harness):
+    """gap_close_scalar (what the kernel runs on the scalar unit) against the lane-parallel formulation, on random
+    and adversarial ballot masks, with invalid (transparent) positions and carries"""
+    rng = np.random.default_rng(99)
+    out = np.zeros(4, dtype=np.int32)
+    cases = []
+    for _ in range(4000):
+        dens_v, dens_h = rng.choice([0.05, 0.5, 0.9, 1.0]), rng.choice([0.0, 0.1, 0.5, 0.9, 1.0])
+        V = int.from_bytes(np.packbits(rng.random(64) < dens_v).tobytes(), "little")
+        H = int.from_bytes(np.packbits(rng.random(64) < dens_h).tobytes(), "little") & V
+        cases.append((V, H))
+    full = (1 << 64) - 1
+    cases += [(full, 0x5555555555555555), (full, 0xAAAAAAAAAAAAAAAA), (full, full), (full, 0), (0, 0), (full, 1 << 63), (full, 1),
+              (0x8000000000000001, 0x8000000000000001), (0xFFFF0000FFFF0000, 0x8000000080000000)]
+    for V, H in cases:
+        for cg in (0, 1, 29, 30, 31, 100):
+            for cany in (0, 1):
+                harness.harness_gap_both(V, H, cg, cany, 31, out.ctypes.data)
+                assert (out[0], out[1]) == (out[2], out[3]), (hex(V), hex(H), cg, cany)
