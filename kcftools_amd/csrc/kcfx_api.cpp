@@ -140,6 +140,8 @@ struct kcfx_ref {
     TileDesc* d_tiles = nullptr;
     int32_t* d_win_tile0 = nullptr;
     TileSummary* d_summ = nullptr;
+    uint64_t* d_bits = nullptr;        // per tile: valid / hit ballots of every 64-position word
+    int64_t* d_csum = nullptr;         // per tile: sum of counts over hits
     kcfx_result* d_res = nullptr;      // used by the synchronous entry point
     hipStream_t stream = nullptr;
     // measurement
@@ -239,6 +241,8 @@ void ref_free(kcfx_ref* r) {
     if (r->d_tiles) (void)hipFree(r->d_tiles);
     if (r->d_win_tile0) (void)hipFree(r->d_win_tile0);
     if (r->d_summ) (void)hipFree(r->d_summ);
+    if (r->d_bits) (void)hipFree(r->d_bits);
+    if (r->d_csum) (void)hipFree(r->d_csum);
     if (r->d_res) (void)hipFree(r->d_res);
     if (r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
@@ -519,6 +523,8 @@ int32_t kcfx_ref_create(int32_t device, int32_t kmer_length, const uint8_t* text
         (e = hipMalloc(&r->d_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(TileDesc))) != hipSuccess ||
         (e = hipMalloc(&r->d_win_tile0, win_tile0.size() * 4)) != hipSuccess ||
         (e = hipMalloc(&r->d_summ, std::max<size_t>(tiles.size(), 1) * sizeof(TileSummary))) != hipSuccess ||
+        (e = hipMalloc(&r->d_bits, std::max<size_t>(tiles.size(), 1) * TILE_BITS_U64 * 8)) != hipSuccess ||
+        (e = hipMalloc(&r->d_csum, std::max<size_t>(tiles.size(), 1) * 8)) != hipSuccess ||
         (e = hipMalloc(&r->d_res, std::max<size_t>((size_t)n_windows, 1) * sizeof(kcfx_result))) != hipSuccess ||
         (!tiles.empty() && (e = hipMemcpyAsync(r->d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, r->stream)) != hipSuccess) ||
         (e = hipMemcpyAsync(r->d_win_tile0, win_tile0.data(), win_tile0.size() * 4, hipMemcpyHostToDevice, r->stream)) != hipSuccess ||
@@ -555,8 +561,9 @@ int32_t kcfx_screen_ref_async(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count
         KCFX_HIP(hipEventRecord(ev0, st));
     }
     KCFX_HIP(launch_screen_tiles(ref->d_text, ref->d_tiles, ref->n_tiles, db->view(), ref->k, db->info.both_strands,
-                                 min_kmer_count, ref->d_summ, st));
+                                 min_kmer_count, ref->d_bits, ref->d_csum, st));
     if (ev1) KCFX_HIP(hipEventRecord(ev1, st));
+    KCFX_HIP(launch_summarize_tiles(ref->d_tiles, ref->n_tiles, ref->d_bits, ref->d_csum, ref->k, ref->d_summ, st));
     KCFX_HIP(launch_finalize_windows(ref->d_summ, ref->d_win_tile0, ref->n_windows, ref->k,
                                      reinterpret_cast<kcfx_result*>(out_device), st));
     return KCFX_OK;

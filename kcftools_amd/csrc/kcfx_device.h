@@ -266,4 +266,37 @@ KCFX_HD void gap_advance(uint64_t H, uint64_t M, GapCarry& c) {
     }
 }
 
+// ---- a tile's hit bitmap -> its summary -----------------------------------------------------------------
+// Vw / Hw: per 64-position word, the ballots of "valid k-mer" and "observed" (hit) written by screen_tiles.
+// Sequential over the words of one tile (<= TILE_K / 64); runs one tile per lane in summarize_tiles_kernel.
+KCFX_HD TileSummary summarize_words(const uint64_t* Vw, const uint64_t* Hw, int n_kmers, int k, int64_t count_sum) {
+    const int n_words = (n_kmers + 63) >> 6;
+    if (n_words == 0) return summary_identity();
+    GapCarry carry{0, 0, false};
+    int32_t n_valid = 0, obs = 0, runs = 0, var_in = 0, inner_in = 0;
+    uint64_t prev_valid = 0, V = 0;
+    for (int w = 0; w < n_words; ++w) {
+        V = Vw[w];
+        const uint64_t H = Hw[w] & V;
+        const uint64_t M = V & ~H;
+        n_valid += __builtin_popcountll(V);
+        obs += __builtin_popcountll(H);
+        runs += __builtin_popcountll(V & ~((V << 1) | prev_valid));     // maximal runs of valid start positions
+        prev_valid = V >> 63;
+        gap_close_scalar(V, H, M, carry, k, var_in, inner_in);          // GetVariants.java:228-244
+        gap_advance(H, M, carry);
+    }
+    TileSummary s;
+    s.n = n_valid;
+    s.obs = obs;
+    s.lead = carry.cany ? carry.lead : n_valid;
+    s.trail = carry.cany ? carry.cg : n_valid;
+    s.var_in = var_in;
+    s.inner_in = inner_in;
+    s.runs = runs;
+    s.flags = (carry.cany ? F_ANY : 0u) | ((Vw[0] & 1) ? F_FIRST : 0u) | (((V >> ((n_kmers - 1) & 63)) & 1) ? F_LAST : 0u);
+    s.count_sum = count_sum;
+    return s;
+}
+
 }  // namespace kcfx

@@ -45,10 +45,14 @@ struct TableView {
 
 // ----------------------------------------------------------------------------------------------------
 // Tile plan: every window is cut into tiles of at most TILE_K consecutive k-mer start positions; one
-// workgroup screens one tile and emits one TileSummary; finalize_windows folds a window's tiles in order.
+// workgroup screens one tile and emits its hit bitmap; summarize_tiles reduces each bitmap to a TileSummary;
+// finalize_windows folds a window's tiles in order.
 // ----------------------------------------------------------------------------------------------------
 constexpr int BLOCK = 256;            // 4 wavefronts
 constexpr int TILE_K = 2048;          // k-mer start positions per tile (multiple of 64)
+constexpr int TILE_WORDS = TILE_K / 64;
+// per tile: TILE_WORDS valid-ballots then TILE_WORDS hit-ballots (screen_tiles -> summarize_tiles)
+constexpr int TILE_BITS_U64 = 2 * TILE_WORDS;
 
 struct TileDesc {
     int64_t text_off;    // offset of the tile's first base in the padded device text
@@ -162,7 +166,10 @@ hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide,
 hipError_t launch_lookup(TableView tv, int32_t k, const uint64_t* keys, int64_t n, int32_t* counts_out, hipStream_t st);
 // screen
 hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32_t n_tiles, TableView tv, int32_t k,
-                               int32_t both_strands, int32_t min_count, TileSummary* out, hipStream_t st);
+                               int32_t both_strands, int32_t min_count, uint64_t* bits, int64_t* count_sums,
+                               hipStream_t st);
+hipError_t launch_summarize_tiles(const TileDesc* tiles, int32_t n_tiles, const uint64_t* bits, const int64_t* count_sums,
+                                  int32_t k, TileSummary* out, hipStream_t st);
 hipError_t launch_finalize_windows(const TileSummary* tiles, const int32_t* win_tile0, int32_t n_windows, int32_t k,
                                    kcfx_result* out, hipStream_t st);
 

@@ -170,7 +170,8 @@ template <bool WIDE, int MODE, int KT, int VAR>
 __global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __restrict__ text,
                                                              const TileDesc* __restrict__ tiles, TableView tv,
                                                              int32_t k_rt, int32_t both_strands, int32_t min_count,
-                                                             TileSummary* __restrict__ out) {
+                                                             uint64_t* __restrict__ bits,
+                                                             int64_t* __restrict__ count_sums) {
     constexpr bool MINI = (MODE == MODE_MINIMIZER);
     constexpr int HLEN = MINI ? TILE_K + 64 : 1;
     __shared__ uint32_t s_fw[2 * (MAX_CHUNKS + 2)];
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __re
     __shared__ uint32_t s_ha[HLEN];                        // sliding-minimum ping
     __shared__ __attribute__((aligned(16))) uint32_t s_hb[MINI ? HLEN : WAVES * RUN_CHUNK * 32];   // pong, then line buffers
     __shared__ uint32_t s_runline[WAVES][64];              // line index of each run, per wave
-    __shared__ TileSummary s_sum[WAVES];
+    __shared__ int64_t s_sum[WAVES];
     static_assert(HLEN == 1 || HLEN * 4 >= WAVES * RUN_CHUNK * 128, "line buffers alias the dead pong array");
 
     const int k = KT ? KT : k_rt;
@@ -218,9 +219,16 @@ __global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __re
     if (MINI) {
         const int n_m = td.n_kmers + wlen - 1;             // every M-mer of every k-mer of the tile
         for (int p = tid; p < n_m; p += BLOCK) {
-            uint64_t f, r;
-            extract_pair(s_fw, s_cw, off + p, M, f, r);
-            s_ha[p] = mmer_hash(f, r);
+            if (KT) {            // M = 16: the M-mer is one dword; same value as mmer_hash on the left-aligned words
+                const int q = off + p, w = q >> 4;
+                const uint32_t sh = (uint32_t)(q & 15) * 2;
+                const uint32_t f = fshl(s_fw[w], s_fw[w + 1], sh), r = brev32(fshl(s_cw[w], s_cw[w + 1], sh));
+                s_ha[p] = hash32(((uint64_t)min(f, r)) << 32);
+            } else {
+                uint64_t f, r;
+                extract_pair(s_fw, s_cw, off + p, M, f, r);
+                s_ha[p] = mmer_hash(f, r);
+            }
         }
         __syncthreads();
         uint32_t* src = s_ha;
@@ -246,14 +254,8 @@ __global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __re
     const uint64_t lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1);   // bits 0..lane
     uint4* my_lines = s_line + wave * (RUN_CHUNK * 8);
 
-    GapCarry carry;
-    carry.cg = 0;
-    carry.lead = 0;
-    carry.cany = false;
-    int32_t n_valid = 0, obs = 0, runs = 0, var_in = 0, inner_in = 0;     // wave-uniform
-    uint32_t prev_valid = 0, first_valid = 0;
-    uint64_t last_V = 0;
-    int64_t sum_acc = 0;                                                     // per lane
+    int64_t sum_acc = 0;                                   // per lane
+    uint64_t* my_bits = bits + (size_t)blockIdx.x * TILE_BITS_U64;
 
     for (int w = w_begin; w < w_end; ++w) {
         const int j = w * 64 + lane;
@@ -327,52 +329,35 @@ __global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __re
         }
         const bool hit = found && (cnt >= min_count);            // GetVariants.java:224
 
+        // this word of the window's hit bitmap (reduced by summarize_tiles_kernel)
         const uint64_t V = __ballot(valid);
         const uint64_t H = __ballot(hit);
-        const uint64_t Mm = V & ~H;
-        n_valid += __popcll(V);
-        obs += __popcll(H);
-        if (hit) sum_acc += (int64_t)cnt;                          // GetVariants.java:226
-
-        // maximal runs of valid start positions (for EFFLEN)
-        runs += __popcll(V & ~((V << 1) | (uint64_t)prev_valid));
-        if (w == w_begin) first_valid = (uint32_t)(V & 1);
-        prev_valid = (uint32_t)(V >> 63);
-        last_V = V;
-
-        // gap accounting (GetVariants.java:228-244), on the scalar unit
-        if (VAR != 2) gap_close_scalar(V, H, Mm, carry, k, var_in, inner_in);
-        gap_advance(H, Mm, carry);
-    }
-
-    // ---- wave summary --------------------------------------------------------------------------------
-    const int64_t count_sum = wave_sum_i64(sum_acc);
-    if (lane == 0) {
-        TileSummary s;
-        if (w_begin == w_end) {
-            s = summary_identity();
-        } else {
-            const int last_pos = min(w_end * 64, td.n_kmers) - 1;
-            s.n = n_valid;
-            s.obs = obs;
-            s.lead = carry.cany ? carry.lead : n_valid;
-            s.trail = carry.cany ? carry.cg : n_valid;
-            s.var_in = var_in;
-            s.inner_in = inner_in;
-            s.runs = runs;
-            s.flags = (carry.cany ? F_ANY : 0u) | (first_valid ? F_FIRST : 0u) |
-                      (((last_V >> (last_pos & 63)) & 1) ? F_LAST : 0u);
-            s.count_sum = count_sum;
+        if (lane == 0) {
+            my_bits[w] = V;
+            my_bits[TILE_WORDS + w] = H;
         }
-        s_sum[wave] = s;
+        if (hit) sum_acc += (int64_t)cnt;                          // GetVariants.java:226
     }
+
+    const int64_t count_sum = wave_sum_i64(sum_acc);
+    if (lane == 0) s_sum[wave] = count_sum;
     __syncthreads();
     if (tid == 0) {
-        TileSummary acc = s_sum[0];
+        int64_t t = 0;
 #pragma unroll
-        for (int i = 1; i < WAVES; ++i) acc = summary_combine(acc, s_sum[i], k);
-        out[blockIdx.x] = acc;
+        for (int i = 0; i < WAVES; ++i) t += s_sum[i];
+        count_sums[blockIdx.x] = t;
     }
+}
+
+// one lane per tile: hit bitmap -> TileSummary (gap monoid + EFFLEN runs), GetVariants.java:228-252
+__global__ void summarize_tiles_kernel(const TileDesc* __restrict__ tiles, int32_t n_tiles,
+                                       const uint64_t* __restrict__ bits, const int64_t* __restrict__ count_sums,
+                                       int32_t k, TileSummary* __restrict__ out) {
+    const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const uint64_t* b = bits + (size_t)t * TILE_BITS_U64;
+    out[t] = summarize_words(b, b + TILE_WORDS, tiles[t].n_kmers, k, count_sums[t]);
 }
 
 // one thread per window: fold its tiles in order (GetVariants.java:248-258)
@@ -446,12 +431,21 @@ hipError_t launch_lookup(TableView tv, int32_t k, const uint64_t* keys, int64_t 
     return hipGetLastError();
 }
 
+hipError_t launch_summarize_tiles(const TileDesc* tiles, int32_t n_tiles, const uint64_t* bits, const int64_t* count_sums,
+                                  int32_t k, TileSummary* out, hipStream_t st) {
+    if (n_tiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(summarize_tiles_kernel, dim3((n_tiles + 63) / 64), dim3(64), 0, st, tiles, n_tiles, bits, count_sums,
+                       k, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32_t n_tiles, TableView tv, int32_t k,
-                               int32_t both_strands, int32_t min_count, TileSummary* out, hipStream_t st) {
+                               int32_t both_strands, int32_t min_count, uint64_t* bits, int64_t* count_sums,
+                               hipStream_t st) {
     if (n_tiles <= 0) return hipSuccess;
     const dim3 g(n_tiles), b(BLOCK);
 #define KCFX_LAUNCH(W, MD, KT, V) \
-    hipLaunchKernelGGL((screen_tiles_kernel<W, MD, KT, V>), g, b, 0, st, text, tiles, tv, k, both_strands, min_count, out)
+    hipLaunchKernelGGL((screen_tiles_kernel<W, MD, KT, V>), g, b, 0, st, text, tiles, tv, k, both_strands, min_count, bits, count_sums)
     const bool spec = (k == 31) && (tv.mode == MODE_KEYHASH || tv.mm_len == 16);   // compile-time k / M
 #ifdef KCFX_EXPERIMENTS
     static const int var = getenv("KCFX_VARIANT") ? atoi(getenv("KCFX_VARIANT")) : 0;

@@ -61,63 +61,30 @@ int harness_extract(const uint8_t* text, int64_t text_off, int n_kmers, int k, u
     return 0;
 }
 
-// the screen_tiles_kernel control flow with counts[j] standing in for the probe result
+// the screen_tiles_kernel -> summarize_tiles_kernel data flow with counts[j] standing in for the probe result:
+// per 64-position word the valid / hit ballots, then summarize_words (the function the kernel runs per tile)
 int harness_screen_tile(const uint8_t* text, int64_t text_off, int n_kmers, int k, const int32_t* counts,
                         int min_count, TileSummary* out) {
     Packed P = pack_tile(text, text_off, n_kmers, k);
     const int n_words = (n_kmers + 63) >> 6;
-    const int waves = BLOCK / 64;
-    const int wpw = (n_words + waves - 1) / waves;
-    TileSummary sums[BLOCK / 64];
-    for (int wave = 0; wave < waves; ++wave) {
-        const int w_begin = std::min(wave * wpw, n_words), w_end = std::min(w_begin + wpw, n_words);
-        GapCarry carry{0, 0, false};
-        int32_t n_valid = 0, obs = 0, runs = 0, var_in = 0, inner_in = 0;
-        uint32_t prev_valid = 0, first_valid = 0;
-        uint64_t last_V = 0;
-        int64_t sum = 0;
-        for (int w = w_begin; w < w_end; ++w) {
-            uint64_t V = 0, H = 0;
-            int32_t cnt[64];
-            for (int lane = 0; lane < 64; ++lane) {
-                const int j = w * 64 + lane;
-                uint64_t f, r;
-                const int q = P.off + std::min(j, n_kmers - 1);
-                bool valid = extract_kmer(P.fw.data(), P.cw.data(), P.vb.data(), q, k, f, r) && j < n_kmers;
-                cnt[lane] = valid ? counts[j] : 0;
-                const bool hit = valid && cnt[lane] >= min_count;
-                if (valid) V |= 1ull << lane;
-                if (hit) H |= 1ull << lane;
-            }
-            const uint64_t M = V & ~H;
-            n_valid += __builtin_popcountll(V);
-            obs += __builtin_popcountll(H);
-            runs += __builtin_popcountll(V & ~((V << 1) | (uint64_t)prev_valid));
-            if (w == w_begin) first_valid = (uint32_t)(V & 1);
-            prev_valid = (uint32_t)(V >> 63);
-            last_V = V;
-            for (int lane = 0; lane < 64; ++lane)
-                if ((H >> lane) & 1) sum += cnt[lane];
-            gap_close_scalar(V, H, M, carry, k, var_in, inner_in);
-            gap_advance(H, M, carry);
+    std::vector<uint64_t> Vw(TILE_WORDS, 0), Hw(TILE_WORDS, 0);
+    int64_t sum = 0;
+    for (int w = 0; w < n_words; ++w) {
+        uint64_t V = 0, H = 0;
+        for (int lane = 0; lane < 64; ++lane) {
+            const int j = w * 64 + lane;
+            uint64_t f, r;
+            const int q = P.off + std::min(j, n_kmers - 1);
+            const bool valid = extract_kmer(P.fw.data(), P.cw.data(), P.vb.data(), q, k, f, r) && j < n_kmers;
+            const int32_t cnt = valid ? counts[j] : 0;
+            const bool hit = valid && cnt >= min_count;
+            if (valid) V |= 1ull << lane;
+            if (hit) { H |= 1ull << lane; sum += cnt; }
         }
-        TileSummary s;
-        if (w_begin == w_end) {
-            s = summary_identity();
-        } else {
-            const int last_pos = std::min(w_end * 64, n_kmers) - 1;
-            s.n = n_valid; s.obs = obs;
-            s.lead = carry.cany ? carry.lead : n_valid;
-            s.trail = carry.cany ? carry.cg : n_valid;
-            s.var_in = var_in; s.inner_in = inner_in; s.runs = runs;
-            s.flags = (carry.cany ? F_ANY : 0u) | (first_valid ? F_FIRST : 0u) | (((last_V >> (last_pos & 63)) & 1) ? F_LAST : 0u);
-            s.count_sum = sum;
-        }
-        sums[wave] = s;
+        Vw[w] = V;
+        Hw[w] = H;
     }
-    TileSummary acc = sums[0];
-    for (int i = 1; i < waves; ++i) acc = summary_combine(acc, sums[i], k);
-    *out = acc;
+    *out = summarize_words(Vw.data(), Hw.data(), n_kmers, k, sum);
     return 0;
 }
 
