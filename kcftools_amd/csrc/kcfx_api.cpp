@@ -175,11 +175,18 @@ int32_t check_device(int32_t device) {
     return KCFX_OK;
 }
 
-double table_load_factor() {
+// Fraction of key slots in use. Minimizer bucketing makes line occupancy clumpy (a minimizer occurrence brings ~8 k-mers
+// at once), and every overflowed line costs its k-mers a second, dependent fetch round, so a sparse table is worth
+// its HBM while HBM is plentiful (288 GB): 0.35 up to 16 GiB of table, then denser. KCFX_TABLE_LOAD overrides.
+double table_load_factor(int64_t n_keys, int slots) {
     const char* s = getenv("KCFX_TABLE_LOAD");
-    double a = s ? atof(s) : 0.5;
-    if (!(a >= 0.05 && a <= 0.9)) a = 0.5;
-    return a;
+    if (s) {
+        const double a = atof(s);
+        if (a >= 0.05 && a <= 0.9) return a;
+    }
+    const double bytes_at = [&](double a) { return (double)n_keys / (slots * a) * LINE_BYTES; }(0.35);
+    if (bytes_at <= 16.0 * (1ull << 30)) return 0.35;
+    return bytes_at <= 64.0 * (1ull << 30) ? 0.45 : 0.6;
 }
 
 // KCFX_TABLE_MODE=keyhash selects per-k-mer hashing (A/B against the default minimizer bucketing)
@@ -210,7 +217,7 @@ int32_t table_alloc(kcfx_db* db, int64_t n_keys, int32_t counter_size) {
     db->info.table_mode = db->mode;
     db->info.minimizer_length = db->mode == MODE_MINIMIZER ? db->mm_len : 0;
     const int slots = db->wide ? SLOTS_U32 : SLOTS_U16;
-    double want = (double)n_keys / (slots * table_load_factor());
+    double want = (double)n_keys / (slots * table_load_factor(n_keys, slots));
     if (want < 64) want = 64;
     if (want > 4294967295.0) return fail(KCFX_ERR_ARG, "database too large for a 32-bit line index");
     db->n_lines = (uint32_t)want + 1;

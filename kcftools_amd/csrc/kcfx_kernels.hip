@@ -142,6 +142,8 @@ __global__ __launch_bounds__(256) void lookup_kernel(TableView tv, int32_t k, co
 // ======================================================================================================
 constexpr int MAX_CHUNKS = (31 + TILE_K + 31 + 31) / 32 + 1;   // 32-base chunks a tile can span
 constexpr int RUN_CHUNK = 16;                                  // line buffers per wave (2 load instructions)
+constexpr int LINE_STRIDE = 9;                                 // uint4 per buffered line: 8 + 1 pad => the 16 lines of a
+                                                               // chunk start on distinct LDS banks (36 r mod 64)
 constexpr int WAVES = BLOCK / 64;
 
 __device__ __forceinline__ int32_t wave_sum_i32(int32_t v) {
@@ -173,15 +175,15 @@ __global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __re
                                                              uint64_t* __restrict__ bits,
                                                              int64_t* __restrict__ count_sums) {
     constexpr bool MINI = (MODE == MODE_MINIMIZER);
-    constexpr int HLEN = MINI ? TILE_K + 64 : 1;
+    constexpr int HLEN = MINI ? TILE_K + 256 : 1;
     __shared__ uint32_t s_fw[2 * (MAX_CHUNKS + 2)];
     __shared__ uint32_t s_cw[2 * (MAX_CHUNKS + 2)];
     __shared__ uint32_t s_vb[MAX_CHUNKS + 2];
     __shared__ uint32_t s_ha[HLEN];                        // sliding-minimum ping
-    __shared__ __attribute__((aligned(16))) uint32_t s_hb[MINI ? HLEN : WAVES * RUN_CHUNK * 32];   // pong, then line buffers
+    __shared__ __attribute__((aligned(16))) uint32_t s_hb[MINI ? HLEN : WAVES * RUN_CHUNK * LINE_STRIDE * 4];   // pong, then line buffers
     __shared__ uint32_t s_runline[WAVES][64];              // line index of each run, per wave
     __shared__ int64_t s_sum[WAVES];
-    static_assert(HLEN == 1 || HLEN * 4 >= WAVES * RUN_CHUNK * 128, "line buffers alias the dead pong array");
+    static_assert(HLEN == 1 || HLEN >= WAVES * RUN_CHUNK * LINE_STRIDE * 4, "line buffers alias the dead pong array");
 
     const int k = KT ? KT : k_rt;
     const int M = KT ? 16 : tv.mm_len;
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __re
     const int w_begin = min(wave * wpw, n_words);
     const int w_end = min(w_begin + wpw, n_words);
     const uint64_t lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1);   // bits 0..lane
-    uint4* my_lines = s_line + wave * (RUN_CHUNK * 8);
+    uint4* my_lines = s_line + wave * (RUN_CHUNK * LINE_STRIDE);
 
     int64_t sum_acc = 0;                                   // per lane
     uint64_t* my_bits = bits + (size_t)blockIdx.x * TILE_BITS_U64;
@@ -304,12 +306,12 @@ __global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __re
                     a = reinterpret_cast<const uint4*>(tv.lines + (size_t)s_runline[wave][r0] * LINE_BYTES)[piece];
                 if (r1 < nruns)
                     b = reinterpret_cast<const uint4*>(tv.lines + (size_t)s_runline[wave][r1] * LINE_BYTES)[piece];
-                my_lines[(lane >> 3) * 8 + piece] = a;
-                my_lines[(8 + (lane >> 3)) * 8 + piece] = b;
+                my_lines[(lane >> 3) * LINE_STRIDE + piece] = a;
+                my_lines[(8 + (lane >> 3)) * LINE_STRIDE + piece] = b;
                 wave_lds_fence();
                 if (pending && my_run >= c0 && my_run < c0 + RUN_CHUNK) {
                     uint4 q[8];
-                    const uint4* src = my_lines + (my_run - c0) * 8;
+                    const uint4* src = my_lines + (my_run - c0) * LINE_STRIDE;
 #pragma unroll
                     for (int s = 0; s < 8; ++s) q[s] = src[s];
                     uint32_t c, meta;
