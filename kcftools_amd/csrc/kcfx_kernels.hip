@@ -169,21 +169,25 @@ __device__ __forceinline__ void wave_lds_fence() {
 //
 // KT = 31: k = 31 and M = 16 are compile-time constants (the BASELINE.json configuration); KT = 0: any k <= 32 / M.
 template <bool WIDE, int MODE, int KT, int VAR>
-__global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __restrict__ text,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void screen_tiles_kernel(const uint8_t* __restrict__ text,
                                                              const TileDesc* __restrict__ tiles, TableView tv,
                                                              int32_t k_rt, int32_t both_strands, int32_t min_count,
                                                              uint64_t* __restrict__ bits,
                                                              int64_t* __restrict__ count_sums) {
     constexpr bool MINI = (MODE == MODE_MINIMIZER);
-    constexpr int HLEN = MINI ? TILE_K + 256 : 1;
+    constexpr int LINEBUF_U32 = WAVES * RUN_CHUNK * LINE_STRIDE * 4;
+    // k = 31 / M = 16: four sliding-minimum steps, the result ends in s_ha and the line buffers reuse s_hb.
+    // Generic k / M: the step count varies, so both arrays are sized for either role.
+    constexpr int HMIN = TILE_K + 64;
+    constexpr int HBIG = HMIN > LINEBUF_U32 ? HMIN : LINEBUF_U32;
+    constexpr int HLEN = MINI ? (KT ? HMIN : HBIG) : 1;
     __shared__ uint32_t s_fw[2 * (MAX_CHUNKS + 2)];
     __shared__ uint32_t s_cw[2 * (MAX_CHUNKS + 2)];
     __shared__ uint32_t s_vb[MAX_CHUNKS + 2];
     __shared__ uint32_t s_ha[HLEN];                        // sliding-minimum ping
-    __shared__ __attribute__((aligned(16))) uint32_t s_hb[MINI ? HLEN : WAVES * RUN_CHUNK * LINE_STRIDE * 4];   // pong, then line buffers
-    __shared__ uint32_t s_runline[WAVES][64];              // line index of each run, per wave
+    __shared__ __attribute__((aligned(16))) uint32_t s_hb[MINI ? HBIG : LINEBUF_U32];   // pong, then line buffers
+    __shared__ uint32_t s_runline[WAVES][65];              // line index of each run, per wave (+1 dummy slot)
     __shared__ int64_t s_sum[WAVES];
-    static_assert(HLEN == 1 || HLEN >= WAVES * RUN_CHUNK * LINE_STRIDE * 4, "line buffers alias the dead pong array");
 
     const int k = KT ? KT : k_rt;
     const int M = KT ? 16 : tv.mm_len;
@@ -254,6 +258,7 @@ __global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __re
     const int w_begin = min(wave * wpw, n_words);
     const int w_end = min(w_begin + wpw, n_words);
     const uint64_t lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1);   // bits 0..lane
+    const uint64_t lane_prev = lane ? (1ull << (lane - 1)) : 0ull;           // bit lane-1
     uint4* my_lines = s_line + wave * (RUN_CHUNK * LINE_STRIDE);
 
     int64_t sum_acc = 0;                                   // per lane
@@ -277,31 +282,32 @@ __global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __re
             tgt = mulhi32(hash32(key), tv.n_lines);
         }
 
-        int32_t cnt = 0;
-        bool found = false;
-        bool pending = valid;
+        // Probe state lives in VGPR integers and is updated with selects: lane-varying bools carried through the
+        // loops would be kept as SGPR masks and cost three scalar instructions per update and block.
+        uint32_t st = valid ? 1u : 0u;          // 1 = pending, 2 = found, 0 = absent / invalid
+        uint32_t cnt = 0;
         if (VAR == 3) {
-            cnt = (int32_t)(key >> 60) + (int32_t)(tgt & 1);
-            found = (key & 0x300) != 0;
-            pending = false;
+            cnt = (uint32_t)(key >> 60) + (tgt & 1);
+            st = (key & 0x300) ? 2u : 0u;
         }
         // ---- cooperative probe rounds: each round fetches, for every run of adjacent pending lanes with the same
         //      target line, that line ONCE (8 lanes x 16 B = one 128-byte request) into wave-private LDS -------------
         for (;;) {
-            const uint64_t P = __ballot(pending);
+            const uint64_t P = __ballot(st == 1u);
             if (!P) break;
             const uint32_t prev_tgt = __shfl_up(tgt, 1, 64);
-            const bool prev_pending = lane > 0 && ((P >> (lane - 1)) & 1);
-            const bool head = pending && (!prev_pending || prev_tgt != tgt);
+            const bool prev_pend = (P & lane_prev) != 0;
+            const bool head = (st == 1u) && (!prev_pend || prev_tgt != tgt);
             const uint64_t HM = __ballot(head);
             const int nruns = __popcll(HM);
             const int my_run = __popcll(HM & lane_le) - 1;
-            if (head) s_runline[wave][my_run] = tgt;
+            // every pending lane stores its run's line index (same value within a run); the others hit a dummy slot
+            s_runline[wave][(st == 1u) ? my_run : 64] = tgt;
             wave_lds_fence();
             for (int c0 = 0; c0 < nruns; c0 += RUN_CHUNK) {
                 const int r0 = c0 + (lane >> 3), r1 = r0 + 8;
                 const int piece = lane & 7;
-                uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
+                uint4 a, b;
                 if (r0 < nruns)
                     a = reinterpret_cast<const uint4*>(tv.lines + (size_t)s_runline[wave][r0] * LINE_BYTES)[piece];
                 if (r1 < nruns)
@@ -309,27 +315,26 @@ __global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __re
                 my_lines[(lane >> 3) * LINE_STRIDE + piece] = a;
                 my_lines[(8 + (lane >> 3)) * LINE_STRIDE + piece] = b;
                 wave_lds_fence();
-                if (pending && my_run >= c0 && my_run < c0 + RUN_CHUNK) {
-                    uint4 q[8];
-                    const uint4* src = my_lines + (my_run - c0) * LINE_STRIDE;
+                // every lane matches (idle lanes against buffer 0); the outcome is merged with selects
+                const uint32_t rel = (uint32_t)(my_run - c0);
+                const bool mine = (st == 1u) && (rel < (uint32_t)RUN_CHUNK);
+                const uint4* src = my_lines + (mine ? rel : 0u) * LINE_STRIDE;
+                uint4 q[8];
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) q[s] = src[s];
-                    uint32_t c, meta;
-                    const bool any = match_line<WIDE, KT == 0>(q, key, c, meta);
-                    if (any) {
-                        found = true;
-                        cnt = (int32_t)c;                   // Java int (KMC.java:395-401)
-                        pending = false;
-                    } else if (!(meta & META_OVERFLOW)) {
-                        pending = false;
-                    } else {
-                        tgt = (tgt + 1 == tv.n_lines) ? 0 : tgt + 1;
-                    }
-                }
+                for (int i = 0; i < 8; ++i) q[i] = src[i];
+                uint32_t c, meta;
+                const bool any = match_line<WIDE, KT == 0>(q, key, c, meta);
+                const uint32_t ov = (meta >> 8) & 1u;                       // overflowed line: look at the next one
+                const uint32_t nst = any ? 2u : ov;
+                const uint32_t ntgt = (tgt + 1 == tv.n_lines) ? 0u : tgt + 1;
+                cnt = (mine && any) ? c : cnt;                              // Java int (KMC.java:395-401)
+                tgt = (mine && nst == 1u) ? ntgt : tgt;
+                st = mine ? nst : st;
                 wave_lds_fence();
             }
         }
-        const bool hit = found && (cnt >= min_count);            // GetVariants.java:224
+        const bool found = (st == 2u);
+        const bool hit = found && ((int32_t)cnt >= min_count);   // GetVariants.java:224
 
         // this word of the window's hit bitmap (reduced by summarize_tiles_kernel)
         const uint64_t V = __ballot(valid);
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __re
             my_bits[w] = V;
             my_bits[TILE_WORDS + w] = H;
         }
-        if (hit) sum_acc += (int64_t)cnt;                          // GetVariants.java:226
+        if (hit) sum_acc += (int64_t)(int32_t)cnt;                 // GetVariants.java:226
     }
 
     const int64_t count_sum = wave_sum_i64(sum_acc);

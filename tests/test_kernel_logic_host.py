@@ -33,7 +33,7 @@ def harness():
         hipcc = "/opt/rocm/bin/hipcc"
         if not os.path.exists(hipcc):
             pytest.skip("hipcc not available")
-        subprocess.run([hipcc, "-O1", "-std=c++17", "-fPIC", "-x", "hip", "--offload-arch=gfx950", "-shared", "-o", so, src],
+        subprocess.run([hipcc, "-O1", "-std=c++17", "-fPIC", "-x", "hip", "--offload-arch=gfx950", "--cuda-host-only", "-shared", "-o", so, src],
                        check=True, capture_output=True)
     L = C.CDLL(so)
     L.harness_extract.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -192,8 +192,9 @@ def test_minimizer_build_side_equals_query_side(harness, oracle):
     # consecutive k-mers share their minimizer in runs: mean run length ~ (w + 1) / 2
     n = 2048
     q = np.zeros(n, dtype=np.uint32)
-    harness.harness_minimizers(buf.ctypes.data, 1000, n, 31, 16, q.ctypes.data, np.zeros(n, dtype=np.uint32).ctypes.data,
-                               np.zeros(n, dtype=np.uint32).ctypes.data)
+    t1 = np.zeros(n, dtype=np.uint32)
+    t2 = np.zeros(n, dtype=np.uint32)
+    harness.harness_minimizers(buf.ctypes.data, 1000, n, 31, 16, q.ctypes.data, t1.ctypes.data, t2.ctypes.data)
     runs = 1 + int((q[1:] != q[:-1]).sum())
     assert 6.0 < n / runs < 12.0
     for w in (0x1B00000000000000, 0xFFFFFFFFFFFFFFFC, 0x123456789ABCDEF0 & ~3):
