@@ -1,0 +1,71 @@
+"""Multi-GPU plumbing for the getVariations hot path: one process per GPU, torch.distributed (RCCL on GPUs,
+gloo in the CPU tests).
+
+The path shards into independent units -- every (window, sample) result depends only on that window's text and
+that sample's database (GetVariants.java:138-150 processes windows independently; utils/run_kcftools.sh:124-140
+runs samples in separate processes) -- so there is NO data-path collective. Two partitionings (SURVEY.md 8 e):
+
+  * samples >= ranks : sample-sharded. Rank r owns samples r, r + W, r + 2W, ...; the reference is replicated.
+  * samples <  ranks : window-sharded. Contiguous window ranges balanced by the number of k-mer start positions;
+                       the sample database is replicated.
+
+The only exchange is the final gather of the 40-byte per-(window, sample) records to rank 0.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+RESULT_WORDS = 10   # kcfx_result = 10 x int32 (the int64 count sum occupies the last two)
+
+
+def samples_of_rank(n_samples: int, world: int, rank: int) -> list[int]:
+    return list(range(rank, n_samples, world))
+
+
+def window_range_of_rank(win_len: np.ndarray, k: int, world: int, rank: int) -> tuple[int, int]:
+    """Contiguous [lo, hi) window range of `rank`, balanced by k-mer start positions (work), not by window count:
+    gene-model windows span 31 bp .. 100 kbp."""
+    work = np.maximum(np.asarray(win_len, dtype=np.int64) - k + 1, 0)
+    total = int(work.sum())
+    n = len(work)
+    if world <= 1 or n == 0:
+        return 0, n
+    cum = np.cumsum(work)
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r / world
+        cuts.append(int(np.searchsorted(cum, target, side="left")) + (1 if total else 0))
+    cuts.append(n)
+    cuts = [min(max(c, 0), n) for c in cuts]
+    for i in range(1, len(cuts)):
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return cuts[rank], cuts[rank + 1]
+
+
+def gather_results(local, dst: int = 0, group=None):
+    """Gather every rank's result records (torch int32 tensor [n_local * 10], device or host) to `dst`.
+    Ranks may hold different numbers of records (window sharding): sizes are exchanged first, the payload is
+    padded to the maximum, and `dst` trims. Returns a list of per-rank tensors on `dst`, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(sizes) if sizes else 0
+    padded = local
+    if local.numel() < m:
+        padded = torch.zeros(m, dtype=local.dtype, device=local.device)
+        padded[: local.numel()] = local
+    out = [torch.zeros(m, dtype=local.dtype, device=local.device) for _ in range(world)] if rank == dst else None
+    dist.gather(padded, out, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return [o[:s] for o, s in zip(out, sizes)]
+
+
+def merge_window_shards(parts: list[np.ndarray]) -> np.ndarray:
+    """Window-sharded run: concatenate the per-rank record arrays in rank order (ranges are contiguous)."""
+    return np.concatenate(parts) if parts else np.zeros(0)

@@ -1,0 +1,98 @@
+"""World-size-2 (and 3) `gloo` tests of the multi-GPU plumbing: the sharding plans and the final gather of the
+per-(window, sample) records. On CPU the per-rank records come from the oracle (this is test infrastructure);
+on the GPU box bench.py runs the same functions with the HIP engine and backend "nccl" (= RCCL)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from kcftools_amd import shard, synth
+
+K = 31
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def make_inputs(tmpdir, n_samples):
+    ref = synth.random_reference(60_000, 7, n_run_every=9000, max_n_run=300)
+    prefixes = []
+    for s in range(n_samples):
+        prm = synth.KmcParams(k=K, p=3, counter_size=2, sig_len=5, n_bins=4)
+        kmers, counts = synth.build_sample_db(synth.mutate_sample(ref, 100 + s), prm, 200 + s, noise_kmers=500)
+        prefix = os.path.join(tmpdir, f"s{s}")
+        synth.write_kmc(prefix, kmers, counts, prm)
+        prefixes.append(prefix)
+    starts, ends = synth.tiling_windows(len(ref), 5_000, K)
+    return ref, prefixes, starts, ends - starts
+
+
+def worker(rank, world, port, tmpdir, n_samples, mode, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import binding as oracle
+    ref, prefixes, wb, wl = make_inputs(tmpdir, n_samples)
+    if mode == "samples":
+        mine = shard.samples_of_rank(n_samples, world, rank)
+        recs = [oracle.OracleDb(prefixes[s]).screen(ref, wb, wl, 1) for s in mine]
+        local = np.concatenate(recs) if recs else np.zeros(0, dtype=oracle.RESULT_DTYPE)
+    else:
+        lo, hi = shard.window_range_of_rank(wl, K, world, rank)
+        local = oracle.OracleDb(prefixes[0]).screen(ref, wb[lo:hi], wl[lo:hi], 1)
+    t = torch.from_numpy(local.view(np.int32).copy())
+    parts = shard.gather_results(t, dst=0)
+    if rank == 0:
+        q.put([p.numpy().copy() for p in parts])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_samples,mode", [(2, 4, "samples"), (2, 1, "windows"), (3, 1, "windows"), (2, 3, "samples")])
+def test_sharded_run_equals_single_process(tmp_path, world, n_samples, mode):
+    from oracle import binding as oracle
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, str(tmp_path), n_samples, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    parts = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref, prefixes, wb, wl = make_inputs(str(tmp_path), n_samples)
+    if mode == "samples":
+        for r in range(world):
+            got = parts[r].view(oracle.RESULT_DTYPE)
+            want = [oracle.OracleDb(prefixes[s]).screen(ref, wb, wl, 1) for s in shard.samples_of_rank(n_samples, world, r)]
+            want = np.concatenate(want) if want else np.zeros(0, dtype=oracle.RESULT_DTYPE)
+            assert np.array_equal(got, want)
+    else:
+        got = shard.merge_window_shards([p.view(oracle.RESULT_DTYPE) for p in parts])
+        want = oracle.OracleDb(prefixes[0]).screen(ref, wb, wl, 1)
+        assert np.array_equal(got, want)
+
+
+def test_window_ranges_partition_and_balance():
+    rng = np.random.default_rng(0)
+    for n, world in [(1, 2), (7, 8), (100, 3), (3052, 8), (27000, 8), (0, 4)]:
+        wl = np.concatenate([rng.integers(1, 200, n // 2), rng.integers(200, 60_000, n - n // 2)]) if n else np.zeros(0, dtype=np.int64)
+        ranges = [shard.window_range_of_rank(wl, K, world, r) for r in range(world)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(ranges[:-1], ranges[1:]))
+        work = np.maximum(wl - K + 1, 0)
+        if n >= 1000:
+            per = [int(work[lo:hi].sum()) for lo, hi in ranges]
+            assert max(per) <= 1.05 * (sum(per) / world) + int(work.max())
+    assert shard.samples_of_rank(8, 8, 3) == [3] and shard.samples_of_rank(32, 8, 7) == [7, 15, 23, 31]
+    assert shard.samples_of_rank(3, 8, 5) == []
