@@ -1,0 +1,69 @@
+// kcfx_jni.cpp -- thin JNI shim over the C ABI of include/kcfx.h (1:1, no logic of its own).
+//
+// NOT compiled in the build image: it has no JDK (no jni.h, no javac); see INTEGRATION.md for the build line and for
+// the Java class (nl.wur.bis.kcftools.Native.Kcfx) whose `native` methods these functions implement. The Java side
+// passes direct ByteBuffers / primitive arrays it owns; handles cross as jlong.
+#include <jni.h>
+
+#include "../../../include/kcfx.h"
+
+namespace {
+void throw_kcfx(JNIEnv* env, int32_t rc) {
+    // GetVariants maps any failure to the reference convention (Logger.error -> exit 1, Utils/Logger.java:29-31)
+    jclass cls = env->FindClass("java/lang/IllegalStateException");
+    if (cls) env->ThrowNew(cls, kcfx_last_error());
+    (void)rc;
+}
+}  // namespace
+
+extern "C" {
+
+// long dbOpen(String kmcPrefix, int device)                              <-> new KMC(prefix, inMemory), KMC.java:56
+JNIEXPORT jlong JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_dbOpen(JNIEnv* env, jclass, jstring prefix, jint device) {
+    const char* p = env->GetStringUTFChars(prefix, nullptr);
+    kcfx_db* db = nullptr;
+    const int32_t rc = kcfx_db_open(p, device, &db);
+    env->ReleaseStringUTFChars(prefix, p);
+    if (rc) { throw_kcfx(env, rc); return 0; }
+    return reinterpret_cast<jlong>(db);
+}
+
+// int[] dbInfo(long db): {k, mode, counterSize, lutPrefixLength, signatureLength, minCount, maxCount, bothStrands}
+JNIEXPORT jintArray JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_dbInfo(JNIEnv* env, jclass, jlong db) {
+    kcfx_db_info_t info;
+    if (int32_t rc = kcfx_db_info(reinterpret_cast<kcfx_db*>(db), &info)) { throw_kcfx(env, rc); return nullptr; }
+    const jint v[8] = {info.kmer_length, info.mode, info.counter_size, info.lut_prefix_length, info.signature_length,
+                       info.min_count, info.max_count, info.both_strands};
+    jintArray out = env->NewIntArray(8);
+    env->SetIntArrayRegion(out, 0, 8, v);
+    return out;
+}
+
+JNIEXPORT void JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_dbClose(JNIEnv*, jclass, jlong db) {
+    kcfx_db_close(reinterpret_cast<kcfx_db*>(db));
+}
+
+// void screen(long db, ByteBuffer text, long[] winBegin, int[] winLen, int minKmerCount, ByteBuffer results)
+// `text` and `results` are direct buffers; results receives nWindows * 40 bytes (kcfx_result, little-endian).
+JNIEXPORT void JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_screen(JNIEnv* env, jclass, jlong db, jobject text,
+                                                                   jlongArray winBegin, jintArray winLen,
+                                                                   jint minKmerCount, jobject results) {
+    const auto* t = static_cast<const uint8_t*>(env->GetDirectBufferAddress(text));
+    const jlong tlen = env->GetDirectBufferCapacity(text);
+    auto* out = static_cast<kcfx_result*>(env->GetDirectBufferAddress(results));
+    const jsize n = env->GetArrayLength(winLen);
+    if (!t || !out || env->GetDirectBufferCapacity(results) < (jlong)n * (jlong)sizeof(kcfx_result)) {
+        jclass cls = env->FindClass("java/lang/IllegalArgumentException");
+        if (cls) env->ThrowNew(cls, "text / results must be direct buffers of sufficient capacity");
+        return;
+    }
+    jlong* wb = env->GetLongArrayElements(winBegin, nullptr);
+    jint* wl = env->GetIntArrayElements(winLen, nullptr);
+    const int32_t rc = kcfx_screen(reinterpret_cast<kcfx_db*>(db), t, tlen, reinterpret_cast<const int64_t*>(wb),
+                                   reinterpret_cast<const int32_t*>(wl), n, minKmerCount, out);
+    env->ReleaseLongArrayElements(winBegin, wb, JNI_ABORT);
+    env->ReleaseIntArrayElements(winLen, wl, JNI_ABORT);
+    if (rc) throw_kcfx(env, rc);
+}
+
+}  // extern "C"

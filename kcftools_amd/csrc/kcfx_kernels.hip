@@ -169,7 +169,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 //
 // KT = 31: k = 31 and M = 16 are compile-time constants (the BASELINE.json configuration); KT = 0: any k <= 32 / M.
 template <bool WIDE, int MODE, int KT, int VAR>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void screen_tiles_kernel(const uint8_t* __restrict__ text,
+__global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __restrict__ text,
                                                              const TileDesc* __restrict__ tiles, TableView tv,
                                                              int32_t k_rt, int32_t both_strands, int32_t min_count,
                                                              uint64_t* __restrict__ bits,

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Summarise a tools/profile_round.sh run (gpurun_out/<tag>/) into profiles/<tag>_*: kernel stats, per-launch HBM
+traffic of screen_tiles (gfx950 correction from MI355X_MICROARCH.md: FETCH_SIZE counts 128-byte requests at 64 B, so
+read bytes = 2 x FETCH_SIZE; checked on the membench calibration kernel), counters, and profiles/traffic.json that
+bench.py reads for roofline.traffic."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = f"gpurun_out/{tag}"
+os.makedirs("profiles", exist_ok=True)
+
+
+def counters(pattern, kernel):
+    agg = collections.defaultdict(list)
+    for f in glob.glob(pattern):
+        for r in csv.DictReader(open(f)):
+            if kernel in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}
+
+
+out = {"tag": tag}
+bench = json.load(open(f"{src}/bench.json"))
+out["bench"] = {k: bench[k] for k in ("value", "ms_per_step", "roofline", "cpu_baseline", "parity", "config")}
+for f in glob.glob(f"{src}/stats/*kernel_stats.csv"):
+    shutil.copy(f, f"profiles/{tag}_kernel_stats.csv")
+    for r in csv.DictReader(open(f)):
+        if "screen_tiles" in r["Name"]:
+            out["rocprof_screen_tiles_avg_ms"] = float(r["AverageNs"]) / 1e6
+            out["rocprof_screen_tiles_calls"] = int(r["Calls"])
+fetch, n1 = counters(f"{src}/pmc_fetch/*counter_collection.csv", "screen_tiles")
+write, _ = counters(f"{src}/pmc_write/*counter_collection.csv", "screen_tiles")
+tcc, _ = counters(f"{src}/pmc_tcc/*counter_collection.csv", "screen_tiles")
+sq, _ = counters(f"{src}/pmc_sq/*counter_collection.csv", "screen_tiles")
+cal, _ = counters(f"{src}/pmc_cal/*counter_collection.csv", "gather_coop<8, 1>")
+out["counters"] = {"FETCH_SIZE_KB": fetch.get("FETCH_SIZE"), "WRITE_SIZE_KB": write.get("WRITE_SIZE"), **tcc, **sq}
+if cal.get("FETCH_SIZE"):
+    known = 64e6 * 128          # kcfx_membench 4 64: 64 M accesses of one whole 128-byte line each
+    out["calibration"] = {"kernel": "gather_coop<8,1> (8 lanes x 16 B per random 128-byte line)", "known_bytes": known,
+                          "FETCH_SIZE_KB": cal["FETCH_SIZE"], "bytes_over_fetch_size": known / (cal["FETCH_SIZE"] * 1024)}
+if fetch.get("FETCH_SIZE") is not None:
+    rd = 2.0 * fetch["FETCH_SIZE"] * 1024
+    wr = (write.get("WRITE_SIZE") or 0.0) * 1024
+    out["hbm_bytes_per_launch"] = rd + wr
+    out["hbm_read_bytes_per_launch"] = rd
+    out["hbm_write_bytes_per_launch"] = wr
+    cfg = bench["config"]
+    json.dump({"tag": tag, "kernel": "screen_tiles_kernel", "hbm_bytes_per_launch": rd + wr,
+               "ref_len": 30427671, "db_kmers": 150000000, "window": 10000,
+               "note": "2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes), separate --pmc passes, averaged over launches"},
+              open("profiles/traffic.json", "w"), indent=1)
+    kms = bench["roofline"]["kernel_avg_ms"]
+    out["hbm_GBps_during_kernel"] = (rd + wr) / (kms * 1e-3) / 1e9
+    out["algorithmic_bytes_per_launch"] = cfg["kmers_per_step_per_gpu"] * bench["roofline"]["algorithmic_bytes_per_kmer"]
+json.dump(out, open(f"profiles/{tag}_summary.json", "w"), indent=1)
+shutil.copy(f"{src}/bench.json", f"profiles/{tag}_bench.json")
+if os.path.exists(f"{src}/membench.log"):
+    shutil.copy(f"{src}/membench.log", f"profiles/{tag}_membench_4GiB.log")
+print(json.dumps(out, indent=1)[:3000])
