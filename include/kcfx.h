@@ -76,6 +76,8 @@ typedef struct {
     double  load_seconds;    /* file read + upload + table build */
     int32_t table_mode;      /* 1 = minimizer-bucketed lines (default), 0 = per-k-mer hashing */
     int32_t minimizer_length;/* M of the minimizer bucketing (0 in mode 0) */
+    int64_t heavy_lines;     /* minimizer home lines whose k-mers were re-homed by key hash (low-complexity repeats) */
+    int64_t overflow_lines;  /* lines that pushed k-mers to the next line */
 } kcfx_db_info_t;
 
 /* ---- database ------------------------------------------------------------------------------------ */

@@ -229,6 +229,22 @@ int32_t table_alloc(kcfx_db* db, int64_t n_keys, int32_t counter_size) {
     return KCFX_OK;
 }
 
+// table_finalize + statistics (heavy / overflowed line counts) into db->info
+int32_t table_finish(kcfx_db* db) {
+    unsigned long long* d_stats = nullptr;
+    unsigned long long h_stats[2] = {0, 0};
+    KCFX_HIP(hipMalloc(&d_stats, sizeof h_stats));
+    hipError_t e = hipMemsetAsync(d_stats, 0, sizeof h_stats, db->stream);
+    if (e == hipSuccess) e = launch_table_finalize(db->d_lines, db->n_lines, db->wide, d_stats, db->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_stats, d_stats, sizeof h_stats, hipMemcpyDeviceToHost, db->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(db->stream);
+    (void)hipFree(d_stats);
+    if (e != hipSuccess) return hip_fail(e, "table_finalize");
+    db->info.heavy_lines = (int64_t)h_stats[0];
+    db->info.overflow_lines = (int64_t)h_stats[1];
+    return KCFX_OK;
+}
+
 void db_free(kcfx_db* db) {
     if (!db) return;
     DeviceGuard g(db->device);
@@ -256,7 +272,8 @@ void ref_free(kcfx_ref* r) {
 }
 
 // stream the .kmc_suf records through the GPU: upload -> decode_records -> table_insert
-int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& h) {
+// pass 0: count the k-mers per minimizer home line (heavy-bucket detection); pass 1: insert
+int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& h, int pass) {
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) return fail(KCFX_ERR_IO, "Error reading suffix buffers from file " + path);
     struct stat st;
@@ -330,7 +347,10 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
         used[turn] = true;
         LOAD_HIP(launch_decode_records(d_rec, first, n, h.record_size, h.suffix_bytes, h.counter_size, h.p, d_lut,
                                        (int64_t)h.lut.size(), d_keys, d_counts, db->stream));
-        LOAD_HIP(launch_table_insert(db->d_lines, db->view(), h.k, d_keys, d_counts, n, db->stream));
+        if (pass == 0)
+            LOAD_HIP(launch_table_count(db->d_lines, db->view(), h.k, d_keys, n, db->stream));
+        else
+            LOAD_HIP(launch_table_insert(db->d_lines, db->view(), h.k, d_keys, d_counts, n, db->stream));
         first += n;
         turn ^= 1;
     }
@@ -387,12 +407,15 @@ int32_t kcfx_db_open(const char* kmc_prefix, int32_t device, kcfx_db** out) {
     hipError_t e = hipStreamCreateWithFlags(&db->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { db_free(db); return hip_fail(e, "hipStreamCreate"); }
     int32_t rc = table_alloc(db, h.total, h.counter_size);
-    if (!rc) rc = load_suffix_file(db, std::string(kmc_prefix) + ".kmc_suf", h);
-    if (!rc) {
-        e = launch_table_finalize(db->d_lines, db->n_lines, db->wide, db->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(db->stream);
-        if (e != hipSuccess) rc = hip_fail(e, "table_finalize");
+    if (!rc && db->mode == MODE_MINIMIZER) {
+        rc = load_suffix_file(db, std::string(kmc_prefix) + ".kmc_suf", h, 0);
+        if (!rc) {
+            e = launch_table_mark_heavy(db->d_lines, db->n_lines, db->stream);
+            if (e != hipSuccess) rc = hip_fail(e, "table_mark_heavy");
+        }
     }
+    if (!rc) rc = load_suffix_file(db, std::string(kmc_prefix) + ".kmc_suf", h, 1);
+    if (!rc) rc = table_finish(db);
     if (rc) { db_free(db); return rc; }
     db->info.load_seconds = now_s() - t0;
     *out = db;
@@ -436,15 +459,13 @@ int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, 
         if ((e = hipMalloc(&d_keys, (size_t)n * 8)) != hipSuccess || (e = hipMalloc(&d_counts, (size_t)n * 4)) != hipSuccess ||
             (e = hipMemcpyAsync(d_keys, kmers, (size_t)n * 8, hipMemcpyHostToDevice, db->stream)) != hipSuccess ||
             (e = hipMemcpyAsync(d_counts, src, (size_t)n * 4, hipMemcpyHostToDevice, db->stream)) != hipSuccess ||
+            (e = launch_table_count(db->d_lines, db->view(), kmer_length, d_keys, n, db->stream)) != hipSuccess ||
+            (db->mode == MODE_MINIMIZER && (e = launch_table_mark_heavy(db->d_lines, db->n_lines, db->stream)) != hipSuccess) ||
             (e = launch_table_insert(db->d_lines, db->view(), kmer_length, d_keys, d_counts, n, db->stream)) != hipSuccess ||
             (e = hipStreamSynchronize(db->stream)) != hipSuccess)
             rc = hip_fail(e, "kcfx_db_build upload/insert");
     }
-    if (!rc) {
-        e = launch_table_finalize(db->d_lines, db->n_lines, db->wide, db->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(db->stream);
-        if (e != hipSuccess) rc = hip_fail(e, "table_finalize");
-    }
+    if (!rc) rc = table_finish(db);
     if (d_keys) (void)hipFree(d_keys);
     if (d_counts) (void)hipFree(d_counts);
     if (rc) { db_free(db); return rc; }

@@ -149,9 +149,20 @@ KCFX_HD uint32_t minimizer_of_kmer(uint64_t x, int k, int M) {
     return best;
 }
 
-KCFX_HD uint32_t home_line(const TableView& tv, uint64_t key, int k) {
-    const uint32_t h = (tv.mode == MODE_MINIMIZER) ? remix32(minimizer_of_kmer(key, k, tv.mm_len)) : hash32(key);
-    return mulhi32(h, tv.n_lines);
+KCFX_HD uint32_t keyhash_line(const TableView& tv, uint64_t key) { return mulhi32(hash32(key), tv.n_lines); }
+KCFX_HD uint32_t minimizer_line(const TableView& tv, uint64_t key, int k) {
+    return mulhi32(remix32(minimizer_of_kmer(key, k, tv.mm_len)), tv.n_lines);
+}
+
+// Probe step of lookup_kernel (screen_tiles has the same logic inlined around its chunk loop).
+// at_home: the line just matched was the key's minimizer home. Returns true while the probe must go on; tgt is advanced.
+KCFX_HD bool probe_next(const TableView& tv, bool at_home, bool found, uint32_t meta, uint64_t key, uint32_t& tgt) {
+    if (found || !(meta & META_OVERFLOW)) return false;
+    if (at_home && (meta & META_HEAVY))             // every k-mer homed here by minimizer lives at its key-hash line
+        tgt = keyhash_line(tv, key);
+    else
+        tgt = (tgt + 1 == tv.n_lines) ? 0u : tgt + 1;
+    return true;
 }
 
 // ---- one 128-byte line against one key ----------------------------------------------------------------

@@ -33,6 +33,13 @@ constexpr int SLOTS_U16 = 12;
 constexpr int SLOTS_U32 = 10;
 constexpr int META_DWORD = 30;
 constexpr uint32_t META_OVERFLOW = 0x100u;
+// bit 9: HEAVY -- more than HEAVY_KEYS k-mers have this line as their MINIMIZER home (a low-complexity repeat can put
+// thousands of k-mers under one minimizer). Their chain would be walked line by line, so all of them are homed by
+// their own key hash instead, and a probe that starts at a HEAVY minimizer home jumps to hash32(key)'s line.
+constexpr uint32_t META_HEAVY = 0x200u;
+constexpr uint32_t HEAVY_KEYS = 4 * SLOTS_U16;
+// build-time encoding of the meta dword: bits 0..23 arrival counter, bit 31 heavy mark
+constexpr uint32_t BUILD_COUNT_MASK = 0x00FFFFFFu, BUILD_HEAVY = 0x80000000u;
 constexpr int MODE_KEYHASH = 0, MODE_MINIMIZER = 1;
 
 struct TableView {
@@ -159,9 +166,11 @@ hipError_t launch_decode_records(const uint8_t* records, int64_t first_record, i
                                  int32_t suffix_bytes, int32_t counter_size, int32_t lut_prefix_length,
                                  const uint64_t* lut, int64_t lut_entries, uint64_t* keys_out, uint32_t* counts_out,
                                  hipStream_t st);
+hipError_t launch_table_count(uint8_t* lines, TableView tv, int32_t k, const uint64_t* keys, int64_t n, hipStream_t st);
+hipError_t launch_table_mark_heavy(uint8_t* lines, uint32_t n_lines, hipStream_t st);
 hipError_t launch_table_insert(uint8_t* lines, TableView tv, int32_t k, const uint64_t* keys,
                                const uint32_t* counts, int64_t n, hipStream_t st);
-hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide, hipStream_t st);
+hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide, unsigned long long* stats, hipStream_t st);
 // lookup
 hipError_t launch_lookup(TableView tv, int32_t k, const uint64_t* keys, int64_t n, int32_t* counts_out, hipStream_t st);
 // screen

@@ -29,8 +29,27 @@ __global__ void table_clear_kernel(uint4* lines, uint64_t n_vec, int32_t key_pie
     }
 }
 
-// During the build the meta dword is a plain arrival counter; table_finalize turns it into
-// {occupied slots, overflow flag}.
+// Build pass 1 (minimizer mode): how many k-mers have each line as their minimizer home
+__global__ void table_count_kernel(uint8_t* lines, TableView tv, int32_t k, const uint64_t* __restrict__ keys, int64_t n) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const uint32_t line = minimizer_line(tv, keys[i], k);
+        atomicAdd(reinterpret_cast<uint32_t*>(lines + (size_t)line * LINE_BYTES) + META_DWORD, 1u);
+    }
+}
+
+__global__ void table_mark_heavy_kernel(uint8_t* lines, uint32_t n_lines) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (; i < n_lines; i += stride) {
+        uint32_t* meta = reinterpret_cast<uint32_t*>(lines + (size_t)i * LINE_BYTES) + META_DWORD;
+        *meta = (*meta > HEAVY_KEYS) ? BUILD_HEAVY : 0u;
+    }
+}
+
+// Build pass 2. The meta dword is {bit 31 heavy mark, bits 0..23 arrival counter}; table_finalize turns it into
+// {occupied slots, overflow flag, heavy flag}.
 template <bool WIDE>
 __global__ void table_insert_kernel(uint8_t* lines, TableView tv, int32_t k, const uint64_t* __restrict__ keys,
                                     const uint32_t* __restrict__ counts, int64_t n) {
@@ -40,10 +59,17 @@ __global__ void table_insert_kernel(uint8_t* lines, TableView tv, int32_t k, con
     for (; i < n; i += stride) {
         const uint64_t key = keys[i];
         const uint32_t c = counts[i];
-        uint32_t line = home_line(tv, key, k);
+        uint32_t line;
+        if (tv.mode == MODE_MINIMIZER) {
+            line = minimizer_line(tv, key, k);
+            const uint32_t m = *(reinterpret_cast<const uint32_t*>(lines + (size_t)line * LINE_BYTES) + META_DWORD);
+            if (m & BUILD_HEAVY) line = keyhash_line(tv, key);
+        } else {
+            line = keyhash_line(tv, key);
+        }
         for (;;) {
             uint8_t* base = lines + (size_t)line * LINE_BYTES;
-            const uint32_t slot = atomicAdd(reinterpret_cast<uint32_t*>(base) + META_DWORD, 1u);
+            const uint32_t slot = atomicAdd(reinterpret_cast<uint32_t*>(base) + META_DWORD, 1u) & BUILD_COUNT_MASK;
             if (slot < S) {
                 reinterpret_cast<uint64_t*>(base)[slot] = key;
                 if (WIDE)
@@ -58,14 +84,18 @@ __global__ void table_insert_kernel(uint8_t* lines, TableView tv, int32_t k, con
 }
 
 template <bool WIDE>
-__global__ void table_finalize_kernel(uint8_t* lines, uint32_t n_lines) {
+__global__ void table_finalize_kernel(uint8_t* lines, uint32_t n_lines, unsigned long long* stats) {
     constexpr uint32_t S = WIDE ? SLOTS_U32 : SLOTS_U16;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t stride = gridDim.x * blockDim.x;
     for (; i < n_lines; i += stride) {
         uint32_t* meta = reinterpret_cast<uint32_t*>(lines + (size_t)i * LINE_BYTES) + META_DWORD;
-        const uint32_t arrivals = *meta;
-        *meta = (arrivals > S) ? (S | META_OVERFLOW) : arrivals;
+        const uint32_t raw = *meta;
+        const uint32_t arrivals = raw & BUILD_COUNT_MASK;
+        // a HEAVY line also carries the overflow bit: probes that miss there stay pending and are redirected
+        *meta = ((arrivals > S) ? (S | META_OVERFLOW) : arrivals) | ((raw & BUILD_HEAVY) ? (META_HEAVY | META_OVERFLOW) : 0u);
+        if (raw & BUILD_HEAVY) atomicAdd(&stats[0], 1ull);      // heavy minimizer home lines
+        if (arrivals > S) atomicAdd(&stats[1], 1ull);           // overflowed lines
     }
 }
 
@@ -111,7 +141,8 @@ __global__ __launch_bounds__(256) void lookup_kernel(TableView tv, int32_t k, co
     const int lane = threadIdx.x & 63;
     for (int64_t i = gtid >> 3; i < n; i += stride) {     // (gtid >> 3) is uniform over each group of 8 lanes
         const uint64_t key = keys[i];
-        uint32_t line = home_line(tv, key, k);
+        uint32_t line = (tv.mode == MODE_MINIMIZER) ? minimizer_line(tv, key, k) : keyhash_line(tv, key);
+        bool at_home = (tv.mode == MODE_MINIMIZER);
         int32_t result = 0;
         for (;;) {
             const uint4 mine = reinterpret_cast<const uint4*>(tv.lines + (size_t)line * LINE_BYTES)[piece];
@@ -126,12 +157,9 @@ __global__ __launch_bounds__(256) void lookup_kernel(TableView tv, int32_t k, co
             }
             uint32_t c, meta;
             const bool any = match_line<WIDE, true>(q, key, c, meta);
-            if (any) {
-                result = (int32_t)c;        // Java int (KMC.java:395-401)
-                break;
-            }
-            if (!(meta & META_OVERFLOW)) break;
-            line = (line + 1 == tv.n_lines) ? 0 : line + 1;
+            if (any) result = (int32_t)c;        // Java int (KMC.java:395-401)
+            if (!probe_next(tv, at_home, any, meta, key, line)) break;
+            at_home = false;
         }
         if (piece == 0) out[i] = result;
     }
@@ -286,15 +314,24 @@ __global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __re
         // loops would be kept as SGPR masks and cost three scalar instructions per update and block.
         uint32_t st = valid ? 1u : 0u;          // 1 = pending, 2 = found, 0 = absent / invalid
         uint32_t cnt = 0;
+        uint32_t home_meta = 0;                 // meta dword of the line matched last (HEAVY check after round 0)
         if (VAR == 3) {
             cnt = (uint32_t)(key >> 60) + (tgt & 1);
             st = (key & 0x300) ? 2u : 0u;
         }
         // ---- cooperative probe rounds: each round fetches, for every run of adjacent pending lanes with the same
         //      target line, that line ONCE (8 lanes x 16 B = one 128-byte request) into wave-private LDS -------------
-        for (;;) {
+        for (int round = 0;; ++round) {
             const uint64_t P = __ballot(st == 1u);
             if (!P) break;
+            if (MINI && round == 1) {
+                // HEAVY minimizer home (table_finalize also sets its overflow bit, so such lanes are still pending):
+                // every k-mer homed there by minimizer lives at its key-hash line instead -- jump, do not walk
+                const bool redirect = (st == 1u) && (home_meta & META_HEAVY);
+                if (__ballot(redirect)) {
+                    if (redirect) tgt = keyhash_line(tv, key);
+                }
+            }
             const uint32_t prev_tgt = __shfl_up(tgt, 1, 64);
             const bool prev_pend = (P & lane_prev) != 0;
             const bool head = (st == 1u) && (!prev_pend || prev_tgt != tgt);
@@ -329,6 +366,7 @@ __global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __re
                 const uint32_t ntgt = (tgt + 1 == tv.n_lines) ? 0u : tgt + 1;
                 cnt = (mine && any) ? c : cnt;                              // Java int (KMC.java:395-401)
                 tgt = (mine && nst == 1u) ? ntgt : tgt;
+                home_meta = mine ? meta : home_meta;
                 st = mine ? nst : st;
                 wave_lds_fence();
             }
@@ -408,6 +446,17 @@ hipError_t launch_decode_records(const uint8_t* records, int64_t first_record, i
     return hipGetLastError();
 }
 
+hipError_t launch_table_count(uint8_t* lines, TableView tv, int32_t k, const uint64_t* keys, int64_t n, hipStream_t st) {
+    if (n <= 0 || tv.mode != MODE_MINIMIZER) return hipSuccess;
+    hipLaunchKernelGGL(table_count_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, tv, k, keys, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_table_mark_heavy(uint8_t* lines, uint32_t n_lines, hipStream_t st) {
+    hipLaunchKernelGGL(table_mark_heavy_kernel, dim3(grid_for(n_lines, 256)), dim3(256), 0, st, lines, n_lines);
+    return hipGetLastError();
+}
+
 hipError_t launch_table_insert(uint8_t* lines, TableView tv, int32_t k, const uint64_t* keys, const uint32_t* counts,
                                int64_t n, hipStream_t st) {
     if (n <= 0) return hipSuccess;
@@ -419,12 +468,12 @@ hipError_t launch_table_insert(uint8_t* lines, TableView tv, int32_t k, const ui
     return hipGetLastError();
 }
 
-hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide, hipStream_t st) {
+hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide, unsigned long long* stats, hipStream_t st) {
     const dim3 g(grid_for(n_lines, 256)), b(256);
     if (wide)
-        hipLaunchKernelGGL(table_finalize_kernel<true>, g, b, 0, st, lines, n_lines);
+        hipLaunchKernelGGL(table_finalize_kernel<true>, g, b, 0, st, lines, n_lines, stats);
     else
-        hipLaunchKernelGGL(table_finalize_kernel<false>, g, b, 0, st, lines, n_lines);
+        hipLaunchKernelGGL(table_finalize_kernel<false>, g, b, 0, st, lines, n_lines, stats);
     return hipGetLastError();
 }
 

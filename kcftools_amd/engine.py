@@ -36,7 +36,8 @@ class DbInfo(C.Structure):
                                           "version", "n_bins")] + \
                [("total_kmers", C.c_int64), ("table_bytes", C.c_int64), ("table_lines", C.c_int64),
                 ("slots_per_line", C.c_int32), ("device", C.c_int32), ("load_seconds", C.c_double),
-                ("table_mode", C.c_int32), ("minimizer_length", C.c_int32)]
+                ("table_mode", C.c_int32), ("minimizer_length", C.c_int32),
+                ("heavy_lines", C.c_int64), ("overflow_lines", C.c_int64)]
 
 
 class KcfxError(RuntimeError):

@@ -237,3 +237,36 @@ def test_async_device_output_on_torch_stream(oracle, tmp_path):
     assert_same(got, want, "async")
     odb = oracle.OracleDb(prefix)
     assert_same(got, odb.screen(ref, s, e - s, 1, threads=4), "async vs oracle")
+
+
+def test_low_complexity_repeats_take_the_heavy_bucket_path(oracle, tmp_path):
+    """Microsatellites / homopolymers put thousands of distinct k-mers under ONE minimizer. Those buckets are detected at
+    load time (kcfx_db_info.heavy_lines) and their k-mers re-homed by key hash, so results stay exact and a probe never
+    walks a long chain."""
+    k = 31
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    parts = []
+    for i in range(2500):
+        unit = [b"AT", b"A", b"CAG", b"TTAGGG", b"AC"][i % 5]
+        parts.append(bytes(acgt[rng.integers(0, 4, int(rng.integers(15, 60)))]))
+        parts.append((unit * 40)[: int(rng.integers(25, 70))])
+    ref = b"".join(parts)
+    sample = synth.mutate_sample(ref, 5, sub_rate=5e-3, indel_rate=5e-4, big_del_per_mb=0)
+    prm = synth.KmcParams(k=k, p=3, counter_size=2, sig_len=7, n_bins=4)
+    kmers, counts = synth.build_sample_db(sample, prm, 6, noise_kmers=3000)
+    prefix = str(tmp_path / "lowcomplex")
+    synth.write_kmc(prefix, kmers, counts, prm)
+    db = engine.KmcDb.open(prefix)
+    odb = oracle.OracleDb(prefix)
+    assert db.info.table_mode == 1 and db.info.heavy_lines > 0
+    assert np.array_equal(db.lookup(kmers), counts.astype(np.uint32).astype(np.int32))
+    s, e = engine.windows(len(ref), 5_000, 0, k)
+    got = db.screen(ref, s, e - s, 1)
+    want = odb.screen(ref, s, e - s, 1, threads=4)
+    assert_same(got, want, "low complexity")
+    assert got["obs"].sum() > 0.5 * got["total_kmers"].sum()
+    # the same through the array-built table
+    db2 = engine.KmcDb.build(kmers, counts, k, 2, True)
+    assert db2.info.heavy_lines > 0
+    assert_same(db2.screen(ref, s, e - s, 1), want, "low complexity (array build)")
