@@ -1,0 +1,237 @@
+// kcftools-amd getVariations -- command-line driver that keeps kcftools' `getVariations` option set
+// (Plugins/GetVariants.java:21-61) and flow (:92-183) around the C ABI of include/kcfx.h:
+//   KMC open -> header -> FASTA index -> (GTF) -> windows -> ONE kcfx_screen call (replaces the thread pool :129-159)
+//   -> Window.addTotalKmers/setEffLength/addData semantics (kcfx_score) -> sort -> KCF text.
+// Host side only; all k-mer work happens in libkcfx.so on the GPU.
+#include <sys/time.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../../../include/kcfx.h"
+#include "fasta_index.h"
+#include "gtf.h"
+#include "kcf_writer.h"
+
+using namespace kcfhost;
+
+namespace {
+const char* CLASS_NAME = "GetVariants";
+
+// Utils/Logger.java:14-32: "yyyy-MM-dd HH:mm:ss:SSS - LEVEL    - <class padded to 20> - msg"; ERROR exits with status 1
+void log_line(const char* level, const std::string& msg) {
+    timeval tv;
+    gettimeofday(&tv, nullptr);
+    std::tm tm;
+    localtime_r(&tv.tv_sec, &tm);
+    char ts[64];
+    std::strftime(ts, sizeof ts, "%Y-%m-%d %H:%M:%S", &tm);
+    std::printf("%s:%03d - %-8s - %-20s - %s\n", ts, (int)(tv.tv_usec / 1000), level, CLASS_NAME, msg.c_str());
+    std::fflush(stdout);
+}
+void info(const std::string& m) { log_line("INFO", m); }
+void warning(const std::string& m) { log_line("WARNING", m); }
+[[noreturn]] void error(const std::string& m) {
+    log_line("ERROR", m);
+    std::exit(1);
+}
+
+struct Options {
+    std::string ref, kmc, out, sample, feature, gtf;
+    int threads = 2, window = 0, min_count = 1, step = 0, device = 0;
+    bool memory = false;
+    double wi = 0.3, wt = 0.3, wr = 0.4;
+};
+
+void usage() {
+    std::puts("Usage: kcftools-amd getVariations -r <ref.fa> -k <kmc prefix> -o <out.kcf> -s <sample> -f window|gene|transcript\n"
+              "       [-w window] [-p step] [-g gtf] [-c min-k-count] [--wi 0.3] [--wt 0.3] [--wr 0.4] [-t threads] [-m] [--device 0]");
+}
+
+struct Win {
+    std::string id, seq;
+    int32_t start, end;      // as printed (0-based half-open in window mode, raw 1-based GTF coordinates otherwise)
+    int64_t text_begin;
+    int32_t text_len;
+    size_t order;
+};
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc < 2 || std::strcmp(argv[1], "getVariations") != 0) {
+        usage();
+        return 2;
+    }
+    Options o;
+    std::string cmdline = "kcftools-amd";
+    for (int i = 1; i < argc; ++i) cmdline += std::string(" ") + argv[i];
+    for (int i = 2; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto val = [&]() -> std::string {
+            if (i + 1 >= argc) error("Missing value for option " + a);
+            return argv[++i];
+        };
+        if (a == "-r" || a == "--reference") o.ref = val();
+        else if (a == "-k" || a == "--kmc") o.kmc = val();
+        else if (a == "-o" || a == "--output") o.out = val();
+        else if (a == "-s" || a == "--sample") o.sample = val();
+        else if (a == "-f" || a == "--feature") o.feature = val();
+        else if (a == "-t" || a == "--threads") o.threads = std::atoi(val().c_str());
+        else if (a == "-m" || a == "--memory") o.memory = true;
+        else if (a == "--wi") o.wi = std::atof(val().c_str());
+        else if (a == "--wt") o.wt = std::atof(val().c_str());
+        else if (a == "--wr") o.wr = std::atof(val().c_str());
+        else if (a == "-w" || a == "--window") o.window = std::atoi(val().c_str());
+        else if (a == "-g" || a == "--gtf") o.gtf = val();
+        else if (a == "-c" || a == "--min-k-count") o.min_count = std::atoi(val().c_str());
+        else if (a == "-p" || a == "--step") o.step = std::atoi(val().c_str());
+        else if (a == "--device") o.device = std::atoi(val().c_str());
+        else if (a == "-h" || a == "--help") { usage(); return 0; }
+        else error("Unknown option: " + a);
+    }
+    if (o.ref.empty() || o.kmc.empty() || o.out.empty() || o.sample.empty() || o.feature.empty()) {
+        usage();
+        error("Missing required option (-r, -k, -o, -s, -f)");
+    }
+    // validateCMD (GetVariants.java:357-386)
+    if (o.feature == "window") {
+        if (o.window <= 0) error("Window size is required for window model");
+        if (!o.gtf.empty()) error("GTF file is not valid for window model");
+    } else if (o.feature == "gene" || o.feature == "transcript") {
+        if (o.gtf.empty()) error("GTF file is required for targeted model");
+        if (o.window > 0) error("Window size is not valid for targeted model");
+    } else {
+        error("Invalid model type: " + o.feature + ". Supported models are 'window' or 'gene' or 'transcript'");
+    }
+    if (o.threads <= 0) error("Number of threads should be greater than 0");
+    if (o.min_count < 1) error("Minimum kmer count should be at least 1");
+    // cleanSampleName (:392-401)
+    {
+        std::string clean = o.sample;
+        for (char& c : clean)
+            if (std::strchr("\\/:*?\"<>|", c)) c = '_';
+        if (clean != o.sample) warning("Sample name contains invalid characters, changed to: " + clean);
+        o.sample = clean;
+    }
+
+    // new KMC(prefix, loadMemory) (:95)
+    kcfx_db* db = nullptr;
+    if (kcfx_db_open(o.kmc.c_str(), o.device, &db)) error(kcfx_last_error());
+    kcfx_db_info_t dbi;
+    kcfx_db_info(db, &dbi);
+    const int k = dbi.kmer_length;
+    info("KMC database: k=" + std::to_string(k) + ", " + std::to_string(dbi.total_kmers) + " k-mers, table " +
+         std::to_string(dbi.table_bytes >> 20) + " MiB on device " + std::to_string(o.device));
+
+    FastaIndex index;
+    std::string err;
+    if (!index.open(o.ref, err)) error(err);
+    Gtf gtf;
+    const bool targeted = o.feature != "window";
+    if (targeted && !gtf.parse(o.gtf, err)) error(err);
+
+    info("Generating windows...");
+    KcfHeaderInfo hdr;
+    hdr.reference = o.ref;
+    hdr.sample = o.sample;
+    hdr.command_line = cmdline;
+    hdr.window = o.window;
+    hdr.step = o.step;
+    hdr.kmer = k;
+    hdr.wi = o.wi;
+    hdr.wt = o.wt;
+    hdr.wr = o.wr;
+
+    std::string text;
+    std::vector<Win> wins;
+    std::vector<std::pair<size_t, size_t>> per_contig;    // [first, last) into wins, in .faidx order
+    for (const auto& e : index.entries()) {
+        hdr.contigs.emplace_back(e.name, e.length);
+        const size_t first = wins.size();
+        if (!targeted) {
+            // getWindows "window" (:293-320) through the ABI, text = the contig once
+            int64_t n = 0;
+            if (kcfx_windows(e.length, o.window, o.step, k, nullptr, nullptr, 0, &n)) error(kcfx_last_error());
+            std::vector<int32_t> s((size_t)n), en((size_t)n);
+            if (n && kcfx_windows(e.length, o.window, o.step, k, s.data(), en.data(), n, &n)) error(kcfx_last_error());
+            const int64_t base = (int64_t)text.size();
+            if (e.length > 0) {
+                std::string seq;
+                if (!index.get_sequence(e, 0, e.length, seq, err)) error(err);
+                text += seq;
+            }
+            for (int64_t i = 0; i < n; ++i)
+                wins.push_back(Win{e.name + "_" + std::to_string(s[(size_t)i]), e.name, s[(size_t)i], en[(size_t)i], base + s[(size_t)i],
+                                   en[(size_t)i] - s[(size_t)i], wins.size()});
+        } else {
+            const bool is_gene = o.feature == "gene";
+            const auto genes = gtf.children(e.name);                       // gtf.getGenes(sequenceName)
+            if (!is_gene && genes.empty()) warning("No genes found in GTF file for sequence: " + e.name);   // :333-336
+            for (const auto& gene : genes) {
+                std::vector<std::string> ids;
+                if (is_gene) {
+                    ids.push_back(gene);
+                } else {
+                    ids = gtf.children(gene);
+                    if (ids.empty()) error("No transcripts found for gene: " + gene + " in GTF file for sequence: " + e.name);   // :339-342
+                }
+                for (const auto& id : ids) {
+                    const GtfFeature* f = gtf.feature(id);
+                    if (!f) error("Feature ID not found: " + id);                         // GTF.java:300-303
+                    std::vector<GtfLoci> loci;
+                    if (!gtf.merged_exon_loci(id, is_gene, loci)) error("Fasta object is null for window: " + id);   // :213-216
+                    const int64_t begin = (int64_t)text.size();
+                    for (const auto& l : loci) {
+                        const FaidxEntry* ce = index.find(l.chrom);
+                        if (!ce) error("Sequence not found in index: " + l.chrom);
+                        std::string seq;
+                        if (!index.get_sequence(*ce, (int64_t)l.start - 1, (int64_t)l.end - l.start + 1, seq, err)) error(err);   // GTF.java:242
+                        text += seq;
+                    }
+                    wins.push_back(Win{id, f->chrom, f->start, f->end, begin, (int32_t)((int64_t)text.size() - begin), wins.size()});
+                }
+            }
+        }
+        per_contig.emplace_back(first, wins.size());
+    }
+    info("Number of windows: " + std::to_string(wins.size()));
+
+    // the hot path: one call instead of the thread pool (:129-159)
+    const int32_t n = (int32_t)wins.size();
+    std::vector<int64_t> wb((size_t)n);
+    std::vector<int32_t> wl((size_t)n);
+    for (int32_t i = 0; i < n; ++i) {
+        wb[(size_t)i] = wins[(size_t)i].text_begin;
+        wl[(size_t)i] = wins[(size_t)i].text_len;
+    }
+    std::vector<kcfx_result> res((size_t)n);
+    if (kcfx_screen(db, reinterpret_cast<const uint8_t*>(text.data()), (int64_t)text.size(), wb.data(), wl.data(), n, o.min_count,
+                    res.data()))
+        error(kcfx_last_error());
+    std::vector<double> score((size_t)n), depth((size_t)n);
+    if (kcfx_score(res.data(), n, o.wi, o.wt, o.wr, score.data(), depth.data())) error(kcfx_last_error());   // Data.java:101-103
+
+    // sort each contig's windows by start (:169-171); ties keep generation order
+    hdr.n_windows = n;
+    std::ofstream out(o.out, std::ios::binary);
+    if (!out) error("Error writing KCF file: " + o.out);
+    info("Writing KCF file: " + o.out);
+    out << kcf_header_text(hdr);
+    for (const auto& pc : per_contig) {
+        std::vector<size_t> order;
+        for (size_t i = pc.first; i < pc.second; ++i) order.push_back(i);
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return wins[a].start < wins[b].start; });
+        for (size_t i : order)
+            out << kcf_row_text(wins[i].seq, wins[i].start, wins[i].end, wins[i].id, res[i], score[i], depth[i]) << "\n";
+    }
+    out.close();
+    kcfx_db_close(db);
+    return 0;
+}

@@ -1,0 +1,25 @@
+// kcf_writer.h -- KCF text as Data/KCFHeader.java:291-330, Data/Window.java:125-152,177-214 and Data/Data.java:120-132
+// render it for a single-sample getVariations run.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../../include/kcfx.h"
+
+namespace kcfhost {
+
+struct KcfHeaderInfo {
+    std::string reference, sample, command_line, date;   // date: yyyy-MM-dd (HelperFunctions.getTodayDate)
+    std::vector<std::pair<std::string, int32_t>> contigs;
+    int32_t window = 0, step = 0, kmer = 0, n_windows = 0;
+    double wi = 0.3, wt = 0.3, wr = 0.4;
+};
+
+std::string kcf_header_text(const KcfHeaderInfo& h);
+std::string kcf_row_text(const std::string& seq, int32_t start, int32_t end, const std::string& id, const kcfx_result& r,
+                         double score, double mean_count);
+std::string today();
+
+}  // namespace kcfhost

@@ -305,3 +305,55 @@ def tiling_windows(seq_len: int, window: int, k: int, step: int = 0) -> tuple[np
                 ends.append(e)
             last_end = e
     return np.asarray(starts, dtype=np.int64), np.asarray(ends, dtype=np.int64)
+
+
+def random_gtf(path: str, contigs: list[tuple[str, int]], seed: int, genes_per_mb: float = 200.0,
+               with_gene_lines: bool = True) -> None:
+    """Synthetic GTF (SURVEY 8d config 3 style): genes with 1-3 transcripts (overlapping isoforms sharing exons),
+    1-8 exons of 50-900 bp, both strands; optionally without `gene` lines (GTF.java:61-68 synthesises them); plus
+    feature types the parser must skip (CDS, start_codon) and a comment / blank line."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    lines = ["# synthetic annotation", ""]
+    gid = 0
+    for name, length in contigs:
+        n_genes = max(1, int(length / 1e6 * genes_per_mb))
+        starts = np.sort(rng.integers(1, max(2, length - 6000), size=n_genes))
+        for gs in starts:
+            gid += 1
+            strand = "+-"[int(rng.integers(0, 2))]
+            gene = f"G{gid:05d}"
+            kind = "pseudogene" if rng.random() < 0.1 else "gene"
+            n_tx = int(rng.integers(1, 4))
+            # shared exon pool
+            n_ex = int(rng.integers(1, 9))
+            pos = int(gs)
+            pool = []
+            for _ in range(n_ex):
+                el = int(rng.integers(50, 900))
+                if pos + el >= length:
+                    break
+                pool.append((pos, pos + el - 1))
+                pos += el + int(rng.integers(30, 600))
+            if not pool:
+                continue
+            gene_end = pool[-1][1]
+            recs = []
+            for t in range(n_tx):
+                tx = f"{gene}.t{t + 1}"
+                keep = [e for e in pool if rng.random() < 0.8] or [pool[0]]
+                # isoform-specific boundary shifts create overlapping, non-identical exons
+                ex = [(max(1, s - int(rng.integers(0, 20)) * (rng.random() < 0.3)), min(length, e + int(rng.integers(0, 20)) * (rng.random() < 0.3))) for s, e in keep]
+                ttype = ["transcript", "mRNA", "lnc_RNA"][int(rng.integers(0, 3))]
+                recs.append((tx, ttype, ex))
+                gene_end = max(gene_end, max(e for _, e in ex))
+            if with_gene_lines:
+                lines.append(f'{name}\tsynth\t{kind}\t{pool[0][0]}\t{gene_end}\t.\t{strand}\t.\tgene_id "{gene}";')
+            for tx, ttype, ex in recs:
+                ts, te = min(s for s, _ in ex), max(e for _, e in ex)
+                lines.append(f'{name}\tsynth\t{ttype}\t{ts}\t{te}\t.\t{strand}\t.\tgene_id "{gene}"; transcript_id "{tx}";')
+                for s, e in ex:
+                    lines.append(f'{name}\tsynth\texon\t{s}\t{e}\t.\t{strand}\t.\tgene_id "{gene}"; transcript_id "{tx}";')
+                    if rng.random() < 0.3:
+                        lines.append(f'{name}\tsynth\tCDS\t{s}\t{e}\t.\t{strand}\t0\tgene_id "{gene}"; transcript_id "{tx}";')
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")

@@ -1,0 +1,104 @@
+"""End-to-end: the `kcftools-amd getVariations` driver (option set of GetVariants.java:21-61) on the golden FASTA + KMC
+database, against KCF text assembled from the oracle's integers with the Python restatement of the KCF writer.
+Everything except the ##date and ##CMD header lines must be byte-identical."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from kcftools_amd import synth
+from oracle import pyhost
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+CLI = os.path.join(ROOT, "kcftools_amd", "bin", "kcftools-amd")
+DB = "db_canon_k31_p3_cs2_m9"
+
+
+def run_cli(args, expect_rc=0):
+    p = subprocess.run([CLI, "getVariations"] + args, capture_output=True, text=True)
+    assert p.returncode == expect_rc, p.stdout + p.stderr
+    return p.stdout
+
+
+def strip_volatile(text):
+    return "\n".join(l for l in text.split("\n") if not l.startswith("##date=") and not l.startswith("##CMD="))
+
+
+def expected_kcf(oracle, fa, windows, sample, window, step, min_count, weights=(0.3, 0.3, 0.4)):
+    """windows: list of (seq, start, end, id, text_bytes) in output order"""
+    odb = oracle.OracleDb(os.path.join(G, DB))
+    entries = pyhost.generate_faidx(fa)
+    rows = []
+    for seq, s, e, wid, text in windows:
+        res = odb.process_window(text, min_count)
+        sc, md, _ = oracle.score(res, *weights)
+        rows.append(pyhost.kcf_row(seq, s, e, wid, res, sc, md))
+    hdr = pyhost.kcf_header(fa, [(n, l) for n, l, *_ in entries], sample, window, step, 31, len(windows), *weights, "x", "d")
+    return strip_volatile(hdr + "\n".join(rows) + "\n")
+
+
+def test_window_mode(oracle, tmp_path):
+    fa = str(tmp_path / "ref.fa")
+    shutil.copy(os.path.join(G, "ref.fa"), fa)
+    data = open(fa, "rb").read()
+    entries = pyhost.generate_faidx(fa)
+    for window, step, mc in ((2000, 0, 1), (5000, 1250, 2)):
+        out = str(tmp_path / f"o_{window}_{step}.kcf")
+        args = ["-r", fa, "-k", os.path.join(G, DB), "-o", out, "-s", "my/sample", "-f", "window", "-w", str(window), "-c", str(mc)]
+        if step:
+            args += ["-p", str(step)]
+        log = run_cli(args)
+        assert "changed to: my_sample" in log
+        wins = []
+        for ent in entries:
+            s, e = synth.tiling_windows(ent[1], window, 31, step)
+            for a, b in zip(s, e):
+                wins.append((ent[0], int(a), int(b), f"{ent[0]}_{a}", pyhost.get_sequence(data, ent, int(a), int(b - a))))
+        assert strip_volatile(open(out).read()) == expected_kcf(oracle, fa, wins, "my_sample", window, step, mc)
+        head = open(out).read().split("\n")
+        assert head[0] == "##format=KCF0.4.0" and any(l.startswith("##CMD=kcftools-amd getVariations -r ") for l in head)
+
+
+@pytest.mark.parametrize("feature", ["gene", "transcript"])
+def test_gene_and_transcript_mode(oracle, tmp_path, feature):
+    fa = str(tmp_path / "ref.fa")
+    shutil.copy(os.path.join(G, "ref.fa"), fa)
+    data = open(fa, "rb").read()
+    entries = pyhost.generate_faidx(fa)
+    gtf = str(tmp_path / "a.gtf")
+    synth.random_gtf(gtf, [(e[0], e[1]) for e in entries], 9, genes_per_mb=1500, with_gene_lines=(feature == "gene"))
+    out = str(tmp_path / "o.kcf")
+    run_cli(["-r", fa, "-k", os.path.join(G, DB), "-o", out, "-s", "S", "-f", feature, "-g", gtf, "--wi", "0.25", "--wt", "0.25", "--wr", "0.5"])
+    model = pyhost.Gtf(gtf)
+    by_name = {e[0]: e for e in entries}
+    wins = []
+    for ent in entries:
+        cw = []
+        for gene in model.kids(ent[0]):
+            for fid in ([gene] if feature == "gene" else model.kids(gene)):
+                c, s, e, _ = model.loci(fid)
+                loci = model.merged_exon_loci(fid, feature == "gene")
+                text = b"".join(pyhost.get_sequence(data, by_name[l[0]], l[1] - 1, l[2] - l[1] + 1) for l in loci)
+                cw.append((c, s, e, fid, text))
+        cw.sort(key=lambda w: w[1])            # GetVariants.java:169-171 (stable; ties keep generation order here)
+        wins += cw
+    assert len(wins) > 20
+    assert strip_volatile(open(out).read()) == expected_kcf(oracle, fa, wins, "S", 0, 0, 1, (0.25, 0.25, 0.5))
+
+
+def test_cli_validation_errors(tmp_path):
+    fa = os.path.join(G, "ref.fa")
+    base = ["-r", fa, "-k", os.path.join(G, DB), "-o", str(tmp_path / "x.kcf"), "-s", "S"]
+    for extra, msg in ((["-f", "window"], "Window size is required"), (["-f", "window", "-w", "1000", "-g", "a.gtf"], "GTF file is not valid"),
+                       (["-f", "gene"], "GTF file is required"), (["-f", "gene", "-g", "a.gtf", "-w", "5"], "Window size is not valid"),
+                       (["-f", "exon", "-w", "10"], "Invalid model type"), (["-f", "window", "-w", "1000", "-c", "0"], "at least 1"),
+                       (["-f", "window", "-w", "1000", "-t", "0"], "greater than 0"), (["-f", "window", "-w", "20"], "window size must exceed"),
+                       (["-f", "window", "-w", "1000", "--wi", "0.5"], "Weights should sum to 1.0")):
+        log = run_cli(base + extra, expect_rc=1)
+        assert msg in log and " - ERROR " in log
+    log = run_cli(["-r", fa, "-k", str(tmp_path / "nodb"), "-o", str(tmp_path / "x.kcf"), "-s", "S", "-f", "window", "-w", "1000"], expect_rc=1)
+    assert "Error reading prefix file" in log

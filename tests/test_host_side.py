@@ -1,0 +1,147 @@
+"""Host-side rows beside the hot path: Java number formats, .faidx index, GTF windows and KCF
+text of the C++ driver (kcftools_amd/csrc/host/, driven through libkcfhost.so) against the Python restatement of the
+cited Java lines (oracle/pyhost.py). PARITY UNPINNED: neither side is the reference."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from kcftools_amd import synth
+from oracle import pyhost
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def host():
+    so = os.path.join(ROOT, "kcftools_amd", "libkcfhost.so")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "kcftools_amd", "csrc"), "../libkcfhost.so"], check=True, capture_output=True)
+    L = C.CDLL(so)
+    for f in ("kcfh_fmt_2f", "kcfh_double_to_string", "kcfh_float_to_string", "kcfh_faidx", "kcfh_get_sequence",
+              "kcfh_gtf_windows", "kcfh_header", "kcfh_row"):
+        getattr(L, f).restype = C.c_char_p
+    L.kcfh_fmt_2f.argtypes = [C.c_double]
+    L.kcfh_double_to_string.argtypes = [C.c_double]
+    L.kcfh_float_to_string.argtypes = [C.c_float]
+    L.kcfh_faidx.argtypes = [C.c_char_p, C.POINTER(C.c_char_p)]
+    L.kcfh_get_sequence.argtypes = [C.c_char_p, C.c_char_p, C.c_long, C.c_long, C.POINTER(C.c_char_p)]
+    L.kcfh_gtf_windows.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p)]
+    return L
+
+
+def test_java_number_formats(host):
+    # known Java outputs: HALF_UP on the shortest repr, not on the binary value ("Text parity")
+    known = {2.125: "2.13", 1.005: "1.01", 0.125: "0.13", 0.375: "0.38", 100.0: "100.00", 0.0: "0.00", 87.36923076923078: "87.37",
+             -236.84615384615378: "-236.85", 1.401298464324817e-45: "0.00", 1234567.891: "1234567.89", 0.995: "1.00", 9.995: "10.00",
+             99.995: "100.00", 0.004999: "0.00", 0.005: "0.01", -0.001: "-0.00", 6314.0: "6314.00", 15.498540678: "15.50"}
+    for x, want in known.items():
+        assert host.kcfh_fmt_2f(x).decode() == want, x
+        assert pyhost.java_fmt_2f(x) == want, x
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.random(3000) * 100, rng.random(500) * 1e6, -rng.random(300) * 300, np.round(rng.random(3000) * 100, 3),
+                         rng.integers(0, 100000, 500) / 8.0])
+    for x in xs:
+        assert host.kcfh_fmt_2f(float(x)).decode() == pyhost.java_fmt_2f(float(x)), x
+    dbl = {0.3: "0.3", 0.4: "0.4", 1.0: "1.0", 0.25: "0.25", 1e7: "1.0E7", 1234567.0: "1234567.0", 0.001: "0.001", 0.0001: "1.0E-4",
+           0.1 + 0.2: "0.30000000000000004", 123456789.0: "1.23456789E8", 0.0: "0.0"}
+    for x, want in dbl.items():
+        assert host.kcfh_double_to_string(x).decode() == want, x
+        assert pyhost.java_double_to_string(x) == want, x
+    flt = {62.0: "62.0", 0.0: "0.0", 1.5: "1.5", 1e7: "1.0E7", 9999999.0: "9999999.0", 0.1: "0.1", 3.0: "3.0", 1234.5: "1234.5"}
+    for x, want in flt.items():
+        assert host.kcfh_float_to_string(x).decode() == want, x
+        assert pyhost.java_float_to_string(x) == want, x
+
+
+def test_faidx_and_get_sequence(host, tmp_path):
+    fa = str(tmp_path / "ref.fa")
+    shutil.copy(os.path.join(G, "ref.fa"), fa)
+    out = C.c_char_p()
+    assert host.kcfh_faidx(fa.encode(), C.byref(out)) == b""
+    entries = pyhost.generate_faidx(fa)
+    assert out.value.decode() == pyhost.faidx_text(entries)
+    assert [e[0] for e in entries] == ["chrA", "chrB", "scaffold_3"]          # name = header up to the first space
+    assert [e[1] for e in entries] == [23456, 9031, 1207] and entries[0][3:] == (60, 61)
+    data = open(fa, "rb").read()
+    seqs = [b"".join(x.split(b"\n")[1:]) for x in data.split(b">")[1:]]
+    rng = np.random.default_rng(1)
+    for ent, seq in zip(entries, seqs):
+        for _ in range(40):
+            s = int(rng.integers(0, ent[1]))
+            l = int(rng.integers(1, ent[1] - s + 1))
+            assert host.kcfh_get_sequence(fa.encode(), ent[0].encode(), s, l, C.byref(out)) == b""
+            assert out.value == seq[s:s + l] == pyhost.get_sequence(data, ent, s, l)
+        assert host.kcfh_get_sequence(fa.encode(), ent[0].encode(), 0, ent[1], C.byref(out)) == b"" and out.value == seq
+        assert b"Invalid range" in host.kcfh_get_sequence(fa.encode(), ent[0].encode(), ent[1] - 5, 6, C.byref(out))
+    assert os.path.exists(fa + ".faidx") and open(fa + ".faidx").read() == pyhost.faidx_text(entries)
+    # rejected inputs (the reference logs an error and exits)
+    bad = str(tmp_path / "bad.fa")
+    open(bad, "w").write(">x\nACGT!\n")
+    assert b"Invalid character" in host.kcfh_faidx(bad.encode(), C.byref(out))
+    open(bad, "w").write(">x\nACGT\n>x\nAC\n")
+    assert b"Duplicate sequence name" in host.kcfh_faidx(bad.encode(), C.byref(out))
+    open(bad, "w").write("ACGT\n")
+    assert b"Invalid fasta file" in host.kcfh_faidx(bad.encode(), C.byref(out))
+
+
+@pytest.mark.parametrize("with_gene_lines", [True, False])
+def test_gtf_windows(host, tmp_path, with_gene_lines):
+    contigs = [("chrA", 23456), ("chrB", 9031), ("scaffold_3", 1207)]
+    gtf = str(tmp_path / "a.gtf")
+    synth.random_gtf(gtf, contigs, 5, genes_per_mb=900, with_gene_lines=with_gene_lines)
+    model = pyhost.Gtf(gtf)
+    out = C.c_char_p()
+    total = 0
+    for chrom, _ in contigs:
+        for is_gene in (1, 0):
+            assert host.kcfh_gtf_windows(gtf.encode(), chrom.encode(), is_gene, C.byref(out)) == b""
+            want = []
+            for gene in model.kids(chrom):
+                for fid in ([gene] if is_gene else model.kids(gene)):
+                    c, s, e, _ = model.loci(fid)
+                    loci = model.merged_exon_loci(fid, bool(is_gene)) or []
+                    want.append(f"{fid}\t{c}\t{s}\t{e}\t" + ";".join(f"{l[0]}:{l[1]}-{l[2]}[{l[3]}]" for l in loci))
+            got = out.value.decode().splitlines()
+            assert got == want
+            total += len(got)
+    assert total > 30
+    # merged loci are disjoint and sorted; isoforms made them overlap before merging
+    for gene in model.kids("chrA"):
+        m = model.merged_exon_loci(gene, True)
+        assert all(a[2] < b[1] for a, b in zip(m[:-1], m[1:]))
+
+
+def test_kcf_text(host):
+    names = (C.c_char_p * 2)(b"chrA", b"chrB")
+    lens = (C.c_int * 2)(23456, 9031)
+    host.kcfh_header.argtypes = [C.c_char_p] * 4 + [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int)] + [C.c_int] * 4 + [C.c_double] * 3
+    got = host.kcfh_header(b"ref.fa", b"S1", b"kcftools-amd getVariations -r ref.fa", b"2026-01-02", 2, names, lens, 10000, 0, 31, 5,
+                           0.3, 0.3, 0.4).decode()
+    want = pyhost.kcf_header("ref.fa", [("chrA", 23456), ("chrB", 9031)], "S1", 10000, 0, 31, 5, 0.3, 0.3, 0.4,
+                             "kcftools-amd getVariations -r ref.fa", "2026-01-02")
+    assert got == want
+    assert got.count("##INFO=") == 10 and got.count("##FORMAT=") == 8 and "##PARAM=<ID=wtk,value=0.4>" in got
+    assert got.splitlines()[0] == "##format=KCF0.4.0" and got.endswith("\tFORMAT\tS1\n")
+
+    class R(C.Structure):
+        _fields_ = [(n, C.c_int32) for n in ("total", "eff", "obs", "var", "inner", "left", "right", "pad")] + [("sum", C.c_int64)]
+    host.kcfh_row.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(R), C.c_double, C.c_double]
+    rng = np.random.default_rng(2)
+    for _ in range(300):
+        total = int(rng.integers(0, 20000))
+        obs = int(rng.integers(0, total + 1))
+        r = R(total, total + 30, obs, int(rng.integers(0, 300)), int(rng.integers(0, 5000)), int(rng.integers(0, 100)),
+              int(rng.integers(0, 100)), 0, obs * int(rng.integers(1, 50)))
+        res = dict(total_kmers=r.total, eff_length=r.eff, obs=r.obs, var=r.var, inner=r.inner, left=r.left, right=r.right)
+        score = float(rng.normal(60, 60)) if obs else 0.0
+        mean = r.sum / obs if obs else 0.0
+        got = host.kcfh_row(b"chrA", 100, 10100, b"chrA_100", C.byref(r), score, mean).decode()
+        assert got == pyhost.kcf_row("chrA", 100, 10100, "chrA_100", res, score, mean)
+    # XS quirk: maxScore starts at Float.MIN_VALUE, so a non-positive score prints XS=0.00 (Window.java:185,205-207)
+    r = R(100, 130, 50, 50, 1372, 0, 1, 0, 150)
+    row = host.kcfh_row(b"c", 0, 130, b"c_0", C.byref(r), -236.84615384615378, 3.0).decode()
+    assert "IS=-236.85;XS=0.00;MS=-236.85" in row and row.endswith("N:50:50:1372:0:1:3.00:-236.85") and ";MV=50.0\t" in row
