@@ -66,9 +66,9 @@ def test_sharded_run_equals_single_process(tmp_path, world, n_samples, mode):
     procs = [ctx.Process(target=worker, args=(r, world, port, str(tmp_path), n_samples, mode, q)) for r in range(world)]
     for p in procs:
         p.start()
-    parts = q.get(timeout=120)
+    parts = q.get(timeout=600)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=300)
         assert p.exitcode == 0
     ref, prefixes, wb, wl = make_inputs(str(tmp_path), n_samples)
     if mode == "samples":
