@@ -93,16 +93,28 @@ KCFX_HD uint32_t brev32(uint32_t x) {
 #endif
 }
 
+// 32 bits of an MSB-first bit stream starting at bit `bitpos` (>= 0). The stream's array must have ONE readable word in
+// front of index 0: the two words are chosen so that the shift lands in 0..31 and maps onto a single v_alignbit_b32
+// (a left funnel shift by 0 would need its own case; a shift by 32 does not).
+KCFX_HD uint32_t alignbit32(uint32_t hi, uint32_t lo, uint32_t sh) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+    return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sh & 31));
+#endif
+}
+KCFX_HD uint32_t bits_at(const uint32_t* a, int bitpos) {
+    const int b = bitpos - 1;
+    const int w = b >> 5;                                   // -1 for bitpos 0
+    return alignbit32(a[w], a[w + 1], 31u - (uint32_t)(b & 31));
+}
+
 // `len` bases starting at packed base position q as left-aligned words: fwd (Kmer.java:232-252) and its reverse
 // complement (Kmer.java:300-338), from the forward code array fw and the complement-swapped array cw (MSB first).
 KCFX_HD void extract_pair(const uint32_t* fw, const uint32_t* cw, int q, int len, uint64_t& fwd, uint64_t& rc) {
-    const int w = q >> 4;
-    const uint32_t s = (uint32_t)(q & 15) * 2;
-    const uint32_t f0 = fw[w], f1 = fw[w + 1], f2 = fw[w + 2];
-    const uint32_t g0 = cw[w], g1 = cw[w + 1], g2 = cw[w + 2];
     const uint64_t mask = ~0ull << (64 - 2 * len);          // top 2*len bits
-    fwd = ((((uint64_t)fshl(f0, f1, s)) << 32) | fshl(f1, f2, s)) & mask;
-    const uint64_t y = ((((uint64_t)fshl(g0, g1, s)) << 32) | fshl(g1, g2, s)) & mask;
+    fwd = ((((uint64_t)bits_at(fw, 2 * q)) << 32) | bits_at(fw, 2 * q + 32)) & mask;
+    const uint64_t y = ((((uint64_t)bits_at(cw, 2 * q)) << 32) | bits_at(cw, 2 * q + 32)) & mask;
     // bit-reverse the 64-bit word: reverses the base order and swaps the bits of every pair back
     const uint64_t r = (((uint64_t)brev32((uint32_t)y)) << 32) | brev32((uint32_t)(y >> 32));
     rc = r << (64 - 2 * len);
@@ -110,9 +122,7 @@ KCFX_HD void extract_pair(const uint32_t* fw, const uint32_t* cw, int q, int len
 
 // all k bases starting at q are A/C/G/T (validity bits vb, MSB first)
 KCFX_HD bool kmer_valid(const uint32_t* vb, int q, int k) {
-    const int w2 = q >> 5;
-    const uint32_t v = fshl(vb[w2], vb[w2 + 1], (uint32_t)(q & 31));
-    return (v >> (32 - k)) == (uint32_t)((1ull << k) - 1);
+    return (bits_at(vb, q) >> (32 - k)) == (uint32_t)((1ull << k) - 1);
 }
 
 KCFX_HD bool extract_kmer(const uint32_t* fw, const uint32_t* cw, const uint32_t* vb, int q, int k, uint64_t& fwd,
@@ -172,6 +182,40 @@ KCFX_HD bool probe_next(const TableView& tv, bool at_home, bool found, uint32_t 
 constexpr uint64_t EMPTY_KEY = ~0ull;
 
 KCFX_HD uint64_t u64_of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+
+// Same as match_line below, reading the line from LDS piece by piece so that at most two 16-byte pieces are live
+// (keeps screen_tiles at <= 64 VGPRs = 8 waves per SIMD). `src` points at the line's 8 pieces.
+template <bool WIDE, bool CHECK_NS>
+__device__ __forceinline__ bool match_line_lds(const uint4* src, uint64_t key, uint32_t& count, uint32_t& meta) {
+    const uint4 tail = src[7];
+    meta = tail.z;
+    const uint32_t ns = CHECK_NS ? (meta & 0xFFu) : 0xFFu;
+    uint32_t c = 0;
+    bool any = false, odd = false;
+    constexpr int KP = WIDE ? 5 : 6;                          // pieces that hold keys
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+        const uint4 p = src[i];
+        const bool m0 = u64_of(p.x, p.y) == key && ns > (uint32_t)(2 * i);
+        const bool m1 = u64_of(p.z, p.w) == key && ns > (uint32_t)(2 * i + 1);
+        uint32_t cw;                                          // the dword(s) holding this pair's counts
+        if (!WIDE) {
+            const uint4 cp = (i < 4) ? src[6] : tail;
+            cw = (i == 0) ? cp.x : (i == 1) ? cp.y : (i == 2) ? cp.z : (i == 3) ? cp.w : (i == 4) ? cp.x : cp.y;
+            c = (m0 | m1) ? cw : c;
+            odd |= m1;
+        } else {
+            const uint4 cp = (i < 2) ? src[5] : (i < 4) ? src[6] : tail;
+            const uint32_t c0 = (i & 1) ? cp.z : cp.x, c1 = (i & 1) ? cp.w : cp.y;
+            c = m0 ? c0 : c;
+            c = m1 ? c1 : c;
+        }
+        any |= m0 | m1;
+    }
+    if (!WIDE) c = odd ? (c >> 16) : (c & 0xFFFFu);
+    count = c;
+    return any;
+}
 
 template <bool WIDE, bool CHECK_NS>
 KCFX_HD bool match_line(const uint4 (&q)[8], uint64_t key, uint32_t& count, uint32_t& meta) {

@@ -197,23 +197,25 @@ __device__ __forceinline__ void wave_lds_fence() {
 //
 // KT = 31: k = 31 and M = 16 are compile-time constants (the BASELINE.json configuration); KT = 0: any k <= 32 / M.
 template <bool WIDE, int MODE, int KT, int VAR>
-__global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __restrict__ text,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void screen_tiles_kernel(const uint8_t* __restrict__ text,
                                                              const TileDesc* __restrict__ tiles, TableView tv,
                                                              int32_t k_rt, int32_t both_strands, int32_t min_count,
                                                              uint64_t* __restrict__ bits,
                                                              int64_t* __restrict__ count_sums) {
     constexpr bool MINI = (MODE == MODE_MINIMIZER);
     constexpr int LINEBUF_U32 = WAVES * RUN_CHUNK * LINE_STRIDE * 4;
-    // k = 31 / M = 16: four sliding-minimum steps, the result ends in s_ha and the line buffers reuse s_hb.
-    // Generic k / M: the step count varies, so both arrays are sized for either role.
-    constexpr int HMIN = TILE_K + 64;
+    // s_ha: M-mer hashes, then prefix minima, then (dead) the fetched table lines; s_hb: suffix minima, then minimizers
+    constexpr int HMIN = TILE_K + 96;                      // + (wlen - 1) + padding of the last block (wlen <= 32)
     constexpr int HBIG = HMIN > LINEBUF_U32 ? HMIN : LINEBUF_U32;
-    constexpr int HLEN = MINI ? (KT ? HMIN : HBIG) : 1;
-    __shared__ uint32_t s_fw[2 * (MAX_CHUNKS + 2)];
-    __shared__ uint32_t s_cw[2 * (MAX_CHUNKS + 2)];
-    __shared__ uint32_t s_vb[MAX_CHUNKS + 2];
-    __shared__ uint32_t s_ha[HLEN];                        // sliding-minimum ping
-    __shared__ __attribute__((aligned(16))) uint32_t s_hb[MINI ? HBIG : LINEBUF_U32];   // pong, then line buffers
+    constexpr int HLEN = MINI ? HBIG : LINEBUF_U32;
+    __shared__ uint32_t s_fwx[2 * (MAX_CHUNKS + 2) + 1];   // [0] is the lead word bits_at may touch
+    __shared__ uint32_t s_cwx[2 * (MAX_CHUNKS + 2) + 1];
+    __shared__ uint32_t s_vbx[MAX_CHUNKS + 2 + 1];
+    uint32_t* const s_fw = s_fwx + 1;
+    uint32_t* const s_cw = s_cwx + 1;
+    uint32_t* const s_vb = s_vbx + 1;
+    __shared__ __attribute__((aligned(16))) uint32_t s_ha[HLEN];
+    __shared__ __attribute__((aligned(16))) uint32_t s_hb[MINI ? HMIN : 1];
     __shared__ uint32_t s_runline[WAVES][65];              // line index of each run, per wave (+1 dummy slot)
     __shared__ int64_t s_sum[WAVES];
 
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __re
     const int off = (int)(td.text_off - a0);
     const int nbases = off + td.n_kmers + k - 1;
     const int nchunks = (nbases + 31) >> 5;
+    if (tid == 0) s_fwx[0] = s_cwx[0] = s_vbx[0] = 0;
     for (int c = tid; c < nchunks + 2; c += BLOCK) {
         uint32_t f0 = 0, f1 = 0, v0 = 0, v1 = 0;
         if (c < nchunks) {
@@ -244,43 +247,76 @@ __global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __re
     }
     __syncthreads();
 
-    // ---- phase 1b (minimizer mode): h[p] = hash of the canonical M-mer at p, then a log-step sliding minimum:
-    //      after the steps F[p] = min h[p .. p+p2-1] (p2 = largest power of two <= wlen); a k-mer's minimizer is
-    //      min(F[j], F[j + wlen - p2]) -- two LDS reads in the main loop instead of wlen ------------------------
-    const uint32_t* s_fin = s_ha;                          // final sliding-minimum array
-    uint4* s_line = reinterpret_cast<uint4*>(s_hb);        // [WAVES][RUN_CHUNK][8] fetched lines
-    int p2 = 1;
+    // ---- phase 1b (minimizer mode): h[p] = hash of the canonical M-mer at p, then the sliding minimum over the
+    //      wlen M-mers of every k-mer in ~3 min per element (van Herk / Gil-Werman): per block of wlen positions
+    //      running prefix minima (in place) and suffix minima; window [p, p+wlen-1] = min(suffix[p], prefix[p+wlen-1]).
+    //      The result lands in s_hb; s_ha is dead afterwards and holds the fetched table lines. -----------------------
+    const uint32_t* s_fin = s_hb;                          // minimizer (minimum hash) of the k-mer at each position
+    uint4* s_line = reinterpret_cast<uint4*>(s_ha);        // [WAVES][RUN_CHUNK][LINE_STRIDE] fetched lines
     if (MINI) {
         const int n_m = td.n_kmers + wlen - 1;             // every M-mer of every k-mer of the tile
-        for (int p = tid; p < n_m; p += BLOCK) {
-            if (KT) {            // M = 16: the M-mer is one dword; same value as mmer_hash on the left-aligned words
-                const int q = off + p, w = q >> 4;
-                const uint32_t sh = (uint32_t)(q & 15) * 2;
-                const uint32_t f = fshl(s_fw[w], s_fw[w + 1], sh), r = brev32(fshl(s_cw[w], s_cw[w + 1], sh));
-                s_ha[p] = hash32(((uint64_t)min(f, r)) << 32);
+        const int n_blk = (n_m + wlen - 1) / wlen;
+        for (int p = tid; p < n_blk * wlen; p += BLOCK) {
+            uint32_t h = 0xFFFFFFFFu;                      // padding of the last block
+            if (p < n_m) {
+                if (KT) {    // M = 16: the M-mer is one dword; same value as mmer_hash on the left-aligned words
+                    const uint32_t f = bits_at(s_fw, 2 * (off + p)), r = brev32(bits_at(s_cw, 2 * (off + p)));
+                    h = hash32(((uint64_t)min(f, r)) << 32);
+                } else {
+                    uint64_t f, r;
+                    extract_pair(s_fw, s_cw, off + p, M, f, r);
+                    h = mmer_hash(f, r);
+                }
+            }
+            s_ha[p] = h;
+        }
+        __syncthreads();
+        for (int b = tid; b < n_blk; b += BLOCK) {
+            const int base = b * wlen;
+            if (KT) {                                      // wlen = 16: one lane scans its block in registers
+                uint32_t v[16];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint4 x = *reinterpret_cast<const uint4*>(&s_ha[base + 4 * i]);
+                    v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
+                }
+                // suffix minima first (written out four at a time), then prefix minima in place: ~20 live registers
+                uint32_t run = 0xFFFFFFFFu;
+#pragma unroll
+                for (int i = 3; i >= 0; --i) {
+                    uint4 o;
+                    o.w = run = min(run, v[4 * i + 3]);
+                    o.z = run = min(run, v[4 * i + 2]);
+                    o.y = run = min(run, v[4 * i + 1]);
+                    o.x = run = min(run, v[4 * i]);
+                    *reinterpret_cast<uint4*>(&s_hb[base + 4 * i]) = o;
+                }
+#pragma unroll
+                for (int i = 1; i < 16; ++i) v[i] = min(v[i], v[i - 1]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<uint4*>(&s_ha[base + 4 * i]) = make_uint4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
             } else {
-                uint64_t f, r;
-                extract_pair(s_fw, s_cw, off + p, M, f, r);
-                s_ha[p] = mmer_hash(f, r);
+                uint32_t run = 0xFFFFFFFFu;
+                for (int i = wlen - 1; i >= 0; --i) {
+                    run = min(run, s_ha[base + i]);
+                    s_hb[base + i] = run;
+                }
+                run = 0xFFFFFFFFu;
+                for (int i = 0; i < wlen; ++i) {
+                    run = min(run, s_ha[base + i]);
+                    s_ha[base + i] = run;
+                }
             }
         }
         __syncthreads();
-        uint32_t* src = s_ha;
-        uint32_t* dst = s_hb;
-        while (p2 * 2 <= wlen) {
-            for (int p = tid; p < n_m; p += BLOCK) dst[p] = min(src[p], src[min(p + p2, n_m - 1)]);
-            __syncthreads();
-            uint32_t* t = src;
-            src = dst;
-            dst = t;
-            p2 *= 2;
-        }
-        s_fin = src;
-        s_line = reinterpret_cast<uint4*>(dst);            // the other array is dead now
+        for (int p = tid; p < td.n_kmers; p += BLOCK) s_hb[p] = min(s_hb[p], s_ha[p + wlen - 1]);
+        __syncthreads();
     }
 
     // ---- phase 2: each wave walks a contiguous range of 64-position words ------------------------------
-    const int lane = tid & 63, wave = tid >> 6;
+    // the wave index is uniform: say so, or the word loop's counter and bounds live in VGPRs (and spill)
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_words = (td.n_kmers + 63) >> 6;
     const int wpw = (n_words + WAVES - 1) / WAVES;
     const int w_begin = min(wave * wpw, n_words);
@@ -304,8 +340,7 @@ __global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __re
         // home line: shared by the whole minimizer run this k-mer belongs to
         uint32_t tgt;
         if (MINI) {
-            const uint32_t mz = min(s_fin[jc], s_fin[jc + wlen - p2]);
-            tgt = mulhi32(remix32(mz), tv.n_lines);
+            tgt = mulhi32(remix32(s_fin[jc]), tv.n_lines);
         } else {
             tgt = mulhi32(hash32(key), tv.n_lines);
         }
@@ -356,11 +391,8 @@ __global__ __launch_bounds__(BLOCK) void screen_tiles_kernel(const uint8_t* __re
                 const uint32_t rel = (uint32_t)(my_run - c0);
                 const bool mine = (st == 1u) && (rel < (uint32_t)RUN_CHUNK);
                 const uint4* src = my_lines + (mine ? rel : 0u) * LINE_STRIDE;
-                uint4 q[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) q[i] = src[i];
                 uint32_t c, meta;
-                const bool any = match_line<WIDE, KT == 0>(q, key, c, meta);
+                const bool any = match_line_lds<WIDE, KT == 0>(src, key, c, meta);
                 const uint32_t ov = (meta >> 8) & 1u;                       // overflowed line: look at the next one
                 const uint32_t nst = any ? 2u : ov;
                 const uint32_t ntgt = (tgt + 1 == tv.n_lines) ? 0u : tgt + 1;

@@ -57,6 +57,17 @@ __global__ __launch_bounds__(256) void gather_coop(const uint8_t* __restrict__ b
     if (acc == 0x12345678u) out[0] = acc;
 }
 
+// dependent-load latency: every lane chases its own chain of random 128-byte-aligned 16-byte loads
+__global__ void chase(const uint8_t* __restrict__ buf, uint32_t n_lines, int steps, uint32_t* out) {
+    uint32_t x = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 99u;
+    for (int i = 0; i < steps; ++i) {
+        const uint32_t line = __umulhi(h32(x + i), n_lines);
+        const uint4 v = *reinterpret_cast<const uint4*>(buf + (size_t)line * 128);
+        x = x * 31u + (v.x ^ v.y ^ v.z ^ v.w);
+    }
+    if (x == 0x12345678u) out[0] = x;
+}
+
 __global__ void stream_read(const uint4* __restrict__ buf, uint64_t n_vec, uint32_t* out) {
     uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -110,5 +121,20 @@ int main(int argc, char** argv) {
 #define COOP(G, I) timeit("coop " #G " lanes x16B, ILP " #I, (double)n_acc, G * 16, [&] { \
         hipLaunchKernelGGL((gather_coop<G, I>), g, b, 0, 0, buf, (uint32_t)(bytes / (G * 16)), n_acc, out); });
     COOP(2, 1) COOP(2, 4) COOP(4, 1) COOP(4, 2) COOP(4, 4) COOP(4, 8) COOP(8, 1) COOP(8, 4) COOP(16, 1) COOP(16, 4)
+    // latency: one wave on the whole chip, then one wave per CU, then 8 waves per CU (dependent chains of 2000 loads)
+    for (int blocks : {1, 256, 2048}) {
+        hipEvent_t a, b2;
+        CK(hipEventCreate(&a)); CK(hipEventCreate(&b2));
+        const int steps = 2000;
+        hipLaunchKernelGGL(chase, dim3(blocks), dim3(64), 0, 0, buf, (uint32_t)(bytes / 128), steps, out);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL(chase, dim3(blocks), dim3(64), 0, 0, buf, (uint32_t)(bytes / 128), steps, out);
+        CK(hipEventRecord(b2));
+        CK(hipEventSynchronize(b2));
+        float ms; CK(hipEventElapsedTime(&ms, a, b2));
+        printf("chase: %4d waves x 64 lanes, %d dependent loads: %.1f ns per load (%.2f G loads/s)\n", blocks, steps, ms * 1e6 / steps,
+               (double)blocks * 64 * steps / ms / 1e6);
+    }
     return 0;
 }

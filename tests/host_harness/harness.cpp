@@ -17,15 +17,21 @@ int32_t hip_fail(hipError_t, const char*) { return 4; }
 static constexpr int MAX_CHUNKS = (31 + TILE_K + 31 + 31) / 32 + 1;
 
 struct Packed {
-    std::vector<uint32_t> fw, cw, vb;
+    std::vector<uint32_t> fwx, cwx, vbx;     // [0] = the lead word bits_at may touch (as in the kernel's LDS arrays)
     int off;
+    const uint32_t* fw() const { return fwx.data() + 1; }
+    const uint32_t* cw() const { return cwx.data() + 1; }
+    const uint32_t* vb() const { return vbx.data() + 1; }
 };
 
 static Packed pack_tile(const uint8_t* text, int64_t text_off, int n_kmers, int k) {
     Packed P;
-    P.fw.assign(2 * (MAX_CHUNKS + 2), 0xDEADBEEFu);
-    P.cw.assign(2 * (MAX_CHUNKS + 2), 0xDEADBEEFu);
-    P.vb.assign(MAX_CHUNKS + 2, 0xDEADBEEFu);
+    P.fwx.assign(2 * (MAX_CHUNKS + 2) + 1, 0xDEADBEEFu);
+    P.cwx.assign(2 * (MAX_CHUNKS + 2) + 1, 0xDEADBEEFu);
+    P.vbx.assign(MAX_CHUNKS + 2 + 1, 0xDEADBEEFu);
+    uint32_t* fw = P.fwx.data() + 1;
+    uint32_t* cw = P.cwx.data() + 1;
+    uint32_t* vb = P.vbx.data() + 1;
     const int64_t a0 = text_off & ~(int64_t)31;
     P.off = (int)(text_off - a0);
     const int nbases = P.off + n_kmers + k - 1;
@@ -38,11 +44,11 @@ static Packed pack_tile(const uint8_t* text, int64_t text_off, int n_kmers, int 
             pack16(x[0], x[1], x[2], x[3], f0, v0);
             pack16(x[4], x[5], x[6], x[7], f1, v1);
         }
-        P.fw[2 * c] = f0;
-        P.fw[2 * c + 1] = f1;
-        P.cw[2 * c] = comp_swap(f0);
-        P.cw[2 * c + 1] = comp_swap(f1);
-        P.vb[c] = (v0 << 16) | v1;
+        fw[2 * c] = f0;
+        fw[2 * c + 1] = f1;
+        cw[2 * c] = comp_swap(f0);
+        cw[2 * c + 1] = comp_swap(f1);
+        vb[c] = (v0 << 16) | v1;
     }
     return P;
 }
@@ -54,7 +60,7 @@ int harness_extract(const uint8_t* text, int64_t text_off, int n_kmers, int k, u
     Packed P = pack_tile(text, text_off, n_kmers, k);
     for (int j = 0; j < n_kmers; ++j) {
         uint64_t f, r;
-        valid[j] = extract_kmer(P.fw.data(), P.cw.data(), P.vb.data(), P.off + j, k, f, r) ? 1 : 0;
+        valid[j] = extract_kmer(P.fw(), P.cw(), P.vb(), P.off + j, k, f, r) ? 1 : 0;
         fwd[j] = f;
         rc[j] = r;
     }
@@ -75,7 +81,7 @@ int harness_screen_tile(const uint8_t* text, int64_t text_off, int n_kmers, int 
             const int j = w * 64 + lane;
             uint64_t f, r;
             const int q = P.off + std::min(j, n_kmers - 1);
-            const bool valid = extract_kmer(P.fw.data(), P.cw.data(), P.vb.data(), q, k, f, r) && j < n_kmers;
+            const bool valid = extract_kmer(P.fw(), P.cw(), P.vb(), q, k, f, r) && j < n_kmers;
             const int32_t cnt = valid ? counts[j] : 0;
             const bool hit = valid && cnt >= min_count;
             if (valid) V |= 1ull << lane;
@@ -125,7 +131,7 @@ int harness_minimizers(const uint8_t* text, int64_t text_off, int n_kmers, int k
     std::vector<uint32_t> h(n_kmers + wlen);
     for (int p = 0; p < n_kmers + wlen - 1; ++p) {
         uint64_t f, r;
-        extract_pair(P.fw.data(), P.cw.data(), P.off + p, M, f, r);
+        extract_pair(P.fw(), P.cw(), P.off + p, M, f, r);
         h[p] = mmer_hash(f, r);
     }
     for (int j = 0; j < n_kmers; ++j) {
@@ -133,7 +139,7 @@ int harness_minimizers(const uint8_t* text, int64_t text_off, int n_kmers, int k
         for (int t = 1; t < wlen; ++t) mz = std::min(mz, h[j + t]);
         query_side[j] = mz;
         uint64_t f, r;
-        extract_pair(P.fw.data(), P.cw.data(), P.off + j, k, f, r);
+        extract_pair(P.fw(), P.cw(), P.off + j, k, f, r);
         build_fwd[j] = minimizer_of_kmer(f, k, M);
         build_canon[j] = minimizer_of_kmer(f < r ? f : r, k, M);
     }
