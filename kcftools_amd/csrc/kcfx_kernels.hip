@@ -185,11 +185,13 @@ __device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
     return v;
 }
 
-// wave-private LDS hand-off: LDS operations of one wave execute in order, so only the compiler has to be kept
-// from moving accesses across this point
+// wave-private LDS hand-off: LDS operations of one wave execute in order, so only the COMPILER has to be kept from
+// moving accesses across this point. (A wavefront-scope fence also works but makes hipcc wait for vmcnt(0), i.e. for
+// the wave's outstanding global stores.)
 __device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
 }
 
 // VAR != 0 only exists in the experiments build (-DKCFX_EXPERIMENTS, libkcfx_exp.so): timing ablations whose
