@@ -71,6 +71,7 @@ struct Opts {
     std::string out;
     bool fasta = false;
     std::string contig = "chr1";
+    std::vector<int64_t> contig_lens;      // --contig-lens a,b,c: the reference is cut into contigs chr1..chrN
 };
 
 int main(int argc, char** argv) {
@@ -91,6 +92,18 @@ int main(int argc, char** argv) {
         else if (a == "--out") o.out = val();
         else if (a == "--fasta") o.fasta = true;
         else if (a == "--contig") o.contig = val();
+        else if (a == "--contig-lens") {
+            std::string v = val();
+            size_t p0 = 0;
+            while (p0 < v.size()) {
+                size_t c = v.find(',', p0);
+                o.contig_lens.push_back(atoll(v.substr(p0, c == std::string::npos ? std::string::npos : c - p0).c_str()));
+                if (c == std::string::npos) break;
+                p0 = c + 1;
+            }
+            o.ref_len = 0;
+            for (int64_t l : o.contig_lens) o.ref_len += l;
+        }
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     if (o.out.empty() || o.k < 9 || o.k > 32 || (o.k - o.p) % 4 != 0 || o.cs < 1 || o.cs > 4 || o.sig_len > o.k) {
@@ -104,6 +117,12 @@ int main(int argc, char** argv) {
 
     // ---- reference ------------------------------------------------------------------------------------
     const int64_t L = o.ref_len;
+    if (o.contig_lens.empty()) o.contig_lens.push_back(L);
+    std::vector<int64_t> contig_start;     // offsets of the contigs in the concatenated reference text
+    {
+        int64_t acc = 0;
+        for (int64_t l : o.contig_lens) { contig_start.push_back(acc); acc += l; }
+    }
     std::vector<uint8_t> ref((size_t)L);
     const uint64_t s1 = mix64(o.seed * 0x1000193ull + 11);
     parallel_for(L, T, [&](int64_t lo, int64_t hi, int) {
@@ -133,10 +152,14 @@ int main(int argc, char** argv) {
         if (o.fasta) {
             f = fopen((o.out + ".fa").c_str(), "wb");
             if (!f) { perror("fa"); return 1; }
-            fprintf(f, ">%s synthetic seed=%llu\n", o.contig.c_str(), (unsigned long long)o.seed);
-            for (int64_t i = 0; i < L; i += 60) {
-                fwrite(ref.data() + i, 1, (size_t)std::min<int64_t>(60, L - i), f);
-                fputc('\n', f);
+            for (size_t c = 0; c < o.contig_lens.size(); ++c) {
+                if (o.contig_lens.size() == 1) fprintf(f, ">%s synthetic seed=%llu\n", o.contig.c_str(), (unsigned long long)o.seed);
+                else fprintf(f, ">chr%zu synthetic seed=%llu\n", c + 1, (unsigned long long)o.seed);
+                const int64_t b = contig_start[c], e = b + o.contig_lens[c];
+                for (int64_t i = b; i < e; i += 60) {
+                    fwrite(ref.data() + i, 1, (size_t)std::min<int64_t>(60, e - i), f);
+                    fputc('\n', f);
+                }
             }
             fclose(f);
         }
@@ -148,7 +171,12 @@ int main(int argc, char** argv) {
     smp.reserve((size_t)L + (size_t)L / 100);
     const uint64_t s2 = mix64(o.sample_seed * 0x9E37ull + 5);
     const uint64_t sub_thr = (uint64_t)(o.sub_rate * 1e6), indel_thr = (uint64_t)(o.indel_rate * 1e6);
+    size_t next_contig = 1;
     for (int64_t i = 0; i < L;) {
+        if (next_contig < contig_start.size() && i >= contig_start[next_contig]) {
+            smp.push_back('#');                 // no sample k-mer spans two contigs
+            ++next_contig;
+        }
         // one 20 kb deletion per 200 kb block (5 per Mb)
         const int64_t blk0 = (i / 200000) * 200000;
         const int64_t del_s = blk0 + (int64_t)(mix64(s2 ^ (0x77ull + (uint64_t)blk0)) % 180000);

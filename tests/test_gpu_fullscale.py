@@ -1,0 +1,122 @@
+"""BASELINE.json full sizes on the GPU (configs[2]-[4] shapes): A. thaliana-sized five-contig genome (119.7 Mb), one
+150 M-k-mer sample database, gene-model windows from a 27 000-gene GTF (irregular sizes), 10 kb and 50 kb tilings.
+Checked through size-independent properties plus oracle comparison on a random sample of windows (the oracle would
+need minutes for all of them). Inputs come from the native generator (seeded)."""
+import json
+import os
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+from kcftools_amd import engine, synth
+from oracle import pyhost
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SYNTH = os.path.join(ROOT, "kcftools_amd", "bin", "kcfx_synth")
+CLI = os.path.join(ROOT, "kcftools_amd", "bin", "kcftools-amd")
+LENS = [30_427_671, 19_698_289, 23_459_830, 18_585_056, 26_975_502]      # TAIR10 chromosome lengths
+FIELDS = engine.INT_FIELDS
+K = 31
+
+
+@pytest.fixture(scope="module")
+def genome(tmp_path_factory):
+    d = tmp_path_factory.mktemp("full")
+    prefix = str(d / "ath")
+    out = subprocess.run([SYNTH, "--out", prefix, "--contig-lens", ",".join(map(str, LENS)), "--seed", "3", "--sample-seed", "4",
+                          "--noise", "44000000", "--fasta"], check=True, capture_output=True, text=True).stdout
+    meta = json.loads(out)
+    text = np.fromfile(prefix + ".ref.txt", dtype=np.uint8).tobytes()
+    assert len(text) == sum(LENS) == 119_146_348
+    db = engine.KmcDb.open(prefix)
+    assert db.info.total_kmers == meta["db_kmers"] > 140_000_000
+    return dict(prefix=prefix, text=text, db=db, meta=meta, dir=str(d))
+
+
+def tiling(window):
+    wb, wl = [], []
+    off = 0
+    for L in LENS:
+        s, e = engine.windows(L, window, 0, K)
+        wb.append(s.astype(np.int64) + off)
+        wl.append((e - s).astype(np.int32))
+        off += L
+    return np.concatenate(wb), np.concatenate(wl)
+
+
+def test_tilings_partition_the_genome(oracle, genome):
+    db, text = genome["db"], genome["text"]
+    wb10, wl10 = tiling(10_000)
+    wb50, wl50 = tiling(50_000)
+    assert len(wb10) == sum(len(engine.windows(L, 10_000, 0, K)[0]) for L in LENS) and len(wb10) > 11_900
+    ref10 = engine.Reference(text, wb10, wl10, K)
+    t0 = time.time()
+    r10 = ref10.screen(db, 1)
+    t10 = time.time() - t0
+    r50 = engine.Reference(text, wb50, wl50, K).screen(db, 1)
+    whole_b = np.cumsum([0] + LENS[:-1])
+    rw = db.screen(text, whole_b, LENS, 1)
+    # every k-mer of a contig lies in exactly one tiling window, whatever the window size (SURVEY a-1)
+    for f in ("total_kmers", "obs", "kmer_count_sum"):
+        assert int(r10[f].sum()) == int(r50[f].sum()) == int(rw[f].sum()), f
+    assert 0.5 < r10["obs"].sum() / r10["total_kmers"].sum() < 0.8
+    # EFFLEN / TOTAL identity: eff - total = (k-1) x (number of valid runs) >= 0, and total <= len - k + 1
+    assert np.all(r10["eff_length"] >= r10["total_kmers"]) and np.all((r10["eff_length"] - r10["total_kmers"]) % (K - 1) == 0)
+    assert np.all(r10["total_kmers"] <= wl10 - K + 1)
+    # accounting identities of the gap state machine: obs + misses = total; every miss-run is counted once
+    misses = r10["total_kmers"] - r10["obs"]
+    assert np.all((r10["var"] == 0) == (misses == 0))
+    assert np.all(r10["left"] + r10["right"] <= misses)
+    # idempotent, and -c is monotone
+    assert all(np.array_equal(ref10.screen(db, 1)[f], r10[f]) for f in FIELDS)
+    r3 = ref10.screen(db, 3)
+    assert np.all(r3["obs"] <= r10["obs"]) and np.array_equal(r3["total_kmers"], r10["total_kmers"])
+    # a random sample of windows against the oracle, both window sizes
+    odb = oracle.OracleDb(genome["prefix"])
+    rng = np.random.default_rng(0)
+    for wb, wl, res in ((wb10, wl10, r10), (wb50, wl50, r50)):
+        idx = rng.choice(len(wb), 60, replace=False)
+        want = odb.screen(text, wb[idx], wl[idx], 1, threads=16)
+        for f in FIELDS:
+            assert np.array_equal(res[f][idx], want[f]), f
+    print(f"12k windows x 119 M k-mers screened in {t10 * 1e3:.1f} ms (host call, results copied back)")
+
+
+def test_gene_model_windows_end_to_end(oracle, genome):
+    """configs[2]: GTF gene windows through the command-line driver; a sample of genes against the oracle + Python writer."""
+    contigs = [(f"chr{i + 1}", L) for i, L in enumerate(LENS)]
+    gtf = os.path.join(genome["dir"], "genes.gtf")
+    synth.random_gtf(gtf, contigs, 11, genes_per_mb=227.0)
+    out = os.path.join(genome["dir"], "genes.kcf")
+    t0 = time.time()
+    p = subprocess.run([CLI, "getVariations", "-r", genome["prefix"] + ".fa", "-k", genome["prefix"], "-o", out, "-s", "S1", "-f", "gene",
+                        "-g", gtf], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout[-2000:]
+    wall = time.time() - t0
+    rows = [l.split("\t") for l in open(out) if not l.startswith("#")]
+    assert len(rows) > 25_000
+    model = pyhost.Gtf(gtf)
+    fa = open(genome["prefix"] + ".fa", "rb").read()
+    entries = {e[0]: e for e in pyhost.generate_faidx(genome["prefix"] + ".fa")}
+    odb = oracle.OracleDb(genome["prefix"])
+    by_id = {r[3]: r for r in rows}
+    rng = np.random.default_rng(1)
+    genes = [g for c, _ in contigs for g in model.kids(c)]
+    assert len(genes) == len(rows)
+    for g in rng.choice(genes, 150, replace=False):
+        c, s, e, _ = model.loci(g)
+        loci = model.merged_exon_loci(g, True)
+        text = b"".join(pyhost.get_sequence(fa, entries[l[0]], l[1] - 1, l[2] - l[1] + 1) for l in loci)
+        res = odb.process_window(text, 1)
+        sc, md, _ = oracle.score(res)
+        assert "\t".join(by_id[g]).rstrip("\n") == pyhost.kcf_row(c, s, e, g, res, sc, md)
+    # rows are grouped by contig in .faidx order and sorted by start inside a contig
+    order = [r[0] for r in rows]
+    assert [c for i, c in enumerate(order) if i == 0 or order[i - 1] != c] == [c for c, _ in contigs]
+    for c, _ in contigs:
+        st = [int(r[1]) for r in rows if r[0] == c]
+        assert st == sorted(st)
+    print(f"getVariations -f gene on 119 Mb / {len(rows)} genes: {wall:.1f} s wall (FASTA + GTF parse, DB load, screen, KCF write)")
