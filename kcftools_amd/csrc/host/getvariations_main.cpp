@@ -54,6 +54,18 @@ void usage() {
               "       [-w window] [-p step] [-g gtf] [-c min-k-count] [--wi 0.3] [--wt 0.3] [--wr 0.4] [-t threads] [-m] [--device 0]");
 }
 
+std::vector<std::string> split_commas(const std::string& v) {
+    std::vector<std::string> out;
+    size_t p = 0;
+    for (;;) {
+        size_t c = v.find(',', p);
+        out.push_back(v.substr(p, c == std::string::npos ? std::string::npos : c - p));
+        if (c == std::string::npos) break;
+        p = c + 1;
+    }
+    return out;
+}
+
 struct Win {
     std::string id, seq;
     int32_t start, end;      // as printed (0-based half-open in window mode, raw 1-based GTF coordinates otherwise)
@@ -112,18 +124,25 @@ int main(int argc, char** argv) {
     }
     if (o.threads <= 0) error("Number of threads should be greater than 0");
     if (o.min_count < 1) error("Minimum kmer count should be at least 1");
+    // Extension: -k and -s may be comma-separated lists of equal length. The reference is uploaded once
+    // and screened against every sample; the output is the multi-sample KCF that `cohort` (Plugins/Cohort.java) would
+    // produce from the S single-sample files.
+    std::vector<std::string> kmc_list = split_commas(o.kmc), sample_list = split_commas(o.sample);
+    if (kmc_list.size() != sample_list.size()) error("The numbers of KMC databases (-k) and sample names (-s) differ");
     // cleanSampleName (:392-401)
-    {
-        std::string clean = o.sample;
+    for (auto& name : sample_list) {
+        std::string clean = name;
         for (char& c : clean)
             if (std::strchr("\\/:*?\"<>|", c)) c = '_';
-        if (clean != o.sample) warning("Sample name contains invalid characters, changed to: " + clean);
-        o.sample = clean;
+        if (clean != name) warning("Sample name contains invalid characters, changed to: " + clean);
+        name = clean;
     }
+    o.sample = sample_list[0];
+    for (size_t i = 1; i < sample_list.size(); ++i) o.sample += "\t" + sample_list[i];    // #CHROM line columns
 
     // new KMC(prefix, loadMemory) (:95)
     kcfx_db* db = nullptr;
-    if (kcfx_db_open(o.kmc.c_str(), o.device, &db)) error(kcfx_last_error());
+    if (kcfx_db_open(kmc_list[0].c_str(), o.device, &db)) error(kcfx_last_error());
     kcfx_db_info_t dbi;
     kcfx_db_info(db, &dbi);
     const int k = dbi.kmer_length;
@@ -211,12 +230,26 @@ int main(int argc, char** argv) {
         wb[(size_t)i] = wins[(size_t)i].text_begin;
         wl[(size_t)i] = wins[(size_t)i].text_len;
     }
-    std::vector<kcfx_result> res((size_t)n);
-    if (kcfx_screen(db, reinterpret_cast<const uint8_t*>(text.data()), (int64_t)text.size(), wb.data(), wl.data(), n, o.min_count,
-                    res.data()))
+    // reference text + windows resident in HBM once; one kcfx_screen_ref per sample
+    const size_t S = kmc_list.size();
+    kcfx_ref* ref = nullptr;
+    if (kcfx_ref_create(o.device, k, reinterpret_cast<const uint8_t*>(text.data()), (int64_t)text.size(), wb.data(), wl.data(), n, &ref))
         error(kcfx_last_error());
-    std::vector<double> score((size_t)n), depth((size_t)n);
-    if (kcfx_score(res.data(), n, o.wi, o.wt, o.wr, score.data(), depth.data())) error(kcfx_last_error());   // Data.java:101-103
+    std::vector<std::vector<kcfx_result>> res(S, std::vector<kcfx_result>((size_t)n));
+    std::vector<std::vector<double>> score(S, std::vector<double>((size_t)n)), depth(S, std::vector<double>((size_t)n));
+    for (size_t s = 0; s < S; ++s) {
+        if (s > 0) {
+            if (kcfx_db_open(kmc_list[s].c_str(), o.device, &db)) error(kcfx_last_error());
+            kcfx_db_info_t di;
+            kcfx_db_info(db, &di);
+            if (di.kmer_length != k) error("Kmer size mismatch between the KMC databases");      // KCFHeader.equals (cohort)
+        }
+        if (kcfx_screen_ref(db, ref, o.min_count, res[s].data())) error(kcfx_last_error());
+        if (kcfx_score(res[s].data(), n, o.wi, o.wt, o.wr, score[s].data(), depth[s].data())) error(kcfx_last_error());   // Data.java:101-103
+        kcfx_db_close(db);
+        db = nullptr;
+    }
+    kcfx_ref_destroy(ref);
 
     // sort each contig's windows by start (:169-171); ties keep generation order
     hdr.n_windows = n;
@@ -228,10 +261,17 @@ int main(int argc, char** argv) {
         std::vector<size_t> order;
         for (size_t i = pc.first; i < pc.second; ++i) order.push_back(i);
         std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return wins[a].start < wins[b].start; });
-        for (size_t i : order)
-            out << kcf_row_text(wins[i].seq, wins[i].start, wins[i].end, wins[i].id, res[i], score[i], depth[i]) << "\n";
+        for (size_t i : order) {
+            if (S == 1) {
+                out << kcf_row_text(wins[i].seq, wins[i].start, wins[i].end, wins[i].id, res[0][i], score[0][i], depth[0][i]) << "\n";
+            } else {
+                std::vector<SampleCol> cols;
+                for (size_t s = 0; s < S; ++s) cols.push_back(cohort_sample(res[s][i], score[s][i], depth[s][i]));
+                out << kcf_row_text_multi(wins[i].seq, wins[i].start, wins[i].end, wins[i].id, res[0][i].total_kmers,
+                                          res[0][i].eff_length, cols) << "\n";
+            }
+        }
     }
     out.close();
-    kcfx_db_close(db);
     return 0;
 }

@@ -1,5 +1,7 @@
 #include "kcf_writer.h"
 
+#include <climits>
+#include <cmath>
 #include <ctime>
 
 #include "java_format.h"
@@ -75,6 +77,47 @@ std::string kcf_row_text(const std::string& seq, int32_t start, int32_t end, con
     s += "\tGT:VA:OB:ID:LD:RD:KD:SC\t";
     s += "N:" + std::to_string(r.var) + ":" + std::to_string(r.obs) + ":" + std::to_string(r.inner) + ":" + std::to_string(r.left) + ":" +
          std::to_string(r.right) + ":" + java_fmt_2f(mean_count) + ":" + java_fmt_2f(score);
+    return s;
+}
+
+SampleCol cohort_sample(const kcfx_result& r, double score, double mean_count) {
+    SampleCol c;
+    c.var = r.var; c.obs = r.obs; c.inner = r.inner; c.left = r.left; c.right = r.right;
+    const double kd = std::stod(java_fmt_2f(mean_count));                       // Double.parseDouble(sampleData[6])
+    const long long kmer_count = (long long)std::floor(kd * r.obs + 0.5);       // Math.round (Window.java:70)
+    c.mean = kmer_count > 0 ? (double)kmer_count / r.obs : 0.0;                 // Data.java:57-59
+    c.score = score;                                                            // same integers, same weights (Data.java:61)
+    return c;
+}
+
+std::string kcf_row_text_multi(const std::string& seq, int32_t start, int32_t end, const std::string& id, int32_t total,
+                               int32_t eff, const std::vector<SampleCol>& samples) {
+    double min_s = 3.4028234663852886e38, max_s = 1.401298464324817e-45, mean_s = 0;   // Float.MAX_VALUE / MIN_VALUE (:184-185)
+    int32_t min_o = INT32_MAX, max_o = INT32_MIN, min_v = INT32_MAX, max_v = INT32_MIN;
+    float mo = 0, mv = 0;                                                       // float accumulators (:24,27)
+    for (const auto& d : samples) {
+        if (d.obs < min_o) min_o = d.obs;
+        if (d.obs > max_o) max_o = d.obs;
+        mo += (float)d.obs;
+        if (d.var < min_v) min_v = d.var;
+        if (d.var > max_v) max_v = d.var;
+        mv += (float)d.var;
+        if (d.score < min_s) min_s = d.score;
+        if (d.score > max_s) max_s = d.score;
+        mean_s += d.score;
+    }
+    const int n = (int)samples.size();
+    mo /= (float)n;
+    mv /= (float)n;
+    mean_s /= n;
+    std::string s = seq + "\t" + std::to_string(start) + "\t" + std::to_string(end) + "\t" + id + "\t" + std::to_string(total) + "\t";
+    s += "EFFLEN=" + std::to_string(eff) + ";IS=" + java_fmt_2f(min_s) + ";XS=" + java_fmt_2f(max_s) + ";MS=" + java_fmt_2f(mean_s) +
+         ";IO=" + std::to_string(min_o) + ";XO=" + std::to_string(max_o) + ";MO=" + java_fmt_2f((double)mo) + ";IV=" +
+         std::to_string(min_v) + ";XV=" + std::to_string(max_v) + ";MV=" + java_float_to_string(mv);
+    s += "\tGT:VA:OB:ID:LD:RD:KD:SC";
+    for (const auto& d : samples)
+        s += "\tN:" + std::to_string(d.var) + ":" + std::to_string(d.obs) + ":" + std::to_string(d.inner) + ":" + std::to_string(d.left) + ":" +
+             std::to_string(d.right) + ":" + java_fmt_2f(d.mean) + ":" + java_fmt_2f(d.score);
     return s;
 }
 

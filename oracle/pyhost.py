@@ -287,3 +287,49 @@ def kcf_row(seq: str, start: int, end: int, wid: str, res: dict, score: float, m
     data = ":".join(["N", str(res["var"]), str(res["obs"]), str(res["inner"]), str(res["left"]), str(res["right"]),
                      java_fmt_2f(mean_count), java_fmt_2f(score)])
     return "\t".join([seq, str(start), str(end), wid, str(res["total_kmers"]), info, "GT:VA:OB:ID:LD:RD:KD:SC", data])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# cohort (Plugins/Cohort.java:71-119): S single-sample KCFs of the same windows -> one multi-sample KCF (row f-4)
+# ---------------------------------------------------------------------------------------------------------
+FLOAT_MAX_VALUE = 3.4028234663852886e38
+
+
+def cohort_sample_from_text(field: str, total: int, eff: int, wi: float, wt: float, wr: float) -> dict:
+    """Window.parseSampleData (Window.java:57-83) + Data ctor (Data.java:40-68): what `cohort` keeps of a sample column.
+    The count sum is re-derived from the 2-decimal KD text: round(KD * obs) (Math.round = floor(x + 0.5))."""
+    import math
+    f = field.split(":")
+    var, obs, inner, left, right = (int(x) for x in f[1:6])
+    kmer_count = math.floor(float(f[6]) * obs + 0.5)                          # Window.java:70
+    mean = kmer_count / obs if kmer_count > 0 else 0.0                         # Data.java:57-59
+    if obs == 0 or total == 0 or eff == 0:                                      # Data.java:96-98
+        sc = 0.0
+    else:
+        sc = ((wr * (obs / total)) + (wi * (1.0 - inner / eff)) + (wt * (1.0 - (left + right) / eff))) * 100.0
+    return dict(ibs=f[0], var=var, obs=obs, inner=inner, left=left, right=right, mean=mean, score=sc)
+
+
+def cohort_row(seq: str, start: int, end: int, wid: str, total: int, eff: int, samples: list[dict]) -> str:
+    """Window.toString for several samples (Window.java:125-152, calculateStats :177-214): min / max / mean over the
+    samples; observed-k-mer and variation means are accumulated in float; maxScore starts at Float.MIN_VALUE."""
+    import numpy as np
+    min_s, max_s, mean_s = FLOAT_MAX_VALUE, FLOAT_MIN_VALUE, 0.0
+    mo = np.float32(0)
+    mv = np.float32(0)
+    for d in samples:
+        min_s = min(min_s, d["score"]) if d["score"] < min_s else min_s
+        max_s = d["score"] if d["score"] > max_s else max_s
+        mean_s += d["score"]
+        mo = np.float32(mo + np.float32(d["obs"]))
+        mv = np.float32(mv + np.float32(d["var"]))
+    n = len(samples)
+    mo = np.float32(mo / np.float32(n))
+    mv = np.float32(mv / np.float32(n))
+    mean_s /= n
+    info = (f"EFFLEN={eff};IS={java_fmt_2f(min_s)};XS={java_fmt_2f(max_s)};MS={java_fmt_2f(mean_s)};"
+            f"IO={min(d['obs'] for d in samples)};XO={max(d['obs'] for d in samples)};MO={java_fmt_2f(float(mo))};"
+            f"IV={min(d['var'] for d in samples)};XV={max(d['var'] for d in samples)};MV={java_float_to_string(float(mv))}")
+    cols = [":".join([d["ibs"], str(d["var"]), str(d["obs"]), str(d["inner"]), str(d["left"]), str(d["right"]),
+                      java_fmt_2f(d["mean"]), java_fmt_2f(d["score"])]) for d in samples]
+    return "\t".join([seq, str(start), str(end), wid, str(total), info, "GT:VA:OB:ID:LD:RD:KD:SC"] + cols)

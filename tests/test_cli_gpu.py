@@ -102,3 +102,41 @@ def test_cli_validation_errors(tmp_path):
         assert msg in log and " - ERROR " in log
     log = run_cli(["-r", fa, "-k", str(tmp_path / "nodb"), "-o", str(tmp_path / "x.kcf"), "-s", "S", "-f", "window", "-w", "1000"], expect_rc=1)
     assert "Error reading prefix file" in log
+
+
+def test_multi_sample_equals_cohort_of_single_sample_runs(oracle, tmp_path):
+    """`-k a,b -s x,y` screens the resident reference against every sample and writes what `cohort`
+    (Plugins/Cohort.java) would produce from the single-sample KCFs: KD re-derived from its 2-decimal text, scores from the
+    integers, min / max / mean statistics over the samples (float accumulators, Float.MIN_VALUE start of XS)."""
+    fa = str(tmp_path / "ref.fa")
+    shutil.copy(os.path.join(G, "ref.fa"), fa)
+    data = open(fa, "rb").read()
+    entries = pyhost.generate_faidx(fa)
+    dbs = ["db_canon_k31_p3_cs2_m9", "db_fwd_k31_p7_cs1_m7"]
+    out = str(tmp_path / "multi.kcf")
+    run_cli(["-r", fa, "-k", ",".join(os.path.join(G, d) for d in dbs), "-o", out, "-s", "S1,S2", "-f", "window", "-w", "3000", "-c", "2"])
+    singles = []
+    for i, d in enumerate(dbs):
+        o1 = str(tmp_path / f"single{i}.kcf")
+        run_cli(["-r", fa, "-k", os.path.join(G, d), "-o", o1, "-s", f"S{i + 1}", "-f", "window", "-w", "3000", "-c", "2"])
+        singles.append([l.rstrip("\n").split("\t") for l in open(o1) if not l.startswith("#")])
+    want_rows = []
+    for r0, r1 in zip(*singles):
+        assert r0[:5] == r1[:5]
+        total = int(r0[4])
+        eff = int(r0[5].split(";")[0].split("=")[1])
+        cols = [pyhost.cohort_sample_from_text(r[7], total, eff, 0.3, 0.3, 0.4) for r in (r0, r1)]
+        want_rows.append(pyhost.cohort_row(r0[0], int(r0[1]), int(r0[2]), r0[3], total, eff, cols))
+    got = open(out).read().split("\n")
+    got_rows = [l for l in got if l and not l.startswith("#")]
+    assert got_rows == want_rows and len(got_rows) > 10
+    assert [l for l in got if l.startswith("#CHROM")][0].endswith("\tFORMAT\tS1\tS2")
+    # and the single-sample files themselves are the oracle's numbers (spot check of the first sample)
+    odb = oracle.OracleDb(os.path.join(G, dbs[0]))
+    ent = entries[0]
+    s, e = synth.tiling_windows(ent[1], 3000, 31)
+    res = odb.process_window(pyhost.get_sequence(data, ent, int(s[2]), int(e[2] - s[2])), 2)
+    sc, md, _ = oracle.score(res)
+    assert "\t".join(singles[0][2]) == pyhost.kcf_row(ent[0], int(s[2]), int(e[2]), f"{ent[0]}_{s[2]}", res, sc, md)
+    log = run_cli(["-r", fa, "-k", os.path.join(G, dbs[0]), "-o", out, "-s", "A,B", "-f", "window", "-w", "3000"], expect_rc=1)
+    assert "differ" in log
