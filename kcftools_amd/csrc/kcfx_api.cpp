@@ -175,18 +175,25 @@ int32_t check_device(int32_t device) {
     return KCFX_OK;
 }
 
-// Fraction of key slots in use. Minimizer bucketing makes line occupancy clumpy (a minimizer occurrence brings ~8 k-mers
-// at once), and every overflowed line costs its k-mers a second, dependent fetch round, so a sparse table is worth
-// its HBM while HBM is plentiful (288 GB): 0.35 up to 16 GiB of table, then denser. KCFX_TABLE_LOAD overrides.
+// Lines are filled sparsely on purpose. The probe costs the same whatever the table size (one line per fetch, 8 lanes
+// at once), and every overflowed line costs its k-mers a second, dependent fetch round (measured on the bench workload:
+// 0.329 ms at load 0.35, 0.287 ms at 0.20, 0.274 ms at 0.10), so a sparse table is worth its HBM while HBM is plentiful
+// (288 GB): the sparsest of 0.20 / 0.35 / 0.60 whose table stays under 48 / 128 GiB and under 60 % of the free device
+// memory (several samples may be resident at once). KCFX_TABLE_LOAD overrides.
 double table_load_factor(int64_t n_keys, int slots) {
     const char* s = getenv("KCFX_TABLE_LOAD");
     if (s) {
         const double a = atof(s);
         if (a >= 0.05 && a <= 0.9) return a;
     }
-    const double bytes_at = [&](double a) { return (double)n_keys / (slots * a) * LINE_BYTES; }(0.35);
-    if (bytes_at <= 16.0 * (1ull << 30)) return 0.35;
-    return bytes_at <= 64.0 * (1ull << 30) ? 0.45 : 0.6;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)256 << 30;
+    const double GiB = (double)(1ull << 30);
+    const double room = 0.6 * (double)free_b;
+    auto bytes_at = [&](double a) { return (double)n_keys / (slots * a) * LINE_BYTES; };
+    if (bytes_at(0.20) <= 48.0 * GiB && bytes_at(0.20) <= room) return 0.20;
+    if (bytes_at(0.35) <= 128.0 * GiB && bytes_at(0.35) <= room) return 0.35;
+    return 0.6;
 }
 
 // KCFX_TABLE_MODE=keyhash selects per-k-mer hashing (A/B against the default minimizer bucketing)
