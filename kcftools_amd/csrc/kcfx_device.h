@@ -25,15 +25,21 @@ KCFX_HD uint32_t hash32(uint64_t key) {
     return h;
 }
 KCFX_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
-// second bijective mix: the minimum of ~16 hashes is skewed towards 0, so it is re-spread before range reduction
-KCFX_HD uint32_t remix32(uint32_t x) {
-    x += 0x68E31DA4u;
-    x ^= x >> 15;
-    x *= 0x2C1B3C6Du;
-    x ^= x >> 12;
-    x *= 0x297A2D39u;
-    x ^= x >> 15;
-    return x;
+// The minimum of ~16 hashes is skewed towards 0: one odd multiply (Fibonacci hashing, a bijection mod 2^32) re-spreads
+// it before range reduction. screen_* is VALU-bound and v_mul_lo_u32 is quarter rate, so every multiply here is priced
+// as four instructions per k-mer.
+KCFX_HD uint32_t remix32(uint32_t x) { return x * 0x9E3779B1u; }
+// line of a minimizer (minimum M-mer hash)
+KCFX_HD uint32_t line_of_minimizer(uint32_t mn, uint32_t n_lines) { return mulhi32(remix32(mn), n_lines); }
+
+// M-mer hash: two multiplies. Only its ORDER matters (minimum selection), plus the spread remix32 gives the winner;
+// the added constant keeps poly-A (word 0) from hashing to 0 and winning every window.
+KCFX_HD uint32_t mhash32(uint64_t word) {
+    uint32_t lo = (uint32_t)word, hi = (uint32_t)(word >> 32);
+    uint32_t h = ((hi + 0x7F4A7C15u) * 0x9E3779B1u) ^ lo;
+    h ^= h >> 15;
+    h *= 0x85EBCA6Bu;
+    return h;
 }
 
 // ---- base packing ------------------------------------------------------------------------------------
@@ -141,7 +147,7 @@ KCFX_HD uint64_t revcomp_word(uint64_t x, int len) {
 }
 
 // hash of the canonical M-mer given its two strands as left-aligned words
-KCFX_HD uint32_t mmer_hash(uint64_t fwd, uint64_t rc) { return hash32(fwd < rc ? fwd : rc); }
+KCFX_HD uint32_t mmer_hash(uint64_t fwd, uint64_t rc) { return mhash32(fwd < rc ? fwd : rc); }
 
 // Build side: minimizer of a stored k-mer word = min over its k-M+1 M-mers of mmer_hash. Strand-symmetric, so the
 // canonical and the forward form of a k-mer agree, and it equals what screen_tiles derives from the reference text
@@ -161,7 +167,7 @@ KCFX_HD uint32_t minimizer_of_kmer(uint64_t x, int k, int M) {
 
 KCFX_HD uint32_t keyhash_line(const TableView& tv, uint64_t key) { return mulhi32(hash32(key), tv.n_lines); }
 KCFX_HD uint32_t minimizer_line(const TableView& tv, uint64_t key, int k) {
-    return mulhi32(remix32(minimizer_of_kmer(key, k, tv.mm_len)), tv.n_lines);
+    return line_of_minimizer(minimizer_of_kmer(key, k, tv.mm_len), tv.n_lines);
 }
 
 // Probe step of lookup_kernel (screen_tiles has the same logic inlined around its chunk loop).

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             if (p < n_m) {
                 if (KT) {    // M = 16: the M-mer is one dword; same value as mmer_hash on the left-aligned words
                     const uint32_t f = bits_at(s_fw, 2 * (off + p)), r = brev32(bits_at(s_cw, 2 * (off + p)));
-                    h = hash32(((uint64_t)min(f, r)) << 32);
+                    h = mhash32(((uint64_t)min(f, r)) << 32);
                 } else {
                     uint64_t f, r;
                     extract_pair(s_fw, s_cw, off + p, M, f, r);
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const int n_words = (td.n_kmers + 63) >> 6;
     const int wpw = (n_words + WAVES - 1) / WAVES;
     const int w_begin = min(wave * wpw, n_words);
-    const int w_end = min(w_begin + wpw, n_words);
+    const int w_end = (VAR == 8) ? w_begin : min(w_begin + wpw, n_words);   // VAR 8: phases 1 / 1b only
     const uint64_t lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1);   // bits 0..lane
     const uint64_t lane_prev = lane ? (1ull << (lane - 1)) : 0ull;           // bit lane-1
     uint4* my_lines = s_line + wave * (RUN_CHUNK * LINE_STRIDE);
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         // home line: shared by the whole minimizer run this k-mer belongs to
         uint32_t tgt;
         if (MINI) {
-            tgt = mulhi32(remix32(s_fin[jc]), tv.n_lines);
+            tgt = line_of_minimizer(s_fin[jc], tv.n_lines);
         } else {
             tgt = mulhi32(hash32(key), tv.n_lines);
         }
@@ -381,18 +381,36 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             for (int c0 = 0; c0 < nruns; c0 += RUN_CHUNK) {
                 const int r0 = c0 + (lane >> 3), r1 = r0 + 8;
                 const int piece = lane & 7;
+                constexpr int LS = (VAR == 9) ? 8 : LINE_STRIDE;
+                if (VAR == 9) {
+                    // LDS-DMA: the 16 bytes of every lane land at (wave-uniform base) + 16 * lane; no VGPR in between
+                    typedef __attribute__((address_space(1))) const void* gptr_t;
+                    typedef __attribute__((address_space(3))) void* lptr_t;
+                    if (r0 < nruns)
+                        __builtin_amdgcn_global_load_lds((gptr_t)(tv.lines + (size_t)s_runline[wave][r0] * LINE_BYTES + 16 * piece),
+                                                         (lptr_t)my_lines, 16, 0, 0);
+                    if (r1 < nruns)
+                        __builtin_amdgcn_global_load_lds((gptr_t)(tv.lines + (size_t)s_runline[wave][r1] * LINE_BYTES + 16 * piece),
+                                                         (lptr_t)(my_lines + 64), 16, 0, 0);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    wave_lds_fence();
+                } else {
                 uint4 a, b;
-                if (r0 < nruns)
-                    a = reinterpret_cast<const uint4*>(tv.lines + (size_t)s_runline[wave][r0] * LINE_BYTES)[piece];
-                if (r1 < nruns)
-                    b = reinterpret_cast<const uint4*>(tv.lines + (size_t)s_runline[wave][r1] * LINE_BYTES)[piece];
-                my_lines[(lane >> 3) * LINE_STRIDE + piece] = a;
-                my_lines[(8 + (lane >> 3)) * LINE_STRIDE + piece] = b;
-                wave_lds_fence();
+                    if (VAR == 6) {                      // VAR 6: no table traffic
+                        a = make_uint4(piece, r0, 0u, 0u);
+                        b = make_uint4(piece, r1, 0u, 0u);
+                    } else if (r0 < nruns)
+                        a = reinterpret_cast<const uint4*>(tv.lines + (size_t)s_runline[wave][r0] * LINE_BYTES)[piece];
+                    if (VAR != 6 && r1 < nruns)
+                        b = reinterpret_cast<const uint4*>(tv.lines + (size_t)s_runline[wave][r1] * LINE_BYTES)[piece];
+                    my_lines[(lane >> 3) * LINE_STRIDE + piece] = a;
+                    my_lines[(8 + (lane >> 3)) * LINE_STRIDE + piece] = b;
+                    wave_lds_fence();
+}
                 // every lane matches (idle lanes against buffer 0); the outcome is merged with selects
                 const uint32_t rel = (uint32_t)(my_run - c0);
                 const bool mine = (st == 1u) && (rel < (uint32_t)RUN_CHUNK);
-                const uint4* src = my_lines + (mine ? rel : 0u) * LINE_STRIDE;
+                const uint4* src = my_lines + (mine ? rel : 0u) * LS;
                 uint32_t c, meta;
                 const bool any = match_line_lds<WIDE, KT == 0>(src, key, c, meta);
                 const uint32_t ov = (meta >> 8) & 1u;                       // overflowed line: look at the next one
@@ -416,6 +434,232 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             my_bits[TILE_WORDS + w] = H;
         }
         if (hit) sum_acc += (int64_t)(int32_t)cnt;                 // GetVariants.java:226
+    }
+
+    const int64_t count_sum = wave_sum_i64(sum_acc);
+    if (lane == 0) s_sum[wave] = count_sum;
+    __syncthreads();
+    if (tid == 0) {
+        int64_t t = 0;
+#pragma unroll
+        for (int i = 0; i < WAVES; ++i) t += s_sum[i];
+        count_sums[blockIdx.x] = t;
+    }
+}
+
+// ======================================================================================================
+// screen_k31: the k = 31 / M = 16 minimizer-table specialisation of screen_tiles (BASELINE.json's configuration)
+// ======================================================================================================
+// Same inputs, outputs and probe semantics as screen_tiles_kernel<*, MODE_MINIMIZER, 31>; what differs is where the
+// latency goes:
+//   * minimizers never touch LDS: with M = 16 a k-mer spans exactly 16 M-mers = one DPP row, so the van Herk prefix /
+//     suffix minima are two 4-step v_min_u32 row scans in registers and the sliding minimum of the k-mer at lane l is
+//     min(S[l], P[l + 15]) (one ds_bpermute pair; lanes 49..63 take P from the next word). No phase 1b, no barriers.
+//   * table lines land in LDS by LDS-DMA (global_load_lds_dwordx4): no destination VGPRs, no ds_write.
+//   * the LDS and VGPRs this frees pay for U = 2 words (128 k-mers) per wave iteration: both words' lines are
+//     requested before the single wait, so one HBM round trip serves twice the k-mers.
+constexpr int K31_RUNS = 16;                                   // line buffers per word per wave (2 DMA instructions)
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_or_ones(uint32_t x) {   // value of the DPP source lane; all ones where there is none
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, CTRL, 0xf, 0xf, false);
+}
+// inclusive prefix (P) and suffix (S) minima within each row of 16 lanes
+__device__ __forceinline__ void row_scan_min(uint32_t h, uint32_t& P, uint32_t& S) {
+    P = h;
+    P = min(P, dpp_or_ones<0x111>(P));                         // row_shr:1
+    P = min(P, dpp_or_ones<0x112>(P));
+    P = min(P, dpp_or_ones<0x114>(P));
+    P = min(P, dpp_or_ones<0x118>(P));
+    S = h;
+    S = min(S, dpp_or_ones<0x101>(S));                         // row_shl:1
+    S = min(S, dpp_or_ones<0x102>(S));
+    S = min(S, dpp_or_ones<0x104>(S));
+    S = min(S, dpp_or_ones<0x108>(S));
+}
+
+template <bool WIDE, bool BOTH, int U>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void screen_k31_kernel(
+    const uint8_t* __restrict__ text, const TileDesc* __restrict__ tiles, TableView tv, int32_t min_count, uint64_t* __restrict__ bits, int64_t* __restrict__ count_sums) {
+    constexpr int k = 31, M = 16;
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    __shared__ uint32_t s_fwx[2 * (MAX_CHUNKS + 2) + 1];   // [0] is the lead word bits_at may touch
+    __shared__ uint32_t s_cwx[2 * (MAX_CHUNKS + 2) + 1];
+    __shared__ uint32_t s_vbx[MAX_CHUNKS + 2 + 1];
+    uint32_t* const s_fw = s_fwx + 1;
+    uint32_t* const s_cw = s_cwx + 1;
+    uint32_t* const s_vb = s_vbx + 1;
+    __shared__ __attribute__((aligned(16))) uint4 s_lines[WAVES][U][K31_RUNS * 8];   // DMA layout: line r at 128 r
+    __shared__ uint32_t s_runline[WAVES][U][65];           // line index of each run (+1 dummy slot)
+    __shared__ int64_t s_sum[WAVES];
+
+    const TileDesc td = tiles[blockIdx.x];
+    const int tid = threadIdx.x;
+
+    // ---- phase 1: ASCII -> 2-bit codes + validity bits in LDS (as screen_tiles_kernel) ----------------
+    const int64_t a0 = td.text_off & ~(int64_t)31;
+    const int off = (int)(td.text_off - a0);
+    const int nbases = off + td.n_kmers + k - 1;
+    const int nchunks = (nbases + 31) >> 5;
+    if (tid == 0) s_fwx[0] = s_cwx[0] = s_vbx[0] = 0;
+    for (int c = tid; c < nchunks + 2; c += BLOCK) {
+        uint32_t f0 = 0, f1 = 0, v0 = 0, v1 = 0;
+        if (c < nchunks) {
+            const uint4* p = reinterpret_cast<const uint4*>(text + a0 + 32 * (int64_t)c);
+            const uint4 x = p[0], y = p[1];
+            pack16(x.x, x.y, x.z, x.w, f0, v0);
+            pack16(y.x, y.y, y.z, y.w, f1, v1);
+        }
+        s_fw[2 * c] = f0;
+        s_fw[2 * c + 1] = f1;
+        s_cw[2 * c] = comp_swap(f0);
+        s_cw[2 * c + 1] = comp_swap(f1);
+        s_vb[c] = (v0 << 16) | v1;
+    }
+    __syncthreads();
+
+    // ---- phase 2: each wave walks a contiguous range of 64-position words, U at a time ---------------------
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_words = (td.n_kmers + 63) >> 6;
+    const int wpw = (n_words + WAVES - 1) / WAVES;
+    const int w_begin = min(wave * wpw, n_words);
+    const int w_end = min(w_begin + wpw, n_words);
+    const int last_m = td.n_kmers + (k - M) - 1;           // last M-mer any k-mer of the tile covers
+    const int piece = lane & 7;
+    const int next15 = ((lane + 15) & 63) << 2;            // ds_bpermute address of lane + 15 (mod 64)
+
+    // Word w, first half of the work: the leading 32 code bits of both strands at this lane's position (kept for the
+    // k-mer extraction one iteration later) and the row-scanned hashes of the canonical 16-mers they spell.
+    auto scan_word = [&](int w, uint32_t& f0, uint32_t& c0, uint32_t& P, uint32_t& S) {
+        const int q = off + min(w * 64 + lane, last_m);
+        f0 = bits_at(s_fw, 2 * q);
+        c0 = bits_at(s_cw, 2 * q);
+        row_scan_min(mhash32(((uint64_t)min(f0, brev32(c0))) << 32), P, S);
+    };
+
+    int64_t sum_acc = 0;                                   // per lane
+    uint64_t* my_bits = bits + (size_t)blockIdx.x * TILE_BITS_U64;
+    uint32_t Fc = 0, Cc = 0, Pc = 0, Sc = 0;               // scan_word of the first word of the next iteration
+    if (w_begin < w_end) scan_word(w_begin, Fc, Cc, Pc, Sc);
+
+    for (int w = w_begin; w < w_end; w += U) {
+        uint32_t Fn[U + 1], Cn[U + 1], Pn[U + 1], Sn[U + 1];
+        Fn[0] = Fc;
+        Cn[0] = Cc;
+        Pn[0] = Pc;
+        Sn[0] = Sc;
+#pragma unroll
+        for (int u = 1; u <= U; ++u) scan_word(w + u, Fn[u], Cn[u], Pn[u], Sn[u]);
+        Fc = Fn[U];
+        Cc = Cn[U];
+        Pc = Pn[U];
+        Sc = Sn[U];
+
+        uint64_t key[U];
+        uint32_t tgt[U], st[U], cnt[U], hm[U];
+        uint64_t V[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // second half of extract_kmer at the position scan_word used (lanes past the last k-mer are invalid anyway)
+            const int j = (w + u) * 64 + lane;
+            const int q = off + min(j, last_m);
+            constexpr uint32_t lo_mask = ~0u << (64 - 2 * k);
+            const uint64_t fwd = (((uint64_t)Fn[u]) << 32) | (bits_at(s_fw, 2 * q + 32) & lo_mask);
+            const uint32_t c1 = bits_at(s_cw, 2 * q + 32) & lo_mask;
+            const uint64_t rc = ((((uint64_t)brev32(c1)) << 32) | brev32(Cn[u])) << (64 - 2 * k);
+            const bool valid = kmer_valid(s_vb, q, k) && (j < td.n_kmers) && (w + u < w_end);
+            // Kmer(Kmer, bothStrands): canonical = min(fwd, revcomp) unsigned (Kmer.java:72-79,406-414)
+            key[u] = (BOTH && rc < fwd) ? rc : fwd;
+            // minimizer of the k-mer = min over its 16 M-mers = min(S[lane], P[lane + 15])
+            const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(next15, (int)Pn[u]);
+            const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute(next15, (int)Pn[u + 1]);
+            const uint32_t mn = min(Sn[u], lane < 49 ? pa : pb);
+            tgt[u] = line_of_minimizer(mn, tv.n_lines);     // home line, shared by the whole minimizer run
+            st[u] = valid ? 1u : 0u;                        // 1 = pending, 2 = found, 0 = absent / invalid
+            cnt[u] = 0;
+            hm[u] = 0;                                      // meta dword of the line matched last
+            V[u] = __ballot(valid);
+        }
+
+        // ---- cooperative probe rounds (see screen_tiles_kernel); the lines of all U words share one wait ----------
+        for (int round = 0;; ++round) {
+            uint64_t any_pending = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) any_pending |= __ballot(st[u] == 1u);
+            if (!any_pending) break;
+            int nruns[U], my_run[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (round == 1) {
+                    // HEAVY minimizer home: its k-mers live at their key-hash lines -- jump, do not walk
+                    const bool redirect = (st[u] == 1u) && (hm[u] & META_HEAVY);
+                    if (__ballot(redirect)) {
+                        // rare: keep the key hash (3 quarter-rate multiplies) from being hoisted into every word
+                        uint32_t klo = (uint32_t)key[u], khi = (uint32_t)(key[u] >> 32);
+                        asm volatile("" : "+v"(klo), "+v"(khi));
+                        if (redirect) tgt[u] = keyhash_line(tv, u64_of(klo, khi));
+                    }
+                }
+                const uint32_t prev_tgt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tgt[u], 0x138, 0xf, 0xf, false);
+                const uint32_t prev_st = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)st[u], 0x138, 0xf, 0xf, false);
+                const bool head = (st[u] == 1u) && (prev_st != 1u || prev_tgt != tgt[u]);
+                const uint64_t HM = __ballot(head);
+                nruns[u] = __popcll(HM);
+                // heads at or below this lane, minus one
+                my_run[u] = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(HM >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)HM, 0u)) +
+                            (head ? 1 : 0) - 1;
+                s_runline[wave][u][(st[u] == 1u) ? my_run[u] : 64] = tgt[u];
+            }
+            wave_lds_fence();
+            int max_runs = nruns[0];
+#pragma unroll
+            for (int u = 1; u < U; ++u) max_runs = max(max_runs, nruns[u]);
+            for (int c0 = 0; c0 < max_runs; c0 += K31_RUNS) {
+                const int r0 = c0 + (lane >> 3), r1 = r0 + 8;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    // 8 lanes x 16 B = one 128-byte request per run; lane i's 16 bytes land at base + 16 i
+                    if (r0 < nruns[u])
+                        __builtin_amdgcn_global_load_lds(
+                            (gptr_t)(tv.lines + (size_t)s_runline[wave][u][r0] * LINE_BYTES + 16 * piece),
+                            (lptr_t)&s_lines[wave][u][0], 16, 0, 0);
+                    if (r1 < nruns[u])
+                        __builtin_amdgcn_global_load_lds(
+                            (gptr_t)(tv.lines + (size_t)s_runline[wave][u][r1] * LINE_BYTES + 16 * piece),
+                            (lptr_t)&s_lines[wave][u][64], 16, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                wave_lds_fence();
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    // every lane matches (idle lanes against buffer 0); the outcome is merged with selects
+                    const uint32_t rel = (uint32_t)(my_run[u] - c0);
+                    const bool mine = (st[u] == 1u) && (rel < (uint32_t)K31_RUNS);
+                    const uint4* src = &s_lines[wave][u][(mine ? rel : 0u) * 8];
+                    uint32_t c, meta;
+                    const bool any = match_line_lds<WIDE, false>(src, key[u], c, meta);
+                    const uint32_t ov = (meta >> 8) & 1u;                   // overflowed line: look at the next one
+                    const uint32_t nst = any ? 2u : ov;
+                    const uint32_t ntgt = (tgt[u] + 1 == tv.n_lines) ? 0u : tgt[u] + 1;
+                    cnt[u] = (mine && any) ? c : cnt[u];                    // Java int (KMC.java:395-401)
+                    tgt[u] = (mine && nst == 1u) ? ntgt : tgt[u];
+                    hm[u] = mine ? meta : hm[u];
+                    st[u] = mine ? nst : st[u];
+                }
+                wave_lds_fence();
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool hit = (st[u] == 2u) && ((int32_t)cnt[u] >= min_count);   // GetVariants.java:224
+            const uint64_t H = __ballot(hit);
+            if (lane == 0 && w + u < w_end) {              // this word of the window's hit bitmap
+                my_bits[w + u] = V[u];
+                my_bits[TILE_WORDS + w + u] = H;
+            }
+            if (hit) sum_acc += (int64_t)(int32_t)cnt[u];                        // GetVariants.java:226
+        }
     }
 
     const int64_t count_sum = wave_sum_i64(sum_acc);
@@ -580,8 +824,23 @@ hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32
     if (!tv.wide && spec && tv.mode == MODE_MINIMIZER && var == 2) { KCFX_LAUNCH(false, MODE_MINIMIZER, 31, 2); return hipGetLastError(); }
     if (!tv.wide && spec && tv.mode == MODE_MINIMIZER && var == 3) { KCFX_LAUNCH(false, MODE_MINIMIZER, 31, 3); return hipGetLastError(); }
     if (!tv.wide && spec && tv.mode == MODE_KEYHASH && var == 3) { KCFX_LAUNCH(false, MODE_KEYHASH, 31, 3); return hipGetLastError(); }
+    if (!tv.wide && spec && tv.mode == MODE_MINIMIZER && var == 6) { KCFX_LAUNCH(false, MODE_MINIMIZER, 31, 6); return hipGetLastError(); }
+    if (!tv.wide && spec && tv.mode == MODE_MINIMIZER && var == 8) { KCFX_LAUNCH(false, MODE_MINIMIZER, 31, 8); return hipGetLastError(); }
+    if (!tv.wide && spec && tv.mode == MODE_MINIMIZER && var == 9) { KCFX_LAUNCH(false, MODE_MINIMIZER, 31, 9); return hipGetLastError(); }
     if (!tv.wide && tv.mode == MODE_MINIMIZER && var == 10) { KCFX_LAUNCH(false, MODE_MINIMIZER, 0, 0); return hipGetLastError(); }
 #endif
+    if (tv.mode == MODE_MINIMIZER && spec && !getenv("KCFX_OLD_KERNEL")) {
+#define KCFX_LAUNCH31(W, BS, UU) \
+    hipLaunchKernelGGL((screen_k31_kernel<W, BS, UU>), g, b, 0, st, text, tiles, tv, min_count, bits, count_sums)
+#ifdef KCFX_EXPERIMENTS
+        static const int words = getenv("KCFX_WORDS") ? atoi(getenv("KCFX_WORDS")) : 1;
+        if (words == 2 && !tv.wide && both_strands) { KCFX_LAUNCH31(false, true, 2); return hipGetLastError(); }
+#endif
+        if (tv.wide) { if (both_strands) KCFX_LAUNCH31(true, true, 1); else KCFX_LAUNCH31(true, false, 1); }
+        else         { if (both_strands) KCFX_LAUNCH31(false, true, 1); else KCFX_LAUNCH31(false, false, 1); }
+#undef KCFX_LAUNCH31
+        return hipGetLastError();
+    }
     if (tv.mode == MODE_MINIMIZER) {
         if (spec) { if (tv.wide) KCFX_LAUNCH(true, MODE_MINIMIZER, 31, 0); else KCFX_LAUNCH(false, MODE_MINIMIZER, 31, 0); }
         else      { if (tv.wide) KCFX_LAUNCH(true, MODE_MINIMIZER, 0, 0); else KCFX_LAUNCH(false, MODE_MINIMIZER, 0, 0); }
