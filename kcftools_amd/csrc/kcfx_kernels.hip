@@ -185,6 +185,10 @@ __device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
     return v;
 }
 
+// __ballot() takes an int: hipcc materialises the predicate (v_cndmask 0/1) and compares it again, two VALU
+// instructions per ballot in a VALU-bound kernel. The builtin reads the condition mask directly.
+__device__ __forceinline__ uint64_t wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // wave-private LDS hand-off: LDS operations of one wave execute in order, so only the COMPILER has to be kept from
 // moving accesses across this point. (A wavefront-scope fence also works but makes hipcc wait for vmcnt(0), i.e. for
 // the wave's outstanding global stores.)
@@ -359,20 +363,20 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         // ---- cooperative probe rounds: each round fetches, for every run of adjacent pending lanes with the same
         //      target line, that line ONCE (8 lanes x 16 B = one 128-byte request) into wave-private LDS -------------
         for (int round = 0;; ++round) {
-            const uint64_t P = __ballot(st == 1u);
+            const uint64_t P = wave_ballot(st == 1u);
             if (!P) break;
             if (MINI && round == 1) {
                 // HEAVY minimizer home (table_finalize also sets its overflow bit, so such lanes are still pending):
                 // every k-mer homed there by minimizer lives at its key-hash line instead -- jump, do not walk
                 const bool redirect = (st == 1u) && (home_meta & META_HEAVY);
-                if (__ballot(redirect)) {
+                if (wave_ballot(redirect)) {
                     if (redirect) tgt = keyhash_line(tv, key);
                 }
             }
             const uint32_t prev_tgt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tgt, 0x138, 0xf, 0xf, false);   // wave_shr:1
             const bool prev_pend = (P & lane_prev) != 0;
             const bool head = (st == 1u) && (!prev_pend || prev_tgt != tgt);
-            const uint64_t HM = __ballot(head);
+            const uint64_t HM = wave_ballot(head);
             const int nruns = __popcll(HM);
             const int my_run = __popcll(HM & lane_le) - 1;
             // every pending lane stores its run's line index (same value within a run); the others hit a dummy slot
@@ -427,8 +431,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         const bool hit = found && ((int32_t)cnt >= min_count);   // GetVariants.java:224
 
         // this word of the window's hit bitmap (reduced by summarize_tiles_kernel)
-        const uint64_t V = __ballot(valid);
-        const uint64_t H = __ballot(hit);
+        const uint64_t V = wave_ballot(valid);
+        const uint64_t H = wave_ballot(hit);
         if (lane == 0) {
             my_bits[w] = V;
             my_bits[TILE_WORDS + w] = H;
@@ -450,15 +454,21 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 // ======================================================================================================
 // screen_k31: the k = 31 / M = 16 minimizer-table specialisation of screen_tiles (BASELINE.json's configuration)
 // ======================================================================================================
-// Same inputs, outputs and probe semantics as screen_tiles_kernel<*, MODE_MINIMIZER, 31>; what differs is where the
-// latency goes:
+// Same inputs, outputs and probe semantics as screen_tiles_kernel<*, MODE_MINIMIZER, 31>. SQ counters show the path is
+// VALU-bound (profiles/r01_notes.md), so this kernel is about instruction count:
 //   * minimizers never touch LDS: with M = 16 a k-mer spans exactly 16 M-mers = one DPP row, so the van Herk prefix /
 //     suffix minima are two 4-step v_min_u32 row scans in registers and the sliding minimum of the k-mer at lane l is
 //     min(S[l], P[l + 15]) (one ds_bpermute pair; lanes 49..63 take P from the next word). No phase 1b, no barriers.
+//   * one word index / shift pair addresses every code-bit read of a word: its own low halves and, 64 positions on, the
+//     leading halves of the next word, which feed that word's M-mer hashes now and its k-mers one iteration later.
 //   * table lines land in LDS by LDS-DMA (global_load_lds_dwordx4): no destination VGPRs, no ds_write.
-//   * the LDS and VGPRs this frees pay for U = 2 words (128 k-mers) per wave iteration: both words' lines are
-//     requested before the single wait, so one HBM round trip serves twice the k-mers.
-constexpr int K31_RUNS = 16;                                   // line buffers per word per wave (2 DMA instructions)
+//   * ballots are taken of single compares and combined on the scalar unit (a ballot of a conjunction costs hipcc a
+//     v_cndmask + v_cmp to re-materialise the predicate).
+// LDS-DMA puts lane i's 16 bytes at base + 16 i. Nine lanes per run, the ninth idle, leave a 16-byte hole after every
+// line: lines start 144 bytes apart, on distinct LDS banks for the match reads (a 128-byte pitch costs 4x the bank
+// conflict cycles, SQ_LDS_BANK_CONFLICT). 7 runs per instruction, 2 instructions per chunk.
+constexpr int K31_RUNS = 14;
+constexpr int K31_PITCH = 9;                                   // uint4 per buffered line
 
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_or_ones(uint32_t x) {   // value of the DPP source lane; all ones where there is none
@@ -477,21 +487,28 @@ __device__ __forceinline__ void row_scan_min(uint32_t h, uint32_t& P, uint32_t& 
     S = min(S, dpp_or_ones<0x104>(S));
     S = min(S, dpp_or_ones<0x108>(S));
 }
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t x) {     // lane l gets lane l-1's value, lane 0 gets 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, false);
+}
 
-template <bool WIDE, bool BOTH, int U>
+template <bool WIDE, bool BOTH>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void screen_k31_kernel(
-    const uint8_t* __restrict__ text, const TileDesc* __restrict__ tiles, TableView tv, int32_t min_count, uint64_t* __restrict__ bits, int64_t* __restrict__ count_sums) {
-    constexpr int k = 31, M = 16;
+    const uint8_t* __restrict__ text, const TileDesc* __restrict__ tiles, TableView tv, int32_t min_count,
+    uint64_t* __restrict__ bits, int64_t* __restrict__ count_sums) {
+    constexpr int k = 31;
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
+    // The word loop reads code bits up to 64 positions past the tile's last k-mer without clamping (what it reads there
+    // only reaches lanes that are invalid anyway): MAX_CHUNKS + 2 chunks cover every such read of a full tile.
+    static_assert(2 * (MAX_CHUNKS + 2) > ((2 * (31 + TILE_K - 1) + 31) >> 5) + 4, "code arrays too short for unclamped reads");
     __shared__ uint32_t s_fwx[2 * (MAX_CHUNKS + 2) + 1];   // [0] is the lead word bits_at may touch
     __shared__ uint32_t s_cwx[2 * (MAX_CHUNKS + 2) + 1];
     __shared__ uint32_t s_vbx[MAX_CHUNKS + 2 + 1];
     uint32_t* const s_fw = s_fwx + 1;
     uint32_t* const s_cw = s_cwx + 1;
     uint32_t* const s_vb = s_vbx + 1;
-    __shared__ __attribute__((aligned(16))) uint4 s_lines[WAVES][U][K31_RUNS * 8];   // DMA layout: line r at 128 r
-    __shared__ uint32_t s_runline[WAVES][U][65];           // line index of each run (+1 dummy slot)
+    __shared__ __attribute__((aligned(16))) uint4 s_lines[WAVES][2 * 64];          // DMA layout: line r at 144 r (7 per 1 KiB)
+    __shared__ uint32_t s_runline[WAVES][65];              // line index of each run (+1 dummy slot)
     __shared__ int64_t s_sum[WAVES];
 
     const TileDesc td = tiles[blockIdx.x];
@@ -519,147 +536,133 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     }
     __syncthreads();
 
-    // ---- phase 2: each wave walks a contiguous range of 64-position words, U at a time ---------------------
+    // ---- phase 2: each wave walks a contiguous range of 64-position words ----------------------------------
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_words = (td.n_kmers + 63) >> 6;
     const int wpw = (n_words + WAVES - 1) / WAVES;
     const int w_begin = min(wave * wpw, n_words);
     const int w_end = min(w_begin + wpw, n_words);
-    const int last_m = td.n_kmers + (k - M) - 1;           // last M-mer any k-mer of the tile covers
-    const int piece = lane & 7;
+    const int fetch_run = (lane * 57) >> 9;                // lane / 9: the run (0..6, 7 = idle) this lane fetches for
+    const int piece = lane - 9 * fetch_run;                // its 16-byte piece of the line (8 = idle)
+    const bool fetcher = piece < 8 && fetch_run < 7;
     const int next15 = ((lane + 15) & 63) << 2;            // ds_bpermute address of lane + 15 (mod 64)
+    uint4* const my_lines = s_lines[wave];
+    uint32_t* const my_runline = s_runline[wave];
 
-    // Word w, first half of the work: the leading 32 code bits of both strands at this lane's position (kept for the
-    // k-mer extraction one iteration later) and the row-scanned hashes of the canonical 16-mers they spell.
-    auto scan_word = [&](int w, uint32_t& f0, uint32_t& c0, uint32_t& P, uint32_t& S) {
-        const int q = off + min(w * 64 + lane, last_m);
-        f0 = bits_at(s_fw, 2 * q);
-        c0 = bits_at(s_cw, 2 * q);
-        row_scan_min(mhash32(((uint64_t)min(f0, brev32(c0))) << 32), P, S);
-    };
+    // canonical 16-mer hash from the leading 32 code bits of both strands
+    auto mmer_of = [](uint32_t f0, uint32_t c0) { return mhash32(((uint64_t)min(f0, brev32(c0))) << 32); };
 
     int64_t sum_acc = 0;                                   // per lane
     uint64_t* my_bits = bits + (size_t)blockIdx.x * TILE_BITS_U64;
-    uint32_t Fc = 0, Cc = 0, Pc = 0, Sc = 0;               // scan_word of the first word of the next iteration
-    if (w_begin < w_end) scan_word(w_begin, Fc, Cc, Pc, Sc);
+    // carried from one word to the next: leading code words of both strands at this lane's position, and the row scans
+    // of the M-mer hashes they give
+    uint32_t Fc = 0, Cc = 0, Pc = 0, Sc = 0;
+    if (w_begin < w_end) {
+        const int q = off + w_begin * 64 + lane;
+        Fc = bits_at(s_fw, 2 * q);
+        Cc = bits_at(s_cw, 2 * q);
+        row_scan_min(mmer_of(Fc, Cc), Pc, Sc);
+    }
 
-    for (int w = w_begin; w < w_end; w += U) {
-        uint32_t Fn[U + 1], Cn[U + 1], Pn[U + 1], Sn[U + 1];
-        Fn[0] = Fc;
-        Cn[0] = Cc;
-        Pn[0] = Pc;
-        Sn[0] = Sc;
-#pragma unroll
-        for (int u = 1; u <= U; ++u) scan_word(w + u, Fn[u], Cn[u], Pn[u], Sn[u]);
-        Fc = Fn[U];
-        Cc = Cn[U];
-        Pc = Pn[U];
-        Sc = Sn[U];
+    for (int w = w_begin; w < w_end; ++w) {
+        const int j = w * 64 + lane;
+        const int q = off + j;
+        // bits [2q+32, 2q+64) of this word and bits [2(q+64), 2(q+64)+32) of the next share one word index and shift
+        const int b = 2 * q + 31;
+        const int wi = b >> 5;
+        const uint32_t sh = 31u - (uint32_t)(b & 31);
+        constexpr uint32_t lo_mask = ~0u << (64 - 2 * k);
+        const uint32_t f1 = alignbit32(s_fw[wi], s_fw[wi + 1], sh) & lo_mask;
+        const uint32_t c1 = alignbit32(s_cw[wi], s_cw[wi + 1], sh) & lo_mask;
+        const uint32_t Fn = alignbit32(s_fw[wi + 3], s_fw[wi + 4], sh);
+        const uint32_t Cn = alignbit32(s_cw[wi + 3], s_cw[wi + 4], sh);
+        uint32_t Pn, Sn;
+        row_scan_min(mmer_of(Fn, Cn), Pn, Sn);
 
-        uint64_t key[U];
-        uint32_t tgt[U], st[U], cnt[U], hm[U];
-        uint64_t V[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            // second half of extract_kmer at the position scan_word used (lanes past the last k-mer are invalid anyway)
-            const int j = (w + u) * 64 + lane;
-            const int q = off + min(j, last_m);
-            constexpr uint32_t lo_mask = ~0u << (64 - 2 * k);
-            const uint64_t fwd = (((uint64_t)Fn[u]) << 32) | (bits_at(s_fw, 2 * q + 32) & lo_mask);
-            const uint32_t c1 = bits_at(s_cw, 2 * q + 32) & lo_mask;
-            const uint64_t rc = ((((uint64_t)brev32(c1)) << 32) | brev32(Cn[u])) << (64 - 2 * k);
-            const bool valid = kmer_valid(s_vb, q, k) && (j < td.n_kmers) && (w + u < w_end);
-            // Kmer(Kmer, bothStrands): canonical = min(fwd, revcomp) unsigned (Kmer.java:72-79,406-414)
-            key[u] = (BOTH && rc < fwd) ? rc : fwd;
-            // minimizer of the k-mer = min over its 16 M-mers = min(S[lane], P[lane + 15])
-            const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(next15, (int)Pn[u]);
-            const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute(next15, (int)Pn[u + 1]);
-            const uint32_t mn = min(Sn[u], lane < 49 ? pa : pb);
-            tgt[u] = line_of_minimizer(mn, tv.n_lines);     // home line, shared by the whole minimizer run
-            st[u] = valid ? 1u : 0u;                        // 1 = pending, 2 = found, 0 = absent / invalid
-            cnt[u] = 0;
-            hm[u] = 0;                                      // meta dword of the line matched last
-            V[u] = __ballot(valid);
-        }
+        // extract_kmer (kcfx_device.h) from the four halves
+        const uint64_t fwd = u64_of(f1, Fc);
+        const uint64_t rc = u64_of(brev32(Cc), brev32(c1)) << (64 - 2 * k);
+        // Kmer(Kmer, bothStrands): canonical = min(fwd, revcomp) unsigned (Kmer.java:72-79,406-414)
+        const uint64_t key = (BOTH && rc < fwd) ? rc : fwd;
+        // all k bases are A/C/G/T, and the position is a k-mer of this tile
+        const uint64_t V = wave_ballot((bits_at(s_vb, q) >> (32 - k)) == (uint32_t)((1ull << k) - 1)) &
+                           wave_ballot(j < td.n_kmers);
 
-        // ---- cooperative probe rounds (see screen_tiles_kernel); the lines of all U words share one wait ----------
+        // minimizer of the k-mer = min over its 16 M-mers = min(S[lane], P[lane + 15])
+        const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(next15, (int)Pc);
+        const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute(next15, (int)Pn);
+        const uint32_t mn = min(Sc, lane < 49 ? pa : pb);
+        uint32_t tgt = line_of_minimizer(mn, tv.n_lines);   // home line, shared by the whole minimizer run
+        Fc = Fn;
+        Cc = Cn;
+        Pc = Pn;
+        Sc = Sn;
+
+        // Probe state lives in VGPR integers and is updated with selects (see screen_tiles_kernel)
+        uint32_t st = (uint32_t)((V >> lane) & 1);          // 1 = pending, 2 = found, 0 = absent / invalid
+        uint32_t cnt = 0;
+        uint32_t hm = 0;                                    // meta dword of the line matched last
+        // ---- cooperative probe rounds: each round fetches, for every run of adjacent pending lanes with the same
+        //      target line, that line ONCE (8 lanes x 16 B = one 128-byte request) into wave-private LDS -------------
         for (int round = 0;; ++round) {
-            uint64_t any_pending = 0;
-#pragma unroll
-            for (int u = 0; u < U; ++u) any_pending |= __ballot(st[u] == 1u);
-            if (!any_pending) break;
-            int nruns[U], my_run[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (round == 1) {
-                    // HEAVY minimizer home: its k-mers live at their key-hash lines -- jump, do not walk
-                    const bool redirect = (st[u] == 1u) && (hm[u] & META_HEAVY);
-                    if (__ballot(redirect)) {
-                        // rare: keep the key hash (3 quarter-rate multiplies) from being hoisted into every word
-                        uint32_t klo = (uint32_t)key[u], khi = (uint32_t)(key[u] >> 32);
-                        asm volatile("" : "+v"(klo), "+v"(khi));
-                        if (redirect) tgt[u] = keyhash_line(tv, u64_of(klo, khi));
-                    }
+            const uint64_t PM = wave_ballot(st == 1u);
+            if (!PM) break;
+            if (round == 1) {
+                // HEAVY minimizer home (table_finalize also sets its overflow bit, so such lanes are still pending):
+                // every k-mer homed there by minimizer lives at its key-hash line instead -- jump, do not walk
+                const uint64_t RM = PM & wave_ballot((hm & META_HEAVY) != 0u);
+                if (RM) {
+                    // rare: keep the key hash (3 quarter-rate multiplies) from being hoisted into every word
+                    uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+                    asm volatile("" : "+v"(klo), "+v"(khi));
+                    if ((RM >> lane) & 1) tgt = keyhash_line(tv, u64_of(klo, khi));
                 }
-                const uint32_t prev_tgt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tgt[u], 0x138, 0xf, 0xf, false);
-                const uint32_t prev_st = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)st[u], 0x138, 0xf, 0xf, false);
-                const bool head = (st[u] == 1u) && (prev_st != 1u || prev_tgt != tgt[u]);
-                const uint64_t HM = __ballot(head);
-                nruns[u] = __popcll(HM);
-                // heads at or below this lane, minus one
-                my_run[u] = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(HM >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)HM, 0u)) +
-                            (head ? 1 : 0) - 1;
-                s_runline[wave][u][(st[u] == 1u) ? my_run[u] : 64] = tgt[u];
             }
+            // heads of runs: pending lanes whose predecessor is not pending or aims at another line
+            const uint64_t HM = PM & (wave_ballot(wave_shr1(st) != 1u) | wave_ballot(wave_shr1(tgt) != tgt));
+            const int nruns = __popcll(HM);
+            // index of this lane's run = heads at or below it, minus one
+            const uint64_t H1 = HM >> 1;
+            const int my_run = (int)__builtin_amdgcn_mbcnt_hi(
+                (uint32_t)(H1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)H1, (uint32_t)((int)(HM & 1) - 1)));
+            // every pending lane stores its run's line index (same value within a run); the others hit a dummy slot
+            my_runline[(st == 1u) ? my_run : 64] = tgt;
             wave_lds_fence();
-            int max_runs = nruns[0];
-#pragma unroll
-            for (int u = 1; u < U; ++u) max_runs = max(max_runs, nruns[u]);
-            for (int c0 = 0; c0 < max_runs; c0 += K31_RUNS) {
-                const int r0 = c0 + (lane >> 3), r1 = r0 + 8;
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    // 8 lanes x 16 B = one 128-byte request per run; lane i's 16 bytes land at base + 16 i
-                    if (r0 < nruns[u])
-                        __builtin_amdgcn_global_load_lds(
-                            (gptr_t)(tv.lines + (size_t)s_runline[wave][u][r0] * LINE_BYTES + 16 * piece),
-                            (lptr_t)&s_lines[wave][u][0], 16, 0, 0);
-                    if (r1 < nruns[u])
-                        __builtin_amdgcn_global_load_lds(
-                            (gptr_t)(tv.lines + (size_t)s_runline[wave][u][r1] * LINE_BYTES + 16 * piece),
-                            (lptr_t)&s_lines[wave][u][64], 16, 0, 0);
-                }
+            for (int c0 = 0; c0 < nruns; c0 += K31_RUNS) {
+                const int r0 = c0 + fetch_run, r1 = r0 + 7;
+                // 8 lanes x 16 B = one 128-byte request per run
+                if (fetcher && r0 < nruns)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(tv.lines + (size_t)my_runline[r0] * LINE_BYTES + 16 * piece),
+                                                     (lptr_t)my_lines, 16, 0, 0);
+                if (fetcher && r1 < nruns)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(tv.lines + (size_t)my_runline[r1] * LINE_BYTES + 16 * piece),
+                                                     (lptr_t)(my_lines + 7 * K31_PITCH), 16, 0, 0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 wave_lds_fence();
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    // every lane matches (idle lanes against buffer 0); the outcome is merged with selects
-                    const uint32_t rel = (uint32_t)(my_run[u] - c0);
-                    const bool mine = (st[u] == 1u) && (rel < (uint32_t)K31_RUNS);
-                    const uint4* src = &s_lines[wave][u][(mine ? rel : 0u) * 8];
-                    uint32_t c, meta;
-                    const bool any = match_line_lds<WIDE, false>(src, key[u], c, meta);
-                    const uint32_t ov = (meta >> 8) & 1u;                   // overflowed line: look at the next one
-                    const uint32_t nst = any ? 2u : ov;
-                    const uint32_t ntgt = (tgt[u] + 1 == tv.n_lines) ? 0u : tgt[u] + 1;
-                    cnt[u] = (mine && any) ? c : cnt[u];                    // Java int (KMC.java:395-401)
-                    tgt[u] = (mine && nst == 1u) ? ntgt : tgt[u];
-                    hm[u] = mine ? meta : hm[u];
-                    st[u] = mine ? nst : st[u];
-                }
+                // every lane matches (idle lanes against buffer 0); the outcome is merged with selects
+                const uint32_t rel = (uint32_t)(my_run - c0);
+                const bool mine = (st == 1u) && (rel < (uint32_t)K31_RUNS);
+                const uint4* src = my_lines + (mine ? rel : 0u) * K31_PITCH;
+                uint32_t c, meta;
+                const bool any = match_line_lds<WIDE, false>(src, key, c, meta);
+                const uint32_t ov = (meta >> 8) & 1u;                       // overflowed line: look at the next one
+                const uint32_t nst = any ? 2u : ov;
+                const uint32_t ntgt = (tgt + 1 == tv.n_lines) ? 0u : tgt + 1;
+                cnt = (mine && any) ? c : cnt;                              // Java int (KMC.java:395-401)
+                tgt = (mine && nst == 1u) ? ntgt : tgt;
+                hm = mine ? meta : hm;
+                st = mine ? nst : st;
                 wave_lds_fence();
             }
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool hit = (st[u] == 2u) && ((int32_t)cnt[u] >= min_count);   // GetVariants.java:224
-            const uint64_t H = __ballot(hit);
-            if (lane == 0 && w + u < w_end) {              // this word of the window's hit bitmap
-                my_bits[w + u] = V[u];
-                my_bits[TILE_WORDS + w + u] = H;
-            }
-            if (hit) sum_acc += (int64_t)(int32_t)cnt[u];                        // GetVariants.java:226
+        // cnt is 0 unless the k-mer was found and min_count >= 1 (checked by the API), so this is "found && count >= -c"
+        const bool hit = (int32_t)cnt >= min_count;                         // GetVariants.java:224
+        const uint64_t H = wave_ballot(hit);
+        if (lane == 0) {                                                    // this word of the window's hit bitmap
+            my_bits[w] = V;
+            my_bits[TILE_WORDS + w] = H;
         }
+        sum_acc += hit ? (int64_t)(int32_t)cnt : 0;                         // GetVariants.java:226
     }
 
     const int64_t count_sum = wave_sum_i64(sum_acc);
@@ -830,14 +833,10 @@ hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32
     if (!tv.wide && tv.mode == MODE_MINIMIZER && var == 10) { KCFX_LAUNCH(false, MODE_MINIMIZER, 0, 0); return hipGetLastError(); }
 #endif
     if (tv.mode == MODE_MINIMIZER && spec && !getenv("KCFX_OLD_KERNEL")) {
-#define KCFX_LAUNCH31(W, BS, UU) \
-    hipLaunchKernelGGL((screen_k31_kernel<W, BS, UU>), g, b, 0, st, text, tiles, tv, min_count, bits, count_sums)
-#ifdef KCFX_EXPERIMENTS
-        static const int words = getenv("KCFX_WORDS") ? atoi(getenv("KCFX_WORDS")) : 1;
-        if (words == 2 && !tv.wide && both_strands) { KCFX_LAUNCH31(false, true, 2); return hipGetLastError(); }
-#endif
-        if (tv.wide) { if (both_strands) KCFX_LAUNCH31(true, true, 1); else KCFX_LAUNCH31(true, false, 1); }
-        else         { if (both_strands) KCFX_LAUNCH31(false, true, 1); else KCFX_LAUNCH31(false, false, 1); }
+#define KCFX_LAUNCH31(W, BS) \
+    hipLaunchKernelGGL((screen_k31_kernel<W, BS>), g, b, 0, st, text, tiles, tv, min_count, bits, count_sums)
+        if (tv.wide) { if (both_strands) KCFX_LAUNCH31(true, true); else KCFX_LAUNCH31(true, false); }
+        else         { if (both_strands) KCFX_LAUNCH31(false, true); else KCFX_LAUNCH31(false, false); }
 #undef KCFX_LAUNCH31
         return hipGetLastError();
     }
