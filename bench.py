@@ -2,7 +2,7 @@
 """bench.py -- k-mers screened/s of the getVariations hot path on N MI355X (BASELINE.json metric).
 
 A "step" is one pass of the hot path over one batch: every window of the reference screened against one
-sample's KMC database (kcfx_screen_ref_async: screen_tiles + finalize_windows), inputs resident in HBM.
+sample's KMC database (kcfx_screen_ref_async: screen_k31 + summarize_tiles + finalize_windows), inputs resident in HBM.
 
 Workload at N=1 (BASELINE.json configs[1]): synthetic A. thaliana chr1-sized reference (30,427,671 bp, seeded),
 one synthetic KMC sample (k=31, counter_size 2, ~150 M k-mers = sample-genome k-mers + random noise k-mers),
@@ -229,7 +229,7 @@ def main():
         "windows_per_s": n_win * world * args.steps / elapsed,
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "screen_tiles_kernel", "kernel_avg_ms": kern_avg_ms, "launches_timed": int(launches),
+                     "kernel": "screen_k31_kernel", "kernel_avg_ms": kern_avg_ms, "launches_timed": int(launches),
                      "algorithmic_bytes_per_kmer": B_ALG},
         "cpu_baseline": cpu,
         "parity": parity,

@@ -56,7 +56,10 @@ struct TableView {
 // finalize_windows folds a window's tiles in order.
 // ----------------------------------------------------------------------------------------------------
 constexpr int BLOCK = 256;            // 4 wavefronts
-constexpr int TILE_K = 2048;          // k-mer start positions per tile (multiple of 64)
+#ifndef KCFX_TILE_K
+#define KCFX_TILE_K 2048
+#endif
+constexpr int TILE_K = KCFX_TILE_K;   // k-mer start positions per tile (multiple of 64)
 constexpr int TILE_WORDS = TILE_K / 64;
 // per tile: TILE_WORDS valid-ballots then TILE_WORDS hit-ballots (screen_tiles -> summarize_tiles)
 constexpr int TILE_BITS_U64 = 2 * TILE_WORDS;

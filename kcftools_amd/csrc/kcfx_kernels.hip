@@ -14,6 +14,8 @@
 
 #include "kcfx_device.h"
 
+#include <type_traits>
+
 namespace kcfx {
 
 // ======================================================================================================
@@ -185,6 +187,18 @@ __device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
     return v;
 }
 
+// wave total of a u32 in six DPP adds (row_shr 1/2/4/8 leave each row's sum in its lane 15; row_bcast15 / row_bcast31
+// carry it across rows); the result is lane 63's value, returned to every lane as a scalar
+__device__ __forceinline__ uint32_t wave_sum_u32_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // __ballot() takes an int: hipcc materialises the predicate (v_cndmask 0/1) and compares it again, two VALU
 // instructions per ballot in a VALU-bound kernel. The builtin reads the condition mask directly.
 __device__ __forceinline__ uint64_t wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -198,14 +212,12 @@ __device__ __forceinline__ void wave_lds_fence() {
     asm volatile("" ::: "memory");
 }
 
-// VAR != 0 only exists in the experiments build (-DKCFX_EXPERIMENTS, libkcfx_exp.so): timing ablations whose
-// results are deliberately wrong. 2: no gap accounting  3: no table probe
-//
-// KT = 31: k = 31 and M = 16 are compile-time constants (the BASELINE.json configuration); KT = 0: any k <= 32 / M.
-template <bool WIDE, int MODE, int KT, int VAR>
+// The general kernel: any k <= 32, any minimizer length, both table modes. The BASELINE.json configuration
+// (k = 31, M = 16, minimizer table) runs screen_k31_kernel below instead; KCFX_GENERIC_KERNEL=1 forces this one.
+template <bool WIDE, int MODE>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void screen_tiles_kernel(const uint8_t* __restrict__ text,
                                                              const TileDesc* __restrict__ tiles, TableView tv,
-                                                             int32_t k_rt, int32_t both_strands, int32_t min_count,
+                                                             int32_t k, int32_t both_strands, int32_t min_count,
                                                              uint64_t* __restrict__ bits,
                                                              int64_t* __restrict__ count_sums) {
     constexpr bool MINI = (MODE == MODE_MINIMIZER);
@@ -225,8 +237,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     __shared__ uint32_t s_runline[WAVES][65];              // line index of each run, per wave (+1 dummy slot)
     __shared__ int64_t s_sum[WAVES];
 
-    const int k = KT ? KT : k_rt;
-    const int M = KT ? 16 : tv.mm_len;
+    const int M = tv.mm_len;
     const int wlen = k - M + 1;                            // M-mers per k-mer
     const TileDesc td = tiles[blockIdx.x];
     const int tid = threadIdx.x;
@@ -265,54 +276,24 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         for (int p = tid; p < n_blk * wlen; p += BLOCK) {
             uint32_t h = 0xFFFFFFFFu;                      // padding of the last block
             if (p < n_m) {
-                if (KT) {    // M = 16: the M-mer is one dword; same value as mmer_hash on the left-aligned words
-                    const uint32_t f = bits_at(s_fw, 2 * (off + p)), r = brev32(bits_at(s_cw, 2 * (off + p)));
-                    h = mhash32(((uint64_t)min(f, r)) << 32);
-                } else {
-                    uint64_t f, r;
-                    extract_pair(s_fw, s_cw, off + p, M, f, r);
-                    h = mmer_hash(f, r);
-                }
+                uint64_t f, r;
+                extract_pair(s_fw, s_cw, off + p, M, f, r);
+                h = mmer_hash(f, r);
             }
             s_ha[p] = h;
         }
         __syncthreads();
         for (int b = tid; b < n_blk; b += BLOCK) {
             const int base = b * wlen;
-            if (KT) {                                      // wlen = 16: one lane scans its block in registers
-                uint32_t v[16];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint4 x = *reinterpret_cast<const uint4*>(&s_ha[base + 4 * i]);
-                    v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
-                }
-                // suffix minima first (written out four at a time), then prefix minima in place: ~20 live registers
-                uint32_t run = 0xFFFFFFFFu;
-#pragma unroll
-                for (int i = 3; i >= 0; --i) {
-                    uint4 o;
-                    o.w = run = min(run, v[4 * i + 3]);
-                    o.z = run = min(run, v[4 * i + 2]);
-                    o.y = run = min(run, v[4 * i + 1]);
-                    o.x = run = min(run, v[4 * i]);
-                    *reinterpret_cast<uint4*>(&s_hb[base + 4 * i]) = o;
-                }
-#pragma unroll
-                for (int i = 1; i < 16; ++i) v[i] = min(v[i], v[i - 1]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    *reinterpret_cast<uint4*>(&s_ha[base + 4 * i]) = make_uint4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
-            } else {
-                uint32_t run = 0xFFFFFFFFu;
-                for (int i = wlen - 1; i >= 0; --i) {
-                    run = min(run, s_ha[base + i]);
-                    s_hb[base + i] = run;
-                }
-                run = 0xFFFFFFFFu;
-                for (int i = 0; i < wlen; ++i) {
-                    run = min(run, s_ha[base + i]);
-                    s_ha[base + i] = run;
-                }
+            uint32_t run = 0xFFFFFFFFu;
+            for (int i = wlen - 1; i >= 0; --i) {
+                run = min(run, s_ha[base + i]);
+                s_hb[base + i] = run;
+            }
+            run = 0xFFFFFFFFu;
+            for (int i = 0; i < wlen; ++i) {
+                run = min(run, s_ha[base + i]);
+                s_ha[base + i] = run;
             }
         }
         __syncthreads();
@@ -326,7 +307,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const int n_words = (td.n_kmers + 63) >> 6;
     const int wpw = (n_words + WAVES - 1) / WAVES;
     const int w_begin = min(wave * wpw, n_words);
-    const int w_end = (VAR == 8) ? w_begin : min(w_begin + wpw, n_words);   // VAR 8: phases 1 / 1b only
+    const int w_end = min(w_begin + wpw, n_words);
     const uint64_t lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1);   // bits 0..lane
     const uint64_t lane_prev = lane ? (1ull << (lane - 1)) : 0ull;           // bit lane-1
     uint4* my_lines = s_line + wave * (RUN_CHUNK * LINE_STRIDE);
@@ -356,10 +337,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         uint32_t st = valid ? 1u : 0u;          // 1 = pending, 2 = found, 0 = absent / invalid
         uint32_t cnt = 0;
         uint32_t home_meta = 0;                 // meta dword of the line matched last (HEAVY check after round 0)
-        if (VAR == 3) {
-            cnt = (uint32_t)(key >> 60) + (tgt & 1);
-            st = (key & 0x300) ? 2u : 0u;
-        }
         // ---- cooperative probe rounds: each round fetches, for every run of adjacent pending lanes with the same
         //      target line, that line ONCE (8 lanes x 16 B = one 128-byte request) into wave-private LDS -------------
         for (int round = 0;; ++round) {
@@ -385,38 +362,20 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             for (int c0 = 0; c0 < nruns; c0 += RUN_CHUNK) {
                 const int r0 = c0 + (lane >> 3), r1 = r0 + 8;
                 const int piece = lane & 7;
-                constexpr int LS = (VAR == 9) ? 8 : LINE_STRIDE;
-                if (VAR == 9) {
-                    // LDS-DMA: the 16 bytes of every lane land at (wave-uniform base) + 16 * lane; no VGPR in between
-                    typedef __attribute__((address_space(1))) const void* gptr_t;
-                    typedef __attribute__((address_space(3))) void* lptr_t;
-                    if (r0 < nruns)
-                        __builtin_amdgcn_global_load_lds((gptr_t)(tv.lines + (size_t)s_runline[wave][r0] * LINE_BYTES + 16 * piece),
-                                                         (lptr_t)my_lines, 16, 0, 0);
-                    if (r1 < nruns)
-                        __builtin_amdgcn_global_load_lds((gptr_t)(tv.lines + (size_t)s_runline[wave][r1] * LINE_BYTES + 16 * piece),
-                                                         (lptr_t)(my_lines + 64), 16, 0, 0);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    wave_lds_fence();
-                } else {
                 uint4 a, b;
-                    if (VAR == 6) {                      // VAR 6: no table traffic
-                        a = make_uint4(piece, r0, 0u, 0u);
-                        b = make_uint4(piece, r1, 0u, 0u);
-                    } else if (r0 < nruns)
-                        a = reinterpret_cast<const uint4*>(tv.lines + (size_t)s_runline[wave][r0] * LINE_BYTES)[piece];
-                    if (VAR != 6 && r1 < nruns)
-                        b = reinterpret_cast<const uint4*>(tv.lines + (size_t)s_runline[wave][r1] * LINE_BYTES)[piece];
-                    my_lines[(lane >> 3) * LINE_STRIDE + piece] = a;
-                    my_lines[(8 + (lane >> 3)) * LINE_STRIDE + piece] = b;
-                    wave_lds_fence();
-}
+                if (r0 < nruns)
+                    a = reinterpret_cast<const uint4*>(tv.lines + (size_t)s_runline[wave][r0] * LINE_BYTES)[piece];
+                if (r1 < nruns)
+                    b = reinterpret_cast<const uint4*>(tv.lines + (size_t)s_runline[wave][r1] * LINE_BYTES)[piece];
+                my_lines[(lane >> 3) * LINE_STRIDE + piece] = a;
+                my_lines[(8 + (lane >> 3)) * LINE_STRIDE + piece] = b;
+                wave_lds_fence();
                 // every lane matches (idle lanes against buffer 0); the outcome is merged with selects
                 const uint32_t rel = (uint32_t)(my_run - c0);
                 const bool mine = (st == 1u) && (rel < (uint32_t)RUN_CHUNK);
-                const uint4* src = my_lines + (mine ? rel : 0u) * LS;
+                const uint4* src = my_lines + (mine ? rel : 0u) * LINE_STRIDE;
                 uint32_t c, meta;
-                const bool any = match_line_lds<WIDE, KT == 0>(src, key, c, meta);
+                const bool any = match_line_lds<WIDE, true>(src, key, c, meta);
                 const uint32_t ov = (meta >> 8) & 1u;                       // overflowed line: look at the next one
                 const uint32_t nst = any ? 2u : ov;
                 const uint32_t ntgt = (tgt + 1 == tv.n_lines) ? 0u : tgt + 1;
@@ -487,8 +446,8 @@ __device__ __forceinline__ void row_scan_min(uint32_t h, uint32_t& P, uint32_t& 
     S = min(S, dpp_or_ones<0x104>(S));
     S = min(S, dpp_or_ones<0x108>(S));
 }
-__device__ __forceinline__ uint32_t wave_shr1(uint32_t x) {     // lane l gets lane l-1's value, lane 0 gets 0
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, false);
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t x) {     // lane l gets lane l-1's value, lane 0 gets 0 (bound_ctrl)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, true);
 }
 
 template <bool WIDE, bool BOTH>
@@ -552,7 +511,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     // canonical 16-mer hash from the leading 32 code bits of both strands
     auto mmer_of = [](uint32_t f0, uint32_t c0) { return mhash32(((uint64_t)min(f0, brev32(c0))) << 32); };
 
-    int64_t sum_acc = 0;                                   // per lane
+    // u16 counters: a wave's total over its <= TILE_WORDS words fits 32 bits; 4-byte counters are Java ints (may be < 0)
+    static_assert((uint64_t)TILE_WORDS * 64 * 65535 < (1ull << 32), "32-bit count sums");
+    typename std::conditional<WIDE, int64_t, uint32_t>::type sum_acc = 0;   // per lane
     uint64_t* my_bits = bits + (size_t)blockIdx.x * TILE_BITS_U64;
     // carried from one word to the next: leading code words of both strands at this lane's position, and the row scans
     // of the M-mer hashes they give
@@ -662,10 +623,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             my_bits[w] = V;
             my_bits[TILE_WORDS + w] = H;
         }
-        sum_acc += hit ? (int64_t)(int32_t)cnt : 0;                         // GetVariants.java:226
+        if (WIDE) sum_acc += hit ? (int64_t)(int32_t)cnt : 0;               // GetVariants.java:226
+        else sum_acc += hit ? cnt : 0u;
     }
 
-    const int64_t count_sum = wave_sum_i64(sum_acc);
+    int64_t count_sum;
+    if constexpr (WIDE) count_sum = wave_sum_i64(sum_acc);
+    else count_sum = (int64_t)wave_sum_u32_dpp(sum_acc);
     if (lane == 0) s_sum[wave] = count_sum;
     __syncthreads();
     if (tid == 0) {
@@ -819,34 +783,20 @@ hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32
                                hipStream_t st) {
     if (n_tiles <= 0) return hipSuccess;
     const dim3 g(n_tiles), b(BLOCK);
-#define KCFX_LAUNCH(W, MD, KT, V) \
-    hipLaunchKernelGGL((screen_tiles_kernel<W, MD, KT, V>), g, b, 0, st, text, tiles, tv, k, both_strands, min_count, bits, count_sums)
-    const bool spec = (k == 31) && (tv.mode == MODE_KEYHASH || tv.mm_len == 16);   // compile-time k / M
-#ifdef KCFX_EXPERIMENTS
-    static const int var = getenv("KCFX_VARIANT") ? atoi(getenv("KCFX_VARIANT")) : 0;
-    if (!tv.wide && spec && tv.mode == MODE_MINIMIZER && var == 2) { KCFX_LAUNCH(false, MODE_MINIMIZER, 31, 2); return hipGetLastError(); }
-    if (!tv.wide && spec && tv.mode == MODE_MINIMIZER && var == 3) { KCFX_LAUNCH(false, MODE_MINIMIZER, 31, 3); return hipGetLastError(); }
-    if (!tv.wide && spec && tv.mode == MODE_KEYHASH && var == 3) { KCFX_LAUNCH(false, MODE_KEYHASH, 31, 3); return hipGetLastError(); }
-    if (!tv.wide && spec && tv.mode == MODE_MINIMIZER && var == 6) { KCFX_LAUNCH(false, MODE_MINIMIZER, 31, 6); return hipGetLastError(); }
-    if (!tv.wide && spec && tv.mode == MODE_MINIMIZER && var == 8) { KCFX_LAUNCH(false, MODE_MINIMIZER, 31, 8); return hipGetLastError(); }
-    if (!tv.wide && spec && tv.mode == MODE_MINIMIZER && var == 9) { KCFX_LAUNCH(false, MODE_MINIMIZER, 31, 9); return hipGetLastError(); }
-    if (!tv.wide && tv.mode == MODE_MINIMIZER && var == 10) { KCFX_LAUNCH(false, MODE_MINIMIZER, 0, 0); return hipGetLastError(); }
-#endif
-    if (tv.mode == MODE_MINIMIZER && spec && !getenv("KCFX_OLD_KERNEL")) {
+#define KCFX_LAUNCH(W, MD) \
+    hipLaunchKernelGGL((screen_tiles_kernel<W, MD>), g, b, 0, st, text, tiles, tv, k, both_strands, min_count, bits, count_sums)
 #define KCFX_LAUNCH31(W, BS) \
     hipLaunchKernelGGL((screen_k31_kernel<W, BS>), g, b, 0, st, text, tiles, tv, min_count, bits, count_sums)
+    const bool generic_only = getenv("KCFX_GENERIC_KERNEL") != nullptr;             // A/B and test hook (read per launch)
+    if (tv.mode == MODE_MINIMIZER && k == 31 && tv.mm_len == 16 && !generic_only) {
         if (tv.wide) { if (both_strands) KCFX_LAUNCH31(true, true); else KCFX_LAUNCH31(true, false); }
         else         { if (both_strands) KCFX_LAUNCH31(false, true); else KCFX_LAUNCH31(false, false); }
-#undef KCFX_LAUNCH31
-        return hipGetLastError();
-    }
-    if (tv.mode == MODE_MINIMIZER) {
-        if (spec) { if (tv.wide) KCFX_LAUNCH(true, MODE_MINIMIZER, 31, 0); else KCFX_LAUNCH(false, MODE_MINIMIZER, 31, 0); }
-        else      { if (tv.wide) KCFX_LAUNCH(true, MODE_MINIMIZER, 0, 0); else KCFX_LAUNCH(false, MODE_MINIMIZER, 0, 0); }
+    } else if (tv.mode == MODE_MINIMIZER) {
+        if (tv.wide) KCFX_LAUNCH(true, MODE_MINIMIZER); else KCFX_LAUNCH(false, MODE_MINIMIZER);
     } else {
-        if (spec) { if (tv.wide) KCFX_LAUNCH(true, MODE_KEYHASH, 31, 0); else KCFX_LAUNCH(false, MODE_KEYHASH, 31, 0); }
-        else      { if (tv.wide) KCFX_LAUNCH(true, MODE_KEYHASH, 0, 0); else KCFX_LAUNCH(false, MODE_KEYHASH, 0, 0); }
+        if (tv.wide) KCFX_LAUNCH(true, MODE_KEYHASH); else KCFX_LAUNCH(false, MODE_KEYHASH);
     }
+#undef KCFX_LAUNCH31
 #undef KCFX_LAUNCH
     return hipGetLastError();
 }

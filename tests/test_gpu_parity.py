@@ -270,3 +270,36 @@ def test_low_complexity_repeats_take_the_heavy_bucket_path(oracle, tmp_path):
     db2 = engine.KmcDb.build(kmers, counts, k, 2, True)
     assert db2.info.heavy_lines > 0
     assert_same(db2.screen(ref, s, e - s, 1), want, "low complexity (array build)")
+
+
+@pytest.mark.parametrize("cs,both", [(2, True), (4, False), (1, True)])
+def test_k31_specialised_and_generic_kernels_agree(oracle, tmp_path, cs, both, monkeypatch):
+    """k = 31 / M = 16 runs screen_k31_kernel (register-resident minimizers, LDS-DMA); KCFX_GENERIC_KERNEL forces the
+    general screen_tiles_kernel on the same table. Both must equal the oracle, on text with N runs, soft-masking,
+    low-complexity stretches and windows that are not tile-aligned."""
+    import os
+    k = 31
+    rng = np.random.default_rng(77)
+    ref = bytearray(synth.random_reference(400_000, 31))
+    for pos in rng.integers(0, len(ref) - 400, 40):
+        ref[pos:pos + int(rng.integers(1, 300))] = b"N" * int(rng.integers(1, 300))
+    ref[1000:1500] = bytes(ref[1000:1500]).lower()
+    ref[50_000:52_000] = b"AC" * 1000
+    ref[90_000:90_700] = b"A" * 700
+    ref = bytes(ref[:400_000])
+    prefix, *_ = make_db(tmp_path, "both", ref, 9, k=k, p=3, cs=cs, m=7, bins=8, both=both, noise=20_000)
+    db = engine.KmcDb.open(prefix)
+    assert db.info.minimizer_length == 16
+    odb = oracle.OracleDb(prefix)
+    begins = np.concatenate([np.arange(0, 390_000, 7_777), [399_000, 399_969, 399_970]]).astype(np.int64)
+    lens = np.minimum(len(ref) - begins, 9_999).astype(np.int32)
+    want = odb.screen(ref, begins, lens, 1, threads=4)
+    fast = db.screen(ref, begins, lens, 1)
+    monkeypatch.setenv("KCFX_GENERIC_KERNEL", "1")
+    assert os.environ["KCFX_GENERIC_KERNEL"] == "1"
+    slow = db.screen(ref, begins, lens, 1)
+    monkeypatch.delenv("KCFX_GENERIC_KERNEL")
+    assert_same(fast, want, "screen_k31_kernel vs oracle")
+    assert_same(slow, want, "screen_tiles_kernel vs oracle")
+    for c in (2, 3):
+        assert_same(db.screen(ref, begins, lens, c), odb.screen(ref, begins, lens, c, threads=4), f"-c {c}")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise a tools/profile_round.sh run (gpurun_out/<tag>/) into profiles/<tag>_*: kernel stats, per-launch HBM
-traffic of screen_tiles (gfx950 correction from MI355X_MICROARCH.md: FETCH_SIZE counts 128-byte requests at 64 B, so
+traffic of the screening kernel (gfx950 correction from MI355X_MICROARCH.md: FETCH_SIZE counts 128-byte requests at 64 B, so
 read bytes = 2 x FETCH_SIZE; checked on the membench calibration kernel), counters, and profiles/traffic.json that
 bench.py reads for roofline.traffic."""
 import collections
@@ -12,6 +12,7 @@ import shutil
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+KERNEL = "screen_k31_kernel"      # the dominant kernel of the bench workload (k = 31, minimizer table)
 src = f"gpurun_out/{tag}"
 os.makedirs("profiles", exist_ok=True)
 
@@ -31,13 +32,16 @@ out["bench"] = {k: bench[k] for k in ("value", "ms_per_step", "roofline", "cpu_b
 for f in glob.glob(f"{src}/stats/*kernel_stats.csv"):
     shutil.copy(f, f"profiles/{tag}_kernel_stats.csv")
     for r in csv.DictReader(open(f)):
-        if "screen_tiles" in r["Name"]:
-            out["rocprof_screen_tiles_avg_ms"] = float(r["AverageNs"]) / 1e6
-            out["rocprof_screen_tiles_calls"] = int(r["Calls"])
-fetch, n1 = counters(f"{src}/pmc_fetch/*counter_collection.csv", "screen_tiles")
-write, _ = counters(f"{src}/pmc_write/*counter_collection.csv", "screen_tiles")
-tcc, _ = counters(f"{src}/pmc_tcc/*counter_collection.csv", "screen_tiles")
-sq, _ = counters(f"{src}/pmc_sq/*counter_collection.csv", "screen_tiles")
+        if KERNEL in r["Name"]:
+            out["rocprof_kernel"] = r["Name"].split("(")[0]
+            out["rocprof_kernel_avg_ms"] = float(r["AverageNs"]) / 1e6
+            out["rocprof_kernel_calls"] = int(r["Calls"])
+fetch, n1 = counters(f"{src}/pmc_fetch/*counter_collection.csv", KERNEL)
+write, _ = counters(f"{src}/pmc_write/*counter_collection.csv", KERNEL)
+tcc, _ = counters(f"{src}/pmc_tcc/*counter_collection.csv", KERNEL)
+sq, _ = counters(f"{src}/pmc_sq/*counter_collection.csv", KERNEL)
+sq2, _ = counters(f"{src}/pmc_sq2/*counter_collection.csv", KERNEL)
+sq.update(sq2)
 cal, _ = counters(f"{src}/pmc_cal/*counter_collection.csv", "gather_coop<8, 1>")
 out["counters"] = {"FETCH_SIZE_KB": fetch.get("FETCH_SIZE"), "WRITE_SIZE_KB": write.get("WRITE_SIZE"), **tcc, **sq}
 if cal.get("FETCH_SIZE"):
@@ -51,7 +55,7 @@ if fetch.get("FETCH_SIZE") is not None:
     out["hbm_read_bytes_per_launch"] = rd
     out["hbm_write_bytes_per_launch"] = wr
     cfg = bench["config"]
-    json.dump({"tag": tag, "kernel": "screen_tiles_kernel", "hbm_bytes_per_launch": rd + wr,
+    json.dump({"tag": tag, "kernel": KERNEL, "hbm_bytes_per_launch": rd + wr,
                "ref_len": 30427671, "db_kmers": 150000000, "window": 10000,
                "note": "2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes), separate --pmc passes, averaged over launches"},
               open("profiles/traffic.json", "w"), indent=1)

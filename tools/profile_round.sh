@@ -14,6 +14,7 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OU
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- $P > /dev/null 2> $OUT/pmc_write.err
 timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_tcc -o t -- $P > /dev/null 2> $OUT/pmc_tcc.err
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq -o q -- $P > /dev/null 2> $OUT/pmc_sq.err
+timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq2 -o q -- $P > /dev/null 2> $OUT/pmc_sq2.err
 # calibration of FETCH_SIZE on the same access pattern with a known byte count (8 lanes x 16 B random 128-byte lines)
 timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_cal -o c -- ./kcftools_amd/bin/kcfx_membench 4 64 > $OUT/membench.log 2> $OUT/pmc_cal.err
 ls $OUT
