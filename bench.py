@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import subprocess
 import sys
@@ -78,6 +79,9 @@ def main():
     ap.add_argument("--workdir", default=os.environ.get("KCFX_BENCH_DIR", "/tmp/kcfx_bench"))
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="target CPU work for the baseline leg (0 = skip)")
     ap.add_argument("--min-count", type=int, default=1)
+    ap.add_argument("--samples", type=int, default=1,
+                    help="samples per GPU; > 1 screens them in one pass over the reference (kcfx_screen_ref_multi, SURVEY f-4). "
+                         "The default 1 is BASELINE.json's configuration")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -105,7 +109,12 @@ def main():
     # ---- data: same reference on every rank, one sample database per rank -------------------------------
     ncpu = os.cpu_count() or 8
     t0 = time.time()
-    prefix, meta = make_dataset(synth_bin, args.workdir, args.ref_len, args.db_kmers, 2 + rank, max(1, ncpu // world))
+    S = max(1, args.samples)
+    prefixes = []
+    for i in range(S):
+        pfx, meta = make_dataset(synth_bin, args.workdir, args.ref_len, args.db_kmers, 2 + rank * S + i, max(1, ncpu // world))
+        prefixes.append(pfx)
+    prefix = prefixes[0]
     text = np.fromfile(prefix + ".ref.txt", dtype=np.uint8).tobytes()
     gen_s = time.time() - t0
     starts, ends = engine.windows(len(text), args.window, 0, K)
@@ -113,25 +122,30 @@ def main():
     win_len = (ends - starts).astype(np.int32)
 
     t0 = time.time()
-    db = engine.KmcDb.open(prefix, device=local_rank)
-    load_s = time.time() - t0
+    dbs = [engine.KmcDb.open(pfx, device=local_rank) for pfx in prefixes]
+    db = dbs[0]
+    load_s = (time.time() - t0) / S
     ref = engine.Reference(text, win_begin, win_len, K, device=local_rank)
     n_win = len(win_begin)
 
-    out = torch.zeros(n_win * 10, dtype=torch.int32, device=f"cuda:{local_rank}")
+    out = torch.zeros(S * n_win * 10, dtype=torch.int32, device=f"cuda:{local_rank}")
     gathered = [torch.zeros_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
     stream = torch.cuda.current_stream()
 
     def step():
-        ref.screen_async(db, out.data_ptr(), stream.cuda_stream, args.min_count)
+        if S == 1:
+            ref.screen_async(db, out.data_ptr(), stream.cuda_stream, args.min_count)
+        else:
+            ref.screen_multi_async(dbs, out.data_ptr(), stream.cuda_stream, args.min_count)
         if world > 1:
             dist.gather(out, gathered, dst=0)      # RCCL over xGMI: 40 B per (window, sample)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    res = out.cpu().numpy().view(engine.RESULT_DTYPE).copy()
-    kmers_per_step = int(res["total_kmers"].sum())
+    res_all = out.cpu().numpy().view(engine.RESULT_DTYPE).reshape(S, n_win).copy()
+    res = res_all[0]                               # the sample checked against the oracle below
+    kmers_per_step = int(res_all["total_kmers"].sum())
 
     # ---- timed region -----------------------------------------------------------------------------------------
     ref.prof_enable(True)
@@ -165,14 +179,17 @@ def main():
     value = kmers_all * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
     kern_avg_ms = kernel_ms / max(1, launches)
-    achieved_gbs = (kmers_per_step * B_ALG) / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
+    launches_per_step = max(1.0, launches / args.steps)                # multi-sample: one launch per <= 8 samples
+    # one ASCII base per reference position is read once for all S samples (SURVEY f-4: B_alg = 1/S + 8 + counter_size)
+    b_alg = 1.0 / S + 8 + COUNTER_SIZE
+    achieved_gbs = (kmers_per_step * b_alg / launches_per_step) / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
 
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("ref_len") == args.ref_len and tj.get("db_kmers") == args.db_kmers and tj.get("window") == args.window:
+            if S == 1 and tj.get("ref_len") == args.ref_len and tj.get("db_kmers") == args.db_kmers and tj.get("window") == args.window:
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -191,7 +208,7 @@ def main():
         t1 = time.perf_counter() - t0
         rate1 = int(w1["total_kmers"].sum()) / t1
         want_kmers = rate1 * args.cpu_baseline_seconds
-        n_s = int(min(n_win, max(threads, want_kmers / max(1, kmers_per_step / n_win))))
+        n_s = int(min(n_win, max(threads, want_kmers / max(1, kmers_per_step / S / n_win))))
         idx = np.linspace(0, n_win - 1, n_s).astype(np.int64)
         t0 = time.perf_counter()
         wN = odb.screen(text, win_begin[idx], win_len[idx], args.min_count, threads=threads)
@@ -220,17 +237,17 @@ def main():
         "vs_baseline": None,
         "dtype": "u64",
         "data": "synthetic",
-        "config": {"workload": f"getVariations: synthetic chr1-sized reference {args.ref_len} bp, 1 KMC sample per GPU "
+        "config": {"workload": f"getVariations: synthetic chr1-sized reference {args.ref_len} bp, {S} KMC sample{'s' if S > 1 else ''} per GPU "
                                f"(k=31, counter_size {COUNTER_SIZE}, {meta['db_kmers']} k-mers), {args.window // 1000} kb tiling windows "
                                f"({n_win} windows), -c {args.min_count}",
-                   "windows": n_win, "kmers_per_step_per_gpu": kmers_per_step, "db_kmers": meta["db_kmers"],
+                   "windows": n_win, "samples_per_gpu": S, "kmers_per_step_per_gpu": kmers_per_step, "db_kmers": meta["db_kmers"],
                    "parallelism": f"sample-sharded x{world}, RCCL gather of 40 B records" if world > 1 else "single GPU",
                    "table_bytes": int(db.info.table_bytes), "hit_rate": float(res["obs"].sum() / max(1, res["total_kmers"].sum()))},
-        "windows_per_s": n_win * world * args.steps / elapsed,
+        "windows_per_s": n_win * S * world * args.steps / elapsed,
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "screen_k31_kernel", "kernel_avg_ms": kern_avg_ms, "launches_timed": int(launches),
-                     "algorithmic_bytes_per_kmer": B_ALG},
+                     "kernel": "screen_k31_kernel" if S == 1 else "screen_k31_multi_kernel", "kernel_avg_ms": kern_avg_ms,
+                     "launches_timed": int(launches), "algorithmic_bytes_per_kmer": b_alg if S > 1 else B_ALG},
         "cpu_baseline": cpu,
         "parity": parity,
         "setup_seconds": {"generate": gen_s, "db_open": load_s, "db_open_inner": float(db.info.load_seconds)},

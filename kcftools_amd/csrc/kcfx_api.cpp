@@ -143,6 +143,12 @@ struct kcfx_ref {
     uint64_t* d_bits = nullptr;        // per tile: valid / hit ballots of every 64-position word
     int64_t* d_csum = nullptr;         // per tile: sum of counts over hits
     kcfx_result* d_res = nullptr;      // used by the synchronous entry point
+    // multi-sample pass (allocated on first use; scratch sized for SCREEN_MULTI_MAX samples)
+    TileSummary* d_msumm = nullptr;
+    uint64_t* d_mbits = nullptr;
+    int64_t* d_mcsum = nullptr;
+    kcfx_result* d_mres = nullptr;     // synchronous multi entry point: n_db * n_windows records
+    size_t mres_bytes = 0;
     hipStream_t stream = nullptr;
     // measurement
     bool prof = false;
@@ -274,6 +280,10 @@ void ref_free(kcfx_ref* r) {
     if (r->d_bits) (void)hipFree(r->d_bits);
     if (r->d_csum) (void)hipFree(r->d_csum);
     if (r->d_res) (void)hipFree(r->d_res);
+    if (r->d_msumm) (void)hipFree(r->d_msumm);
+    if (r->d_mbits) (void)hipFree(r->d_mbits);
+    if (r->d_mcsum) (void)hipFree(r->d_mcsum);
+    if (r->d_mres) (void)hipFree(r->d_mres);
     if (r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
 }
@@ -598,9 +608,102 @@ int32_t kcfx_screen_ref_async(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count
     KCFX_HIP(launch_screen_tiles(ref->d_text, ref->d_tiles, ref->n_tiles, db->view(), ref->k, db->info.both_strands,
                                  min_kmer_count, ref->d_bits, ref->d_csum, st));
     if (ev1) KCFX_HIP(hipEventRecord(ev1, st));
-    KCFX_HIP(launch_summarize_tiles(ref->d_tiles, ref->n_tiles, ref->d_bits, ref->d_csum, ref->k, ref->d_summ, st));
-    KCFX_HIP(launch_finalize_windows(ref->d_summ, ref->d_win_tile0, ref->n_windows, ref->k,
+    KCFX_HIP(launch_summarize_tiles(ref->d_tiles, ref->n_tiles, 1, ref->d_bits, ref->d_csum, ref->k, ref->d_summ, st));
+    KCFX_HIP(launch_finalize_windows(ref->d_summ, ref->n_tiles, 1, ref->d_win_tile0, ref->n_windows, ref->k,
                                      reinterpret_cast<kcfx_result*>(out_device), st));
+    return KCFX_OK;
+}
+
+// SURVEY f-4: S resident databases, one pass over the reference. Databases the multi-sample kernel cannot take
+// (k != 31, key-hash tables) go through the single-sample path into their slice of the output.
+int32_t kcfx_screen_ref_multi_async(kcfx_db* const* dbs, int32_t n_db, kcfx_ref* ref, int32_t min_kmer_count,
+                                    void* out_device, void* hip_stream) {
+    if (!ref || n_db < 0 || (n_db > 0 && (!dbs || !out_device))) return fail(KCFX_ERR_ARG, "null argument");
+    if (min_kmer_count < 1) return fail(KCFX_ERR_ARG, "Minimum kmer count should be at least 1");   // GetVariants.java:383-385
+    for (int32_t i = 0; i < n_db; ++i) {
+        if (!dbs[i]) return fail(KCFX_ERR_ARG, "null database handle");
+        if (dbs[i]->device != ref->device) return fail(KCFX_ERR_ARG, "database and reference live on different devices");
+        if (dbs[i]->info.kmer_length != ref->k) return fail(KCFX_ERR_ARG, "reference was planned for a different k-mer length");
+    }
+    if (n_db == 0 || ref->n_windows == 0) return KCFX_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    kcfx_result* out = reinterpret_cast<kcfx_result*>(out_device);
+    DeviceGuard g(ref->device);
+    if (!ref->d_mbits) {
+        const size_t nt = std::max<size_t>(ref->n_tiles, 1);
+        KCFX_HIP(hipMalloc(&ref->d_mbits, nt * SCREEN_MULTI_MAX * TILE_BITS_U64 * 8));
+        KCFX_HIP(hipMalloc(&ref->d_mcsum, nt * SCREEN_MULTI_MAX * sizeof(int64_t)));
+        KCFX_HIP(hipMalloc(&ref->d_msumm, nt * SCREEN_MULTI_MAX * sizeof(TileSummary)));
+    }
+    std::vector<char> done(n_db, 0);
+    for (int32_t first = 0; first < n_db; ++first) {
+        if (done[first]) continue;
+        kcfx_db* d0 = dbs[first];
+        if (!screen_multi_supported(d0->view(), ref->k)) {
+            if (int32_t rc = kcfx_screen_ref_async(d0, ref, min_kmer_count, out + (size_t)first * ref->n_windows, hip_stream))
+                return rc;
+            done[first] = 1;
+            continue;
+        }
+        // batch: the next databases of the same strandedness the kernel can take, in input order
+        int32_t idx[SCREEN_MULTI_MAX];
+        TableView tvs[SCREEN_MULTI_MAX];
+        int32_t nb = 0;
+        for (int32_t j = first; j < n_db && nb < SCREEN_MULTI_MAX; ++j) {
+            if (done[j] || !screen_multi_supported(dbs[j]->view(), ref->k)) continue;
+            if (dbs[j]->info.both_strands != d0->info.both_strands) continue;
+            idx[nb] = j;
+            tvs[nb++] = dbs[j]->view();
+            done[j] = 1;
+        }
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (ref->prof) {
+            if (ref->events_used == ref->events.size()) {
+                hipEvent_t a, b;
+                KCFX_HIP(hipEventCreate(&a));
+                KCFX_HIP(hipEventCreate(&b));
+                ref->events.emplace_back(a, b);
+            }
+            ev0 = ref->events[ref->events_used].first;
+            ev1 = ref->events[ref->events_used].second;
+            ref->events_used++;
+            KCFX_HIP(hipEventRecord(ev0, st));
+        }
+        KCFX_HIP(launch_screen_multi(ref->d_text, ref->d_tiles, ref->n_tiles, tvs, nb, d0->info.both_strands, min_kmer_count,
+                                     ref->d_mbits, ref->d_mcsum, st));
+        if (ev1) KCFX_HIP(hipEventRecord(ev1, st));
+        KCFX_HIP(launch_summarize_tiles(ref->d_tiles, ref->n_tiles, nb, ref->d_mbits, ref->d_mcsum, ref->k, ref->d_msumm, st));
+        // consecutive output slices take one launch; scattered ones (mixed batches) one each
+        for (int32_t b = 0; b < nb;) {
+            int32_t e = b + 1;
+            while (e < nb && idx[e] == idx[e - 1] + 1) ++e;
+            KCFX_HIP(launch_finalize_windows(ref->d_msumm + (size_t)b * ref->n_tiles, ref->n_tiles, e - b, ref->d_win_tile0,
+                                             ref->n_windows, ref->k, out + (size_t)idx[b] * ref->n_windows, st));
+            b = e;
+        }
+    }
+    return KCFX_OK;
+}
+
+int32_t kcfx_screen_ref_multi(kcfx_db* const* dbs, int32_t n_db, kcfx_ref* ref, int32_t min_kmer_count, kcfx_result* out) {
+    if (!ref || n_db < 0 || (n_db > 0 && !dbs)) return fail(KCFX_ERR_ARG, "null argument");
+    if (n_db == 0 || ref->n_windows == 0) {
+        if (min_kmer_count < 1) return fail(KCFX_ERR_ARG, "Minimum kmer count should be at least 1");
+        return KCFX_OK;
+    }
+    if (!out) return fail(KCFX_ERR_ARG, "null argument");
+    DeviceGuard g(ref->device);
+    const size_t bytes = (size_t)n_db * ref->n_windows * sizeof(kcfx_result);
+    if (ref->mres_bytes < bytes) {          // sized for the largest n_db seen so far
+        if (ref->d_mres) (void)hipFree(ref->d_mres);
+        ref->d_mres = nullptr;
+        ref->mres_bytes = 0;
+        KCFX_HIP(hipMalloc(&ref->d_mres, bytes));
+        ref->mres_bytes = bytes;
+    }
+    if (int32_t rc = kcfx_screen_ref_multi_async(dbs, n_db, ref, min_kmer_count, ref->d_mres, ref->stream)) return rc;
+    KCFX_HIP(hipMemcpyAsync(out, ref->d_mres, bytes, hipMemcpyDeviceToHost, ref->stream));
+    KCFX_HIP(hipStreamSynchronize(ref->stream));
     return KCFX_OK;
 }
 

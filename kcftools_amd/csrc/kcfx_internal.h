@@ -180,9 +180,16 @@ hipError_t launch_lookup(TableView tv, int32_t k, const uint64_t* keys, int64_t 
 hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32_t n_tiles, TableView tv, int32_t k,
                                int32_t both_strands, int32_t min_count, uint64_t* bits, int64_t* count_sums,
                                hipStream_t st);
-hipError_t launch_summarize_tiles(const TileDesc* tiles, int32_t n_tiles, const uint64_t* bits, const int64_t* count_sums,
-                                  int32_t k, TileSummary* out, hipStream_t st);
-hipError_t launch_finalize_windows(const TileSummary* tiles, const int32_t* win_tile0, int32_t n_windows, int32_t k,
-                                   kcfx_result* out, hipStream_t st);
+hipError_t launch_summarize_tiles(const TileDesc* tiles, int32_t n_tiles, int32_t n_samples, const uint64_t* bits,
+                                  const int64_t* count_sums, int32_t k, TileSummary* out, hipStream_t st);
+// S <= SCREEN_MULTI_MAX tables in one pass over the reference (k = 31, M = 16 minimizer tables with one strandedness);
+// sample s writes bits + s * n_tiles * TILE_BITS_U64 and count_sums + s * n_tiles
+constexpr int SCREEN_MULTI_MAX = 8;
+bool screen_multi_supported(const TableView& tv, int32_t k);
+hipError_t launch_screen_multi(const uint8_t* text, const TileDesc* tiles, int32_t n_tiles, const TableView* tvs,
+                               int32_t n_tables, int32_t both_strands, int32_t min_count, uint64_t* bits, int64_t* count_sums,
+                               hipStream_t st);
+hipError_t launch_finalize_windows(const TileSummary* tiles, int32_t n_tiles, int32_t n_samples, const int32_t* win_tile0,
+                                   int32_t n_windows, int32_t k, kcfx_result* out, hipStream_t st);
 
 }  // namespace kcfx

@@ -450,35 +450,107 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t x) {     // lane l gets l
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, true);
 }
 
-template <bool WIDE, bool BOTH>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void screen_k31_kernel(
-    const uint8_t* __restrict__ text, const TileDesc* __restrict__ tiles, TableView tv, int32_t min_count,
-    uint64_t* __restrict__ bits, int64_t* __restrict__ count_sums) {
-    constexpr int k = 31;
+// Per-lane constants of the cooperative line fetch
+struct K31Fetch {
+    int fetch_run;        // lane / 9: the run (0..6, 7 = idle) this lane fetches for
+    int piece;            // its 16-byte piece of the line (8 = idle)
+    bool fetcher;
+    uint4* lines;         // this wave's line buffers (2 x 63 uint4)
+    uint32_t* runline;    // this wave's run -> line index list (65 entries)
+};
+
+// KMC.getCount for the 64 k-mers of one word against one table: `key` (canonical word), `mn` (minimizer), `V` (ballot of
+// valid k-mers). Returns the stored counter, 0 when absent / invalid.
+// Cooperative probe rounds: each round fetches, for every run of adjacent pending lanes with the same target line, that
+// line ONCE (8 lanes x 16 B = one 128-byte request, LDS-DMA) into wave-private LDS, then every lane compares its key
+// against its run's line. Probe state lives in VGPR integers and is updated with selects (see screen_tiles_kernel).
+template <bool WIDE>
+__device__ __forceinline__ uint32_t k31_probe_word(const TableView& tv, const K31Fetch& f, int lane, uint64_t key,
+                                                   uint32_t mn, uint64_t V) {
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
+    uint32_t tgt = line_of_minimizer(mn, tv.n_lines);       // home line, shared by the whole minimizer run
+    uint32_t st = (uint32_t)((V >> lane) & 1);              // 1 = pending, 2 = found, 0 = absent / invalid
+    uint32_t cnt = 0;
+    uint32_t hm = 0;                                        // meta dword of the line matched last
+    for (int round = 0;; ++round) {
+        const uint64_t PM = wave_ballot(st == 1u);
+        if (!PM) break;
+        if (round == 1) {
+            // HEAVY minimizer home (table_finalize also sets its overflow bit, so such lanes are still pending):
+            // every k-mer homed there by minimizer lives at its key-hash line instead -- jump, do not walk
+            const uint64_t RM = PM & wave_ballot((hm & META_HEAVY) != 0u);
+            if (RM) {
+                // rare: keep the key hash (three multiplies) from being hoisted into every word
+                uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+                asm volatile("" : "+v"(klo), "+v"(khi));
+                if ((RM >> lane) & 1) tgt = keyhash_line(tv, u64_of(klo, khi));
+            }
+        }
+        // heads of runs: pending lanes whose predecessor is not pending or aims at another line
+        const uint64_t HM = PM & (wave_ballot(wave_shr1(st) != 1u) | wave_ballot(wave_shr1(tgt) != tgt));
+        const int nruns = __popcll(HM);
+        // index of this lane's run = heads at or below it, minus one
+        const uint64_t H1 = HM >> 1;
+        const int my_run = (int)__builtin_amdgcn_mbcnt_hi(
+            (uint32_t)(H1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)H1, (uint32_t)((int)(HM & 1) - 1)));
+        // every pending lane stores its run's line index (same value within a run); the others hit a dummy slot
+        f.runline[(st == 1u) ? my_run : 64] = tgt;
+        wave_lds_fence();
+        for (int c0 = 0; c0 < nruns; c0 += K31_RUNS) {
+            const int r0 = c0 + f.fetch_run, r1 = r0 + 7;
+            // 8 lanes x 16 B = one 128-byte request per run
+            if (f.fetcher && r0 < nruns)
+                __builtin_amdgcn_global_load_lds((gptr_t)(tv.lines + (size_t)f.runline[r0] * LINE_BYTES + 16 * f.piece),
+                                                 (lptr_t)f.lines, 16, 0, 0);
+            if (f.fetcher && r1 < nruns)
+                __builtin_amdgcn_global_load_lds((gptr_t)(tv.lines + (size_t)f.runline[r1] * LINE_BYTES + 16 * f.piece),
+                                                 (lptr_t)(f.lines + 7 * K31_PITCH), 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_lds_fence();
+            // every lane matches (idle lanes against buffer 0); the outcome is merged with selects
+            const uint32_t rel = (uint32_t)(my_run - c0);
+            const bool mine = (st == 1u) && (rel < (uint32_t)K31_RUNS);
+            const uint4* src = f.lines + (mine ? rel : 0u) * K31_PITCH;
+            uint32_t c, meta;
+            const bool any = match_line_lds<WIDE, false>(src, key, c, meta);
+            const uint32_t ov = (meta >> 8) & 1u;                       // overflowed line: look at the next one
+            const uint32_t nst = any ? 2u : ov;
+            const uint32_t ntgt = (tgt + 1 == tv.n_lines) ? 0u : tgt + 1;
+            cnt = (mine && any) ? c : cnt;                              // Java int (KMC.java:395-401)
+            tgt = (mine && nst == 1u) ? ntgt : tgt;
+            hm = mine ? meta : hm;
+            st = mine ? nst : st;
+            wave_lds_fence();
+        }
+    }
+    return cnt;
+}
+
+// LDS of the k31 kernels: packed code / validity bits of the tile + per-wave line buffers
+struct K31Shared {
     // The word loop reads code bits up to 64 positions past the tile's last k-mer without clamping (what it reads there
     // only reaches lanes that are invalid anyway): MAX_CHUNKS + 2 chunks cover every such read of a full tile.
     static_assert(2 * (MAX_CHUNKS + 2) > ((2 * (31 + TILE_K - 1) + 31) >> 5) + 4, "code arrays too short for unclamped reads");
-    __shared__ uint32_t s_fwx[2 * (MAX_CHUNKS + 2) + 1];   // [0] is the lead word bits_at may touch
-    __shared__ uint32_t s_cwx[2 * (MAX_CHUNKS + 2) + 1];
-    __shared__ uint32_t s_vbx[MAX_CHUNKS + 2 + 1];
-    uint32_t* const s_fw = s_fwx + 1;
-    uint32_t* const s_cw = s_cwx + 1;
-    uint32_t* const s_vb = s_vbx + 1;
-    __shared__ __attribute__((aligned(16))) uint4 s_lines[WAVES][2 * 64];          // DMA layout: line r at 144 r (7 per 1 KiB)
-    __shared__ uint32_t s_runline[WAVES][65];              // line index of each run (+1 dummy slot)
-    __shared__ int64_t s_sum[WAVES];
+    uint32_t fwx[2 * (MAX_CHUNKS + 2) + 1];                 // [0] is the lead word bits_at may touch
+    uint32_t cwx[2 * (MAX_CHUNKS + 2) + 1];
+    uint32_t vbx[MAX_CHUNKS + 2 + 1];
+    __attribute__((aligned(16))) uint4 lines[WAVES][2 * 64]; // DMA layout: line r at 144 r (7 per instruction)
+    uint32_t runline[WAVES][65];                            // line index of each run (+1 dummy slot)
+    int64_t sum[WAVES];
+};
 
-    const TileDesc td = tiles[blockIdx.x];
-    const int tid = threadIdx.x;
-
-    // ---- phase 1: ASCII -> 2-bit codes + validity bits in LDS (as screen_tiles_kernel) ----------------
+// phase 1: ASCII -> 2-bit codes + validity bits in LDS (as screen_tiles_kernel); returns the tile's bit offset `off`
+__device__ __forceinline__ int k31_pack_tile(K31Shared& sh, const uint8_t* __restrict__ text, const TileDesc& td, int tid) {
+    constexpr int k = 31;
     const int64_t a0 = td.text_off & ~(int64_t)31;
     const int off = (int)(td.text_off - a0);
     const int nbases = off + td.n_kmers + k - 1;
     const int nchunks = (nbases + 31) >> 5;
-    if (tid == 0) s_fwx[0] = s_cwx[0] = s_vbx[0] = 0;
+    uint32_t* const s_fw = sh.fwx + 1;
+    uint32_t* const s_cw = sh.cwx + 1;
+    uint32_t* const s_vb = sh.vbx + 1;
+    if (tid == 0) sh.fwx[0] = sh.cwx[0] = sh.vbx[0] = 0;
     for (int c = tid; c < nchunks + 2; c += BLOCK) {
         uint32_t f0 = 0, f1 = 0, v0 = 0, v1 = 0;
         if (c < nchunks) {
@@ -494,38 +566,38 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         s_vb[c] = (v0 << 16) | v1;
     }
     __syncthreads();
+    return off;
+}
 
-    // ---- phase 2: each wave walks a contiguous range of 64-position words ----------------------------------
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_words = (td.n_kmers + 63) >> 6;
-    const int wpw = (n_words + WAVES - 1) / WAVES;
-    const int w_begin = min(wave * wpw, n_words);
-    const int w_end = min(w_begin + wpw, n_words);
-    const int fetch_run = (lane * 57) >> 9;                // lane / 9: the run (0..6, 7 = idle) this lane fetches for
-    const int piece = lane - 9 * fetch_run;                // its 16-byte piece of the line (8 = idle)
-    const bool fetcher = piece < 8 && fetch_run < 7;
-    const int next15 = ((lane + 15) & 63) << 2;            // ds_bpermute address of lane + 15 (mod 64)
-    uint4* const my_lines = s_lines[wave];
-    uint32_t* const my_runline = s_runline[wave];
+// The words of a tile as one wave sees them: canonical key, minimizer and validity ballot of 64 consecutive positions per
+// step, everything in registers. Carried from one word to the next: the leading code words of both strands at this lane's
+// position and the row scans of the M-mer hashes they give.
+template <bool BOTH>
+struct K31Words {
+    const uint32_t *s_fw, *s_cw, *s_vb;
+    int off, n_kmers, lane, next15;
+    uint32_t Fc, Cc, Pc, Sc;
 
     // canonical 16-mer hash from the leading 32 code bits of both strands
-    auto mmer_of = [](uint32_t f0, uint32_t c0) { return mhash32(((uint64_t)min(f0, brev32(c0))) << 32); };
-
-    // u16 counters: a wave's total over its <= TILE_WORDS words fits 32 bits; 4-byte counters are Java ints (may be < 0)
-    static_assert((uint64_t)TILE_WORDS * 64 * 65535 < (1ull << 32), "32-bit count sums");
-    typename std::conditional<WIDE, int64_t, uint32_t>::type sum_acc = 0;   // per lane
-    uint64_t* my_bits = bits + (size_t)blockIdx.x * TILE_BITS_U64;
-    // carried from one word to the next: leading code words of both strands at this lane's position, and the row scans
-    // of the M-mer hashes they give
-    uint32_t Fc = 0, Cc = 0, Pc = 0, Sc = 0;
-    if (w_begin < w_end) {
+    static __device__ __forceinline__ uint32_t mmer_of(uint32_t f0, uint32_t c0) {
+        return mhash32(((uint64_t)min(f0, brev32(c0))) << 32);
+    }
+    __device__ __forceinline__ void start(const K31Shared& sh, int off_, int n_kmers_, int lane_, int w_begin) {
+        s_fw = sh.fwx + 1;
+        s_cw = sh.cwx + 1;
+        s_vb = sh.vbx + 1;
+        off = off_;
+        n_kmers = n_kmers_;
+        lane = lane_;
+        next15 = ((lane + 15) & 63) << 2;                   // ds_bpermute address of lane + 15 (mod 64)
         const int q = off + w_begin * 64 + lane;
         Fc = bits_at(s_fw, 2 * q);
         Cc = bits_at(s_cw, 2 * q);
         row_scan_min(mmer_of(Fc, Cc), Pc, Sc);
     }
-
-    for (int w = w_begin; w < w_end; ++w) {
+    // word w (call with consecutive w): key, minimizer, validity
+    __device__ __forceinline__ void next(int w, uint64_t& key, uint32_t& mn, uint64_t& V) {
+        constexpr int k = 31;
         const int j = w * 64 + lane;
         const int q = off + j;
         // bits [2q+32, 2q+64) of this word and bits [2(q+64), 2(q+64)+32) of the next share one word index and shift
@@ -539,83 +611,63 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         const uint32_t Cn = alignbit32(s_cw[wi + 3], s_cw[wi + 4], sh);
         uint32_t Pn, Sn;
         row_scan_min(mmer_of(Fn, Cn), Pn, Sn);
-
         // extract_kmer (kcfx_device.h) from the four halves
         const uint64_t fwd = u64_of(f1, Fc);
         const uint64_t rc = u64_of(brev32(Cc), brev32(c1)) << (64 - 2 * k);
         // Kmer(Kmer, bothStrands): canonical = min(fwd, revcomp) unsigned (Kmer.java:72-79,406-414)
-        const uint64_t key = (BOTH && rc < fwd) ? rc : fwd;
+        key = (BOTH && rc < fwd) ? rc : fwd;
         // all k bases are A/C/G/T, and the position is a k-mer of this tile
-        const uint64_t V = wave_ballot((bits_at(s_vb, q) >> (32 - k)) == (uint32_t)((1ull << k) - 1)) &
-                           wave_ballot(j < td.n_kmers);
-
+        V = wave_ballot((bits_at(s_vb, q) >> (32 - k)) == (uint32_t)((1ull << k) - 1)) & wave_ballot(j < n_kmers);
         // minimizer of the k-mer = min over its 16 M-mers = min(S[lane], P[lane + 15])
         const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(next15, (int)Pc);
         const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute(next15, (int)Pn);
-        const uint32_t mn = min(Sc, lane < 49 ? pa : pb);
-        uint32_t tgt = line_of_minimizer(mn, tv.n_lines);   // home line, shared by the whole minimizer run
+        mn = min(Sc, lane < 49 ? pa : pb);
         Fc = Fn;
         Cc = Cn;
         Pc = Pn;
         Sc = Sn;
+    }
+};
 
-        // Probe state lives in VGPR integers and is updated with selects (see screen_tiles_kernel)
-        uint32_t st = (uint32_t)((V >> lane) & 1);          // 1 = pending, 2 = found, 0 = absent / invalid
-        uint32_t cnt = 0;
-        uint32_t hm = 0;                                    // meta dword of the line matched last
-        // ---- cooperative probe rounds: each round fetches, for every run of adjacent pending lanes with the same
-        //      target line, that line ONCE (8 lanes x 16 B = one 128-byte request) into wave-private LDS -------------
-        for (int round = 0;; ++round) {
-            const uint64_t PM = wave_ballot(st == 1u);
-            if (!PM) break;
-            if (round == 1) {
-                // HEAVY minimizer home (table_finalize also sets its overflow bit, so such lanes are still pending):
-                // every k-mer homed there by minimizer lives at its key-hash line instead -- jump, do not walk
-                const uint64_t RM = PM & wave_ballot((hm & META_HEAVY) != 0u);
-                if (RM) {
-                    // rare: keep the key hash (3 quarter-rate multiplies) from being hoisted into every word
-                    uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
-                    asm volatile("" : "+v"(klo), "+v"(khi));
-                    if ((RM >> lane) & 1) tgt = keyhash_line(tv, u64_of(klo, khi));
-                }
-            }
-            // heads of runs: pending lanes whose predecessor is not pending or aims at another line
-            const uint64_t HM = PM & (wave_ballot(wave_shr1(st) != 1u) | wave_ballot(wave_shr1(tgt) != tgt));
-            const int nruns = __popcll(HM);
-            // index of this lane's run = heads at or below it, minus one
-            const uint64_t H1 = HM >> 1;
-            const int my_run = (int)__builtin_amdgcn_mbcnt_hi(
-                (uint32_t)(H1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)H1, (uint32_t)((int)(HM & 1) - 1)));
-            // every pending lane stores its run's line index (same value within a run); the others hit a dummy slot
-            my_runline[(st == 1u) ? my_run : 64] = tgt;
-            wave_lds_fence();
-            for (int c0 = 0; c0 < nruns; c0 += K31_RUNS) {
-                const int r0 = c0 + fetch_run, r1 = r0 + 7;
-                // 8 lanes x 16 B = one 128-byte request per run
-                if (fetcher && r0 < nruns)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(tv.lines + (size_t)my_runline[r0] * LINE_BYTES + 16 * piece),
-                                                     (lptr_t)my_lines, 16, 0, 0);
-                if (fetcher && r1 < nruns)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(tv.lines + (size_t)my_runline[r1] * LINE_BYTES + 16 * piece),
-                                                     (lptr_t)(my_lines + 7 * K31_PITCH), 16, 0, 0);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                wave_lds_fence();
-                // every lane matches (idle lanes against buffer 0); the outcome is merged with selects
-                const uint32_t rel = (uint32_t)(my_run - c0);
-                const bool mine = (st == 1u) && (rel < (uint32_t)K31_RUNS);
-                const uint4* src = my_lines + (mine ? rel : 0u) * K31_PITCH;
-                uint32_t c, meta;
-                const bool any = match_line_lds<WIDE, false>(src, key, c, meta);
-                const uint32_t ov = (meta >> 8) & 1u;                       // overflowed line: look at the next one
-                const uint32_t nst = any ? 2u : ov;
-                const uint32_t ntgt = (tgt + 1 == tv.n_lines) ? 0u : tgt + 1;
-                cnt = (mine && any) ? c : cnt;                              // Java int (KMC.java:395-401)
-                tgt = (mine && nst == 1u) ? ntgt : tgt;
-                hm = mine ? meta : hm;
-                st = mine ? nst : st;
-                wave_lds_fence();
-            }
-        }
+__device__ __forceinline__ K31Fetch k31_fetch_setup(K31Shared& sh, int lane, int wave) {
+    K31Fetch f;
+    f.fetch_run = (lane * 57) >> 9;
+    f.piece = lane - 9 * f.fetch_run;
+    f.fetcher = f.piece < 8 && f.fetch_run < 7;
+    f.lines = sh.lines[wave];
+    f.runline = sh.runline[wave];
+    return f;
+}
+
+template <bool WIDE, bool BOTH>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void screen_k31_kernel(
+    const uint8_t* __restrict__ text, const TileDesc* __restrict__ tiles, TableView tv, int32_t min_count,
+    uint64_t* __restrict__ bits, int64_t* __restrict__ count_sums) {
+    __shared__ K31Shared sh;
+    const TileDesc td = tiles[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int off = k31_pack_tile(sh, text, td, tid);
+
+    // ---- phase 2: each wave walks a contiguous range of 64-position words ----------------------------------
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_words = (td.n_kmers + 63) >> 6;
+    const int wpw = (n_words + WAVES - 1) / WAVES;
+    const int w_begin = min(wave * wpw, n_words);
+    const int w_end = min(w_begin + wpw, n_words);
+    const K31Fetch fetch = k31_fetch_setup(sh, lane, wave);
+
+    // u16 counters: a wave's total over its <= TILE_WORDS words fits 32 bits; 4-byte counters are Java ints (may be < 0)
+    static_assert((uint64_t)TILE_WORDS * 64 * 65535 < (1ull << 32), "32-bit count sums");
+    typename std::conditional<WIDE, int64_t, uint32_t>::type sum_acc = 0;   // per lane
+    uint64_t* my_bits = bits + (size_t)blockIdx.x * TILE_BITS_U64;
+    K31Words<BOTH> words;
+    if (w_begin < w_end) words.start(sh, off, td.n_kmers, lane, w_begin);
+
+    for (int w = w_begin; w < w_end; ++w) {
+        uint64_t key, V;
+        uint32_t mn;
+        words.next(w, key, mn, V);
+        const uint32_t cnt = k31_probe_word<WIDE>(tv, fetch, lane, key, mn, V);
         // cnt is 0 unless the k-mer was found and min_count >= 1 (checked by the API), so this is "found && count >= -c"
         const bool hit = (int32_t)cnt >= min_count;                         // GetVariants.java:224
         const uint64_t H = wave_ballot(hit);
@@ -630,13 +682,77 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     int64_t count_sum;
     if constexpr (WIDE) count_sum = wave_sum_i64(sum_acc);
     else count_sum = (int64_t)wave_sum_u32_dpp(sum_acc);
-    if (lane == 0) s_sum[wave] = count_sum;
+    if (lane == 0) sh.sum[wave] = count_sum;
     __syncthreads();
     if (tid == 0) {
         int64_t t = 0;
 #pragma unroll
-        for (int i = 0; i < WAVES; ++i) t += s_sum[i];
+        for (int i = 0; i < WAVES; ++i) t += sh.sum[i];
         count_sums[blockIdx.x] = t;
+    }
+}
+
+// ---- S samples in one pass over the reference (SURVEY f-4) ------------------------------------------------------
+// The same tile walk, but every word's keys / minimizers / validity are derived once and probed against S resident
+// tables: pack, strands, hashing and the sliding minimum are amortised over the samples. Sample s writes its own hit
+// bitmap (bits + s * bits_stride, the validity words replicated) and count sums (count_sums + s * n_tiles), so
+// summarize_tiles / finalize_windows run unchanged per sample.
+constexpr int MULTI_MAX = SCREEN_MULTI_MAX;
+struct MultiTables {
+    TableView tv[MULTI_MAX];
+    int32_t n;
+};
+
+template <bool BOTH>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void screen_k31_multi_kernel(
+    const uint8_t* __restrict__ text, const TileDesc* __restrict__ tiles, int32_t n_tiles, MultiTables mt, int32_t min_count,
+    uint64_t* __restrict__ bits, int64_t bits_stride, int64_t* __restrict__ count_sums) {
+    __shared__ K31Shared sh;
+    __shared__ int64_t s_msum[WAVES][MULTI_MAX];
+    const TileDesc td = tiles[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int off = k31_pack_tile(sh, text, td, tid);
+
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_words = (td.n_kmers + 63) >> 6;
+    const int wpw = (n_words + WAVES - 1) / WAVES;
+    const int w_begin = min(wave * wpw, n_words);
+    const int w_end = min(w_begin + wpw, n_words);
+    const K31Fetch fetch = k31_fetch_setup(sh, lane, wave);
+    if (lane < MULTI_MAX) s_msum[wave][lane] = 0;
+    wave_lds_fence();
+    K31Words<BOTH> words;
+    if (w_begin < w_end) words.start(sh, off, td.n_kmers, lane, w_begin);
+
+    for (int w = w_begin; w < w_end; ++w) {
+        uint64_t key, V;
+        uint32_t mn;
+        words.next(w, key, mn, V);
+        for (int s = 0; s < mt.n; ++s) {
+            const TableView tv = mt.tv[s];
+            uint32_t cnt;
+            if (tv.wide) cnt = k31_probe_word<true>(tv, fetch, lane, key, mn, V);
+            else cnt = k31_probe_word<false>(tv, fetch, lane, key, mn, V);
+            const bool hit = (int32_t)cnt >= min_count;                     // GetVariants.java:224
+            const uint64_t H = wave_ballot(hit);
+            // the word's count sum goes straight to the wave's per-sample total (no per-lane accumulator per sample)
+            int64_t wsum;
+            if (tv.wide) wsum = wave_sum_i64(hit ? (int64_t)(int32_t)cnt : 0);       // Java ints (KMC.java:395-401)
+            else wsum = (int64_t)wave_sum_u32_dpp(hit ? cnt : 0u);
+            if (lane == 0) {
+                uint64_t* my_bits = bits + (size_t)s * bits_stride + (size_t)blockIdx.x * TILE_BITS_U64;
+                my_bits[w] = V;
+                my_bits[TILE_WORDS + w] = H;
+                s_msum[wave][s] += wsum;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < mt.n) {
+        int64_t t = 0;
+#pragma unroll
+        for (int i = 0; i < WAVES; ++i) t += s_msum[i][tid];
+        count_sums[(size_t)tid * n_tiles + blockIdx.x] = t;
     }
 }
 
@@ -666,6 +782,10 @@ __global__ void summarize_tiles_kernel(const TileDesc* __restrict__ tiles, int32
                                        const uint64_t* __restrict__ bits, const int64_t* __restrict__ count_sums,
                                        int32_t k, TileSummary* __restrict__ out) {
     constexpr int PW = TILE_WORDS / SUM_LANES;             // words per piece
+    // blockIdx.y = sample of a multi-sample pass: its bitmaps, count sums and summaries follow the previous sample's
+    bits += (size_t)blockIdx.y * n_tiles * TILE_BITS_U64;
+    count_sums += (size_t)blockIdx.y * n_tiles;
+    out += (size_t)blockIdx.y * n_tiles;
     const int32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     const int32_t t = g / SUM_LANES, sub = g % SUM_LANES;
     TileSummary acc = summary_identity();
@@ -688,10 +808,13 @@ __global__ void summarize_tiles_kernel(const TileDesc* __restrict__ tiles, int32
 }
 
 // one thread per window: fold its tiles in order (GetVariants.java:248-258)
-__global__ void finalize_windows_kernel(const TileSummary* __restrict__ tiles, const int32_t* __restrict__ win_tile0,
-                                        int32_t n_windows, int32_t k, kcfx_result* __restrict__ out) {
+__global__ void finalize_windows_kernel(const TileSummary* __restrict__ tiles, int32_t n_tiles,
+                                        const int32_t* __restrict__ win_tile0, int32_t n_windows, int32_t k,
+                                        kcfx_result* __restrict__ out) {
     const int32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_windows) return;
+    tiles += (size_t)blockIdx.y * n_tiles;                 // sample of a multi-sample pass
+    out += (size_t)blockIdx.y * n_windows;
     TileSummary acc = summary_identity();
     for (int32_t t = win_tile0[w]; t < win_tile0[w + 1]; ++t) acc = summary_combine(acc, tiles[t], k);
     if (acc.flags & F_EMPTY) {
@@ -769,12 +892,12 @@ hipError_t launch_lookup(TableView tv, int32_t k, const uint64_t* keys, int64_t 
     return hipGetLastError();
 }
 
-hipError_t launch_summarize_tiles(const TileDesc* tiles, int32_t n_tiles, const uint64_t* bits, const int64_t* count_sums,
-                                  int32_t k, TileSummary* out, hipStream_t st) {
-    if (n_tiles <= 0) return hipSuccess;
+hipError_t launch_summarize_tiles(const TileDesc* tiles, int32_t n_tiles, int32_t n_samples, const uint64_t* bits,
+                                  const int64_t* count_sums, int32_t k, TileSummary* out, hipStream_t st) {
+    if (n_tiles <= 0 || n_samples <= 0) return hipSuccess;
     const int64_t lanes = (int64_t)n_tiles * SUM_LANES;
-    hipLaunchKernelGGL(summarize_tiles_kernel, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, st, tiles, n_tiles, bits,
-                       count_sums, k, out);
+    hipLaunchKernelGGL(summarize_tiles_kernel, dim3((uint32_t)((lanes + 255) / 256), n_samples), dim3(256), 0, st, tiles,
+                       n_tiles, bits, count_sums, k, out);
     return hipGetLastError();
 }
 
@@ -801,11 +924,33 @@ hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32
     return hipGetLastError();
 }
 
-hipError_t launch_finalize_windows(const TileSummary* tiles, const int32_t* win_tile0, int32_t n_windows, int32_t k,
-                                   kcfx_result* out, hipStream_t st) {
-    if (n_windows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(finalize_windows_kernel, dim3((n_windows + 127) / 128), dim3(128), 0, st, tiles, win_tile0,
-                       n_windows, k, out);
+bool screen_multi_supported(const TableView& tv, int32_t k) {
+    return tv.mode == MODE_MINIMIZER && k == 31 && tv.mm_len == 16;
+}
+
+hipError_t launch_screen_multi(const uint8_t* text, const TileDesc* tiles, int32_t n_tiles, const TableView* tvs,
+                               int32_t n_tables, int32_t both_strands, int32_t min_count, uint64_t* bits, int64_t* count_sums,
+                               hipStream_t st) {
+    if (n_tiles <= 0 || n_tables <= 0) return hipSuccess;
+    if (n_tables > MULTI_MAX) return hipErrorInvalidValue;
+    MultiTables mt;
+    for (int i = 0; i < MULTI_MAX; ++i) mt.tv[i] = tvs[i < n_tables ? i : 0];
+    mt.n = n_tables;
+    const int64_t stride = (int64_t)n_tiles * TILE_BITS_U64;
+    if (both_strands)
+        hipLaunchKernelGGL((screen_k31_multi_kernel<true>), dim3(n_tiles), dim3(BLOCK), 0, st, text, tiles, n_tiles, mt,
+                           min_count, bits, stride, count_sums);
+    else
+        hipLaunchKernelGGL((screen_k31_multi_kernel<false>), dim3(n_tiles), dim3(BLOCK), 0, st, text, tiles, n_tiles, mt,
+                           min_count, bits, stride, count_sums);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize_windows(const TileSummary* tiles, int32_t n_tiles, int32_t n_samples, const int32_t* win_tile0,
+                                   int32_t n_windows, int32_t k, kcfx_result* out, hipStream_t st) {
+    if (n_windows <= 0 || n_samples <= 0) return hipSuccess;
+    hipLaunchKernelGGL(finalize_windows_kernel, dim3((n_windows + 127) / 128, n_samples), dim3(128), 0, st, tiles, n_tiles,
+                       win_tile0, n_windows, k, out);
     return hipGetLastError();
 }
 

@@ -25,7 +25,8 @@ assert RESULT_DTYPE.itemsize == 40
 ABI_SYMBOLS = (
     "kcfx_db_open", "kcfx_db_build", "kcfx_db_info", "kcfx_db_lookup", "kcfx_db_close",
     "kcfx_ref_create", "kcfx_ref_n_windows", "kcfx_ref_n_kmer_slots", "kcfx_ref_destroy",
-    "kcfx_screen_ref", "kcfx_screen_ref_async", "kcfx_screen", "kcfx_score", "kcfx_windows",
+    "kcfx_screen_ref", "kcfx_screen_ref_async", "kcfx_screen_ref_multi", "kcfx_screen_ref_multi_async", "kcfx_screen",
+    "kcfx_score", "kcfx_windows",
     "kcfx_prof_enable", "kcfx_prof_read", "kcfx_last_error", "kcfx_device_count", "kcfx_version",
 )
 
@@ -96,6 +97,8 @@ def lib() -> C.CDLL:
         L.kcfx_ref_destroy.restype = None
         L.kcfx_screen_ref.argtypes = [vp, vp, i32, vp]
         L.kcfx_screen_ref_async.argtypes = [vp, vp, i32, vp, vp]
+        L.kcfx_screen_ref_multi.argtypes = [vp, i32, vp, i32, vp]
+        L.kcfx_screen_ref_multi_async.argtypes = [vp, i32, vp, i32, vp, vp]
         L.kcfx_screen.argtypes = [vp, vp, i64, vp, vp, i32, i32, vp]
         L.kcfx_score.argtypes = [vp, i64, dbl, dbl, dbl, vp, vp]
         L.kcfx_windows.argtypes = [i32, i32, i32, i32, vp, vp, i64, C.POINTER(i64)]
@@ -196,6 +199,18 @@ class Reference:
     def screen_async(self, db: KmcDb, out_device_ptr: int, stream: int = 0, min_count: int = 1) -> None:
         """Asynchronous launch on `stream` (a hipStream_t as int); results stay in device memory."""
         _check(lib().kcfx_screen_ref_async(db._h, self._h, min_count, C.c_void_p(out_device_ptr), C.c_void_p(stream)))
+
+    def screen_multi(self, dbs, min_count: int = 1) -> np.ndarray:
+        """One pass over the reference for several resident databases: array [len(dbs), n_windows]."""
+        handles = (C.c_void_p * max(len(dbs), 1))(*[C.cast(d._h, C.c_void_p).value for d in dbs])
+        out = np.zeros((len(dbs), self.n_windows), dtype=RESULT_DTYPE)
+        _check(lib().kcfx_screen_ref_multi(handles, len(dbs), self._h, min_count, out.ctypes.data))
+        return out
+
+    def screen_multi_async(self, dbs, out_device_ptr: int, stream: int = 0, min_count: int = 1) -> None:
+        handles = (C.c_void_p * max(len(dbs), 1))(*[C.cast(d._h, C.c_void_p).value for d in dbs])
+        _check(lib().kcfx_screen_ref_multi_async(handles, len(dbs), self._h, min_count, C.c_void_p(out_device_ptr),
+                                                 C.c_void_p(stream)))
 
     def prof_enable(self, on: bool = True) -> None:
         _check(lib().kcfx_prof_enable(self._h, int(on)))

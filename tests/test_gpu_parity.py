@@ -303,3 +303,41 @@ def test_k31_specialised_and_generic_kernels_agree(oracle, tmp_path, cs, both, m
     assert_same(slow, want, "screen_tiles_kernel vs oracle")
     for c in (2, 3):
         assert_same(db.screen(ref, begins, lens, c), odb.screen(ref, begins, lens, c, threads=4), f"-c {c}")
+
+
+def test_multi_sample_pass_equals_single_sample_passes(oracle, tmp_path):
+    """SURVEY f-4: kcfx_screen_ref_multi screens S resident databases in one pass over the reference. Every slice must
+    equal kcfx_screen_ref on that database (and the oracle). The mix forces every route: 10 narrow canonical tables (a full
+    batch of 8 + 2), a 4-byte-counter table in the same batch, a non-canonical table (its own batch), a k-mer-hash table
+    (`KCFX_TABLE_MODE=keyhash`, single-sample path) -- interleaved, so output slices are not contiguous per batch."""
+    import os
+    k = 31
+    ref = synth.random_reference(250_000, 5)
+    ref = ref[:100_000] + b"N" * 37 + ref[100_037:180_000] + b"ACGT" * 500 + ref[182_000:]
+    s, e = engine.windows(len(ref), 10_000, 0, k)
+    specs = [dict(cs=2, both=True)] * 3 + [dict(cs=4, both=True), dict(cs=2, both=False)] + [dict(cs=1, both=True)] * 4 + \
+            [dict(cs=2, both=True, keyhash=True)] + [dict(cs=2, both=True)] * 3
+    dbs, prefixes = [], []
+    for i, sp in enumerate(specs):
+        prefix, *_ = make_db(tmp_path, f"s{i}", ref, 100 + i, k=k, p=3, cs=sp["cs"], m=7, bins=4, both=sp["both"],
+                             noise=3_000)
+        if sp.get("keyhash"):
+            os.environ["KCFX_TABLE_MODE"] = "keyhash"
+        try:
+            dbs.append(engine.KmcDb.open(prefix))
+        finally:
+            os.environ.pop("KCFX_TABLE_MODE", None)
+        prefixes.append(prefix)
+    assert dbs[9].info.table_mode == 0 and dbs[0].info.table_mode == 1
+    r = engine.Reference(ref, s, e - s, k)
+    got = r.screen_multi(dbs, 1)
+    assert got.shape == (len(dbs), len(s))
+    for i, db in enumerate(dbs):
+        assert_same(got[i], r.screen(db, 1), f"sample {i}: multi vs single")
+        assert_same(got[i], oracle.OracleDb(prefixes[i]).screen(ref, s, e - s, 1, threads=4), f"sample {i}: multi vs oracle")
+    got3 = r.screen_multi(dbs[:3], 2)
+    for i in range(3):
+        assert_same(got3[i], r.screen(dbs[i], 2), f"-c 2 sample {i}")
+    assert r.screen_multi([], 1).shape == (0, len(s))
+    with pytest.raises(engine.KcfxError):
+        r.screen_multi(dbs[:2], 0)
