@@ -230,25 +230,39 @@ int main(int argc, char** argv) {
         wb[(size_t)i] = wins[(size_t)i].text_begin;
         wl[(size_t)i] = wins[(size_t)i].text_len;
     }
-    // reference text + windows resident in HBM once; one kcfx_screen_ref per sample
+    // reference text + windows resident in HBM once; the samples are screened in batches of up to 8 resident databases,
+    // one pass over the reference per batch (kcfx_screen_ref_multi; a single sample is a batch of one)
     const size_t S = kmc_list.size();
     kcfx_ref* ref = nullptr;
     if (kcfx_ref_create(o.device, k, reinterpret_cast<const uint8_t*>(text.data()), (int64_t)text.size(), wb.data(), wl.data(), n, &ref))
         error(kcfx_last_error());
     std::vector<std::vector<kcfx_result>> res(S, std::vector<kcfx_result>((size_t)n));
     std::vector<std::vector<double>> score(S, std::vector<double>((size_t)n)), depth(S, std::vector<double>((size_t)n));
-    for (size_t s = 0; s < S; ++s) {
-        if (s > 0) {
-            if (kcfx_db_open(kmc_list[s].c_str(), o.device, &db)) error(kcfx_last_error());
+    constexpr size_t BATCH = 8;
+    std::vector<kcfx_result> batch_res;
+    for (size_t s0 = 0; s0 < S; s0 += BATCH) {
+        const size_t nb = std::min(BATCH, S - s0);
+        std::vector<kcfx_db*> dbs(nb, nullptr);
+        for (size_t b = 0; b < nb; ++b) {
+            if (s0 + b == 0) {
+                dbs[b] = db;                                                             // opened above for the header
+                continue;
+            }
+            if (kcfx_db_open(kmc_list[s0 + b].c_str(), o.device, &dbs[b])) error(kcfx_last_error());
             kcfx_db_info_t di;
-            kcfx_db_info(db, &di);
+            kcfx_db_info(dbs[b], &di);
             if (di.kmer_length != k) error("Kmer size mismatch between the KMC databases");      // KCFHeader.equals (cohort)
         }
-        if (kcfx_screen_ref(db, ref, o.min_count, res[s].data())) error(kcfx_last_error());
-        if (kcfx_score(res[s].data(), n, o.wi, o.wt, o.wr, score[s].data(), depth[s].data())) error(kcfx_last_error());   // Data.java:101-103
-        kcfx_db_close(db);
-        db = nullptr;
+        batch_res.resize(nb * (size_t)n);
+        if (kcfx_screen_ref_multi(dbs.data(), (int32_t)nb, ref, o.min_count, batch_res.data())) error(kcfx_last_error());
+        for (size_t b = 0; b < nb; ++b) {
+            const size_t s = s0 + b;
+            std::copy(batch_res.begin() + (ptrdiff_t)(b * (size_t)n), batch_res.begin() + (ptrdiff_t)((b + 1) * (size_t)n), res[s].begin());
+            if (kcfx_score(res[s].data(), n, o.wi, o.wt, o.wr, score[s].data(), depth[s].data())) error(kcfx_last_error());   // Data.java:101-103
+            kcfx_db_close(dbs[b]);
+        }
     }
+    db = nullptr;
     kcfx_ref_destroy(ref);
 
     // sort each contig's windows by start (:169-171); ties keep generation order

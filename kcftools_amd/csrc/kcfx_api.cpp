@@ -13,7 +13,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "kcfx_internal.h"
@@ -44,39 +47,70 @@ struct KmcHeader {
     int32_t n_bins = 0;
     int64_t total = 0;
     int32_t suffix_bytes = 0, record_size = 0;
-    std::vector<uint64_t> lut;   // n_bins * 4^p global record indices
+    // n_bins * 4^p global record indices: a view into `file` (the whole .kmc_pre, 64 MiB for p = 7; file offset 4 is not
+    // 8-byte aligned, hence the byte pointer + memcpy accessors)
+    std::unique_ptr<uint8_t[]> file;
+    const uint8_t* lut_bytes = nullptr;
+    int64_t lut_entries = 0;
+    uint64_t lut_at(int64_t i) const { uint64_t v; memcpy(&v, lut_bytes + 8 * i, 8); return v; }
 };
 
 static uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
 static uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
 
-static int32_t read_whole(const std::string& path, std::vector<uint8_t>& out) {
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) return fail(KCFX_ERR_IO, "Error reading prefix file " + path);
-    fseeko(f, 0, SEEK_END);
-    const off_t n = ftello(f);
-    fseeko(f, 0, SEEK_SET);
-    out.resize((size_t)n);
-    if (n > 0 && fread(out.data(), 1, (size_t)n, f) != (size_t)n) {
-        fclose(f);
-        return fail(KCFX_ERR_IO, "short read on " + path);
+// pread `bytes` at `offset` into dst with a few threads (page cache -> pinned memory is a memcpy: one thread moves
+// ~5 GB/s, the .kmc_suf of a 150 M-k-mer sample is 1.2 GB)
+static bool parallel_pread(int fd, uint8_t* dst, int64_t bytes, int64_t offset) {
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(8, bytes >> 22));      // >= 4 MiB per thread
+    std::atomic<bool> ok{true};
+    auto work = [&](int t) {
+        const int64_t lo = bytes * t / T, hi = bytes * (t + 1) / T;
+        int64_t got = lo;
+        while (got < hi) {
+            const ssize_t r = pread(fd, dst + got, (size_t)(hi - got), offset + got);
+            if (r <= 0) {
+                ok = false;
+                return;
+            }
+            got += r;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    return ok;
+}
+
+// whole file into an uninitialised buffer (no zero-fill pass)
+static int32_t read_whole(const std::string& path, std::unique_ptr<uint8_t[]>& out, int64_t& size) {
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return fail(KCFX_ERR_IO, "Error reading prefix file " + path);
+    struct stat st;
+    if (fstat(fd, &st) != 0) {
+        close(fd);
+        return fail(KCFX_ERR_IO, "Error reading prefix file " + path);
     }
-    fclose(f);
+    size = (int64_t)st.st_size;
+    out.reset(new uint8_t[(size_t)std::max<int64_t>(size, 1)]);
+    const bool ok = parallel_pread(fd, out.get(), size, 0);
+    close(fd);
+    if (!ok) return fail(KCFX_ERR_IO, "short read on " + path);
     return KCFX_OK;
 }
 
 // KMC.java:107-168 readPrefixFile
 static int32_t parse_prefix_file(const std::string& path, KmcHeader& h) {
-    std::vector<uint8_t> pre;
-    if (int32_t rc = read_whole(path, pre)) return rc;
-    const int64_t size = (int64_t)pre.size();
+    int64_t size = 0;
+    if (int32_t rc = read_whole(path, h.file, size)) return rc;
+    const uint8_t* pre = h.file.get();
     if (size < 4 + 8 + 68 + 8) return fail(KCFX_ERR_FORMAT, "prefix file too small: " + path);
-    if (memcmp(pre.data(), "KMCP", 4) != 0 || memcmp(pre.data() + size - 4, "KMCP", 4) != 0)
+    if (memcmp(pre, "KMCP", 4) != 0 || memcmp(pre + size - 4, "KMCP", 4) != 0)
         return fail(KCFX_ERR_FORMAT, "missing KMCP markers in " + path);
-    const int64_t header_offset = rd32(pre.data() + size - 8);             // :117-118
+    const int64_t header_offset = rd32(pre + size - 8);                    // :117-118
     const int64_t pos = size - header_offset - 8;                          // :121
     if (header_offset < 68 || pos < 4 + 8) return fail(KCFX_ERR_FORMAT, "bad header offset in " + path);
-    const uint8_t* q = pre.data() + pos;
+    const uint8_t* q = pre + pos;
     h.k = (int32_t)rd32(q + 0);                                            // :124
     h.mode = (int32_t)rd32(q + 4);
     h.counter_size = (int32_t)rd32(q + 8);
@@ -100,12 +134,16 @@ static int32_t parse_prefix_file(const std::string& path, KmcHeader& h) {
     if (map_start < 4 + 8) return fail(KCFX_ERR_FORMAT, "prefix file too small for its signature map");
     h.n_bins = (int32_t)((map_start - 8 - 4) / (lut_size * 8));            // :156
     const int64_t entries = (int64_t)h.n_bins * lut_size;                  // :160
-    h.lut.resize((size_t)entries);
-    if (entries) memcpy(h.lut.data(), pre.data() + 4, (size_t)entries * 8);   // :153,:161-163
-    for (int64_t i = 1; i < entries; ++i)
-        if (h.lut[i] < h.lut[i - 1]) return fail(KCFX_ERR_FORMAT, "LUT is not monotonic");
-    if (entries && h.lut[entries - 1] > (uint64_t)h.total) return fail(KCFX_ERR_FORMAT, "LUT points past total_kmers");
-    if (h.total > 0 && (entries == 0 || h.lut[0] != 0)) return fail(KCFX_ERR_FORMAT, "LUT does not start at record 0");
+    h.lut_bytes = pre + 4;                                                 // :153,:161-163
+    h.lut_entries = entries;
+    uint64_t prev = 0;
+    for (int64_t i = 0; i < entries; ++i) {
+        const uint64_t v = h.lut_at(i);
+        if (v < prev) return fail(KCFX_ERR_FORMAT, "LUT is not monotonic");
+        prev = v;
+    }
+    if (entries && h.lut_at(entries - 1) > (uint64_t)h.total) return fail(KCFX_ERR_FORMAT, "LUT points past total_kmers");
+    if (h.total > 0 && (entries == 0 || h.lut_at(0) != 0)) return fail(KCFX_ERR_FORMAT, "LUT does not start at record 0");
     h.suffix_bytes = (h.k - h.p) / 4;
     h.record_size = h.counter_size + h.suffix_bytes;                       // :61
     return KCFX_OK;
@@ -114,6 +152,47 @@ static int32_t parse_prefix_file(const std::string& path, KmcHeader& h) {
 }  // namespace kcfx
 
 using namespace kcfx;
+
+// ------------------------------------------------------------------------------------------------------
+// streams: creating one costs ~90 ms on this stack (a hardware queue behind it), which would dominate kcfx_db_open;
+// handles borrow from a per-device pool and hand the stream back (idle) when they are destroyed
+// ------------------------------------------------------------------------------------------------------
+namespace {
+std::mutex g_stream_mu;
+std::vector<std::pair<int, hipStream_t>> g_stream_pool;
+
+hipError_t stream_acquire(int device, hipStream_t* out) {
+    {
+        std::lock_guard<std::mutex> lk(g_stream_mu);
+        for (size_t i = 0; i < g_stream_pool.size(); ++i)
+            if (g_stream_pool[i].first == device) {
+                *out = g_stream_pool[i].second;
+                g_stream_pool.erase(g_stream_pool.begin() + (ptrdiff_t)i);
+                return hipSuccess;
+            }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+// databases only use their stream while loading and in kcfx_db_lookup: one shared stream per device, for the process
+std::vector<std::pair<int, hipStream_t>> g_db_streams;
+hipError_t db_stream(int device, hipStream_t* out) {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    for (auto& e : g_db_streams)
+        if (e.first == device) {
+            *out = e.second;
+            return hipSuccess;
+        }
+    const hipError_t e = hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    if (e == hipSuccess) g_db_streams.emplace_back(device, *out);
+    return e;
+}
+void stream_release(int device, hipStream_t st) {
+    if (!st) return;
+    (void)hipStreamSynchronize(st);
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    g_stream_pool.emplace_back(device, st);
+}
+}  // namespace
 
 // ------------------------------------------------------------------------------------------------------
 // handles
@@ -261,8 +340,8 @@ int32_t table_finish(kcfx_db* db) {
 void db_free(kcfx_db* db) {
     if (!db) return;
     DeviceGuard g(db->device);
+    if (db->stream) (void)hipStreamSynchronize(db->stream);   // shared per device (db_stream), never destroyed
     if (db->d_lines) (void)hipFree(db->d_lines);
-    if (db->stream) (void)hipStreamDestroy(db->stream);
     delete db;
 }
 
@@ -284,13 +363,27 @@ void ref_free(kcfx_ref* r) {
     if (r->d_mbits) (void)hipFree(r->d_mbits);
     if (r->d_mcsum) (void)hipFree(r->d_mcsum);
     if (r->d_mres) (void)hipFree(r->d_mres);
-    if (r->stream) (void)hipStreamDestroy(r->stream);
+    stream_release(r->device, r->stream);
     delete r;
 }
 
-// stream the .kmc_suf records through the GPU: upload -> decode_records -> table_insert
-// pass 0: count the k-mers per minimizer home line (heavy-bucket detection); pass 1: insert
-int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& h, int pass) {
+// KCFX_LOAD_TRACE=1: phase timings of kcfx_db_open on stderr
+struct LoadTrace {
+    bool on = getenv("KCFX_LOAD_TRACE") != nullptr;
+    double t = now_s();
+    void mark(const char* what) {
+        if (!on) return;
+        const double n = now_s();
+        fprintf(stderr, "[kcfx load] %-28s %8.1f ms\n", what, (n - t) * 1e3);
+        t = n;
+    }
+};
+
+// Stream the .kmc_suf records through the GPU once: upload -> decode_records -> (key, count) arrays.
+//   minimizer tables need two passes over the k-mers (count per home line, mark heavy homes, insert). When the decoded
+//   records fit beside the table (12 B per k-mer) they stay in HBM between the passes and the file is read once;
+//   otherwise the file is streamed twice.
+int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& h) {
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) return fail(KCFX_ERR_IO, "Error reading suffix buffers from file " + path);
     struct stat st;
@@ -303,10 +396,11 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
         close(fd);
         return fail(KCFX_ERR_FORMAT, "missing KMCS marker in " + path);
     }
-    const int64_t CH = 16ll << 20;   // records per chunk
+    LoadTrace tr;
+    const int64_t CH = 4ll << 20;    // records per chunk
     const int64_t chunk_bytes = CH * h.record_size;
     uint8_t* h_buf[2] = {nullptr, nullptr};
-    uint8_t* d_rec = nullptr;
+    uint8_t* d_rec[2] = {nullptr, nullptr};
     uint64_t* d_lut = nullptr;
     uint64_t* d_keys = nullptr;
     uint32_t* d_counts = nullptr;
@@ -315,9 +409,9 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     auto cleanup = [&]() {
         for (int i = 0; i < 2; ++i) {
             if (h_buf[i]) (void)hipHostFree(h_buf[i]);
+            if (d_rec[i]) (void)hipFree(d_rec[i]);
             if (done[i]) (void)hipEventDestroy(done[i]);
         }
-        if (d_rec) (void)hipFree(d_rec);
         if (d_lut) (void)hipFree(d_lut);
         if (d_keys) (void)hipFree(d_keys);
         if (d_counts) (void)hipFree(d_counts);
@@ -332,48 +426,78 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
             return rc;                                  \
         }                                               \
     } while (0)
+    const bool two_phase = (db->mode == MODE_MINIMIZER);
+    // keep every decoded record resident between the phases?
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    const bool resident = two_phase && getenv("KCFX_LOAD_STREAM_TWICE") == nullptr &&
+                          (double)h.total * 12.0 + (double)(2 * chunk_bytes) + (double)(64 << 20) < 0.5 * (double)free_b;
     const int64_t n_chunk_max = std::min<int64_t>(CH, std::max<int64_t>(h.total, 1));
+    const int64_t n_keys_buf = resident ? std::max<int64_t>(h.total, 1) : n_chunk_max;
     for (int i = 0; i < 2; ++i) {
         LOAD_HIP(hipHostMalloc(&h_buf[i], (size_t)std::min(chunk_bytes, std::max<int64_t>(h.total * h.record_size, 16)), hipHostMallocDefault));
+        LOAD_HIP(hipMalloc(&d_rec[i], (size_t)n_chunk_max * h.record_size + 16));
         LOAD_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
     }
-    LOAD_HIP(hipMalloc(&d_rec, (size_t)n_chunk_max * h.record_size + 16));
-    LOAD_HIP(hipMalloc(&d_lut, std::max<size_t>(h.lut.size(), 1) * 8));
-    LOAD_HIP(hipMalloc(&d_keys, (size_t)n_chunk_max * 8));
-    LOAD_HIP(hipMalloc(&d_counts, (size_t)n_chunk_max * 4));
-    if (!h.lut.empty()) LOAD_HIP(hipMemcpyAsync(d_lut, h.lut.data(), h.lut.size() * 8, hipMemcpyHostToDevice, db->stream));
-    int64_t first = 0;
-    int turn = 0;
-    bool used[2] = {false, false};
-    while (first < h.total) {
-        const int64_t n = std::min(CH, h.total - first);
-        const int64_t bytes = n * h.record_size;
-        if (used[turn]) LOAD_HIP(hipEventSynchronize(done[turn]));
-        int64_t got = 0;
-        while (got < bytes) {
-            const ssize_t r = pread(fd, h_buf[turn] + got, (size_t)(bytes - got), 4 + first * h.record_size + got);
-            if (r <= 0) {
+    LOAD_HIP(hipMalloc(&d_lut, (size_t)std::max<int64_t>(h.lut_entries, 1) * 8));
+    LOAD_HIP(hipMalloc(&d_keys, (size_t)n_keys_buf * 8));
+    LOAD_HIP(hipMalloc(&d_counts, (size_t)n_keys_buf * 4));
+    if (h.lut_entries) LOAD_HIP(hipMemcpyAsync(d_lut, h.lut_bytes, (size_t)h.lut_entries * 8, hipMemcpyHostToDevice, db->stream));
+    tr.mark("buffers + LUT upload");
+
+    // phase: 0 = count per home line (minimizer tables only), 1 = insert
+    auto stream_file = [&](int phase, bool keep) -> int32_t {
+        int64_t first = 0;
+        int turn = 0;
+        bool used[2] = {false, false};
+        while (first < h.total) {
+            const int64_t n = std::min(CH, h.total - first);
+            const int64_t bytes = n * h.record_size;
+            if (used[turn]) LOAD_HIP(hipEventSynchronize(done[turn]));      // the copy out of h_buf[turn] has finished
+            if (!parallel_pread(fd, h_buf[turn], bytes, 4 + first * h.record_size)) {
                 cleanup();
                 return fail(KCFX_ERR_IO, "short read on " + path);
             }
-            got += r;
+            // d_rec[turn] was last read by the decode two chunks ago, which precedes this copy in stream order
+            LOAD_HIP(hipMemcpyAsync(d_rec[turn], h_buf[turn], (size_t)bytes, hipMemcpyHostToDevice, db->stream));
+            LOAD_HIP(hipEventRecord(done[turn], db->stream));
+            used[turn] = true;
+            uint64_t* keys = d_keys + (keep ? first : 0);
+            uint32_t* counts = d_counts + (keep ? first : 0);
+            LOAD_HIP(launch_decode_records(d_rec[turn], first, n, h.record_size, h.suffix_bytes, h.counter_size, h.p, d_lut,
+                                           h.lut_entries, keys, counts, db->stream));
+            if (phase == 0)
+                LOAD_HIP(launch_table_count(db->d_lines, db->view(), h.k, keys, n, db->stream));
+            else
+                LOAD_HIP(launch_table_insert(db->d_lines, db->view(), h.k, keys, counts, n, db->stream));
+            first += n;
+            turn ^= 1;
         }
-        // d_rec is reused by every chunk: stream order (copy -> decode -> insert -> next copy) keeps it safe
-        LOAD_HIP(hipMemcpyAsync(d_rec, h_buf[turn], (size_t)bytes, hipMemcpyHostToDevice, db->stream));
-        LOAD_HIP(hipEventRecord(done[turn], db->stream));
-        used[turn] = true;
-        LOAD_HIP(launch_decode_records(d_rec, first, n, h.record_size, h.suffix_bytes, h.counter_size, h.p, d_lut,
-                                       (int64_t)h.lut.size(), d_keys, d_counts, db->stream));
-        if (pass == 0)
-            LOAD_HIP(launch_table_count(db->d_lines, db->view(), h.k, d_keys, n, db->stream));
-        else
-            LOAD_HIP(launch_table_insert(db->d_lines, db->view(), h.k, d_keys, d_counts, n, db->stream));
-        first += n;
-        turn ^= 1;
+        return KCFX_OK;
+    };
+
+    if (!two_phase) {
+        if ((rc = stream_file(1, false))) return rc;
+    } else {
+        if ((rc = stream_file(0, resident))) return rc;
+        tr.mark("file -> decode -> count (host)");
+        LOAD_HIP(launch_table_mark_heavy(db->d_lines, db->n_lines, db->stream));
+        if (resident) {
+            // second phase straight from HBM, in launches of at most 2^30 records
+            for (int64_t first = 0; first < h.total; first += (1ll << 30)) {
+                const int64_t n = std::min<int64_t>(1ll << 30, h.total - first);
+                LOAD_HIP(launch_table_insert(db->d_lines, db->view(), h.k, d_keys + first, d_counts + first, n, db->stream));
+            }
+        } else {
+            LOAD_HIP(hipStreamSynchronize(db->stream));
+            if ((rc = stream_file(1, false))) return rc;
+        }
     }
     LOAD_HIP(hipStreamSynchronize(db->stream));
+    tr.mark("insert + sync");
 #undef LOAD_HIP
     cleanup();
+    tr.mark("free buffers");
     return KCFX_OK;
 }
 
@@ -403,7 +527,9 @@ int32_t kcfx_db_open(const char* kmc_prefix, int32_t device, kcfx_db** out) {
     *out = nullptr;
     const double t0 = now_s();
     KmcHeader h;
+    LoadTrace tr;
     if (int32_t rc = parse_prefix_file(std::string(kmc_prefix) + ".kmc_pre", h)) return rc;
+    tr.mark("parse .kmc_pre");
     if (int32_t rc = check_device(device)) return rc;
     DeviceGuard g(device);
     if (!g.ok) return fail(KCFX_ERR_DEVICE, "hipSetDevice failed");
@@ -421,18 +547,15 @@ int32_t kcfx_db_open(const char* kmc_prefix, int32_t device, kcfx_db** out) {
     db->info.n_bins = h.n_bins;
     db->info.total_kmers = h.total;
     db->info.device = device;
-    hipError_t e = hipStreamCreateWithFlags(&db->stream, hipStreamNonBlocking);
+    hipError_t e = db_stream(device, &db->stream);
     if (e != hipSuccess) { db_free(db); return hip_fail(e, "hipStreamCreate"); }
+    tr.mark("device + stream");
     int32_t rc = table_alloc(db, h.total, h.counter_size);
-    if (!rc && db->mode == MODE_MINIMIZER) {
-        rc = load_suffix_file(db, std::string(kmc_prefix) + ".kmc_suf", h, 0);
-        if (!rc) {
-            e = launch_table_mark_heavy(db->d_lines, db->n_lines, db->stream);
-            if (e != hipSuccess) rc = hip_fail(e, "table_mark_heavy");
-        }
-    }
-    if (!rc) rc = load_suffix_file(db, std::string(kmc_prefix) + ".kmc_suf", h, 1);
+    if (tr.on) (void)hipStreamSynchronize(db->stream);
+    tr.mark("table alloc + clear");
+    if (!rc) rc = load_suffix_file(db, std::string(kmc_prefix) + ".kmc_suf", h);
     if (!rc) rc = table_finish(db);
+    tr.mark("finalize");
     if (rc) { db_free(db); return rc; }
     db->info.load_seconds = now_s() - t0;
     *out = db;
@@ -460,7 +583,7 @@ int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, 
     uint64_t* d_keys = nullptr;
     uint32_t* d_counts = nullptr;
     int32_t rc = KCFX_OK;
-    hipError_t e = hipStreamCreateWithFlags(&db->stream, hipStreamNonBlocking);
+    hipError_t e = db_stream(device, &db->stream);
     if (e != hipSuccess) rc = hip_fail(e, "hipStreamCreate");
     if (!rc) rc = table_alloc(db, n, counter_size);
     if (!rc && n > 0) {
@@ -561,7 +684,7 @@ int32_t kcfx_ref_create(int32_t device, int32_t kmer_length, const uint8_t* text
     r->n_slots = n_slots;
     const size_t text_alloc = (size_t)text_len + 128;   // the pack phase reads whole 32-byte chunks
     hipError_t e;
-    if ((e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking)) != hipSuccess ||
+    if ((e = stream_acquire(device, &r->stream)) != hipSuccess ||
         (e = hipMalloc(&r->d_text, text_alloc)) != hipSuccess ||
         (e = hipMemsetAsync(r->d_text + text_len, 0, 128, r->stream)) != hipSuccess ||
         (text_len > 0 && (e = hipMemcpyAsync(r->d_text, text, (size_t)text_len, hipMemcpyHostToDevice, r->stream)) != hipSuccess) ||
