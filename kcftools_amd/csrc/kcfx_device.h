@@ -26,8 +26,7 @@ KCFX_HD uint32_t hash32(uint64_t key) {
 }
 KCFX_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 // The minimum of ~16 hashes is skewed towards 0: one odd multiply (Fibonacci hashing, a bijection mod 2^32) re-spreads
-// it before range reduction. screen_* is VALU-bound and v_mul_lo_u32 is quarter rate, so every multiply here is priced
-// as four instructions per k-mer.
+// it before range reduction. screen_* is VALU-issue bound, so every instruction here is paid per k-mer.
 KCFX_HD uint32_t remix32(uint32_t x) { return x * 0x9E3779B1u; }
 // line of a minimizer (minimum M-mer hash)
 KCFX_HD uint32_t line_of_minimizer(uint32_t mn, uint32_t n_lines) { return mulhi32(remix32(mn), n_lines); }
