@@ -2,7 +2,7 @@
 """bench.py -- k-mers screened/s of the getVariations hot path on N MI355X (BASELINE.json metric).
 
 A "step" is one pass of the hot path over one batch: every window of the reference screened against one
-sample's KMC database (kcfx_screen_ref_async: screen_k31 + summarize_tiles + finalize_windows), inputs resident in HBM.
+sample's KMC database (kcfx_screen_ref_async: screen_k31 + reduce_windows), inputs resident in HBM.
 
 Workload at N=1 (BASELINE.json configs[1]): synthetic A. thaliana chr1-sized reference (30,427,671 bp, seeded),
 one synthetic KMC sample (k=31, counter_size 2, ~150 M k-mers = sample-genome k-mers + random noise k-mers),

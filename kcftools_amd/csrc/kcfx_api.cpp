@@ -218,12 +218,10 @@ struct kcfx_ref {
     uint8_t* d_text = nullptr;
     TileDesc* d_tiles = nullptr;
     int32_t* d_win_tile0 = nullptr;
-    TileSummary* d_summ = nullptr;
     uint64_t* d_bits = nullptr;        // per tile: valid / hit ballots of every 64-position word
     int64_t* d_csum = nullptr;         // per tile: sum of counts over hits
     kcfx_result* d_res = nullptr;      // used by the synchronous entry point
     // multi-sample pass (allocated on first use; scratch sized for SCREEN_MULTI_MAX samples)
-    TileSummary* d_msumm = nullptr;
     uint64_t* d_mbits = nullptr;
     int64_t* d_mcsum = nullptr;
     kcfx_result* d_mres = nullptr;     // synchronous multi entry point: n_db * n_windows records
@@ -355,11 +353,9 @@ void ref_free(kcfx_ref* r) {
     if (r->d_text) (void)hipFree(r->d_text);
     if (r->d_tiles) (void)hipFree(r->d_tiles);
     if (r->d_win_tile0) (void)hipFree(r->d_win_tile0);
-    if (r->d_summ) (void)hipFree(r->d_summ);
     if (r->d_bits) (void)hipFree(r->d_bits);
     if (r->d_csum) (void)hipFree(r->d_csum);
     if (r->d_res) (void)hipFree(r->d_res);
-    if (r->d_msumm) (void)hipFree(r->d_msumm);
     if (r->d_mbits) (void)hipFree(r->d_mbits);
     if (r->d_mcsum) (void)hipFree(r->d_mcsum);
     if (r->d_mres) (void)hipFree(r->d_mres);
@@ -690,7 +686,6 @@ int32_t kcfx_ref_create(int32_t device, int32_t kmer_length, const uint8_t* text
         (text_len > 0 && (e = hipMemcpyAsync(r->d_text, text, (size_t)text_len, hipMemcpyHostToDevice, r->stream)) != hipSuccess) ||
         (e = hipMalloc(&r->d_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(TileDesc))) != hipSuccess ||
         (e = hipMalloc(&r->d_win_tile0, win_tile0.size() * 4)) != hipSuccess ||
-        (e = hipMalloc(&r->d_summ, std::max<size_t>(tiles.size(), 1) * sizeof(TileSummary))) != hipSuccess ||
         (e = hipMalloc(&r->d_bits, std::max<size_t>(tiles.size(), 1) * TILE_BITS_U64 * 8)) != hipSuccess ||
         (e = hipMalloc(&r->d_csum, std::max<size_t>(tiles.size(), 1) * 8)) != hipSuccess ||
         (e = hipMalloc(&r->d_res, std::max<size_t>((size_t)n_windows, 1) * sizeof(kcfx_result))) != hipSuccess ||
@@ -731,9 +726,8 @@ int32_t kcfx_screen_ref_async(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count
     KCFX_HIP(launch_screen_tiles(ref->d_text, ref->d_tiles, ref->n_tiles, db->view(), ref->k, db->info.both_strands,
                                  min_kmer_count, ref->d_bits, ref->d_csum, st));
     if (ev1) KCFX_HIP(hipEventRecord(ev1, st));
-    KCFX_HIP(launch_summarize_tiles(ref->d_tiles, ref->n_tiles, 1, ref->d_bits, ref->d_csum, ref->k, ref->d_summ, st));
-    KCFX_HIP(launch_finalize_windows(ref->d_summ, ref->n_tiles, 1, ref->d_win_tile0, ref->n_windows, ref->k,
-                                     reinterpret_cast<kcfx_result*>(out_device), st));
+    KCFX_HIP(launch_reduce_windows(ref->d_tiles, ref->n_tiles, 1, ref->d_bits, ref->d_csum, ref->d_win_tile0, ref->n_windows,
+                                   ref->k, reinterpret_cast<kcfx_result*>(out_device), st));
     return KCFX_OK;
 }
 
@@ -756,7 +750,6 @@ int32_t kcfx_screen_ref_multi_async(kcfx_db* const* dbs, int32_t n_db, kcfx_ref*
         const size_t nt = std::max<size_t>(ref->n_tiles, 1);
         KCFX_HIP(hipMalloc(&ref->d_mbits, nt * SCREEN_MULTI_MAX * TILE_BITS_U64 * 8));
         KCFX_HIP(hipMalloc(&ref->d_mcsum, nt * SCREEN_MULTI_MAX * sizeof(int64_t)));
-        KCFX_HIP(hipMalloc(&ref->d_msumm, nt * SCREEN_MULTI_MAX * sizeof(TileSummary)));
     }
     std::vector<char> done(n_db, 0);
     for (int32_t first = 0; first < n_db; ++first) {
@@ -795,13 +788,13 @@ int32_t kcfx_screen_ref_multi_async(kcfx_db* const* dbs, int32_t n_db, kcfx_ref*
         KCFX_HIP(launch_screen_multi(ref->d_text, ref->d_tiles, ref->n_tiles, tvs, nb, d0->info.both_strands, min_kmer_count,
                                      ref->d_mbits, ref->d_mcsum, st));
         if (ev1) KCFX_HIP(hipEventRecord(ev1, st));
-        KCFX_HIP(launch_summarize_tiles(ref->d_tiles, ref->n_tiles, nb, ref->d_mbits, ref->d_mcsum, ref->k, ref->d_msumm, st));
         // consecutive output slices take one launch; scattered ones (mixed batches) one each
         for (int32_t b = 0; b < nb;) {
             int32_t e = b + 1;
             while (e < nb && idx[e] == idx[e - 1] + 1) ++e;
-            KCFX_HIP(launch_finalize_windows(ref->d_msumm + (size_t)b * ref->n_tiles, ref->n_tiles, e - b, ref->d_win_tile0,
-                                             ref->n_windows, ref->k, out + (size_t)idx[b] * ref->n_windows, st));
+            KCFX_HIP(launch_reduce_windows(ref->d_tiles, ref->n_tiles, e - b, ref->d_mbits + (size_t)b * ref->n_tiles * TILE_BITS_U64,
+                                           ref->d_mcsum + (size_t)b * ref->n_tiles, ref->d_win_tile0, ref->n_windows, ref->k,
+                                           out + (size_t)idx[b] * ref->n_windows, st));
             b = e;
         }
     }

@@ -328,7 +328,7 @@ KCFX_HD void gap_advance(uint64_t H, uint64_t M, GapCarry& c) {
 
 // ---- a tile's hit bitmap -> its summary -----------------------------------------------------------------
 // Vw / Hw: per 64-position word, the ballots of "valid k-mer" and "observed" (hit) written by screen_tiles.
-// Sequential over the words of one tile (<= TILE_K / 64); runs one tile per lane in summarize_tiles_kernel.
+// Sequential over the words of one tile (<= TILE_K / 64); reduce_windows_kernel calls it on 4-word pieces.
 KCFX_HD TileSummary summarize_words(const uint64_t* Vw, const uint64_t* Hw, int n_kmers, int k, int64_t count_sum) {
     const int n_words = (n_kmers + 63) >> 6;
     if (n_words == 0) return summary_identity();

@@ -52,8 +52,8 @@ struct TableView {
 
 // ----------------------------------------------------------------------------------------------------
 // Tile plan: every window is cut into tiles of at most TILE_K consecutive k-mer start positions; one
-// workgroup screens one tile and emits its hit bitmap; summarize_tiles reduces each bitmap to a TileSummary;
-// finalize_windows folds a window's tiles in order.
+// workgroup screens one tile and emits its hit bitmap; reduce_windows summarises the bitmaps piecewise (TileSummary)
+// and folds a window's pieces in order.
 // ----------------------------------------------------------------------------------------------------
 constexpr int BLOCK = 256;            // 4 wavefronts
 #ifndef KCFX_TILE_K
@@ -61,7 +61,7 @@ constexpr int BLOCK = 256;            // 4 wavefronts
 #endif
 constexpr int TILE_K = KCFX_TILE_K;   // k-mer start positions per tile (multiple of 64)
 constexpr int TILE_WORDS = TILE_K / 64;
-// per tile: TILE_WORDS valid-ballots then TILE_WORDS hit-ballots (screen_tiles -> summarize_tiles)
+// per tile: TILE_WORDS valid-ballots then TILE_WORDS hit-ballots (screen kernel -> reduce_windows)
 constexpr int TILE_BITS_U64 = 2 * TILE_WORDS;
 
 struct TileDesc {
@@ -180,8 +180,10 @@ hipError_t launch_lookup(TableView tv, int32_t k, const uint64_t* keys, int64_t 
 hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32_t n_tiles, TableView tv, int32_t k,
                                int32_t both_strands, int32_t min_count, uint64_t* bits, int64_t* count_sums,
                                hipStream_t st);
-hipError_t launch_summarize_tiles(const TileDesc* tiles, int32_t n_tiles, int32_t n_samples, const uint64_t* bits,
-                                  const int64_t* count_sums, int32_t k, TileSummary* out, hipStream_t st);
+// hit bitmaps + count sums of n_samples consecutive samples -> kcfx_result per (sample, window)
+hipError_t launch_reduce_windows(const TileDesc* tiles, int32_t n_tiles, int32_t n_samples, const uint64_t* bits,
+                                 const int64_t* count_sums, const int32_t* win_tile0, int32_t n_windows, int32_t k,
+                                 kcfx_result* out, hipStream_t st);
 // S <= SCREEN_MULTI_MAX tables in one pass over the reference (k = 31, M = 16 minimizer tables with one strandedness);
 // sample s writes bits + s * n_tiles * TILE_BITS_U64 and count_sums + s * n_tiles
 constexpr int SCREEN_MULTI_MAX = 8;
@@ -189,7 +191,6 @@ bool screen_multi_supported(const TableView& tv, int32_t k);
 hipError_t launch_screen_multi(const uint8_t* text, const TileDesc* tiles, int32_t n_tiles, const TableView* tvs,
                                int32_t n_tables, int32_t both_strands, int32_t min_count, uint64_t* bits, int64_t* count_sums,
                                hipStream_t st);
-hipError_t launch_finalize_windows(const TileSummary* tiles, int32_t n_tiles, int32_t n_samples, const int32_t* win_tile0,
-                                   int32_t n_windows, int32_t k, kcfx_result* out, hipStream_t st);
+
 
 }  // namespace kcfx

@@ -3,12 +3,14 @@
 //   table_*          : build the HBM table from (k-mer word, count) pairs        (load time)
 //   decode_records   : KMC .kmc_suf records + LUT -> (k-mer word, count)         (load time; KMC.java:427-450)
 //   lookup           : batched KMC.getCount                                      (KMC.java:292-326)
-//   screen_tiles     : THE hot kernel. ASCII window text -> 2-bit pack in LDS -> per-lane canonical k-mer ->
-//                      minimizer runs -> cooperative 128-byte line fetches -> wave ballots -> gap monoid
-//                                                     (GetVariants.java:202-252, Fasta.java:90-167, Kmer.java)
-//   finalize_windows : fold a window's tile summaries -> kcfx_result             (GetVariants.java:254-258)
+//   screen_k31       : THE hot kernel (k = 31, minimizer table). ASCII window text -> 2-bit pack in LDS -> per-lane
+//                      canonical k-mer -> minimizer runs -> cooperative 128-byte line fetches -> wave ballots
+//                                                     (GetVariants.java:202-227, Fasta.java:90-167, Kmer.java)
+//   screen_k31_multi : the same for up to 8 resident samples per pass over the reference (SURVEY f-4)
+//   screen_tiles     : the general form (any k <= 32, both table modes)
+//   reduce_windows   : hit bitmaps -> gap monoid -> kcfx_result per (window, sample)   (GetVariants.java:228-258)
 //
-// Integer / index work, HBM-bound: no MFMA. Lane <-> consecutive k-mer start positions, so one __ballot is a
+// Integer / index work: no MFMA. Lane <-> consecutive k-mer start positions, so one __ballot is a
 // 64-position slice of the window's hit bitmap.
 #include <cstdlib>
 
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         const bool found = (st == 2u);
         const bool hit = found && ((int32_t)cnt >= min_count);   // GetVariants.java:224
 
-        // this word of the window's hit bitmap (reduced by summarize_tiles_kernel)
+        // this word of the window's hit bitmap (reduced by reduce_windows_kernel)
         const uint64_t V = wave_ballot(valid);
         const uint64_t H = wave_ballot(hit);
         if (lane == 0) {
@@ -696,7 +698,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 // The same tile walk, but every word's keys / minimizers / validity are derived once and probed against S resident
 // tables: pack, strands, hashing and the sliding minimum are amortised over the samples. Sample s writes its own hit
 // bitmap (bits + s * bits_stride, the validity words replicated) and count sums (count_sums + s * n_tiles), so
-// summarize_tiles / finalize_windows run unchanged per sample.
+// reduce_windows runs unchanged per sample (blockIdx.y).
 constexpr int MULTI_MAX = SCREEN_MULTI_MAX;
 struct MultiTables {
     TableView tv[MULTI_MAX];
@@ -757,10 +759,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 }
 
 // hit bitmap -> TileSummary (gap monoid + EFFLEN runs), GetVariants.java:228-252. SUM_LANES lanes per tile: each walks
-// TILE_WORDS / SUM_LANES consecutive words, then the pieces are folded in order with the same monoid that folds tiles
-// into windows (one lane per tile walked 32 dependent words and took 20 us for 15 k tiles).
+// TILE_WORDS / SUM_LANES consecutive words, then the pieces are folded in order with the monoid (one lane per tile walked
+// 32 dependent words and took 20 us for 15 k tiles).
 constexpr int SUM_LANES = 8;
-static_assert(TILE_WORDS % SUM_LANES == 0 && 64 % SUM_LANES == 0, "summarize_tiles_kernel piece size");
+static_assert(TILE_WORDS % SUM_LANES == 0 && 64 % SUM_LANES == 0, "reduce_windows_kernel piece size");
 
 __device__ __forceinline__ TileSummary shfl_down_summary(const TileSummary& s, int off) {
     TileSummary r;
@@ -778,49 +780,48 @@ __device__ __forceinline__ TileSummary shfl_down_summary(const TileSummary& s, i
     return r;
 }
 
-__global__ void summarize_tiles_kernel(const TileDesc* __restrict__ tiles, int32_t n_tiles,
-                                       const uint64_t* __restrict__ bits, const int64_t* __restrict__ count_sums,
-                                       int32_t k, TileSummary* __restrict__ out) {
+// One wave per (window, sample): lane l takes piece l % 8 of tile l / 8 of the current group of 8 tiles, the 64 pieces
+// are folded in order with shuffles, groups are chained on lane 0, and lane 0 writes the kcfx_result
+// (GetVariants.java:248-258). One launch instead of a per-tile and a per-window kernel.
+constexpr int REDUCE_BLOCK = 256;
+__global__ __launch_bounds__(REDUCE_BLOCK) void reduce_windows_kernel(const TileDesc* __restrict__ tiles, int32_t n_tiles,
+                                                                      const uint64_t* __restrict__ bits,
+                                                                      const int64_t* __restrict__ count_sums,
+                                                                      const int32_t* __restrict__ win_tile0, int32_t n_windows,
+                                                                      int32_t k, kcfx_result* __restrict__ out) {
     constexpr int PW = TILE_WORDS / SUM_LANES;             // words per piece
-    // blockIdx.y = sample of a multi-sample pass: its bitmaps, count sums and summaries follow the previous sample's
+    constexpr int GROUP = 64 / SUM_LANES;                  // tiles per wave step
+    // blockIdx.y = sample of a multi-sample pass: its bitmaps, count sums and results follow the previous sample's
     bits += (size_t)blockIdx.y * n_tiles * TILE_BITS_U64;
     count_sums += (size_t)blockIdx.y * n_tiles;
-    out += (size_t)blockIdx.y * n_tiles;
-    const int32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    const int32_t t = g / SUM_LANES, sub = g % SUM_LANES;
-    TileSummary acc = summary_identity();
-    if (t < n_tiles) {
-        const int n_local = min(tiles[t].n_kmers - sub * PW * 64, PW * 64);
-        if (n_local > 0) {
-            const uint64_t* b = bits + (size_t)t * TILE_BITS_U64 + sub * PW;
-            acc = summarize_words(b, b + TILE_WORDS, n_local, k, sub == 0 ? count_sums[t] : 0);
-        }
-    }
-#pragma unroll
-    for (int off = 1; off < SUM_LANES; off <<= 1) {
-        const TileSummary nb = shfl_down_summary(acc, off);
-        if ((sub & (2 * off - 1)) == 0) acc = summary_combine(acc, nb, k);
-    }
-    if (t < n_tiles && sub == 0) {
-        // a tile of a window shorter than k has no piece at all: it stays the identity, as before
-        out[t] = acc;
-    }
-}
-
-// one thread per window: fold its tiles in order (GetVariants.java:248-258)
-__global__ void finalize_windows_kernel(const TileSummary* __restrict__ tiles, int32_t n_tiles,
-                                        const int32_t* __restrict__ win_tile0, int32_t n_windows, int32_t k,
-                                        kcfx_result* __restrict__ out) {
-    const int32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_windows) return;
-    tiles += (size_t)blockIdx.y * n_tiles;                 // sample of a multi-sample pass
     out += (size_t)blockIdx.y * n_windows;
-    TileSummary acc = summary_identity();
-    for (int32_t t = win_tile0[w]; t < win_tile0[w + 1]; ++t) acc = summary_combine(acc, tiles[t], k);
-    if (acc.flags & F_EMPTY) {
-        acc.flags = 0;   // window shorter than k: empty list => all zeros (GetVariants.java:219)
+    const int lane = threadIdx.x & 63;
+    const int32_t w = blockIdx.x * (REDUCE_BLOCK / 64) + (threadIdx.x >> 6);
+    if (w >= n_windows) return;
+    const int32_t t_begin = win_tile0[w], t_end = win_tile0[w + 1];
+    const int sub = lane % SUM_LANES;
+    TileSummary total = summary_identity();                // meaningful on lane 0
+    for (int32_t t0 = t_begin; t0 < t_end; t0 += GROUP) {
+        const int32_t t = t0 + lane / SUM_LANES;
+        TileSummary acc = summary_identity();
+        if (t < t_end) {
+            const int n_local = min(tiles[t].n_kmers - sub * PW * 64, PW * 64);
+            if (n_local > 0) {
+                const uint64_t* b = bits + (size_t)t * TILE_BITS_U64 + sub * PW;
+                acc = summarize_words(b, b + TILE_WORDS, n_local, k, sub == 0 ? count_sums[t] : 0);
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const TileSummary nb = shfl_down_summary(acc, off);
+            if ((lane & (2 * off - 1)) == 0) acc = summary_combine(acc, nb, k);
+        }
+        if (lane == 0) total = summary_combine(total, acc, k);
     }
-    out[w] = summary_finalize(acc, k);
+    if (lane == 0) {
+        if (total.flags & F_EMPTY) total.flags = 0;   // window shorter than k: empty list => all zeros (GetVariants.java:219)
+        out[w] = summary_finalize(total, k);
+    }
 }
 
 // ======================================================================================================
@@ -892,12 +893,13 @@ hipError_t launch_lookup(TableView tv, int32_t k, const uint64_t* keys, int64_t 
     return hipGetLastError();
 }
 
-hipError_t launch_summarize_tiles(const TileDesc* tiles, int32_t n_tiles, int32_t n_samples, const uint64_t* bits,
-                                  const int64_t* count_sums, int32_t k, TileSummary* out, hipStream_t st) {
-    if (n_tiles <= 0 || n_samples <= 0) return hipSuccess;
-    const int64_t lanes = (int64_t)n_tiles * SUM_LANES;
-    hipLaunchKernelGGL(summarize_tiles_kernel, dim3((uint32_t)((lanes + 255) / 256), n_samples), dim3(256), 0, st, tiles,
-                       n_tiles, bits, count_sums, k, out);
+hipError_t launch_reduce_windows(const TileDesc* tiles, int32_t n_tiles, int32_t n_samples, const uint64_t* bits,
+                                 const int64_t* count_sums, const int32_t* win_tile0, int32_t n_windows, int32_t k,
+                                 kcfx_result* out, hipStream_t st) {
+    if (n_windows <= 0 || n_samples <= 0) return hipSuccess;
+    const int wpb = REDUCE_BLOCK / 64;
+    hipLaunchKernelGGL(reduce_windows_kernel, dim3((n_windows + wpb - 1) / wpb, n_samples), dim3(REDUCE_BLOCK), 0, st, tiles,
+                       n_tiles, bits, count_sums, win_tile0, n_windows, k, out);
     return hipGetLastError();
 }
 
@@ -943,14 +945,6 @@ hipError_t launch_screen_multi(const uint8_t* text, const TileDesc* tiles, int32
     else
         hipLaunchKernelGGL((screen_k31_multi_kernel<false>), dim3(n_tiles), dim3(BLOCK), 0, st, text, tiles, n_tiles, mt,
                            min_count, bits, stride, count_sums);
-    return hipGetLastError();
-}
-
-hipError_t launch_finalize_windows(const TileSummary* tiles, int32_t n_tiles, int32_t n_samples, const int32_t* win_tile0,
-                                   int32_t n_windows, int32_t k, kcfx_result* out, hipStream_t st) {
-    if (n_windows <= 0 || n_samples <= 0) return hipSuccess;
-    hipLaunchKernelGGL(finalize_windows_kernel, dim3((n_windows + 127) / 128, n_samples), dim3(128), 0, st, tiles, n_tiles,
-                       win_tile0, n_windows, k, out);
     return hipGetLastError();
 }
 

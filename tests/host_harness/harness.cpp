@@ -67,7 +67,7 @@ int harness_extract(const uint8_t* text, int64_t text_off, int n_kmers, int k, u
     return 0;
 }
 
-// the screen_tiles_kernel -> summarize_tiles_kernel data flow with counts[j] standing in for the probe result:
+// the screen kernel -> reduce_windows_kernel data flow with counts[j] standing in for the probe result:
 // per 64-position word the valid / hit ballots, then summarize_words (the function the kernel runs per tile)
 int harness_screen_tile(const uint8_t* text, int64_t text_off, int n_kmers, int k, const int32_t* counts,
                         int min_count, TileSummary* out) {
