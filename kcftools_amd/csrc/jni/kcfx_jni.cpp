@@ -66,4 +66,50 @@ JNIEXPORT void JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_screen(JNIEnv* env, 
     if (rc) throw_kcfx(env, rc);
 }
 
+// long refCreate(int device, int k, ByteBuffer text, long[] winBegin, int[] winLen)   -- reference resident for several samples
+JNIEXPORT jlong JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_refCreate(JNIEnv* env, jclass, jint device, jint k, jobject text,
+                                                                       jlongArray winBegin, jintArray winLen) {
+    const auto* t = static_cast<const uint8_t*>(env->GetDirectBufferAddress(text));
+    if (!t) {
+        jclass cls = env->FindClass("java/lang/IllegalArgumentException");
+        if (cls) env->ThrowNew(cls, "text must be a direct buffer");
+        return 0;
+    }
+    const jlong tlen = env->GetDirectBufferCapacity(text);
+    const jsize n = env->GetArrayLength(winLen);
+    jlong* wb = env->GetLongArrayElements(winBegin, nullptr);
+    jint* wl = env->GetIntArrayElements(winLen, nullptr);
+    kcfx_ref* ref = nullptr;
+    const int32_t rc = kcfx_ref_create(device, k, t, tlen, reinterpret_cast<const int64_t*>(wb),
+                                       reinterpret_cast<const int32_t*>(wl), n, &ref);
+    env->ReleaseLongArrayElements(winBegin, wb, JNI_ABORT);
+    env->ReleaseIntArrayElements(winLen, wl, JNI_ABORT);
+    if (rc) { throw_kcfx(env, rc); return 0; }
+    return reinterpret_cast<jlong>(ref);
+}
+
+JNIEXPORT void JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_refDestroy(JNIEnv*, jclass, jlong ref) {
+    kcfx_ref_destroy(reinterpret_cast<kcfx_ref*>(ref));
+}
+
+// void screenRefMulti(long[] dbs, long ref, int minKmerCount, ByteBuffer results)
+// results: dbs.length * nWindows * 40 bytes, sample-major -- what S getVariations runs + cohort produce (Cohort.java:71-119)
+JNIEXPORT void JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_screenRefMulti(JNIEnv* env, jclass, jlongArray dbs, jlong ref,
+                                                                            jint minKmerCount, jobject results) {
+    auto* r = reinterpret_cast<kcfx_ref*>(ref);
+    auto* out = static_cast<kcfx_result*>(env->GetDirectBufferAddress(results));
+    const jsize s = env->GetArrayLength(dbs);
+    const jlong need = (jlong)s * (jlong)kcfx_ref_n_windows(r) * (jlong)sizeof(kcfx_result);
+    if (!out || env->GetDirectBufferCapacity(results) < need) {
+        jclass cls = env->FindClass("java/lang/IllegalArgumentException");
+        if (cls) env->ThrowNew(cls, "results must be a direct buffer of dbs.length * nWindows * 40 bytes");
+        return;
+    }
+    jlong* h = env->GetLongArrayElements(dbs, nullptr);
+    static_assert(sizeof(jlong) == sizeof(kcfx_db*), "handles cross as jlong");
+    const int32_t rc = kcfx_screen_ref_multi(reinterpret_cast<kcfx_db* const*>(h), s, r, minKmerCount, out);
+    env->ReleaseLongArrayElements(dbs, h, JNI_ABORT);
+    if (rc) throw_kcfx(env, rc);
+}
+
 }  // extern "C"
