@@ -120,3 +120,48 @@ def test_gene_model_windows_end_to_end(oracle, genome):
         st = [int(r[1]) for r in rows if r[0] == c]
         assert st == sorted(st)
     print(f"getVariations -f gene on 119 Mb / {len(rows)} genes: {wall:.1f} s wall (FASTA + GTF parse, DB load, screen, KCF write)")
+
+
+def test_eight_samples_in_one_pass(oracle, genome):
+    """configs[3] shape: the 119 Mb genome tiled at 10 kb against 8 resident sample databases, one pass over the reference
+    per step (kcfx_screen_ref_multi) -- 12 k windows x 8 samples. Every slice must equal the single-sample pass; two
+    samples are also sampled against the oracle; then the same through the command-line driver for three of them."""
+    prefixes = [genome["prefix"]]
+    for seed in range(11, 18):
+        pfx = os.path.join(genome["dir"], f"s{seed}")
+        subprocess.run([SYNTH, "--out", pfx, "--contig-lens", ",".join(map(str, LENS)), "--seed", "3", "--sample-seed", str(seed),
+                        "--noise", "1000000"], check=True, capture_output=True, text=True)
+        prefixes.append(pfx)
+    dbs = [genome["db"]] + [engine.KmcDb.open(p) for p in prefixes[1:]]
+    assert all(d.info.total_kmers > 90_000_000 for d in dbs)
+    text = genome["text"]
+    wb, wl = tiling(10_000)
+    ref = engine.Reference(text, wb, wl, K)
+    t0 = time.time()
+    got = ref.screen_multi(dbs, 1)
+    wall = time.time() - t0
+    assert got.shape == (8, len(wb))
+    for s, db in enumerate(dbs):
+        single = ref.screen(db, 1)
+        for f in FIELDS:
+            assert np.array_equal(got[s][f], single[f]), (s, f)
+    assert len({int(got[s]["obs"].sum()) for s in range(8)}) == 8          # eight different samples
+    rng = np.random.default_rng(5)
+    for s in (3, 7):
+        odb = oracle.OracleDb(prefixes[s])
+        idx = rng.choice(len(wb), 40, replace=False)
+        want = odb.screen(text, wb[idx], wl[idx], 1, threads=16)
+        for f in FIELDS:
+            assert np.array_equal(got[s][f][idx], want[f]), (s, f)
+    n_kmers = int(got["total_kmers"].sum())
+    print(f"8 samples x {len(wb)} windows = {n_kmers / 1e9:.2f} G k-mer probes in {wall * 1e3:.1f} ms (host call, results copied back)")
+    # the command-line driver on three of them: one multi-sample KCF, rows = windows, 3 sample columns
+    out = os.path.join(genome["dir"], "cohort.kcf")
+    p = subprocess.run([CLI, "getVariations", "-r", genome["prefix"] + ".fa", "-k", ",".join(prefixes[:3]), "-o", out,
+                        "-s", "A,B,C", "-f", "window", "-w", "10000"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout[-2000:]
+    rows = [l.rstrip("\n").split("\t") for l in open(out) if not l.startswith("#")]
+    assert len(rows) == len(wb) and all(len(r) == 7 + 3 for r in rows)
+    for s in range(3):
+        obs_col = np.array([int(r[7 + s].split(":")[2]) for r in rows])
+        assert np.array_equal(np.sort(obs_col), np.sort(got[s]["obs"]))
