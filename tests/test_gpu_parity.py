@@ -341,3 +341,43 @@ def test_multi_sample_pass_equals_single_sample_passes(oracle, tmp_path):
     assert r.screen_multi([], 1).shape == (0, len(s))
     with pytest.raises(engine.KcfxError):
         r.screen_multi(dbs[:2], 0)
+
+
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_window_geometry_against_oracle(oracle, tmp_path, seed, generic, monkeypatch):
+    """Random databases x windows whose lengths sit on the kernel's internal borders (k-mer count 0 / 1 / 63 / 64 / 65,
+    one tile +-1, several tiles +-1, word-aligned and not), random offsets (every alignment of the 32-base pack chunks),
+    N runs crossing window and tile borders, soft-masked stretches. k = 31 runs screen_k31_kernel (or, forced, the general
+    screen_tiles_kernel); both strandedness and all counter widths come up over the seeds."""
+    if generic:
+        monkeypatch.setenv("KCFX_GENERIC_KERNEL", "1")
+    rng = np.random.default_rng(1000 + seed)
+    k = 31
+    L = 180_000
+    ref = bytearray(synth.random_reference(L, 500 + seed))
+    for _ in range(25):
+        pos = int(rng.integers(0, L - 3000))
+        n = int(rng.choice([1, 2, 30, 31, 32, 64, 500, 2500]))
+        ref[pos:pos + n] = b"N" * n
+    for _ in range(10):
+        pos = int(rng.integers(0, L - 3000))
+        ref[pos:pos + 700] = bytes(ref[pos:pos + 700]).lower()
+    ref = bytes(ref)
+    cs = int(rng.choice([1, 2, 4]))
+    both = bool(rng.integers(0, 2))
+    prefix, *_ = make_db(tmp_path, "fz", ref, 300 + seed, k=k, p=int(rng.choice([3, 7])), cs=cs, m=7, bins=4, both=both,
+                         noise=5_000)
+    db = engine.KmcDb.open(prefix)
+    odb = oracle.OracleDb(prefix)
+    tile = 2048
+    kmers = [0, 1, 2, 62, 63, 64, 65, 127, 128, 129, tile - 1, tile, tile + 1, tile + 63, tile + 64, 2 * tile - 1, 2 * tile,
+             2 * tile + 1, 3 * tile + 17, 5 * tile, 9970, 20_000]
+    lens = [max(0, n + k - 1) for n in kmers] + [0, 5, k - 1] + [int(x) for x in rng.integers(1, 30_000, 40)]
+    begins = [int(rng.integers(0, L - ln + 1)) for ln in lens]
+    begins = np.array(begins, dtype=np.int64)
+    lens = np.array(lens, dtype=np.int32)
+    got = db.screen(ref, begins, lens, 1)
+    want = odb.screen(ref, begins, lens, 1, threads=4)
+    assert_same(got, want, f"fuzz seed {seed} (cs={cs}, both={both})")
+    assert_scores(oracle, got, want)
