@@ -10,6 +10,7 @@
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off, no dependencies besides pthread).
  */
 #define _FILE_OFFSET_BITS 64
+#define _POSIX_C_SOURCE 200809L   /* fseeko / ftello under -std=c11: without the prototype they return int and a .kmc_suf over 2 GiB looks truncated */
 #include "kcf_oracle.h"
 
 #include <pthread.h>
