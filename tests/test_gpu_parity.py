@@ -344,7 +344,7 @@ def test_multi_sample_pass_equals_single_sample_passes(oracle, tmp_path):
 
 
 @pytest.mark.parametrize("generic", [False, True])
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("KCFX_FUZZ_SEEDS", "6"))))   # soak: KCFX_FUZZ_SEEDS=200
 def test_fuzz_window_geometry_against_oracle(oracle, tmp_path, seed, generic, monkeypatch):
     """Random databases x windows whose lengths sit on the kernel's internal borders (k-mer count 0 / 1 / 63 / 64 / 65,
     one tile +-1, several tiles +-1, word-aligned and not), random offsets (every alignment of the 32-base pack chunks),
