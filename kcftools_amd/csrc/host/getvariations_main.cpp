@@ -12,6 +12,7 @@
 #include <ctime>
 #include <fstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/kcfx.h"
@@ -44,14 +45,15 @@ void warning(const std::string& m) { log_line("WARNING", m); }
 
 struct Options {
     std::string ref, kmc, out, sample, feature, gtf;
-    int threads = 2, window = 0, min_count = 1, step = 0, device = 0;
+    int threads = 2, window = 0, min_count = 1, step = 0;
+    std::vector<int> devices{0};          // --device N | --devices a,b,...: samples are sharded over them
     bool memory = false;
     double wi = 0.3, wt = 0.3, wr = 0.4;
 };
 
 void usage() {
     std::puts("Usage: kcftools-amd getVariations -r <ref.fa> -k <kmc prefix> -o <out.kcf> -s <sample> -f window|gene|transcript\n"
-              "       [-w window] [-p step] [-g gtf] [-c min-k-count] [--wi 0.3] [--wt 0.3] [--wr 0.4] [-t threads] [-m] [--device 0]");
+              "       [-w window] [-p step] [-g gtf] [-c min-k-count] [--wi 0.3] [--wt 0.3] [--wr 0.4] [-t threads] [-m] [--device 0 | --devices 0,1,...]");
 }
 
 std::vector<std::string> split_commas(const std::string& v) {
@@ -104,7 +106,11 @@ int main(int argc, char** argv) {
         else if (a == "-g" || a == "--gtf") o.gtf = val();
         else if (a == "-c" || a == "--min-k-count") o.min_count = std::atoi(val().c_str());
         else if (a == "-p" || a == "--step") o.step = std::atoi(val().c_str());
-        else if (a == "--device") o.device = std::atoi(val().c_str());
+        else if (a == "--device" || a == "--devices") {
+            o.devices.clear();
+            for (const auto& d : split_commas(val())) o.devices.push_back(std::atoi(d.c_str()));
+            if (o.devices.empty()) o.devices.push_back(0);
+        }
         else if (a == "-h" || a == "--help") { usage(); return 0; }
         else error("Unknown option: " + a);
     }
@@ -142,12 +148,12 @@ int main(int argc, char** argv) {
 
     // new KMC(prefix, loadMemory) (:95)
     kcfx_db* db = nullptr;
-    if (kcfx_db_open(kmc_list[0].c_str(), o.device, &db)) error(kcfx_last_error());
+    if (kcfx_db_open(kmc_list[0].c_str(), o.devices[0], &db)) error(kcfx_last_error());
     kcfx_db_info_t dbi;
     kcfx_db_info(db, &dbi);
     const int k = dbi.kmer_length;
     info("KMC database: k=" + std::to_string(k) + ", " + std::to_string(dbi.total_kmers) + " k-mers, table " +
-         std::to_string(dbi.table_bytes >> 20) + " MiB on device " + std::to_string(o.device));
+         std::to_string(dbi.table_bytes >> 20) + " MiB on device " + std::to_string(o.devices[0]));
 
     FastaIndex index;
     std::string err;
@@ -230,40 +236,55 @@ int main(int argc, char** argv) {
         wb[(size_t)i] = wins[(size_t)i].text_begin;
         wl[(size_t)i] = wins[(size_t)i].text_len;
     }
-    // reference text + windows resident in HBM once; the samples are screened in batches of up to 8 resident databases,
-    // one pass over the reference per batch (kcfx_screen_ref_multi; a single sample is a batch of one)
+    // Reference text + windows resident in HBM once per device; the samples are sharded over the devices (sample s on
+    // device s mod G: independent units, no exchange -- SURVEY 8 e) and screened in batches of up to 8 resident
+    // databases, one pass over the reference per batch (kcfx_screen_ref_multi; a single sample is a batch of one).
     const size_t S = kmc_list.size();
-    kcfx_ref* ref = nullptr;
-    if (kcfx_ref_create(o.device, k, reinterpret_cast<const uint8_t*>(text.data()), (int64_t)text.size(), wb.data(), wl.data(), n, &ref))
-        error(kcfx_last_error());
+    const size_t G = std::min(o.devices.size(), S);
     std::vector<std::vector<kcfx_result>> res(S, std::vector<kcfx_result>((size_t)n));
     std::vector<std::vector<double>> score(S, std::vector<double>((size_t)n)), depth(S, std::vector<double>((size_t)n));
-    constexpr size_t BATCH = 8;
-    std::vector<kcfx_result> batch_res;
-    for (size_t s0 = 0; s0 < S; s0 += BATCH) {
-        const size_t nb = std::min(BATCH, S - s0);
-        std::vector<kcfx_db*> dbs(nb, nullptr);
-        for (size_t b = 0; b < nb; ++b) {
-            if (s0 + b == 0) {
-                dbs[b] = db;                                                             // opened above for the header
-                continue;
+    auto worker = [&](size_t g) {
+        const int device = o.devices[g];
+        std::vector<size_t> mine;
+        for (size_t s = g; s < S; s += G) mine.push_back(s);
+        kcfx_ref* ref = nullptr;
+        if (kcfx_ref_create(device, k, reinterpret_cast<const uint8_t*>(text.data()), (int64_t)text.size(), wb.data(), wl.data(), n, &ref))
+            error(kcfx_last_error());
+        constexpr size_t BATCH = 8;
+        std::vector<kcfx_result> batch_res;
+        for (size_t i0 = 0; i0 < mine.size(); i0 += BATCH) {
+            const size_t nb = std::min(BATCH, mine.size() - i0);
+            std::vector<kcfx_db*> dbs(nb, nullptr);
+            for (size_t b = 0; b < nb; ++b) {
+                const size_t s = mine[i0 + b];
+                if (s == 0) {
+                    dbs[b] = db;                                                         // opened above for the header
+                    continue;
+                }
+                if (kcfx_db_open(kmc_list[s].c_str(), device, &dbs[b])) error(kcfx_last_error());
+                kcfx_db_info_t di;
+                kcfx_db_info(dbs[b], &di);
+                if (di.kmer_length != k) error("Kmer size mismatch between the KMC databases");  // KCFHeader.equals (cohort)
             }
-            if (kcfx_db_open(kmc_list[s0 + b].c_str(), o.device, &dbs[b])) error(kcfx_last_error());
-            kcfx_db_info_t di;
-            kcfx_db_info(dbs[b], &di);
-            if (di.kmer_length != k) error("Kmer size mismatch between the KMC databases");      // KCFHeader.equals (cohort)
+            batch_res.resize(nb * (size_t)n);
+            if (kcfx_screen_ref_multi(dbs.data(), (int32_t)nb, ref, o.min_count, batch_res.data())) error(kcfx_last_error());
+            for (size_t b = 0; b < nb; ++b) {
+                const size_t s = mine[i0 + b];
+                std::copy(batch_res.begin() + (ptrdiff_t)(b * (size_t)n), batch_res.begin() + (ptrdiff_t)((b + 1) * (size_t)n), res[s].begin());
+                if (kcfx_score(res[s].data(), n, o.wi, o.wt, o.wr, score[s].data(), depth[s].data())) error(kcfx_last_error());   // Data.java:101-103
+                kcfx_db_close(dbs[b]);
+            }
         }
-        batch_res.resize(nb * (size_t)n);
-        if (kcfx_screen_ref_multi(dbs.data(), (int32_t)nb, ref, o.min_count, batch_res.data())) error(kcfx_last_error());
-        for (size_t b = 0; b < nb; ++b) {
-            const size_t s = s0 + b;
-            std::copy(batch_res.begin() + (ptrdiff_t)(b * (size_t)n), batch_res.begin() + (ptrdiff_t)((b + 1) * (size_t)n), res[s].begin());
-            if (kcfx_score(res[s].data(), n, o.wi, o.wt, o.wr, score[s].data(), depth[s].data())) error(kcfx_last_error());   // Data.java:101-103
-            kcfx_db_close(dbs[b]);
-        }
+        kcfx_ref_destroy(ref);
+    };
+    if (G <= 1) {
+        worker(0);
+    } else {
+        std::vector<std::thread> th;
+        for (size_t g = 0; g < G; ++g) th.emplace_back(worker, g);
+        for (auto& t : th) t.join();
     }
     db = nullptr;
-    kcfx_ref_destroy(ref);
 
     // sort each contig's windows by start (:169-171); ties keep generation order
     hdr.n_windows = n;

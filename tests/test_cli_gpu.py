@@ -140,3 +140,20 @@ def test_multi_sample_equals_cohort_of_single_sample_runs(oracle, tmp_path):
     assert "\t".join(singles[0][2]) == pyhost.kcf_row(ent[0], int(s[2]), int(e[2]), f"{ent[0]}_{s[2]}", res, sc, md)
     log = run_cli(["-r", fa, "-k", os.path.join(G, dbs[0]), "-o", out, "-s", "A,B", "-f", "window", "-w", "3000"], expect_rc=1)
     assert "differ" in log
+
+
+def test_samples_sharded_over_devices_give_the_same_file(tmp_path):
+    """`--devices a,b,...` shards the samples over GPUs (sample s on device s mod G, one worker thread each, own resident
+    reference, no exchange). A one-GPU box can only check the threading: `--devices 0,0,0` runs three workers against the
+    same GPU concurrently and must write byte-identical output (header lines with the command line aside)."""
+    fa = str(tmp_path / "ref.fa")
+    shutil.copy(os.path.join(G, "ref.fa"), fa)
+    dbs = ["db_canon_k31_p3_cs2_m9", "db_fwd_k31_p7_cs1_m7", "db_canon_k31_p3_cs2_m9", "db_fwd_k31_p7_cs1_m7",
+           "db_canon_k31_p3_cs2_m9"]
+    k = ",".join(os.path.join(G, d) for d in dbs)
+    outs = []
+    for i, dev in enumerate((["--device", "0"], ["--devices", "0,0,0"], ["--devices", "0,0"])):
+        out = str(tmp_path / f"m{i}.kcf")
+        run_cli(["-r", fa, "-k", k, "-o", out, "-s", "A,B,C,D,E", "-f", "window", "-w", "3000"] + dev)
+        outs.append([l for l in open(out) if not l.startswith("##CMD") and not l.startswith("##date") and not l.startswith("##fileDate")])
+    assert outs[0] == outs[1] == outs[2] and sum(1 for l in outs[0] if not l.startswith("#")) > 10
