@@ -165,3 +165,35 @@ def test_eight_samples_in_one_pass(oracle, genome):
     for s in range(3):
         obs_col = np.array([int(r[7 + s].split(":")[2]) for r in rows])
         assert np.array_equal(np.sort(obs_col), np.sort(got[s]["obs"]))
+
+
+@pytest.mark.skipif(not os.environ.get("KCFX_HUGE"), reason="wheat-scale run (configs[4] reference size): KCFX_HUGE=<bases>, e.g. 14.5e9")
+def test_wheat_scale_reference(oracle, genome):
+    """configs[4] shape on the reference side: a KCFX_HUGE-base text (the 119 Mb genome repeated with 0.5 % point mutations),
+    50 kb tiling windows (290 k for 14.5 Gb), against the 150 M-k-mer database; sampled windows against the oracle.
+    Measured on an MI355X: 14.5 Gb -> 4.4 s upload, 103 ms per screening call = 139 G k-mers/s."""
+    L = int(float(os.environ["KCFX_HUGE"]))
+    rng = np.random.default_rng(7)
+    base = np.frombuffer(genome["text"], dtype=np.uint8)
+    text = np.tile(base, (L + len(base) - 1) // len(base))[:L].copy()
+    pos = rng.integers(0, L, size=L // 200)
+    text[pos] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=len(pos))]
+    W = 50_000
+    starts = np.arange(0, L - K + 1, W - K + 1, dtype=np.int64)
+    lens = np.minimum(W, L - starts).astype(np.int32)
+    starts, lens = starts[lens >= K], lens[lens >= K]
+    ref = engine.Reference(text.tobytes(), starts, lens, K)
+    t0 = time.time()
+    res = ref.screen(genome["db"], 1)
+    wall = time.time() - t0
+    n = int(res["total_kmers"].sum())
+    assert n > 0.95 * L
+    odb = oracle.OracleDb(genome["prefix"])
+    idx = np.concatenate([rng.choice(len(starts), 40, replace=False), [0, len(starts) - 1]])
+    tb = memoryview(text)
+    for i in idx:
+        w = bytes(tb[int(starts[i]):int(starts[i]) + int(lens[i])])
+        want = odb.screen(w, np.array([0], dtype=np.int64), np.array([len(w)], dtype=np.int32), 1)
+        for f in FIELDS:
+            assert want[f][0] == res[f][i], (i, f)
+    print(f"{L / 1e9:.1f} Gb reference, {len(starts)} windows: {n / 1e9:.2f} G k-mers in {wall * 1e3:.1f} ms")
