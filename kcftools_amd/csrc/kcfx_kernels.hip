@@ -170,19 +170,11 @@ __global__ __launch_bounds__(256) void lookup_kernel(TableView tv, int32_t k, co
 }
 
 // ======================================================================================================
-// screen_tiles
+// screening: wave-level helpers
 // ======================================================================================================
 constexpr int MAX_CHUNKS = (31 + TILE_K + 31 + 31) / 32 + 1;   // 32-base chunks a tile can span
-constexpr int RUN_CHUNK = 16;                                  // line buffers per wave (2 load instructions)
-constexpr int LINE_STRIDE = 9;                                 // uint4 per buffered line: 8 + 1 pad => the 16 lines of a
-                                                               // chunk start on distinct LDS banks (36 r mod 64)
 constexpr int WAVES = BLOCK / 64;
 
-__device__ __forceinline__ int32_t wave_sum_i32(int32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
 __device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -214,6 +206,108 @@ __device__ __forceinline__ void wave_lds_fence() {
     asm volatile("" ::: "memory");
 }
 
+// ======================================================================================================
+// the probe: KMC.getCount for the 64 k-mers of one word (shared by all screening kernels)
+// ======================================================================================================
+// LDS-DMA puts lane i's 16 bytes at base + 16 i. Nine lanes per run, the ninth idle, leave a 16-byte hole after every
+// line: lines start 144 bytes apart, on distinct LDS banks for the match reads (a 128-byte pitch costs 4x the bank
+// conflict cycles, SQ_LDS_BANK_CONFLICT). 7 runs per instruction, 2 instructions per chunk.
+constexpr int K31_RUNS = 14;
+constexpr int K31_PITCH = 9;                                   // uint4 per buffered line
+
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t x) {     // lane l gets lane l-1's value, lane 0 gets 0 (bound_ctrl)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, true);
+}
+
+
+// Per-lane constants of the cooperative line fetch
+struct K31Fetch {
+    int fetch_run;        // lane / 9: the run (0..6, 7 = idle) this lane fetches for
+    int piece;            // its 16-byte piece of the line (8 = idle)
+    bool fetcher;
+    uint4* lines;         // this wave's line buffers (2 x 63 uint4)
+    uint32_t* runline;    // this wave's run -> line index list (65 entries)
+};
+
+// KMC.getCount for the 64 k-mers of one word against one table: `key` (canonical word), `home` (first line to look at), `V`
+// (ballot of valid k-mers). Returns the stored counter, 0 when absent / invalid.
+// Cooperative probe rounds: each round fetches, for every run of adjacent pending lanes with the same target line, that
+// line ONCE (8 lanes x 16 B = one 128-byte request, LDS-DMA) into wave-private LDS, then every lane compares its key
+// against its run's line. Probe state lives in VGPR integers and is updated with selects (see screen_tiles_kernel).
+// CHECK_NS: k = 32 (the all-ones word is a k-mer, see match_line); MINI: minimizer table (HEAVY homes exist).
+template <bool WIDE, bool CHECK_NS, bool MINI>
+__device__ __forceinline__ uint32_t probe_word(const TableView& tv, const K31Fetch& f, int lane, uint64_t key,
+                                               uint32_t home, uint64_t V) {
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    uint32_t tgt = home;                                    // minimizer tables: shared by the whole minimizer run
+    uint32_t st = (uint32_t)((V >> lane) & 1);              // 1 = pending, 2 = found, 0 = absent / invalid
+    uint32_t cnt = 0;
+    uint32_t hm = 0;                                        // meta dword of the line matched last
+    for (int round = 0;; ++round) {
+        const uint64_t PM = wave_ballot(st == 1u);
+        if (!PM) break;
+        if (MINI && round == 1) {
+            // HEAVY minimizer home (table_finalize also sets its overflow bit, so such lanes are still pending):
+            // every k-mer homed there by minimizer lives at its key-hash line instead -- jump, do not walk
+            const uint64_t RM = PM & wave_ballot((hm & META_HEAVY) != 0u);
+            if (RM) {
+                // rare: keep the key hash (three multiplies) from being hoisted into every word
+                uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+                asm volatile("" : "+v"(klo), "+v"(khi));
+                if ((RM >> lane) & 1) tgt = keyhash_line(tv, u64_of(klo, khi));
+            }
+        }
+        // heads of runs: pending lanes whose predecessor is not pending or aims at another line
+        const uint64_t HM = PM & (wave_ballot(wave_shr1(st) != 1u) | wave_ballot(wave_shr1(tgt) != tgt));
+        const int nruns = __popcll(HM);
+        // index of this lane's run = heads at or below it, minus one
+        const uint64_t H1 = HM >> 1;
+        const int my_run = (int)__builtin_amdgcn_mbcnt_hi(
+            (uint32_t)(H1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)H1, (uint32_t)((int)(HM & 1) - 1)));
+        // every pending lane stores its run's line index (same value within a run); the others hit a dummy slot
+        f.runline[(st == 1u) ? my_run : 64] = tgt;
+        wave_lds_fence();
+        for (int c0 = 0; c0 < nruns; c0 += K31_RUNS) {
+            const int r0 = c0 + f.fetch_run, r1 = r0 + 7;
+            // 8 lanes x 16 B = one 128-byte request per run
+            if (f.fetcher && r0 < nruns)
+                __builtin_amdgcn_global_load_lds((gptr_t)(tv.lines + (size_t)f.runline[r0] * LINE_BYTES + 16 * f.piece),
+                                                 (lptr_t)f.lines, 16, 0, 0);
+            if (f.fetcher && r1 < nruns)
+                __builtin_amdgcn_global_load_lds((gptr_t)(tv.lines + (size_t)f.runline[r1] * LINE_BYTES + 16 * f.piece),
+                                                 (lptr_t)(f.lines + 7 * K31_PITCH), 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_lds_fence();
+            // every lane matches (idle lanes against buffer 0); the outcome is merged with selects
+            const uint32_t rel = (uint32_t)(my_run - c0);
+            const bool mine = (st == 1u) && (rel < (uint32_t)K31_RUNS);
+            const uint4* src = f.lines + (mine ? rel : 0u) * K31_PITCH;
+            uint32_t c, meta;
+            const bool any = match_line_lds<WIDE, CHECK_NS>(src, key, c, meta);
+            const uint32_t ov = (meta >> 8) & 1u;                       // overflowed line: look at the next one
+            const uint32_t nst = any ? 2u : ov;
+            const uint32_t ntgt = (tgt + 1 == tv.n_lines) ? 0u : tgt + 1;
+            cnt = (mine && any) ? c : cnt;                              // Java int (KMC.java:395-401)
+            tgt = (mine && nst == 1u) ? ntgt : tgt;
+            hm = mine ? meta : hm;
+            st = mine ? nst : st;
+            wave_lds_fence();
+        }
+    }
+    return cnt;
+}
+
+__device__ __forceinline__ K31Fetch fetch_setup(uint4* lines, uint32_t* runline, int lane) {
+    K31Fetch f;
+    f.fetch_run = (lane * 57) >> 9;
+    f.piece = lane - 9 * f.fetch_run;
+    f.fetcher = f.piece < 8 && f.fetch_run < 7;
+    f.lines = lines;
+    f.runline = runline;
+    return f;
+}
+
 // The general kernel: any k <= 32, any minimizer length, both table modes. The BASELINE.json configuration
 // (k = 31, M = 16, minimizer table) runs screen_k31_kernel below instead; KCFX_GENERIC_KERNEL=1 forces this one.
 template <bool WIDE, int MODE>
@@ -223,7 +317,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                                                              uint64_t* __restrict__ bits,
                                                              int64_t* __restrict__ count_sums) {
     constexpr bool MINI = (MODE == MODE_MINIMIZER);
-    constexpr int LINEBUF_U32 = WAVES * RUN_CHUNK * LINE_STRIDE * 4;
+    constexpr int LINEBUF_U32 = WAVES * (2 * 64) * 4;      // per wave: 2 DMA instructions x 64 lanes x 16 B
     // s_ha: M-mer hashes, then prefix minima, then (dead) the fetched table lines; s_hb: suffix minima, then minimizers
     constexpr int HMIN = TILE_K + 96;                      // + (wlen - 1) + padding of the last block (wlen <= 32)
     constexpr int HBIG = HMIN > LINEBUF_U32 ? HMIN : LINEBUF_U32;
@@ -271,7 +365,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     //      running prefix minima (in place) and suffix minima; window [p, p+wlen-1] = min(suffix[p], prefix[p+wlen-1]).
     //      The result lands in s_hb; s_ha is dead afterwards and holds the fetched table lines. -----------------------
     const uint32_t* s_fin = s_hb;                          // minimizer (minimum hash) of the k-mer at each position
-    uint4* s_line = reinterpret_cast<uint4*>(s_ha);        // [WAVES][RUN_CHUNK][LINE_STRIDE] fetched lines
+    uint4* s_line = reinterpret_cast<uint4*>(s_ha);        // [WAVES][2 * 64] fetched lines (LDS-DMA layout, K31Fetch)
     if (MINI) {
         const int n_m = td.n_kmers + wlen - 1;             // every M-mer of every k-mer of the tile
         const int n_blk = (n_m + wlen - 1) / wlen;
@@ -310,9 +404,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const int wpw = (n_words + WAVES - 1) / WAVES;
     const int w_begin = min(wave * wpw, n_words);
     const int w_end = min(w_begin + wpw, n_words);
-    const uint64_t lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1);   // bits 0..lane
-    const uint64_t lane_prev = lane ? (1ull << (lane - 1)) : 0ull;           // bit lane-1
-    uint4* my_lines = s_line + wave * (RUN_CHUNK * LINE_STRIDE);
+    const K31Fetch fetch = fetch_setup(s_line + wave * (2 * 64), s_runline[wave], lane);
 
     int64_t sum_acc = 0;                                   // per lane
     uint64_t* my_bits = bits + (size_t)blockIdx.x * TILE_BITS_U64;
@@ -321,84 +413,21 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         const int j = w * 64 + lane;
         const int jc = min(j, td.n_kmers - 1);
         uint64_t fwd, rc;
-        bool valid = extract_kmer(s_fw, s_cw, s_vb, off + jc, k, fwd, rc);
-        valid = valid && (j < td.n_kmers);
+        const bool ok = extract_kmer(s_fw, s_cw, s_vb, off + jc, k, fwd, rc);
+        const uint64_t V = wave_ballot(ok) & wave_ballot(j < td.n_kmers);
         // Kmer(Kmer, bothStrands): canonical = min(fwd, revcomp) unsigned (Kmer.java:72-79,406-414)
         const uint64_t key = (both_strands && rc < fwd) ? rc : fwd;
-
-        // home line: shared by the whole minimizer run this k-mer belongs to
-        uint32_t tgt;
-        if (MINI) {
-            tgt = line_of_minimizer(s_fin[jc], tv.n_lines);
-        } else {
-            tgt = mulhi32(hash32(key), tv.n_lines);
-        }
-
-        // Probe state lives in VGPR integers and is updated with selects: lane-varying bools carried through the
-        // loops would be kept as SGPR masks and cost three scalar instructions per update and block.
-        uint32_t st = valid ? 1u : 0u;          // 1 = pending, 2 = found, 0 = absent / invalid
-        uint32_t cnt = 0;
-        uint32_t home_meta = 0;                 // meta dword of the line matched last (HEAVY check after round 0)
-        // ---- cooperative probe rounds: each round fetches, for every run of adjacent pending lanes with the same
-        //      target line, that line ONCE (8 lanes x 16 B = one 128-byte request) into wave-private LDS -------------
-        for (int round = 0;; ++round) {
-            const uint64_t P = wave_ballot(st == 1u);
-            if (!P) break;
-            if (MINI && round == 1) {
-                // HEAVY minimizer home (table_finalize also sets its overflow bit, so such lanes are still pending):
-                // every k-mer homed there by minimizer lives at its key-hash line instead -- jump, do not walk
-                const bool redirect = (st == 1u) && (home_meta & META_HEAVY);
-                if (wave_ballot(redirect)) {
-                    if (redirect) tgt = keyhash_line(tv, key);
-                }
-            }
-            const uint32_t prev_tgt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tgt, 0x138, 0xf, 0xf, false);   // wave_shr:1
-            const bool prev_pend = (P & lane_prev) != 0;
-            const bool head = (st == 1u) && (!prev_pend || prev_tgt != tgt);
-            const uint64_t HM = wave_ballot(head);
-            const int nruns = __popcll(HM);
-            const int my_run = __popcll(HM & lane_le) - 1;
-            // every pending lane stores its run's line index (same value within a run); the others hit a dummy slot
-            s_runline[wave][(st == 1u) ? my_run : 64] = tgt;
-            wave_lds_fence();
-            for (int c0 = 0; c0 < nruns; c0 += RUN_CHUNK) {
-                const int r0 = c0 + (lane >> 3), r1 = r0 + 8;
-                const int piece = lane & 7;
-                uint4 a, b;
-                if (r0 < nruns)
-                    a = reinterpret_cast<const uint4*>(tv.lines + (size_t)s_runline[wave][r0] * LINE_BYTES)[piece];
-                if (r1 < nruns)
-                    b = reinterpret_cast<const uint4*>(tv.lines + (size_t)s_runline[wave][r1] * LINE_BYTES)[piece];
-                my_lines[(lane >> 3) * LINE_STRIDE + piece] = a;
-                my_lines[(8 + (lane >> 3)) * LINE_STRIDE + piece] = b;
-                wave_lds_fence();
-                // every lane matches (idle lanes against buffer 0); the outcome is merged with selects
-                const uint32_t rel = (uint32_t)(my_run - c0);
-                const bool mine = (st == 1u) && (rel < (uint32_t)RUN_CHUNK);
-                const uint4* src = my_lines + (mine ? rel : 0u) * LINE_STRIDE;
-                uint32_t c, meta;
-                const bool any = match_line_lds<WIDE, true>(src, key, c, meta);
-                const uint32_t ov = (meta >> 8) & 1u;                       // overflowed line: look at the next one
-                const uint32_t nst = any ? 2u : ov;
-                const uint32_t ntgt = (tgt + 1 == tv.n_lines) ? 0u : tgt + 1;
-                cnt = (mine && any) ? c : cnt;                              // Java int (KMC.java:395-401)
-                tgt = (mine && nst == 1u) ? ntgt : tgt;
-                home_meta = mine ? meta : home_meta;
-                st = mine ? nst : st;
-                wave_lds_fence();
-            }
-        }
-        const bool found = (st == 2u);
-        const bool hit = found && ((int32_t)cnt >= min_count);   // GetVariants.java:224
-
-        // this word of the window's hit bitmap (reduced by reduce_windows_kernel)
-        const uint64_t V = wave_ballot(valid);
+        // first line to look at: the minimizer's (shared by the whole run this k-mer belongs to) or the key's own
+        const uint32_t home = MINI ? line_of_minimizer(s_fin[jc], tv.n_lines) : keyhash_line(tv, key);
+        const uint32_t cnt = probe_word<WIDE, true, MINI>(tv, fetch, lane, key, home, V);
+        // cnt is 0 unless the k-mer was found and min_count >= 1 (checked by the API), so this is "found && count >= -c"
+        const bool hit = (int32_t)cnt >= min_count;              // GetVariants.java:224
         const uint64_t H = wave_ballot(hit);
-        if (lane == 0) {
+        if (lane == 0) {                                         // this word of the window's hit bitmap
             my_bits[w] = V;
             my_bits[TILE_WORDS + w] = H;
         }
-        if (hit) sum_acc += (int64_t)(int32_t)cnt;                 // GetVariants.java:226
+        sum_acc += hit ? (int64_t)(int32_t)cnt : 0;              // GetVariants.java:226
     }
 
     const int64_t count_sum = wave_sum_i64(sum_acc);
@@ -425,12 +454,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 //   * table lines land in LDS by LDS-DMA (global_load_lds_dwordx4): no destination VGPRs, no ds_write.
 //   * ballots are taken of single compares and combined on the scalar unit (a ballot of a conjunction costs hipcc a
 //     v_cndmask + v_cmp to re-materialise the predicate).
-// LDS-DMA puts lane i's 16 bytes at base + 16 i. Nine lanes per run, the ninth idle, leave a 16-byte hole after every
-// line: lines start 144 bytes apart, on distinct LDS banks for the match reads (a 128-byte pitch costs 4x the bank
-// conflict cycles, SQ_LDS_BANK_CONFLICT). 7 runs per instruction, 2 instructions per chunk.
-constexpr int K31_RUNS = 14;
-constexpr int K31_PITCH = 9;                                   // uint4 per buffered line
-
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_or_ones(uint32_t x) {   // value of the DPP source lane; all ones where there is none
     return (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, CTRL, 0xf, 0xf, false);
@@ -448,87 +471,6 @@ __device__ __forceinline__ void row_scan_min(uint32_t h, uint32_t& P, uint32_t& 
     S = min(S, dpp_or_ones<0x104>(S));
     S = min(S, dpp_or_ones<0x108>(S));
 }
-__device__ __forceinline__ uint32_t wave_shr1(uint32_t x) {     // lane l gets lane l-1's value, lane 0 gets 0 (bound_ctrl)
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, true);
-}
-
-// Per-lane constants of the cooperative line fetch
-struct K31Fetch {
-    int fetch_run;        // lane / 9: the run (0..6, 7 = idle) this lane fetches for
-    int piece;            // its 16-byte piece of the line (8 = idle)
-    bool fetcher;
-    uint4* lines;         // this wave's line buffers (2 x 63 uint4)
-    uint32_t* runline;    // this wave's run -> line index list (65 entries)
-};
-
-// KMC.getCount for the 64 k-mers of one word against one table: `key` (canonical word), `mn` (minimizer), `V` (ballot of
-// valid k-mers). Returns the stored counter, 0 when absent / invalid.
-// Cooperative probe rounds: each round fetches, for every run of adjacent pending lanes with the same target line, that
-// line ONCE (8 lanes x 16 B = one 128-byte request, LDS-DMA) into wave-private LDS, then every lane compares its key
-// against its run's line. Probe state lives in VGPR integers and is updated with selects (see screen_tiles_kernel).
-template <bool WIDE>
-__device__ __forceinline__ uint32_t k31_probe_word(const TableView& tv, const K31Fetch& f, int lane, uint64_t key,
-                                                   uint32_t mn, uint64_t V) {
-    typedef __attribute__((address_space(1))) const void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    uint32_t tgt = line_of_minimizer(mn, tv.n_lines);       // home line, shared by the whole minimizer run
-    uint32_t st = (uint32_t)((V >> lane) & 1);              // 1 = pending, 2 = found, 0 = absent / invalid
-    uint32_t cnt = 0;
-    uint32_t hm = 0;                                        // meta dword of the line matched last
-    for (int round = 0;; ++round) {
-        const uint64_t PM = wave_ballot(st == 1u);
-        if (!PM) break;
-        if (round == 1) {
-            // HEAVY minimizer home (table_finalize also sets its overflow bit, so such lanes are still pending):
-            // every k-mer homed there by minimizer lives at its key-hash line instead -- jump, do not walk
-            const uint64_t RM = PM & wave_ballot((hm & META_HEAVY) != 0u);
-            if (RM) {
-                // rare: keep the key hash (three multiplies) from being hoisted into every word
-                uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
-                asm volatile("" : "+v"(klo), "+v"(khi));
-                if ((RM >> lane) & 1) tgt = keyhash_line(tv, u64_of(klo, khi));
-            }
-        }
-        // heads of runs: pending lanes whose predecessor is not pending or aims at another line
-        const uint64_t HM = PM & (wave_ballot(wave_shr1(st) != 1u) | wave_ballot(wave_shr1(tgt) != tgt));
-        const int nruns = __popcll(HM);
-        // index of this lane's run = heads at or below it, minus one
-        const uint64_t H1 = HM >> 1;
-        const int my_run = (int)__builtin_amdgcn_mbcnt_hi(
-            (uint32_t)(H1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)H1, (uint32_t)((int)(HM & 1) - 1)));
-        // every pending lane stores its run's line index (same value within a run); the others hit a dummy slot
-        f.runline[(st == 1u) ? my_run : 64] = tgt;
-        wave_lds_fence();
-        for (int c0 = 0; c0 < nruns; c0 += K31_RUNS) {
-            const int r0 = c0 + f.fetch_run, r1 = r0 + 7;
-            // 8 lanes x 16 B = one 128-byte request per run
-            if (f.fetcher && r0 < nruns)
-                __builtin_amdgcn_global_load_lds((gptr_t)(tv.lines + (size_t)f.runline[r0] * LINE_BYTES + 16 * f.piece),
-                                                 (lptr_t)f.lines, 16, 0, 0);
-            if (f.fetcher && r1 < nruns)
-                __builtin_amdgcn_global_load_lds((gptr_t)(tv.lines + (size_t)f.runline[r1] * LINE_BYTES + 16 * f.piece),
-                                                 (lptr_t)(f.lines + 7 * K31_PITCH), 16, 0, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            wave_lds_fence();
-            // every lane matches (idle lanes against buffer 0); the outcome is merged with selects
-            const uint32_t rel = (uint32_t)(my_run - c0);
-            const bool mine = (st == 1u) && (rel < (uint32_t)K31_RUNS);
-            const uint4* src = f.lines + (mine ? rel : 0u) * K31_PITCH;
-            uint32_t c, meta;
-            const bool any = match_line_lds<WIDE, false>(src, key, c, meta);
-            const uint32_t ov = (meta >> 8) & 1u;                       // overflowed line: look at the next one
-            const uint32_t nst = any ? 2u : ov;
-            const uint32_t ntgt = (tgt + 1 == tv.n_lines) ? 0u : tgt + 1;
-            cnt = (mine && any) ? c : cnt;                              // Java int (KMC.java:395-401)
-            tgt = (mine && nst == 1u) ? ntgt : tgt;
-            hm = mine ? meta : hm;
-            st = mine ? nst : st;
-            wave_lds_fence();
-        }
-    }
-    return cnt;
-}
-
 // LDS of the k31 kernels: packed code / validity bits of the tile + per-wave line buffers
 struct K31Shared {
     // The word loop reads code bits up to 64 positions past the tile's last k-mer without clamping (what it reads there
@@ -631,16 +573,6 @@ struct K31Words {
     }
 };
 
-__device__ __forceinline__ K31Fetch k31_fetch_setup(K31Shared& sh, int lane, int wave) {
-    K31Fetch f;
-    f.fetch_run = (lane * 57) >> 9;
-    f.piece = lane - 9 * f.fetch_run;
-    f.fetcher = f.piece < 8 && f.fetch_run < 7;
-    f.lines = sh.lines[wave];
-    f.runline = sh.runline[wave];
-    return f;
-}
-
 template <bool WIDE, bool BOTH>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void screen_k31_kernel(
     const uint8_t* __restrict__ text, const TileDesc* __restrict__ tiles, TableView tv, int32_t min_count,
@@ -656,7 +588,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const int wpw = (n_words + WAVES - 1) / WAVES;
     const int w_begin = min(wave * wpw, n_words);
     const int w_end = min(w_begin + wpw, n_words);
-    const K31Fetch fetch = k31_fetch_setup(sh, lane, wave);
+    const K31Fetch fetch = fetch_setup(sh.lines[wave], sh.runline[wave], lane);
 
     // u16 counters: a wave's total over its <= TILE_WORDS words fits 32 bits; 4-byte counters are Java ints (may be < 0)
     static_assert((uint64_t)TILE_WORDS * 64 * 65535 < (1ull << 32), "32-bit count sums");
@@ -669,7 +601,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         uint64_t key, V;
         uint32_t mn;
         words.next(w, key, mn, V);
-        const uint32_t cnt = k31_probe_word<WIDE>(tv, fetch, lane, key, mn, V);
+        const uint32_t cnt = probe_word<WIDE, false, true>(tv, fetch, lane, key, line_of_minimizer(mn, tv.n_lines), V);
         // cnt is 0 unless the k-mer was found and min_count >= 1 (checked by the API), so this is "found && count >= -c"
         const bool hit = (int32_t)cnt >= min_count;                         // GetVariants.java:224
         const uint64_t H = wave_ballot(hit);
@@ -720,7 +652,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const int wpw = (n_words + WAVES - 1) / WAVES;
     const int w_begin = min(wave * wpw, n_words);
     const int w_end = min(w_begin + wpw, n_words);
-    const K31Fetch fetch = k31_fetch_setup(sh, lane, wave);
+    const K31Fetch fetch = fetch_setup(sh.lines[wave], sh.runline[wave], lane);
     if (lane < MULTI_MAX) s_msum[wave][lane] = 0;
     wave_lds_fence();
     K31Words<BOTH> words;
@@ -733,8 +665,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         for (int s = 0; s < mt.n; ++s) {
             const TableView tv = mt.tv[s];
             uint32_t cnt;
-            if (tv.wide) cnt = k31_probe_word<true>(tv, fetch, lane, key, mn, V);
-            else cnt = k31_probe_word<false>(tv, fetch, lane, key, mn, V);
+            if (tv.wide) cnt = probe_word<true, false, true>(tv, fetch, lane, key, line_of_minimizer(mn, tv.n_lines), V);
+            else cnt = probe_word<false, false, true>(tv, fetch, lane, key, line_of_minimizer(mn, tv.n_lines), V);
             const bool hit = (int32_t)cnt >= min_count;                     // GetVariants.java:224
             const uint64_t H = wave_ballot(hit);
             // the word's count sum goes straight to the wave's per-sample total (no per-lane accumulator per sample)
