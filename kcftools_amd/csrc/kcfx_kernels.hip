@@ -209,6 +209,9 @@ __device__ __forceinline__ void wave_lds_fence() {
 // ======================================================================================================
 // the probe: KMC.getCount for the 64 k-mers of one word (shared by all screening kernels)
 // ======================================================================================================
+// Table lines land in LDS by LDS-DMA (global_load_lds_dwordx4): no destination VGPRs, no ds_write. Ballots are taken of
+// single compares and combined on the scalar unit (a ballot of a conjunction costs hipcc a v_cndmask + v_cmp to
+// re-materialise the predicate).
 // LDS-DMA puts lane i's 16 bytes at base + 16 i. Nine lanes per run, the ninth idle, leave a 16-byte hole after every
 // line: lines start 144 bytes apart, on distinct LDS banks for the match reads (a 128-byte pitch costs 4x the bank
 // conflict cycles, SQ_LDS_BANK_CONFLICT). 7 runs per instruction, 2 instructions per chunk.
@@ -218,7 +221,6 @@ constexpr int K31_PITCH = 9;                                   // uint4 per buff
 __device__ __forceinline__ uint32_t wave_shr1(uint32_t x) {     // lane l gets lane l-1's value, lane 0 gets 0 (bound_ctrl)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, true);
 }
-
 
 // Per-lane constants of the cooperative line fetch
 struct K31Fetch {
@@ -233,7 +235,8 @@ struct K31Fetch {
 // (ballot of valid k-mers). Returns the stored counter, 0 when absent / invalid.
 // Cooperative probe rounds: each round fetches, for every run of adjacent pending lanes with the same target line, that
 // line ONCE (8 lanes x 16 B = one 128-byte request, LDS-DMA) into wave-private LDS, then every lane compares its key
-// against its run's line. Probe state lives in VGPR integers and is updated with selects (see screen_tiles_kernel).
+// against its run's line. Probe state lives in VGPR integers and is updated with selects: lane-varying bools carried
+// through the loops would be kept as SGPR masks and cost three scalar instructions per update and block.
 // CHECK_NS: k = 32 (the all-ones word is a k-mer, see match_line); MINI: minimizer table (HEAVY homes exist).
 template <bool WIDE, bool CHECK_NS, bool MINI>
 __device__ __forceinline__ uint32_t probe_word(const TableView& tv, const K31Fetch& f, int lane, uint64_t key,
@@ -451,9 +454,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 //     min(S[l], P[l + 15]) (one ds_bpermute pair; lanes 49..63 take P from the next word). No phase 1b, no barriers.
 //   * one word index / shift pair addresses every code-bit read of a word: its own low halves and, 64 positions on, the
 //     leading halves of the next word, which feed that word's M-mer hashes now and its k-mers one iteration later.
-//   * table lines land in LDS by LDS-DMA (global_load_lds_dwordx4): no destination VGPRs, no ds_write.
-//   * ballots are taken of single compares and combined on the scalar unit (a ballot of a conjunction costs hipcc a
-//     v_cndmask + v_cmp to re-materialise the predicate).
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_or_ones(uint32_t x) {   // value of the DPP source lane; all ones where there is none
     return (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, CTRL, 0xf, 0xf, false);
