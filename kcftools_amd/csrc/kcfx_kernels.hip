@@ -237,66 +237,80 @@ struct K31Fetch {
 // line ONCE (8 lanes x 16 B = one 128-byte request, LDS-DMA) into wave-private LDS, then every lane compares its key
 // against its run's line. Probe state lives in VGPR integers and is updated with selects: lane-varying bools carried
 // through the loops would be kept as SGPR masks and cost three scalar instructions per update and block.
-// CHECK_NS: k = 32 (the all-ones word is a k-mer, see match_line); MINI: minimizer table (HEAVY homes exist).
+// CHECK_NS: k = 32 (the all-ones word is a k-mer, see match_line).
+//
+// One round for the lanes in PM (= ballot of st == 1, not empty): st becomes 2 (found, cnt set), 1 (the line overflowed:
+// tgt moved on to the next line) or 0 (absent); meta = meta dword of the line a lane looked at.
+template <bool WIDE, bool CHECK_NS>
+__device__ __forceinline__ void probe_round(const TableView& tv, const K31Fetch& f, uint64_t PM, uint64_t key, uint32_t& tgt,
+                                            uint32_t& st, uint32_t& cnt, uint32_t& meta_seen) {
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    // heads of runs: pending lanes whose predecessor is not pending or aims at another line
+    const uint64_t HM = PM & (wave_ballot(wave_shr1(st) != 1u) | wave_ballot(wave_shr1(tgt) != tgt));
+    const int nruns = __popcll(HM);
+    // index of this lane's run = heads at or below it, minus one
+    const uint64_t H1 = HM >> 1;
+    const int my_run = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(H1 >> 32),
+                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)H1, (uint32_t)((int)(HM & 1) - 1)));
+    // every pending lane stores its run's line index (same value within a run); the others hit a dummy slot
+    f.runline[(st == 1u) ? my_run : 64] = tgt;
+    wave_lds_fence();
+    for (int c0 = 0; c0 < nruns; c0 += K31_RUNS) {
+        const int r0 = c0 + f.fetch_run, r1 = r0 + 7;
+        // 8 lanes x 16 B = one 128-byte request per run
+        if (f.fetcher && r0 < nruns)
+            __builtin_amdgcn_global_load_lds((gptr_t)(tv.lines + (size_t)f.runline[r0] * LINE_BYTES + 16 * f.piece),
+                                             (lptr_t)f.lines, 16, 0, 0);
+        if (f.fetcher && r1 < nruns)
+            __builtin_amdgcn_global_load_lds((gptr_t)(tv.lines + (size_t)f.runline[r1] * LINE_BYTES + 16 * f.piece),
+                                             (lptr_t)(f.lines + 7 * K31_PITCH), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_lds_fence();
+        // every lane matches (idle lanes against buffer 0); the outcome is merged with selects
+        const uint32_t rel = (uint32_t)(my_run - c0);
+        const bool mine = (st == 1u) && (rel < (uint32_t)K31_RUNS);
+        const uint4* src = f.lines + (mine ? rel : 0u) * K31_PITCH;
+        uint32_t c, meta;
+        const bool any = match_line_lds<WIDE, CHECK_NS>(src, key, c, meta);
+        const uint32_t ov = (meta >> 8) & 1u;                       // overflowed line: look at the next one
+        const uint32_t nst = any ? 2u : ov;
+        const uint32_t ntgt = (tgt + 1 == tv.n_lines) ? 0u : tgt + 1;
+        cnt = (mine && any) ? c : cnt;                              // Java int (KMC.java:395-401)
+        tgt = (mine && nst == 1u) ? ntgt : tgt;
+        meta_seen = mine ? meta : meta_seen;
+        st = mine ? nst : st;
+        wave_lds_fence();
+    }
+}
+
+// HEAVY minimizer home (table_finalize also sets its overflow bit, so lanes that missed there are still pending): every
+// k-mer homed there by minimizer lives at its key-hash line instead -- jump, do not walk. `home_meta` = meta dword of the
+// home line, PM = pending lanes after the first round.
+__device__ __forceinline__ void heavy_redirect(const TableView& tv, int lane, uint64_t PM, uint32_t home_meta, uint64_t key,
+                                               uint32_t& tgt) {
+    const uint64_t RM = PM & wave_ballot((home_meta & META_HEAVY) != 0u);
+    if (RM) {
+        // rare: keep the key hash (three multiplies) from being hoisted into every word
+        uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+        asm volatile("" : "+v"(klo), "+v"(khi));
+        if ((RM >> lane) & 1) tgt = keyhash_line(tv, u64_of(klo, khi));
+    }
+}
+
+// All rounds of one word, one after the other. MINI: minimizer table (HEAVY homes exist).
 template <bool WIDE, bool CHECK_NS, bool MINI>
 __device__ __forceinline__ uint32_t probe_word(const TableView& tv, const K31Fetch& f, int lane, uint64_t key,
                                                uint32_t home, uint64_t V) {
-    typedef __attribute__((address_space(1))) const void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
     uint32_t tgt = home;                                    // minimizer tables: shared by the whole minimizer run
     uint32_t st = (uint32_t)((V >> lane) & 1);              // 1 = pending, 2 = found, 0 = absent / invalid
     uint32_t cnt = 0;
-    uint32_t hm = 0;                                        // meta dword of the line matched last
+    uint32_t meta = 0;
     for (int round = 0;; ++round) {
         const uint64_t PM = wave_ballot(st == 1u);
         if (!PM) break;
-        if (MINI && round == 1) {
-            // HEAVY minimizer home (table_finalize also sets its overflow bit, so such lanes are still pending):
-            // every k-mer homed there by minimizer lives at its key-hash line instead -- jump, do not walk
-            const uint64_t RM = PM & wave_ballot((hm & META_HEAVY) != 0u);
-            if (RM) {
-                // rare: keep the key hash (three multiplies) from being hoisted into every word
-                uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
-                asm volatile("" : "+v"(klo), "+v"(khi));
-                if ((RM >> lane) & 1) tgt = keyhash_line(tv, u64_of(klo, khi));
-            }
-        }
-        // heads of runs: pending lanes whose predecessor is not pending or aims at another line
-        const uint64_t HM = PM & (wave_ballot(wave_shr1(st) != 1u) | wave_ballot(wave_shr1(tgt) != tgt));
-        const int nruns = __popcll(HM);
-        // index of this lane's run = heads at or below it, minus one
-        const uint64_t H1 = HM >> 1;
-        const int my_run = (int)__builtin_amdgcn_mbcnt_hi(
-            (uint32_t)(H1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)H1, (uint32_t)((int)(HM & 1) - 1)));
-        // every pending lane stores its run's line index (same value within a run); the others hit a dummy slot
-        f.runline[(st == 1u) ? my_run : 64] = tgt;
-        wave_lds_fence();
-        for (int c0 = 0; c0 < nruns; c0 += K31_RUNS) {
-            const int r0 = c0 + f.fetch_run, r1 = r0 + 7;
-            // 8 lanes x 16 B = one 128-byte request per run
-            if (f.fetcher && r0 < nruns)
-                __builtin_amdgcn_global_load_lds((gptr_t)(tv.lines + (size_t)f.runline[r0] * LINE_BYTES + 16 * f.piece),
-                                                 (lptr_t)f.lines, 16, 0, 0);
-            if (f.fetcher && r1 < nruns)
-                __builtin_amdgcn_global_load_lds((gptr_t)(tv.lines + (size_t)f.runline[r1] * LINE_BYTES + 16 * f.piece),
-                                                 (lptr_t)(f.lines + 7 * K31_PITCH), 16, 0, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            wave_lds_fence();
-            // every lane matches (idle lanes against buffer 0); the outcome is merged with selects
-            const uint32_t rel = (uint32_t)(my_run - c0);
-            const bool mine = (st == 1u) && (rel < (uint32_t)K31_RUNS);
-            const uint4* src = f.lines + (mine ? rel : 0u) * K31_PITCH;
-            uint32_t c, meta;
-            const bool any = match_line_lds<WIDE, CHECK_NS>(src, key, c, meta);
-            const uint32_t ov = (meta >> 8) & 1u;                       // overflowed line: look at the next one
-            const uint32_t nst = any ? 2u : ov;
-            const uint32_t ntgt = (tgt + 1 == tv.n_lines) ? 0u : tgt + 1;
-            cnt = (mine && any) ? c : cnt;                              // Java int (KMC.java:395-401)
-            tgt = (mine && nst == 1u) ? ntgt : tgt;
-            hm = mine ? meta : hm;
-            st = mine ? nst : st;
-            wave_lds_fence();
-        }
+        if (MINI && round == 1) heavy_redirect(tv, lane, PM, meta, key, tgt);
+        probe_round<WIDE, CHECK_NS>(tv, f, PM, key, tgt, st, cnt, meta);
     }
     return cnt;
 }
@@ -573,11 +587,63 @@ struct K31Words {
     }
 };
 
+// Probe rounds after the first are sparse: an instrumented build counts 13.7 pending lanes per word after round 0 (21 %:
+// a minimizer run of up to 16 k-mers overflows its 12-slot home line 40 % of the time, and every k-mer of such a run
+// that is not in the home line -- pushed out, or absent from the database -- must look at the next line), yet 91 % of the
+// words would run a full-width second round for them. Instead the pending k-mers of successive words are queued,
+// compacted, in wave-private LDS and probed 64 at a time; their hits are OR-ed into the wave's hit words afterwards.
+constexpr int K31_WORDS_PER_WAVE = (TILE_WORDS + WAVES - 1) / WAVES;
+constexpr int K31_QUEUE = 128;                              // < 64 left over + <= 64 new entries
+struct K31Queue {
+    uint64_t key[K31_QUEUE];
+    uint32_t tgt[K31_QUEUE];
+    uint32_t id[K31_QUEUE];                                 // (word of the wave << 6) | lane
+    unsigned long long hit[K31_WORDS_PER_WAVE];             // hit ballots of the wave's words
+};
+
+// One probe round for the first min(qn, 64) queued k-mers; those that must go on are queued again. Returns the new qn.
+template <bool WIDE>
+__device__ __forceinline__ int k31_deferred_round(const TableView& tv, const K31Fetch& f, K31Queue& q, int lane, int qn,
+                                                  int32_t min_count, typename std::conditional<WIDE, int64_t, uint32_t>::type& sum_acc) {
+    const int nb = min(qn, 64), rest = qn - nb;
+    const uint64_t key = q.key[lane];
+    uint32_t tgt = q.tgt[lane];
+    const uint32_t id = q.id[lane];
+    // the entries behind the batch move to the front
+    const uint64_t k2 = q.key[64 + lane];
+    const uint32_t t2 = q.tgt[64 + lane], i2 = q.id[64 + lane];
+    wave_lds_fence();
+    if (lane < rest) {
+        q.key[lane] = k2;
+        q.tgt[lane] = t2;
+        q.id[lane] = i2;
+    }
+    uint32_t st = lane < nb ? 1u : 0u, cnt = 0, meta = 0;
+    const uint64_t PM = nb == 64 ? ~0ull : ((1ull << nb) - 1);
+    probe_round<WIDE, false>(tv, f, PM, key, tgt, st, cnt, meta);
+    const bool hit = (int32_t)cnt >= min_count;             // cnt is 0 unless found; GetVariants.java:224
+    if (hit) atomicOr(&q.hit[id >> 6], 1ull << (id & 63));
+    if (WIDE) sum_acc += hit ? (int64_t)(int32_t)cnt : 0;   // GetVariants.java:226
+    else sum_acc += hit ? cnt : 0u;
+    const uint64_t again = wave_ballot(st == 1u);
+    if (again) {
+        const int pos = rest + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(again >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)again, 0u));
+        if (st == 1u) {
+            q.key[pos] = key;
+            q.tgt[pos] = tgt;
+            q.id[pos] = id;
+        }
+    }
+    wave_lds_fence();
+    return rest + __popcll(again);
+}
+
 template <bool WIDE, bool BOTH>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void screen_k31_kernel(
     const uint8_t* __restrict__ text, const TileDesc* __restrict__ tiles, TableView tv, int32_t min_count,
     uint64_t* __restrict__ bits, int64_t* __restrict__ count_sums) {
     __shared__ K31Shared sh;
+    __shared__ K31Queue s_queue[WAVES];
     const TileDesc td = tiles[blockIdx.x];
     const int tid = threadIdx.x;
     const int off = k31_pack_tile(sh, text, td, tid);
@@ -589,6 +655,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const int w_begin = min(wave * wpw, n_words);
     const int w_end = min(w_begin + wpw, n_words);
     const K31Fetch fetch = fetch_setup(sh.lines[wave], sh.runline[wave], lane);
+    K31Queue& q = s_queue[wave];
+    int qn = 0;                                             // queued k-mers (wave-uniform)
 
     // u16 counters: a wave's total over its <= TILE_WORDS words fits 32 bits; 4-byte counters are Java ints (may be < 0)
     static_assert((uint64_t)TILE_WORDS * 64 * 65535 < (1ull << 32), "32-bit count sums");
@@ -601,17 +669,36 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         uint64_t key, V;
         uint32_t mn;
         words.next(w, key, mn, V);
-        const uint32_t cnt = probe_word<WIDE, false, true>(tv, fetch, lane, key, line_of_minimizer(mn, tv.n_lines), V);
+        uint32_t tgt = line_of_minimizer(mn, tv.n_lines);   // home line, shared by the whole minimizer run
+        uint32_t st = (uint32_t)((V >> lane) & 1);          // 1 = pending, 2 = found, 0 = absent / invalid
+        uint32_t cnt = 0, meta = 0;
+        if (V) probe_round<WIDE, false>(tv, fetch, V, key, tgt, st, cnt, meta);      // the home lines
         // cnt is 0 unless the k-mer was found and min_count >= 1 (checked by the API), so this is "found && count >= -c"
         const bool hit = (int32_t)cnt >= min_count;                         // GetVariants.java:224
         const uint64_t H = wave_ballot(hit);
-        if (lane == 0) {                                                    // this word of the window's hit bitmap
-            my_bits[w] = V;
-            my_bits[TILE_WORDS + w] = H;
+        if (lane == 0) {
+            my_bits[w] = V;                                                 // validity word of the window's bitmap
+            q.hit[w - w_begin] = H;                                         // hits so far; queued k-mers may add theirs
         }
         if (WIDE) sum_acc += hit ? (int64_t)(int32_t)cnt : 0;               // GetVariants.java:226
         else sum_acc += hit ? cnt : 0u;
+        // the rest of this word's probing is queued
+        const uint64_t PM = wave_ballot(st == 1u);
+        if (PM) {
+            heavy_redirect(tv, lane, PM, meta, key, tgt);
+            const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(PM >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)PM, 0u));
+            if (st == 1u) {
+                q.key[pos] = key;
+                q.tgt[pos] = tgt;
+                q.id[pos] = (uint32_t)(((w - w_begin) << 6) | lane);
+            }
+            qn += __popcll(PM);
+        }
+        wave_lds_fence();
+        while (qn >= 64) qn = k31_deferred_round<WIDE>(tv, fetch, q, lane, qn, min_count, sum_acc);
     }
+    while (qn > 0) qn = k31_deferred_round<WIDE>(tv, fetch, q, lane, qn, min_count, sum_acc);
+    if (lane < w_end - w_begin) my_bits[TILE_WORDS + w_begin + lane] = q.hit[lane];   // hit words of the window's bitmap
 
     int64_t count_sum;
     if constexpr (WIDE) count_sum = wave_sum_i64(sum_acc);
