@@ -259,10 +259,10 @@ int32_t check_device(int32_t device) {
 }
 
 // Lines are filled sparsely on purpose. The probe costs the same whatever the table size (one line per fetch, 8 lanes
-// at once), and every overflowed line costs its k-mers a second, dependent fetch round (measured on the bench workload:
-// 0.329 ms at load 0.35, 0.287 ms at 0.20, 0.274 ms at 0.10), so a sparse table is worth its HBM while HBM is plentiful
-// (288 GB): the sparsest of 0.20 / 0.35 / 0.60 whose table stays under 48 / 128 GiB and under 60 % of the free device
-// memory (several samples may be resident at once). KCFX_TABLE_LOAD overrides.
+// at once), and every overflowed line sends its k-mers to a further probe round (measured on the bench workload with
+// the queued-rounds kernel: 0.199 / 0.210 / 0.221 / 0.239 ms at load 0.15 / 0.20 / 0.30 / 0.40), so a sparse table is
+// worth its HBM while HBM is plentiful (288 GB): the sparsest of 0.15 / 0.35 / 0.60 whose table stays under 48 / 128 GiB
+// and under 60 % of the free device memory (several samples may be resident at once). KCFX_TABLE_LOAD overrides.
 double table_load_factor(int64_t n_keys, int slots) {
     const char* s = getenv("KCFX_TABLE_LOAD");
     if (s) {
@@ -274,7 +274,7 @@ double table_load_factor(int64_t n_keys, int slots) {
     const double GiB = (double)(1ull << 30);
     const double room = 0.6 * (double)free_b;
     auto bytes_at = [&](double a) { return (double)n_keys / (slots * a) * LINE_BYTES; };
-    if (bytes_at(0.20) <= 48.0 * GiB && bytes_at(0.20) <= room) return 0.20;
+    if (bytes_at(0.15) <= 48.0 * GiB && bytes_at(0.15) <= room) return 0.15;
     if (bytes_at(0.35) <= 128.0 * GiB && bytes_at(0.35) <= room) return 0.35;
     return 0.6;
 }
