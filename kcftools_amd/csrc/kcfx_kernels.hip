@@ -246,8 +246,8 @@ __device__ __forceinline__ void probe_round(const TableView& tv, const K31Fetch&
                                             uint32_t& st, uint32_t& cnt, uint32_t& meta_seen) {
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
-    // heads of runs: pending lanes whose predecessor is not pending or aims at another line
-    const uint64_t HM = PM & (wave_ballot(wave_shr1(st) != 1u) | wave_ballot(wave_shr1(tgt) != tgt));
+    // heads of runs: pending lanes whose predecessor is not pending (a scalar shift of PM) or aims at another line
+    const uint64_t HM = PM & (~(PM << 1) | wave_ballot(wave_shr1(tgt) != tgt));
     const int nruns = __popcll(HM);
     // index of this lane's run = heads at or below it, minus one
     const uint64_t H1 = HM >> 1;
