@@ -185,12 +185,14 @@ def main():
     achieved_gbs = (kmers_per_step * b_alg / launches_per_step) / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
 
     traffic = None
+    rocprof_ms = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             if S == 1 and tj.get("ref_len") == args.ref_len and tj.get("db_kmers") == args.db_kmers and tj.get("window") == args.window:
                 traffic = tj.get("hbm_bytes_per_launch")
+                rocprof_ms = tj.get("rocprof_kernel_avg_ms")    # the committed rocprofv3 --stats average of the same kernel
         except Exception:
             traffic = None
 
@@ -247,7 +249,8 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "screen_k31_kernel" if S == 1 else "screen_k31_multi_kernel", "kernel_avg_ms": kern_avg_ms,
-                     "launches_timed": int(launches), "algorithmic_bytes_per_kmer": b_alg if S > 1 else B_ALG},
+                     "launches_timed": int(launches), "algorithmic_bytes_per_kmer": b_alg if S > 1 else B_ALG,
+                     "rocprof_kernel_avg_ms": rocprof_ms},
         "cpu_baseline": cpu,
         "parity": parity,
         "setup_seconds": {"generate": gen_s, "db_open": load_s, "db_open_inner": float(db.info.load_seconds)},

@@ -56,6 +56,7 @@ if fetch.get("FETCH_SIZE") is not None:
     out["hbm_write_bytes_per_launch"] = wr
     cfg = bench["config"]
     json.dump({"tag": tag, "kernel": KERNEL, "hbm_bytes_per_launch": rd + wr,
+               "rocprof_kernel_avg_ms": out.get("rocprof_kernel_avg_ms"),
                "ref_len": 30427671, "db_kmers": 150000000, "window": 10000,
                "note": "2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes), separate --pmc passes, averaged over launches"},
               open("profiles/traffic.json", "w"), indent=1)
