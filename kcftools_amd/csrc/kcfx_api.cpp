@@ -725,11 +725,9 @@ int32_t kcfx_screen_ref_async(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count
         ev0 = ref->events[ref->events_used].first;
         ev1 = ref->events[ref->events_used].second;
         ref->events_used++;
-        KCFX_HIP(hipEventRecord(ev0, st));
     }
     KCFX_HIP(launch_screen_tiles(ref->d_text, ref->d_tiles, ref->n_tiles, db->view(), ref->k, db->info.both_strands,
-                                 min_kmer_count, ref->d_bits, ref->d_csum, st));
-    if (ev1) KCFX_HIP(hipEventRecord(ev1, st));
+                                 min_kmer_count, ref->d_bits, ref->d_csum, st, ev0, ev1));
     KCFX_HIP(launch_reduce_windows(ref->d_tiles, ref->n_tiles, 1, ref->d_bits, ref->d_csum, ref->d_win_tile0, ref->n_windows,
                                    ref->k, reinterpret_cast<kcfx_result*>(out_device), st));
     return KCFX_OK;
@@ -787,11 +785,9 @@ int32_t kcfx_screen_ref_multi_async(kcfx_db* const* dbs, int32_t n_db, kcfx_ref*
             ev0 = ref->events[ref->events_used].first;
             ev1 = ref->events[ref->events_used].second;
             ref->events_used++;
-            KCFX_HIP(hipEventRecord(ev0, st));
         }
         KCFX_HIP(launch_screen_multi(ref->d_text, ref->d_tiles, ref->n_tiles, tvs, nb, d0->info.both_strands, min_kmer_count,
-                                     ref->d_mbits, ref->d_mcsum, st));
-        if (ev1) KCFX_HIP(hipEventRecord(ev1, st));
+                                     ref->d_mbits, ref->d_mcsum, st, ev0, ev1));
         // consecutive output slices take one launch; scattered ones (mixed batches) one each
         for (int32_t b = 0; b < nb;) {
             int32_t e = b + 1;

@@ -179,7 +179,7 @@ hipError_t launch_lookup(TableView tv, int32_t k, const uint64_t* keys, int64_t 
 // screen
 hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32_t n_tiles, TableView tv, int32_t k,
                                int32_t both_strands, int32_t min_count, uint64_t* bits, int64_t* count_sums,
-                               hipStream_t st);
+                               hipStream_t st, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // hit bitmaps + count sums of n_samples consecutive samples -> kcfx_result per (sample, window)
 hipError_t launch_reduce_windows(const TileDesc* tiles, int32_t n_tiles, int32_t n_samples, const uint64_t* bits,
                                  const int64_t* count_sums, const int32_t* win_tile0, int32_t n_windows, int32_t k,
@@ -190,7 +190,7 @@ constexpr int SCREEN_MULTI_MAX = 8;
 bool screen_multi_supported(const TableView& tv, int32_t k);
 hipError_t launch_screen_multi(const uint8_t* text, const TileDesc* tiles, int32_t n_tiles, const TableView* tvs,
                                int32_t n_tables, int32_t both_strands, int32_t min_count, uint64_t* bits, int64_t* count_sums,
-                               hipStream_t st);
+                               hipStream_t st, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 
 }  // namespace kcfx

@@ -12,6 +12,8 @@
 //
 // Integer / index work: no MFMA. Lane <-> consecutive k-mer start positions, so one __ballot is a
 // 64-position slice of the window's hit bitmap.
+#include <hip/hip_ext.h>
+
 #include <cstdlib>
 
 #include "kcfx_device.h"
@@ -924,13 +926,15 @@ hipError_t launch_reduce_windows(const TileDesc* tiles, int32_t n_tiles, int32_t
 
 hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32_t n_tiles, TableView tv, int32_t k,
                                int32_t both_strands, int32_t min_count, uint64_t* bits, int64_t* count_sums,
-                               hipStream_t st) {
+                               hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (n_tiles <= 0) return hipSuccess;
     const dim3 g(n_tiles), b(BLOCK);
+    // ev_start / ev_stop (may be null) take the kernel's own begin / end timestamps (hipExtLaunchKernelGGL), which is
+    // what rocprofv3 --kernel-trace reports; events recorded around the launch would add the dispatch gaps
 #define KCFX_LAUNCH(W, MD) \
-    hipLaunchKernelGGL((screen_tiles_kernel<W, MD>), g, b, 0, st, text, tiles, tv, k, both_strands, min_count, bits, count_sums)
+    hipExtLaunchKernelGGL((screen_tiles_kernel<W, MD>), g, b, 0, st, ev_start, ev_stop, 0, text, tiles, tv, k, both_strands, min_count, bits, count_sums)
 #define KCFX_LAUNCH31(W, BS) \
-    hipLaunchKernelGGL((screen_k31_kernel<W, BS>), g, b, 0, st, text, tiles, tv, min_count, bits, count_sums)
+    hipExtLaunchKernelGGL((screen_k31_kernel<W, BS>), g, b, 0, st, ev_start, ev_stop, 0, text, tiles, tv, min_count, bits, count_sums)
     const bool generic_only = getenv("KCFX_GENERIC_KERNEL") != nullptr;             // A/B and test hook (read per launch)
     if (tv.mode == MODE_MINIMIZER && k == 31 && tv.mm_len == 16 && !generic_only) {
         if (tv.wide) { if (both_strands) KCFX_LAUNCH31(true, true); else KCFX_LAUNCH31(true, false); }
@@ -951,7 +955,7 @@ bool screen_multi_supported(const TableView& tv, int32_t k) {
 
 hipError_t launch_screen_multi(const uint8_t* text, const TileDesc* tiles, int32_t n_tiles, const TableView* tvs,
                                int32_t n_tables, int32_t both_strands, int32_t min_count, uint64_t* bits, int64_t* count_sums,
-                               hipStream_t st) {
+                               hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (n_tiles <= 0 || n_tables <= 0) return hipSuccess;
     if (n_tables > MULTI_MAX) return hipErrorInvalidValue;
     MultiTables mt;
@@ -959,11 +963,11 @@ hipError_t launch_screen_multi(const uint8_t* text, const TileDesc* tiles, int32
     mt.n = n_tables;
     const int64_t stride = (int64_t)n_tiles * TILE_BITS_U64;
     if (both_strands)
-        hipLaunchKernelGGL((screen_k31_multi_kernel<true>), dim3(n_tiles), dim3(BLOCK), 0, st, text, tiles, n_tiles, mt,
-                           min_count, bits, stride, count_sums);
+        hipExtLaunchKernelGGL((screen_k31_multi_kernel<true>), dim3(n_tiles), dim3(BLOCK), 0, st, ev_start, ev_stop, 0, text,
+                              tiles, n_tiles, mt, min_count, bits, stride, count_sums);
     else
-        hipLaunchKernelGGL((screen_k31_multi_kernel<false>), dim3(n_tiles), dim3(BLOCK), 0, st, text, tiles, n_tiles, mt,
-                           min_count, bits, stride, count_sums);
+        hipExtLaunchKernelGGL((screen_k31_multi_kernel<false>), dim3(n_tiles), dim3(BLOCK), 0, st, ev_start, ev_stop, 0, text,
+                              tiles, n_tiles, mt, min_count, bits, stride, count_sums);
     return hipGetLastError();
 }
 
