@@ -726,15 +726,116 @@ struct MultiTables {
     int32_t n;
 };
 
+// The later probe rounds of all samples share one queue per wave: an entry carries its sample in the top 3 bits of its line
+// number (tables of the multi-sample pass have fewer than 2^29 lines and 2-byte counters, screen_multi_supported), so
+// run detection, the run list and the re-queue work on the tagged value; the table base and size come from a small LDS
+// table per lane.
+constexpr int MULTI_TAG_SHIFT = 29;
+constexpr uint32_t MULTI_LINE_MASK = (1u << MULTI_TAG_SHIFT) - 1;
+struct MultiTab {
+    const uint8_t* lines;
+    uint32_t n_lines, pad;
+};
+struct K31MultiQueue {
+    uint64_t key[K31_QUEUE];
+    uint32_t tgt[K31_QUEUE];                                 // (sample << 29) | line
+    uint16_t id[K31_QUEUE];                                  // (word of the wave << 6) | lane
+    unsigned long long hit[MULTI_MAX][K31_WORDS_PER_WAVE];   // hit ballots per sample and word of the wave
+};
+
+// k31_deferred_round for entries of mixed samples; count sums go to sums[sample] (LDS atomics from the hit lanes)
+__device__ __forceinline__ int k31_deferred_round_multi(const MultiTab* tab, const K31Fetch& f, K31MultiQueue& q, int lane,
+                                                        int qn, int32_t min_count, unsigned long long* sums) {
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int nb = min(qn, 64), rest = qn - nb;
+    const uint64_t key = q.key[lane];
+    uint32_t tgt = q.tgt[lane];
+    const uint32_t id = q.id[lane];
+    const uint64_t k2 = q.key[64 + lane];
+    const uint32_t t2 = q.tgt[64 + lane], i2 = q.id[64 + lane];
+    wave_lds_fence();
+    if (lane < rest) {                                       // the entries behind the batch move to the front
+        q.key[lane] = k2;
+        q.tgt[lane] = t2;
+        q.id[lane] = (uint16_t)i2;
+    }
+    uint32_t st = lane < nb ? 1u : 0u, cnt = 0;
+    const uint64_t PM = nb == 64 ? ~0ull : ((1ull << nb) - 1);
+    const uint32_t smp = tgt >> MULTI_TAG_SHIFT;
+    const uint32_t n_lines = tab[lane < nb ? smp : 0u].n_lines;
+    // one probe round (probe_round with the table looked up per run)
+    const uint64_t HM = PM & (~(PM << 1) | wave_ballot(wave_shr1(tgt) != tgt));
+    const int nruns = __popcll(HM);
+    const uint64_t H1 = HM >> 1;
+    const int my_run = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(H1 >> 32),
+                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)H1, (uint32_t)((int)(HM & 1) - 1)));
+    f.runline[(st == 1u) ? my_run : 64] = tgt;
+    wave_lds_fence();
+    for (int c0 = 0; c0 < nruns; c0 += K31_RUNS) {
+        const int r0 = c0 + f.fetch_run, r1 = r0 + 7;
+        if (f.fetcher && r0 < nruns) {
+            const uint32_t v = f.runline[r0];
+            __builtin_amdgcn_global_load_lds(
+                (gptr_t)(tab[v >> MULTI_TAG_SHIFT].lines + (size_t)(v & MULTI_LINE_MASK) * LINE_BYTES + 16 * f.piece),
+                (lptr_t)f.lines, 16, 0, 0);
+        }
+        if (f.fetcher && r1 < nruns) {
+            const uint32_t v = f.runline[r1];
+            __builtin_amdgcn_global_load_lds(
+                (gptr_t)(tab[v >> MULTI_TAG_SHIFT].lines + (size_t)(v & MULTI_LINE_MASK) * LINE_BYTES + 16 * f.piece),
+                (lptr_t)(f.lines + 7 * K31_PITCH), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_lds_fence();
+        const uint32_t rel = (uint32_t)(my_run - c0);
+        const bool mine = (st == 1u) && (rel < (uint32_t)K31_RUNS);
+        const uint4* src = f.lines + (mine ? rel : 0u) * K31_PITCH;
+        uint32_t c, meta;
+        const bool any = match_line_lds<false, false>(src, key, c, meta);
+        const uint32_t ov = (meta >> 8) & 1u;
+        const uint32_t nst = any ? 2u : ov;
+        const uint32_t line = tgt & MULTI_LINE_MASK;
+        const uint32_t ntgt = (tgt & ~MULTI_LINE_MASK) | ((line + 1 == n_lines) ? 0u : line + 1);
+        cnt = (mine && any) ? c : cnt;
+        tgt = (mine && nst == 1u) ? ntgt : tgt;
+        st = mine ? nst : st;
+        wave_lds_fence();
+    }
+    const bool hit = (int32_t)cnt >= min_count;             // cnt is 0 unless found; GetVariants.java:224
+    if (hit) {
+        atomicOr(&q.hit[smp][id >> 6], 1ull << (id & 63));
+        atomicAdd(&sums[smp], (unsigned long long)cnt);     // GetVariants.java:226
+    }
+    const uint64_t again = wave_ballot(st == 1u);
+    if (again) {
+        const int pos = rest + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(again >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)again, 0u));
+        if (st == 1u) {
+            q.key[pos] = key;
+            q.tgt[pos] = tgt;
+            q.id[pos] = (uint16_t)id;
+        }
+    }
+    wave_lds_fence();
+    return rest + __popcll(again);
+}
+
 template <bool BOTH>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void screen_k31_multi_kernel(
     const uint8_t* __restrict__ text, const TileDesc* __restrict__ tiles, int32_t n_tiles, MultiTables mt, int32_t min_count,
     uint64_t* __restrict__ bits, int64_t bits_stride, int64_t* __restrict__ count_sums) {
     __shared__ K31Shared sh;
-    __shared__ int64_t s_msum[WAVES][MULTI_MAX];
+    __shared__ K31MultiQueue s_queue[WAVES];
+    __shared__ unsigned long long s_msum[WAVES][MULTI_MAX];
+    __shared__ MultiTab s_tab[MULTI_MAX];
     const TileDesc td = tiles[blockIdx.x];
     const int tid = threadIdx.x;
-    const int off = k31_pack_tile(sh, text, td, tid);
+    if (tid < MULTI_MAX) {
+        const TableView t = mt.tv[tid < mt.n ? tid : 0];
+        s_tab[tid].lines = t.lines;
+        s_tab[tid].n_lines = t.n_lines;
+    }
+    const int off = k31_pack_tile(sh, text, td, tid);       // (block barrier inside)
 
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_words = (td.n_kmers + 63) >> 6;
@@ -742,6 +843,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const int w_begin = min(wave * wpw, n_words);
     const int w_end = min(w_begin + wpw, n_words);
     const K31Fetch fetch = fetch_setup(sh.lines[wave], sh.runline[wave], lane);
+    K31MultiQueue& q = s_queue[wave];
+    int qn = 0;
     if (lane < MULTI_MAX) s_msum[wave][lane] = 0;
     wave_lds_fence();
     K31Words<BOTH> words;
@@ -751,31 +854,50 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         uint64_t key, V;
         uint32_t mn;
         words.next(w, key, mn, V);
+        if (lane == 0) {
+            for (int s = 0; s < mt.n; ++s) bits[(size_t)s * bits_stride + (size_t)blockIdx.x * TILE_BITS_U64 + w] = V;
+        }
         for (int s = 0; s < mt.n; ++s) {
             const TableView tv = mt.tv[s];
-            uint32_t cnt;
-            if (tv.wide) cnt = probe_word<true, false, true>(tv, fetch, lane, key, line_of_minimizer(mn, tv.n_lines), V);
-            else cnt = probe_word<false, false, true>(tv, fetch, lane, key, line_of_minimizer(mn, tv.n_lines), V);
+            uint32_t tgt = line_of_minimizer(mn, tv.n_lines);
+            uint32_t st = (uint32_t)((V >> lane) & 1), cnt = 0, meta = 0;
+            if (V) probe_round<false, false>(tv, fetch, V, key, tgt, st, cnt, meta);      // the home lines
             const bool hit = (int32_t)cnt >= min_count;                     // GetVariants.java:224
             const uint64_t H = wave_ballot(hit);
             // the word's count sum goes straight to the wave's per-sample total (no per-lane accumulator per sample)
-            int64_t wsum;
-            if (tv.wide) wsum = wave_sum_i64(hit ? (int64_t)(int32_t)cnt : 0);       // Java ints (KMC.java:395-401)
-            else wsum = (int64_t)wave_sum_u32_dpp(hit ? cnt : 0u);
+            const uint32_t wsum = wave_sum_u32_dpp(hit ? cnt : 0u);
             if (lane == 0) {
-                uint64_t* my_bits = bits + (size_t)s * bits_stride + (size_t)blockIdx.x * TILE_BITS_U64;
-                my_bits[w] = V;
-                my_bits[TILE_WORDS + w] = H;
+                q.hit[s][w - w_begin] = H;                                  // hits so far; queued k-mers may add theirs
                 s_msum[wave][s] += wsum;
             }
+            const uint64_t PM = wave_ballot(st == 1u);
+            if (PM) {
+                heavy_redirect(tv, lane, PM, meta, key, tgt);
+                const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(PM >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)PM, 0u));
+                if (st == 1u) {
+                    q.key[pos] = key;
+                    q.tgt[pos] = ((uint32_t)s << MULTI_TAG_SHIFT) | tgt;
+                    q.id[pos] = (uint16_t)(((w - w_begin) << 6) | lane);
+                }
+                qn += __popcll(PM);
+            }
+            wave_lds_fence();
+            while (qn >= 64) qn = k31_deferred_round_multi(s_tab, fetch, q, lane, qn, min_count, s_msum[wave]);
         }
+    }
+    while (qn > 0) qn = k31_deferred_round_multi(s_tab, fetch, q, lane, qn, min_count, s_msum[wave]);
+    // hit words of every sample's bitmap
+    const int nw = w_end - w_begin;
+    for (int i = lane; i < mt.n * nw; i += 64) {
+        const int s = i / nw, wl = i - s * nw;
+        bits[(size_t)s * bits_stride + (size_t)blockIdx.x * TILE_BITS_U64 + TILE_WORDS + w_begin + wl] = q.hit[s][wl];
     }
     __syncthreads();
     if (tid < mt.n) {
-        int64_t t = 0;
+        unsigned long long t = 0;
 #pragma unroll
         for (int i = 0; i < WAVES; ++i) t += s_msum[i][tid];
-        count_sums[(size_t)tid * n_tiles + blockIdx.x] = t;
+        count_sums[(size_t)tid * n_tiles + blockIdx.x] = (int64_t)t;
     }
 }
 
@@ -950,7 +1072,8 @@ hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32
 }
 
 bool screen_multi_supported(const TableView& tv, int32_t k) {
-    return tv.mode == MODE_MINIMIZER && k == 31 && tv.mm_len == 16;
+    // 2-byte counters and < 2^29 lines (64 GiB): the shared queue of the multi-sample kernel tags line numbers with the sample
+    return tv.mode == MODE_MINIMIZER && k == 31 && tv.mm_len == 16 && !tv.wide && tv.n_lines < (1u << MULTI_TAG_SHIFT);
 }
 
 hipError_t launch_screen_multi(const uint8_t* text, const TileDesc* tiles, int32_t n_tiles, const TableView* tvs,
