@@ -381,3 +381,35 @@ def test_fuzz_window_geometry_against_oracle(oracle, tmp_path, seed, generic, mo
     want = odb.screen(ref, begins, lens, 1, threads=4)
     assert_same(got, want, f"fuzz seed {seed} (cs={cs}, both={both})")
     assert_scores(oracle, got, want)
+
+
+def test_async_entry_point_is_graph_capturable(oracle, tmp_path):
+    """kcfx_screen_ref_async only enqueues two kernels on the caller's stream (no allocation, no synchronisation), so a
+    caller can capture it into a HIP graph and replay it; same for the multi-sample entry point once its scratch exists."""
+    import torch
+    k = 31
+    ref = synth.random_reference(200_000, 41)
+    prefix, *_ = make_db(tmp_path, "g", ref, 77)
+    prefix2, *_ = make_db(tmp_path, "g2", ref, 78)
+    db, db2 = engine.KmcDb.open(prefix), engine.KmcDb.open(prefix2)
+    s, e = engine.windows(len(ref), 10_000, 0, k)
+    r = engine.Reference(ref, s, e - s, k)
+    want = r.screen(db, 1)
+    want2 = r.screen_multi([db, db2], 1)                  # also allocates the multi-sample scratch
+    out = torch.zeros(len(s) * 10, dtype=torch.int32, device="cuda:0")
+    out2 = torch.zeros(2 * len(s) * 10, dtype=torch.int32, device="cuda:0")
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        st = torch.cuda.current_stream().cuda_stream
+        r.screen_async(db, out.data_ptr(), st, 1)
+        r.screen_multi_async([db, db2], out2.data_ptr(), st, 1)
+    out.zero_()
+    out2.zero_()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert_same(out.cpu().numpy().view(engine.RESULT_DTYPE), want, "graph replay")
+    got2 = out2.cpu().numpy().view(engine.RESULT_DTYPE).reshape(2, len(s))
+    for i in range(2):
+        assert_same(got2[i], want2[i], f"graph replay, sample {i}")
