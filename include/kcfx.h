@@ -124,7 +124,8 @@ int32_t kcfx_screen_ref_async(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count
 /* Several samples, ONE pass over the reference (SURVEY f-4): what the reference does as S getVariations runs followed by
  * `cohort` (run_kcftools.sh:124-140, Plugins/Cohort.java:71-119). out[s * n_windows + w] = sample s (input order),
  * window w; each slice equals kcfx_screen_ref(dbs[s], ...). Databases must live on ref's device and share its k;
- * k = 31 minimizer tables are screened up to 8 at a time by one kernel, the rest one by one. */
+ * k = 31 minimizer tables with counters of at most 2 bytes are screened up to 8 at a time by one kernel, the rest one by
+ * one (same results either way). */
 int32_t kcfx_screen_ref_multi(kcfx_db* const* dbs, int32_t n_db, kcfx_ref* ref, int32_t min_kmer_count, kcfx_result* out);
 /* Same, asynchronous on `hip_stream`, results left in device memory (n_db * n_windows records). The first call on a
  * reference allocates its multi-sample scratch; later calls allocate nothing. */
