@@ -87,6 +87,10 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal of the N > 1 control flow on a one-GPU box (not a measurement): every rank on device 0, gloo instead of RCCL
+    rehearsal = os.environ.get("KCFX_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -105,7 +109,10 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     # ---- data: same reference on every rank, one sample database per rank -------------------------------
     ncpu = os.cpu_count() or 8
@@ -130,7 +137,8 @@ def main():
     n_win = len(win_begin)
 
     out = torch.zeros(S * n_win * 10, dtype=torch.int32, device=f"cuda:{local_rank}")
-    gathered = [torch.zeros_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
+    cdev = "cpu" if rehearsal else f"cuda:{local_rank}"     # where the tensors of the collectives live
+    gathered = [torch.zeros_like(out, device=cdev) for _ in range(world)] if (world > 1 and rank == 0) else None
     stream = torch.cuda.current_stream()
 
     def step():
@@ -141,7 +149,7 @@ def main():
 
     def final_gather():
         if world > 1:
-            dist.gather(out, gathered, dst=0)      # RCCL over xGMI: 40 B per (window, sample), once per job
+            dist.gather(out.to(cdev), gathered, dst=0)      # RCCL over xGMI: 40 B per (window, sample), once per job
 
     for _ in range(args.warmup):
         step()
@@ -168,8 +176,8 @@ def main():
     kernel_ms, launches = ref.prof_read(reset=True)
     ref.prof_enable(False)
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-    tot = torch.tensor([kmers_per_step], dtype=torch.int64, device=f"cuda:{local_rank}")
+    el = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    tot = torch.tensor([kmers_per_step], dtype=torch.int64, device=cdev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -248,7 +256,9 @@ def main():
                                f"(k=31, counter_size {COUNTER_SIZE}, {meta['db_kmers']} k-mers), {args.window // 1000} kb tiling windows "
                                f"({n_win} windows), -c {args.min_count}",
                    "windows": n_win, "samples_per_gpu": S, "kmers_per_step_per_gpu": kmers_per_step, "db_kmers": meta["db_kmers"],
-                   "parallelism": f"sample-sharded x{world}, no data-path collective, one final RCCL gather of 40 B records" if world > 1 else "single GPU",
+                   "parallelism": (f"sample-sharded x{world}, no data-path collective, one final RCCL gather of 40 B records"
+                                   + (" -- REHEARSAL: all ranks on one GPU over gloo, not a measurement" if rehearsal else ""))
+                   if world > 1 else "single GPU",
                    "table_bytes": int(db.info.table_bytes), "hit_rate": float(res["obs"].sum() / max(1, res["total_kmers"].sum()))},
         "windows_per_s": n_win * S * world * args.steps / elapsed,
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
