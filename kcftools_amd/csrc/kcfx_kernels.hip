@@ -492,8 +492,8 @@ struct K31Shared {
     // The word loop reads code bits up to 64 positions past the tile's last k-mer without clamping (what it reads there
     // only reaches lanes that are invalid anyway): MAX_CHUNKS + 2 chunks cover every such read of a full tile.
     static_assert(2 * (MAX_CHUNKS + 2) > ((2 * (31 + TILE_K - 1) + 31) >> 5) + 4, "code arrays too short for unclamped reads");
-    uint32_t fwx[2 * (MAX_CHUNKS + 2) + 1];                 // [0] is the lead word bits_at may touch
-    uint32_t cwx[2 * (MAX_CHUNKS + 2) + 1];
+    // code words of both strands, interleaved (.x forward, .y complement-swapped): one 8-byte LDS read serves both
+    __attribute__((aligned(8))) uint2 fcx[2 * (MAX_CHUNKS + 2) + 1];   // [0] is the lead word a bit read may touch
     uint32_t vbx[MAX_CHUNKS + 2 + 1];
     __attribute__((aligned(16))) uint4 lines[WAVES][2 * 64]; // DMA layout: line r at 144 r (7 per instruction)
     uint32_t runline[WAVES][65];                            // line index of each run (+1 dummy slot)
@@ -507,10 +507,12 @@ __device__ __forceinline__ int k31_pack_tile(K31Shared& sh, const uint8_t* __res
     const int off = (int)(td.text_off - a0);
     const int nbases = off + td.n_kmers + k - 1;
     const int nchunks = (nbases + 31) >> 5;
-    uint32_t* const s_fw = sh.fwx + 1;
-    uint32_t* const s_cw = sh.cwx + 1;
+    uint2* const s_fc = sh.fcx + 1;
     uint32_t* const s_vb = sh.vbx + 1;
-    if (tid == 0) sh.fwx[0] = sh.cwx[0] = sh.vbx[0] = 0;
+    if (tid == 0) {
+        sh.fcx[0] = make_uint2(0u, 0u);
+        sh.vbx[0] = 0;
+    }
     for (int c = tid; c < nchunks + 2; c += BLOCK) {
         uint32_t f0 = 0, f1 = 0, v0 = 0, v1 = 0;
         if (c < nchunks) {
@@ -519,10 +521,8 @@ __device__ __forceinline__ int k31_pack_tile(K31Shared& sh, const uint8_t* __res
             pack16(x.x, x.y, x.z, x.w, f0, v0);
             pack16(y.x, y.y, y.z, y.w, f1, v1);
         }
-        s_fw[2 * c] = f0;
-        s_fw[2 * c + 1] = f1;
-        s_cw[2 * c] = comp_swap(f0);
-        s_cw[2 * c + 1] = comp_swap(f1);
+        s_fc[2 * c] = make_uint2(f0, comp_swap(f0));
+        s_fc[2 * c + 1] = make_uint2(f1, comp_swap(f1));
         s_vb[c] = (v0 << 16) | v1;
     }
     __syncthreads();
@@ -534,7 +534,8 @@ __device__ __forceinline__ int k31_pack_tile(K31Shared& sh, const uint8_t* __res
 // position and the row scans of the M-mer hashes they give.
 template <bool BOTH>
 struct K31Words {
-    const uint32_t *s_fw, *s_cw, *s_vb;
+    const uint2* s_fc;
+    const uint32_t* s_vb;
     int off, n_kmers, lane, next15;
     uint32_t Fc, Cc, Pc, Sc;
 
@@ -543,16 +544,18 @@ struct K31Words {
         return mhash32(((uint64_t)min(f0, brev32(c0))) << 32);
     }
     __device__ __forceinline__ void start(const K31Shared& sh, int off_, int n_kmers_, int lane_, int w_begin) {
-        s_fw = sh.fwx + 1;
-        s_cw = sh.cwx + 1;
+        s_fc = sh.fcx + 1;
         s_vb = sh.vbx + 1;
         off = off_;
         n_kmers = n_kmers_;
         lane = lane_;
         next15 = ((lane + 15) & 63) << 2;                   // ds_bpermute address of lane + 15 (mod 64)
         const int q = off + w_begin * 64 + lane;
-        Fc = bits_at(s_fw, 2 * q);
-        Cc = bits_at(s_cw, 2 * q);
+        const int b0 = 2 * q - 1, w0 = b0 >> 5;              // bits_at(., 2q) on both strands at once
+        const uint32_t sh0 = 31u - (uint32_t)(b0 & 31);
+        const uint2 x = s_fc[w0], y = s_fc[w0 + 1];
+        Fc = alignbit32(x.x, y.x, sh0);
+        Cc = alignbit32(x.y, y.y, sh0);
         row_scan_min(mmer_of(Fc, Cc), Pc, Sc);
     }
     // word w (call with consecutive w): key, minimizer, validity
@@ -565,10 +568,11 @@ struct K31Words {
         const int wi = b >> 5;
         const uint32_t sh = 31u - (uint32_t)(b & 31);
         constexpr uint32_t lo_mask = ~0u << (64 - 2 * k);
-        const uint32_t f1 = alignbit32(s_fw[wi], s_fw[wi + 1], sh) & lo_mask;
-        const uint32_t c1 = alignbit32(s_cw[wi], s_cw[wi + 1], sh) & lo_mask;
-        const uint32_t Fn = alignbit32(s_fw[wi + 3], s_fw[wi + 4], sh);
-        const uint32_t Cn = alignbit32(s_cw[wi + 3], s_cw[wi + 4], sh);
+        const uint2 x0 = s_fc[wi], x1 = s_fc[wi + 1], x3 = s_fc[wi + 3], x4 = s_fc[wi + 4];
+        const uint32_t f1 = alignbit32(x0.x, x1.x, sh) & lo_mask;
+        const uint32_t c1 = alignbit32(x0.y, x1.y, sh) & lo_mask;
+        const uint32_t Fn = alignbit32(x3.x, x4.x, sh);
+        const uint32_t Cn = alignbit32(x3.y, x4.y, sh);
         uint32_t Pn, Sn;
         row_scan_min(mmer_of(Fn, Cn), Pn, Sn);
         // extract_kmer (kcfx_device.h) from the four halves
