@@ -311,11 +311,25 @@ int32_t table_alloc(kcfx_db* db, int64_t n_keys, int32_t counter_size) {
     db->info.table_mode = db->mode;
     db->info.minimizer_length = db->mode == MODE_MINIMIZER ? db->mm_len : 0;
     const int slots = db->wide ? SLOTS_U32 : SLOTS_U16;
-    double want = (double)n_keys / (slots * table_load_factor(n_keys, slots));
-    if (want < 64) want = 64;
-    if (want > 4294967295.0) return fail(KCFX_ERR_ARG, "database too large for a 32-bit line index");
-    db->n_lines = (uint32_t)want + 1;
-    KCFX_HIP(hipMalloc(&db->d_lines, (size_t)db->n_lines * LINE_BYTES));
+    // the policy's load factor first; if the device cannot give that much memory after all, denser tables before giving up
+    const double first = table_load_factor(n_keys, slots);
+    const double tries[4] = {first, 0.35, 0.6, 0.85};
+    hipError_t e = hipErrorOutOfMemory;
+    for (int i = 0; i < 4 && e != hipSuccess; ++i) {
+        if (i > 0 && tries[i] <= first) continue;           // only ever denser than the first attempt
+        double want = (double)n_keys / (slots * tries[i]);
+        if (want < 64) want = 64;
+        if (want > 4294967295.0) return fail(KCFX_ERR_ARG, "database too large for a 32-bit line index");
+        db->n_lines = (uint32_t)want + 1;
+        e = hipMalloc(&db->d_lines, (size_t)db->n_lines * LINE_BYTES);
+        if (e == hipErrorOutOfMemory) {
+            (void)hipGetLastError();
+            db->d_lines = nullptr;
+            continue;
+        }
+        break;
+    }
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc of the k-mer table");
     KCFX_HIP(launch_table_clear(db->d_lines, db->n_lines, db->wide, db->stream));
     db->info.table_bytes = (int64_t)db->n_lines * LINE_BYTES;
     db->info.table_lines = db->n_lines;
