@@ -171,7 +171,7 @@ def test_eight_samples_in_one_pass(oracle, genome):
 def test_wheat_scale_reference(oracle, genome):
     """configs[4] shape on the reference side: a KCFX_HUGE-base text (the 119 Mb genome repeated with 0.5 % point mutations),
     50 kb tiling windows (290 k for 14.5 Gb), against the 150 M-k-mer database; sampled windows against the oracle.
-    Measured on an MI355X: 14.5 Gb -> 4.4 s upload, 103 ms per screening call = 139 G k-mers/s."""
+    Measured on an MI355X: 14.5 Gb -> 4.4 s upload, 86 ms per screening call = 167 G k-mers/s."""
     L = int(float(os.environ["KCFX_HUGE"]))
     rng = np.random.default_rng(7)
     base = np.frombuffer(genome["text"], dtype=np.uint8)
