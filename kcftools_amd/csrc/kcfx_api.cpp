@@ -205,8 +205,14 @@ struct kcfx_db {
     int32_t wide = 0;
     int32_t mode = MODE_MINIMIZER;
     int32_t mm_len = 0;
+    int32_t generic = 0;                 // KCFX_GENERIC_KERNEL at open time: screen with the general kernel
+    int32_t fmt = FORMAT_LINES;          // FORMAT_CELLS: d_lines holds 1 << lbits cell lines, d_stash the overflow k-mers
+    int32_t lbits = 0;
+    uint4* d_stash = nullptr;
+    uint32_t stash_mask = 0;
+    unsigned long long* d_stats = nullptr;   // FORMAT_CELLS build counters (cells_insert_kernel)
     hipStream_t stream = nullptr;
-    TableView view() const { return TableView{d_lines, n_lines, wide, mode, mm_len}; }
+    TableView view() const { return TableView{d_lines, n_lines, wide, mode, mm_len, fmt, lbits, stash_mask, d_stash, generic}; }
 };
 
 struct kcfx_ref {
@@ -304,7 +310,83 @@ int32_t minimizer_len(int32_t k, int64_t n_keys) {
     return std::max(1, std::min(m, std::min(k, 32)));
 }
 
+// FORMAT_CELLS (kcfx_internal.h) is what the BASELINE configuration gets: k = 31, both strands, counters of at most 2
+// bytes, minimizer bucketing. KCFX_TABLE_FORMAT=lines keeps the 12-slot line table (A/B and test hook, read at open time).
+bool cells_eligible(const kcfx_db* db, int32_t counter_size) {
+    const char* s = getenv("KCFX_TABLE_FORMAT");
+    if (s && !strcmp(s, "lines")) return false;
+    return db->info.kmer_length == 31 && db->info.both_strands && counter_size <= 2 && table_mode() == MODE_MINIMIZER &&
+           minimizer_len(31, 0) == 16;
+}
+
+// 2^lbits lines of 16 cells. The sparser the table the fewer k-mers find their cell taken and go to the stash (bench
+// workload, 150 M k-mers: 9.7 % at 2^26 lines, 6.2 % at 2^27), and every stash lookup is a random 16-byte fetch of its own:
+// aim at ~0.075 k-mers per cell while that stays under 48 GiB and 50 % of the free memory, else halve down to ~1 per cell.
+// KCFX_TABLE_LBITS overrides.
+int32_t cells_lbits(int64_t n_keys) {
+    const char* s = getenv("KCFX_TABLE_LBITS");
+    if (s && atoi(s) >= CELL_LBITS_MIN && atoi(s) <= CELL_LBITS_MAX) return atoi(s);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)256 << 30;
+    const double room = std::min(48.0 * (double)(1ull << 30), 0.5 * (double)free_b);
+    int32_t L = CELL_LBITS_MIN;
+    while (L < CELL_LBITS_MAX && 16.0 * (double)(1ull << L) * 0.075 < (double)n_keys) ++L;
+    while (L > CELL_LBITS_MIN && (double)(1ull << L) * LINE_BYTES > room && 16.0 * (double)(1ull << (L - 1)) >= (double)n_keys) --L;
+    return L;
+}
+
+int32_t cells_alloc(kcfx_db* db, int64_t n_keys) {
+    db->fmt = FORMAT_CELLS;
+    db->wide = 0;
+    db->mode = MODE_MINIMIZER;
+    db->mm_len = 16;
+    db->info.table_mode = MODE_MINIMIZER;
+    db->info.minimizer_length = 16;
+    db->info.table_format = FORMAT_CELLS;
+    hipError_t e = hipErrorOutOfMemory;
+    for (int32_t L = cells_lbits(n_keys); L >= CELL_LBITS_MIN; --L) {
+        e = hipMalloc(&db->d_lines, (size_t)LINE_BYTES << L);
+        if (e == hipErrorOutOfMemory) {                     // denser tables before giving up
+            (void)hipGetLastError();
+            db->d_lines = nullptr;
+            continue;
+        }
+        db->lbits = L;
+        break;
+    }
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc of the k-mer table");
+    db->n_lines = 1u << db->lbits;
+    KCFX_HIP(hipMemsetAsync(db->d_lines, 0, (size_t)LINE_BYTES << db->lbits, db->stream));
+    KCFX_HIP(hipMalloc(&db->d_stats, 4 * sizeof(unsigned long long)));
+    KCFX_HIP(hipMemsetAsync(db->d_stats, 0, 4 * sizeof(unsigned long long), db->stream));
+    db->info.table_bytes = (int64_t)LINE_BYTES << db->lbits;
+    db->info.table_lines = db->n_lines;
+    db->info.slots_per_line = 16;
+    return KCFX_OK;
+}
+
+// between the two build passes of a FORMAT_CELLS table: read how many k-mers lost their cell, size and clear the stash
+int32_t cells_stash_alloc(kcfx_db* db) {
+    unsigned long long h[4] = {0, 0, 0, 0};
+    KCFX_HIP(hipMemcpyAsync(h, db->d_stats, sizeof h, hipMemcpyDeviceToHost, db->stream));
+    KCFX_HIP(hipStreamSynchronize(db->stream));
+    db->info.stash_kmers = (int64_t)h[0];
+    db->info.stored_kmers = (int64_t)h[1];
+    db->info.multi_cell_kmers = (int64_t)h[2];
+    uint64_t slots = 1024;                                  // load <= 0.25: ~1.2 entries looked at per lookup
+    while (slots < 4 * h[0]) slots <<= 1;
+    if (slots > (1ull << 32)) return fail(KCFX_ERR_ARG, "stash too large for a 32-bit slot index");
+    db->stash_mask = (uint32_t)(slots - 1);
+    KCFX_HIP(hipMalloc(&db->d_stash, (size_t)slots * sizeof(uint4)));
+    KCFX_HIP(hipMemsetAsync(db->d_stash, 0xFF, (size_t)slots * sizeof(uint4), db->stream));
+    db->info.stash_bytes = (int64_t)(slots * sizeof(uint4));
+    db->info.table_bytes += db->info.stash_bytes;
+    return KCFX_OK;
+}
+
 int32_t table_alloc(kcfx_db* db, int64_t n_keys, int32_t counter_size) {
+    db->generic = getenv("KCFX_GENERIC_KERNEL") != nullptr;   // A/B and test hook: read when the handle is made, never per launch
+    if (cells_eligible(db, counter_size) && !db->generic) return cells_alloc(db, n_keys);
     db->wide = counter_size > 2 ? 1 : 0;
     db->mode = table_mode();
     db->mm_len = minimizer_len(db->info.kmer_length, n_keys);
@@ -339,6 +421,12 @@ int32_t table_alloc(kcfx_db* db, int64_t n_keys, int32_t counter_size) {
 
 // table_finalize + statistics (heavy / overflowed line counts) into db->info
 int32_t table_finish(kcfx_db* db) {
+    if (db->fmt == FORMAT_CELLS) {
+        KCFX_HIP(hipStreamSynchronize(db->stream));
+        if (db->d_stats) (void)hipFree(db->d_stats);
+        db->d_stats = nullptr;
+        return KCFX_OK;
+    }
     unsigned long long* d_stats = nullptr;
     unsigned long long h_stats[2] = {0, 0};
     KCFX_HIP(hipMalloc(&d_stats, sizeof h_stats));
@@ -358,6 +446,8 @@ void db_free(kcfx_db* db) {
     DeviceGuard g(db->device);
     if (db->stream) (void)hipStreamSynchronize(db->stream);   // shared per device (db_stream), never destroyed
     if (db->d_lines) (void)hipFree(db->d_lines);
+    if (db->d_stash) (void)hipFree(db->d_stash);
+    if (db->d_stats) (void)hipFree(db->d_stats);
     delete db;
 }
 
@@ -440,6 +530,7 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
             return rc;                                  \
         }                                               \
     } while (0)
+    const bool cells = (db->fmt == FORMAT_CELLS);
     const bool two_phase = (db->mode == MODE_MINIMIZER);
     // keep every decoded record resident between the phases?
     size_t free_b = 0, total_b = 0;
@@ -480,7 +571,11 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
             uint32_t* counts = d_counts + (keep ? first : 0);
             LOAD_HIP(launch_decode_records(d_rec[turn], first, n, h.record_size, h.suffix_bytes, h.counter_size, h.p, d_lut,
                                            h.lut_entries, keys, counts, db->stream));
-            if (phase == 0)
+            if (cells && phase == 0)
+                LOAD_HIP(launch_cells_insert(db->d_lines, db->lbits, keys, counts, n, db->d_stats, db->stream));
+            else if (cells)
+                LOAD_HIP(launch_cells_stash(db->d_lines, db->lbits, keys, counts, n, db->d_stash, db->stash_mask, db->stream));
+            else if (phase == 0)
                 LOAD_HIP(launch_table_count(db->d_lines, db->view(), h.k, keys, n, db->stream));
             else
                 LOAD_HIP(launch_table_insert(db->d_lines, db->view(), h.k, keys, counts, n, db->stream));
@@ -495,12 +590,24 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     } else {
         if ((rc = stream_file(0, resident))) return rc;
         tr.mark("file -> decode -> count (host)");
-        LOAD_HIP(launch_table_mark_heavy(db->d_lines, db->n_lines, db->stream));
+        if (cells) {
+            if ((rc = cells_stash_alloc(db))) {
+                cleanup();
+                return rc;
+            }
+            tr.mark("stash alloc");
+        } else {
+            LOAD_HIP(launch_table_mark_heavy(db->d_lines, db->n_lines, db->stream));
+        }
         if (resident) {
             // second phase straight from HBM, in launches of at most 2^30 records
             for (int64_t first = 0; first < h.total; first += (1ll << 30)) {
                 const int64_t n = std::min<int64_t>(1ll << 30, h.total - first);
-                LOAD_HIP(launch_table_insert(db->d_lines, db->view(), h.k, d_keys + first, d_counts + first, n, db->stream));
+                if (cells)
+                    LOAD_HIP(launch_cells_stash(db->d_lines, db->lbits, d_keys + first, d_counts + first, n, db->d_stash,
+                                                db->stash_mask, db->stream));
+                else
+                    LOAD_HIP(launch_table_insert(db->d_lines, db->view(), h.k, d_keys + first, d_counts + first, n, db->stream));
             }
         } else {
             LOAD_HIP(hipStreamSynchronize(db->stream));
@@ -612,13 +719,24 @@ int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, 
         }
         if ((e = hipMalloc(&d_keys, (size_t)n * 8)) != hipSuccess || (e = hipMalloc(&d_counts, (size_t)n * 4)) != hipSuccess ||
             (e = hipMemcpyAsync(d_keys, kmers, (size_t)n * 8, hipMemcpyHostToDevice, db->stream)) != hipSuccess ||
-            (e = hipMemcpyAsync(d_counts, src, (size_t)n * 4, hipMemcpyHostToDevice, db->stream)) != hipSuccess ||
-            (e = launch_table_count(db->d_lines, db->view(), kmer_length, d_keys, n, db->stream)) != hipSuccess ||
-            (db->mode == MODE_MINIMIZER && (e = launch_table_mark_heavy(db->d_lines, db->n_lines, db->stream)) != hipSuccess) ||
-            (e = launch_table_insert(db->d_lines, db->view(), kmer_length, d_keys, d_counts, n, db->stream)) != hipSuccess ||
-            (e = hipStreamSynchronize(db->stream)) != hipSuccess)
-            rc = hip_fail(e, "kcfx_db_build upload/insert");
+            (e = hipMemcpyAsync(d_counts, src, (size_t)n * 4, hipMemcpyHostToDevice, db->stream)) != hipSuccess)
+            rc = hip_fail(e, "kcfx_db_build upload");
+        if (!rc && db->fmt == FORMAT_CELLS) {
+            if ((e = launch_cells_insert(db->d_lines, db->lbits, d_keys, d_counts, n, db->d_stats, db->stream)) != hipSuccess)
+                rc = hip_fail(e, "kcfx_db_build insert");
+            if (!rc) rc = cells_stash_alloc(db);
+            if (!rc && ((e = launch_cells_stash(db->d_lines, db->lbits, d_keys, d_counts, n, db->d_stash, db->stash_mask, db->stream)) != hipSuccess ||
+                        (e = hipStreamSynchronize(db->stream)) != hipSuccess))
+                rc = hip_fail(e, "kcfx_db_build stash");
+        } else if (!rc) {
+            if ((e = launch_table_count(db->d_lines, db->view(), kmer_length, d_keys, n, db->stream)) != hipSuccess ||
+                (db->mode == MODE_MINIMIZER && (e = launch_table_mark_heavy(db->d_lines, db->n_lines, db->stream)) != hipSuccess) ||
+                (e = launch_table_insert(db->d_lines, db->view(), kmer_length, d_keys, d_counts, n, db->stream)) != hipSuccess ||
+                (e = hipStreamSynchronize(db->stream)) != hipSuccess)
+                rc = hip_fail(e, "kcfx_db_build insert");
+        }
     }
+    if (!rc && n == 0 && db->fmt == FORMAT_CELLS) rc = cells_stash_alloc(db);
     if (!rc) rc = table_finish(db);
     if (d_keys) (void)hipFree(d_keys);
     if (d_counts) (void)hipFree(d_counts);

@@ -180,6 +180,100 @@ KCFX_HD bool probe_next(const TableView& tv, bool at_home, bool found, uint32_t 
     return true;
 }
 
+// ---- FORMAT_CELLS (kcfx_internal.h): k = 31, M = 16 --------------------------------------------------
+// 27-bit hash of a canonical 16-mer, top-aligned (low 5 bits zero). For every fixed (cm & 31) it is a bijection of
+// cm >> 5: cm * odd = 32 (a * odd + q(b)) + r(b) for cm = 32 a + b, the right xorshift and the second odd multiply act
+// bijectively on the top 27 bits once the low 5 are cleared. Low -> high diffusion only: the ORDER of the values picks the
+// minimizer and the top bits pick the line.
+KCFX_HD uint32_t mm27(uint32_t cm) {
+    uint32_t u = cm * 0x9E3779B1u;
+    u ^= u >> 15;
+    u &= ~31u;
+    return u * 0x85EBCA6Bu;
+}
+// What one lane feeds into the sliding minimum: hash | strand bit (bit 4: the canonical form is the reverse complement of
+// the 16-mer as the text reads it) | position label (bits 3..0, distinct within any 16 consecutive positions). The minimum
+// therefore carries where the minimizer sits and which way round it is.
+KCFX_HD uint32_t mm27_tagged(uint32_t fwd_m, uint32_t rc_m, uint32_t label) {
+    const uint32_t cm = fwd_m < rc_m ? fwd_m : rc_m;
+    return mm27(cm) | (rc_m < fwd_m ? 16u : 0u) | label;
+}
+// minimum hash (low 5 bits ignored) + the low 5 bits of the minimizer itself -> G32: line = top lbits, r = the rest.
+// The minimum of 16 hashes is skewed towards 0, hence the odd multiply (a bijection on the top 27 bits).
+KCFX_HD uint32_t cell_g32(uint32_t min_hash, uint32_t cm) { return ((min_hash & ~31u) * 0xC2B2AE35u) | (cm & 31u); }
+
+// the 15 bases of N around the 16-mer at base offset sh / 2, left-aligned (low 2 bits zero); *m_out = that 16-mer
+KCFX_HD uint32_t cell_flank(uint64_t N, uint32_t sh, uint32_t* m_out) {
+    const uint64_t t = N << sh;
+    const uint32_t keep = 0xFFFFFFFFu >> sh;                  // bits that come from behind the 16-mer
+    *m_out = (uint32_t)(t >> 32);
+    return (keep & ((uint32_t)t >> sh)) | (~keep & (uint32_t)(N >> 32));
+}
+
+struct CellProbe {
+    uint32_t line;      // top lbits of G32
+    uint32_t sh;        // 2 * cell index (= byte offset of the cell's r / count; w is at 2 * sh)
+    uint32_t w;         // flank bits (flag bits clear)
+    uint32_t r;         // low 32 - lbits bits of G32
+};
+
+// Query side, one lane: F / R = the k-mer as the text reads it and its reverse complement, mn = the tagged minimum over
+// the k-mer's 16 M-mers, lane = this lane's position label base (mm27_tagged was fed (lane + offset) & 15).
+KCFX_HD CellProbe cell_probe_of(uint64_t F, uint64_t R, uint32_t mn, uint32_t lane, int32_t lbits) {
+    const bool flip = (mn & 16u) != 0;                        // the minimizer is canonical on the other strand
+    const uint64_t N = flip ? R : F;
+    uint32_t sh = ((mn - lane) << 1) & 30u;                   // 2 * offset of the minimizer in F
+    sh ^= flip ? 30u : 0u;                                    // in R it sits at 15 - offset
+    CellProbe p;
+    uint32_t cm;
+    p.w = cell_flank(N, sh, &cm);
+    const uint32_t g = cell_g32(mn, cm);
+    p.sh = sh;
+    p.line = g >> (32 - lbits);
+    p.r = g & (0xFFFFFFFFu >> lbits);
+    return p;
+}
+
+KCFX_HD uint32_t rc16(uint32_t m) { return brev32(comp_swap(m)); }
+
+// Build side: every cell a stored canonical 31-mer C must be findable in. Normally one; several when the minimum hash
+// is attained at more than one offset (a repeated 16-mer, or two 16-mers that agree in their leading 27 hash bits --
+// the query's tie-break depends on the k-mer's alignment in the text, so every tied offset gets a copy), two per offset
+// when the 16-mer is its own reverse complement (either strand may be the one the text reads).
+constexpr int CELL_MAX_CANDS = 32;
+KCFX_HD int cells_of_key(uint64_t C, int32_t lbits, CellProbe* out) {
+    const uint64_t Rc = revcomp_word(C, 31);
+    uint32_t best = 0xFFFFFFFFu;
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t m = (uint32_t)((C << (2 * j)) >> 32), r = rc16(m);
+        const uint32_t h = mm27(m < r ? m : r);
+        best = h < best ? h : best;
+    }
+    int n = 0;
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t m = (uint32_t)((C << (2 * j)) >> 32), r = rc16(m);
+        const uint32_t cm = m < r ? m : r;
+        if (mm27(cm) != best) continue;
+        for (int strand = 0; strand < 2; ++strand) {
+            // strand 0: N = C (needs m canonical), strand 1: N = revcomp(C) (needs rc(m) canonical)
+            if (strand == 0 ? (m > r) : (r > m)) continue;
+            const uint64_t N = strand ? Rc : C;
+            const uint32_t sh = 2u * (uint32_t)(strand ? 15 - j : j);
+            CellProbe p;
+            uint32_t got;
+            p.w = cell_flank(N, sh, &got);
+            const uint32_t g = cell_g32(best, cm);
+            p.sh = sh;
+            p.line = g >> (32 - lbits);
+            p.r = g & (0xFFFFFFFFu >> lbits);
+            out[n++] = p;
+        }
+    }
+    return n;
+}
+
+KCFX_HD uint32_t stash_slot(uint64_t key, uint32_t mask) { return hash32(key) & mask; }
+
 // ---- one 128-byte line against one key ----------------------------------------------------------------
 // q[0..7] = the line as eight 16-byte pieces. Empty slots hold EMPTY_KEY (all ones), which no k-mer word with
 // k < 32 can equal (its low 2*(32-k) bits are zero); CHECK_NS additionally masks slots >= the occupied count and

@@ -42,12 +42,41 @@ constexpr uint32_t HEAVY_KEYS = 4 * SLOTS_U16;
 constexpr uint32_t BUILD_COUNT_MASK = 0x00FFFFFFu, BUILD_HEAVY = 0x80000000u;
 constexpr int MODE_KEYHASH = 0, MODE_MINIMIZER = 1;
 
+// ----------------------------------------------------------------------------------------------------
+// FORMAT_CELLS (k = 31, both-strands databases, counters of at most 2 bytes -- the BASELINE.json configuration):
+// the line a k-mer lives in is still chosen by its minimizer (M = 16), but INSIDE the line the k-mer has exactly one
+// cell: cell index = offset of the minimizer in the k-mer, read on the strand where the minimizer 16-mer is in
+// canonical form ("N orientation"). The 16 k-mers that can share a minimizer occurrence have 16 distinct offsets, so a
+// run of consecutive reference k-mers maps onto distinct cells of ONE line and a probe is one 4-byte + two 2-byte LDS
+// reads and two compares instead of a 12-way 64-bit compare. A cell holds a quotiented key, exact by construction:
+//
+//   128-byte line = 16 x u32 w | 16 x u16 r | 16 x u16 count
+//     w     = the 30 flank bits (the 15 bases of N around the minimizer, left-aligned) | bit 0: some k-mer that maps
+//             to this cell lives in the stash | bit 1: reserved
+//     r     = low (32 - lbits) bits of G32 = (27-bit minimizer hash, re-spread) : (minimizer & 31); the line number is
+//             the top lbits of G32, and G32 <-> canonical minimizer 16-mer is a bijection (cell_g32)
+//     count = the stored counter; 0 = empty cell (a k-mer whose counter is 0 can never be observed -- GetVariants.java:224
+//             needs count >= -c >= 1 -- so it is not stored)
+//   (line, cell, w, r) -> N -> canonical k-mer is injective, so equality of (w, r) in the k-mer's cell IS equality of
+//   the k-mer. K-mers that find their cell taken go to the stash: open addressing over 16-byte entries
+//   {u64 key, u32 count, u32 pad}, slot = hash32(key) & mask, probed by the lanes individually.
+// ----------------------------------------------------------------------------------------------------
+constexpr int FORMAT_LINES = 0, FORMAT_CELLS = 1;
+constexpr int CELL_LBITS_MIN = 16, CELL_LBITS_MAX = 31;     // r must fit 16 bits; n_lines fits 32
+constexpr int CELL_R_OFF = 64, CELL_C_OFF = 96;             // byte offsets of the r and count arrays in a line
+constexpr uint32_t CELL_FLAG_STASH = 1u, CELL_FLAG_MASK = 3u;
+
 struct TableView {
     const uint8_t* lines;
     uint32_t n_lines;
     int32_t wide;        // 0: LAYOUT_U16, 1: LAYOUT_U32
     int32_t mode;        // MODE_KEYHASH / MODE_MINIMIZER
     int32_t mm_len;      // M (minimizer length, <= min(k, 32)); unused in MODE_KEYHASH
+    int32_t fmt;         // FORMAT_LINES (above) / FORMAT_CELLS
+    int32_t lbits;       // FORMAT_CELLS: n_lines == 1 << lbits
+    uint32_t stash_mask; // FORMAT_CELLS: stash slots - 1 (a power of two)
+    const uint4* stash;
+    int32_t generic;     // screen with the general kernel whatever k / M (test and A/B hook, fixed when the handle is made)
 };
 
 // ----------------------------------------------------------------------------------------------------
@@ -174,6 +203,11 @@ hipError_t launch_table_mark_heavy(uint8_t* lines, uint32_t n_lines, hipStream_t
 hipError_t launch_table_insert(uint8_t* lines, TableView tv, int32_t k, const uint64_t* keys,
                                const uint32_t* counts, int64_t n, hipStream_t st);
 hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide, unsigned long long* stats, hipStream_t st);
+// FORMAT_CELLS build: pass 1 claims cells and counts the k-mers that need the stash (stats[0]); pass 2 fills the stash
+hipError_t launch_cells_insert(uint8_t* lines, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n,
+                               unsigned long long* stats, hipStream_t st);
+hipError_t launch_cells_stash(const uint8_t* lines, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n,
+                              uint4* stash, uint32_t stash_mask, hipStream_t st);
 // lookup
 hipError_t launch_lookup(TableView tv, int32_t k, const uint64_t* keys, int64_t n, int32_t* counts_out, hipStream_t st);
 // screen

@@ -171,6 +171,126 @@ __global__ __launch_bounds__(256) void lookup_kernel(TableView tv, int32_t k, co
     }
 }
 
+
+// ======================================================================================================
+// FORMAT_CELLS build + lookup (layout and exactness argument: kcfx_internal.h; cell derivation: kcfx_device.h)
+// ======================================================================================================
+// Pass 1: every stored k-mer claims its cell(s); the first arrival wins (16-bit count != 0 marks a taken cell, claimed
+// with a CAS on the dword holding the count pair), later ones flag the cell and are counted for the stash.
+// stats[0] = k-mers that need the stash, stats[1] = k-mers stored (count != 0), stats[2] = k-mers with more than one cell
+__global__ void cells_insert_kernel(uint8_t* lines, int32_t lbits, const uint64_t* __restrict__ keys,
+                                    const uint32_t* __restrict__ counts, int64_t n, unsigned long long* stats) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const uint32_t c = counts[i] & 0xFFFFu;
+        if (c == 0) continue;                       // can never be observed (count >= -c >= 1 is needed): not stored
+        CellProbe cand[CELL_MAX_CANDS];
+        const int nc = cells_of_key(keys[i], lbits, cand);
+        bool lost = false;
+        for (int a = 0; a < nc; ++a) {
+            uint8_t* base = lines + (size_t)cand[a].line * LINE_BYTES;
+            const uint32_t cell = cand[a].sh >> 1, shift = (cell & 1u) * 16u;
+            uint32_t* cw = reinterpret_cast<uint32_t*>(base + CELL_C_OFF) + (cell >> 1);
+            uint32_t old = __atomic_load_n(cw, __ATOMIC_RELAXED);
+            bool won = false;
+            for (;;) {
+                if ((old >> shift) & 0xFFFFu) break;
+                const uint32_t prev = atomicCAS(cw, old, old | (c << shift));
+                if (prev == old) {
+                    won = true;
+                    break;
+                }
+                old = prev;
+            }
+            uint32_t* ww = reinterpret_cast<uint32_t*>(base) + cell;
+            if (won) {
+                atomicOr(ww, cand[a].w);
+                atomicOr(reinterpret_cast<uint32_t*>(base + CELL_R_OFF) + (cell >> 1), cand[a].r << shift);
+            } else {
+                atomicOr(ww, CELL_FLAG_STASH);
+                lost = true;
+            }
+        }
+        if (lost) atomicAdd(&stats[0], 1ull);
+        atomicAdd(&stats[1], 1ull);
+        if (nc > 1) atomicAdd(&stats[2], 1ull);
+    }
+}
+
+// Pass 2 (after pass 1 has completed): a k-mer that does not find itself in every one of its cells goes to the stash.
+__global__ void cells_stash_kernel(const uint8_t* __restrict__ lines, int32_t lbits, const uint64_t* __restrict__ keys,
+                                   const uint32_t* __restrict__ counts, int64_t n, uint4* stash, uint32_t mask) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const uint32_t c = counts[i] & 0xFFFFu;
+        if (c == 0) continue;
+        const uint64_t key = keys[i];
+        CellProbe cand[CELL_MAX_CANDS];
+        const int nc = cells_of_key(key, lbits, cand);
+        bool lost = false;
+        for (int a = 0; a < nc; ++a) {
+            const uint8_t* base = lines + (size_t)cand[a].line * LINE_BYTES;
+            const uint32_t sh = cand[a].sh;
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(base + 2 * sh);
+            const uint32_t r = *reinterpret_cast<const uint16_t*>(base + CELL_R_OFF + sh);
+            const uint32_t cc = *reinterpret_cast<const uint16_t*>(base + CELL_C_OFF + sh);
+            lost |= !(((w ^ cand[a].w) <= CELL_FLAG_MASK) && r == cand[a].r && cc == c);
+        }
+        if (!lost) continue;
+        uint32_t slot = stash_slot(key, mask);
+        for (;;) {
+            unsigned long long* kp = reinterpret_cast<unsigned long long*>(stash + slot);
+            const unsigned long long prev = atomicCAS(kp, (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+            if (prev == EMPTY_KEY) {
+                reinterpret_cast<uint32_t*>(kp)[2] = c;
+                break;
+            }
+            if (prev == key) break;                 // the same word twice in the input
+            slot = (slot + 1) & mask;
+        }
+    }
+}
+
+// stored counter of `key` in the stash, 0 when absent
+__device__ __forceinline__ uint32_t stash_find(const TableView& tv, uint64_t key) {
+    uint32_t slot = stash_slot(key, tv.stash_mask);
+    for (;;) {
+        const uint4 e = tv.stash[slot];
+        const uint64_t ek = u64_of(e.x, e.y);
+        if (ek == key) return e.z;
+        if (ek == EMPTY_KEY) return 0u;
+        slot = (slot + 1) & tv.stash_mask;
+    }
+}
+
+// batched KMC.getCount on a FORMAT_CELLS table, one lane per key (utility path)
+__global__ __launch_bounds__(256) void lookup_cells_kernel(TableView tv, const uint64_t* __restrict__ keys, int64_t n,
+                                                           int32_t* __restrict__ out) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const uint64_t key = keys[i];
+        int32_t result = 0;
+        // only canonical words are stored (both-strands database); a k = 31 word has its low two bits clear
+        if (key <= revcomp_word(key, 31) && (key & 3ull) == 0) {
+            CellProbe cand[CELL_MAX_CANDS];
+            cells_of_key(key, tv.lbits, cand);                  // any one of its cells decides
+            const uint8_t* base = tv.lines + (size_t)cand[0].line * LINE_BYTES;
+            const uint32_t sh = cand[0].sh;
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(base + 2 * sh);
+            const uint32_t r = *reinterpret_cast<const uint16_t*>(base + CELL_R_OFF + sh);
+            const uint32_t c = *reinterpret_cast<const uint16_t*>(base + CELL_C_OFF + sh);
+            if (((w ^ cand[0].w) <= CELL_FLAG_MASK) && r == cand[0].r)
+                result = (int32_t)c;
+            else if (w & CELL_FLAG_STASH)
+                result = (int32_t)stash_find(tv, key);
+        }
+        out[i] = result;
+    }
+}
+
 // ======================================================================================================
 // screening: wave-level helpers
 // ======================================================================================================
@@ -532,16 +652,19 @@ __device__ __forceinline__ int k31_pack_tile(K31Shared& sh, const uint8_t* __res
 // The words of a tile as one wave sees them: canonical key, minimizer and validity ballot of 64 consecutive positions per
 // step, everything in registers. Carried from one word to the next: the leading code words of both strands at this lane's
 // position and the row scans of the M-mer hashes they give.
-template <bool BOTH>
+template <bool CELLS>
 struct K31Words {
     const uint2* s_fc;
     const uint32_t* s_vb;
     int off, n_kmers, lane, next15;
     uint32_t Fc, Cc, Pc, Sc;
 
-    // canonical 16-mer hash from the leading 32 code bits of both strands
-    static __device__ __forceinline__ uint32_t mmer_of(uint32_t f0, uint32_t c0) {
-        return mhash32(((uint64_t)min(f0, brev32(c0))) << 32);
+    // what a position feeds into the sliding minimum, from the leading 32 code bits of both strands: the hash of its canonical
+    // 16-mer; FORMAT_CELLS tables tag it with the strand and the position (mm27_tagged) so that the minimum also says where
+    // the minimizer sits in each k-mer
+    __device__ __forceinline__ uint32_t mmer_of(uint32_t f0, uint32_t c0) const {
+        if constexpr (CELLS) return mm27_tagged(f0, brev32(c0), (uint32_t)lane & 15u);
+        else return mhash32(((uint64_t)min(f0, brev32(c0))) << 32);
     }
     __device__ __forceinline__ void start(const K31Shared& sh, int off_, int n_kmers_, int lane_, int w_begin) {
         s_fc = sh.fcx + 1;
@@ -558,8 +681,9 @@ struct K31Words {
         Cc = alignbit32(x.y, y.y, sh0);
         row_scan_min(mmer_of(Fc, Cc), Pc, Sc);
     }
-    // word w (call with consecutive w): key, minimizer, validity
-    __device__ __forceinline__ void next(int w, uint64_t& key, uint32_t& mn, uint64_t& V) {
+    // word w (call with consecutive w): the k-mer as the text reads it and its reverse complement (Kmer.java:232-252,
+    // :300-338), the minimum over its 16 M-mers, validity
+    __device__ __forceinline__ void next(int w, uint64_t& fwd, uint64_t& rc, uint32_t& mn, uint64_t& V) {
         constexpr int k = 31;
         const int j = w * 64 + lane;
         const int q = off + j;
@@ -576,13 +700,11 @@ struct K31Words {
         uint32_t Pn, Sn;
         row_scan_min(mmer_of(Fn, Cn), Pn, Sn);
         // extract_kmer (kcfx_device.h) from the four halves
-        const uint64_t fwd = u64_of(f1, Fc);
-        const uint64_t rc = u64_of(brev32(Cc), brev32(c1)) << (64 - 2 * k);
-        // Kmer(Kmer, bothStrands): canonical = min(fwd, revcomp) unsigned (Kmer.java:72-79,406-414)
-        key = (BOTH && rc < fwd) ? rc : fwd;
+        fwd = u64_of(f1, Fc);
+        rc = u64_of(brev32(Cc), brev32(c1)) << (64 - 2 * k);
         // all k bases are A/C/G/T, and the position is a k-mer of this tile
         V = wave_ballot((bits_at(s_vb, q) >> (32 - k)) == (uint32_t)((1ull << k) - 1)) & wave_ballot(j < n_kmers);
-        // minimizer of the k-mer = min over its 16 M-mers = min(S[lane], P[lane + 15])
+        // minimum over the k-mer's 16 M-mers = min(S[lane], P[lane + 15])
         const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(next15, (int)Pc);
         const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute(next15, (int)Pn);
         mn = min(Sc, lane < 49 ? pa : pb);
@@ -668,13 +790,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     static_assert((uint64_t)TILE_WORDS * 64 * 65535 < (1ull << 32), "32-bit count sums");
     typename std::conditional<WIDE, int64_t, uint32_t>::type sum_acc = 0;   // per lane
     uint64_t* my_bits = bits + (size_t)blockIdx.x * TILE_BITS_U64;
-    K31Words<BOTH> words;
+    K31Words<false> words;
     if (w_begin < w_end) words.start(sh, off, td.n_kmers, lane, w_begin);
 
     for (int w = w_begin; w < w_end; ++w) {
-        uint64_t key, V;
+        uint64_t fwd, rc, V;
         uint32_t mn;
-        words.next(w, key, mn, V);
+        words.next(w, fwd, rc, mn, V);
+        // Kmer(Kmer, bothStrands): canonical = min(fwd, revcomp) unsigned (Kmer.java:72-79,406-414)
+        const uint64_t key = (BOTH && rc < fwd) ? rc : fwd;
         uint32_t tgt = line_of_minimizer(mn, tv.n_lines);   // home line, shared by the whole minimizer run
         uint32_t st = (uint32_t)((V >> lane) & 1);          // 1 = pending, 2 = found, 0 = absent / invalid
         uint32_t cnt = 0, meta = 0;
@@ -709,6 +833,145 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     int64_t count_sum;
     if constexpr (WIDE) count_sum = wave_sum_i64(sum_acc);
     else count_sum = (int64_t)wave_sum_u32_dpp(sum_acc);
+    if (lane == 0) sh.sum[wave] = count_sum;
+    __syncthreads();
+    if (tid == 0) {
+        int64_t t = 0;
+#pragma unroll
+        for (int i = 0; i < WAVES; ++i) t += sh.sum[i];
+        count_sums[blockIdx.x] = t;
+    }
+}
+
+// ======================================================================================================
+// screen_k31c: the same tile walk against a FORMAT_CELLS table (k = 31, both strands, counters <= 2 bytes)
+// ======================================================================================================
+// One line per minimizer run as before (same LDS-DMA fetch), but a lane reads exactly ONE cell of its run's line -- the
+// cell numbered by the minimizer's offset in the k-mer -- and compares 32 + 16 quotient bits: 3 LDS reads and 3 compares
+// where screen_k31 runs 8 x ds_read_b128 and 12 x v_cmp_eq_u64 per round, and no second round over lines: a k-mer whose
+// cell is flagged "someone who belongs here lives in the stash" (a few per cent) is queued and looked up in the stash
+// 64 at a time, each lane fetching its own 16-byte entry.
+struct K31CQueue {
+    uint64_t key[K31_QUEUE];
+    uint32_t id[K31_QUEUE];                                 // (word of the wave << 6) | lane
+    unsigned long long hit[K31_WORDS_PER_WAVE];             // hit ballots of the wave's words
+};
+
+// First (and only line-granular) probe of a word. st: 1 on valid lanes. Outputs cnt (0 unless the k-mer is in its cell) and
+// pend (1: not in its cell, and the cell is flagged for the stash).
+__device__ __forceinline__ void probe_cells(const TableView& tv, const K31Fetch& f, uint64_t V, uint32_t st, const CellProbe& p,
+                                            uint32_t& cnt, uint32_t& pend) {
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const uint32_t tgt = p.line;
+    // heads of runs: valid lanes whose predecessor is invalid or aims at another line
+    const uint64_t HM = V & (~(V << 1) | wave_ballot(wave_shr1(tgt) != tgt));
+    const int nruns = __popcll(HM);
+    const uint64_t H1 = HM >> 1;
+    const int my_run = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(H1 >> 32),
+                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)H1, (uint32_t)((int)(HM & 1) - 1)));
+    f.runline[(st == 1u) ? my_run : 64] = tgt;
+    wave_lds_fence();
+    for (int c0 = 0; c0 < nruns; c0 += K31_RUNS) {
+        const int r0 = c0 + f.fetch_run, r1 = r0 + 7;
+        if (f.fetcher && r0 < nruns)
+            __builtin_amdgcn_global_load_lds((gptr_t)(tv.lines + (size_t)f.runline[r0] * LINE_BYTES + 16 * f.piece),
+                                             (lptr_t)f.lines, 16, 0, 0);
+        if (f.fetcher && r1 < nruns)
+            __builtin_amdgcn_global_load_lds((gptr_t)(tv.lines + (size_t)f.runline[r1] * LINE_BYTES + 16 * f.piece),
+                                             (lptr_t)(f.lines + 7 * K31_PITCH), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_lds_fence();
+        const uint32_t rel = (uint32_t)(my_run - c0);
+        const bool mine = (st == 1u) && (rel < (uint32_t)K31_RUNS);
+        const uint8_t* base = reinterpret_cast<const uint8_t*>(f.lines + (mine ? rel : 0u) * K31_PITCH);
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(base + 2 * p.sh);
+        const uint32_t r = *reinterpret_cast<const uint16_t*>(base + CELL_R_OFF + p.sh);
+        const uint32_t c = *reinterpret_cast<const uint16_t*>(base + CELL_C_OFF + p.sh);
+        const bool match = ((w ^ p.w) <= CELL_FLAG_MASK) && (r == p.r);
+        cnt = (mine && match) ? c : cnt;
+        pend = (mine && !match) ? (w & CELL_FLAG_STASH) : pend;
+        wave_lds_fence();
+    }
+}
+
+// Stash lookups for the first min(qn, 64) queued k-mers; returns the new qn.
+__device__ __forceinline__ int k31c_stash_round(const TableView& tv, K31CQueue& q, int lane, int qn, int32_t min_count,
+                                                uint32_t& sum_acc) {
+    const int nb = min(qn, 64), rest = qn - nb;
+    const uint64_t key = q.key[lane];
+    const uint32_t id = q.id[lane];
+    const uint64_t k2 = q.key[64 + lane];
+    const uint32_t i2 = q.id[64 + lane];
+    wave_lds_fence();
+    if (lane < rest) {                                      // the entries behind the batch move to the front
+        q.key[lane] = k2;
+        q.id[lane] = i2;
+    }
+    uint32_t cnt = 0;
+    if (lane < nb) cnt = stash_find(tv, key);
+    const bool hit = (int32_t)cnt >= min_count;             // cnt is 0 unless found; GetVariants.java:224
+    if (hit) atomicOr(&q.hit[id >> 6], 1ull << (id & 63));
+    sum_acc += hit ? cnt : 0u;                              // GetVariants.java:226
+    wave_lds_fence();
+    return rest;
+}
+
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void screen_k31c_kernel(
+    const uint8_t* __restrict__ text, const TileDesc* __restrict__ tiles, TableView tv, int32_t min_count,
+    uint64_t* __restrict__ bits, int64_t* __restrict__ count_sums) {
+    __shared__ K31Shared sh;
+    __shared__ K31CQueue s_queue[WAVES];
+    const TileDesc td = tiles[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int off = k31_pack_tile(sh, text, td, tid);
+
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_words = (td.n_kmers + 63) >> 6;
+    const int wpw = (n_words + WAVES - 1) / WAVES;
+    const int w_begin = min(wave * wpw, n_words);
+    const int w_end = min(w_begin + wpw, n_words);
+    const K31Fetch fetch = fetch_setup(sh.lines[wave], sh.runline[wave], lane);
+    K31CQueue& q = s_queue[wave];
+    int qn = 0;                                             // queued k-mers (wave-uniform)
+
+    uint32_t sum_acc = 0;                                   // per lane; u16 counters: fits (static_assert in screen_k31_kernel)
+    uint64_t* my_bits = bits + (size_t)blockIdx.x * TILE_BITS_U64;
+    K31Words<true> words;
+    if (w_begin < w_end) words.start(sh, off, td.n_kmers, lane, w_begin);
+
+    for (int w = w_begin; w < w_end; ++w) {
+        uint64_t fwd, rc, V;
+        uint32_t mn;
+        words.next(w, fwd, rc, mn, V);
+        const CellProbe p = cell_probe_of(fwd, rc, mn, (uint32_t)lane, tv.lbits);
+        const uint32_t st = (uint32_t)((V >> lane) & 1);
+        uint32_t cnt = 0, pend = 0;
+        if (V) probe_cells(tv, fetch, V, st, p, cnt, pend);
+        // cnt is 0 unless the k-mer was found and min_count >= 1 (checked by the API), so this is "found && count >= -c"
+        const bool hit = (int32_t)cnt >= min_count;                         // GetVariants.java:224
+        const uint64_t H = wave_ballot(hit);
+        if (lane == 0) {
+            my_bits[w] = V;                                                 // validity word of the window's bitmap
+            q.hit[w - w_begin] = H;                                         // hits so far; queued k-mers may add theirs
+        }
+        sum_acc += hit ? cnt : 0u;                                          // GetVariants.java:226
+        const uint64_t PM = wave_ballot(pend != 0u);
+        if (PM) {
+            const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(PM >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)PM, 0u));
+            if (pend != 0u) {
+                q.key[pos] = rc < fwd ? rc : fwd;                           // Kmer(Kmer, bothStrands), Kmer.java:72-79
+                q.id[pos] = (uint32_t)(((w - w_begin) << 6) | lane);
+            }
+            qn += __popcll(PM);
+        }
+        wave_lds_fence();
+        while (qn >= 64) qn = k31c_stash_round(tv, q, lane, qn, min_count, sum_acc);
+    }
+    while (qn > 0) qn = k31c_stash_round(tv, q, lane, qn, min_count, sum_acc);
+    if (lane < w_end - w_begin) my_bits[TILE_WORDS + w_begin + lane] = q.hit[lane];   // hit words of the window's bitmap
+
+    const int64_t count_sum = (int64_t)wave_sum_u32_dpp(sum_acc);
     if (lane == 0) sh.sum[wave] = count_sum;
     __syncthreads();
     if (tid == 0) {
@@ -851,13 +1114,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     int qn = 0;
     if (lane < MULTI_MAX) s_msum[wave][lane] = 0;
     wave_lds_fence();
-    K31Words<BOTH> words;
+    K31Words<false> words;
     if (w_begin < w_end) words.start(sh, off, td.n_kmers, lane, w_begin);
 
     for (int w = w_begin; w < w_end; ++w) {
-        uint64_t key, V;
+        uint64_t fwd, rc, V;
         uint32_t mn;
-        words.next(w, key, mn, V);
+        words.next(w, fwd, rc, mn, V);
+        const uint64_t key = (BOTH && rc < fwd) ? rc : fwd;     // Kmer.java:72-79
         if (lane == 0) {
             for (int s = 0; s < mt.n; ++s) bits[(size_t)s * bits_stride + (size_t)blockIdx.x * TILE_BITS_U64 + w] = V;
         }
@@ -1030,8 +1294,27 @@ hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide,
     return hipGetLastError();
 }
 
+hipError_t launch_cells_insert(uint8_t* lines, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n,
+                               unsigned long long* stats, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(cells_insert_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, lbits, keys, counts, n, stats);
+    return hipGetLastError();
+}
+
+hipError_t launch_cells_stash(const uint8_t* lines, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n,
+                              uint4* stash, uint32_t stash_mask, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(cells_stash_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, lbits, keys, counts, n, stash,
+                       stash_mask);
+    return hipGetLastError();
+}
+
 hipError_t launch_lookup(TableView tv, int32_t k, const uint64_t* keys, int64_t n, int32_t* counts_out, hipStream_t st) {
     if (n <= 0) return hipSuccess;
+    if (tv.fmt == FORMAT_CELLS) {
+        hipLaunchKernelGGL(lookup_cells_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, tv, keys, n, counts_out);
+        return hipGetLastError();
+    }
     const dim3 g(grid_for(n * 8, 256, 256 * 16)), b(256);
     if (tv.wide)
         hipLaunchKernelGGL(lookup_kernel<true>, g, b, 0, st, tv, k, keys, n, counts_out);
@@ -1061,8 +1344,10 @@ hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32
     hipExtLaunchKernelGGL((screen_tiles_kernel<W, MD>), g, b, 0, st, ev_start, ev_stop, 0, text, tiles, tv, k, both_strands, min_count, bits, count_sums)
 #define KCFX_LAUNCH31(W, BS) \
     hipExtLaunchKernelGGL((screen_k31_kernel<W, BS>), g, b, 0, st, ev_start, ev_stop, 0, text, tiles, tv, min_count, bits, count_sums)
-    const bool generic_only = getenv("KCFX_GENERIC_KERNEL") != nullptr;             // A/B and test hook (read per launch)
-    if (tv.mode == MODE_MINIMIZER && k == 31 && tv.mm_len == 16 && !generic_only) {
+    const bool generic_only = tv.generic != 0;                                      // A/B and test hook, fixed at kcfx_db_open
+    if (tv.fmt == FORMAT_CELLS) {
+        hipExtLaunchKernelGGL(screen_k31c_kernel, g, b, 0, st, ev_start, ev_stop, 0, text, tiles, tv, min_count, bits, count_sums);
+    } else if (tv.mode == MODE_MINIMIZER && k == 31 && tv.mm_len == 16 && !generic_only) {
         if (tv.wide) { if (both_strands) KCFX_LAUNCH31(true, true); else KCFX_LAUNCH31(true, false); }
         else         { if (both_strands) KCFX_LAUNCH31(false, true); else KCFX_LAUNCH31(false, false); }
     } else if (tv.mode == MODE_MINIMIZER) {
@@ -1077,7 +1362,8 @@ hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32
 
 bool screen_multi_supported(const TableView& tv, int32_t k) {
     // 2-byte counters and < 2^29 lines (64 GiB): the shared queue of the multi-sample kernel tags line numbers with the sample
-    return tv.mode == MODE_MINIMIZER && k == 31 && tv.mm_len == 16 && !tv.wide && tv.n_lines < (1u << MULTI_TAG_SHIFT);
+    return tv.fmt == FORMAT_LINES && tv.mode == MODE_MINIMIZER && k == 31 && tv.mm_len == 16 && !tv.wide &&
+           tv.n_lines < (1u << MULTI_TAG_SHIFT);
 }
 
 hipError_t launch_screen_multi(const uint8_t* text, const TileDesc* tiles, int32_t n_tiles, const TableView* tvs,

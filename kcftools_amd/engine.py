@@ -38,7 +38,9 @@ class DbInfo(C.Structure):
                [("total_kmers", C.c_int64), ("table_bytes", C.c_int64), ("table_lines", C.c_int64),
                 ("slots_per_line", C.c_int32), ("device", C.c_int32), ("load_seconds", C.c_double),
                 ("table_mode", C.c_int32), ("minimizer_length", C.c_int32),
-                ("heavy_lines", C.c_int64), ("overflow_lines", C.c_int64)]
+                ("heavy_lines", C.c_int64), ("overflow_lines", C.c_int64),
+                ("table_format", C.c_int32), ("_pad", C.c_int32), ("stored_kmers", C.c_int64),
+                ("stash_kmers", C.c_int64), ("stash_bytes", C.c_int64), ("multi_cell_kmers", C.c_int64)]
 
 
 class KcfxError(RuntimeError):

@@ -145,6 +145,51 @@ int harness_minimizers(const uint8_t* text, int64_t text_off, int n_kmers, int k
     }
     return 0;
 }
+// FORMAT_CELLS consistency (k = 31, M = 16): the cell the query side derives for the k-mer at every position (tagged
+// hashes, sliding minimum, cell_probe_of -- what screen_k31c_kernel does in registers) must be one of the cells the
+// build side stores the canonical k-mer in (cells_of_key). Returns the number of positions where it is not (0 = pass);
+// n_cands_out[j] = number of build-side candidates, probe_out[4 j ..] = the query-side (line, sh, w, r).
+int harness_cells(const uint8_t* text, int64_t text_off, int n_kmers, int lbits, int32_t* n_cands_out, uint32_t* probe_out) {
+    const int k = 31, M = 16;
+    Packed P = pack_tile(text, text_off, n_kmers, k);
+    std::vector<uint32_t> h(n_kmers + 16);
+    for (int p = 0; p < n_kmers + 15; ++p) {
+        uint64_t f, r;
+        extract_pair(P.fw(), P.cw(), P.off + p, M, f, r);
+        h[p] = mm27_tagged((uint32_t)(f >> 32), (uint32_t)(r >> 32), (uint32_t)p & 15u);
+    }
+    int bad = 0;
+    for (int j = 0; j < n_kmers; ++j) {
+        uint32_t mn = h[j];
+        for (int t = 1; t < 16; ++t) mn = std::min(mn, h[j + t]);
+        uint64_t F, R;
+        extract_pair(P.fw(), P.cw(), P.off + j, k, F, R);
+        const CellProbe q = cell_probe_of(F, R, mn, (uint32_t)j & 63u, lbits);
+        CellProbe c[CELL_MAX_CANDS];
+        const int n = cells_of_key(F < R ? F : R, lbits, c);
+        bool ok = false;
+        for (int i = 0; i < n; ++i) ok |= c[i].line == q.line && c[i].sh == q.sh && c[i].w == q.w && c[i].r == q.r;
+        if (!ok) ++bad;
+        n_cands_out[j] = n;
+        probe_out[4 * j] = q.line;
+        probe_out[4 * j + 1] = q.sh;
+        probe_out[4 * j + 2] = q.w;
+        probe_out[4 * j + 3] = q.r;
+    }
+    return bad;
+}
+// injectivity spot check: the cells of two different canonical k-mers never coincide in (line, sh, w, r)
+int harness_cells_of_key(uint64_t C, int lbits, uint32_t* out) {
+    CellProbe c[CELL_MAX_CANDS];
+    const int n = cells_of_key(C, lbits, c);
+    for (int i = 0; i < n; ++i) {
+        out[4 * i] = c[i].line;
+        out[4 * i + 1] = c[i].sh;
+        out[4 * i + 2] = c[i].w;
+        out[4 * i + 3] = c[i].r;
+    }
+    return n;
+}
 uint64_t harness_revcomp_word(uint64_t x, int len) { return revcomp_word(x, len); }
 int harness_tile_k(void) { return TILE_K; }
 

@@ -239,10 +239,14 @@ def test_async_device_output_on_torch_stream(oracle, tmp_path):
     assert_same(got, odb.screen(ref, s, e - s, 1, threads=4), "async vs oracle")
 
 
-def test_low_complexity_repeats_take_the_heavy_bucket_path(oracle, tmp_path):
-    """Microsatellites / homopolymers put thousands of distinct k-mers under ONE minimizer. Those buckets are detected at
-    load time (kcfx_db_info.heavy_lines) and their k-mers re-homed by key hash, so results stay exact and a probe never
-    walks a long chain."""
+@pytest.mark.parametrize("fmt", ["cells", "lines"])
+def test_low_complexity_repeats_take_the_heavy_bucket_path(oracle, tmp_path, fmt, monkeypatch):
+    """Microsatellites / homopolymers put thousands of distinct k-mers under ONE minimizer. In the 12-slot line table those
+    buckets are detected at load time (kcfx_db_info.heavy_lines) and their k-mers re-homed by key hash; in the cell table
+    they collide in their cells and go to the stash, and repeated 16-mers inside a k-mer (tied minimizers) store it in
+    several cells. Either way results stay exact and a probe never walks a long chain."""
+    if fmt == "lines":
+        monkeypatch.setenv("KCFX_TABLE_FORMAT", "lines")
     k = 31
     rng = np.random.default_rng(77)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -259,7 +263,11 @@ def test_low_complexity_repeats_take_the_heavy_bucket_path(oracle, tmp_path):
     synth.write_kmc(prefix, kmers, counts, prm)
     db = engine.KmcDb.open(prefix)
     odb = oracle.OracleDb(prefix)
-    assert db.info.table_mode == 1 and db.info.heavy_lines > 0
+    if fmt == "lines":
+        assert db.info.table_format == 0 and db.info.table_mode == 1 and db.info.heavy_lines > 0
+    else:
+        assert db.info.table_format == 1 and db.info.stash_kmers > 0 and db.info.multi_cell_kmers > 0
+        assert db.info.stored_kmers == len(kmers)
     assert np.array_equal(db.lookup(kmers), counts.astype(np.uint32).astype(np.int32))
     s, e = engine.windows(len(ref), 5_000, 0, k)
     got = db.screen(ref, s, e - s, 1)
@@ -268,7 +276,7 @@ def test_low_complexity_repeats_take_the_heavy_bucket_path(oracle, tmp_path):
     assert got["obs"].sum() > 0.5 * got["total_kmers"].sum()
     # the same through the array-built table
     db2 = engine.KmcDb.build(kmers, counts, k, 2, True)
-    assert db2.info.heavy_lines > 0
+    assert (db2.info.heavy_lines > 0) if fmt == "lines" else (db2.info.stash_kmers == db.info.stash_kmers)
     assert_same(db2.screen(ref, s, e - s, 1), want, "low complexity (array build)")
 
 
@@ -290,17 +298,23 @@ def test_k31_specialised_and_generic_kernels_agree(oracle, tmp_path, cs, both, m
     prefix, *_ = make_db(tmp_path, "both", ref, 9, k=k, p=3, cs=cs, m=7, bins=8, both=both, noise=20_000)
     db = engine.KmcDb.open(prefix)
     assert db.info.minimizer_length == 16
+    assert db.info.table_format == (1 if (both and cs <= 2) else 0)
     odb = oracle.OracleDb(prefix)
     begins = np.concatenate([np.arange(0, 390_000, 7_777), [399_000, 399_969, 399_970]]).astype(np.int64)
     lens = np.minimum(len(ref) - begins, 9_999).astype(np.int32)
     want = odb.screen(ref, begins, lens, 1, threads=4)
     fast = db.screen(ref, begins, lens, 1)
+    # the hooks are read when a handle is made: the 12-slot line table (screen_k31_kernel), then the general kernel
+    monkeypatch.setenv("KCFX_TABLE_FORMAT", "lines")
+    db_lines = engine.KmcDb.open(prefix)
+    assert db_lines.info.table_format == 0
     monkeypatch.setenv("KCFX_GENERIC_KERNEL", "1")
-    assert os.environ["KCFX_GENERIC_KERNEL"] == "1"
-    slow = db.screen(ref, begins, lens, 1)
+    db_generic = engine.KmcDb.open(prefix)
     monkeypatch.delenv("KCFX_GENERIC_KERNEL")
-    assert_same(fast, want, "screen_k31_kernel vs oracle")
-    assert_same(slow, want, "screen_tiles_kernel vs oracle")
+    monkeypatch.delenv("KCFX_TABLE_FORMAT")
+    assert_same(fast, want, "default kernel vs oracle")
+    assert_same(db_lines.screen(ref, begins, lens, 1), want, "screen_k31_kernel vs oracle")
+    assert_same(db_generic.screen(ref, begins, lens, 1), want, "screen_tiles_kernel vs oracle")
     for c in (2, 3):
         assert_same(db.screen(ref, begins, lens, c), odb.screen(ref, begins, lens, c, threads=4), f"-c {c}")
 
@@ -343,15 +357,18 @@ def test_multi_sample_pass_equals_single_sample_passes(oracle, tmp_path):
         r.screen_multi(dbs[:2], 0)
 
 
-@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("kernel", ["default", "lines", "generic"])
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("KCFX_FUZZ_SEEDS", "6"))))   # soak: KCFX_FUZZ_SEEDS=200
-def test_fuzz_window_geometry_against_oracle(oracle, tmp_path, seed, generic, monkeypatch):
+def test_fuzz_window_geometry_against_oracle(oracle, tmp_path, seed, kernel, monkeypatch):
     """Random databases x windows whose lengths sit on the kernel's internal borders (k-mer count 0 / 1 / 63 / 64 / 65,
     one tile +-1, several tiles +-1, word-aligned and not), random offsets (every alignment of the 32-base pack chunks),
-    N runs crossing window and tile borders, soft-masked stretches. k = 31 runs screen_k31_kernel (or, forced, the general
-    screen_tiles_kernel); both strandedness and all counter widths come up over the seeds."""
-    if generic:
+    N runs crossing window and tile borders, soft-masked stretches. k = 31 runs screen_k31c_kernel on a cell table when the
+    database is canonical with counters of at most 2 bytes, else screen_k31_kernel on a line table ("lines" forces that
+    one, "generic" the general screen_tiles_kernel); both strandedness and all counter widths come up over the seeds."""
+    if kernel == "generic":
         monkeypatch.setenv("KCFX_GENERIC_KERNEL", "1")
+    if kernel == "lines":
+        monkeypatch.setenv("KCFX_TABLE_FORMAT", "lines")
     rng = np.random.default_rng(1000 + seed)
     k = 31
     L = 180_000
@@ -366,9 +383,12 @@ def test_fuzz_window_geometry_against_oracle(oracle, tmp_path, seed, generic, mo
     ref = bytes(ref)
     cs = int(rng.choice([1, 2, 4]))
     both = bool(rng.integers(0, 2))
+    if kernel == "default":                 # always the cell table (canonical, narrow counters)
+        cs, both = 1 + seed % 2, True
     prefix, *_ = make_db(tmp_path, "fz", ref, 300 + seed, k=k, p=int(rng.choice([3, 7])), cs=cs, m=7, bins=4, both=both,
                          noise=5_000)
     db = engine.KmcDb.open(prefix)
+    assert db.info.table_format == (1 if kernel == "default" else 0)
     odb = oracle.OracleDb(prefix)
     tile = 2048
     kmers = [0, 1, 2, 62, 63, 64, 65, 127, 128, 129, tile - 1, tile, tile + 1, tile + 63, tile + 64, 2 * tile - 1, 2 * tile,
