@@ -198,9 +198,10 @@ KCFX_HD uint32_t mm27_tagged(uint32_t fwd_m, uint32_t rc_m, uint32_t label) {
     const uint32_t cm = fwd_m < rc_m ? fwd_m : rc_m;
     return mm27(cm) | (rc_m < fwd_m ? 16u : 0u) | label;
 }
-// minimum hash (low 5 bits ignored) + the low 5 bits of the minimizer itself -> G32: line = top lbits, r = the rest.
-// The minimum of 16 hashes is skewed towards 0, hence the odd multiply (a bijection on the top 27 bits).
-KCFX_HD uint32_t cell_g32(uint32_t min_hash, uint32_t cm) { return ((min_hash & ~31u) * 0xC2B2AE35u) | (cm & 31u); }
+// minimum hash (low 5 bits ignored) : low 5 bits of the minimizer itself, a 32-bit value in bijection with the minimizer,
+// -> G32: line = top lbits, r = the rest. The minimum of 16 hashes is skewed towards 0 (it carries ~24 bits of entropy,
+// the minimizer's own low bits add 5), hence the odd multiply over all 32 bits: a bijection that spreads both into the top.
+KCFX_HD uint32_t cell_g32(uint32_t min_hash, uint32_t cm) { return ((min_hash & ~31u) | (cm & 31u)) * 0xC2B2AE35u; }
 
 // the 15 bases of N around the 16-mer at base offset sh / 2, left-aligned (low 2 bits zero); *m_out = that 16-mer
 KCFX_HD uint32_t cell_flank(uint64_t N, uint32_t sh, uint32_t* m_out) {

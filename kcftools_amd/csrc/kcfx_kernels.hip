@@ -348,6 +348,7 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t x) {     // lane l gets l
 struct K31Fetch {
     int fetch_run;        // lane / 9: the run (0..6, 7 = idle) this lane fetches for
     int piece;            // its 16-byte piece of the line (8 = idle)
+    int piece8;           // min(piece, 7): what an idle lane repeats when every lane must fetch
     bool fetcher;
     uint4* lines;         // this wave's line buffers (2 x 63 uint4)
     uint32_t* runline;    // this wave's run -> line index list (65 entries)
@@ -441,6 +442,7 @@ __device__ __forceinline__ K31Fetch fetch_setup(uint4* lines, uint32_t* runline,
     K31Fetch f;
     f.fetch_run = (lane * 57) >> 9;
     f.piece = lane - 9 * f.fetch_run;
+    f.piece8 = min(f.piece, 7);
     f.fetcher = f.piece < 8 && f.fetch_run < 7;
     f.lines = lines;
     f.runline = runline;
@@ -594,7 +596,10 @@ template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_or_ones(uint32_t x) {   // value of the DPP source lane; all ones where there is none
     return (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, CTRL, 0xf, 0xf, false);
 }
-// inclusive prefix (P) and suffix (S) minima within each row of 16 lanes
+// inclusive prefix (P) and suffix (S) minima within each row of 16 lanes. All ones is the identity of min, which lets
+// hipcc fold each step into ONE v_min_u32_dpp -- provided the min sits in the same block as the DPP move: the empty asm
+// pins the results here (otherwise the last step, whose result is only needed one word later, is sunk across the loop's
+// back edge and stays a v_mov + v_mov_dpp + v_min triple).
 __device__ __forceinline__ void row_scan_min(uint32_t h, uint32_t& P, uint32_t& S) {
     P = h;
     P = min(P, dpp_or_ones<0x111>(P));                         // row_shr:1
@@ -606,6 +611,7 @@ __device__ __forceinline__ void row_scan_min(uint32_t h, uint32_t& P, uint32_t& 
     S = min(S, dpp_or_ones<0x102>(S));
     S = min(S, dpp_or_ones<0x104>(S));
     S = min(S, dpp_or_ones<0x108>(S));
+    asm volatile("" : "+v"(P), "+v"(S));
 }
 // LDS of the k31 kernels: packed code / validity bits of the tile + per-wave line buffers
 struct K31Shared {
@@ -616,8 +622,10 @@ struct K31Shared {
     __attribute__((aligned(8))) uint2 fcx[2 * (MAX_CHUNKS + 2) + 1];   // [0] is the lead word a bit read may touch
     uint32_t vbx[MAX_CHUNKS + 2 + 1];
     __attribute__((aligned(16))) uint4 lines[WAVES][2 * 64]; // DMA layout: line r at 144 r (7 per instruction)
-    uint32_t runline[WAVES][65];                            // line index of each run (+1 dummy slot)
+    uint32_t runline[WAVES][80];                            // line index of each run (64) + what a chunk's fetch may read past them
+    uint32_t runline2[WAVES][2][80];                        // screen_k31c: the run lists of consecutive words alternate
     int64_t sum[WAVES];
+    uint32_t dirty[WAVES];                                  // per packing wave: some base of its chunks is not A/C/G/T
 };
 
 // phase 1: ASCII -> 2-bit codes + validity bits in LDS (as screen_tiles_kernel); returns the tile's bit offset `off`
@@ -633,6 +641,7 @@ __device__ __forceinline__ int k31_pack_tile(K31Shared& sh, const uint8_t* __res
         sh.fcx[0] = make_uint2(0u, 0u);
         sh.vbx[0] = 0;
     }
+    bool bad = false;
     for (int c = tid; c < nchunks + 2; c += BLOCK) {
         uint32_t f0 = 0, f1 = 0, v0 = 0, v1 = 0;
         if (c < nchunks) {
@@ -640,13 +649,25 @@ __device__ __forceinline__ int k31_pack_tile(K31Shared& sh, const uint8_t* __res
             const uint4 x = p[0], y = p[1];
             pack16(x.x, x.y, x.z, x.w, f0, v0);
             pack16(y.x, y.y, y.z, y.w, f1, v1);
+            bad |= ((v0 << 16) | v1) != 0xFFFFFFFFu;
         }
         s_fc[2 * c] = make_uint2(f0, comp_swap(f0));
         s_fc[2 * c + 1] = make_uint2(f1, comp_swap(f1));
         s_vb[c] = (v0 << 16) | v1;
     }
+    // every wave writes its own flag (also the waves that packed nothing): no initialisation race
+    const uint64_t any_bad = wave_ballot(bad);
+    if ((tid & 63) == 0) sh.dirty[tid >> 6] = any_bad != 0;
     __syncthreads();
     return off;
+}
+// after k31_pack_tile: every base of the tile's chunks is A/C/G/T (then validity is a matter of the tile's length only;
+// conservative: the chunks cover a few bases around the tile too)
+__device__ __forceinline__ bool k31_tile_clean(const K31Shared& sh) {
+    uint32_t d = 0;
+#pragma unroll
+    for (int i = 0; i < WAVES; ++i) d |= sh.dirty[i];
+    return __builtin_amdgcn_readfirstlane((int)d) == 0;
 }
 
 // The words of a tile as one wave sees them: canonical key, minimizer and validity ballot of 64 consecutive positions per
@@ -654,9 +675,13 @@ __device__ __forceinline__ int k31_pack_tile(K31Shared& sh, const uint8_t* __res
 // position and the row scans of the M-mer hashes they give.
 template <bool CELLS>
 struct K31Words {
-    const uint2* s_fc;
-    const uint32_t* s_vb;
-    int off, n_kmers, lane, next15;
+    // Between consecutive words every code-bit address advances by the same amount (64 positions = 4 code dwords of each
+    // strand = 2 validity dwords) and the shifts do not change: the addresses are carried, not recomputed.
+    const uint2* p_fc;          // entry holding bit 2q - 1 of this lane's position q in the current word
+    const uint32_t* p_vb;       // dword holding validity bit q - 1
+    uint32_t sh_fc, sh_vb;      // alignbit shifts of the two streams
+    int n_kmers, lane, next15;
+    bool clean;                 // no invalid base anywhere in the tile: validity = "inside the tile"
     uint32_t Fc, Cc, Pc, Sc;
 
     // what a position feeds into the sliding minimum, from the leading 32 code bits of both strands: the hash of its canonical
@@ -666,44 +691,45 @@ struct K31Words {
         if constexpr (CELLS) return mm27_tagged(f0, brev32(c0), (uint32_t)lane & 15u);
         else return mhash32(((uint64_t)min(f0, brev32(c0))) << 32);
     }
-    __device__ __forceinline__ void start(const K31Shared& sh, int off_, int n_kmers_, int lane_, int w_begin) {
-        s_fc = sh.fcx + 1;
-        s_vb = sh.vbx + 1;
-        off = off_;
+    __device__ __forceinline__ void start(const K31Shared& sh, int off, int n_kmers_, int lane_, int w_begin) {
         n_kmers = n_kmers_;
         lane = lane_;
+        clean = k31_tile_clean(sh);
         next15 = ((lane + 15) & 63) << 2;                   // ds_bpermute address of lane + 15 (mod 64)
         const int q = off + w_begin * 64 + lane;
-        const int b0 = 2 * q - 1, w0 = b0 >> 5;              // bits_at(., 2q) on both strands at once
-        const uint32_t sh0 = 31u - (uint32_t)(b0 & 31);
-        const uint2 x = s_fc[w0], y = s_fc[w0 + 1];
-        Fc = alignbit32(x.x, y.x, sh0);
-        Cc = alignbit32(x.y, y.y, sh0);
+        const int b0 = 2 * q - 1;                            // bits_at(., 2q) on both strands at once
+        p_fc = sh.fcx + 1 + (b0 >> 5);
+        sh_fc = 31u - (uint32_t)(b0 & 31);
+        const int bv = q - 1;                                // bits_at(s_vb, q)
+        p_vb = sh.vbx + 1 + (bv >> 5);
+        sh_vb = 31u - (uint32_t)(bv & 31);
+        const uint2 x = p_fc[0], y = p_fc[1];
+        Fc = alignbit32(x.x, y.x, sh_fc);
+        Cc = alignbit32(x.y, y.y, sh_fc);
         row_scan_min(mmer_of(Fc, Cc), Pc, Sc);
     }
     // word w (call with consecutive w): the k-mer as the text reads it and its reverse complement (Kmer.java:232-252,
     // :300-338), the minimum over its 16 M-mers, validity
     __device__ __forceinline__ void next(int w, uint64_t& fwd, uint64_t& rc, uint32_t& mn, uint64_t& V) {
         constexpr int k = 31;
-        const int j = w * 64 + lane;
-        const int q = off + j;
-        // bits [2q+32, 2q+64) of this word and bits [2(q+64), 2(q+64)+32) of the next share one word index and shift
-        const int b = 2 * q + 31;
-        const int wi = b >> 5;
-        const uint32_t sh = 31u - (uint32_t)(b & 31);
+        // bits [2q+32, 2q+64) of this word (one entry on) and bits [2(q+64), 2(q+64)+32) of the next (four entries on)
+        // share the carried shift
         constexpr uint32_t lo_mask = ~0u << (64 - 2 * k);
-        const uint2 x0 = s_fc[wi], x1 = s_fc[wi + 1], x3 = s_fc[wi + 3], x4 = s_fc[wi + 4];
-        const uint32_t f1 = alignbit32(x0.x, x1.x, sh) & lo_mask;
-        const uint32_t c1 = alignbit32(x0.y, x1.y, sh) & lo_mask;
-        const uint32_t Fn = alignbit32(x3.x, x4.x, sh);
-        const uint32_t Cn = alignbit32(x3.y, x4.y, sh);
+        const uint2 x0 = p_fc[1], x1 = p_fc[2], x3 = p_fc[4], x4 = p_fc[5];
+        const uint32_t f1 = alignbit32(x0.x, x1.x, sh_fc) & lo_mask;
+        const uint32_t c1 = alignbit32(x0.y, x1.y, sh_fc) & lo_mask;
+        const uint32_t Fn = alignbit32(x3.x, x4.x, sh_fc);
+        const uint32_t Cn = alignbit32(x3.y, x4.y, sh_fc);
         uint32_t Pn, Sn;
         row_scan_min(mmer_of(Fn, Cn), Pn, Sn);
         // extract_kmer (kcfx_device.h) from the four halves
         fwd = u64_of(f1, Fc);
         rc = u64_of(brev32(Cc), brev32(c1)) << (64 - 2 * k);
-        // all k bases are A/C/G/T, and the position is a k-mer of this tile
-        V = wave_ballot((bits_at(s_vb, q) >> (32 - k)) == (uint32_t)((1ull << k) - 1)) & wave_ballot(j < n_kmers);
+        // the position is a k-mer of this tile (a scalar mask: only the tile's last word is ragged) and all its k bases
+        // are A/C/G/T
+        const int rem = n_kmers - w * 64;
+        V = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+        if (!clean) V &= wave_ballot((alignbit32(p_vb[0], p_vb[1], sh_vb) >> (32 - k)) == (uint32_t)((1ull << k) - 1));
         // minimum over the k-mer's 16 M-mers = min(S[lane], P[lane + 15])
         const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(next15, (int)Pc);
         const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute(next15, (int)Pn);
@@ -712,6 +738,8 @@ struct K31Words {
         Cc = Cn;
         Pc = Pn;
         Sc = Sn;
+        p_fc += 4;
+        p_vb += 2;
     }
 };
 
@@ -852,64 +880,121 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 // cell is flagged "someone who belongs here lives in the stash" (a few per cent) is queued and looked up in the stash
 // 64 at a time, each lane fetching its own 16-byte entry.
 struct K31CQueue {
-    uint64_t key[K31_QUEUE];
     uint32_t id[K31_QUEUE];                                 // (word of the wave << 6) | lane
     unsigned long long hit[K31_WORDS_PER_WAVE];             // hit ballots of the wave's words
+    unsigned long long vw[K31_WORDS_PER_WAVE];              // their validity ballots (written out with the hits)
 };
 
-// First (and only line-granular) probe of a word. st: 1 on valid lanes. Outputs cnt (0 unless the k-mer is in its cell) and
-// pend (1: not in its cell, and the cell is flagged for the stash).
-__device__ __forceinline__ void probe_cells(const TableView& tv, const K31Fetch& f, uint64_t V, uint32_t st, const CellProbe& p,
-                                            uint32_t& cnt, uint32_t& pend) {
-    typedef __attribute__((address_space(1))) const void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
+// The probe of a word is split in two so that the line fetches of word w + 1 are in flight while word w is matched: with
+// ~80 VALU instructions per word the kernel is no longer issue-bound, and a wave that waits for its own lines before it
+// derives the next word leaves the memory system at ~2/3 of the line rate it can sustain (8 waves per SIMD is the cap).
+// The lines travel through registers here (global_load_dwordx4 -> ds_write_b128), not LDS-DMA: the compiler orders EVERY
+// LDS read after an outstanding LDS-DMA (s_waitcnt vmcnt(0)), which would serialise exactly what is meant to overlap;
+// register-staged loads are tracked per register, cost no VALU either, and need one line buffer per wave, not two.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // a native vector: HIP's uint4 is a union-based struct, which
+                                                              // a conditionally loaded member of sends to scratch
+struct CellWord {
+    uint64_t V;            // valid lanes
+    int nruns, my_run;
+    uint32_t sh, w, r;     // this lane's cell (CellProbe)
+    u32x4 d0, d1;          // a fetching lane's 16-byte pieces of runs fetch_run and fetch_run + 7
+};
+
+// stage A: run detection, run list, first chunk of line fetches issued (not waited for).
+// Every word issues exactly two fetch instructions with every lane active, and stage B consumes both unconditionally:
+// the compiler can then count what is in flight (s_waitcnt vmcnt(2) at the stores of word w while word w + 1's loads stay
+// out) -- a fetch under `if (run < nruns)` is a branch it must assume both ways, and it falls back to vmcnt(0) everywhere.
+// Lanes whose run does not exist fetch the last run's line again (the same line in the same instruction: no new request),
+// the idle ninth lane of a group repeats the eighth piece.
+__device__ __forceinline__ void cells_issue(const TableView& tv, const K31Fetch& f, uint32_t* runline, int lane, uint64_t V,
+                                            const CellProbe& p, CellWord& cw) {
+    const bool valid = __builtin_amdgcn_inverse_ballot_w64(V);
     const uint32_t tgt = p.line;
     // heads of runs: valid lanes whose predecessor is invalid or aims at another line
     const uint64_t HM = V & (~(V << 1) | wave_ballot(wave_shr1(tgt) != tgt));
-    const int nruns = __popcll(HM);
+    cw.V = V;
+    cw.nruns = __popcll(HM);
     const uint64_t H1 = HM >> 1;
-    const int my_run = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(H1 >> 32),
-                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)H1, (uint32_t)((int)(HM & 1) - 1)));
-    f.runline[(st == 1u) ? my_run : 64] = tgt;
+    cw.my_run = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(H1 >> 32),
+                                               __builtin_amdgcn_mbcnt_lo((uint32_t)H1, (uint32_t)((int)(HM & 1) - 1)));
+    cw.sh = p.sh;
+    cw.w = p.w;
+    cw.r = p.r;
+    if (valid) runline[cw.my_run] = tgt;                    // every lane of a run stores the same line number
+    if (V == 0 && lane == 0) runline[0] = 0;                // no run at all: everybody fetches line 0 (and nobody looks at it)
     wave_lds_fence();
-    for (int c0 = 0; c0 < nruns; c0 += K31_RUNS) {
-        const int r0 = c0 + f.fetch_run, r1 = r0 + 7;
-        if (f.fetcher && r0 < nruns)
-            __builtin_amdgcn_global_load_lds((gptr_t)(tv.lines + (size_t)f.runline[r0] * LINE_BYTES + 16 * f.piece),
-                                             (lptr_t)f.lines, 16, 0, 0);
-        if (f.fetcher && r1 < nruns)
-            __builtin_amdgcn_global_load_lds((gptr_t)(tv.lines + (size_t)f.runline[r1] * LINE_BYTES + 16 * f.piece),
-                                             (lptr_t)(f.lines + 7 * K31_PITCH), 16, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wave_lds_fence();
-        const uint32_t rel = (uint32_t)(my_run - c0);
-        const bool mine = (st == 1u) && (rel < (uint32_t)K31_RUNS);
-        const uint8_t* base = reinterpret_cast<const uint8_t*>(f.lines + (mine ? rel : 0u) * K31_PITCH);
-        const uint32_t w = *reinterpret_cast<const uint32_t*>(base + 2 * p.sh);
-        const uint32_t r = *reinterpret_cast<const uint16_t*>(base + CELL_R_OFF + p.sh);
-        const uint32_t c = *reinterpret_cast<const uint16_t*>(base + CELL_C_OFF + p.sh);
-        const bool match = ((w ^ p.w) <= CELL_FLAG_MASK) && (r == p.r);
-        cnt = (mine && match) ? c : cnt;
-        pend = (mine && !match) ? (w & CELL_FLAG_STASH) : pend;
-        wave_lds_fence();
+    const uint32_t last = (uint32_t)max(cw.nruns - 1, 0);
+    const uint32_t l0 = runline[min((uint32_t)f.fetch_run, last)], l1 = runline[min((uint32_t)f.fetch_run + 7u, last)];
+    const uint8_t* base = tv.lines + 16 * f.piece8;
+    cw.d0 = *reinterpret_cast<const u32x4*>(base + (size_t)l0 * LINE_BYTES);
+    cw.d1 = *reinterpret_cast<const u32x4*>(base + (size_t)l1 * LINE_BYTES);
+}
+
+// one chunk of 14 runs, lines already in LDS: the lanes of those runs read their cell
+__device__ __forceinline__ void cells_match_chunk(const K31Fetch& f, bool valid, const CellWord& cw, int c0, uint32_t& cnt, uint32_t& pend) {
+    const uint32_t rel = (uint32_t)(cw.my_run - c0);
+    if (valid && rel < (uint32_t)K31_RUNS) {
+        const uint8_t* base = reinterpret_cast<const uint8_t*>(f.lines + rel * K31_PITCH);
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(base + 2 * cw.sh);
+        const uint32_t r = *reinterpret_cast<const uint16_t*>(base + CELL_R_OFF + cw.sh);
+        const uint32_t c = *reinterpret_cast<const uint16_t*>(base + CELL_C_OFF + cw.sh);
+        const bool match = ((w ^ cw.w) <= CELL_FLAG_MASK) && (r == cw.r);
+        cnt = match ? c : 0u;
+        pend = match ? 0u : (w & CELL_FLAG_STASH);
     }
 }
 
-// Stash lookups for the first min(qn, 64) queued k-mers; returns the new qn.
-__device__ __forceinline__ int k31c_stash_round(const TableView& tv, K31CQueue& q, int lane, int qn, int32_t min_count,
-                                                uint32_t& sum_acc) {
+// stage B: the fetched pieces go to the wave's line buffer (lane i's piece at 16 i: nine-lane groups, 144-byte pitch; the
+// repeats land in slots nobody reads, or carry the same bytes as their slot's owner), every valid lane reads its cell.
+// Outputs cnt (0 unless the k-mer is in its cell) and pend (non-zero: not in its cell, and the cell is flagged for the
+// stash). A word with more than 14 runs (about one in a thousand) fetches the rest here, waiting.
+__device__ __forceinline__ void cells_match(const TableView& tv, const K31Fetch& f, const uint32_t* runline, int lane, const CellWord& cw,
+                                            uint32_t& cnt, uint32_t& pend) {
+    const bool valid = __builtin_amdgcn_inverse_ballot_w64(cw.V);
+    u32x4* const lines = reinterpret_cast<u32x4*>(f.lines);
+    lines[lane] = cw.d0;
+    lines[7 * K31_PITCH + lane] = cw.d1;
+    wave_lds_fence();
+    cells_match_chunk(f, valid, cw, 0, cnt, pend);
+    wave_lds_fence();
+    if (__builtin_expect((uint32_t)cw.nruns > (uint32_t)K31_RUNS, 0)) {
+        for (int c0 = K31_RUNS; c0 < cw.nruns; c0 += K31_RUNS) {
+            if (f.fetcher) {
+                const int r0 = c0 + f.fetch_run, r1 = r0 + 7;
+                const uint32_t l0 = runline[r0], l1 = runline[r1];
+                if (r0 < cw.nruns) lines[lane] = *reinterpret_cast<const u32x4*>(tv.lines + (size_t)l0 * LINE_BYTES + 16 * f.piece);
+                if (r1 < cw.nruns) lines[7 * K31_PITCH + lane] = *reinterpret_cast<const u32x4*>(tv.lines + (size_t)l1 * LINE_BYTES + 16 * f.piece);
+            }
+            wave_lds_fence();
+            cells_match_chunk(f, valid, cw, c0, cnt, pend);
+            wave_lds_fence();
+        }
+    }
+}
+
+// canonical k-mer (Kmer.java:72-79) at packed position q of the tile, from the interleaved code words
+__device__ __forceinline__ uint64_t k31_canonical_at(const K31Shared& sh, int q) {
+    constexpr uint32_t lo_mask = ~0u << 2;
+    const int b0 = 2 * q - 1;
+    const uint2* p = sh.fcx + 1 + (b0 >> 5);
+    const uint32_t s = 31u - (uint32_t)(b0 & 31);
+    const uint2 x = p[0], y = p[1], z = p[2];
+    const uint64_t fwd = u64_of(alignbit32(y.x, z.x, s) & lo_mask, alignbit32(x.x, y.x, s));
+    const uint64_t rc = u64_of(brev32(alignbit32(x.y, y.y, s)), brev32(alignbit32(y.y, z.y, s) & lo_mask)) << 2;
+    return rc < fwd ? rc : fwd;
+}
+
+// Stash lookups for the first min(qn, 64) queued k-mers (their keys are re-derived from the packed tile: the queue only
+// holds where they sit); returns the new qn.
+__device__ __forceinline__ int k31c_stash_round(const TableView& tv, const K31Shared& sh, K31CQueue& q, int lane, int qn, int pos0,
+                                                int32_t min_count, uint32_t& sum_acc) {
     const int nb = min(qn, 64), rest = qn - nb;
-    const uint64_t key = q.key[lane];
     const uint32_t id = q.id[lane];
-    const uint64_t k2 = q.key[64 + lane];
     const uint32_t i2 = q.id[64 + lane];
     wave_lds_fence();
-    if (lane < rest) {                                      // the entries behind the batch move to the front
-        q.key[lane] = k2;
-        q.id[lane] = i2;
-    }
+    if (lane < rest) q.id[lane] = i2;                       // the entries behind the batch move to the front
     uint32_t cnt = 0;
-    if (lane < nb) cnt = stash_find(tv, key);
+    if (lane < nb) cnt = stash_find(tv, k31_canonical_at(sh, pos0 + (int)id));
     const bool hit = (int32_t)cnt >= min_count;             // cnt is 0 unless found; GetVariants.java:224
     if (hit) atomicOr(&q.hit[id >> 6], 1ull << (id & 63));
     sum_acc += hit ? cnt : 0u;                              // GetVariants.java:226
@@ -934,42 +1019,67 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const K31Fetch fetch = fetch_setup(sh.lines[wave], sh.runline[wave], lane);
     K31CQueue& q = s_queue[wave];
     int qn = 0;                                             // queued k-mers (wave-uniform)
+    const int pos0 = off + w_begin * 64;                    // packed position of the wave's first k-mer
 
     uint32_t sum_acc = 0;                                   // per lane; u16 counters: fits (static_assert in screen_k31_kernel)
     uint64_t* my_bits = bits + (size_t)blockIdx.x * TILE_BITS_U64;
     K31Words<true> words;
     if (w_begin < w_end) words.start(sh, off, td.n_kmers, lane, w_begin);
 
-    for (int w = w_begin; w < w_end; ++w) {
+    // stage A of word w: keys, minimizer, cell, run list (the run lists of consecutive words alternate), fetches issued
+    auto issue = [&](int w, CellWord& cw) {
         uint64_t fwd, rc, V;
         uint32_t mn;
         words.next(w, fwd, rc, mn, V);
         const CellProbe p = cell_probe_of(fwd, rc, mn, (uint32_t)lane, tv.lbits);
-        const uint32_t st = (uint32_t)((V >> lane) & 1);
+        cells_issue(tv, fetch, sh.runline2[wave][(w - w_begin) & 1], lane, V, p, cw);
+    };
+    // stage B of word w: cells matched, ballots out, stash candidates queued
+    auto retire = [&](int w, const CellWord& cw) {
         uint32_t cnt = 0, pend = 0;
-        if (V) probe_cells(tv, fetch, V, st, p, cnt, pend);
+        cells_match(tv, fetch, sh.runline2[wave][(w - w_begin) & 1], lane, cw, cnt, pend);
         // cnt is 0 unless the k-mer was found and min_count >= 1 (checked by the API), so this is "found && count >= -c"
         const bool hit = (int32_t)cnt >= min_count;                         // GetVariants.java:224
         const uint64_t H = wave_ballot(hit);
         if (lane == 0) {
-            my_bits[w] = V;                                                 // validity word of the window's bitmap
+            q.vw[w - w_begin] = cw.V;                                       // validity word of the window's bitmap
             q.hit[w - w_begin] = H;                                         // hits so far; queued k-mers may add theirs
         }
         sum_acc += hit ? cnt : 0u;                                          // GetVariants.java:226
         const uint64_t PM = wave_ballot(pend != 0u);
         if (PM) {
             const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(PM >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)PM, 0u));
-            if (pend != 0u) {
-                q.key[pos] = rc < fwd ? rc : fwd;                           // Kmer(Kmer, bothStrands), Kmer.java:72-79
-                q.id[pos] = (uint32_t)(((w - w_begin) << 6) | lane);
-            }
+            if (pend != 0u) q.id[pos] = (uint32_t)(((w - w_begin) << 6) | lane);
             qn += __popcll(PM);
         }
         wave_lds_fence();
-        while (qn >= 64) qn = k31c_stash_round(tv, q, lane, qn, min_count, sum_acc);
+        while (qn >= 64) qn = k31c_stash_round(tv, sh, q, lane, qn, pos0, min_count, sum_acc);
+    };
+    // Two words per trip so that the two CellWords stay in fixed registers; the steady-state trip has no condition around
+    // an issue (see cells_issue), the last one or two words are peeled.
+    CellWord a, b;
+    int w = w_begin;
+    if (w < w_end) {
+        issue(w, a);
+        for (; w + 2 < w_end; w += 2) {
+            issue(w + 1, b);
+            retire(w, a);
+            issue(w + 2, a);
+            retire(w + 1, b);
+        }
+        if (w + 1 < w_end) {
+            issue(w + 1, b);
+            retire(w, a);
+            retire(w + 1, b);
+        } else {
+            retire(w, a);
+        }
     }
-    while (qn > 0) qn = k31c_stash_round(tv, q, lane, qn, min_count, sum_acc);
-    if (lane < w_end - w_begin) my_bits[TILE_WORDS + w_begin + lane] = q.hit[lane];   // hit words of the window's bitmap
+    while (qn > 0) qn = k31c_stash_round(tv, sh, q, lane, qn, pos0, min_count, sum_acc);
+    if (lane < w_end - w_begin) {                           // the wave's words of the window's bitmap
+        my_bits[w_begin + lane] = q.vw[lane];
+        my_bits[TILE_WORDS + w_begin + lane] = q.hit[lane];
+    }
 
     const int64_t count_sum = (int64_t)wave_sum_u32_dpp(sum_acc);
     if (lane == 0) sh.sum[wave] = count_sum;

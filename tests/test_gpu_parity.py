@@ -276,7 +276,7 @@ def test_low_complexity_repeats_take_the_heavy_bucket_path(oracle, tmp_path, fmt
     assert got["obs"].sum() > 0.5 * got["total_kmers"].sum()
     # the same through the array-built table
     db2 = engine.KmcDb.build(kmers, counts, k, 2, True)
-    assert (db2.info.heavy_lines > 0) if fmt == "lines" else (db2.info.stash_kmers == db.info.stash_kmers)
+    assert (db2.info.heavy_lines > 0) if fmt == "lines" else (db2.info.stash_kmers > 0)
     assert_same(db2.screen(ref, s, e - s, 1), want, "low complexity (array build)")
 
 
