@@ -263,7 +263,8 @@ def main():
         "windows_per_s": n_win * S * world * args.steps / elapsed,
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "screen_k31_kernel" if S == 1 else "screen_k31_multi_kernel", "kernel_avg_ms": kern_avg_ms,
+                     "kernel": (("screen_k31c_kernel" if db.info.table_format == 1 else "screen_k31_kernel") if S == 1
+                                else "screen_k31_multi_kernel"), "kernel_avg_ms": kern_avg_ms,
                      "launches_timed": int(launches), "algorithmic_bytes_per_kmer": b_alg if S > 1 else B_ALG,
                      "rocprof_kernel_avg_ms": rocprof_ms},
         "cpu_baseline": cpu,

@@ -47,13 +47,14 @@ constexpr int MODE_KEYHASH = 0, MODE_MINIMIZER = 1;
 // the line a k-mer lives in is still chosen by its minimizer (M = 16), but INSIDE the line the k-mer has exactly one
 // cell: cell index = offset of the minimizer in the k-mer, read on the strand where the minimizer 16-mer is in
 // canonical form ("N orientation"). The 16 k-mers that can share a minimizer occurrence have 16 distinct offsets, so a
-// run of consecutive reference k-mers maps onto distinct cells of ONE line and a probe is one 4-byte + two 2-byte LDS
-// reads and two compares instead of a 12-way 64-bit compare. A cell holds a quotiented key, exact by construction:
+// run of consecutive reference k-mers maps onto distinct cells of ONE line, and a probe is ONE 8-byte load per lane --
+// the lanes of a run hit the same 128-byte line, which the memory pipeline fetches once -- and two compares: no
+// cooperative line fetch, no LDS staging, no 12-way 64-bit compare. A cell holds a quotiented key, exact by construction:
 //
-//   128-byte line = 16 x u32 w | 16 x u16 r | 16 x u16 count
+//   128-byte line = 16 x 8-byte cell;  cell = u32 w | u16 r | u16 count
 //     w     = the 30 flank bits (the 15 bases of N around the minimizer, left-aligned) | bit 0: some k-mer that maps
 //             to this cell lives in the stash | bit 1: reserved
-//     r     = low (32 - lbits) bits of G32 = (27-bit minimizer hash, re-spread) : (minimizer & 31); the line number is
+//     r     = low (32 - lbits) bits of G32 = (27-bit minimizer hash : minimizer & 31), re-spread; the line number is
 //             the top lbits of G32, and G32 <-> canonical minimizer 16-mer is a bijection (cell_g32)
 //     count = the stored counter; 0 = empty cell (a k-mer whose counter is 0 can never be observed -- GetVariants.java:224
 //             needs count >= -c >= 1 -- so it is not stored)
@@ -63,8 +64,11 @@ constexpr int MODE_KEYHASH = 0, MODE_MINIMIZER = 1;
 // ----------------------------------------------------------------------------------------------------
 constexpr int FORMAT_LINES = 0, FORMAT_CELLS = 1;
 constexpr int CELL_LBITS_MIN = 16, CELL_LBITS_MAX = 31;     // r must fit 16 bits; n_lines fits 32
-constexpr int CELL_R_OFF = 64, CELL_C_OFF = 96;             // byte offsets of the r and count arrays in a line
 constexpr uint32_t CELL_FLAG_STASH = 1u, CELL_FLAG_MASK = 3u;
+// a cell as one 64-bit word: w in bits 0..31, r in 32..47, count in 48..63
+__host__ __device__ inline uint64_t cell_word(uint32_t w, uint32_t r, uint32_t count) {
+    return (uint64_t)w | ((uint64_t)(r & 0xFFFFu) << 32) | ((uint64_t)(count & 0xFFFFu) << 48);
+}
 
 struct TableView {
     const uint8_t* lines;

@@ -175,9 +175,10 @@ __global__ __launch_bounds__(256) void lookup_kernel(TableView tv, int32_t k, co
 // ======================================================================================================
 // FORMAT_CELLS build + lookup (layout and exactness argument: kcfx_internal.h; cell derivation: kcfx_device.h)
 // ======================================================================================================
-// Pass 1: every stored k-mer claims its cell(s); the first arrival wins (16-bit count != 0 marks a taken cell, claimed
-// with a CAS on the dword holding the count pair), later ones flag the cell and are counted for the stash.
-// stats[0] = k-mers that need the stash, stats[1] = k-mers stored (count != 0), stats[2] = k-mers with more than one cell
+// Pass 1: every stored k-mer claims its cell(s) with one 64-bit CAS (count == 0 marks an empty cell; its flag bits may
+// already be set by an earlier loser and are kept); the first arrival wins, later ones flag the cell and are counted for
+// the stash. stats[0] = k-mers that need the stash, stats[1] = k-mers stored (count != 0), stats[2] = k-mers with more
+// than one cell
 __global__ void cells_insert_kernel(uint8_t* lines, int32_t lbits, const uint64_t* __restrict__ keys,
                                     const uint32_t* __restrict__ counts, int64_t n, unsigned long long* stats) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -189,26 +190,20 @@ __global__ void cells_insert_kernel(uint8_t* lines, int32_t lbits, const uint64_
         const int nc = cells_of_key(keys[i], lbits, cand);
         bool lost = false;
         for (int a = 0; a < nc; ++a) {
-            uint8_t* base = lines + (size_t)cand[a].line * LINE_BYTES;
-            const uint32_t cell = cand[a].sh >> 1, shift = (cell & 1u) * 16u;
-            uint32_t* cw = reinterpret_cast<uint32_t*>(base + CELL_C_OFF) + (cell >> 1);
-            uint32_t old = __atomic_load_n(cw, __ATOMIC_RELAXED);
+            unsigned long long* cell = reinterpret_cast<unsigned long long*>(lines + (size_t)cand[a].line * LINE_BYTES + 4 * cand[a].sh);
+            const unsigned long long mine = cell_word(cand[a].w, cand[a].r, c);
+            unsigned long long old = __atomic_load_n(cell, __ATOMIC_RELAXED);
             bool won = false;
-            for (;;) {
-                if ((old >> shift) & 0xFFFFu) break;
-                const uint32_t prev = atomicCAS(cw, old, old | (c << shift));
+            while ((old >> 48) == 0) {
+                const unsigned long long prev = atomicCAS(cell, old, mine | (old & CELL_FLAG_MASK));
                 if (prev == old) {
                     won = true;
                     break;
                 }
                 old = prev;
             }
-            uint32_t* ww = reinterpret_cast<uint32_t*>(base) + cell;
-            if (won) {
-                atomicOr(ww, cand[a].w);
-                atomicOr(reinterpret_cast<uint32_t*>(base + CELL_R_OFF) + (cell >> 1), cand[a].r << shift);
-            } else {
-                atomicOr(ww, CELL_FLAG_STASH);
+            if (!won) {
+                atomicOr(reinterpret_cast<uint32_t*>(cell), CELL_FLAG_STASH);
                 lost = true;
             }
         }
@@ -231,12 +226,8 @@ __global__ void cells_stash_kernel(const uint8_t* __restrict__ lines, int32_t lb
         const int nc = cells_of_key(key, lbits, cand);
         bool lost = false;
         for (int a = 0; a < nc; ++a) {
-            const uint8_t* base = lines + (size_t)cand[a].line * LINE_BYTES;
-            const uint32_t sh = cand[a].sh;
-            const uint32_t w = *reinterpret_cast<const uint32_t*>(base + 2 * sh);
-            const uint32_t r = *reinterpret_cast<const uint16_t*>(base + CELL_R_OFF + sh);
-            const uint32_t cc = *reinterpret_cast<const uint16_t*>(base + CELL_C_OFF + sh);
-            lost |= !(((w ^ cand[a].w) <= CELL_FLAG_MASK) && r == cand[a].r && cc == c);
+            const uint64_t cell = *reinterpret_cast<const uint64_t*>(lines + (size_t)cand[a].line * LINE_BYTES + 4 * cand[a].sh);
+            lost |= (cell & ~(uint64_t)CELL_FLAG_MASK) != cell_word(cand[a].w, cand[a].r, c);
         }
         if (!lost) continue;
         uint32_t slot = stash_slot(key, mask);
@@ -277,14 +268,10 @@ __global__ __launch_bounds__(256) void lookup_cells_kernel(TableView tv, const u
         if (key <= revcomp_word(key, 31) && (key & 3ull) == 0) {
             CellProbe cand[CELL_MAX_CANDS];
             cells_of_key(key, tv.lbits, cand);                  // any one of its cells decides
-            const uint8_t* base = tv.lines + (size_t)cand[0].line * LINE_BYTES;
-            const uint32_t sh = cand[0].sh;
-            const uint32_t w = *reinterpret_cast<const uint32_t*>(base + 2 * sh);
-            const uint32_t r = *reinterpret_cast<const uint16_t*>(base + CELL_R_OFF + sh);
-            const uint32_t c = *reinterpret_cast<const uint16_t*>(base + CELL_C_OFF + sh);
-            if (((w ^ cand[0].w) <= CELL_FLAG_MASK) && r == cand[0].r)
-                result = (int32_t)c;
-            else if (w & CELL_FLAG_STASH)
+            const uint64_t cell = *reinterpret_cast<const uint64_t*>(tv.lines + (size_t)cand[0].line * LINE_BYTES + 4 * cand[0].sh);
+            if (((cell ^ cell_word(cand[0].w, cand[0].r, 0)) & 0x0000FFFFFFFFFFFCull) == 0)
+                result = (int32_t)(cell >> 48);
+            else if (cell & CELL_FLAG_STASH)
                 result = (int32_t)stash_find(tv, key);
         }
         out[i] = result;
@@ -613,23 +600,26 @@ __device__ __forceinline__ void row_scan_min(uint32_t h, uint32_t& P, uint32_t& 
     S = min(S, dpp_or_ones<0x108>(S));
     asm volatile("" : "+v"(P), "+v"(S));
 }
-// LDS of the k31 kernels: packed code / validity bits of the tile + per-wave line buffers
-struct K31Shared {
+// LDS of the k31 kernels: packed code / validity bits of the tile ...
+struct K31Pack {
     // The word loop reads code bits up to 64 positions past the tile's last k-mer without clamping (what it reads there
     // only reaches lanes that are invalid anyway): MAX_CHUNKS + 2 chunks cover every such read of a full tile.
     static_assert(2 * (MAX_CHUNKS + 2) > ((2 * (31 + TILE_K - 1) + 31) >> 5) + 4, "code arrays too short for unclamped reads");
     // code words of both strands, interleaved (.x forward, .y complement-swapped): one 8-byte LDS read serves both
     __attribute__((aligned(8))) uint2 fcx[2 * (MAX_CHUNKS + 2) + 1];   // [0] is the lead word a bit read may touch
     uint32_t vbx[MAX_CHUNKS + 2 + 1];
-    __attribute__((aligned(16))) uint4 lines[WAVES][2 * 64]; // DMA layout: line r at 144 r (7 per instruction)
-    uint32_t runline[WAVES][80];                            // line index of each run (64) + what a chunk's fetch may read past them
-    uint32_t runline2[WAVES][2][80];                        // screen_k31c: the run lists of consecutive words alternate
-    int64_t sum[WAVES];
     uint32_t dirty[WAVES];                                  // per packing wave: some base of its chunks is not A/C/G/T
+    int64_t sum[WAVES];
+};
+// ... + the per-wave line buffers of the line-table kernels
+struct K31Shared {
+    K31Pack pk;
+    __attribute__((aligned(16))) uint4 lines[WAVES][2 * 64]; // DMA layout: line r at 144 r (7 per instruction)
+    uint32_t runline[WAVES][65];                            // line index of each run (+1 dummy slot)
 };
 
 // phase 1: ASCII -> 2-bit codes + validity bits in LDS (as screen_tiles_kernel); returns the tile's bit offset `off`
-__device__ __forceinline__ int k31_pack_tile(K31Shared& sh, const uint8_t* __restrict__ text, const TileDesc& td, int tid) {
+__device__ __forceinline__ int k31_pack_tile(K31Pack& sh, const uint8_t* __restrict__ text, const TileDesc& td, int tid) {
     constexpr int k = 31;
     const int64_t a0 = td.text_off & ~(int64_t)31;
     const int off = (int)(td.text_off - a0);
@@ -663,7 +653,7 @@ __device__ __forceinline__ int k31_pack_tile(K31Shared& sh, const uint8_t* __res
 }
 // after k31_pack_tile: every base of the tile's chunks is A/C/G/T (then validity is a matter of the tile's length only;
 // conservative: the chunks cover a few bases around the tile too)
-__device__ __forceinline__ bool k31_tile_clean(const K31Shared& sh) {
+__device__ __forceinline__ bool k31_tile_clean(const K31Pack& sh) {
     uint32_t d = 0;
 #pragma unroll
     for (int i = 0; i < WAVES; ++i) d |= sh.dirty[i];
@@ -691,7 +681,7 @@ struct K31Words {
         if constexpr (CELLS) return mm27_tagged(f0, brev32(c0), (uint32_t)lane & 15u);
         else return mhash32(((uint64_t)min(f0, brev32(c0))) << 32);
     }
-    __device__ __forceinline__ void start(const K31Shared& sh, int off, int n_kmers_, int lane_, int w_begin) {
+    __device__ __forceinline__ void start(const K31Pack& sh, int off, int n_kmers_, int lane_, int w_begin) {
         n_kmers = n_kmers_;
         lane = lane_;
         clean = k31_tile_clean(sh);
@@ -802,7 +792,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     __shared__ K31Queue s_queue[WAVES];
     const TileDesc td = tiles[blockIdx.x];
     const int tid = threadIdx.x;
-    const int off = k31_pack_tile(sh, text, td, tid);
+    const int off = k31_pack_tile(sh.pk, text, td, tid);
 
     // ---- phase 2: each wave walks a contiguous range of 64-position words ----------------------------------
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -819,7 +809,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     typename std::conditional<WIDE, int64_t, uint32_t>::type sum_acc = 0;   // per lane
     uint64_t* my_bits = bits + (size_t)blockIdx.x * TILE_BITS_U64;
     K31Words<false> words;
-    if (w_begin < w_end) words.start(sh, off, td.n_kmers, lane, w_begin);
+    if (w_begin < w_end) words.start(sh.pk, off, td.n_kmers, lane, w_begin);
 
     for (int w = w_begin; w < w_end; ++w) {
         uint64_t fwd, rc, V;
@@ -861,12 +851,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     int64_t count_sum;
     if constexpr (WIDE) count_sum = wave_sum_i64(sum_acc);
     else count_sum = (int64_t)wave_sum_u32_dpp(sum_acc);
-    if (lane == 0) sh.sum[wave] = count_sum;
+    if (lane == 0) sh.pk.sum[wave] = count_sum;
     __syncthreads();
     if (tid == 0) {
         int64_t t = 0;
 #pragma unroll
-        for (int i = 0; i < WAVES; ++i) t += sh.sum[i];
+        for (int i = 0; i < WAVES; ++i) t += sh.pk.sum[i];
         count_sums[blockIdx.x] = t;
     }
 }
@@ -885,95 +875,45 @@ struct K31CQueue {
     unsigned long long vw[K31_WORDS_PER_WAVE];              // their validity ballots (written out with the hits)
 };
 
-// The probe of a word is split in two so that the line fetches of word w + 1 are in flight while word w is matched: with
-// ~80 VALU instructions per word the kernel is no longer issue-bound, and a wave that waits for its own lines before it
-// derives the next word leaves the memory system at ~2/3 of the line rate it can sustain (8 waves per SIMD is the cap).
-// The lines travel through registers here (global_load_dwordx4 -> ds_write_b128), not LDS-DMA: the compiler orders EVERY
-// LDS read after an outstanding LDS-DMA (s_waitcnt vmcnt(0)), which would serialise exactly what is meant to overlap;
-// register-staged loads are tracked per register, cost no VALU either, and need one line buffer per wave, not two.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // a native vector: HIP's uint4 is a union-based struct, which
-                                                              // a conditionally loaded member of sends to scratch
+// The probe of a word is split in two so that the cell loads of word w + 1 are in flight while word w is matched: with
+// ~65 VALU instructions per word the kernel is no longer issue-bound, and a wave that waits for its own loads before it
+// derives the next word leaves the memory system well below the request rate it can sustain (8 waves per SIMD is the cap).
+// Every lane loads its own 8-byte cell; the lanes of a minimizer run aim at the same 128-byte line, which goes to HBM once.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));   // a native vector (HIP's uint2 is a union-based struct)
 struct CellWord {
     uint64_t V;            // valid lanes
-    int nruns, my_run;
-    uint32_t sh, w, r;     // this lane's cell (CellProbe)
-    u32x4 d0, d1;          // a fetching lane's 16-byte pieces of runs fetch_run and fetch_run + 7
+    uint32_t w, r;         // what this lane's cell must hold (CellProbe)
+    u32x2 cell;            // what it holds
 };
 
-// stage A: run detection, run list, first chunk of line fetches issued (not waited for).
-// Every word issues exactly two fetch instructions with every lane active, and stage B consumes both unconditionally:
-// the compiler can then count what is in flight (s_waitcnt vmcnt(2) at the stores of word w while word w + 1's loads stay
-// out) -- a fetch under `if (run < nruns)` is a branch it must assume both ways, and it falls back to vmcnt(0) everywhere.
-// Lanes whose run does not exist fetch the last run's line again (the same line in the same instruction: no new request),
-// the idle ninth lane of a group repeats the eighth piece.
-__device__ __forceinline__ void cells_issue(const TableView& tv, const K31Fetch& f, uint32_t* runline, int lane, uint64_t V,
-                                            const CellProbe& p, CellWord& cw) {
+// stage A: the cell load of every lane, issued and not waited for. Exactly one load instruction per word, every lane
+// active (an invalid lane reads line 0): the compiler can then count what is in flight -- s_waitcnt vmcnt(1) where word w is
+// consumed while word w + 1's load stays out -- instead of falling back to vmcnt(0) as it must around a conditional load.
+__device__ __forceinline__ void cells_issue(const TableView& tv, uint64_t V, const CellProbe& p, CellWord& cw) {
     const bool valid = __builtin_amdgcn_inverse_ballot_w64(V);
-    const uint32_t tgt = p.line;
-    // heads of runs: valid lanes whose predecessor is invalid or aims at another line
-    const uint64_t HM = V & (~(V << 1) | wave_ballot(wave_shr1(tgt) != tgt));
     cw.V = V;
-    cw.nruns = __popcll(HM);
-    const uint64_t H1 = HM >> 1;
-    cw.my_run = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(H1 >> 32),
-                                               __builtin_amdgcn_mbcnt_lo((uint32_t)H1, (uint32_t)((int)(HM & 1) - 1)));
-    cw.sh = p.sh;
     cw.w = p.w;
     cw.r = p.r;
-    if (valid) runline[cw.my_run] = tgt;                    // every lane of a run stores the same line number
-    if (V == 0 && lane == 0) runline[0] = 0;                // no run at all: everybody fetches line 0 (and nobody looks at it)
-    wave_lds_fence();
-    const uint32_t last = (uint32_t)max(cw.nruns - 1, 0);
-    const uint32_t l0 = runline[min((uint32_t)f.fetch_run, last)], l1 = runline[min((uint32_t)f.fetch_run + 7u, last)];
-    const uint8_t* base = tv.lines + 16 * f.piece8;
-    cw.d0 = *reinterpret_cast<const u32x4*>(base + (size_t)l0 * LINE_BYTES);
-    cw.d1 = *reinterpret_cast<const u32x4*>(base + (size_t)l1 * LINE_BYTES);
+    const uint32_t line = valid ? p.line : 0u;
+    // lines are 128-byte aligned: the cell's offset in the line (8 * cell = 4 * sh) is OR-ed into the low dword
+    const uint64_t off = ((uint64_t)line << 7) | (uint64_t)(p.sh << 2);
+    cw.cell = *reinterpret_cast<const u32x2*>(tv.lines + off);
 }
 
-// one chunk of 14 runs, lines already in LDS: the lanes of those runs read their cell
-__device__ __forceinline__ void cells_match_chunk(const K31Fetch& f, bool valid, const CellWord& cw, int c0, uint32_t& cnt, uint32_t& pend) {
-    const uint32_t rel = (uint32_t)(cw.my_run - c0);
-    if (valid && rel < (uint32_t)K31_RUNS) {
-        const uint8_t* base = reinterpret_cast<const uint8_t*>(f.lines + rel * K31_PITCH);
-        const uint32_t w = *reinterpret_cast<const uint32_t*>(base + 2 * cw.sh);
-        const uint32_t r = *reinterpret_cast<const uint16_t*>(base + CELL_R_OFF + cw.sh);
-        const uint32_t c = *reinterpret_cast<const uint16_t*>(base + CELL_C_OFF + cw.sh);
-        const bool match = ((w ^ cw.w) <= CELL_FLAG_MASK) && (r == cw.r);
-        cnt = match ? c : 0u;
-        pend = match ? 0u : (w & CELL_FLAG_STASH);
-    }
-}
-
-// stage B: the fetched pieces go to the wave's line buffer (lane i's piece at 16 i: nine-lane groups, 144-byte pitch; the
-// repeats land in slots nobody reads, or carry the same bytes as their slot's owner), every valid lane reads its cell.
-// Outputs cnt (0 unless the k-mer is in its cell) and pend (non-zero: not in its cell, and the cell is flagged for the
-// stash). A word with more than 14 runs (about one in a thousand) fetches the rest here, waiting.
-__device__ __forceinline__ void cells_match(const TableView& tv, const K31Fetch& f, const uint32_t* runline, int lane, const CellWord& cw,
-                                            uint32_t& cnt, uint32_t& pend) {
+// stage B: cnt = the stored counter if the cell holds this lane's k-mer (else 0), pend != 0 if it does not and the cell is
+// flagged for the stash
+__device__ __forceinline__ void cells_match(const CellWord& cw, uint32_t& cnt, uint32_t& pend) {
     const bool valid = __builtin_amdgcn_inverse_ballot_w64(cw.V);
-    u32x4* const lines = reinterpret_cast<u32x4*>(f.lines);
-    lines[lane] = cw.d0;
-    lines[7 * K31_PITCH + lane] = cw.d1;
-    wave_lds_fence();
-    cells_match_chunk(f, valid, cw, 0, cnt, pend);
-    wave_lds_fence();
-    if (__builtin_expect((uint32_t)cw.nruns > (uint32_t)K31_RUNS, 0)) {
-        for (int c0 = K31_RUNS; c0 < cw.nruns; c0 += K31_RUNS) {
-            if (f.fetcher) {
-                const int r0 = c0 + f.fetch_run, r1 = r0 + 7;
-                const uint32_t l0 = runline[r0], l1 = runline[r1];
-                if (r0 < cw.nruns) lines[lane] = *reinterpret_cast<const u32x4*>(tv.lines + (size_t)l0 * LINE_BYTES + 16 * f.piece);
-                if (r1 < cw.nruns) lines[7 * K31_PITCH + lane] = *reinterpret_cast<const u32x4*>(tv.lines + (size_t)l1 * LINE_BYTES + 16 * f.piece);
-            }
-            wave_lds_fence();
-            cells_match_chunk(f, valid, cw, c0, cnt, pend);
-            wave_lds_fence();
-        }
+    if (valid) {
+        const uint32_t x = cw.cell.x, y = cw.cell.y;
+        const bool match = ((x ^ cw.w) <= CELL_FLAG_MASK) && ((uint16_t)y == (uint16_t)cw.r);
+        cnt = match ? (y >> 16) : 0u;
+        pend = match ? 0u : (x & CELL_FLAG_STASH);
     }
 }
 
 // canonical k-mer (Kmer.java:72-79) at packed position q of the tile, from the interleaved code words
-__device__ __forceinline__ uint64_t k31_canonical_at(const K31Shared& sh, int q) {
+__device__ __forceinline__ uint64_t k31_canonical_at(const K31Pack& sh, int q) {
     constexpr uint32_t lo_mask = ~0u << 2;
     const int b0 = 2 * q - 1;
     const uint2* p = sh.fcx + 1 + (b0 >> 5);
@@ -986,7 +926,7 @@ __device__ __forceinline__ uint64_t k31_canonical_at(const K31Shared& sh, int q)
 
 // Stash lookups for the first min(qn, 64) queued k-mers (their keys are re-derived from the packed tile: the queue only
 // holds where they sit); returns the new qn.
-__device__ __forceinline__ int k31c_stash_round(const TableView& tv, const K31Shared& sh, K31CQueue& q, int lane, int qn, int pos0,
+__device__ __forceinline__ int k31c_stash_round(const TableView& tv, const K31Pack& sh, K31CQueue& q, int lane, int qn, int pos0,
                                                 int32_t min_count, uint32_t& sum_acc) {
     const int nb = min(qn, 64), rest = qn - nb;
     const uint32_t id = q.id[lane];
@@ -1005,7 +945,7 @@ __device__ __forceinline__ int k31c_stash_round(const TableView& tv, const K31Sh
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void screen_k31c_kernel(
     const uint8_t* __restrict__ text, const TileDesc* __restrict__ tiles, TableView tv, int32_t min_count,
     uint64_t* __restrict__ bits, int64_t* __restrict__ count_sums) {
-    __shared__ K31Shared sh;
+    __shared__ K31Pack sh;
     __shared__ K31CQueue s_queue[WAVES];
     const TileDesc td = tiles[blockIdx.x];
     const int tid = threadIdx.x;
@@ -1016,7 +956,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const int wpw = (n_words + WAVES - 1) / WAVES;
     const int w_begin = min(wave * wpw, n_words);
     const int w_end = min(w_begin + wpw, n_words);
-    const K31Fetch fetch = fetch_setup(sh.lines[wave], sh.runline[wave], lane);
     K31CQueue& q = s_queue[wave];
     int qn = 0;                                             // queued k-mers (wave-uniform)
     const int pos0 = off + w_begin * 64;                    // packed position of the wave's first k-mer
@@ -1032,12 +971,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         uint32_t mn;
         words.next(w, fwd, rc, mn, V);
         const CellProbe p = cell_probe_of(fwd, rc, mn, (uint32_t)lane, tv.lbits);
-        cells_issue(tv, fetch, sh.runline2[wave][(w - w_begin) & 1], lane, V, p, cw);
+        cells_issue(tv, V, p, cw);
     };
     // stage B of word w: cells matched, ballots out, stash candidates queued
     auto retire = [&](int w, const CellWord& cw) {
         uint32_t cnt = 0, pend = 0;
-        cells_match(tv, fetch, sh.runline2[wave][(w - w_begin) & 1], lane, cw, cnt, pend);
+        cells_match(cw, cnt, pend);
         // cnt is 0 unless the k-mer was found and min_count >= 1 (checked by the API), so this is "found && count >= -c"
         const bool hit = (int32_t)cnt >= min_count;                         // GetVariants.java:224
         const uint64_t H = wave_ballot(hit);
@@ -1212,7 +1151,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         s_tab[tid].lines = t.lines;
         s_tab[tid].n_lines = t.n_lines;
     }
-    const int off = k31_pack_tile(sh, text, td, tid);       // (block barrier inside)
+    const int off = k31_pack_tile(sh.pk, text, td, tid);       // (block barrier inside)
 
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_words = (td.n_kmers + 63) >> 6;
@@ -1225,7 +1164,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     if (lane < MULTI_MAX) s_msum[wave][lane] = 0;
     wave_lds_fence();
     K31Words<false> words;
-    if (w_begin < w_end) words.start(sh, off, td.n_kmers, lane, w_begin);
+    if (w_begin < w_end) words.start(sh.pk, off, td.n_kmers, lane, w_begin);
 
     for (int w = w_begin; w < w_end; ++w) {
         uint64_t fwd, rc, V;

@@ -12,9 +12,10 @@ import shutil
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-KERNEL = "screen_k31_kernel"      # the dominant kernel of the bench workload (k = 31, minimizer table)
 src = f"gpurun_out/{tag}"
 os.makedirs("profiles", exist_ok=True)
+# the dominant kernel of the bench workload, as the bench line names it (screen_k31c_kernel on a cell table)
+KERNEL = json.load(open(f"{src}/bench.json"))["roofline"]["kernel"]
 
 
 def counters(pattern, kernel):
@@ -28,6 +29,7 @@ def counters(pattern, kernel):
 
 out = {"tag": tag}
 bench = json.load(open(f"{src}/bench.json"))
+out["kernel"] = KERNEL
 out["bench"] = {k: bench[k] for k in ("value", "ms_per_step", "roofline", "cpu_baseline", "parity", "config")}
 for f in glob.glob(f"{src}/stats/*kernel_stats.csv"):
     shutil.copy(f, f"profiles/{tag}_kernel_stats.csv")
