@@ -85,6 +85,7 @@ typedef struct {
     int64_t stash_kmers;     /* format 1: k-mers that found a cell taken and live in the stash */
     int64_t stash_bytes;     /* format 1: HBM bytes of the stash (included in table_bytes) */
     int64_t multi_cell_kmers;/* format 1: k-mers stored in more than one cell (tied or palindromic minimizers) */
+    int64_t second_choice_kmers; /* format 1: placements in the second-choice cell of a line (first choice taken) */
 } kcfx_db_info_t;
 
 /* ---- database ------------------------------------------------------------------------------------ */

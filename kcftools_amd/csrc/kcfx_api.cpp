@@ -373,6 +373,7 @@ int32_t cells_stash_alloc(kcfx_db* db) {
     db->info.stash_kmers = (int64_t)h[0];
     db->info.stored_kmers = (int64_t)h[1];
     db->info.multi_cell_kmers = (int64_t)h[2];
+    db->info.second_choice_kmers = (int64_t)h[3];
     uint64_t slots = 1024;                                  // load <= 0.25: ~1.2 entries looked at per lookup
     while (slots < 4 * h[0]) slots <<= 1;
     if (slots > (1ull << 32)) return fail(KCFX_ERR_ARG, "stash too large for a 32-bit slot index");
@@ -550,7 +551,17 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     if (h.lut_entries) LOAD_HIP(hipMemcpyAsync(d_lut, h.lut_bytes, (size_t)h.lut_entries * 8, hipMemcpyHostToDevice, db->stream));
     tr.mark("buffers + LUT upload");
 
-    // phase: 0 = count per home line (minimizer tables only), 1 = insert
+    // One pass of the build over a batch of decoded records. Line tables: 0 = count per home line (minimizer tables only),
+    // 1 = insert. Cell tables: 0 = bid for first-choice cells, 1 = settle the losers, 2 = fill the stash.
+    auto apply = [&](int phase, const uint64_t* keys, const uint32_t* counts, int64_t n) -> hipError_t {
+        if (cells) {
+            if (phase == 0) return launch_cells_insert(db->d_lines, db->lbits, keys, counts, n, db->stream);
+            if (phase == 1) return launch_cells_settle(db->d_lines, db->lbits, keys, counts, n, db->d_stats, db->stream);
+            return launch_cells_stash(db->d_lines, db->lbits, keys, counts, n, db->d_stash, db->stash_mask, db->stream);
+        }
+        if (phase == 0) return launch_table_count(db->d_lines, db->view(), h.k, keys, n, db->stream);
+        return launch_table_insert(db->d_lines, db->view(), h.k, keys, counts, n, db->stream);
+    };
     auto stream_file = [&](int phase, bool keep) -> int32_t {
         int64_t first = 0;
         int turn = 0;
@@ -571,47 +582,42 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
             uint32_t* counts = d_counts + (keep ? first : 0);
             LOAD_HIP(launch_decode_records(d_rec[turn], first, n, h.record_size, h.suffix_bytes, h.counter_size, h.p, d_lut,
                                            h.lut_entries, keys, counts, db->stream));
-            if (cells && phase == 0)
-                LOAD_HIP(launch_cells_insert(db->d_lines, db->lbits, keys, counts, n, db->d_stats, db->stream));
-            else if (cells)
-                LOAD_HIP(launch_cells_stash(db->d_lines, db->lbits, keys, counts, n, db->d_stash, db->stash_mask, db->stream));
-            else if (phase == 0)
-                LOAD_HIP(launch_table_count(db->d_lines, db->view(), h.k, keys, n, db->stream));
-            else
-                LOAD_HIP(launch_table_insert(db->d_lines, db->view(), h.k, keys, counts, n, db->stream));
+            LOAD_HIP(apply(phase, keys, counts, n));
             first += n;
             turn ^= 1;
         }
         return KCFX_OK;
+    };
+    // a later pass: straight from HBM when the decoded records were kept (launches of at most 2^30 records), else the
+    // file is streamed again
+    auto later_pass = [&](int phase) -> int32_t {
+        if (resident) {
+            for (int64_t first = 0; first < h.total; first += (1ll << 30)) {
+                const int64_t n = std::min<int64_t>(1ll << 30, h.total - first);
+                LOAD_HIP(apply(phase, d_keys + first, d_counts + first, n));
+            }
+            return KCFX_OK;
+        }
+        LOAD_HIP(hipStreamSynchronize(db->stream));
+        return stream_file(phase, false);
     };
 
     if (!two_phase) {
         if ((rc = stream_file(1, false))) return rc;
     } else {
         if ((rc = stream_file(0, resident))) return rc;
-        tr.mark("file -> decode -> count (host)");
+        tr.mark("file -> decode -> first pass (host)");
         if (cells) {
+            if ((rc = later_pass(1))) return rc;
             if ((rc = cells_stash_alloc(db))) {
                 cleanup();
                 return rc;
             }
-            tr.mark("stash alloc");
+            tr.mark("settle + stash alloc");
+            if ((rc = later_pass(2))) return rc;
         } else {
             LOAD_HIP(launch_table_mark_heavy(db->d_lines, db->n_lines, db->stream));
-        }
-        if (resident) {
-            // second phase straight from HBM, in launches of at most 2^30 records
-            for (int64_t first = 0; first < h.total; first += (1ll << 30)) {
-                const int64_t n = std::min<int64_t>(1ll << 30, h.total - first);
-                if (cells)
-                    LOAD_HIP(launch_cells_stash(db->d_lines, db->lbits, d_keys + first, d_counts + first, n, db->d_stash,
-                                                db->stash_mask, db->stream));
-                else
-                    LOAD_HIP(launch_table_insert(db->d_lines, db->view(), h.k, d_keys + first, d_counts + first, n, db->stream));
-            }
-        } else {
-            LOAD_HIP(hipStreamSynchronize(db->stream));
-            if ((rc = stream_file(1, false))) return rc;
+            if ((rc = later_pass(1))) return rc;
         }
     }
     LOAD_HIP(hipStreamSynchronize(db->stream));
@@ -722,7 +728,8 @@ int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, 
             (e = hipMemcpyAsync(d_counts, src, (size_t)n * 4, hipMemcpyHostToDevice, db->stream)) != hipSuccess)
             rc = hip_fail(e, "kcfx_db_build upload");
         if (!rc && db->fmt == FORMAT_CELLS) {
-            if ((e = launch_cells_insert(db->d_lines, db->lbits, d_keys, d_counts, n, db->d_stats, db->stream)) != hipSuccess)
+            if ((e = launch_cells_insert(db->d_lines, db->lbits, d_keys, d_counts, n, db->stream)) != hipSuccess ||
+                (e = launch_cells_settle(db->d_lines, db->lbits, d_keys, d_counts, n, db->d_stats, db->stream)) != hipSuccess)
                 rc = hip_fail(e, "kcfx_db_build insert");
             if (!rc) rc = cells_stash_alloc(db);
             if (!rc && ((e = launch_cells_stash(db->d_lines, db->lbits, d_keys, d_counts, n, db->d_stash, db->stash_mask, db->stream)) != hipSuccess ||

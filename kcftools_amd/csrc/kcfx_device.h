@@ -211,6 +211,12 @@ KCFX_HD uint32_t cell_flank(uint64_t N, uint32_t sh, uint32_t* m_out) {
     return (keep & ((uint32_t)t >> sh)) | (~keep & (uint32_t)(N >> 32));
 }
 
+// Second choice: a k-mer that finds its cell taken may live in ONE other cell of the same line, 1, 3, .. 15 cells away
+// (xor) as its leading flank bits say; there it is stored with bit 15 of r set, so that it can never be mistaken for the
+// k-mer that has the same (w, r) and this cell as its first choice. sh = 2 * cell index.
+constexpr uint32_t CELL_R_ALT = 0x8000u;
+KCFX_HD uint32_t cell_alt_sh(uint32_t sh, uint32_t w) { return sh ^ (((w >> 27) & 0x1Cu) | 2u); }
+
 struct CellProbe {
     uint32_t line;      // top lbits of G32
     uint32_t sh;        // 2 * cell index (= byte offset of the cell's r / count; w is at 2 * sh)

@@ -56,14 +56,18 @@ constexpr int MODE_KEYHASH = 0, MODE_MINIMIZER = 1;
 //             to this cell lives in the stash | bit 1: reserved
 //     r     = low (32 - lbits) bits of G32 = (27-bit minimizer hash : minimizer & 31), re-spread; the line number is
 //             the top lbits of G32, and G32 <-> canonical minimizer 16-mer is a bijection (cell_g32)
+//             (at most 15 bits: lbits >= 17) | bit 15: this k-mer sits in its SECOND-choice cell
 //     count = the stored counter; 0 = empty cell (a k-mer whose counter is 0 can never be observed -- GetVariants.java:224
 //             needs count >= -c >= 1 -- so it is not stored)
 //   (line, cell, w, r) -> N -> canonical k-mer is injective, so equality of (w, r) in the k-mer's cell IS equality of
-//   the k-mer. K-mers that find their cell taken go to the stash: open addressing over 16-byte entries
-//   {u64 key, u32 count, u32 pad}, slot = hash32(key) & mask, probed by the lanes individually.
+//   the k-mer. When several k-mers want one cell the one with the largest counter gets it (a 64-bit atomic max: the
+//   build is deterministic, and in a real database the genomic k-mer beats its sequencing-error neighbours, which
+//   share its minimizer and offset). A loser takes its second-choice cell in the same line if that is empty
+//   (cell_alt_sh), else it goes to the stash: open addressing over 16-byte entries {u64 key, u32 count, u32 pad},
+//   slot = hash32(key) & mask, probed by the lanes individually.
 // ----------------------------------------------------------------------------------------------------
 constexpr int FORMAT_LINES = 0, FORMAT_CELLS = 1;
-constexpr int CELL_LBITS_MIN = 16, CELL_LBITS_MAX = 31;     // r must fit 16 bits; n_lines fits 32
+constexpr int CELL_LBITS_MIN = 17, CELL_LBITS_MAX = 31;     // r must fit 15 bits (bit 15 marks a second-choice cell); n_lines fits 32
 constexpr uint32_t CELL_FLAG_STASH = 1u, CELL_FLAG_MASK = 3u;
 // a cell as one 64-bit word: w in bits 0..31, r in 32..47, count in 48..63
 __host__ __device__ inline uint64_t cell_word(uint32_t w, uint32_t r, uint32_t count) {
@@ -88,7 +92,10 @@ struct TableView {
 // workgroup screens one tile and emits its hit bitmap; reduce_windows summarises the bitmaps piecewise (TileSummary)
 // and folds a window's pieces in order.
 // ----------------------------------------------------------------------------------------------------
-constexpr int BLOCK = 256;            // 4 wavefronts
+#ifndef KCFX_BLOCK
+#define KCFX_BLOCK 256
+#endif
+constexpr int BLOCK = KCFX_BLOCK;     // 4 wavefronts
 #ifndef KCFX_TILE_K
 #define KCFX_TILE_K 2048
 #endif
@@ -207,8 +214,10 @@ hipError_t launch_table_mark_heavy(uint8_t* lines, uint32_t n_lines, hipStream_t
 hipError_t launch_table_insert(uint8_t* lines, TableView tv, int32_t k, const uint64_t* keys,
                                const uint32_t* counts, int64_t n, hipStream_t st);
 hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide, unsigned long long* stats, hipStream_t st);
-// FORMAT_CELLS build: pass 1 claims cells and counts the k-mers that need the stash (stats[0]); pass 2 fills the stash
-hipError_t launch_cells_insert(uint8_t* lines, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n,
+// FORMAT_CELLS build: pass 1 bids for first-choice cells; pass 2 (after ALL of pass 1) settles the losers into second-choice
+// cells or flags them for the stash (stats[0] = how many); pass 3 (after ALL of pass 2) fills the stash
+hipError_t launch_cells_insert(uint8_t* lines, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n, hipStream_t st);
+hipError_t launch_cells_settle(uint8_t* lines, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n,
                                unsigned long long* stats, hipStream_t st);
 hipError_t launch_cells_stash(const uint8_t* lines, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n,
                               uint4* stash, uint32_t stash_mask, hipStream_t st);

@@ -175,12 +175,10 @@ __global__ __launch_bounds__(256) void lookup_kernel(TableView tv, int32_t k, co
 // ======================================================================================================
 // FORMAT_CELLS build + lookup (layout and exactness argument: kcfx_internal.h; cell derivation: kcfx_device.h)
 // ======================================================================================================
-// Pass 1: every stored k-mer claims its cell(s) with one 64-bit CAS (count == 0 marks an empty cell; its flag bits may
-// already be set by an earlier loser and are kept); the first arrival wins, later ones flag the cell and are counted for
-// the stash. stats[0] = k-mers that need the stash, stats[1] = k-mers stored (count != 0), stats[2] = k-mers with more
-// than one cell
+// Pass 1: every stored k-mer bids for its first-choice cell(s) with a 64-bit atomic max -- the count is the most
+// significant field, so the most abundant k-mer gets the cell whatever the arrival order.
 __global__ void cells_insert_kernel(uint8_t* lines, int32_t lbits, const uint64_t* __restrict__ keys,
-                                    const uint32_t* __restrict__ counts, int64_t n, unsigned long long* stats) {
+                                    const uint32_t* __restrict__ counts, int64_t n) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
@@ -188,22 +186,55 @@ __global__ void cells_insert_kernel(uint8_t* lines, int32_t lbits, const uint64_
         if (c == 0) continue;                       // can never be observed (count >= -c >= 1 is needed): not stored
         CellProbe cand[CELL_MAX_CANDS];
         const int nc = cells_of_key(keys[i], lbits, cand);
+        for (int a = 0; a < nc; ++a)
+            atomicMax(reinterpret_cast<unsigned long long*>(lines + (size_t)cand[a].line * LINE_BYTES + 4 * cand[a].sh),
+                      (unsigned long long)cell_word(cand[a].w, cand[a].r, c));
+    }
+}
+
+// where a k-mer stands after the bidding: in its first-choice cell, in its second-choice cell, or in neither
+__device__ __forceinline__ int cell_standing(const uint8_t* lines, const CellProbe& p, uint32_t c) {
+    const uint8_t* line = lines + (size_t)p.line * LINE_BYTES;
+    const uint64_t first = __atomic_load_n(reinterpret_cast<const uint64_t*>(line + 4 * p.sh), __ATOMIC_RELAXED);
+    if ((first & ~(uint64_t)CELL_FLAG_MASK) == cell_word(p.w, p.r, c)) return 0;
+    const uint64_t second = __atomic_load_n(reinterpret_cast<const uint64_t*>(line + 4 * cell_alt_sh(p.sh, p.w)), __ATOMIC_RELAXED);
+    if ((second & ~(uint64_t)CELL_FLAG_MASK) == cell_word(p.w, p.r | CELL_R_ALT, c)) return 1;
+    return 2;
+}
+
+// Pass 2 (after pass 1 has completed): a k-mer that lost a bid takes its second-choice cell if that is still empty (no
+// k-mer has it as first choice then), else it flags its first-choice cell -- "someone who belongs here lives in the
+// stash" -- and is counted. stats[0] = k-mers for the stash, [1] = k-mers stored (count != 0), [2] = k-mers with more
+// than one first-choice cell, [3] = second-choice placements
+__global__ void cells_settle_kernel(uint8_t* lines, int32_t lbits, const uint64_t* __restrict__ keys,
+                                    const uint32_t* __restrict__ counts, int64_t n, unsigned long long* stats) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const uint32_t c = counts[i] & 0xFFFFu;
+        if (c == 0) continue;
+        CellProbe cand[CELL_MAX_CANDS];
+        const int nc = cells_of_key(keys[i], lbits, cand);
         bool lost = false;
         for (int a = 0; a < nc; ++a) {
-            unsigned long long* cell = reinterpret_cast<unsigned long long*>(lines + (size_t)cand[a].line * LINE_BYTES + 4 * cand[a].sh);
-            const unsigned long long mine = cell_word(cand[a].w, cand[a].r, c);
-            unsigned long long old = __atomic_load_n(cell, __ATOMIC_RELAXED);
+            if (cell_standing(lines, cand[a], c) != 2) continue;     // (1: the same word twice in the input)
+            uint8_t* line = lines + (size_t)cand[a].line * LINE_BYTES;
+            unsigned long long* alt = reinterpret_cast<unsigned long long*>(line + 4 * cell_alt_sh(cand[a].sh, cand[a].w));
+            const unsigned long long mine = cell_word(cand[a].w, cand[a].r | CELL_R_ALT, c);
+            unsigned long long old = __atomic_load_n(alt, __ATOMIC_RELAXED);
             bool won = false;
             while ((old >> 48) == 0) {
-                const unsigned long long prev = atomicCAS(cell, old, mine | (old & CELL_FLAG_MASK));
+                const unsigned long long prev = atomicCAS(alt, old, mine | (old & CELL_FLAG_MASK));
                 if (prev == old) {
                     won = true;
                     break;
                 }
                 old = prev;
             }
-            if (!won) {
-                atomicOr(reinterpret_cast<uint32_t*>(cell), CELL_FLAG_STASH);
+            if (won) {
+                atomicAdd(&stats[3], 1ull);
+            } else if ((old & ~(unsigned long long)CELL_FLAG_MASK) != mine) {
+                atomicOr(reinterpret_cast<uint32_t*>(line + 4 * cand[a].sh), CELL_FLAG_STASH);
                 lost = true;
             }
         }
@@ -213,7 +244,7 @@ __global__ void cells_insert_kernel(uint8_t* lines, int32_t lbits, const uint64_
     }
 }
 
-// Pass 2 (after pass 1 has completed): a k-mer that does not find itself in every one of its cells goes to the stash.
+// Pass 3 (after pass 2 has completed): a k-mer that stands in neither cell of one of its candidates goes to the stash.
 __global__ void cells_stash_kernel(const uint8_t* __restrict__ lines, int32_t lbits, const uint64_t* __restrict__ keys,
                                    const uint32_t* __restrict__ counts, int64_t n, uint4* stash, uint32_t mask) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -225,10 +256,7 @@ __global__ void cells_stash_kernel(const uint8_t* __restrict__ lines, int32_t lb
         CellProbe cand[CELL_MAX_CANDS];
         const int nc = cells_of_key(key, lbits, cand);
         bool lost = false;
-        for (int a = 0; a < nc; ++a) {
-            const uint64_t cell = *reinterpret_cast<const uint64_t*>(lines + (size_t)cand[a].line * LINE_BYTES + 4 * cand[a].sh);
-            lost |= (cell & ~(uint64_t)CELL_FLAG_MASK) != cell_word(cand[a].w, cand[a].r, c);
-        }
+        for (int a = 0; a < nc; ++a) lost |= cell_standing(lines, cand[a], c) == 2;
         if (!lost) continue;
         uint32_t slot = stash_slot(key, mask);
         for (;;) {
@@ -268,10 +296,15 @@ __global__ __launch_bounds__(256) void lookup_cells_kernel(TableView tv, const u
         if (key <= revcomp_word(key, 31) && (key & 3ull) == 0) {
             CellProbe cand[CELL_MAX_CANDS];
             cells_of_key(key, tv.lbits, cand);                  // any one of its cells decides
-            const uint64_t cell = *reinterpret_cast<const uint64_t*>(tv.lines + (size_t)cand[0].line * LINE_BYTES + 4 * cand[0].sh);
-            if (((cell ^ cell_word(cand[0].w, cand[0].r, 0)) & 0x0000FFFFFFFFFFFCull) == 0)
-                result = (int32_t)(cell >> 48);
-            else if (cell & CELL_FLAG_STASH)
+            const uint8_t* line = tv.lines + (size_t)cand[0].line * LINE_BYTES;
+            const uint64_t first = *reinterpret_cast<const uint64_t*>(line + 4 * cand[0].sh);
+            const uint64_t second = *reinterpret_cast<const uint64_t*>(line + 4 * cell_alt_sh(cand[0].sh, cand[0].w));
+            constexpr uint64_t KEY_BITS = 0x0000FFFFFFFFFFFCull;                // w without the flags, r
+            if (((first ^ cell_word(cand[0].w, cand[0].r, 0)) & KEY_BITS) == 0)
+                result = (int32_t)(first >> 48);
+            else if (((second ^ cell_word(cand[0].w, cand[0].r | CELL_R_ALT, 0)) & KEY_BITS) == 0)
+                result = (int32_t)(second >> 48);
+            else if (first & CELL_FLAG_STASH)
                 result = (int32_t)stash_find(tv, key);
         }
         out[i] = result;
@@ -883,12 +916,13 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));   // a native vector
 struct CellWord {
     uint64_t V;            // valid lanes
     uint32_t w, r;         // what this lane's cell must hold (CellProbe)
-    u32x2 cell;            // what it holds
+    u32x2 cell, alt;       // what its first- and second-choice cells hold
 };
 
-// stage A: the cell load of every lane, issued and not waited for. Exactly one load instruction per word, every lane
-// active (an invalid lane reads line 0): the compiler can then count what is in flight -- s_waitcnt vmcnt(1) where word w is
-// consumed while word w + 1's load stays out -- instead of falling back to vmcnt(0) as it must around a conditional load.
+// stage A: the loads of every lane's two cells (same line), issued and not waited for. Exactly two load instructions per
+// word, every lane active (an invalid lane reads line 0): the compiler can then count what is in flight -- s_waitcnt
+// vmcnt(2) where word w is consumed while word w + 1's loads stay out -- instead of falling back to vmcnt(0) as it must
+// around a conditional load.
 __device__ __forceinline__ void cells_issue(const TableView& tv, uint64_t V, const CellProbe& p, CellWord& cw) {
     const bool valid = __builtin_amdgcn_inverse_ballot_w64(V);
     cw.V = V;
@@ -896,8 +930,9 @@ __device__ __forceinline__ void cells_issue(const TableView& tv, uint64_t V, con
     cw.r = p.r;
     const uint32_t line = valid ? p.line : 0u;
     // lines are 128-byte aligned: the cell's offset in the line (8 * cell = 4 * sh) is OR-ed into the low dword
-    const uint64_t off = ((uint64_t)line << 7) | (uint64_t)(p.sh << 2);
-    cw.cell = *reinterpret_cast<const u32x2*>(tv.lines + off);
+    const uint64_t off = (uint64_t)line << 7;
+    cw.cell = *reinterpret_cast<const u32x2*>(tv.lines + (off | (uint64_t)(p.sh << 2)));
+    cw.alt = *reinterpret_cast<const u32x2*>(tv.lines + (off | (uint64_t)(cell_alt_sh(p.sh, p.w) << 2)));
 }
 
 // stage B: cnt = the stored counter if the cell holds this lane's k-mer (else 0), pend != 0 if it does not and the cell is
@@ -905,10 +940,11 @@ __device__ __forceinline__ void cells_issue(const TableView& tv, uint64_t V, con
 __device__ __forceinline__ void cells_match(const CellWord& cw, uint32_t& cnt, uint32_t& pend) {
     const bool valid = __builtin_amdgcn_inverse_ballot_w64(cw.V);
     if (valid) {
-        const uint32_t x = cw.cell.x, y = cw.cell.y;
-        const bool match = ((x ^ cw.w) <= CELL_FLAG_MASK) && ((uint16_t)y == (uint16_t)cw.r);
-        cnt = match ? (y >> 16) : 0u;
-        pend = match ? 0u : (x & CELL_FLAG_STASH);
+        const uint32_t x = cw.cell.x, y = cw.cell.y, xa = cw.alt.x, ya = cw.alt.y;
+        const bool first = ((x ^ cw.w) <= CELL_FLAG_MASK) && ((uint16_t)y == (uint16_t)cw.r);
+        const bool second = ((xa ^ cw.w) <= CELL_FLAG_MASK) && ((uint16_t)ya == (uint16_t)(cw.r | CELL_R_ALT));
+        cnt = first ? (y >> 16) : second ? (ya >> 16) : 0u;
+        pend = (first || second) ? 0u : (x & CELL_FLAG_STASH);
     }
 }
 
@@ -1343,10 +1379,16 @@ hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide,
     return hipGetLastError();
 }
 
-hipError_t launch_cells_insert(uint8_t* lines, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n,
+hipError_t launch_cells_insert(uint8_t* lines, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(cells_insert_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, lbits, keys, counts, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_cells_settle(uint8_t* lines, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n,
                                unsigned long long* stats, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(cells_insert_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, lbits, keys, counts, n, stats);
+    hipLaunchKernelGGL(cells_settle_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, lbits, keys, counts, n, stats);
     return hipGetLastError();
 }
 

@@ -40,7 +40,8 @@ class DbInfo(C.Structure):
                 ("table_mode", C.c_int32), ("minimizer_length", C.c_int32),
                 ("heavy_lines", C.c_int64), ("overflow_lines", C.c_int64),
                 ("table_format", C.c_int32), ("_pad", C.c_int32), ("stored_kmers", C.c_int64),
-                ("stash_kmers", C.c_int64), ("stash_bytes", C.c_int64), ("multi_cell_kmers", C.c_int64)]
+                ("stash_kmers", C.c_int64), ("stash_bytes", C.c_int64), ("multi_cell_kmers", C.c_int64),
+                ("second_choice_kmers", C.c_int64)]
 
 
 class KcfxError(RuntimeError):
