@@ -17,6 +17,9 @@
  *   Window.addTotalKmers/setEffLength/addData args Plugins/GetVariants.java:254-258 -> kcfx_result
  *   Data.update / Data.computeScore                Data/Data.java:70-107       -> kcfx_score
  *   Logger.error -> System.exit(1)                 Utils/Logger.java:29-31     -> int32 status + kcfx_last_error
+ *   one run per sample, then `cohort`              utils/run_kcftools.sh:124-140, Plugins/GetVariants.java:129-151
+ *                                                                               -> kcfx_ctx_create + kcfx_screen_sharded
+ *                                                                                  (every GPU of the node, one call)
  *
  * Conventions
  *   - every entry point returns 0 on success, non-zero on failure; the library never exits or aborts;
@@ -46,6 +49,7 @@ extern "C" {
 
 typedef struct kcfx_db kcfx_db;     /* one KMC database re-indexed into an HBM-resident table on one GPU */
 typedef struct kcfx_ref kcfx_ref;   /* reference text + window list resident in HBM on one GPU */
+typedef struct kcfx_ctx kcfx_ctx;   /* a set of GPUs of one node that kcfx_screen_sharded spreads a job over */
 
 /* Per (window, sample) integers: exactly the arguments of Window.addTotalKmers(int), Window.setEffLength(int)
  * and Window.addData(sample, obs, var, inner, left, right, kmerCount, ...)  (GetVariants.java:254-258). 40 bytes. */
@@ -101,6 +105,10 @@ int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, 
 
 int32_t kcfx_db_info(const kcfx_db* db, kcfx_db_info_t* info);
 
+/* The header fields alone (KMC.java:107-168 readPrefixFile; what GetVariants.java:96,103 needs for the KCF header before
+ * any window is screened): parses <kmc_prefix>.kmc_pre on the host, touches no GPU. The table_* fields stay zero. */
+int32_t kcfx_db_header(const char* kmc_prefix, kcfx_db_info_t* info);
+
 /* Batched KMC.getCount (KMC.java:292-326): counts_out[i] = stored counter of kmers[i] or 0.  The words are looked
  * up as given (canonicalise first for a both-strands database, as Kmer(Kmer, bothStrands) does, Kmer.java:57-65).
  * Counts are Java ints: a 4-byte counter with the top bit set is negative. Host pointers. */
@@ -126,7 +134,10 @@ void kcfx_ref_destroy(kcfx_ref* ref);
 int32_t kcfx_screen_ref(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count, kcfx_result* out);
 
 /* Same, asynchronous on `hip_stream` (a hipStream_t, NULL = default stream) with the results left in device
- * memory `out_device` (n_windows * sizeof(kcfx_result) bytes). No host synchronisation, no allocation. */
+ * memory `out_device` (n_windows * sizeof(kcfx_result) bytes). No host synchronisation, no allocation.
+ * ONE screen in flight per kcfx_ref: the hit bitmaps between the two kernels of a call are scratch owned by the
+ * reference, so calls on the same reference must be ordered (same stream, or an event between them); use one
+ * kcfx_ref per stream to overlap. */
 int32_t kcfx_screen_ref_async(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count, void* out_device, void* hip_stream);
 
 /* Several samples, ONE pass over the reference (SURVEY f-4): what the reference does as S getVariations runs followed by
@@ -152,6 +163,39 @@ int32_t kcfx_score(const kcfx_result* res, int64_t n, double wi, double wt, doub
  * *n_out = number of windows. window <= k-1 in tiling mode (the reference loops forever) is KCFX_ERR_ARG. */
 int32_t kcfx_windows(int32_t seq_len, int32_t window, int32_t step, int32_t kmer_length,
                      int32_t* starts, int32_t* ends, int64_t cap, int64_t* n_out);
+
+/* ---- all GPUs of a node ---------------------------------------------------------------------------------- */
+
+/* The units are independent -- a (window, sample) result needs that window's text and that sample's database only
+ * (GetVariants.java:138-150) -- so a job shards with no exchange step: one worker thread per listed device inside the
+ * library, each with its own resident reference. A device index may be listed more than once (shards share the GPU). */
+int32_t kcfx_ctx_create(const int32_t* devices, int32_t n_devices, kcfx_ctx** out);
+int32_t kcfx_ctx_n_devices(const kcfx_ctx* ctx);
+void kcfx_ctx_destroy(kcfx_ctx* ctx);
+
+#define KCFX_SHARD_AUTO 0      /* samples when n_samples >= devices, else windows */
+#define KCFX_SHARD_SAMPLES 1   /* device g screens samples g, g + G, ... against the whole window list */
+#define KCFX_SHARD_WINDOWS 2   /* device g screens a contiguous window range (equal k-mer start positions) of every sample */
+
+typedef struct {
+    int32_t shard_mode_used, n_devices;
+    double seconds_total;         /* wall time of the call */
+    double seconds_ref;           /* slowest device: reference upload + tile plan */
+    double seconds_db_open_sum;   /* summed over (device, sample): kcfx_db_open */
+    double seconds_screen_sum;    /* summed over (device, sample): kcfx_screen_ref */
+    double seconds_exposed_load;  /* slowest device: time its screening waited for a database (the rest of the loading
+                                     ran under the previous sample's screening) */
+} kcfx_shard_stats;
+
+/* getVariations for n_samples databases against one reference, on every device of `ctx`: what the reference does as one
+ * process per sample (run_kcftools.sh:124-140), each fanning its windows over a thread pool (GetVariants.java:129-151).
+ * out[s * n_windows + w] (host) = sample s (input order), window w -- each slice equals kcfx_screen_ref on that sample.
+ * On a device the next sample's database is opened while the current one is screened (at most two resident). Every
+ * database must have k-mer length `kmer_length`. `stats` may be NULL. Synchronous; the caller's buffers are not retained. */
+int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int32_t n_samples, int32_t kmer_length,
+                            const uint8_t* text, int64_t text_len, const int64_t* win_begin, const int32_t* win_len,
+                            int32_t n_windows, int32_t min_kmer_count, int32_t shard_mode, kcfx_result* out,
+                            kcfx_shard_stats* stats);
 
 /* ---- measurement ------------------------------------------------------------------------------------ */
 

@@ -46,14 +46,15 @@ void warning(const std::string& m) { log_line("WARNING", m); }
 struct Options {
     std::string ref, kmc, out, sample, feature, gtf;
     int threads = 2, window = 0, min_count = 1, step = 0;
-    std::vector<int> devices{0};          // --device N | --devices a,b,...: samples are sharded over them
+    std::vector<int> devices{0};          // --device N | --devices a,b,...: the job is sharded over them (kcfx_screen_sharded)
+    int shard = KCFX_SHARD_AUTO;          // --shard auto|samples|windows
     bool memory = false;
     double wi = 0.3, wt = 0.3, wr = 0.4;
 };
 
 void usage() {
     std::puts("Usage: kcftools-amd getVariations -r <ref.fa> -k <kmc prefix> -o <out.kcf> -s <sample> -f window|gene|transcript\n"
-              "       [-w window] [-p step] [-g gtf] [-c min-k-count] [--wi 0.3] [--wt 0.3] [--wr 0.4] [-t threads] [-m] [--device 0 | --devices 0,1,...]");
+              "       [-w window] [-p step] [-g gtf] [-c min-k-count] [--wi 0.3] [--wt 0.3] [--wr 0.4] [-t threads] [-m] [--device 0 | --devices 0,1,...] [--shard auto|samples|windows]");
 }
 
 std::vector<std::string> split_commas(const std::string& v) {
@@ -111,6 +112,13 @@ int main(int argc, char** argv) {
             for (const auto& d : split_commas(val())) o.devices.push_back(std::atoi(d.c_str()));
             if (o.devices.empty()) o.devices.push_back(0);
         }
+        else if (a == "--shard") {
+            const std::string v = val();
+            if (v == "auto") o.shard = KCFX_SHARD_AUTO;
+            else if (v == "samples") o.shard = KCFX_SHARD_SAMPLES;
+            else if (v == "windows") o.shard = KCFX_SHARD_WINDOWS;
+            else error("Invalid --shard value: " + v + " (auto, samples or windows)");
+        }
         else if (a == "-h" || a == "--help") { usage(); return 0; }
         else error("Unknown option: " + a);
     }
@@ -146,14 +154,12 @@ int main(int argc, char** argv) {
     o.sample = sample_list[0];
     for (size_t i = 1; i < sample_list.size(); ++i) o.sample += "\t" + sample_list[i];    // #CHROM line columns
 
-    // new KMC(prefix, loadMemory) (:95)
-    kcfx_db* db = nullptr;
-    if (kcfx_db_open(kmc_list[0].c_str(), o.devices[0], &db)) error(kcfx_last_error());
+    // new KMC(prefix, loadMemory) (:95): the header now (k for the windows and the KCF header, :96,:103); the records are
+    // loaded onto the GPUs by kcfx_screen_sharded, each database while the previous one is being screened
     kcfx_db_info_t dbi;
-    kcfx_db_info(db, &dbi);
+    if (kcfx_db_header(kmc_list[0].c_str(), &dbi)) error(kcfx_last_error());
     const int k = dbi.kmer_length;
-    info("KMC database: k=" + std::to_string(k) + ", " + std::to_string(dbi.total_kmers) + " k-mers, table " +
-         std::to_string(dbi.table_bytes >> 20) + " MiB on device " + std::to_string(o.devices[0]));
+    info("KMC database: k=" + std::to_string(k) + ", " + std::to_string(dbi.total_kmers) + " k-mers");
 
     FastaIndex index;
     std::string err;
@@ -236,55 +242,35 @@ int main(int argc, char** argv) {
         wb[(size_t)i] = wins[(size_t)i].text_begin;
         wl[(size_t)i] = wins[(size_t)i].text_len;
     }
-    // Reference text + windows resident in HBM once per device; the samples are sharded over the devices (sample s on
-    // device s mod G: independent units, no exchange -- SURVEY 8 e) and screened in batches of up to 8 resident
-    // databases, one pass over the reference per batch (kcfx_screen_ref_multi; a single sample is a batch of one).
+    // One call for every sample on every device (replaces the thread pool :129-159 and the per-sample runs of
+    // run_kcftools.sh:124-140): sample- or window-sharded, databases opened while their predecessors are screened. Errors
+    // come back as a status -- nothing exits from a worker thread.
     const size_t S = kmc_list.size();
-    const size_t G = std::min(o.devices.size(), S);
-    std::vector<std::vector<kcfx_result>> res(S, std::vector<kcfx_result>((size_t)n));
+    std::vector<kcfx_result> all(S * (size_t)n);
     std::vector<std::vector<double>> score(S, std::vector<double>((size_t)n)), depth(S, std::vector<double>((size_t)n));
-    auto worker = [&](size_t g) {
-        const int device = o.devices[g];
-        std::vector<size_t> mine;
-        for (size_t s = g; s < S; s += G) mine.push_back(s);
-        kcfx_ref* ref = nullptr;
-        if (kcfx_ref_create(device, k, reinterpret_cast<const uint8_t*>(text.data()), (int64_t)text.size(), wb.data(), wl.data(), n, &ref))
-            error(kcfx_last_error());
-        constexpr size_t BATCH = 8;
-        std::vector<kcfx_result> batch_res;
-        for (size_t i0 = 0; i0 < mine.size(); i0 += BATCH) {
-            const size_t nb = std::min(BATCH, mine.size() - i0);
-            std::vector<kcfx_db*> dbs(nb, nullptr);
-            for (size_t b = 0; b < nb; ++b) {
-                const size_t s = mine[i0 + b];
-                if (s == 0) {
-                    dbs[b] = db;                                                         // opened above for the header
-                    continue;
-                }
-                if (kcfx_db_open(kmc_list[s].c_str(), device, &dbs[b])) error(kcfx_last_error());
-                kcfx_db_info_t di;
-                kcfx_db_info(dbs[b], &di);
-                if (di.kmer_length != k) error("Kmer size mismatch between the KMC databases");  // KCFHeader.equals (cohort)
-            }
-            batch_res.resize(nb * (size_t)n);
-            if (kcfx_screen_ref_multi(dbs.data(), (int32_t)nb, ref, o.min_count, batch_res.data())) error(kcfx_last_error());
-            for (size_t b = 0; b < nb; ++b) {
-                const size_t s = mine[i0 + b];
-                std::copy(batch_res.begin() + (ptrdiff_t)(b * (size_t)n), batch_res.begin() + (ptrdiff_t)((b + 1) * (size_t)n), res[s].begin());
-                if (kcfx_score(res[s].data(), n, o.wi, o.wt, o.wr, score[s].data(), depth[s].data())) error(kcfx_last_error());   // Data.java:101-103
-                kcfx_db_close(dbs[b]);
-            }
-        }
-        kcfx_ref_destroy(ref);
-    };
-    if (G <= 1) {
-        worker(0);
-    } else {
-        std::vector<std::thread> th;
-        for (size_t g = 0; g < G; ++g) th.emplace_back(worker, g);
-        for (auto& t : th) t.join();
+    {
+        std::vector<int32_t> devices(o.devices.begin(), o.devices.end());
+        std::vector<const char*> prefixes;
+        for (const auto& p : kmc_list) prefixes.push_back(p.c_str());
+        kcfx_ctx* ctx = nullptr;
+        if (kcfx_ctx_create(devices.data(), (int32_t)devices.size(), &ctx)) error(kcfx_last_error());
+        kcfx_shard_stats st;
+        const int32_t rc = kcfx_screen_sharded(ctx, prefixes.data(), (int32_t)S, k, reinterpret_cast<const uint8_t*>(text.data()),
+                                               (int64_t)text.size(), wb.data(), wl.data(), n, o.min_count, o.shard, all.data(), &st);
+        const std::string msg = rc ? kcfx_last_error() : "";
+        kcfx_ctx_destroy(ctx);
+        if (rc) error(msg);
+        char line[256];
+        std::snprintf(line, sizeof line, "Screened %zu sample(s) on %d device(s), %s-sharded: %.3f s (reference %.3f s, database loading %.3f s of which %.3f s not hidden behind screening, screening %.3f s)",
+                      S, st.n_devices, st.shard_mode_used == KCFX_SHARD_SAMPLES ? "sample" : "window", st.seconds_total, st.seconds_ref,
+                      st.seconds_db_open_sum, st.seconds_exposed_load, st.seconds_screen_sum);
+        info(line);
     }
-    db = nullptr;
+    std::vector<const kcfx_result*> res(S);
+    for (size_t s = 0; s < S; ++s) {
+        res[s] = all.data() + s * (size_t)n;
+        if (kcfx_score(res[s], n, o.wi, o.wt, o.wr, score[s].data(), depth[s].data())) error(kcfx_last_error());   // Data.java:101-103
+    }
 
     // sort each contig's windows by start (:169-171); ties keep generation order
     hdr.n_windows = n;

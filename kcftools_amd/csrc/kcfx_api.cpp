@@ -630,6 +630,20 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
 
 }  // namespace
 
+static void info_from_header(const KmcHeader& h, kcfx_db_info_t& info) {
+    info.kmer_length = h.k;
+    info.mode = h.mode;
+    info.counter_size = h.counter_size;
+    info.lut_prefix_length = h.p;
+    info.signature_length = h.sig_len;
+    info.min_count = h.min_count;
+    info.max_count = h.max_count;
+    info.both_strands = h.both;
+    info.version = h.version;
+    info.n_bins = h.n_bins;
+    info.total_kmers = h.total;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------------
@@ -662,17 +676,7 @@ int32_t kcfx_db_open(const char* kmc_prefix, int32_t device, kcfx_db** out) {
     if (!g.ok) return fail(KCFX_ERR_DEVICE, "hipSetDevice failed");
     kcfx_db* db = new kcfx_db();
     db->device = device;
-    db->info.kmer_length = h.k;
-    db->info.mode = h.mode;
-    db->info.counter_size = h.counter_size;
-    db->info.lut_prefix_length = h.p;
-    db->info.signature_length = h.sig_len;
-    db->info.min_count = h.min_count;
-    db->info.max_count = h.max_count;
-    db->info.both_strands = h.both;
-    db->info.version = h.version;
-    db->info.n_bins = h.n_bins;
-    db->info.total_kmers = h.total;
+    info_from_header(h, db->info);
     db->info.device = device;
     hipError_t e = db_stream(device, &db->stream);
     if (e != hipSuccess) { db_free(db); return hip_fail(e, "hipStreamCreate"); }
@@ -750,6 +754,16 @@ int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, 
     if (rc) { db_free(db); return rc; }
     db->info.load_seconds = now_s() - t0;
     *out = db;
+    return KCFX_OK;
+}
+
+int32_t kcfx_db_header(const char* kmc_prefix, kcfx_db_info_t* info) {
+    if (!kmc_prefix || !info) return fail(KCFX_ERR_ARG, "null argument");
+    KmcHeader h;
+    if (int32_t rc = parse_prefix_file(std::string(kmc_prefix) + ".kmc_pre", h)) return rc;
+    memset(info, 0, sizeof *info);
+    info_from_header(h, *info);
+    info->device = -1;
     return KCFX_OK;
 }
 

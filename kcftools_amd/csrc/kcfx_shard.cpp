@@ -1,0 +1,241 @@
+// kcfx_shard.cpp -- the multi-GPU entry points of the C ABI (include/kcfx.h: kcfx_ctx_*, kcfx_screen_sharded).
+//
+// The path shards into independent units: a (window, sample) result depends only on that window's text and that sample's
+// database (GetVariants.java:138-150 hands windows to a thread pool one by one; utils/run_kcftools.sh:124-140 runs the
+// samples as separate processes). So there is no exchange step: one worker thread per device, each with its own resident
+// reference, and either
+//   samples >= devices : sample-sharded -- device g screens samples g, g + G, ...; every device holds the whole window list
+//   samples <  devices : window-sharded -- device g screens a contiguous window range (balanced by k-mer start positions)
+//                        of every sample, and uploads only the text that range covers.
+// Inside a worker the next sample's database is opened (file read, upload, table build) by a loader thread while the
+// current one is screened: at most two databases are resident per device, and a sample costs max(load, screen), not the sum.
+// Built on the public entry points only (kcfx_db_open / kcfx_ref_create / kcfx_screen_ref); HIP is never touched here.
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "kcfx_internal.h"
+
+struct kcfx_ctx {
+    std::vector<int32_t> devices;
+};
+
+namespace {
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int32_t fail(int32_t code, const std::string& msg) {
+    kcfx::set_error(msg);
+    return code;
+}
+
+// contiguous [lo, hi) window ranges with equal numbers of k-mer start positions (gene-model windows span 31 bp .. 100 kbp)
+std::vector<int32_t> window_cuts(const int32_t* win_len, int32_t n, int32_t k, int32_t parts) {
+    std::vector<int64_t> cum((size_t)n + 1, 0);
+    for (int32_t i = 0; i < n; ++i) cum[(size_t)i + 1] = cum[(size_t)i] + std::max<int64_t>(0, (int64_t)win_len[i] - k + 1);
+    const int64_t total = cum[(size_t)n];
+    std::vector<int32_t> cuts((size_t)parts + 1, n);
+    cuts[0] = 0;
+    for (int32_t p = 1; p < parts; ++p) {
+        const int64_t target = total * p / parts;
+        const int32_t c = (int32_t)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+        cuts[(size_t)p] = std::max(cuts[(size_t)p - 1], std::min(c, n));
+    }
+    return cuts;
+}
+
+struct Worker {
+    int32_t device = 0;
+    std::vector<int32_t> samples;     // the samples this device screens, in order
+    int32_t w_lo = 0, w_hi = 0;       // its window range
+    // outcome
+    int32_t rc = KCFX_OK;
+    std::string error;
+    double t_ref = 0, t_open = 0, t_screen = 0, t_wait = 0;
+};
+
+}  // namespace
+
+extern "C" {
+
+int32_t kcfx_ctx_create(const int32_t* devices, int32_t n_devices, kcfx_ctx** out) {
+    if (!out || n_devices < 1 || !devices) return fail(KCFX_ERR_ARG, "kcfx_ctx_create: at least one device is required");
+    *out = nullptr;
+    int32_t have = 0;
+    if (kcfx_device_count(&have) != KCFX_OK || have <= 0)
+        return fail(KCFX_ERR_DEVICE, "no HIP device available (libkcfx has no CPU fallback)");
+    for (int32_t i = 0; i < n_devices; ++i)
+        if (devices[i] < 0 || devices[i] >= have) return fail(KCFX_ERR_ARG, "device index out of range");
+    kcfx_ctx* c = new kcfx_ctx();
+    c->devices.assign(devices, devices + n_devices);      // the same device may be listed twice (two shards on one GPU)
+    *out = c;
+    return KCFX_OK;
+}
+
+int32_t kcfx_ctx_n_devices(const kcfx_ctx* ctx) { return ctx ? (int32_t)ctx->devices.size() : 0; }
+
+void kcfx_ctx_destroy(kcfx_ctx* ctx) { delete ctx; }
+
+int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int32_t n_samples, int32_t kmer_length,
+                            const uint8_t* text, int64_t text_len, const int64_t* win_begin, const int32_t* win_len,
+                            int32_t n_windows, int32_t min_kmer_count, int32_t shard_mode, kcfx_result* out,
+                            kcfx_shard_stats* stats) {
+    if (!ctx || n_samples < 0 || n_windows < 0 || text_len < 0 || (n_samples > 0 && !kmc_prefixes) ||
+        (n_windows > 0 && (!win_begin || !win_len)) || (text_len > 0 && !text) ||
+        ((int64_t)n_samples * n_windows > 0 && !out))
+        return fail(KCFX_ERR_ARG, "null argument");
+    if (min_kmer_count < 1) return fail(KCFX_ERR_ARG, "Minimum kmer count should be at least 1");   // GetVariants.java:383-385
+    if (shard_mode < KCFX_SHARD_AUTO || shard_mode > KCFX_SHARD_WINDOWS) return fail(KCFX_ERR_ARG, "unknown shard mode");
+    for (int32_t s = 0; s < n_samples; ++s)
+        if (!kmc_prefixes[s]) return fail(KCFX_ERR_ARG, "null database prefix");
+    for (int32_t w = 0; w < n_windows; ++w)
+        if (win_begin[w] < 0 || win_len[w] < 0 || win_begin[w] + (int64_t)win_len[w] > text_len)
+            return fail(KCFX_ERR_ARG, "window " + std::to_string(w) + " lies outside the text");      // FastaIndex.java:131-134
+    const double t0 = now_s();
+    const int32_t G = (int32_t)ctx->devices.size();
+    int32_t mode = shard_mode;
+    if (mode == KCFX_SHARD_AUTO) mode = (n_samples >= G || n_windows == 0) ? KCFX_SHARD_SAMPLES : KCFX_SHARD_WINDOWS;
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->shard_mode_used = mode;
+        stats->n_devices = G;
+    }
+    if (n_samples == 0 || n_windows == 0) return KCFX_OK;
+
+    std::vector<Worker> workers((size_t)G);
+    const std::vector<int32_t> cuts = (mode == KCFX_SHARD_WINDOWS) ? window_cuts(win_len, n_windows, kmer_length, G) : std::vector<int32_t>();
+    for (int32_t g = 0; g < G; ++g) {
+        Worker& wk = workers[(size_t)g];
+        wk.device = ctx->devices[(size_t)g];
+        if (mode == KCFX_SHARD_SAMPLES) {
+            for (int32_t s = g; s < n_samples; s += G) wk.samples.push_back(s);
+            wk.w_lo = 0;
+            wk.w_hi = n_windows;
+        } else {
+            for (int32_t s = 0; s < n_samples; ++s) wk.samples.push_back(s);
+            wk.w_lo = cuts[(size_t)g];
+            wk.w_hi = cuts[(size_t)g + 1];
+        }
+    }
+
+    auto run = [&](Worker& wk) {
+        const int32_t nw = wk.w_hi - wk.w_lo;
+        if (wk.samples.empty() || nw <= 0) return;
+        auto failed = [&](int32_t rc) {
+            wk.rc = rc;
+            wk.error = kcfx_last_error();
+        };
+        // the text this window range covers (all of it when the whole list is screened here)
+        int64_t t_lo = text_len, t_hi = 0;
+        for (int32_t w = wk.w_lo; w < wk.w_hi; ++w) {
+            t_lo = std::min(t_lo, win_begin[w]);
+            t_hi = std::max(t_hi, win_begin[w] + (int64_t)win_len[w]);
+        }
+        if (t_hi < t_lo) t_lo = t_hi = 0;
+        std::vector<int64_t> wb((size_t)nw);
+        for (int32_t i = 0; i < nw; ++i) wb[(size_t)i] = win_begin[wk.w_lo + i] - t_lo;
+        double t = now_s();
+        kcfx_ref* ref = nullptr;
+        if (int32_t rc = kcfx_ref_create(wk.device, kmer_length, text + t_lo, t_hi - t_lo, wb.data(), win_len + wk.w_lo, nw, &ref)) {
+            failed(rc);
+            return;
+        }
+        wk.t_ref = now_s() - t;
+
+        // loader thread: opens the databases in order, at most one ahead of the one being screened
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<kcfx_db*> ready;
+        bool stop = false, loader_done = false;
+        int32_t load_rc = KCFX_OK;
+        std::string load_error;
+        std::thread loader([&]() {
+            for (size_t i = 0; i < wk.samples.size(); ++i) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return stop || ready.size() < 1; });
+                    if (stop) break;
+                }
+                const double t1 = now_s();
+                kcfx_db* db = nullptr;
+                const int32_t rc = kcfx_db_open(kmc_prefixes[wk.samples[i]], wk.device, &db);
+                std::lock_guard<std::mutex> lk(mu);
+                wk.t_open += now_s() - t1;
+                if (rc) {
+                    load_rc = rc;
+                    load_error = kcfx_last_error();
+                    break;
+                }
+                ready.push_back(db);
+                cv.notify_all();
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            loader_done = true;
+            cv.notify_all();
+        });
+        for (size_t i = 0; i < wk.samples.size() && wk.rc == KCFX_OK; ++i) {
+            kcfx_db* db = nullptr;
+            {
+                const double t1 = now_s();
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !ready.empty() || loader_done; });
+                wk.t_wait += now_s() - t1;
+                if (ready.empty()) {                    // the loader failed
+                    wk.rc = load_rc ? load_rc : KCFX_ERR_DEVICE;
+                    wk.error = load_error;
+                    break;
+                }
+                db = ready.front();
+                ready.pop_front();
+                cv.notify_all();
+            }
+            kcfx_db_info_t info;
+            kcfx_db_info(db, &info);
+            const double t1 = now_s();
+            if (info.kmer_length != kmer_length) {
+                wk.rc = KCFX_ERR_ARG;
+                wk.error = "Kmer size mismatch between the KMC databases";          // KCFHeader.equals (Cohort.java:71-119)
+            } else if (int32_t rc = kcfx_screen_ref(db, ref, min_kmer_count, out + (size_t)wk.samples[i] * n_windows + wk.w_lo)) {
+                failed(rc);
+            }
+            wk.t_screen += now_s() - t1;
+            kcfx_db_close(db);
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+            cv.notify_all();
+        }
+        loader.join();
+        for (kcfx_db* db : ready) kcfx_db_close(db);
+        kcfx_ref_destroy(ref);
+    };
+
+    if (G == 1) {
+        run(workers[0]);
+    } else {
+        std::vector<std::thread> th;
+        for (int32_t g = 0; g < G; ++g) th.emplace_back(run, std::ref(workers[(size_t)g]));
+        for (auto& x : th) x.join();
+    }
+    if (stats) {
+        stats->seconds_total = now_s() - t0;
+        for (const Worker& wk : workers) {
+            stats->seconds_ref = std::max(stats->seconds_ref, wk.t_ref);
+            stats->seconds_db_open_sum += wk.t_open;
+            stats->seconds_screen_sum += wk.t_screen;
+            stats->seconds_exposed_load = std::max(stats->seconds_exposed_load, wk.t_wait);
+        }
+    }
+    for (const Worker& wk : workers)
+        if (wk.rc != KCFX_OK) return fail(wk.rc, "device " + std::to_string(wk.device) + ": " + wk.error);
+    return KCFX_OK;
+}
+
+}  // extern "C"

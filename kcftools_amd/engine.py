@@ -23,9 +23,10 @@ assert RESULT_DTYPE.itemsize == 40
 
 # every symbol include/kcfx.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
-    "kcfx_db_open", "kcfx_db_build", "kcfx_db_info", "kcfx_db_lookup", "kcfx_db_close",
+    "kcfx_db_open", "kcfx_db_build", "kcfx_db_info", "kcfx_db_header", "kcfx_db_lookup", "kcfx_db_close",
     "kcfx_ref_create", "kcfx_ref_n_windows", "kcfx_ref_n_kmer_slots", "kcfx_ref_destroy",
     "kcfx_screen_ref", "kcfx_screen_ref_async", "kcfx_screen_ref_multi", "kcfx_screen_ref_multi_async", "kcfx_screen",
+    "kcfx_ctx_create", "kcfx_ctx_n_devices", "kcfx_ctx_destroy", "kcfx_screen_sharded",
     "kcfx_score", "kcfx_windows",
     "kcfx_prof_enable", "kcfx_prof_read", "kcfx_last_error", "kcfx_device_count", "kcfx_version",
 )
@@ -42,6 +43,15 @@ class DbInfo(C.Structure):
                 ("table_format", C.c_int32), ("_pad", C.c_int32), ("stored_kmers", C.c_int64),
                 ("stash_kmers", C.c_int64), ("stash_bytes", C.c_int64), ("multi_cell_kmers", C.c_int64),
                 ("second_choice_kmers", C.c_int64)]
+
+
+class ShardStats(C.Structure):
+    _fields_ = [("shard_mode_used", C.c_int32), ("n_devices", C.c_int32), ("seconds_total", C.c_double),
+                ("seconds_ref", C.c_double), ("seconds_db_open_sum", C.c_double), ("seconds_screen_sum", C.c_double),
+                ("seconds_exposed_load", C.c_double)]
+
+
+SHARD_AUTO, SHARD_SAMPLES, SHARD_WINDOWS = 0, 1, 2
 
 
 class KcfxError(RuntimeError):
@@ -89,6 +99,12 @@ def lib() -> C.CDLL:
         L.kcfx_db_open.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
         L.kcfx_db_build.argtypes = [vp, vp, i64, i32, i32, i32, i32, C.POINTER(vp)]
         L.kcfx_db_info.argtypes = [vp, C.POINTER(DbInfo)]
+        L.kcfx_db_header.argtypes = [C.c_char_p, C.POINTER(DbInfo)]
+        L.kcfx_ctx_create.argtypes = [vp, i32, C.POINTER(vp)]
+        L.kcfx_ctx_n_devices.argtypes = [vp]
+        L.kcfx_ctx_destroy.argtypes = [vp]
+        L.kcfx_ctx_destroy.restype = None
+        L.kcfx_screen_sharded.argtypes = [vp, vp, i32, i32, vp, i64, vp, vp, i32, i32, i32, vp, C.POINTER(ShardStats)]
         L.kcfx_db_lookup.argtypes = [vp, vp, i64, vp]
         L.kcfx_db_close.argtypes = [vp]
         L.kcfx_db_close.restype = None
@@ -120,6 +136,34 @@ def device_count() -> int:
     n = C.c_int32(0)
     _check(lib().kcfx_device_count(C.byref(n)))
     return n.value
+
+
+def db_header(kmc_prefix: str) -> DbInfo:
+    """Header fields of a KMC database (KMC.java:107-168) without touching a GPU."""
+    info = DbInfo()
+    _check(lib().kcfx_db_header(os.fsencode(kmc_prefix), C.byref(info)))
+    return info
+
+
+def screen_sharded(kmc_prefixes, k: int, text: bytes, win_begin, win_len, min_count: int = 1, devices=(0,),
+                   mode: int = SHARD_AUTO) -> tuple[np.ndarray, ShardStats]:
+    """kcfx_screen_sharded: every listed device screens its share (samples or window ranges); array [samples, windows]."""
+    wb = np.ascontiguousarray(win_begin, dtype=np.int64)
+    wl = np.ascontiguousarray(win_len, dtype=np.int32)
+    buf = np.frombuffer(text, dtype=np.uint8)
+    dev = (C.c_int32 * len(devices))(*devices)
+    ctx = C.c_void_p()
+    _check(lib().kcfx_ctx_create(dev, len(devices), C.byref(ctx)))
+    try:
+        names = [os.fsencode(p) for p in kmc_prefixes]
+        arr = (C.c_char_p * max(len(names), 1))(*names)
+        out = np.zeros((len(names), len(wb)), dtype=RESULT_DTYPE)
+        st = ShardStats()
+        _check(lib().kcfx_screen_sharded(ctx, arr, len(names), k, buf.ctypes.data if len(buf) else None, len(buf),
+                                         wb.ctypes.data, wl.ctypes.data, len(wb), min_count, mode, out.ctypes.data, C.byref(st)))
+    finally:
+        lib().kcfx_ctx_destroy(ctx)
+    return out, st
 
 
 class KmcDb:

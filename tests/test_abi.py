@@ -35,6 +35,25 @@ def test_no_gpu_means_loud_failure_not_fallback():
     assert ei.value.code == 4 and "no CPU fallback" in str(ei.value)
     with pytest.raises(engine.KcfxError):
         engine.Reference(b"ACGT" * 20, [0], [80], 31)
+    with pytest.raises(engine.KcfxError) as ei:
+        engine.screen_sharded(["nowhere"], 31, b"ACGT" * 20, [0], [80], devices=(0,))
+    assert ei.value.code == 4 and "no CPU fallback" in str(ei.value)
+
+
+def test_db_header_is_host_only(tmp_path):
+    """kcfx_db_header reads the KMC header fields (KMC.java:124-139) without a GPU."""
+    from kcftools_amd import synth
+    prm = synth.KmcParams(k=31, p=3, counter_size=2, sig_len=7, n_bins=5, both_strands=False, min_count=2, max_count=1234)
+    prefix = str(tmp_path / "db")
+    kmers = np.array([4, 8, 1 << 40], dtype=np.uint64)
+    synth.write_kmc(prefix, kmers, np.array([1, 2, 3]), prm)
+    i = engine.db_header(prefix)
+    assert (i.kmer_length, i.lut_prefix_length, i.counter_size, i.signature_length, i.n_bins) == (31, 3, 2, 7, 5)
+    assert (i.both_strands, i.min_count, i.max_count, i.total_kmers, i.version) == (0, 2, 1234, 3, 0x200)
+    assert i.table_bytes == 0 and i.device == -1
+    with pytest.raises(engine.KcfxError) as ei:
+        engine.db_header(str(tmp_path / "missing"))
+    assert ei.value.code == 2
 
 
 def test_error_codes_without_gpu(tmp_path):

@@ -1,0 +1,67 @@
+"""kcfx_ctx_create + kcfx_screen_sharded (the multi-GPU entry of the C ABI) on ONE GPU: the same device listed two or
+three times gives two or three worker threads, each with its own resident reference -- the control flow of a node with
+several GPUs. Every slice must equal the unsharded kcfx_screen_ref and the oracle, in both partitionings."""
+import numpy as np
+import pytest
+
+from kcftools_amd import engine, synth
+from test_gpu_parity import assert_same, make_db
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def job(tmp_path_factory):
+    tmp = tmp_path_factory.mktemp("sharded")
+    k = 31
+    ref = synth.random_reference(300_000, 71, n_run_every=40_000, max_n_run=700)
+    specs = [dict(cs=2, both=True), dict(cs=1, both=True), dict(cs=4, both=True), dict(cs=2, both=False), dict(cs=2, both=True)]
+    prefixes = [make_db(tmp, f"s{i}", ref, 900 + i, k=k, p=3, cs=sp["cs"], m=7, bins=4, both=sp["both"], noise=4_000)[0]
+                for i, sp in enumerate(specs)]
+    rng = np.random.default_rng(5)
+    # tiling windows + gene-like irregular ones (short, empty, overlapping), unsorted
+    s, e = engine.windows(len(ref), 10_000, 0, k)
+    lens = np.concatenate([e - s, rng.integers(0, 9_000, 40), [0, 30, 31]])
+    begins = np.concatenate([s, rng.integers(0, len(ref) - 9_000, 40), [5, 77, 123]])
+    want = np.stack([engine.KmcDb.open(p).screen(ref, begins, lens, 1) for p in prefixes])
+    return k, ref, prefixes, begins, lens, want
+
+
+@pytest.mark.parametrize("devices,mode", [((0, 0), engine.SHARD_SAMPLES), ((0, 0), engine.SHARD_WINDOWS), ((0, 0, 0), engine.SHARD_WINDOWS),
+                                          ((0,), engine.SHARD_AUTO), ((0, 0), engine.SHARD_AUTO), ((0,) * 7, engine.SHARD_AUTO)])
+def test_sharded_equals_unsharded(oracle, job, devices, mode):
+    k, ref, prefixes, begins, lens, want = job
+    got, st = engine.screen_sharded(prefixes, k, ref, begins, lens, 1, devices=devices, mode=mode)
+    assert got.shape == want.shape
+    for i in range(len(prefixes)):
+        assert_same(got[i], want[i], f"sample {i}, devices {devices}, mode {mode}")
+    auto = engine.SHARD_SAMPLES if len(prefixes) >= len(devices) else engine.SHARD_WINDOWS
+    assert st.shard_mode_used == (mode or auto) and st.n_devices == len(devices)
+    assert st.seconds_total > 0 and st.seconds_screen_sum > 0 and st.seconds_db_open_sum > 0
+    # one sample against the oracle, to anchor the comparison
+    assert_same(got[0], oracle.OracleDb(prefixes[0]).screen(ref, begins, lens, 1, threads=4), "vs oracle")
+
+
+def test_sharded_edge_cases_and_errors(job, tmp_path):
+    k, ref, prefixes, begins, lens, want = job
+    # fewer windows than devices, -c 2, no samples, no windows
+    got, _ = engine.screen_sharded(prefixes[:1], k, ref, begins[:2], lens[:2], 1, devices=(0, 0, 0, 0), mode=engine.SHARD_WINDOWS)
+    assert_same(got[0], want[0][:2], "2 windows on 4 shards")
+    got2, _ = engine.screen_sharded(prefixes[:2], k, ref, begins, lens, 2, devices=(0, 0))
+    for i in range(2):
+        assert_same(got2[i], engine.KmcDb.open(prefixes[i]).screen(ref, begins, lens, 2), "-c 2")
+    assert engine.screen_sharded([], k, ref, begins, lens, 1, devices=(0, 0))[0].shape == (0, len(begins))
+    assert engine.screen_sharded(prefixes[:1], k, ref, [], [], 1, devices=(0, 0))[0].shape == (1, 0)
+    # a missing database, a k mismatch, a bad window, a bad threshold: a status and a message, never an exit
+    with pytest.raises(engine.KcfxError) as ei:
+        engine.screen_sharded([prefixes[0], str(tmp_path / "missing"), prefixes[1]], k, ref, begins, lens, 1, devices=(0, 0))
+    assert ei.value.code == 2 and "device 0" in str(ei.value)
+    with pytest.raises(engine.KcfxError) as ei:
+        engine.screen_sharded(prefixes[:1], 23, ref, begins, lens, 1, devices=(0,))
+    assert "Kmer size mismatch" in str(ei.value)
+    with pytest.raises(engine.KcfxError):
+        engine.screen_sharded(prefixes[:1], k, ref, [len(ref) - 5], [50], 1, devices=(0,))
+    with pytest.raises(engine.KcfxError):
+        engine.screen_sharded(prefixes[:1], k, ref, begins, lens, 0, devices=(0,))
+    with pytest.raises(engine.KcfxError):
+        engine.screen_sharded(prefixes[:1], k, ref, begins, lens, 1, devices=(0, 99))
