@@ -136,14 +136,23 @@ static int32_t parse_prefix_file(const std::string& path, KmcHeader& h) {
     const int64_t entries = (int64_t)h.n_bins * lut_size;                  // :160
     h.lut_bytes = pre + 4;                                                 // :153,:161-163
     h.lut_entries = entries;
+    // Sanity of the LUT (prefix sums of record counts). The reference reads these values without looking at them
+    // (KMC.java:153-163), and no database written by the real `kmc` tool has been available to check the expectations
+    // against, so a violation is reported, not refused: the lookups of the affected prefixes are then as undefined here as
+    // they are in the reference.
     uint64_t prev = 0;
+    bool monotonic = true;
     for (int64_t i = 0; i < entries; ++i) {
         const uint64_t v = h.lut_at(i);
-        if (v < prev) return fail(KCFX_ERR_FORMAT, "LUT is not monotonic");
+        monotonic = monotonic && v >= prev;
         prev = v;
     }
-    if (entries && h.lut_at(entries - 1) > (uint64_t)h.total) return fail(KCFX_ERR_FORMAT, "LUT points past total_kmers");
-    if (h.total > 0 && (entries == 0 || h.lut_at(0) != 0)) return fail(KCFX_ERR_FORMAT, "LUT does not start at record 0");
+    if (!monotonic) fprintf(stderr, "kcfx: warning: %s: LUT is not monotonic\n", path.c_str());
+    if (entries && h.lut_at(entries - 1) > (uint64_t)h.total)
+        fprintf(stderr, "kcfx: warning: %s: LUT points past total_kmers\n", path.c_str());
+    if (h.total > 0 && entries > 0 && h.lut_at(0) != 0)
+        fprintf(stderr, "kcfx: warning: %s: LUT does not start at record 0\n", path.c_str());
+    if (h.total > 0 && entries == 0) return fail(KCFX_ERR_FORMAT, "prefix file has no LUT");
     h.suffix_bytes = (h.k - h.p) / 4;
     h.record_size = h.counter_size + h.suffix_bytes;                       // :61
     return KCFX_OK;
@@ -230,6 +239,7 @@ struct kcfx_ref {
     // multi-sample pass (allocated on first use; scratch sized for SCREEN_MULTI_MAX samples)
     uint64_t* d_mbits = nullptr;
     int64_t* d_mcsum = nullptr;
+    int32_t multi_cap = 0;             // samples the multi-sample scratch holds
     kcfx_result* d_mres = nullptr;     // synchronous multi entry point: n_db * n_windows records
     size_t mres_bytes = 0;
     hipStream_t stream = nullptr;
@@ -868,7 +878,7 @@ int32_t kcfx_screen_ref_async(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
     DeviceGuard g(db->device);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (ref->prof) {
+    if (ref->prof && ref->n_tiles > 0) {                   // (an event that is never recorded cannot be read back)
         if (ref->events_used == ref->events.size()) {
             hipEvent_t a, b;
             KCFX_HIP(hipEventCreate(&a));
@@ -901,10 +911,23 @@ int32_t kcfx_screen_ref_multi_async(kcfx_db* const* dbs, int32_t n_db, kcfx_ref*
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
     kcfx_result* out = reinterpret_cast<kcfx_result*>(out_device);
     DeviceGuard g(ref->device);
-    if (!ref->d_mbits) {
-        const size_t nt = std::max<size_t>(ref->n_tiles, 1);
-        KCFX_HIP(hipMalloc(&ref->d_mbits, nt * SCREEN_MULTI_MAX * TILE_BITS_U64 * 8));
-        KCFX_HIP(hipMalloc(&ref->d_mcsum, nt * SCREEN_MULTI_MAX * sizeof(int64_t)));
+    // scratch of the multi-sample kernel: only if some database can take it, sized for the largest batch this call forms
+    // (512 B per tile and sample: 29 GB for eight samples of a 14.5 Gb reference -- not to be allocated on spec)
+    {
+        int32_t eligible = 0;
+        for (int32_t i = 0; i < n_db; ++i) eligible += screen_multi_supported(dbs[i]->view(), ref->k) ? 1 : 0;
+        const int32_t want = std::min<int32_t>(eligible, SCREEN_MULTI_MAX);
+        if (want > ref->multi_cap) {
+            if (ref->d_mbits) (void)hipFree(ref->d_mbits);
+            if (ref->d_mcsum) (void)hipFree(ref->d_mcsum);
+            ref->d_mbits = nullptr;
+            ref->d_mcsum = nullptr;
+            ref->multi_cap = 0;
+            const size_t nt = std::max<size_t>(ref->n_tiles, 1);
+            KCFX_HIP(hipMalloc(&ref->d_mbits, nt * (size_t)want * TILE_BITS_U64 * 8));
+            KCFX_HIP(hipMalloc(&ref->d_mcsum, nt * (size_t)want * sizeof(int64_t)));
+            ref->multi_cap = want;
+        }
     }
     std::vector<char> done(n_db, 0);
     for (int32_t first = 0; first < n_db; ++first) {
@@ -920,7 +943,7 @@ int32_t kcfx_screen_ref_multi_async(kcfx_db* const* dbs, int32_t n_db, kcfx_ref*
         int32_t idx[SCREEN_MULTI_MAX];
         TableView tvs[SCREEN_MULTI_MAX];
         int32_t nb = 0;
-        for (int32_t j = first; j < n_db && nb < SCREEN_MULTI_MAX; ++j) {
+        for (int32_t j = first; j < n_db && nb < ref->multi_cap; ++j) {
             if (done[j] || !screen_multi_supported(dbs[j]->view(), ref->k)) continue;
             if (dbs[j]->info.both_strands != d0->info.both_strands) continue;
             idx[nb] = j;
@@ -928,7 +951,7 @@ int32_t kcfx_screen_ref_multi_async(kcfx_db* const* dbs, int32_t n_db, kcfx_ref*
             done[j] = 1;
         }
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
-        if (ref->prof) {
+        if (ref->prof && ref->n_tiles > 0) {
             if (ref->events_used == ref->events.size()) {
                 hipEvent_t a, b;
                 KCFX_HIP(hipEventCreate(&a));

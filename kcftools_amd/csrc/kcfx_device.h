@@ -198,10 +198,14 @@ KCFX_HD uint32_t mm27_tagged(uint32_t fwd_m, uint32_t rc_m, uint32_t label) {
     const uint32_t cm = fwd_m < rc_m ? fwd_m : rc_m;
     return mm27(cm) | (rc_m < fwd_m ? 16u : 0u) | label;
 }
-// minimum hash (low 5 bits ignored) : low 5 bits of the minimizer itself, a 32-bit value in bijection with the minimizer,
-// -> G32: line = top lbits, r = the rest. The minimum of 16 hashes is skewed towards 0 (it carries ~24 bits of entropy,
-// the minimizer's own low bits add 5), hence the odd multiply over all 32 bits: a bijection that spreads both into the top.
-KCFX_HD uint32_t cell_g32(uint32_t min_hash, uint32_t cm) { return ((min_hash & ~31u) | (cm & 31u)) * 0xC2B2AE35u; }
+// canonical minimizer 16-mer -> G32: line = top lbits, r = the rest. A bijection on 32 bits (odd multiplies, right
+// xorshift), so (line, r) identify the minimizer exactly, and independent of mm27: the MINIMUM of 16 hashes is skewed towards
+// 0 and keeps only ~24 bits of entropy, which would leave most lines of a table of 2^27 or more lines unused.
+KCFX_HD uint32_t cell_g32(uint32_t cm) {
+    uint32_t x = cm * 0xC2B2AE35u;
+    x ^= x >> 15;
+    return x * 0x27D4EB2Fu;
+}
 
 // the 15 bases of N around the 16-mer at base offset sh / 2, left-aligned (low 2 bits zero); *m_out = that 16-mer
 KCFX_HD uint32_t cell_flank(uint64_t N, uint32_t sh, uint32_t* m_out) {
@@ -234,7 +238,7 @@ KCFX_HD CellProbe cell_probe_of(uint64_t F, uint64_t R, uint32_t mn, uint32_t la
     CellProbe p;
     uint32_t cm;
     p.w = cell_flank(N, sh, &cm);
-    const uint32_t g = cell_g32(mn, cm);
+    const uint32_t g = cell_g32(cm);
     p.sh = sh;
     p.line = g >> (32 - lbits);
     p.r = g & (0xFFFFFFFFu >> lbits);
@@ -269,7 +273,7 @@ KCFX_HD int cells_of_key(uint64_t C, int32_t lbits, CellProbe* out) {
             CellProbe p;
             uint32_t got;
             p.w = cell_flank(N, sh, &got);
-            const uint32_t g = cell_g32(best, cm);
+            const uint32_t g = cell_g32(cm);
             p.sh = sh;
             p.line = g >> (32 - lbits);
             p.r = g & (0xFFFFFFFFu >> lbits);

@@ -54,8 +54,8 @@ constexpr int MODE_KEYHASH = 0, MODE_MINIMIZER = 1;
 //   128-byte line = 16 x 8-byte cell;  cell = u32 w | u16 r | u16 count
 //     w     = the 30 flank bits (the 15 bases of N around the minimizer, left-aligned) | bit 0: some k-mer that maps
 //             to this cell lives in the stash | bit 1: reserved
-//     r     = low (32 - lbits) bits of G32 = (27-bit minimizer hash : minimizer & 31), re-spread; the line number is
-//             the top lbits of G32, and G32 <-> canonical minimizer 16-mer is a bijection (cell_g32)
+//     r     = low (32 - lbits) bits of G32 = a 32-bit mix of the canonical minimizer 16-mer; the line number is the top
+//             lbits of G32, and G32 <-> minimizer is a bijection (cell_g32)
 //             (at most 15 bits: lbits >= 17) | bit 15: this k-mer sits in its SECOND-choice cell
 //     count = the stored counter; 0 = empty cell (a k-mer whose counter is 0 can never be observed -- GetVariants.java:224
 //             needs count >= -c >= 1 -- so it is not stored)

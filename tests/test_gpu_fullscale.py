@@ -36,6 +36,18 @@ def genome(tmp_path_factory):
     return dict(prefix=prefix, text=text, db=db, meta=meta, dir=str(d))
 
 
+@pytest.fixture(scope="module")
+def cohort(genome):
+    """Eight samples of the genome: the fixture's own plus seven more seeds (about 100 M k-mers each)."""
+    prefixes = [genome["prefix"]]
+    for seed in range(11, 18):
+        pfx = os.path.join(genome["dir"], f"s{seed}")
+        subprocess.run([SYNTH, "--out", pfx, "--contig-lens", ",".join(map(str, LENS)), "--seed", "3", "--sample-seed", str(seed),
+                        "--noise", "1000000"], check=True, capture_output=True, text=True)
+        prefixes.append(pfx)
+    return prefixes
+
+
 def tiling(window):
     wb, wl = [], []
     off = 0
@@ -122,16 +134,11 @@ def test_gene_model_windows_end_to_end(oracle, genome):
     print(f"getVariations -f gene on 119 Mb / {len(rows)} genes: {wall:.1f} s wall (FASTA + GTF parse, DB load, screen, KCF write)")
 
 
-def test_eight_samples_in_one_pass(oracle, genome):
+def test_eight_samples_in_one_pass(oracle, genome, cohort):
     """configs[3] shape: the 119 Mb genome tiled at 10 kb against 8 resident sample databases, one pass over the reference
     per step (kcfx_screen_ref_multi) -- 12 k windows x 8 samples. Every slice must equal the single-sample pass; two
     samples are also sampled against the oracle; then the same through the command-line driver for three of them."""
-    prefixes = [genome["prefix"]]
-    for seed in range(11, 18):
-        pfx = os.path.join(genome["dir"], f"s{seed}")
-        subprocess.run([SYNTH, "--out", pfx, "--contig-lens", ",".join(map(str, LENS)), "--seed", "3", "--sample-seed", str(seed),
-                        "--noise", "1000000"], check=True, capture_output=True, text=True)
-        prefixes.append(pfx)
+    prefixes = cohort
     dbs = [genome["db"]] + [engine.KmcDb.open(p) for p in prefixes[1:]]
     assert all(d.info.total_kmers > 90_000_000 for d in dbs)
     text = genome["text"]
@@ -167,13 +174,30 @@ def test_eight_samples_in_one_pass(oracle, genome):
         assert np.array_equal(np.sort(obs_col), np.sort(got[s]["obs"]))
 
 
-@pytest.mark.skipif(not os.environ.get("KCFX_HUGE"), reason="wheat-scale run (configs[4] reference size): KCFX_HUGE=<bases>, e.g. 14.5e9")
-def test_wheat_scale_reference(oracle, genome):
-    """configs[4] shape on the reference side: a KCFX_HUGE-base text (the 119 Mb genome repeated with 0.5 % point mutations),
-    50 kb tiling windows (290 k for 14.5 Gb), against the 150 M-k-mer database; sampled windows against the oracle.
-    Measured on an MI355X: 14.5 Gb -> 4.4 s upload, 86 ms per screening call = 167 G k-mers/s."""
-    L = int(float(os.environ["KCFX_HUGE"]))
+def test_config5_shape_wheat_scale(oracle, genome, cohort, monkeypatch):
+    """BASELINE.json configs[4] ("wheat-scale reference, many samples, HBM-resident KMC DB stress") at a size the default
+    suite can afford: a 3.2 Gb reference (KCFX_HUGE=<bases> for more, e.g. 14.5e9: the 119 Mb genome repeated with 0.5 %
+    point mutations), 50 kb tiling windows (64 k of them), TEN samples -- the eight of the cohort, one of them a second time
+    through a table built by re-streaming its file (the path a database too large to keep decoded takes), and ONE LARGE
+    database of 2.1 G k-mers (17 GB .kmc_suf; a 2^28-line cell table at 0.5 k-mers per cell, so second-choice cells and the
+    stash carry real weight) -- through kcfx_screen_sharded (one database screened while the next is loaded) and through
+    kcfx_screen_ref_multi (ten > 8 forces a second batch; the large database is also opened as a 12-slot line table, whose
+    2^29+ lines the multi-sample kernel must refuse). Sampled windows against the oracle for three of the samples."""
+    import shutil
+    L = int(float(os.environ.get("KCFX_HUGE", "3.2e9")))
+    big_kmers = int(float(os.environ.get("KCFX_BIG_DB", "2.0e9")))
+    need = big_kmers * 9 + L * 2
+    if shutil.disk_usage(genome["dir"]).free < need:
+        pytest.skip(f"needs {need / 1e9:.0f} GB of scratch disk for the large database")
     rng = np.random.default_rng(7)
+    t_all = time.time()
+    # ---- the large database: the cohort's first sample genome + 2 G random k-mers -------------------------------------
+    big = os.path.join(genome["dir"], "big")
+    t0 = time.time()
+    subprocess.run([SYNTH, "--out", big, "--contig-lens", ",".join(map(str, LENS)), "--seed", "3", "--sample-seed", "21",
+                    "--noise", str(big_kmers)], check=True, capture_output=True, text=True)
+    t_gen = time.time() - t0
+    # ---- the reference ------------------------------------------------------------------------------------------------
     base = np.frombuffer(genome["text"], dtype=np.uint8)
     text = np.tile(base, (L + len(base) - 1) // len(base))[:L].copy()
     pos = rng.integers(0, L, size=L // 200)
@@ -182,18 +206,76 @@ def test_wheat_scale_reference(oracle, genome):
     starts = np.arange(0, L - K + 1, W - K + 1, dtype=np.int64)
     lens = np.minimum(W, L - starts).astype(np.int32)
     starts, lens = starts[lens >= K], lens[lens >= K]
-    ref = engine.Reference(text.tobytes(), starts, lens, K)
+    tbytes = text.tobytes()
+    del text
+    prefixes = list(cohort) + [cohort[1], big]             # ten samples; #8 repeats #1 (re-streamed table below)
+    # ---- every GPU entry point the CLI uses: sharded over "two devices" (the one GPU twice), next database loaded during
+    #      the current screening ---------------------------------------------------------------------------------------
     t0 = time.time()
-    res = ref.screen(genome["db"], 1)
-    wall = time.time() - t0
-    n = int(res["total_kmers"].sum())
+    got, st = engine.screen_sharded(prefixes, K, tbytes, starts, lens, 1, devices=(0, 0))
+    t_sharded = time.time() - t0
+    assert got.shape == (10, len(starts)) and st.shard_mode_used == engine.SHARD_SAMPLES
+    n = int(got[0]["total_kmers"].sum())
     assert n > 0.95 * L
-    odb = oracle.OracleDb(genome["prefix"])
-    idx = np.concatenate([rng.choice(len(starts), 40, replace=False), [0, len(starts) - 1]])
-    tb = memoryview(text)
-    for i in idx:
-        w = bytes(tb[int(starts[i]):int(starts[i]) + int(lens[i])])
-        want = odb.screen(w, np.array([0], dtype=np.int64), np.array([len(w)], dtype=np.int32), 1)
+    for f in FIELDS:
+        assert np.array_equal(got[8][f], got[1][f]), f                                  # the same sample twice
+    assert len({int(got[s]["obs"].sum()) for s in (0, 1, 2, 3, 4, 5, 6, 7, 9)}) == 9    # nine different samples
+    assert int(got[9]["obs"].sum()) > int(got[0]["obs"].sum()) * 0.5
+    # loading overlapped screening: what the screening threads waited for is less than what the loads took
+    assert st.seconds_exposed_load < st.seconds_db_open_sum
+    # ---- the same ten through resident handles and kcfx_screen_ref_multi ----------------------------------------------
+    ref = engine.Reference(tbytes, starts, lens, K)
+    t0 = time.time()
+    big_db = engine.KmcDb.open(big)
+    t_big_open = time.time() - t0
+    bi = big_db.info
+    assert bi.total_kmers > big_kmers and bi.table_format == 1 and bi.table_lines >= 1 << 28
+    # half a k-mer per cell, and 2 G k-mers share ~0.6 G distinct 16-mer minimizers: second choices and the stash carry weight
+    assert 0 < bi.stash_kmers < 0.4 * bi.total_kmers and bi.second_choice_kmers > 0
+    monkeypatch.setenv("KCFX_LOAD_STREAM_TWICE", "1")
+    restreamed = engine.KmcDb.open(cohort[1])
+    monkeypatch.delenv("KCFX_LOAD_STREAM_TWICE")
+    dbs = [genome["db"]] + [engine.KmcDb.open(p) for p in cohort[1:]] + [restreamed, big_db]
+    t0 = time.time()
+    multi = ref.screen_multi(dbs, 1)
+    t_multi = time.time() - t0
+    for s in range(10):
         for f in FIELDS:
-            assert want[f][0] == res[f][i], (i, f)
-    print(f"{L / 1e9:.1f} Gb reference, {len(starts)} windows: {n / 1e9:.2f} G k-mers in {wall * 1e3:.1f} ms")
+            assert np.array_equal(multi[s][f], got[s][f]), (s, f)
+    del dbs[1:8]                                            # free HBM for the line-table form of the large database
+    # ---- the large database as a 12-slot line table: >= 2^29 lines, which the multi-sample kernel refuses ---------------
+    monkeypatch.setenv("KCFX_TABLE_FORMAT", "lines")
+    monkeypatch.setenv("KCFX_TABLE_LOAD", "0.3")
+    t0 = time.time()
+    big_lines = engine.KmcDb.open(big)
+    t_lines_open = time.time() - t0
+    small_lines = engine.KmcDb.open(cohort[2])
+    monkeypatch.delenv("KCFX_TABLE_FORMAT")
+    monkeypatch.delenv("KCFX_TABLE_LOAD")
+    assert big_lines.info.table_format == 0 and big_lines.info.table_lines >= 1 << 29
+    pair = ref.screen_multi([small_lines, big_lines], 1)
+    for f in FIELDS:
+        assert np.array_equal(pair[0][f], got[2][f]) and np.array_equal(pair[1][f], got[9][f]), f
+    del big_lines, small_lines
+    # ---- sampled windows against the oracle ----------------------------------------------------------------------------
+    tb = memoryview(tbytes)
+    for s, pfx in ((0, cohort[0]), (5, cohort[5]), (9, big)):
+        odb = oracle.OracleDb(pfx)
+        idx = np.concatenate([rng.choice(len(starts), 24, replace=False), [0, len(starts) - 1]])
+        for i in idx:
+            w = bytes(tb[int(starts[i]):int(starts[i]) + int(lens[i])])
+            want = odb.screen(w, np.array([0], dtype=np.int64), np.array([len(w)], dtype=np.int32), 1)
+            for f in FIELDS:
+                assert want[f][0] == got[s][f][i], (s, i, f)
+    line = (f"config-5 shape: {L / 1e9:.1f} Gb reference, {len(starts)} windows x 10 samples = {10 * n / 1e9:.1f} G k-mer probes; "
+            f"large database {bi.total_kmers / 1e9:.2f} G k-mers generated in {t_gen:.0f} s, opened in {t_big_open:.1f} s "
+            f"(cell table 2^{int(np.log2(bi.table_lines))} lines, {bi.table_bytes / 2**30:.0f} GiB incl. stash, "
+            f"{bi.second_choice_kmers / 1e6:.0f} M second-choice, {bi.stash_kmers / 1e6:.0f} M stash k-mers; as a line table "
+            f"{t_lines_open:.1f} s); kcfx_screen_sharded (2 workers, load overlapped): {t_sharded:.1f} s wall, loads "
+            f"{st.seconds_db_open_sum:.1f} s of which {st.seconds_exposed_load:.1f} s exposed, screening {st.seconds_screen_sum:.2f} s; "
+            f"kcfx_screen_ref_multi on 10 resident databases: {t_multi * 1e3:.0f} ms = {10 * n / t_multi / 1e9:.0f} G k-mers/s; "
+            f"test wall {time.time() - t_all:.0f} s")
+    print(line)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "config5_shape.log"), "a") as fh:
+        fh.write(line + "\n")
