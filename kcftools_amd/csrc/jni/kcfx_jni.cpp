@@ -112,4 +112,52 @@ JNIEXPORT void JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_screenRefMulti(JNIEn
     if (rc) throw_kcfx(env, rc);
 }
 
+// int[] dbHeader(String kmcPrefix): the dbInfo fields from the header alone, no GPU (KMC.java:107-168; GetVariants.java:96,103)
+JNIEXPORT jintArray JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_dbHeader(JNIEnv* env, jclass, jstring prefix) {
+    const char* p = env->GetStringUTFChars(prefix, nullptr);
+    kcfx_db_info_t info;
+    const int32_t rc = kcfx_db_header(p, &info);
+    env->ReleaseStringUTFChars(prefix, p);
+    if (rc) { throw_kcfx(env, rc); return nullptr; }
+    const jint v[8] = {info.kmer_length, info.mode, info.counter_size, info.lut_prefix_length, info.signature_length,
+                       info.min_count, info.max_count, info.both_strands};
+    jintArray out = env->NewIntArray(8);
+    env->SetIntArrayRegion(out, 0, 8, v);
+    return out;
+}
+
+// void screenSharded(int[] devices, String[] kmcPrefixes, int k, ByteBuffer text, long[] winBegin, int[] winLen,
+//                    int minKmerCount, int shardMode, ByteBuffer results)
+// Every GPU of the node in one call (kcfx_ctx_create + kcfx_screen_sharded): replaces the per-sample processes of
+// run_kcftools.sh:124-140 and the thread pool of GetVariants.java:129-151. results: samples * nWindows * 40 bytes, sample-major.
+JNIEXPORT void JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_screenSharded(JNIEnv* env, jclass, jintArray devices, jobjectArray prefixes,
+                                                                           jint k, jobject text, jlongArray winBegin, jintArray winLen,
+                                                                           jint minKmerCount, jint shardMode, jobject results) {
+    const auto* t = static_cast<const uint8_t*>(env->GetDirectBufferAddress(text));
+    auto* out = static_cast<kcfx_result*>(env->GetDirectBufferAddress(results));
+    const jsize n = env->GetArrayLength(winLen), s = env->GetArrayLength(prefixes), g = env->GetArrayLength(devices);
+    if (!t || !out || env->GetDirectBufferCapacity(results) < (jlong)s * n * (jlong)sizeof(kcfx_result)) {
+        jclass cls = env->FindClass("java/lang/IllegalArgumentException");
+        if (cls) env->ThrowNew(cls, "text / results must be direct buffers; results holds samples * nWindows * 40 bytes");
+        return;
+    }
+    jint* dev = env->GetIntArrayElements(devices, nullptr);
+    kcfx_ctx* ctx = nullptr;
+    int32_t rc = kcfx_ctx_create(reinterpret_cast<const int32_t*>(dev), g, &ctx);
+    env->ReleaseIntArrayElements(devices, dev, JNI_ABORT);
+    if (rc) { throw_kcfx(env, rc); return; }
+    const char** names = new const char*[s > 0 ? s : 1];
+    for (jsize i = 0; i < s; ++i) names[i] = env->GetStringUTFChars(static_cast<jstring>(env->GetObjectArrayElement(prefixes, i)), nullptr);
+    jlong* wb = env->GetLongArrayElements(winBegin, nullptr);
+    jint* wl = env->GetIntArrayElements(winLen, nullptr);
+    rc = kcfx_screen_sharded(ctx, names, s, k, t, env->GetDirectBufferCapacity(text), reinterpret_cast<const int64_t*>(wb),
+                             reinterpret_cast<const int32_t*>(wl), n, minKmerCount, shardMode, out, nullptr);
+    env->ReleaseLongArrayElements(winBegin, wb, JNI_ABORT);
+    env->ReleaseIntArrayElements(winLen, wl, JNI_ABORT);
+    for (jsize i = 0; i < s; ++i) env->ReleaseStringUTFChars(static_cast<jstring>(env->GetObjectArrayElement(prefixes, i)), names[i]);
+    delete[] names;
+    kcfx_ctx_destroy(ctx);
+    if (rc) throw_kcfx(env, rc);
+}
+
 }  // extern "C"

@@ -157,3 +157,32 @@ def test_samples_sharded_over_devices_give_the_same_file(tmp_path):
         run_cli(["-r", fa, "-k", k, "-o", out, "-s", "A,B,C,D,E", "-f", "window", "-w", "3000"] + dev)
         outs.append([l for l in open(out) if not l.startswith("##CMD") and not l.startswith("##date") and not l.startswith("##fileDate")])
     assert outs[0] == outs[1] == outs[2] and sum(1 for l in outs[0] if not l.startswith("#")) > 10
+
+
+def test_pin_helper_accepts_the_driver_output_for_every_golden_case(tmp_path):
+    """tools/pin_against_jar.sh compares the REAL kcftools jar's KCF with tests/golden/expected.json through
+    tools/kcf_vs_expected.py. No JVM exists here, but the helper itself can be exercised: the KCF our own driver writes for
+    each of the nine golden cases (three databases -- canonical k=31, forward-only k=31, canonical k=23 -- times three window
+    geometries incl. -p and -c) must pass it, and a corrupted row must not."""
+    import json
+    helper = os.path.join(ROOT, "tools", "kcf_vs_expected.py")
+    exp_path = os.path.join(G, "expected.json")
+    fa = str(tmp_path / "ref.fa")
+    shutil.copy(os.path.join(G, "ref.fa"), fa)
+    cases = json.load(open(exp_path))["cases"]
+    assert len(cases) == 9
+    for idx, c in enumerate(cases):
+        out = str(tmp_path / f"case{idx}.kcf")
+        args = ["-r", fa, "-k", os.path.join(G, c["db"]), "-o", out, "-s", "S", "-f", "window", "-w", str(c["window"]), "-c", str(c["min_count"])]
+        if c["step"]:
+            args += ["-p", str(c["step"])]
+        run_cli(args)
+        p = subprocess.run(["python3", helper, out, exp_path, str(idx)], capture_output=True, text=True)
+        assert p.returncode == 0, (idx, p.stdout)
+    lines = open(out).read().split("\n")
+    row = next(i for i, l in enumerate(lines) if l and not l.startswith("#"))
+    f = lines[row].split("\t")
+    f[4] = str(int(f[4]) + 1)
+    lines[row] = "\t".join(f)
+    open(out, "w").write("\n".join(lines))
+    assert subprocess.run(["python3", helper, out, exp_path, str(idx)], capture_output=True, text=True).returncode == 1
