@@ -22,6 +22,18 @@
 
 namespace kcfx {
 
+// wave total of a u32 in six DPP adds (row_shr 1/2/4/8 leave each row's sum in its lane 15; row_bcast15 / row_bcast31
+// carry it across rows); the result is lane 63's value, returned to every lane as a scalar
+__device__ __forceinline__ uint32_t wave_sum_u32_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // ======================================================================================================
 // table build
 // ======================================================================================================
@@ -210,6 +222,7 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t lbits, const uint64_
                                     const uint32_t* __restrict__ counts, int64_t n, unsigned long long* stats) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint32_t n_lost = 0, n_stored = 0, n_multi = 0, n_second = 0;      // per lane; one atomic per wave at the end
     for (; i < n; i += stride) {
         const uint32_t c = counts[i] & 0xFFFFu;
         if (c == 0) continue;
@@ -232,15 +245,23 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t lbits, const uint64_
                 old = prev;
             }
             if (won) {
-                atomicAdd(&stats[3], 1ull);
+                ++n_second;
             } else if ((old & ~(unsigned long long)CELL_FLAG_MASK) != mine) {
                 atomicOr(reinterpret_cast<uint32_t*>(line + 4 * cand[a].sh), CELL_FLAG_STASH);
                 lost = true;
             }
         }
-        if (lost) atomicAdd(&stats[0], 1ull);
-        atomicAdd(&stats[1], 1ull);
-        if (nc > 1) atomicAdd(&stats[2], 1ull);
+        n_lost += lost ? 1u : 0u;
+        ++n_stored;
+        n_multi += nc > 1 ? 1u : 0u;
+    }
+    // (150 M atomics on four addresses took 80 ms; a wave total each takes none)
+    const uint32_t t0 = wave_sum_u32_dpp(n_lost), t1 = wave_sum_u32_dpp(n_stored), t2 = wave_sum_u32_dpp(n_multi), t3 = wave_sum_u32_dpp(n_second);
+    if ((threadIdx.x & 63) == 0) {
+        if (t0) atomicAdd(&stats[0], (unsigned long long)t0);
+        if (t1) atomicAdd(&stats[1], (unsigned long long)t1);
+        if (t2) atomicAdd(&stats[2], (unsigned long long)t2);
+        if (t3) atomicAdd(&stats[3], (unsigned long long)t3);
     }
 }
 
@@ -321,18 +342,6 @@ __device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
-}
-
-// wave total of a u32 in six DPP adds (row_shr 1/2/4/8 leave each row's sum in its lane 15; row_bcast15 / row_bcast31
-// carry it across rows); the result is lane 63's value, returned to every lane as a scalar
-__device__ __forceinline__ uint32_t wave_sum_u32_dpp(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1, 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // __ballot() takes an int: hipcc materialises the predicate (v_cndmask 0/1) and compares it again, two VALU
