@@ -82,7 +82,7 @@ typedef struct {
     int32_t minimizer_length;/* M of the minimizer bucketing (0 in mode 0) */
     int64_t heavy_lines;     /* minimizer home lines whose k-mers were re-homed by key hash (low-complexity repeats) */
     int64_t overflow_lines;  /* lines that pushed k-mers to the next line */
-    int32_t table_format;    /* 0 = 12-slot lines; 1 = 16 offset-addressed cells per line + stash (k = 31, both strands,
+    int32_t table_format;    /* 0 = 12-slot lines; 1 = 16 offset-addressed cells per line + stash (k = 27..31, both strands,
                                 counter_size <= 2: the default there) */
     int32_t _pad;
     int64_t stored_kmers;    /* format 1: k-mers with a non-zero counter (the others can never be observed) */

@@ -320,27 +320,36 @@ int32_t minimizer_len(int32_t k, int64_t n_keys) {
     return std::max(1, std::min(m, std::min(k, 32)));
 }
 
-// FORMAT_CELLS (kcfx_internal.h) is what the BASELINE configuration gets: k = 31, both strands, counters of at most 2
-// bytes, minimizer bucketing. KCFX_TABLE_FORMAT=lines keeps the 12-slot line table (A/B and test hook, read at open time).
+// largest lbits a k-mer length allows: the line number is the top of a 32-bit mix of the (k - 15)-base minimizer
+int32_t cells_lbits_cap(int32_t k) { return std::min<int32_t>(CELL_LBITS_MAX, 2 * (k - 15) - 2); }
+
+// FORMAT_CELLS (kcfx_internal.h) is what the BASELINE configuration gets: k = 27 .. 31 (31 in BASELINE.json), both strands,
+// counters of at most 2 bytes, minimizer bucketing. KCFX_TABLE_FORMAT=lines keeps the 12-slot line table (A/B and test
+// hook, read at open time).
 bool cells_eligible(const kcfx_db* db, int32_t counter_size) {
     const char* s = getenv("KCFX_TABLE_FORMAT");
     if (s && !strcmp(s, "lines")) return false;
-    return db->info.kmer_length == 31 && db->info.both_strands && counter_size <= 2 && table_mode() == MODE_MINIMIZER &&
-           minimizer_len(31, 0) == 16;
+    const int32_t k = db->info.kmer_length;
+    if (k < CELL_K_MIN || k > CELL_K_MAX || !db->info.both_strands || counter_size > 2 || table_mode() != MODE_MINIMIZER ||
+        getenv("KCFX_MM_LEN") != nullptr)
+        return false;
+    // the minimizer is k - 15 bases: a line number cannot carry more than its 2 (k - 15) bits
+    return db->info.total_kmers <= (int64_t)16 << cells_lbits_cap(k);
 }
 
 // 2^lbits lines of 16 cells. The sparser the table the fewer k-mers find their cell taken and go to the stash (bench
 // workload, 150 M k-mers: 9.7 % at 2^26 lines, 6.2 % at 2^27), and every stash lookup is a random 16-byte fetch of its own:
 // aim at ~0.075 k-mers per cell while that stays under 48 GiB and 50 % of the free memory, else halve down to ~1 per cell.
 // KCFX_TABLE_LBITS overrides.
-int32_t cells_lbits(int64_t n_keys) {
+int32_t cells_lbits(int64_t n_keys, int32_t k) {
+    const int32_t cap = cells_lbits_cap(k);
     const char* s = getenv("KCFX_TABLE_LBITS");
-    if (s && atoi(s) >= CELL_LBITS_MIN && atoi(s) <= CELL_LBITS_MAX) return atoi(s);
+    if (s && atoi(s) >= CELL_LBITS_MIN && atoi(s) <= cap) return atoi(s);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)256 << 30;
     const double room = std::min(48.0 * (double)(1ull << 30), 0.5 * (double)free_b);
     int32_t L = CELL_LBITS_MIN;
-    while (L < CELL_LBITS_MAX && 16.0 * (double)(1ull << L) * 0.075 < (double)n_keys) ++L;
+    while (L < cap && 16.0 * (double)(1ull << L) * 0.075 < (double)n_keys) ++L;
     while (L > CELL_LBITS_MIN && (double)(1ull << L) * LINE_BYTES > room && 16.0 * (double)(1ull << (L - 1)) >= (double)n_keys) --L;
     return L;
 }
@@ -349,12 +358,12 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys) {
     db->fmt = FORMAT_CELLS;
     db->wide = 0;
     db->mode = MODE_MINIMIZER;
-    db->mm_len = 16;
+    db->mm_len = db->info.kmer_length - 15;
     db->info.table_mode = MODE_MINIMIZER;
-    db->info.minimizer_length = 16;
+    db->info.minimizer_length = db->mm_len;
     db->info.table_format = FORMAT_CELLS;
     hipError_t e = hipErrorOutOfMemory;
-    for (int32_t L = cells_lbits(n_keys); L >= CELL_LBITS_MIN; --L) {
+    for (int32_t L = cells_lbits(n_keys, db->info.kmer_length); L >= CELL_LBITS_MIN; --L) {
         e = hipMalloc(&db->d_lines, (size_t)LINE_BYTES << L);
         if (e == hipErrorOutOfMemory) {                     // denser tables before giving up
             (void)hipGetLastError();
@@ -565,9 +574,9 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     // 1 = insert. Cell tables: 0 = bid for first-choice cells, 1 = settle the losers, 2 = fill the stash.
     auto apply = [&](int phase, const uint64_t* keys, const uint32_t* counts, int64_t n) -> hipError_t {
         if (cells) {
-            if (phase == 0) return launch_cells_insert(db->d_lines, db->lbits, keys, counts, n, db->stream);
-            if (phase == 1) return launch_cells_settle(db->d_lines, db->lbits, keys, counts, n, db->d_stats, db->stream);
-            return launch_cells_stash(db->d_lines, db->lbits, keys, counts, n, db->d_stash, db->stash_mask, db->stream);
+            if (phase == 0) return launch_cells_insert(db->d_lines, db->info.kmer_length, db->lbits, keys, counts, n, db->stream);
+            if (phase == 1) return launch_cells_settle(db->d_lines, db->info.kmer_length, db->lbits, keys, counts, n, db->d_stats, db->stream);
+            return launch_cells_stash(db->d_lines, db->info.kmer_length, db->lbits, keys, counts, n, db->d_stash, db->stash_mask, db->stream);
         }
         if (phase == 0) return launch_table_count(db->d_lines, db->view(), h.k, keys, n, db->stream);
         return launch_table_insert(db->d_lines, db->view(), h.k, keys, counts, n, db->stream);
@@ -742,11 +751,11 @@ int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, 
             (e = hipMemcpyAsync(d_counts, src, (size_t)n * 4, hipMemcpyHostToDevice, db->stream)) != hipSuccess)
             rc = hip_fail(e, "kcfx_db_build upload");
         if (!rc && db->fmt == FORMAT_CELLS) {
-            if ((e = launch_cells_insert(db->d_lines, db->lbits, d_keys, d_counts, n, db->stream)) != hipSuccess ||
-                (e = launch_cells_settle(db->d_lines, db->lbits, d_keys, d_counts, n, db->d_stats, db->stream)) != hipSuccess)
+            if ((e = launch_cells_insert(db->d_lines, db->info.kmer_length, db->lbits, d_keys, d_counts, n, db->stream)) != hipSuccess ||
+                (e = launch_cells_settle(db->d_lines, db->info.kmer_length, db->lbits, d_keys, d_counts, n, db->d_stats, db->stream)) != hipSuccess)
                 rc = hip_fail(e, "kcfx_db_build insert");
             if (!rc) rc = cells_stash_alloc(db);
-            if (!rc && ((e = launch_cells_stash(db->d_lines, db->lbits, d_keys, d_counts, n, db->d_stash, db->stash_mask, db->stream)) != hipSuccess ||
+            if (!rc && ((e = launch_cells_stash(db->d_lines, db->info.kmer_length, db->lbits, d_keys, d_counts, n, db->d_stash, db->stash_mask, db->stream)) != hipSuccess ||
                         (e = hipStreamSynchronize(db->stream)) != hipSuccess))
                 rc = hip_fail(e, "kcfx_db_build stash");
         } else if (!rc) {

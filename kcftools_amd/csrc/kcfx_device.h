@@ -207,37 +207,46 @@ KCFX_HD uint32_t cell_g32(uint32_t cm) {
     return x * 0x27D4EB2Fu;
 }
 
-// the 15 bases of N around the 16-mer at base offset sh / 2, left-aligned (low 2 bits zero); *m_out = that 16-mer
-KCFX_HD uint32_t cell_flank(uint64_t N, uint32_t sh, uint32_t* m_out) {
-    const uint64_t t = N << sh;
-    const uint32_t keep = 0xFFFFFFFFu >> sh;                  // bits that come from behind the 16-mer
-    *m_out = (uint32_t)(t >> 32);
-    return (keep & ((uint32_t)t >> sh)) | (~keep & (uint32_t)(N >> 32));
-}
-
 // Second choice: a k-mer that finds its cell taken may live in ONE other cell of the same line, 1, 3, .. 15 cells away
 // (xor) as its leading flank bits say; there it is stored with bit 15 of r set, so that it can never be mistaken for the
 // k-mer that has the same (w, r) and this cell as its first choice. sh = 2 * cell index.
 constexpr uint32_t CELL_R_ALT = 0x8000u;
 KCFX_HD uint32_t cell_alt_sh(uint32_t sh, uint32_t w) { return sh ^ (((w >> 27) & 0x1Cu) | 2u); }
 
+// Cell tables exist for k = 27 .. 31: the minimizer length is M = k - 15, so that a k-mer always spans 16 M-mers (one DPP
+// row, 16 cells per line) and its flank is always 15 bases = 30 bits. M-mers are kept left-aligned in 32 bits.
+KCFX_HD constexpr int cell_mlen(int k) { return k - 15; }
+KCFX_HD constexpr uint32_t cell_mmask(int M) { return 0xFFFFFFFFu << (32 - 2 * M); }
+
+// reverse complement of a left-aligned M-mer (comp_swap also complements the padding; the shift drops it)
+KCFX_HD uint32_t rc_mmer(uint32_t m, int M) { return brev32(comp_swap(m)) << (32 - 2 * M); }
+
+// the 15 bases of N around the M-mer at base offset sh / 2, left-aligned (low 2 bits zero); *m_out = that M-mer
+KCFX_HD uint32_t cell_flank(uint64_t N, uint32_t sh, int M, uint32_t* m_out) {
+    const uint64_t t = N << sh;
+    const uint32_t keep = 0xFFFFFFFFu >> sh;                  // bits that come from behind the M-mer
+    *m_out = (uint32_t)(t >> 32) & cell_mmask(M);
+    const uint32_t behind = M == 16 ? (uint32_t)t : (uint32_t)((t << (2 * M)) >> 32);
+    return (keep & (behind >> sh)) | (~keep & (uint32_t)(N >> 32));
+}
+
 struct CellProbe {
     uint32_t line;      // top lbits of G32
-    uint32_t sh;        // 2 * cell index (= byte offset of the cell's r / count; w is at 2 * sh)
+    uint32_t sh;        // 2 * cell index (the cell is at byte 4 * sh of the line)
     uint32_t w;         // flank bits (flag bits clear)
     uint32_t r;         // low 32 - lbits bits of G32
 };
 
 // Query side, one lane: F / R = the k-mer as the text reads it and its reverse complement, mn = the tagged minimum over
 // the k-mer's 16 M-mers, lane = this lane's position label base (mm27_tagged was fed (lane + offset) & 15).
-KCFX_HD CellProbe cell_probe_of(uint64_t F, uint64_t R, uint32_t mn, uint32_t lane, int32_t lbits) {
+KCFX_HD CellProbe cell_probe_of(uint64_t F, uint64_t R, uint32_t mn, uint32_t lane, int32_t lbits, int M) {
     const bool flip = (mn & 16u) != 0;                        // the minimizer is canonical on the other strand
     const uint64_t N = flip ? R : F;
     uint32_t sh = ((mn - lane) << 1) & 30u;                   // 2 * offset of the minimizer in F
     sh ^= flip ? 30u : 0u;                                    // in R it sits at 15 - offset
     CellProbe p;
     uint32_t cm;
-    p.w = cell_flank(N, sh, &cm);
+    p.w = cell_flank(N, sh, M, &cm);
     const uint32_t g = cell_g32(cm);
     p.sh = sh;
     p.line = g >> (32 - lbits);
@@ -245,24 +254,23 @@ KCFX_HD CellProbe cell_probe_of(uint64_t F, uint64_t R, uint32_t mn, uint32_t la
     return p;
 }
 
-KCFX_HD uint32_t rc16(uint32_t m) { return brev32(comp_swap(m)); }
-
-// Build side: every cell a stored canonical 31-mer C must be findable in. Normally one; several when the minimum hash
-// is attained at more than one offset (a repeated 16-mer, or two 16-mers that agree in their leading 27 hash bits --
+// Build side: every cell a stored canonical k-mer C must be findable in. Normally one; several when the minimum hash
+// is attained at more than one offset (a repeated M-mer, or two M-mers that agree in their leading 27 hash bits --
 // the query's tie-break depends on the k-mer's alignment in the text, so every tied offset gets a copy), two per offset
-// when the 16-mer is its own reverse complement (either strand may be the one the text reads).
+// when the M-mer is its own reverse complement (either strand may be the one the text reads).
 constexpr int CELL_MAX_CANDS = 32;
-KCFX_HD int cells_of_key(uint64_t C, int32_t lbits, CellProbe* out) {
-    const uint64_t Rc = revcomp_word(C, 31);
+KCFX_HD int cells_of_key(uint64_t C, int32_t k, int32_t lbits, CellProbe* out) {
+    const int M = cell_mlen(k);
+    const uint64_t Rc = revcomp_word(C, k);
     uint32_t best = 0xFFFFFFFFu;
     for (int j = 0; j < 16; ++j) {
-        const uint32_t m = (uint32_t)((C << (2 * j)) >> 32), r = rc16(m);
+        const uint32_t m = (uint32_t)((C << (2 * j)) >> 32) & cell_mmask(M), r = rc_mmer(m, M);
         const uint32_t h = mm27(m < r ? m : r);
         best = h < best ? h : best;
     }
     int n = 0;
     for (int j = 0; j < 16; ++j) {
-        const uint32_t m = (uint32_t)((C << (2 * j)) >> 32), r = rc16(m);
+        const uint32_t m = (uint32_t)((C << (2 * j)) >> 32) & cell_mmask(M), r = rc_mmer(m, M);
         const uint32_t cm = m < r ? m : r;
         if (mm27(cm) != best) continue;
         for (int strand = 0; strand < 2; ++strand) {
@@ -272,7 +280,7 @@ KCFX_HD int cells_of_key(uint64_t C, int32_t lbits, CellProbe* out) {
             const uint32_t sh = 2u * (uint32_t)(strand ? 15 - j : j);
             CellProbe p;
             uint32_t got;
-            p.w = cell_flank(N, sh, &got);
+            p.w = cell_flank(N, sh, M, &got);
             const uint32_t g = cell_g32(cm);
             p.sh = sh;
             p.line = g >> (32 - lbits);

@@ -43,8 +43,8 @@ constexpr uint32_t BUILD_COUNT_MASK = 0x00FFFFFFu, BUILD_HEAVY = 0x80000000u;
 constexpr int MODE_KEYHASH = 0, MODE_MINIMIZER = 1;
 
 // ----------------------------------------------------------------------------------------------------
-// FORMAT_CELLS (k = 31, both-strands databases, counters of at most 2 bytes -- the BASELINE.json configuration):
-// the line a k-mer lives in is still chosen by its minimizer (M = 16), but INSIDE the line the k-mer has exactly one
+// FORMAT_CELLS (k = 27 .. 31, both-strands databases, counters of at most 2 bytes -- BASELINE.json's k = 31 among them):
+// the line a k-mer lives in is still chosen by its minimizer (M = k - 15, so that a k-mer spans exactly 16 M-mers), but INSIDE the line the k-mer has exactly one
 // cell: cell index = offset of the minimizer in the k-mer, read on the strand where the minimizer 16-mer is in
 // canonical form ("N orientation"). The 16 k-mers that can share a minimizer occurrence have 16 distinct offsets, so a
 // run of consecutive reference k-mers maps onto distinct cells of ONE line, and a probe is ONE 8-byte load per lane --
@@ -67,6 +67,7 @@ constexpr int MODE_KEYHASH = 0, MODE_MINIMIZER = 1;
 //   slot = hash32(key) & mask, probed by the lanes individually.
 // ----------------------------------------------------------------------------------------------------
 constexpr int FORMAT_LINES = 0, FORMAT_CELLS = 1;
+constexpr int CELL_K_MIN = 27, CELL_K_MAX = 31;               // cell tables: minimizer length k - 15, so that a k-mer spans 16 of them
 constexpr int CELL_LBITS_MIN = 17, CELL_LBITS_MAX = 31;     // r must fit 15 bits (bit 15 marks a second-choice cell); n_lines fits 32
 constexpr uint32_t CELL_FLAG_STASH = 1u, CELL_FLAG_MASK = 3u;
 // a cell as one 64-bit word: w in bits 0..31, r in 32..47, count in 48..63
@@ -216,10 +217,10 @@ hipError_t launch_table_insert(uint8_t* lines, TableView tv, int32_t k, const ui
 hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide, unsigned long long* stats, hipStream_t st);
 // FORMAT_CELLS build: pass 1 bids for first-choice cells; pass 2 (after ALL of pass 1) settles the losers into second-choice
 // cells or flags them for the stash (stats[0] = how many); pass 3 (after ALL of pass 2) fills the stash
-hipError_t launch_cells_insert(uint8_t* lines, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n, hipStream_t st);
-hipError_t launch_cells_settle(uint8_t* lines, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n,
+hipError_t launch_cells_insert(uint8_t* lines, int32_t k, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n, hipStream_t st);
+hipError_t launch_cells_settle(uint8_t* lines, int32_t k, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n,
                                unsigned long long* stats, hipStream_t st);
-hipError_t launch_cells_stash(const uint8_t* lines, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n,
+hipError_t launch_cells_stash(const uint8_t* lines, int32_t k, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n,
                               uint4* stash, uint32_t stash_mask, hipStream_t st);
 // lookup
 hipError_t launch_lookup(TableView tv, int32_t k, const uint64_t* keys, int64_t n, int32_t* counts_out, hipStream_t st);

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void lookup_kernel(TableView tv, int32_t k, co
 // ======================================================================================================
 // Pass 1: every stored k-mer bids for its first-choice cell(s) with a 64-bit atomic max -- the count is the most
 // significant field, so the most abundant k-mer gets the cell whatever the arrival order.
-__global__ void cells_insert_kernel(uint8_t* lines, int32_t lbits, const uint64_t* __restrict__ keys,
+__global__ void cells_insert_kernel(uint8_t* lines, int32_t k, int32_t lbits, const uint64_t* __restrict__ keys,
                                     const uint32_t* __restrict__ counts, int64_t n) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -197,7 +197,7 @@ __global__ void cells_insert_kernel(uint8_t* lines, int32_t lbits, const uint64_
         const uint32_t c = counts[i] & 0xFFFFu;
         if (c == 0) continue;                       // can never be observed (count >= -c >= 1 is needed): not stored
         CellProbe cand[CELL_MAX_CANDS];
-        const int nc = cells_of_key(keys[i], lbits, cand);
+        const int nc = cells_of_key(keys[i], k, lbits, cand);
         for (int a = 0; a < nc; ++a)
             atomicMax(reinterpret_cast<unsigned long long*>(lines + (size_t)cand[a].line * LINE_BYTES + 4 * cand[a].sh),
                       (unsigned long long)cell_word(cand[a].w, cand[a].r, c));
@@ -218,7 +218,7 @@ __device__ __forceinline__ int cell_standing(const uint8_t* lines, const CellPro
 // k-mer has it as first choice then), else it flags its first-choice cell -- "someone who belongs here lives in the
 // stash" -- and is counted. stats[0] = k-mers for the stash, [1] = k-mers stored (count != 0), [2] = k-mers with more
 // than one first-choice cell, [3] = second-choice placements
-__global__ void cells_settle_kernel(uint8_t* lines, int32_t lbits, const uint64_t* __restrict__ keys,
+__global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, const uint64_t* __restrict__ keys,
                                     const uint32_t* __restrict__ counts, int64_t n, unsigned long long* stats) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -227,7 +227,7 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t lbits, const uint64_
         const uint32_t c = counts[i] & 0xFFFFu;
         if (c == 0) continue;
         CellProbe cand[CELL_MAX_CANDS];
-        const int nc = cells_of_key(keys[i], lbits, cand);
+        const int nc = cells_of_key(keys[i], k, lbits, cand);
         bool lost = false;
         for (int a = 0; a < nc; ++a) {
             if (cell_standing(lines, cand[a], c) != 2) continue;     // (1: the same word twice in the input)
@@ -266,7 +266,7 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t lbits, const uint64_
 }
 
 // Pass 3 (after pass 2 has completed): a k-mer that stands in neither cell of one of its candidates goes to the stash.
-__global__ void cells_stash_kernel(const uint8_t* __restrict__ lines, int32_t lbits, const uint64_t* __restrict__ keys,
+__global__ void cells_stash_kernel(const uint8_t* __restrict__ lines, int32_t k, int32_t lbits, const uint64_t* __restrict__ keys,
                                    const uint32_t* __restrict__ counts, int64_t n, uint4* stash, uint32_t mask) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -275,7 +275,7 @@ __global__ void cells_stash_kernel(const uint8_t* __restrict__ lines, int32_t lb
         if (c == 0) continue;
         const uint64_t key = keys[i];
         CellProbe cand[CELL_MAX_CANDS];
-        const int nc = cells_of_key(key, lbits, cand);
+        const int nc = cells_of_key(key, k, lbits, cand);
         bool lost = false;
         for (int a = 0; a < nc; ++a) lost |= cell_standing(lines, cand[a], c) == 2;
         if (!lost) continue;
@@ -306,17 +306,17 @@ __device__ __forceinline__ uint32_t stash_find(const TableView& tv, uint64_t key
 }
 
 // batched KMC.getCount on a FORMAT_CELLS table, one lane per key (utility path)
-__global__ __launch_bounds__(256) void lookup_cells_kernel(TableView tv, const uint64_t* __restrict__ keys, int64_t n,
+__global__ __launch_bounds__(256) void lookup_cells_kernel(TableView tv, int32_t k, const uint64_t* __restrict__ keys, int64_t n,
                                                            int32_t* __restrict__ out) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         const uint64_t key = keys[i];
         int32_t result = 0;
-        // only canonical words are stored (both-strands database); a k = 31 word has its low two bits clear
-        if (key <= revcomp_word(key, 31) && (key & 3ull) == 0) {
+        // only canonical words are stored (both-strands database); a k-mer word has its low 64 - 2k bits clear
+        if (key <= revcomp_word(key, k) && (key & ~(~0ull << (64 - 2 * k))) == 0) {
             CellProbe cand[CELL_MAX_CANDS];
-            cells_of_key(key, tv.lbits, cand);                  // any one of its cells decides
+            cells_of_key(key, k, tv.lbits, cand);               // any one of its cells decides
             const uint8_t* line = tv.lines + (size_t)cand[0].line * LINE_BYTES;
             const uint64_t first = *reinterpret_cast<const uint64_t*>(line + 4 * cand[0].sh);
             const uint64_t second = *reinterpret_cast<const uint64_t*>(line + 4 * cell_alt_sh(cand[0].sh, cand[0].w));
@@ -705,7 +705,7 @@ __device__ __forceinline__ bool k31_tile_clean(const K31Pack& sh) {
 // The words of a tile as one wave sees them: canonical key, minimizer and validity ballot of 64 consecutive positions per
 // step, everything in registers. Carried from one word to the next: the leading code words of both strands at this lane's
 // position and the row scans of the M-mer hashes they give.
-template <bool CELLS>
+template <bool CELLS, int K = 31>
 struct K31Words {
     // Between consecutive words every code-bit address advances by the same amount (64 positions = 4 code dwords of each
     // strand = 2 validity dwords) and the shifts do not change: the addresses are carried, not recomputed.
@@ -720,8 +720,15 @@ struct K31Words {
     // 16-mer; FORMAT_CELLS tables tag it with the strand and the position (mm27_tagged) so that the minimum also says where
     // the minimizer sits in each k-mer
     __device__ __forceinline__ uint32_t mmer_of(uint32_t f0, uint32_t c0) const {
-        if constexpr (CELLS) return mm27_tagged(f0, brev32(c0), (uint32_t)lane & 15u);
-        else return mhash32(((uint64_t)min(f0, brev32(c0))) << 32);
+        if constexpr (CELLS) {
+            // the M-mer (M = K - 15) is the leading 2M bits; its reverse complement comes from the same bits of the
+            // complement-swapped stream, reversed (for M = 16 the masks and the shift vanish)
+            constexpr int M = cell_mlen(K);
+            constexpr uint32_t mm = cell_mmask(M);
+            return mm27_tagged(f0 & mm, brev32(c0 & mm) << (32 - 2 * M), (uint32_t)lane & 15u);
+        } else {
+            return mhash32(((uint64_t)min(f0, brev32(c0))) << 32);
+        }
     }
     __device__ __forceinline__ void start(const K31Pack& sh, int off, int n_kmers_, int lane_, int w_begin) {
         n_kmers = n_kmers_;
@@ -743,7 +750,7 @@ struct K31Words {
     // word w (call with consecutive w): the k-mer as the text reads it and its reverse complement (Kmer.java:232-252,
     // :300-338), the minimum over its 16 M-mers, validity
     __device__ __forceinline__ void next(int w, uint64_t& fwd, uint64_t& rc, uint32_t& mn, uint64_t& V) {
-        constexpr int k = 31;
+        constexpr int k = K;
         // bits [2q+32, 2q+64) of this word (one entry on) and bits [2(q+64), 2(q+64)+32) of the next (four entries on)
         // share the carried shift
         constexpr uint32_t lo_mask = ~0u << (64 - 2 * k);
@@ -958,19 +965,21 @@ __device__ __forceinline__ void cells_match(const CellWord& cw, uint32_t& cnt, u
 }
 
 // canonical k-mer (Kmer.java:72-79) at packed position q of the tile, from the interleaved code words
+template <int K>
 __device__ __forceinline__ uint64_t k31_canonical_at(const K31Pack& sh, int q) {
-    constexpr uint32_t lo_mask = ~0u << 2;
+    constexpr uint32_t lo_mask = ~0u << (64 - 2 * K);
     const int b0 = 2 * q - 1;
     const uint2* p = sh.fcx + 1 + (b0 >> 5);
     const uint32_t s = 31u - (uint32_t)(b0 & 31);
     const uint2 x = p[0], y = p[1], z = p[2];
     const uint64_t fwd = u64_of(alignbit32(y.x, z.x, s) & lo_mask, alignbit32(x.x, y.x, s));
-    const uint64_t rc = u64_of(brev32(alignbit32(x.y, y.y, s)), brev32(alignbit32(y.y, z.y, s) & lo_mask)) << 2;
+    const uint64_t rc = u64_of(brev32(alignbit32(x.y, y.y, s)), brev32(alignbit32(y.y, z.y, s) & lo_mask)) << (64 - 2 * K);
     return rc < fwd ? rc : fwd;
 }
 
 // Stash lookups for the first min(qn, 64) queued k-mers (their keys are re-derived from the packed tile: the queue only
 // holds where they sit); returns the new qn.
+template <int K>
 __device__ __forceinline__ int k31c_stash_round(const TableView& tv, const K31Pack& sh, K31CQueue& q, int lane, int qn, int pos0,
                                                 int32_t min_count, uint32_t& sum_acc) {
     const int nb = min(qn, 64), rest = qn - nb;
@@ -979,7 +988,7 @@ __device__ __forceinline__ int k31c_stash_round(const TableView& tv, const K31Pa
     wave_lds_fence();
     if (lane < rest) q.id[lane] = i2;                       // the entries behind the batch move to the front
     uint32_t cnt = 0;
-    if (lane < nb) cnt = stash_find(tv, k31_canonical_at(sh, pos0 + (int)id));
+    if (lane < nb) cnt = stash_find(tv, k31_canonical_at<K>(sh, pos0 + (int)id));
     const bool hit = (int32_t)cnt >= min_count;             // cnt is 0 unless found; GetVariants.java:224
     if (hit) atomicOr(&q.hit[id >> 6], 1ull << (id & 63));
     sum_acc += hit ? cnt : 0u;                              // GetVariants.java:226
@@ -987,6 +996,7 @@ __device__ __forceinline__ int k31c_stash_round(const TableView& tv, const K31Pa
     return rest;
 }
 
+template <int K>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void screen_k31c_kernel(
     const uint8_t* __restrict__ text, const TileDesc* __restrict__ tiles, TableView tv, int32_t min_count,
     uint64_t* __restrict__ bits, int64_t* __restrict__ count_sums) {
@@ -1007,7 +1017,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 
     uint32_t sum_acc = 0;                                   // per lane; u16 counters: fits (static_assert in screen_k31_kernel)
     uint64_t* my_bits = bits + (size_t)blockIdx.x * TILE_BITS_U64;
-    K31Words<true> words;
+    K31Words<true, K> words;
     if (w_begin < w_end) words.start(sh, off, td.n_kmers, lane, w_begin);
 
     // stage A of word w: keys, minimizer, cell, run list (the run lists of consecutive words alternate), fetches issued
@@ -1015,7 +1025,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         uint64_t fwd, rc, V;
         uint32_t mn;
         words.next(w, fwd, rc, mn, V);
-        const CellProbe p = cell_probe_of(fwd, rc, mn, (uint32_t)lane, tv.lbits);
+        const CellProbe p = cell_probe_of(fwd, rc, mn, (uint32_t)lane, tv.lbits, cell_mlen(K));
         cells_issue(tv, V, p, cw);
     };
     // stage B of word w: cells matched, ballots out, stash candidates queued
@@ -1037,7 +1047,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             qn += __popcll(PM);
         }
         wave_lds_fence();
-        while (qn >= 64) qn = k31c_stash_round(tv, sh, q, lane, qn, pos0, min_count, sum_acc);
+        while (qn >= 64) qn = k31c_stash_round<K>(tv, sh, q, lane, qn, pos0, min_count, sum_acc);
     };
     // Two words per trip so that the two CellWords stay in fixed registers; the steady-state trip has no condition around
     // an issue (see cells_issue), the last one or two words are peeled.
@@ -1059,7 +1069,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             retire(w, a);
         }
     }
-    while (qn > 0) qn = k31c_stash_round(tv, sh, q, lane, qn, pos0, min_count, sum_acc);
+    while (qn > 0) qn = k31c_stash_round<K>(tv, sh, q, lane, qn, pos0, min_count, sum_acc);
     if (lane < w_end - w_begin) {                           // the wave's words of the window's bitmap
         my_bits[w_begin + lane] = q.vw[lane];
         my_bits[TILE_WORDS + w_begin + lane] = q.hit[lane];
@@ -1388,23 +1398,23 @@ hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide,
     return hipGetLastError();
 }
 
-hipError_t launch_cells_insert(uint8_t* lines, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n, hipStream_t st) {
+hipError_t launch_cells_insert(uint8_t* lines, int32_t k, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(cells_insert_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, lbits, keys, counts, n);
+    hipLaunchKernelGGL(cells_insert_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, k, lbits, keys, counts, n);
     return hipGetLastError();
 }
 
-hipError_t launch_cells_settle(uint8_t* lines, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n,
+hipError_t launch_cells_settle(uint8_t* lines, int32_t k, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n,
                                unsigned long long* stats, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(cells_settle_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, lbits, keys, counts, n, stats);
+    hipLaunchKernelGGL(cells_settle_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, k, lbits, keys, counts, n, stats);
     return hipGetLastError();
 }
 
-hipError_t launch_cells_stash(const uint8_t* lines, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n,
+hipError_t launch_cells_stash(const uint8_t* lines, int32_t k, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n,
                               uint4* stash, uint32_t stash_mask, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(cells_stash_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, lbits, keys, counts, n, stash,
+    hipLaunchKernelGGL(cells_stash_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, k, lbits, keys, counts, n, stash,
                        stash_mask);
     return hipGetLastError();
 }
@@ -1412,7 +1422,7 @@ hipError_t launch_cells_stash(const uint8_t* lines, int32_t lbits, const uint64_
 hipError_t launch_lookup(TableView tv, int32_t k, const uint64_t* keys, int64_t n, int32_t* counts_out, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     if (tv.fmt == FORMAT_CELLS) {
-        hipLaunchKernelGGL(lookup_cells_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, tv, keys, n, counts_out);
+        hipLaunchKernelGGL(lookup_cells_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, tv, k, keys, n, counts_out);
         return hipGetLastError();
     }
     const dim3 g(grid_for(n * 8, 256, 256 * 16)), b(256);
@@ -1446,7 +1456,16 @@ hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32
     hipExtLaunchKernelGGL((screen_k31_kernel<W, BS>), g, b, 0, st, ev_start, ev_stop, 0, text, tiles, tv, min_count, bits, count_sums)
     const bool generic_only = tv.generic != 0;                                      // A/B and test hook, fixed at kcfx_db_open
     if (tv.fmt == FORMAT_CELLS) {
-        hipExtLaunchKernelGGL(screen_k31c_kernel, g, b, 0, st, ev_start, ev_stop, 0, text, tiles, tv, min_count, bits, count_sums);
+#define KCFX_LAUNCHC(KK) hipExtLaunchKernelGGL((screen_k31c_kernel<KK>), g, b, 0, st, ev_start, ev_stop, 0, text, tiles, tv, min_count, bits, count_sums)
+        switch (k) {
+            case 27: KCFX_LAUNCHC(27); break;
+            case 28: KCFX_LAUNCHC(28); break;
+            case 29: KCFX_LAUNCHC(29); break;
+            case 30: KCFX_LAUNCHC(30); break;
+            case 31: KCFX_LAUNCHC(31); break;
+            default: return hipErrorInvalidValue;
+        }
+#undef KCFX_LAUNCHC
     } else if (tv.mode == MODE_MINIMIZER && k == 31 && tv.mm_len == 16 && !generic_only) {
         if (tv.wide) { if (both_strands) KCFX_LAUNCH31(true, true); else KCFX_LAUNCH31(true, false); }
         else         { if (both_strands) KCFX_LAUNCH31(false, true); else KCFX_LAUNCH31(false, false); }

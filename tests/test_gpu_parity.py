@@ -47,6 +47,12 @@ CONFIGS = [
     (23, 3, 2, 5, 7, True),
     (15, 3, 1, 5, 3, False),
     (32, 4, 2, 7, 4, True),
+    # k = 27 .. 30 on canonical databases with narrow counters take the cell table too (minimizer length k - 15)
+    (30, 2, 2, 7, 4, True),
+    (29, 5, 1, 7, 3, True),
+    (28, 4, 2, 5, 4, True),
+    (27, 3, 2, 5, 3, True),
+    (29, 1, 2, 7, 2, False),
 ]
 
 
@@ -58,6 +64,8 @@ def test_lookup_matches_getcount(oracle, tmp_path, k, p, cs, m, bins, both):
     odb = oracle.OracleDb(prefix)
     i = db.info
     assert (i.kmer_length, i.lut_prefix_length, i.counter_size, i.signature_length, i.n_bins) == (k, p, cs, m, bins)
+    assert i.table_format == (1 if (27 <= k <= 31 and both and cs <= 2) else 0)
+    assert i.minimizer_length == k - 15 if i.table_format == 1 else True
     assert bool(i.both_strands) == both and i.total_kmers == len(kmers) and i.version == 0x200
     assert i.min_count == prm.min_count and i.max_count == int(np.int32(np.uint32(prm.max_count)))   # Java int (KMC.java:131)
     got = db.lookup(kmers)
@@ -370,7 +378,8 @@ def test_fuzz_window_geometry_against_oracle(oracle, tmp_path, seed, kernel, mon
     if kernel == "lines":
         monkeypatch.setenv("KCFX_TABLE_FORMAT", "lines")
     rng = np.random.default_rng(1000 + seed)
-    k = 31
+    # the cell-table kernel exists for k = 27 .. 31: every other "default" seed leaves 31
+    k = (31, 29, 31, 30, 27, 28)[seed % 6] if kernel == "default" else 31
     L = 180_000
     ref = bytearray(synth.random_reference(L, 500 + seed))
     for _ in range(25):
@@ -385,8 +394,8 @@ def test_fuzz_window_geometry_against_oracle(oracle, tmp_path, seed, kernel, mon
     both = bool(rng.integers(0, 2))
     if kernel == "default":                 # always the cell table (canonical, narrow counters)
         cs, both = 1 + seed % 2, True
-    prefix, *_ = make_db(tmp_path, "fz", ref, 300 + seed, k=k, p=int(rng.choice([3, 7])), cs=cs, m=7, bins=4, both=both,
-                         noise=5_000)
+    p_of_k = {31: int(rng.choice([3, 7])), 30: 2, 29: 5, 28: 4, 27: 3}
+    prefix, *_ = make_db(tmp_path, "fz", ref, 300 + seed, k=k, p=p_of_k[k], cs=cs, m=7, bins=4, both=both, noise=5_000)
     db = engine.KmcDb.open(prefix)
     assert db.info.table_format == (1 if kernel == "default" else 0)
     odb = oracle.OracleDb(prefix)

@@ -47,8 +47,8 @@ def harness():
     L.harness_revcomp_word.argtypes = [C.c_uint64, C.c_int]
     L.harness_revcomp_word.restype = C.c_uint64
     L.harness_gap_both.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p]
-    L.harness_cells.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    L.harness_cells_of_key.argtypes = [C.c_uint64, C.c_int, C.c_void_p]
+    L.harness_cells.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.harness_cells_of_key.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_void_p]
     return L
 
 
@@ -232,33 +232,33 @@ def test_cell_table_build_side_covers_query_side(harness, oracle):
     (line, cell, w, r): that is what makes the 48-bit compare exact."""
     rng = np.random.default_rng(33)
     acgt = np.frombuffer(b"ACGTacgt", dtype=np.uint8)
-    pal = b"ACGTACGTACGTACGT"            # its own reverse complement
+    pal = b"ACGTACGTACGTACGT"            # its own reverse complement (and so are its even-length prefixes)
     pal2 = b"AAAACCCCGGGGTTTT"
     text = bytes(rng.choice(acgt, 6000))
     text = (text[:500] + b"A" * 80 + b"AT" * 40 + b"ACG" * 30 + text[500:1500] + pal + text[1500:1600] + pal + pal2 +
             text[1600:1700] + pal2 * 3 + text[1700:2500] + text[2000:2300] + b"N" + text[2500:])
     buf = padded(text)
     seen = {}
-    for lbits in (16, 19, 27, 31):
+    for k, lbits in ((31, 17), (31, 19), (31, 27), (31, 30), (30, 21), (29, 19), (29, 26), (28, 20), (27, 17), (27, 22)):
         for begin in (0, 1, 7, 33, 64, 501):
-            n = min(2048, len(text) - begin - 31 + 1)
+            n = min(2048, len(text) - begin - k + 1)
             ncand = np.zeros(n, dtype=np.int32)
             probe = np.zeros(4 * n, dtype=np.uint32)
-            bad = harness.harness_cells(buf.ctypes.data, begin, n, lbits, ncand.ctypes.data, probe.ctypes.data)
-            assert bad == 0, (lbits, begin)
+            bad = harness.harness_cells(buf.ctypes.data, begin, n, k, lbits, ncand.ctypes.data, probe.ctypes.data)
+            assert bad == 0, (k, lbits, begin)
             assert ncand.min() >= 1 and ncand.max() <= 32
             if lbits == 19:
                 assert (ncand > 1).sum() > 50          # the tie / palindrome paths were exercised
                 assert (ncand == 1).mean() > 0.8
     # injectivity over every cell of every distinct canonical k-mer of the text (valid positions only)
-    lst = np.zeros(len(text), dtype=np.uint64)
-    m = oracle.lib().kcfo_kmers_list(text, len(text), 31, lst.ctypes.data)
-    canon = np.unique(np.minimum(lst[:m], synth.revcomp(lst[:m], 31)))
     out = np.zeros(4 * 32, dtype=np.uint32)
-    for lbits in (16, 24):
+    for k, lbits in ((31, 17), (31, 24), (29, 20), (27, 18)):
+        lst = np.zeros(len(text), dtype=np.uint64)
+        m = oracle.lib().kcfo_kmers_list(text, len(text), k, lst.ctypes.data)
+        canon = np.unique(np.minimum(lst[:m], synth.revcomp(lst[:m], k)))
         seen = {}
         for c in canon:
-            nc = harness.harness_cells_of_key(int(c), lbits, out.ctypes.data)
+            nc = harness.harness_cells_of_key(int(c), k, lbits, out.ctypes.data)
             for i in range(nc):
                 cell = tuple(int(x) for x in out[4 * i:4 * i + 4])
-                assert seen.setdefault(cell, int(c)) == int(c), (lbits, hex(int(c)), hex(seen[cell]))
+                assert seen.setdefault(cell, int(c)) == int(c), (k, lbits, hex(int(c)), hex(seen[cell]))
