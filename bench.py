@@ -281,16 +281,19 @@ def main():
         cal = min(n_win, 8)
         t0 = time.perf_counter()
         w1 = odb.screen(text, win_begin[:cal], win_len[:cal], args.min_count, threads=1)
-        rate1 = int(w1["total_kmers"].sum()) / (time.perf_counter() - t0)
+        rate1 = int(w1["total_kmers"].sum()) / (time.perf_counter() - t0)     # (warms the page cache of the database files too)
         by_threads = {}
         best = None
         ok = True
         checked = 0
-        rate_guess = rate1
         for T in sorted({1, min(16, ncpu), min(64, ncpu), ncpu}):
-            # a sample sized for ~cpu_baseline_seconds of wall at this thread count (scaled from the previous count's rate)
-            want = rate_guess * (T if T == 1 else 1) * args.cpu_baseline_seconds
-            n_s = int(max(T, want / kmers_per_window))
+            # calibrate this thread count on a short sample, then run ~cpu_baseline_seconds of wall
+            n_c = int(min(n_win, max(4 * T, 64)))
+            idx = np.linspace(0, n_win - 1, n_c).astype(np.int64)
+            t0 = time.perf_counter()
+            wc = odb.screen(text, win_begin[idx], win_len[idx], args.min_count, threads=T)
+            rate_c = int(wc["total_kmers"].sum()) / (time.perf_counter() - t0)
+            n_s = int(max(T, rate_c * args.cpu_baseline_seconds / kmers_per_window))
             # evenly spaced windows; more than one pass over the window list when the list is shorter than the budget
             idx = (np.linspace(0, n_win - 1, n_s).astype(np.int64) if n_s <= n_win
                    else np.resize(np.arange(n_win, dtype=np.int64), n_s))
@@ -300,7 +303,6 @@ def main():
             cpu_kmers = int(wN["total_kmers"].sum())
             rate = cpu_kmers / tN
             by_threads[str(T)] = {"value": rate, "seconds": tN, "windows": n_s, "kmers": cpu_kmers}
-            rate_guess = rate * 2 if T < ncpu else rate          # the next count has more threads
             # the same windows from the GPU run must be bit-identical
             ok = ok and all(np.array_equal(res[f][idx], wN[f]) for f in engine.INT_FIELDS)
             checked = max(checked, min(n_s, n_win))

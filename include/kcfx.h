@@ -146,10 +146,15 @@ int32_t kcfx_screen_ref_async(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count
  * k = 31 minimizer tables with counters of at most 2 bytes are screened up to 8 at a time by one kernel, the rest one by
  * one (same results either way). */
 int32_t kcfx_screen_ref_multi(kcfx_db* const* dbs, int32_t n_db, kcfx_ref* ref, int32_t min_kmer_count, kcfx_result* out);
-/* Same, asynchronous on `hip_stream`, results left in device memory (n_db * n_windows records). The first call on a
- * reference allocates its multi-sample scratch; later calls allocate nothing. */
+/* Same, asynchronous on `hip_stream`, results left in device memory (n_db * n_windows records). Databases that the
+ * multi-sample kernel takes (12-slot line tables) need scratch of 512 B per tile and sample on the reference: it is allocated
+ * by the first call that needs it, or beforehand by kcfx_ref_reserve_multi -- do that before capturing the call into a HIP
+ * graph (an allocation is not capturable). Cell tables (table_format 1) are screened one launch per sample and need none. */
 int32_t kcfx_screen_ref_multi_async(kcfx_db* const* dbs, int32_t n_db, kcfx_ref* ref, int32_t min_kmer_count,
                                     void* out_device, void* hip_stream);
+
+/* Reserve the multi-sample scratch of `ref` for batches of up to `n_samples` line-table databases (clamped to 8). */
+int32_t kcfx_ref_reserve_multi(kcfx_ref* ref, int32_t n_samples);
 
 /* One-shot convenience: kcfx_ref_create + kcfx_screen_ref + kcfx_ref_destroy. */
 int32_t kcfx_screen(kcfx_db* db, const uint8_t* text, int64_t text_len, const int64_t* win_begin,

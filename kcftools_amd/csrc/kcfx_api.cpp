@@ -925,18 +925,7 @@ int32_t kcfx_screen_ref_multi_async(kcfx_db* const* dbs, int32_t n_db, kcfx_ref*
     {
         int32_t eligible = 0;
         for (int32_t i = 0; i < n_db; ++i) eligible += screen_multi_supported(dbs[i]->view(), ref->k) ? 1 : 0;
-        const int32_t want = std::min<int32_t>(eligible, SCREEN_MULTI_MAX);
-        if (want > ref->multi_cap) {
-            if (ref->d_mbits) (void)hipFree(ref->d_mbits);
-            if (ref->d_mcsum) (void)hipFree(ref->d_mcsum);
-            ref->d_mbits = nullptr;
-            ref->d_mcsum = nullptr;
-            ref->multi_cap = 0;
-            const size_t nt = std::max<size_t>(ref->n_tiles, 1);
-            KCFX_HIP(hipMalloc(&ref->d_mbits, nt * (size_t)want * TILE_BITS_U64 * 8));
-            KCFX_HIP(hipMalloc(&ref->d_mcsum, nt * (size_t)want * sizeof(int64_t)));
-            ref->multi_cap = want;
-        }
+        if (int32_t rc = kcfx_ref_reserve_multi(ref, eligible)) return rc;
     }
     std::vector<char> done(n_db, 0);
     for (int32_t first = 0; first < n_db; ++first) {
@@ -983,6 +972,23 @@ int32_t kcfx_screen_ref_multi_async(kcfx_db* const* dbs, int32_t n_db, kcfx_ref*
             b = e;
         }
     }
+    return KCFX_OK;
+}
+
+int32_t kcfx_ref_reserve_multi(kcfx_ref* ref, int32_t n_samples) {
+    if (!ref || n_samples < 0) return fail(KCFX_ERR_ARG, "null argument");
+    const int32_t want = std::min<int32_t>(n_samples, SCREEN_MULTI_MAX);
+    if (want <= ref->multi_cap) return KCFX_OK;
+    DeviceGuard g(ref->device);
+    if (ref->d_mbits) (void)hipFree(ref->d_mbits);
+    if (ref->d_mcsum) (void)hipFree(ref->d_mcsum);
+    ref->d_mbits = nullptr;
+    ref->d_mcsum = nullptr;
+    ref->multi_cap = 0;
+    const size_t nt = std::max<size_t>(ref->n_tiles, 1);
+    KCFX_HIP(hipMalloc(&ref->d_mbits, nt * (size_t)want * TILE_BITS_U64 * 8));
+    KCFX_HIP(hipMalloc(&ref->d_mcsum, nt * (size_t)want * sizeof(int64_t)));
+    ref->multi_cap = want;
     return KCFX_OK;
 }
 

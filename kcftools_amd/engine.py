@@ -26,6 +26,7 @@ ABI_SYMBOLS = (
     "kcfx_db_open", "kcfx_db_build", "kcfx_db_info", "kcfx_db_header", "kcfx_db_lookup", "kcfx_db_close",
     "kcfx_ref_create", "kcfx_ref_n_windows", "kcfx_ref_n_kmer_slots", "kcfx_ref_destroy",
     "kcfx_screen_ref", "kcfx_screen_ref_async", "kcfx_screen_ref_multi", "kcfx_screen_ref_multi_async", "kcfx_screen",
+    "kcfx_ref_reserve_multi",
     "kcfx_ctx_create", "kcfx_ctx_n_devices", "kcfx_ctx_destroy", "kcfx_screen_sharded",
     "kcfx_score", "kcfx_windows",
     "kcfx_prof_enable", "kcfx_prof_read", "kcfx_last_error", "kcfx_device_count", "kcfx_version",
@@ -116,6 +117,7 @@ def lib() -> C.CDLL:
         L.kcfx_ref_destroy.restype = None
         L.kcfx_screen_ref.argtypes = [vp, vp, i32, vp]
         L.kcfx_screen_ref_async.argtypes = [vp, vp, i32, vp, vp]
+        L.kcfx_ref_reserve_multi.argtypes = [vp, i32]
         L.kcfx_screen_ref_multi.argtypes = [vp, i32, vp, i32, vp]
         L.kcfx_screen_ref_multi_async.argtypes = [vp, i32, vp, i32, vp, vp]
         L.kcfx_screen.argtypes = [vp, vp, i64, vp, vp, i32, i32, vp]
@@ -258,6 +260,10 @@ class Reference:
         handles = (C.c_void_p * max(len(dbs), 1))(*[C.cast(d._h, C.c_void_p).value for d in dbs])
         _check(lib().kcfx_screen_ref_multi_async(handles, len(dbs), self._h, min_count, C.c_void_p(out_device_ptr),
                                                  C.c_void_p(stream)))
+
+    def reserve_multi(self, n_samples: int) -> None:
+        """Allocate the multi-sample scratch now (needed before capturing screen_multi_async into a HIP graph)."""
+        _check(lib().kcfx_ref_reserve_multi(self._h, n_samples))
 
     def prof_enable(self, on: bool = True) -> None:
         _check(lib().kcfx_prof_enable(self._h, int(on)))

@@ -424,7 +424,8 @@ def test_async_entry_point_is_graph_capturable(oracle, tmp_path):
     s, e = engine.windows(len(ref), 10_000, 0, k)
     r = engine.Reference(ref, s, e - s, k)
     want = r.screen(db, 1)
-    want2 = r.screen_multi([db, db2], 1)                  # also allocates the multi-sample scratch
+    r.reserve_multi(2)                                    # scratch for line-table batches: nothing may allocate under capture
+    want2 = r.screen_multi([db, db2], 1)
     out = torch.zeros(len(s) * 10, dtype=torch.int32, device="cuda:0")
     out2 = torch.zeros(2 * len(s) * 10, dtype=torch.int32, device="cuda:0")
     side = torch.cuda.Stream()
