@@ -3,6 +3,8 @@
 Bar (BASELINE.json north_star): every per-window integer bit-exact; identity score within 1e-6 (it is
 computed from the integers by the same IEEE operations, so it is in fact bit-identical).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -420,26 +422,32 @@ def test_async_entry_point_is_graph_capturable(oracle, tmp_path):
     ref = synth.random_reference(200_000, 41)
     prefix, *_ = make_db(tmp_path, "g", ref, 77)
     prefix2, *_ = make_db(tmp_path, "g2", ref, 78)
-    db, db2 = engine.KmcDb.open(prefix), engine.KmcDb.open(prefix2)
+    db = engine.KmcDb.open(prefix)                        # a cell table: one launch per sample, no scratch beyond the reference's
+    os.environ["KCFX_TABLE_FORMAT"] = "lines"             # two line tables: the multi-sample kernel and its scratch
+    try:
+        db2, db3 = engine.KmcDb.open(prefix2), engine.KmcDb.open(prefix)
+    finally:
+        os.environ.pop("KCFX_TABLE_FORMAT", None)
+    assert (db.info.table_format, db2.info.table_format, db3.info.table_format) == (1, 0, 0)
     s, e = engine.windows(len(ref), 10_000, 0, k)
     r = engine.Reference(ref, s, e - s, k)
     want = r.screen(db, 1)
     r.reserve_multi(2)                                    # scratch for line-table batches: nothing may allocate under capture
-    want2 = r.screen_multi([db, db2], 1)
+    want2 = r.screen_multi([db, db2, db3], 1)
     out = torch.zeros(len(s) * 10, dtype=torch.int32, device="cuda:0")
-    out2 = torch.zeros(2 * len(s) * 10, dtype=torch.int32, device="cuda:0")
+    out2 = torch.zeros(3 * len(s) * 10, dtype=torch.int32, device="cuda:0")
     side = torch.cuda.Stream()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, stream=side):
         st = torch.cuda.current_stream().cuda_stream
         r.screen_async(db, out.data_ptr(), st, 1)
-        r.screen_multi_async([db, db2], out2.data_ptr(), st, 1)
+        r.screen_multi_async([db, db2, db3], out2.data_ptr(), st, 1)
     out.zero_()
     out2.zero_()
     for _ in range(3):
         g.replay()
     torch.cuda.synchronize()
     assert_same(out.cpu().numpy().view(engine.RESULT_DTYPE), want, "graph replay")
-    got2 = out2.cpu().numpy().view(engine.RESULT_DTYPE).reshape(2, len(s))
-    for i in range(2):
+    got2 = out2.cpu().numpy().view(engine.RESULT_DTYPE).reshape(3, len(s))
+    for i in range(3):
         assert_same(got2[i], want2[i], f"graph replay, sample {i}")
