@@ -219,7 +219,8 @@ struct kcfx_db {
     int32_t lbits = 0;
     uint4* d_stash = nullptr;
     uint32_t stash_mask = 0;
-    unsigned long long* d_stats = nullptr;   // FORMAT_CELLS build counters (cells_insert_kernel)
+    unsigned long long* d_stats = nullptr;   // FORMAT_CELLS build counters (cells_settle_kernel)
+    uint32_t* d_pop = nullptr;               // FORMAT_CELLS build scratch: k-mers per minimizer sub-bucket (freed after the build)
     hipStream_t stream = nullptr;
     TableView view() const { return TableView{d_lines, n_lines, wide, mode, mm_len, fmt, lbits, stash_mask, d_stash, generic}; }
 };
@@ -378,6 +379,8 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys) {
     KCFX_HIP(hipMemsetAsync(db->d_lines, 0, (size_t)LINE_BYTES << db->lbits, db->stream));
     KCFX_HIP(hipMalloc(&db->d_stats, 4 * sizeof(unsigned long long)));
     KCFX_HIP(hipMemsetAsync(db->d_stats, 0, 4 * sizeof(unsigned long long), db->stream));
+    KCFX_HIP(hipMalloc(&db->d_pop, cells_pop_bytes(db->lbits)));
+    KCFX_HIP(hipMemsetAsync(db->d_pop, 0, cells_pop_bytes(db->lbits), db->stream));
     db->info.table_bytes = (int64_t)LINE_BYTES << db->lbits;
     db->info.table_lines = db->n_lines;
     db->info.slots_per_line = 16;
@@ -444,7 +447,9 @@ int32_t table_finish(kcfx_db* db) {
     if (db->fmt == FORMAT_CELLS) {
         KCFX_HIP(hipStreamSynchronize(db->stream));
         if (db->d_stats) (void)hipFree(db->d_stats);
+        if (db->d_pop) (void)hipFree(db->d_pop);
         db->d_stats = nullptr;
+        db->d_pop = nullptr;
         return KCFX_OK;
     }
     unsigned long long* d_stats = nullptr;
@@ -468,6 +473,7 @@ void db_free(kcfx_db* db) {
     if (db->d_lines) (void)hipFree(db->d_lines);
     if (db->d_stash) (void)hipFree(db->d_stash);
     if (db->d_stats) (void)hipFree(db->d_stats);
+    if (db->d_pop) (void)hipFree(db->d_pop);
     delete db;
 }
 
@@ -571,12 +577,15 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     tr.mark("buffers + LUT upload");
 
     // One pass of the build over a batch of decoded records. Line tables: 0 = count per home line (minimizer tables only),
-    // 1 = insert. Cell tables: 0 = bid for first-choice cells, 1 = settle the losers, 2 = fill the stash.
+    // 1 = insert. Cell tables: 0 = count per minimizer sub-bucket, 1 / 2 = bids of the crowded / the other k-mers, 3 = settle
+    // the losers, 4 = fill the stash.
     auto apply = [&](int phase, const uint64_t* keys, const uint32_t* counts, int64_t n) -> hipError_t {
         if (cells) {
-            if (phase == 0) return launch_cells_insert(db->d_lines, db->info.kmer_length, db->lbits, keys, counts, n, db->stream);
-            if (phase == 1) return launch_cells_settle(db->d_lines, db->info.kmer_length, db->lbits, keys, counts, n, db->d_stats, db->stream);
-            return launch_cells_stash(db->d_lines, db->info.kmer_length, db->lbits, keys, counts, n, db->d_stash, db->stash_mask, db->stream);
+            const int32_t kk = db->info.kmer_length;
+            if (phase == 0) return launch_cells_count(db->d_pop, kk, db->lbits, keys, counts, n, db->stream);
+            if (phase == 1 || phase == 2) return launch_cells_insert(db->d_lines, db->d_pop, phase == 1 ? 1 : 0, kk, db->lbits, keys, counts, n, db->stream);
+            if (phase == 3) return launch_cells_settle(db->d_lines, kk, db->lbits, keys, counts, n, db->d_stats, db->stream);
+            return launch_cells_stash(db->d_lines, kk, db->lbits, keys, counts, n, db->d_stash, db->stash_mask, db->stream);
         }
         if (phase == 0) return launch_table_count(db->d_lines, db->view(), h.k, keys, n, db->stream);
         return launch_table_insert(db->d_lines, db->view(), h.k, keys, counts, n, db->stream);
@@ -627,13 +636,14 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
         if ((rc = stream_file(0, resident))) return rc;
         tr.mark("file -> decode -> first pass (host)");
         if (cells) {
-            if ((rc = later_pass(1))) return rc;
+            for (int phase = 1; phase <= 3; ++phase)
+                if ((rc = later_pass(phase))) return rc;
             if ((rc = cells_stash_alloc(db))) {
                 cleanup();
                 return rc;
             }
-            tr.mark("settle + stash alloc");
-            if ((rc = later_pass(2))) return rc;
+            tr.mark("bids + settle + stash alloc");
+            if ((rc = later_pass(4))) return rc;
         } else {
             LOAD_HIP(launch_table_mark_heavy(db->d_lines, db->n_lines, db->stream));
             if ((rc = later_pass(1))) return rc;
@@ -751,8 +761,10 @@ int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, 
             (e = hipMemcpyAsync(d_counts, src, (size_t)n * 4, hipMemcpyHostToDevice, db->stream)) != hipSuccess)
             rc = hip_fail(e, "kcfx_db_build upload");
         if (!rc && db->fmt == FORMAT_CELLS) {
-            if ((e = launch_cells_insert(db->d_lines, db->info.kmer_length, db->lbits, d_keys, d_counts, n, db->stream)) != hipSuccess ||
-                (e = launch_cells_settle(db->d_lines, db->info.kmer_length, db->lbits, d_keys, d_counts, n, db->d_stats, db->stream)) != hipSuccess)
+            if ((e = launch_cells_count(db->d_pop, kmer_length, db->lbits, d_keys, d_counts, n, db->stream)) != hipSuccess ||
+                (e = launch_cells_insert(db->d_lines, db->d_pop, 1, kmer_length, db->lbits, d_keys, d_counts, n, db->stream)) != hipSuccess ||
+                (e = launch_cells_insert(db->d_lines, db->d_pop, 0, kmer_length, db->lbits, d_keys, d_counts, n, db->stream)) != hipSuccess ||
+                (e = launch_cells_settle(db->d_lines, kmer_length, db->lbits, d_keys, d_counts, n, db->d_stats, db->stream)) != hipSuccess)
                 rc = hip_fail(e, "kcfx_db_build insert");
             if (!rc) rc = cells_stash_alloc(db);
             if (!rc && ((e = launch_cells_stash(db->d_lines, db->info.kmer_length, db->lbits, d_keys, d_counts, n, db->d_stash, db->stash_mask, db->stream)) != hipSuccess ||

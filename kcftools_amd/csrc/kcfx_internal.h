@@ -53,15 +53,16 @@ constexpr int MODE_KEYHASH = 0, MODE_MINIMIZER = 1;
 //
 //   128-byte line = 16 x 8-byte cell;  cell = u32 w | u16 r | u16 count
 //     w     = the 30 flank bits (the 15 bases of N around the minimizer, left-aligned) | bit 0: some k-mer that maps
-//             to this cell lives in the stash | bit 1: reserved
+//             to this cell lives in the stash | bit 1: the occupant is of the "crowded" class (build time only)
 //     r     = low (32 - lbits) bits of G32 = a 32-bit mix of the canonical minimizer 16-mer; the line number is the top
 //             lbits of G32, and G32 <-> minimizer is a bijection (cell_g32)
 //             (at most 15 bits: lbits >= 17) | bit 15: this k-mer sits in its SECOND-choice cell
 //     count = the stored counter; 0 = empty cell (a k-mer whose counter is 0 can never be observed -- GetVariants.java:224
 //             needs count >= -c >= 1 -- so it is not stored)
 //   (line, cell, w, r) -> N -> canonical k-mer is injective, so equality of (w, r) in the k-mer's cell IS equality of
-//   the k-mer. When several k-mers want one cell the one with the largest counter gets it (a 64-bit atomic max: the
-//   build is deterministic, and in a real database the genomic k-mer beats its sequencing-error neighbours, which
+//   the k-mer. When several k-mers want one cell, a k-mer whose minimizer is shared by >= 3 k-mers of the database
+//   (the genome's runs -- what a reference window asks for) beats an isolated one, then the larger counter wins (64-bit
+//   atomic max: deterministic, and in a real database the genomic k-mer beats its sequencing-error neighbours, which
 //   share its minimizer and offset). A loser takes its second-choice cell in the same line if that is empty
 //   (cell_alt_sh), else it goes to the stash: open addressing over 16-byte entries {u64 key, u32 count, u32 pad},
 //   slot = hash32(key) & mask, probed by the lanes individually.
@@ -215,9 +216,13 @@ hipError_t launch_table_mark_heavy(uint8_t* lines, uint32_t n_lines, hipStream_t
 hipError_t launch_table_insert(uint8_t* lines, TableView tv, int32_t k, const uint64_t* keys,
                                const uint32_t* counts, int64_t n, hipStream_t st);
 hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide, unsigned long long* stats, hipStream_t st);
-// FORMAT_CELLS build: pass 1 bids for first-choice cells; pass 2 (after ALL of pass 1) settles the losers into second-choice
-// cells or flags them for the stash (stats[0] = how many); pass 3 (after ALL of pass 2) fills the stash
-hipError_t launch_cells_insert(uint8_t* lines, int32_t k, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n, hipStream_t st);
+// FORMAT_CELLS build, five passes over the k-mers, each after ALL of the one before: count per minimizer sub-bucket
+// (cells_pop_bytes of zeroed scratch), bids of the crowded class (cls 1), bids of the others (cls 0), settle the losers into
+// second-choice cells or flag them for the stash (stats[0] = how many), fill the stash
+size_t cells_pop_bytes(int32_t lbits);
+hipError_t launch_cells_count(uint32_t* pop32, int32_t k, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n, hipStream_t st);
+hipError_t launch_cells_insert(uint8_t* lines, const uint32_t* pop32, int32_t cls, int32_t k, int32_t lbits, const uint64_t* keys,
+                               const uint32_t* counts, int64_t n, hipStream_t st);
 hipError_t launch_cells_settle(uint8_t* lines, int32_t k, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n,
                                unsigned long long* stats, hipStream_t st);
 hipError_t launch_cells_stash(const uint8_t* lines, int32_t k, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n,

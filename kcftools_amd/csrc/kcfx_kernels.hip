@@ -187,10 +187,40 @@ __global__ __launch_bounds__(256) void lookup_kernel(TableView tv, int32_t k, co
 // ======================================================================================================
 // FORMAT_CELLS build + lookup (layout and exactness argument: kcfx_internal.h; cell derivation: kcfx_device.h)
 // ======================================================================================================
-// Pass 1: every stored k-mer bids for its first-choice cell(s) with a 64-bit atomic max -- the count is the most
-// significant field, so the most abundant k-mer gets the cell whatever the arrival order.
-__global__ void cells_insert_kernel(uint8_t* lines, int32_t k, int32_t lbits, const uint64_t* __restrict__ keys,
-                                    const uint32_t* __restrict__ counts, int64_t n) {
+// Who gets a contested cell. A reference window asks for the k-mers of a genome, which come in runs that share their
+// minimizer; an isolated k-mer (a sequencing error, a contaminant) is asked for rarely. So: first the k-mer whose minimizer
+// is shared by more k-mers of the database (class "crowded": >= CELL_CROWD of them in its sub-bucket = line + 2 more bits of
+// the minimizer's mix), then the larger counter. Exactness never depends on this -- it only decides who lives in a cell and
+// who in the stash; on the bench database it halves the stash look-ups of a screening pass.
+constexpr uint32_t CELL_CROWD = 3;
+constexpr uint32_t CELL_FLAG_CROWDED = 2u;                  // bit 1 of w: the occupant is of the crowded class
+__host__ __device__ inline int cell_sub_bits(int32_t lbits) { return lbits <= 30 ? 2 : 32 - lbits; }
+__device__ __forceinline__ uint64_t cell_sub_bucket(const CellProbe& p, int32_t lbits) {
+    const int sb = cell_sub_bits(lbits);
+    return ((uint64_t)p.line << sb) | (p.r >> (32 - lbits - sb));
+}
+
+// Pass 0: k-mers per sub-bucket, one byte each (a byte that overflows spills into its neighbour: the classes are a
+// heuristic, see above)
+__global__ void cells_count_kernel(uint32_t* pop32, int32_t k, int32_t lbits, const uint64_t* __restrict__ keys,
+                                   const uint32_t* __restrict__ counts, int64_t n) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        if ((counts[i] & 0xFFFFu) == 0) continue;
+        CellProbe cand[CELL_MAX_CANDS];
+        cells_of_key(keys[i], k, lbits, cand);
+        const uint64_t sub = cell_sub_bucket(cand[0], lbits);
+        atomicAdd(&pop32[sub >> 2], 1u << (8 * (uint32_t)(sub & 3)));
+    }
+}
+
+// Pass 1 (cls = 1) and pass 2 (cls = 0, after ALL of pass 1): every stored k-mer of the class bids for its first-choice
+// cell(s). Crowded k-mers bid with a 64-bit atomic max -- the count is the most significant field, so the most abundant
+// one gets the cell whatever the arrival order. The others do the same among themselves (a CAS loop), but never replace a
+// crowded occupant.
+__global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__ pop32, int32_t cls, int32_t k, int32_t lbits,
+                                    const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, int64_t n) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
@@ -198,9 +228,23 @@ __global__ void cells_insert_kernel(uint8_t* lines, int32_t k, int32_t lbits, co
         if (c == 0) continue;                       // can never be observed (count >= -c >= 1 is needed): not stored
         CellProbe cand[CELL_MAX_CANDS];
         const int nc = cells_of_key(keys[i], k, lbits, cand);
-        for (int a = 0; a < nc; ++a)
-            atomicMax(reinterpret_cast<unsigned long long*>(lines + (size_t)cand[a].line * LINE_BYTES + 4 * cand[a].sh),
-                      (unsigned long long)cell_word(cand[a].w, cand[a].r, c));
+        const uint64_t sub = cell_sub_bucket(cand[0], lbits);
+        const bool crowded = ((pop32[sub >> 2] >> (8 * (uint32_t)(sub & 3))) & 0xFFu) >= CELL_CROWD;
+        if ((int32_t)crowded != cls) continue;
+        for (int a = 0; a < nc; ++a) {
+            unsigned long long* cell = reinterpret_cast<unsigned long long*>(lines + (size_t)cand[a].line * LINE_BYTES + 4 * cand[a].sh);
+            if (crowded) {
+                atomicMax(cell, (unsigned long long)cell_word(cand[a].w | CELL_FLAG_CROWDED, cand[a].r, c));
+            } else {
+                const unsigned long long mine = cell_word(cand[a].w, cand[a].r, c);
+                unsigned long long old = __atomic_load_n(cell, __ATOMIC_RELAXED);
+                while (!(old & CELL_FLAG_CROWDED) && old < mine) {
+                    const unsigned long long prev = atomicCAS(cell, old, mine);
+                    if (prev == old) break;
+                    old = prev;
+                }
+            }
+        }
     }
 }
 
@@ -1398,11 +1442,20 @@ hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide,
     return hipGetLastError();
 }
 
-hipError_t launch_cells_insert(uint8_t* lines, int32_t k, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n, hipStream_t st) {
+hipError_t launch_cells_count(uint32_t* pop32, int32_t k, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(cells_insert_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, k, lbits, keys, counts, n);
+    hipLaunchKernelGGL(cells_count_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, pop32, k, lbits, keys, counts, n);
     return hipGetLastError();
 }
+
+hipError_t launch_cells_insert(uint8_t* lines, const uint32_t* pop32, int32_t cls, int32_t k, int32_t lbits, const uint64_t* keys,
+                               const uint32_t* counts, int64_t n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(cells_insert_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, pop32, cls, k, lbits, keys, counts, n);
+    return hipGetLastError();
+}
+
+size_t cells_pop_bytes(int32_t lbits) { return (size_t)1 << (lbits + cell_sub_bits(lbits)); }
 
 hipError_t launch_cells_settle(uint8_t* lines, int32_t k, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n,
                                unsigned long long* stats, hipStream_t st) {
