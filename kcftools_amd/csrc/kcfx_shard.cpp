@@ -153,6 +153,7 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
         std::condition_variable cv;
         std::deque<kcfx_db*> ready;
         bool stop = false, loader_done = false;
+        int in_use = 0;                                  // databases the screening thread holds (0 or 1)
         int32_t load_rc = KCFX_OK;
         std::string load_error;
         std::thread loader([&]() {
@@ -164,7 +165,17 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
                 }
                 const double t1 = now_s();
                 kcfx_db* db = nullptr;
-                const int32_t rc = kcfx_db_open(kmc_prefixes[wk.samples[i]], wk.device, &db);
+                int32_t rc = kcfx_db_open(kmc_prefixes[wk.samples[i]], wk.device, &db);
+                if (rc == KCFX_ERR_DEVICE) {
+                    // most likely out of HBM next to the database being screened (two wheat-scale tables do not always fit):
+                    // wait until this device holds no other database of ours, then try once more with all of it
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return stop || (in_use == 0 && ready.empty()); });
+                    if (!stop) {
+                        lk.unlock();
+                        rc = kcfx_db_open(kmc_prefixes[wk.samples[i]], wk.device, &db);
+                    }
+                }
                 std::lock_guard<std::mutex> lk(mu);
                 wk.t_open += now_s() - t1;
                 if (rc) {
@@ -193,6 +204,7 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
                 }
                 db = ready.front();
                 ready.pop_front();
+                in_use = 1;
                 cv.notify_all();
             }
             kcfx_db_info_t info;
@@ -206,6 +218,11 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
             }
             wk.t_screen += now_s() - t1;
             kcfx_db_close(db);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                in_use = 0;
+                cv.notify_all();
+            }
         }
         {
             std::lock_guard<std::mutex> lk(mu);
