@@ -679,7 +679,7 @@ static void info_from_header(const KmcHeader& h, kcfx_db_info_t& info) {
 extern "C" {
 
 const char* kcfx_last_error(void) { return g_error.c_str(); }
-const char* kcfx_version(void) { return "kcfx 0.1.0 (gfx950)"; }
+const char* kcfx_version(void) { return "kcfx 0.2.0 (gfx950)"; }
 
 int32_t kcfx_device_count(int32_t* n) {
     if (!n) return fail(KCFX_ERR_ARG, "null argument");
