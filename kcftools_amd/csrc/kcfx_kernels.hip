@@ -1,13 +1,17 @@
 // kcfx_kernels.hip -- hand-written HIP kernels for gfx950 (CDNA4, wave64) of the getVariations engine.
 //
-//   table_*          : build the HBM table from (k-mer word, count) pairs        (load time)
 //   decode_records   : KMC .kmc_suf records + LUT -> (k-mer word, count)         (load time; KMC.java:427-450)
-//   lookup           : batched KMC.getCount                                      (KMC.java:292-326)
-//   screen_k31       : THE hot kernel (k = 31, minimizer table). ASCII window text -> 2-bit pack in LDS -> per-lane
-//                      canonical k-mer -> minimizer runs -> cooperative 128-byte line fetches -> wave ballots
+//   cells_*          : build the cell table (FORMAT_CELLS, kcfx_internal.h) from (k-mer word, count) pairs   (load time)
+//   table_*          : build the 12-slot line table (FORMAT_LINES) from the same pairs                         (load time)
+//   lookup_*         : batched KMC.getCount                                      (KMC.java:292-326)
+//   screen_k31c<K>   : THE hot kernel (k = 27 .. 31, cell table; BASELINE.json runs K = 31). ASCII window text -> 2-bit pack
+//                      in LDS -> per lane: both strands of the k-mer, tagged minimizer, its cell -> ONE 8-byte load per
+//                      choice of cell, software-pipelined one word ahead -> wave ballots
 //                                                     (GetVariants.java:202-227, Fasta.java:90-167, Kmer.java)
-//   screen_k31_multi : the same for up to 8 resident samples per pass over the reference (SURVEY f-4)
-//   screen_tiles     : the general form (any k <= 32, both table modes)
+//   screen_k31       : the round-1 kernel (k = 31, line table): minimizer runs -> cooperative 128-byte line fetches ->
+//                      12-way compare; now for forward-only databases and 3- / 4-byte counters
+//   screen_k31_multi : the same for up to 8 resident line tables per pass over the reference (SURVEY f-4)
+//   screen_tiles     : the general form (any k <= 32, both line-table modes)
 //   reduce_windows   : hit bitmaps -> gap monoid -> kcfx_result per (window, sample)   (GetVariants.java:228-258)
 //
 // Integer / index work: no MFMA. Lane <-> consecutive k-mer start positions, so one __ballot is a
@@ -522,7 +526,7 @@ __device__ __forceinline__ K31Fetch fetch_setup(uint4* lines, uint32_t* runline,
     return f;
 }
 
-// The general kernel: any k <= 32, any minimizer length, both table modes. The BASELINE.json configuration
+// The general kernel: any k <= 32, any minimizer length, both line-table modes. A k = 31 line table
 // (k = 31, M = 16, minimizer table) runs screen_k31_kernel below instead; KCFX_GENERIC_KERNEL=1 forces this one.
 template <bool WIDE, int MODE>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void screen_tiles_kernel(const uint8_t* __restrict__ text,
@@ -656,7 +660,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 }
 
 // ======================================================================================================
-// screen_k31: the k = 31 / M = 16 minimizer-table specialisation of screen_tiles (BASELINE.json's configuration)
+// screen_k31: the k = 31 / M = 16 line-table specialisation of screen_tiles (round 1's hot kernel)
 // ======================================================================================================
 // Same inputs, outputs and probe semantics as screen_tiles_kernel<*, MODE_MINIMIZER, 31>. SQ counters show the path is
 // VALU-bound (profiles/r01_notes.md), so this kernel is about instruction count:
