@@ -425,7 +425,6 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t x) {     // lane l gets l
 struct K31Fetch {
     int fetch_run;        // lane / 9: the run (0..6, 7 = idle) this lane fetches for
     int piece;            // its 16-byte piece of the line (8 = idle)
-    int piece8;           // min(piece, 7): what an idle lane repeats when every lane must fetch
     bool fetcher;
     uint4* lines;         // this wave's line buffers (2 x 63 uint4)
     uint32_t* runline;    // this wave's run -> line index list (65 entries)
@@ -519,7 +518,6 @@ __device__ __forceinline__ K31Fetch fetch_setup(uint4* lines, uint32_t* runline,
     K31Fetch f;
     f.fetch_run = (lane * 57) >> 9;
     f.piece = lane - 9 * f.fetch_run;
-    f.piece8 = min(f.piece, 7);
     f.fetcher = f.piece < 8 && f.fetch_run < 7;
     f.lines = lines;
     f.runline = runline;

@@ -57,6 +57,33 @@ __global__ __launch_bounds__(256) void gather_coop(const uint8_t* __restrict__ b
     if (acc == 0x12345678u) out[0] = acc;
 }
 
+// the access pattern of screen_k31c: RUN consecutive lanes read one 8-byte cell each (consecutive cells) of the same random
+// 128-byte line, LOADS of them per lane (the second 8 cells further, mod 16), ILP independent words per trip
+template <int RUN, int LOADS, int ILP>
+__global__ __launch_bounds__(256) void gather_runs(const uint8_t* __restrict__ buf, uint32_t n_lines, uint64_t n_acc, uint32_t* out) {
+    const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    uint64_t i = tid;                                   // one access = one lane's cell(s)
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    for (; i < n_acc; i += stride * ILP) {
+        uint2 v[ILP][LOADS];
+#pragma unroll
+        for (int u = 0; u < ILP; ++u) {
+            const uint64_t a = i + u * stride;
+            const uint32_t line = __umulhi(h32((uint32_t)(a / RUN) * 2654435761u + 12345u), n_lines);
+            const uint32_t cell = (uint32_t)(a % RUN + (a / RUN) * 5) & 15u;
+            const uint8_t* p = buf + (size_t)line * 128;
+#pragma unroll
+            for (int l = 0; l < LOADS; ++l) v[u][l] = *reinterpret_cast<const uint2*>(p + 8 * ((cell + 8 * l) & 15u));
+        }
+#pragma unroll
+        for (int u = 0; u < ILP; ++u)
+#pragma unroll
+            for (int l = 0; l < LOADS; ++l) acc += v[u][l].x ^ v[u][l].y;
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
 // dependent-load latency: every lane chases its own chain of random 128-byte-aligned 16-byte loads
 __global__ void chase(const uint8_t* __restrict__ buf, uint32_t n_lines, int steps, uint32_t* out) {
     uint32_t x = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 99u;
@@ -110,6 +137,12 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     printf("table %.2f GiB, %llu accesses per launch\n", gib, (unsigned long long)n_acc);
     const dim3 g(256 * 8), b(256);
+    if (argc > 3) {     // "runs": only the screen_k31c pattern; rates are per lane access -- lines/s = accesses/s / RUN
+#define RUNS(R, L, I) timeit("runs of " #R " lanes x8B, " #L " load(s), ILP " #I, (double)n_acc, 8 * L, [&] { \
+        hipLaunchKernelGGL((gather_runs<R, L, I>), g, b, 0, 0, buf, (uint32_t)(bytes / 128), n_acc, out); });
+        RUNS(8, 1, 1) RUNS(8, 2, 1) RUNS(8, 1, 2) RUNS(8, 2, 2) RUNS(8, 2, 4) RUNS(4, 1, 2) RUNS(16, 1, 2) RUNS(1, 1, 1) RUNS(1, 1, 4)
+        return 0;
+    }
     timeit("stream read 16B/lane", (double)bytes / 16, 16, [&] { hipLaunchKernelGGL(stream_read, g, b, 0, 0, (const uint4*)buf, bytes / 16, out); });
 #define LANE(V, L, I) timeit("lane " #V "x16B of " #L "B line, ILP " #I, (double)n_acc, V * 16, [&] { \
         hipLaunchKernelGGL((gather_lane<V, L, I>), g, b, 0, 0, buf, (uint32_t)(bytes / L), n_acc, out); });
