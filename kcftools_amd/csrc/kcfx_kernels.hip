@@ -1238,7 +1238,7 @@ __device__ __forceinline__ int k31_deferred_round_multi(const MultiTab* tab, con
 }
 
 template <bool BOTH>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void screen_k31_multi_kernel(
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) void screen_k31_multi_kernel(
     const uint8_t* __restrict__ text, const TileDesc* __restrict__ tiles, int32_t n_tiles, MultiTables mt, int32_t min_count,
     uint64_t* __restrict__ bits, int64_t bits_stride, int64_t* __restrict__ count_sums) {
     __shared__ K31Shared sh;
