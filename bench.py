@@ -251,6 +251,8 @@ def main():
 
     kernel_name = ("screen_k31c_kernel" if db.info.table_format == 1 else "screen_k31_kernel") if (S == 1 or db.info.table_format == 1) \
         else "screen_k31_multi_kernel"
+    if os.environ.get("KCFX_GENERIC_KERNEL"):           # A/B hook: the general kernel on a line table
+        kernel_name = "screen_tiles_kernel"
     # HBM traffic comes from PMC counters, which need their own rocprofv3 passes (tools/profile_round.sh): the figure below
     # is the committed one for the same kernel and workload, NOT measured in this run -- traffic_source says so, and it is
     # dropped when the committed profile is of another kernel or workload.
