@@ -46,6 +46,7 @@ extern "C" {
 #define KCFX_ERR_FORMAT 3    /* not a KMC 0x200 database, unsupported k / prefix length */
 #define KCFX_ERR_DEVICE 4    /* HIP error (no device, out of memory, launch failure) */
 #define KCFX_ERR_WEIGHTS 5   /* wi + wt + wr != 1.0 (Data.java:101-103; the reference exits) */
+#define KCFX_ERR_HOST 6      /* host side: out of memory, thread start failure (no C++ exception ever crosses this ABI) */
 
 typedef struct kcfx_db kcfx_db;     /* one KMC database re-indexed into an HBM-resident table on one GPU */
 typedef struct kcfx_ref kcfx_ref;   /* reference text + window list resident in HBM on one GPU */

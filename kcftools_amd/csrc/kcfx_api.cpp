@@ -30,6 +30,24 @@ int32_t hip_fail(hipError_t e, const char* what) {
     (void)hipGetLastError();
     return KCFX_ERR_DEVICE;
 }
+// Nothing may propagate out of an extern "C" entry point (the callers are C, ctypes, JNI): every one that allocates host
+// memory, builds strings or starts threads is a function-try-block ending in this. Called inside catch (...).
+int32_t exception_to_status(const char* fn) noexcept {
+    try {
+        try {
+            throw;
+        } catch (const std::bad_alloc&) {
+            set_error(std::string(fn) + ": out of host memory");
+        } catch (const std::exception& e) {
+            set_error(std::string(fn) + ": " + e.what());
+        } catch (...) {
+            set_error(std::string(fn) + ": unexpected C++ exception");
+        }
+    } catch (...) {                                   // no memory even for the message
+    }
+    return KCFX_ERR_HOST;
+}
+
 static int32_t fail(int32_t code, const std::string& msg) {
     g_error = msg;
     return code;
@@ -673,9 +691,22 @@ static void info_from_header(const KmcHeader& h, kcfx_db_info_t& info) {
     info.total_kmers = h.total;
 }
 
+// a handle under construction: freed on every exit path (error return or exception) unless released
+struct DbHold {
+    kcfx_db* p = nullptr;
+    ~DbHold() { db_free(p); }
+    kcfx_db* release() { kcfx_db* q = p; p = nullptr; return q; }
+};
+struct RefHold {
+    kcfx_ref* p = nullptr;
+    ~RefHold() { ref_free(p); }
+    kcfx_ref* release() { kcfx_ref* q = p; p = nullptr; return q; }
+};
+
 // ------------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------------
+#define KCFX_CATCH(fn) catch (...) { return kcfx::exception_to_status(fn); }
 extern "C" {
 
 const char* kcfx_last_error(void) { return g_error.c_str(); }
@@ -692,7 +723,7 @@ int32_t kcfx_device_count(int32_t* n) {
     return KCFX_OK;
 }
 
-int32_t kcfx_db_open(const char* kmc_prefix, int32_t device, kcfx_db** out) {
+int32_t kcfx_db_open(const char* kmc_prefix, int32_t device, kcfx_db** out) try {
     if (!kmc_prefix || !out) return fail(KCFX_ERR_ARG, "null argument");
     *out = nullptr;
     const double t0 = now_s();
@@ -703,12 +734,13 @@ int32_t kcfx_db_open(const char* kmc_prefix, int32_t device, kcfx_db** out) {
     if (int32_t rc = check_device(device)) return rc;
     DeviceGuard g(device);
     if (!g.ok) return fail(KCFX_ERR_DEVICE, "hipSetDevice failed");
-    kcfx_db* db = new kcfx_db();
+    DbHold hold;
+    kcfx_db* db = hold.p = new kcfx_db();
     db->device = device;
     info_from_header(h, db->info);
     db->info.device = device;
     hipError_t e = db_stream(device, &db->stream);
-    if (e != hipSuccess) { db_free(db); return hip_fail(e, "hipStreamCreate"); }
+    if (e != hipSuccess) return hip_fail(e, "hipStreamCreate");
     tr.mark("device + stream");
     int32_t rc = table_alloc(db, h.total, h.counter_size);
     if (tr.on) (void)hipStreamSynchronize(db->stream);
@@ -716,14 +748,14 @@ int32_t kcfx_db_open(const char* kmc_prefix, int32_t device, kcfx_db** out) {
     if (!rc) rc = load_suffix_file(db, std::string(kmc_prefix) + ".kmc_suf", h);
     if (!rc) rc = table_finish(db);
     tr.mark("finalize");
-    if (rc) { db_free(db); return rc; }
+    if (rc) return rc;
     db->info.load_seconds = now_s() - t0;
-    *out = db;
+    *out = hold.release();
     return KCFX_OK;
-}
+} KCFX_CATCH("kcfx_db_open")
 
 int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, int32_t kmer_length,
-                      int32_t counter_size, int32_t both_strands, int32_t device, kcfx_db** out) {
+                      int32_t counter_size, int32_t both_strands, int32_t device, kcfx_db** out) try {
     if (!out || n < 0 || (n > 0 && (!kmers || !counts))) return fail(KCFX_ERR_ARG, "null argument");
     *out = nullptr;
     if (kmer_length < 1 || kmer_length > 32) return fail(KCFX_ERR_FORMAT, "unsupported k-mer length (1..32)");
@@ -732,7 +764,8 @@ int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, 
     if (int32_t rc = check_device(device)) return rc;
     DeviceGuard g(device);
     if (!g.ok) return fail(KCFX_ERR_DEVICE, "hipSetDevice failed");
-    kcfx_db* db = new kcfx_db();
+    DbHold hold;
+    kcfx_db* db = hold.p = new kcfx_db();
     db->device = device;
     db->info.kmer_length = kmer_length;
     db->info.counter_size = counter_size;
@@ -740,8 +773,16 @@ int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, 
     db->info.version = 0x200;
     db->info.total_kmers = n;
     db->info.device = device;
-    uint64_t* d_keys = nullptr;
-    uint32_t* d_counts = nullptr;
+    struct Scratch {                                   // (freed on every exit path)
+        uint64_t* keys = nullptr;
+        uint32_t* counts = nullptr;
+        ~Scratch() {
+            if (keys) (void)hipFree(keys);
+            if (counts) (void)hipFree(counts);
+        }
+    } scratch;
+    uint64_t*& d_keys = scratch.keys;
+    uint32_t*& d_counts = scratch.counts;
     int32_t rc = KCFX_OK;
     hipError_t e = db_stream(device, &db->stream);
     if (e != hipSuccess) rc = hip_fail(e, "hipStreamCreate");
@@ -780,15 +821,13 @@ int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, 
     }
     if (!rc && n == 0 && db->fmt == FORMAT_CELLS) rc = cells_stash_alloc(db);
     if (!rc) rc = table_finish(db);
-    if (d_keys) (void)hipFree(d_keys);
-    if (d_counts) (void)hipFree(d_counts);
-    if (rc) { db_free(db); return rc; }
+    if (rc) return rc;
     db->info.load_seconds = now_s() - t0;
-    *out = db;
+    *out = hold.release();
     return KCFX_OK;
-}
+} KCFX_CATCH("kcfx_db_build")
 
-int32_t kcfx_db_header(const char* kmc_prefix, kcfx_db_info_t* info) {
+int32_t kcfx_db_header(const char* kmc_prefix, kcfx_db_info_t* info) try {
     if (!kmc_prefix || !info) return fail(KCFX_ERR_ARG, "null argument");
     KmcHeader h;
     if (int32_t rc = parse_prefix_file(std::string(kmc_prefix) + ".kmc_pre", h)) return rc;
@@ -796,7 +835,7 @@ int32_t kcfx_db_header(const char* kmc_prefix, kcfx_db_info_t* info) {
     info_from_header(h, *info);
     info->device = -1;
     return KCFX_OK;
-}
+} KCFX_CATCH("kcfx_db_header")
 
 int32_t kcfx_db_info(const kcfx_db* db, kcfx_db_info_t* info) {
     if (!db || !info) return fail(KCFX_ERR_ARG, "null argument");
@@ -804,7 +843,7 @@ int32_t kcfx_db_info(const kcfx_db* db, kcfx_db_info_t* info) {
     return KCFX_OK;
 }
 
-int32_t kcfx_db_lookup(kcfx_db* db, const uint64_t* kmers, int64_t n, int32_t* counts_out) {
+int32_t kcfx_db_lookup(kcfx_db* db, const uint64_t* kmers, int64_t n, int32_t* counts_out) try {
     if (!db || n < 0 || (n > 0 && (!kmers || !counts_out))) return fail(KCFX_ERR_ARG, "null argument");
     if (n == 0) return KCFX_OK;
     DeviceGuard g(db->device);
@@ -821,12 +860,12 @@ int32_t kcfx_db_lookup(kcfx_db* db, const uint64_t* kmers, int64_t n, int32_t* c
     if (d_k) (void)hipFree(d_k);
     if (d_c) (void)hipFree(d_c);
     return rc;
-}
+} KCFX_CATCH("kcfx_db_lookup")
 
 void kcfx_db_close(kcfx_db* db) { db_free(db); }
 
 int32_t kcfx_ref_create(int32_t device, int32_t kmer_length, const uint8_t* text, int64_t text_len,
-                        const int64_t* win_begin, const int32_t* win_len, int32_t n_windows, kcfx_ref** out) {
+                        const int64_t* win_begin, const int32_t* win_len, int32_t n_windows, kcfx_ref** out) try {
     if (!out || text_len < 0 || n_windows < 0 || (text_len > 0 && !text) || (n_windows > 0 && (!win_begin || !win_len)))
         return fail(KCFX_ERR_ARG, "null argument");
     *out = nullptr;
@@ -860,7 +899,8 @@ int32_t kcfx_ref_create(int32_t device, int32_t kmer_length, const uint8_t* text
     if (int32_t rc = check_device(device)) return rc;
     DeviceGuard g(device);
     if (!g.ok) return fail(KCFX_ERR_DEVICE, "hipSetDevice failed");
-    kcfx_ref* r = new kcfx_ref();
+    RefHold hold;
+    kcfx_ref* r = hold.p = new kcfx_ref();
     r->device = device;
     r->k = k;
     r->n_windows = n_windows;
@@ -879,19 +919,17 @@ int32_t kcfx_ref_create(int32_t device, int32_t kmer_length, const uint8_t* text
         (e = hipMalloc(&r->d_res, std::max<size_t>((size_t)n_windows, 1) * sizeof(kcfx_result))) != hipSuccess ||
         (!tiles.empty() && (e = hipMemcpyAsync(r->d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, r->stream)) != hipSuccess) ||
         (e = hipMemcpyAsync(r->d_win_tile0, win_tile0.data(), win_tile0.size() * 4, hipMemcpyHostToDevice, r->stream)) != hipSuccess ||
-        (e = hipStreamSynchronize(r->stream)) != hipSuccess) {
-        ref_free(r);
+        (e = hipStreamSynchronize(r->stream)) != hipSuccess)
         return hip_fail(e, "kcfx_ref_create");
-    }
-    *out = r;
+    *out = hold.release();
     return KCFX_OK;
-}
+} KCFX_CATCH("kcfx_ref_create")
 
 int32_t kcfx_ref_n_windows(const kcfx_ref* ref) { return ref ? ref->n_windows : 0; }
 int64_t kcfx_ref_n_kmer_slots(const kcfx_ref* ref) { return ref ? ref->n_slots : 0; }
 void kcfx_ref_destroy(kcfx_ref* ref) { ref_free(ref); }
 
-int32_t kcfx_screen_ref_async(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count, void* out_device, void* hip_stream) {
+int32_t kcfx_screen_ref_async(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count, void* out_device, void* hip_stream) try {
     if (!db || !ref || !out_device) return fail(KCFX_ERR_ARG, "null argument");
     if (db->device != ref->device) return fail(KCFX_ERR_ARG, "database and reference live on different devices");
     if (db->info.kmer_length != ref->k) return fail(KCFX_ERR_ARG, "reference was planned for a different k-mer length");
@@ -915,12 +953,12 @@ int32_t kcfx_screen_ref_async(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count
     KCFX_HIP(launch_reduce_windows(ref->d_tiles, ref->n_tiles, 1, ref->d_bits, ref->d_csum, ref->d_win_tile0, ref->n_windows,
                                    ref->k, reinterpret_cast<kcfx_result*>(out_device), st));
     return KCFX_OK;
-}
+} KCFX_CATCH("kcfx_screen_ref_async")
 
 // SURVEY f-4: S resident databases, one pass over the reference. Databases the multi-sample kernel cannot take
 // (k != 31, key-hash tables) go through the single-sample path into their slice of the output.
 int32_t kcfx_screen_ref_multi_async(kcfx_db* const* dbs, int32_t n_db, kcfx_ref* ref, int32_t min_kmer_count,
-                                    void* out_device, void* hip_stream) {
+                                    void* out_device, void* hip_stream) try {
     if (!ref || n_db < 0 || (n_db > 0 && (!dbs || !out_device))) return fail(KCFX_ERR_ARG, "null argument");
     if (min_kmer_count < 1) return fail(KCFX_ERR_ARG, "Minimum kmer count should be at least 1");   // GetVariants.java:383-385
     for (int32_t i = 0; i < n_db; ++i) {
@@ -985,9 +1023,9 @@ int32_t kcfx_screen_ref_multi_async(kcfx_db* const* dbs, int32_t n_db, kcfx_ref*
         }
     }
     return KCFX_OK;
-}
+} KCFX_CATCH("kcfx_screen_ref_multi_async")
 
-int32_t kcfx_ref_reserve_multi(kcfx_ref* ref, int32_t n_samples) {
+int32_t kcfx_ref_reserve_multi(kcfx_ref* ref, int32_t n_samples) try {
     if (!ref || n_samples < 0) return fail(KCFX_ERR_ARG, "null argument");
     const int32_t want = std::min<int32_t>(n_samples, SCREEN_MULTI_MAX);
     if (want <= ref->multi_cap) return KCFX_OK;
@@ -1002,9 +1040,9 @@ int32_t kcfx_ref_reserve_multi(kcfx_ref* ref, int32_t n_samples) {
     KCFX_HIP(hipMalloc(&ref->d_mcsum, nt * (size_t)want * sizeof(int64_t)));
     ref->multi_cap = want;
     return KCFX_OK;
-}
+} KCFX_CATCH("kcfx_ref_reserve_multi")
 
-int32_t kcfx_screen_ref_multi(kcfx_db* const* dbs, int32_t n_db, kcfx_ref* ref, int32_t min_kmer_count, kcfx_result* out) {
+int32_t kcfx_screen_ref_multi(kcfx_db* const* dbs, int32_t n_db, kcfx_ref* ref, int32_t min_kmer_count, kcfx_result* out) try {
     if (!ref || n_db < 0 || (n_db > 0 && !dbs)) return fail(KCFX_ERR_ARG, "null argument");
     if (n_db == 0 || ref->n_windows == 0) {
         if (min_kmer_count < 1) return fail(KCFX_ERR_ARG, "Minimum kmer count should be at least 1");
@@ -1024,9 +1062,9 @@ int32_t kcfx_screen_ref_multi(kcfx_db* const* dbs, int32_t n_db, kcfx_ref* ref, 
     KCFX_HIP(hipMemcpyAsync(out, ref->d_mres, bytes, hipMemcpyDeviceToHost, ref->stream));
     KCFX_HIP(hipStreamSynchronize(ref->stream));
     return KCFX_OK;
-}
+} KCFX_CATCH("kcfx_screen_ref_multi")
 
-int32_t kcfx_screen_ref(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count, kcfx_result* out) {
+int32_t kcfx_screen_ref(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count, kcfx_result* out) try {
     if (!db || !ref || (!out && ref->n_windows > 0)) return fail(KCFX_ERR_ARG, "null argument");
     if (ref->n_windows == 0) return KCFX_OK;
     if (int32_t rc = kcfx_screen_ref_async(db, ref, min_kmer_count, ref->d_res, ref->stream)) return rc;
@@ -1034,10 +1072,10 @@ int32_t kcfx_screen_ref(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count, kcfx
     KCFX_HIP(hipMemcpyAsync(out, ref->d_res, (size_t)ref->n_windows * sizeof(kcfx_result), hipMemcpyDeviceToHost, ref->stream));
     KCFX_HIP(hipStreamSynchronize(ref->stream));
     return KCFX_OK;
-}
+} KCFX_CATCH("kcfx_screen_ref")
 
 int32_t kcfx_screen(kcfx_db* db, const uint8_t* text, int64_t text_len, const int64_t* win_begin,
-                    const int32_t* win_len, int32_t n_windows, int32_t min_kmer_count, kcfx_result* out) {
+                    const int32_t* win_len, int32_t n_windows, int32_t min_kmer_count, kcfx_result* out) try {
     if (!db) return fail(KCFX_ERR_ARG, "null argument");
     kcfx_ref* ref = nullptr;
     if (int32_t rc = kcfx_ref_create(db->device, db->info.kmer_length, text, text_len, win_begin, win_len, n_windows, &ref))
@@ -1045,7 +1083,7 @@ int32_t kcfx_screen(kcfx_db* db, const uint8_t* text, int64_t text_len, const in
     const int32_t rc = kcfx_screen_ref(db, ref, min_kmer_count, out);
     kcfx_ref_destroy(ref);
     return rc;
-}
+} KCFX_CATCH("kcfx_screen")
 
 // Data.java:87 and :95-107. Separate statements + -ffp-contract=off: strict left-to-right IEEE double, no FMA.
 int32_t kcfx_score(const kcfx_result* res, int64_t n, double wi, double wt, double wr, double* score, double* mean_count) {
@@ -1075,7 +1113,7 @@ int32_t kcfx_score(const kcfx_result* res, int64_t n, double wi, double wt, doub
 
 // GetVariants.java:293-320
 int32_t kcfx_windows(int32_t seq_len, int32_t window, int32_t step, int32_t kmer_length, int32_t* starts, int32_t* ends,
-                     int64_t cap, int64_t* n_out) {
+                     int64_t cap, int64_t* n_out) try {
     if (!n_out || kmer_length < 1) return fail(KCFX_ERR_ARG, "null argument");
     if (window <= 0) return fail(KCFX_ERR_ARG, "Window size is required for window model");   // GetVariants.java:360-362
     const int32_t k = kmer_length;
@@ -1104,7 +1142,7 @@ int32_t kcfx_windows(int32_t seq_len, int32_t window, int32_t step, int32_t kmer
     }
     *n_out = n;
     return KCFX_OK;
-}
+} KCFX_CATCH("kcfx_windows")
 
 int32_t kcfx_prof_enable(kcfx_ref* ref, int32_t enable) {
     if (!ref) return fail(KCFX_ERR_ARG, "null argument");
@@ -1112,7 +1150,7 @@ int32_t kcfx_prof_enable(kcfx_ref* ref, int32_t enable) {
     return KCFX_OK;
 }
 
-int32_t kcfx_prof_read(kcfx_ref* ref, double* kernel_ms_sum, int64_t* launches, int32_t reset) {
+int32_t kcfx_prof_read(kcfx_ref* ref, double* kernel_ms_sum, int64_t* launches, int32_t reset) try {
     if (!ref) return fail(KCFX_ERR_ARG, "null argument");
     DeviceGuard g(ref->device);
     double sum = 0;
@@ -1126,6 +1164,6 @@ int32_t kcfx_prof_read(kcfx_ref* ref, double* kernel_ms_sum, int64_t* launches, 
     if (launches) *launches = (int64_t)ref->events_used;
     if (reset) ref->events_used = 0;
     return KCFX_OK;
-}
+} KCFX_CATCH("kcfx_prof_read")
 
 }  // extern "C"

@@ -197,6 +197,7 @@ __host__ __device__ inline kcfx_result summary_finalize(const TileSummary& s, in
 // ---- error plumbing ---------------------------------------------------------------------------------
 void set_error(const std::string& msg);
 int32_t hip_fail(hipError_t e, const char* what);
+int32_t exception_to_status(const char* fn) noexcept;    // inside catch (...): last_error := what was thrown, returns KCFX_ERR_HOST
 
 #define KCFX_HIP(call)                                         \
     do {                                                       \

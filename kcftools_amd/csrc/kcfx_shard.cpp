@@ -64,7 +64,7 @@ struct Worker {
 
 extern "C" {
 
-int32_t kcfx_ctx_create(const int32_t* devices, int32_t n_devices, kcfx_ctx** out) {
+int32_t kcfx_ctx_create(const int32_t* devices, int32_t n_devices, kcfx_ctx** out) try {
     if (!out || n_devices < 1 || !devices) return fail(KCFX_ERR_ARG, "kcfx_ctx_create: at least one device is required");
     *out = nullptr;
     int32_t have = 0;
@@ -76,7 +76,7 @@ int32_t kcfx_ctx_create(const int32_t* devices, int32_t n_devices, kcfx_ctx** ou
     c->devices.assign(devices, devices + n_devices);      // the same device may be listed twice (two shards on one GPU)
     *out = c;
     return KCFX_OK;
-}
+} catch (...) { return kcfx::exception_to_status("kcfx_ctx_create"); }
 
 int32_t kcfx_ctx_n_devices(const kcfx_ctx* ctx) { return ctx ? (int32_t)ctx->devices.size() : 0; }
 
@@ -85,7 +85,7 @@ void kcfx_ctx_destroy(kcfx_ctx* ctx) { delete ctx; }
 int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int32_t n_samples, int32_t kmer_length,
                             const uint8_t* text, int64_t text_len, const int64_t* win_begin, const int32_t* win_len,
                             int32_t n_windows, int32_t min_kmer_count, int32_t shard_mode, kcfx_result* out,
-                            kcfx_shard_stats* stats) {
+                            kcfx_shard_stats* stats) try {
     if (!ctx || n_samples < 0 || n_windows < 0 || text_len < 0 || (n_samples > 0 && !kmc_prefixes) ||
         (n_windows > 0 && (!win_begin || !win_len)) || (text_len > 0 && !text) ||
         ((int64_t)n_samples * n_windows > 0 && !out))
@@ -124,7 +124,8 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
         }
     }
 
-    auto run = [&](Worker& wk) {
+    // (a worker never lets an exception escape its thread: it becomes the worker's status)
+    auto run_body = [&](Worker& wk) {
         const int32_t nw = wk.w_hi - wk.w_lo;
         if (wk.samples.empty() || nw <= 0) return;
         auto failed = [&](int32_t rc) {
@@ -141,11 +142,15 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
         std::vector<int64_t> wb((size_t)nw);
         for (int32_t i = 0; i < nw; ++i) wb[(size_t)i] = win_begin[wk.w_lo + i] - t_lo;
         double t = now_s();
-        kcfx_ref* ref = nullptr;
-        if (int32_t rc = kcfx_ref_create(wk.device, kmer_length, text + t_lo, t_hi - t_lo, wb.data(), win_len + wk.w_lo, nw, &ref)) {
+        struct RefHold {                                 // destroyed on every exit path
+            kcfx_ref* p = nullptr;
+            ~RefHold() { kcfx_ref_destroy(p); }
+        } ref_hold;
+        if (int32_t rc = kcfx_ref_create(wk.device, kmer_length, text + t_lo, t_hi - t_lo, wb.data(), win_len + wk.w_lo, nw, &ref_hold.p)) {
             failed(rc);
             return;
         }
+        kcfx_ref* const ref = ref_hold.p;
         wk.t_ref = now_s() - t;
 
         // loader thread: opens the databases in order, at most one ahead of the one being screened
@@ -157,6 +162,7 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
         int32_t load_rc = KCFX_OK;
         std::string load_error;
         std::thread loader([&]() {
+            try {
             for (size_t i = 0; i < wk.samples.size(); ++i) {
                 {
                     std::unique_lock<std::mutex> lk(mu);
@@ -186,10 +192,33 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
                 ready.push_back(db);
                 cv.notify_all();
             }
+            } catch (...) {
+                const int32_t rc = kcfx::exception_to_status("kcfx_screen_sharded (loader)");
+                std::lock_guard<std::mutex> lk(mu);
+                load_rc = rc;
+                try { load_error = kcfx_last_error(); } catch (...) {}
+            }
             std::lock_guard<std::mutex> lk(mu);
             loader_done = true;
             cv.notify_all();
         });
+        // on every way out of this scope (normal, error, exception): stop the loader, join it, close what it had ready
+        struct Joiner {
+            std::thread& t;
+            std::mutex& mu;
+            std::condition_variable& cv;
+            bool& stop;
+            std::deque<kcfx_db*>& ready;
+            ~Joiner() {
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    stop = true;
+                    cv.notify_all();
+                }
+                if (t.joinable()) t.join();
+                for (kcfx_db* db : ready) kcfx_db_close(db);
+            }
+        } joiner{loader, mu, cv, stop, ready};
         for (size_t i = 0; i < wk.samples.size() && wk.rc == KCFX_OK; ++i) {
             kcfx_db* db = nullptr;
             {
@@ -224,21 +253,27 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
                 cv.notify_all();
             }
         }
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            stop = true;
-            cv.notify_all();
+    };
+    auto run = [&](Worker& wk) {
+        try {
+            run_body(wk);
+        } catch (...) {
+            wk.rc = kcfx::exception_to_status("kcfx_screen_sharded (worker)");
+            try { wk.error = kcfx_last_error(); } catch (...) {}
         }
-        loader.join();
-        for (kcfx_db* db : ready) kcfx_db_close(db);
-        kcfx_ref_destroy(ref);
     };
 
     if (G == 1) {
         run(workers[0]);
     } else {
         std::vector<std::thread> th;
-        for (int32_t g = 0; g < G; ++g) th.emplace_back(run, std::ref(workers[(size_t)g]));
+        th.reserve((size_t)G);
+        try {
+            for (int32_t g = 0; g < G; ++g) th.emplace_back(run, std::ref(workers[(size_t)g]));
+        } catch (...) {                                  // a thread could not be started: its share is not screened
+            workers[th.size()].rc = kcfx::exception_to_status("kcfx_screen_sharded (thread start)");
+            workers[th.size()].error = "could not start a worker thread";
+        }
         for (auto& x : th) x.join();
     }
     if (stats) {
@@ -253,6 +288,6 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
     for (const Worker& wk : workers)
         if (wk.rc != KCFX_OK) return fail(wk.rc, "device " + std::to_string(wk.device) + ": " + wk.error);
     return KCFX_OK;
-}
+} catch (...) { return kcfx::exception_to_status("kcfx_screen_sharded"); }
 
 }  // extern "C"
