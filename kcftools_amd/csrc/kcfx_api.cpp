@@ -383,6 +383,7 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys) {
     db->info.table_format = FORMAT_CELLS;
     hipError_t e = hipErrorOutOfMemory;
     for (int32_t L = cells_lbits(n_keys, db->info.kmer_length); L >= CELL_LBITS_MIN; --L) {
+        if ((double)n_keys > 16.0 * (double)(1ull << L)) break;     // fewer cells than k-mers: not a cell table any more
         e = hipMalloc(&db->d_lines, (size_t)LINE_BYTES << L);
         if (e == hipErrorOutOfMemory) {                     // denser tables before giving up
             (void)hipGetLastError();
@@ -405,7 +406,10 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys) {
     return KCFX_OK;
 }
 
-// between the two build passes of a FORMAT_CELLS table: read how many k-mers lost their cell, size and clear the stash
+// between the two build passes of a FORMAT_CELLS table: read how many k-mers lost their cell, size and clear the stash.
+// Open addressing with linear probing (stash_find): load <= 0.25 (~1.2 entries looked at per lookup) while that fits in
+// half of the free device memory (KCFX_STASH_BUDGET=<bytes> overrides the budget), else denser, down to load 0.8; a stash
+// that does not fit even then fails with KCFX_ERR_DEVICE and the caller rebuilds the database as a 12-slot line table.
 int32_t cells_stash_alloc(kcfx_db* db) {
     unsigned long long h[4] = {0, 0, 0, 0};
     KCFX_HIP(hipMemcpyAsync(h, db->d_stats, sizeof h, hipMemcpyDeviceToHost, db->stream));
@@ -414,9 +418,16 @@ int32_t cells_stash_alloc(kcfx_db* db) {
     db->info.stored_kmers = (int64_t)h[1];
     db->info.multi_cell_kmers = (int64_t)h[2];
     db->info.second_choice_kmers = (int64_t)h[3];
-    uint64_t slots = 1024;                                  // load <= 0.25: ~1.2 entries looked at per lookup
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)256 << 30;
+    double budget = 0.5 * (double)free_b;
+    if (const char* s = getenv("KCFX_STASH_BUDGET")) budget = std::max(0.0, atof(s));
+    uint64_t slots = 1024;
     while (slots < 4 * h[0]) slots <<= 1;
-    if (slots > (1ull << 32)) return fail(KCFX_ERR_ARG, "stash too large for a 32-bit slot index");
+    while (slots > 1024 && (double)slots * sizeof(uint4) > budget && (double)(slots >> 1) * 0.8 >= (double)h[0]) slots >>= 1;
+    if ((double)slots * sizeof(uint4) > budget && slots > 1024)
+        return fail(KCFX_ERR_DEVICE, "the stash of the cell table (" + std::to_string(h[0]) + " k-mers) does not fit the device memory budget");
+    if (slots > (1ull << 32)) return fail(KCFX_ERR_DEVICE, "stash too large for a 32-bit slot index");
     db->stash_mask = (uint32_t)(slots - 1);
     KCFX_HIP(hipMalloc(&db->d_stash, (size_t)slots * sizeof(uint4)));
     KCFX_HIP(hipMemsetAsync(db->d_stash, 0xFF, (size_t)slots * sizeof(uint4), db->stream));
@@ -425,9 +436,30 @@ int32_t cells_stash_alloc(kcfx_db* db) {
     return KCFX_OK;
 }
 
-int32_t table_alloc(kcfx_db* db, int64_t n_keys, int32_t counter_size) {
+// back to "no table" (the handle keeps its stream and header fields): before a rebuild in the other format
+void table_release(kcfx_db* db) {
+    (void)hipStreamSynchronize(db->stream);
+    if (db->d_lines) (void)hipFree(db->d_lines);
+    if (db->d_stash) (void)hipFree(db->d_stash);
+    if (db->d_stats) (void)hipFree(db->d_stats);
+    if (db->d_pop) (void)hipFree(db->d_pop);
+    db->d_lines = nullptr;
+    db->d_stash = nullptr;
+    db->d_stats = nullptr;
+    db->d_pop = nullptr;
+    db->fmt = FORMAT_LINES;
+    db->lbits = 0;
+    db->stash_mask = 0;
+    db->n_lines = 0;
+    db->info.table_format = FORMAT_LINES;
+    db->info.table_bytes = db->info.stash_bytes = 0;
+    db->info.stash_kmers = db->info.stored_kmers = db->info.multi_cell_kmers = db->info.second_choice_kmers = 0;
+    (void)hipGetLastError();
+}
+
+int32_t table_alloc(kcfx_db* db, int64_t n_keys, int32_t counter_size, bool allow_cells = true) {
     db->generic = getenv("KCFX_GENERIC_KERNEL") != nullptr;   // A/B and test hook: read when the handle is made, never per launch
-    if (cells_eligible(db, counter_size) && !db->generic) return cells_alloc(db, n_keys);
+    if (allow_cells && cells_eligible(db, counter_size) && !db->generic) return cells_alloc(db, n_keys);
     db->wide = counter_size > 2 ? 1 : 0;
     db->mode = table_mode();
     db->mm_len = minimizer_len(db->info.kmer_length, n_keys);
@@ -746,6 +778,16 @@ int32_t kcfx_db_open(const char* kmc_prefix, int32_t device, kcfx_db** out) try 
     if (tr.on) (void)hipStreamSynchronize(db->stream);
     tr.mark("table alloc + clear");
     if (!rc) rc = load_suffix_file(db, std::string(kmc_prefix) + ".kmc_suf", h);
+    if (rc == KCFX_ERR_DEVICE && db->fmt == FORMAT_CELLS) {
+        // the cell table or its stash did not fit (a database of many billions of k-mers next to another resident one):
+        // the 12-slot line table stores a k-mer in 11-30 bytes instead of 100+, at ~0.55x the screening speed
+        const std::string why = g_error;
+        table_release(db);
+        fprintf(stderr, "kcfx: %s: cell table not built (%s); building a line table instead\n", kmc_prefix, why.c_str());
+        rc = table_alloc(db, h.total, h.counter_size, false);
+        if (!rc) rc = load_suffix_file(db, std::string(kmc_prefix) + ".kmc_suf", h);
+        tr.mark("rebuilt as a line table");
+    }
     if (!rc) rc = table_finish(db);
     tr.mark("finalize");
     if (rc) return rc;
@@ -785,9 +827,8 @@ int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, 
     uint32_t*& d_counts = scratch.counts;
     int32_t rc = KCFX_OK;
     hipError_t e = db_stream(device, &db->stream);
-    if (e != hipSuccess) rc = hip_fail(e, "hipStreamCreate");
-    if (!rc) rc = table_alloc(db, n, counter_size);
-    if (!rc && n > 0) {
+    if (e != hipSuccess) return hip_fail(e, "hipStreamCreate");
+    if (n > 0) {
         // the stored counter is counter_size bytes wide (KMC.java:395-401)
         std::vector<uint32_t> masked;
         const uint32_t* src = counts;
@@ -799,25 +840,36 @@ int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, 
         }
         if ((e = hipMalloc(&d_keys, (size_t)n * 8)) != hipSuccess || (e = hipMalloc(&d_counts, (size_t)n * 4)) != hipSuccess ||
             (e = hipMemcpyAsync(d_keys, kmers, (size_t)n * 8, hipMemcpyHostToDevice, db->stream)) != hipSuccess ||
-            (e = hipMemcpyAsync(d_counts, src, (size_t)n * 4, hipMemcpyHostToDevice, db->stream)) != hipSuccess)
-            rc = hip_fail(e, "kcfx_db_build upload");
-        if (!rc && db->fmt == FORMAT_CELLS) {
+            (e = hipMemcpyAsync(d_counts, src, (size_t)n * 4, hipMemcpyHostToDevice, db->stream)) != hipSuccess ||
+            (e = hipStreamSynchronize(db->stream)) != hipSuccess)            // (`masked` goes out of scope below)
+            return hip_fail(e, "kcfx_db_build upload");
+    }
+    auto build = [&](bool allow_cells) -> int32_t {
+        int32_t rc = table_alloc(db, n, counter_size, allow_cells);
+        if (rc || n == 0) return rc;
+        if (db->fmt == FORMAT_CELLS) {
             if ((e = launch_cells_count(db->d_pop, kmer_length, db->lbits, d_keys, d_counts, n, db->stream)) != hipSuccess ||
                 (e = launch_cells_insert(db->d_lines, db->d_pop, 1, kmer_length, db->lbits, d_keys, d_counts, n, db->stream)) != hipSuccess ||
                 (e = launch_cells_insert(db->d_lines, db->d_pop, 0, kmer_length, db->lbits, d_keys, d_counts, n, db->stream)) != hipSuccess ||
                 (e = launch_cells_settle(db->d_lines, kmer_length, db->lbits, d_keys, d_counts, n, db->d_stats, db->stream)) != hipSuccess)
-                rc = hip_fail(e, "kcfx_db_build insert");
-            if (!rc) rc = cells_stash_alloc(db);
-            if (!rc && ((e = launch_cells_stash(db->d_lines, db->info.kmer_length, db->lbits, d_keys, d_counts, n, db->d_stash, db->stash_mask, db->stream)) != hipSuccess ||
-                        (e = hipStreamSynchronize(db->stream)) != hipSuccess))
-                rc = hip_fail(e, "kcfx_db_build stash");
-        } else if (!rc) {
+                return hip_fail(e, "kcfx_db_build insert");
+            if ((rc = cells_stash_alloc(db))) return rc;
+            if ((e = launch_cells_stash(db->d_lines, db->info.kmer_length, db->lbits, d_keys, d_counts, n, db->d_stash, db->stash_mask, db->stream)) != hipSuccess ||
+                (e = hipStreamSynchronize(db->stream)) != hipSuccess)
+                return hip_fail(e, "kcfx_db_build stash");
+        } else {
             if ((e = launch_table_count(db->d_lines, db->view(), kmer_length, d_keys, n, db->stream)) != hipSuccess ||
                 (db->mode == MODE_MINIMIZER && (e = launch_table_mark_heavy(db->d_lines, db->n_lines, db->stream)) != hipSuccess) ||
                 (e = launch_table_insert(db->d_lines, db->view(), kmer_length, d_keys, d_counts, n, db->stream)) != hipSuccess ||
                 (e = hipStreamSynchronize(db->stream)) != hipSuccess)
-                rc = hip_fail(e, "kcfx_db_build insert");
+                return hip_fail(e, "kcfx_db_build insert");
         }
+        return KCFX_OK;
+    };
+    rc = build(true);
+    if (rc == KCFX_ERR_DEVICE && db->fmt == FORMAT_CELLS) {      // as in kcfx_db_open: the line table needs far less memory
+        table_release(db);
+        rc = build(false);
     }
     if (!rc && n == 0 && db->fmt == FORMAT_CELLS) rc = cells_stash_alloc(db);
     if (!rc) rc = table_finish(db);

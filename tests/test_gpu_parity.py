@@ -225,6 +225,39 @@ def test_config1_scale(oracle, tmp_path):
     assert 0.5 < got["obs"].sum() / got["total_kmers"].sum() < 0.95     # realistic hit rate
 
 
+def test_stash_budget_and_line_table_fallback(oracle, tmp_path, monkeypatch, capfd):
+    """A cell table whose stash does not fit its memory budget: first a denser stash (open addressing, load up to 0.8), and
+    when even that does not fit the database is rebuilt as a 12-slot line table (the path a many-billion-k-mer database
+    takes next to another resident one). Forced here with a tiny table (2^17 lines for 1.1 M k-mers: a third of them lose
+    their cell) and KCFX_STASH_BUDGET; results must not change. Both the file loader and the array build."""
+    k = 31
+    ref = synth.random_reference(1_000_000, 5)
+    prefix, kmers, counts, prm = make_db(tmp_path, "stash", ref, 6, k=31, p=7, cs=2, m=9, bins=64, noise=100_000)
+    s, e = engine.windows(len(ref), 10_000, 0, k)
+    want = oracle.OracleDb(prefix).screen(ref, s, e - s, 1, threads=8)
+    monkeypatch.setenv("KCFX_TABLE_LBITS", "17")
+    roomy = engine.KmcDb.open(prefix)
+    n_stash = roomy.info.stash_kmers
+    assert roomy.info.table_format == 1 and n_stash > 50_000
+    assert roomy.info.stash_bytes >= 4 * 16 * n_stash                      # load <= 0.25
+    assert_same(roomy.screen(ref, s, e - s, 1), want, "roomy stash")
+    # a budget between load 0.8 and load 0.25: a denser stash, still a cell table
+    monkeypatch.setenv("KCFX_STASH_BUDGET", str(roomy.info.stash_bytes // 2))
+    for db in (engine.KmcDb.open(prefix), engine.KmcDb.build(kmers, counts, k, 2, True)):
+        assert db.info.table_format == 1 and db.info.stash_kmers == n_stash
+        assert 16 * n_stash / 0.8 <= db.info.stash_bytes <= roomy.info.stash_bytes // 2
+        assert_same(db.screen(ref, s, e - s, 1), want, "dense stash")
+    # no budget at all: the line table takes over, with a note on stderr
+    monkeypatch.setenv("KCFX_STASH_BUDGET", "1000")
+    capfd.readouterr()
+    for db in (engine.KmcDb.open(prefix), engine.KmcDb.build(kmers, counts, k, 2, True)):
+        assert db.info.table_format == 0 and db.info.stash_kmers == 0 and db.info.table_lines > 0
+        assert_same(db.screen(ref, s, e - s, 1), want, "line-table fallback")
+        got = db.lookup(kmers[:5000])
+        assert np.array_equal(got, np.minimum(counts[:5000], 65535).astype(np.int32))
+    assert "building a line table instead" in capfd.readouterr().err
+
+
 def test_async_device_output_on_torch_stream(oracle, tmp_path):
     import torch
     k = 31
