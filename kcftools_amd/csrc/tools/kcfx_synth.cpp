@@ -66,6 +66,7 @@ struct Opts {
     int64_t ref_len = 1000000;
     uint64_t seed = 1, sample_seed = 2;
     int64_t noise = 0;
+    int64_t error_events = 0;              // --error-events: read-error model, see below
     int k = 31, p = 7, cs = 2, sig_len = 9, n_bins = 512, threads = 0;
     double sub_rate = 1e-2, indel_rate = 1e-3;
     std::string out;
@@ -83,6 +84,7 @@ int main(int argc, char** argv) {
         else if (a == "--seed") o.seed = strtoull(val(), nullptr, 10);
         else if (a == "--sample-seed") o.sample_seed = strtoull(val(), nullptr, 10);
         else if (a == "--noise") o.noise = atoll(val());
+        else if (a == "--error-events") o.error_events = atoll(val());
         else if (a == "--k") o.k = atoi(val());
         else if (a == "--p") o.p = atoi(val());
         else if (a == "--cs") o.cs = atoi(val());
@@ -106,8 +108,9 @@ int main(int argc, char** argv) {
         }
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
+    if (o.error_events > 0 && o.k > 31) { fprintf(stderr, "--error-events needs k <= 31\n"); return 2; }
     if (o.out.empty() || o.k < 9 || o.k > 32 || (o.k - o.p) % 4 != 0 || o.cs < 1 || o.cs > 4 || o.sig_len > o.k) {
-        fprintf(stderr, "usage: kcfx_synth --out PREFIX [--ref-len N --seed S --sample-seed S --noise N --k 31 --p 7 --cs 2 --bins 512 --threads T --fasta]\n");
+        fprintf(stderr, "usage: kcfx_synth --out PREFIX [--ref-len N --seed S --sample-seed S --noise N --error-events N --k 31 --p 7 --cs 2 --bins 512 --threads T --fasta]\n");
         return 2;
     }
     if (o.threads <= 0) o.threads = (int)std::max(1u, std::thread::hardware_concurrency());
@@ -237,6 +240,38 @@ int main(int argc, char** argv) {
             }
         });
     }
+    // --error-events E: what a k-mer count of sequencing reads (kmc -ci1) contains beside the genome -- E substitution
+    // errors at random sample positions, each contributing the (up to k) k-mers that cover the wrong base. They come in
+    // runs that share minimizers with their genomic neighbours and are seen once (counter 1), while genomic k-mers are seen
+    // "depth" times. Marked by bit 0 of the word (free for k <= 31) until the counts are assigned.
+    if (o.error_events > 0) {
+        const uint64_t s5 = mix64(o.sample_seed * 131 + 0xE44);
+        std::vector<std::vector<uint64_t>> part((size_t)T);
+        parallel_for(o.error_events, T, [&](int64_t lo, int64_t hi, int t) {
+            std::vector<uint64_t>& out = part[(size_t)t];
+            auto code_of = [](uint8_t c) -> int { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; };
+            for (int64_t e = lo; e < hi; ++e) {
+                const uint64_t h = mix64(s5 + (uint64_t)e);
+                const int64_t x = (int64_t)(h % smp.size());
+                const int orig = code_of(smp[(size_t)x]);
+                if (orig < 0) continue;
+                const int wrong = (orig + 1 + (int)((h >> 40) % 3)) & 3;
+                for (int64_t st = std::max<int64_t>(0, x - k + 1); st <= x && st + k <= (int64_t)smp.size(); ++st) {
+                    uint64_t fw = 0, rc = 0;
+                    bool ok = true;
+                    for (int j = 0; j < k; ++j) {
+                        const int c = (st + j == x) ? wrong : code_of(smp[(size_t)(st + j)]);
+                        if (c < 0) { ok = false; break; }
+                        fw = (fw << 2) | (uint64_t)c;
+                        rc |= (uint64_t)(3 - c) << (2 * j);
+                    }
+                    if (ok) out.push_back((std::min(fw, rc) << shift) | 1ull);
+                }
+            }
+        });
+        for (auto& v : part) km.insert(km.end(), v.begin(), v.end());
+    }
+    const size_t n_error_kmers = km.size() - n_sample_kmers - (size_t)o.noise;
     const double t_km = now_s();
 
     // ---- sort + unique + counts (256 top-byte buckets, sorted in parallel) -------------------------------
@@ -266,9 +301,12 @@ int main(int argc, char** argv) {
                     std::sort(lo, hi);
                     size_t w = boff[b];
                     for (uint64_t* p = lo; p < hi;) {
+                        // (an error k-mer that equals a genomic one sorts right behind it: one group, genomic)
+                        const uint64_t word = *p & ~1ull;
+                        const bool only_errors = (*p & 1ull) != 0;
                         uint64_t* q = p;
-                        while (q < hi && *q == *p) ++q;
-                        sorted[w] = *p;
+                        while (q < hi && (*q & ~1ull) == word) ++q;
+                        sorted[w] = word | (only_errors ? 1ull : 0ull);
                         occ[w] = (uint32_t)(q - p);
                         ++w;
                         p = q;
@@ -295,11 +333,13 @@ int main(int argc, char** argv) {
     parallel_for(256, T, [&](int64_t lo, int64_t hi, int) {
         for (int64_t b = lo; b < hi; ++b) {
             for (size_t j = 0; j < ucount[b]; ++j) {
-                const uint64_t w = sorted[boff[b] + j];
+                const bool only_errors = (sorted[boff[b] + j] & 1ull) != 0 && o.error_events > 0;
+                const uint64_t w = o.error_events > 0 ? (sorted[boff[b] + j] & ~1ull) : sorted[boff[b] + j];
                 const size_t d = uoff[b] + j;
                 uk[d] = w;
                 const uint64_t h = mix64(w ^ 0xC0FFEEull);
-                uint64_t c = (uint64_t)occ[boff[b] + j] * (1 + h % 30);     // depth-like spread for -c and KD
+                // depth-like spread for -c and KD; a k-mer that only read errors produced is seen as often as they occurred
+                uint64_t c = only_errors ? (uint64_t)occ[boff[b] + j] : (uint64_t)occ[boff[b] + j] * (1 + h % 30);
                 uc[d] = (uint32_t)std::min<uint64_t>(c, cmax);
                 uint32_t best = 1u << (2 * m);
                 for (int i = 0; i + m <= k; ++i) {
@@ -372,10 +412,10 @@ int main(int argc, char** argv) {
         fclose(f);
     }
     const double t_end = now_s();
-    printf("{\"ref_len\": %lld, \"sample_len\": %zu, \"sample_kmers\": %zu, \"noise_kmers\": %lld, \"db_kmers\": %zu, "
+    printf("{\"ref_len\": %lld, \"sample_len\": %zu, \"sample_kmers\": %zu, \"noise_kmers\": %lld, \"error_kmers\": %zu, \"db_kmers\": %zu, "
            "\"k\": %d, \"p\": %d, \"counter_size\": %d, \"n_bins\": %d, \"seed\": %llu, \"sample_seed\": %llu, \"threads\": %d, "
            "\"seconds\": {\"ref\": %.2f, \"sample\": %.2f, \"kmers\": %.2f, \"sort\": %.2f, \"bins\": %.2f, \"write\": %.2f, \"total\": %.2f}}\n",
-           (long long)L, smp.size(), n_sample_kmers, (long long)o.noise, N, k, o.p, o.cs, o.n_bins,
+           (long long)L, smp.size(), n_sample_kmers, (long long)o.noise, n_error_kmers, N, k, o.p, o.cs, o.n_bins,
            (unsigned long long)o.seed, (unsigned long long)o.sample_seed, T, t_ref - t0, t_smp - t_ref, t_km - t_smp,
            t_sort - t_km, t_bin - t_sort, t_end - t_bin, t_end - t0);
     return 0;
