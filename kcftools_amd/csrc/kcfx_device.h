@@ -213,6 +213,24 @@ KCFX_HD uint32_t cell_g32(uint32_t cm) {
 constexpr uint32_t CELL_R_ALT = 0x8000u;
 KCFX_HD uint32_t cell_alt_sh(uint32_t sh, uint32_t w) { return sh ^ (((w >> 27) & 0x1Cu) | 2u); }
 
+// The r field of a cell: bits 0 .. 31 - lbits carry the rest of G32, bit 15 the second-choice mark; the lbits - 17 bits in
+// between would be zero. In a cell that is flagged "someone who belongs here lives in the stash" they say WHO: every
+// stashed k-mer sets the bit its flank selects (a one-hash Bloom filter per cell). A query that finds its cell taken by
+// another k-mer goes to the stash only if its own bit is set -- in a k-mer count of sequencing reads nearly every genomic
+// cell is flagged (the error neighbours of the genomic k-mer want the same cell and lose to its larger counter), and
+// every absent reference k-mer would otherwise cost a stash look-up.
+KCFX_HD uint32_t cell_rmask(int32_t lbits) { return (0xFFFFFFFFu >> lbits) | CELL_R_ALT; }       // the bits of r that identify
+KCFX_HD uint32_t cell_spare_bits(int32_t lbits) { return (uint32_t)(lbits - 17); }
+// bit position inside r of the filter bit of a k-mer with flank w (meaningful only when cell_spare_bits(lbits) > 0)
+KCFX_HD uint32_t cell_filter_pos(uint32_t w, int32_t lbits) {
+    const uint32_t h = (w >> 2) * 0x9E3779B1u;                  // single-base neighbours must spread: multiplicative hash
+    return (uint32_t)(32 - lbits) + (uint32_t)(((uint64_t)h * cell_spare_bits(lbits)) >> 32);
+}
+// the bits of a 64-bit cell word that identify the k-mer and carry its counter (flags and filter bits excluded)
+KCFX_HD uint64_t cell_keycount_mask(int32_t lbits) {
+    return 0xFFFF0000FFFFFFFCull | ((uint64_t)cell_rmask(lbits) << 32);
+}
+
 // Cell tables exist for k = 27 .. 31: the minimizer length is M = k - 15, so that a k-mer always spans 16 M-mers (one DPP
 // row, 16 cells per line) and its flank is always 15 bases = 30 bits. M-mers are kept left-aligned in 32 bits.
 KCFX_HD constexpr int cell_mlen(int k) { return k - 15; }

@@ -56,7 +56,9 @@ constexpr int MODE_KEYHASH = 0, MODE_MINIMIZER = 1;
 //             to this cell lives in the stash | bit 1: the occupant is of the "crowded" class (build time only)
 //     r     = low (32 - lbits) bits of G32 = a 32-bit mix of the canonical minimizer 16-mer; the line number is the top
 //             lbits of G32, and G32 <-> minimizer is a bijection (cell_g32)
-//             (at most 15 bits: lbits >= 17) | bit 15: this k-mer sits in its SECOND-choice cell
+//             (at most 15 bits: lbits >= 17) | bit 15: this k-mer sits in its SECOND-choice cell | the lbits - 17 bits in
+//             between: in a cell flagged for the stash, a one-hash Bloom filter of the flanks of the k-mers that went
+//             there (cell_filter_pos) -- a query that misses in a flagged cell looks into the stash only if its bit is set
 //     count = the stored counter; 0 = empty cell (a k-mer whose counter is 0 can never be observed -- GetVariants.java:224
 //             needs count >= -c >= 1 -- so it is not stored)
 //   (line, cell, w, r) -> N -> canonical k-mer is injective, so equality of (w, r) in the k-mer's cell IS equality of

@@ -253,18 +253,19 @@ __global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__
 }
 
 // where a k-mer stands after the bidding: in its first-choice cell, in its second-choice cell, or in neither
-__device__ __forceinline__ int cell_standing(const uint8_t* lines, const CellProbe& p, uint32_t c) {
+__device__ __forceinline__ int cell_standing(const uint8_t* lines, const CellProbe& p, uint32_t c, int32_t lbits) {
+    const uint64_t kc = cell_keycount_mask(lbits);              // (flags and stash-filter bits are not part of the k-mer)
     const uint8_t* line = lines + (size_t)p.line * LINE_BYTES;
     const uint64_t first = __atomic_load_n(reinterpret_cast<const uint64_t*>(line + 4 * p.sh), __ATOMIC_RELAXED);
-    if ((first & ~(uint64_t)CELL_FLAG_MASK) == cell_word(p.w, p.r, c)) return 0;
+    if ((first & kc) == cell_word(p.w, p.r, c)) return 0;
     const uint64_t second = __atomic_load_n(reinterpret_cast<const uint64_t*>(line + 4 * cell_alt_sh(p.sh, p.w)), __ATOMIC_RELAXED);
-    if ((second & ~(uint64_t)CELL_FLAG_MASK) == cell_word(p.w, p.r | CELL_R_ALT, c)) return 1;
+    if ((second & kc) == cell_word(p.w, p.r | CELL_R_ALT, c)) return 1;
     return 2;
 }
 
 // Pass 2 (after pass 1 has completed): a k-mer that lost a bid takes its second-choice cell if that is still empty (no
 // k-mer has it as first choice then), else it flags its first-choice cell -- "someone who belongs here lives in the
-// stash" -- and is counted. stats[0] = k-mers for the stash, [1] = k-mers stored (count != 0), [2] = k-mers with more
+// stash", and which filter bit that someone has (cell_filter_pos) -- and is counted. stats[0] = k-mers for the stash, [1] = k-mers stored (count != 0), [2] = k-mers with more
 // than one first-choice cell, [3] = second-choice placements
 __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, const uint64_t* __restrict__ keys,
                                     const uint32_t* __restrict__ counts, int64_t n, unsigned long long* stats) {
@@ -277,15 +278,16 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, co
         CellProbe cand[CELL_MAX_CANDS];
         const int nc = cells_of_key(keys[i], k, lbits, cand);
         bool lost = false;
+        const uint64_t kc = cell_keycount_mask(lbits);
         for (int a = 0; a < nc; ++a) {
-            if (cell_standing(lines, cand[a], c) != 2) continue;     // (1: the same word twice in the input)
+            if (cell_standing(lines, cand[a], c, lbits) != 2) continue;     // (1: the same word twice in the input)
             uint8_t* line = lines + (size_t)cand[a].line * LINE_BYTES;
             unsigned long long* alt = reinterpret_cast<unsigned long long*>(line + 4 * cell_alt_sh(cand[a].sh, cand[a].w));
             const unsigned long long mine = cell_word(cand[a].w, cand[a].r | CELL_R_ALT, c);
             unsigned long long old = __atomic_load_n(alt, __ATOMIC_RELAXED);
             bool won = false;
             while ((old >> 48) == 0) {
-                const unsigned long long prev = atomicCAS(alt, old, mine | (old & CELL_FLAG_MASK));
+                const unsigned long long prev = atomicCAS(alt, old, mine | (old & ~kc));
                 if (prev == old) {
                     won = true;
                     break;
@@ -294,8 +296,10 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, co
             }
             if (won) {
                 ++n_second;
-            } else if ((old & ~(unsigned long long)CELL_FLAG_MASK) != mine) {
-                atomicOr(reinterpret_cast<uint32_t*>(line + 4 * cand[a].sh), CELL_FLAG_STASH);
+            } else if ((old & kc) != mine) {
+                unsigned long long mark = CELL_FLAG_STASH;
+                if (cell_spare_bits(lbits) > 0) mark |= 1ull << (32 + cell_filter_pos(cand[a].w, lbits));
+                atomicOr(reinterpret_cast<unsigned long long*>(line + 4 * cand[a].sh), mark);
                 lost = true;
             }
         }
@@ -325,7 +329,7 @@ __global__ void cells_stash_kernel(const uint8_t* __restrict__ lines, int32_t k,
         CellProbe cand[CELL_MAX_CANDS];
         const int nc = cells_of_key(key, k, lbits, cand);
         bool lost = false;
-        for (int a = 0; a < nc; ++a) lost |= cell_standing(lines, cand[a], c) == 2;
+        for (int a = 0; a < nc; ++a) lost |= cell_standing(lines, cand[a], c, lbits) == 2;
         if (!lost) continue;
         uint32_t slot = stash_slot(key, mask);
         for (;;) {
@@ -368,12 +372,13 @@ __global__ __launch_bounds__(256) void lookup_cells_kernel(TableView tv, int32_t
             const uint8_t* line = tv.lines + (size_t)cand[0].line * LINE_BYTES;
             const uint64_t first = *reinterpret_cast<const uint64_t*>(line + 4 * cand[0].sh);
             const uint64_t second = *reinterpret_cast<const uint64_t*>(line + 4 * cell_alt_sh(cand[0].sh, cand[0].w));
-            constexpr uint64_t KEY_BITS = 0x0000FFFFFFFFFFFCull;                // w without the flags, r
+            const uint64_t KEY_BITS = cell_keycount_mask(tv.lbits) & 0x0000FFFFFFFFFFFFull;     // w without the flags, r without the filter
             if (((first ^ cell_word(cand[0].w, cand[0].r, 0)) & KEY_BITS) == 0)
                 result = (int32_t)(first >> 48);
             else if (((second ^ cell_word(cand[0].w, cand[0].r | CELL_R_ALT, 0)) & KEY_BITS) == 0)
                 result = (int32_t)(second >> 48);
-            else if (first & CELL_FLAG_STASH)
+            else if ((first & CELL_FLAG_STASH) &&
+                     (cell_spare_bits(tv.lbits) == 0 || ((first >> (32 + cell_filter_pos(cand[0].w, tv.lbits))) & 1)))
                 result = (int32_t)stash_find(tv, key);
         }
         out[i] = result;
@@ -999,14 +1004,18 @@ __device__ __forceinline__ void cells_issue(const TableView& tv, uint64_t V, con
 
 // stage B: cnt = the stored counter if the cell holds this lane's k-mer (else 0), pend != 0 if it does not and the cell is
 // flagged for the stash
-__device__ __forceinline__ void cells_match(const CellWord& cw, uint32_t& cnt, uint32_t& pend) {
+__device__ __forceinline__ void cells_match(const CellWord& cw, int32_t lbits, uint32_t& cnt, uint32_t& pend) {
     const bool valid = __builtin_amdgcn_inverse_ballot_w64(cw.V);
+    const uint32_t rmask = cell_rmask(lbits);                   // (wave-uniform: scalar registers)
+    const bool filtered = cell_spare_bits(lbits) > 0;
     if (valid) {
         const uint32_t x = cw.cell.x, y = cw.cell.y, xa = cw.alt.x, ya = cw.alt.y;
-        const bool first = ((x ^ cw.w) <= CELL_FLAG_MASK) && ((uint16_t)y == (uint16_t)cw.r);
-        const bool second = ((xa ^ cw.w) <= CELL_FLAG_MASK) && ((uint16_t)ya == (uint16_t)(cw.r | CELL_R_ALT));
+        const bool first = ((x ^ cw.w) <= CELL_FLAG_MASK) && ((uint16_t)(y & rmask) == (uint16_t)cw.r);
+        const bool second = ((xa ^ cw.w) <= CELL_FLAG_MASK) && ((uint16_t)(ya & rmask) == (uint16_t)(cw.r | CELL_R_ALT));
         cnt = first ? (y >> 16) : second ? (ya >> 16) : 0u;
-        pend = (first || second) ? 0u : (x & CELL_FLAG_STASH);
+        // the stash only if the cell is flagged AND (when the table has filter bits) the bit of this flank is set
+        const uint32_t mine = filtered ? ((y >> cell_filter_pos(cw.w, lbits)) & 1u) : 1u;
+        pend = (first || second) ? 0u : (x & CELL_FLAG_STASH & mine);
     }
 }
 
@@ -1077,7 +1086,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     // stage B of word w: cells matched, ballots out, stash candidates queued
     auto retire = [&](int w, const CellWord& cw) {
         uint32_t cnt = 0, pend = 0;
-        cells_match(cw, cnt, pend);
+        cells_match(cw, tv.lbits, cnt, pend);
         // cnt is 0 unless the k-mer was found and min_count >= 1 (checked by the API), so this is "found && count >= -c"
         const bool hit = (int32_t)cnt >= min_count;                         // GetVariants.java:224
         const uint64_t H = wave_ballot(hit);
