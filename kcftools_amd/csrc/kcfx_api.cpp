@@ -383,7 +383,8 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys) {
     db->info.table_format = FORMAT_CELLS;
     hipError_t e = hipErrorOutOfMemory;
     for (int32_t L = cells_lbits(n_keys, db->info.kmer_length); L >= CELL_LBITS_MIN; --L) {
-        if ((double)n_keys > 16.0 * (double)(1ull << L)) break;     // fewer cells than k-mers: not a cell table any more
+        if ((double)n_keys > 16.0 * (double)(1ull << L))            // fewer cells than k-mers: not a cell table any more
+            return fail(KCFX_ERR_DEVICE, "no cell table of 2^" + std::to_string(L) + " or more lines fits the device memory (or KCFX_TABLE_LBITS)");
         e = hipMalloc(&db->d_lines, (size_t)LINE_BYTES << L);
         if (e == hipErrorOutOfMemory) {                     // denser tables before giving up
             (void)hipGetLastError();

@@ -258,6 +258,40 @@ def test_stash_budget_and_line_table_fallback(oracle, tmp_path, monkeypatch, cap
     assert "building a line table instead" in capfd.readouterr().err
 
 
+@pytest.mark.parametrize("lbits", [17, 18, 21, 25])
+def test_read_error_like_database(oracle, tmp_path, monkeypatch, lbits):
+    """A database shaped like a k-mer count of sequencing reads (kcfx_synth --error-events: runs of count-1 k-mers around
+    substitution errors, five times more of them than genomic k-mers): the error neighbours of a genomic k-mer want its
+    cell, lose to its counter, go to the stash and set their filter bit in the flagged cell. lbits = 17 has no filter bits,
+    18 has one, 25 has eight. Screening (every window) and KMC.getCount of present, stashed and absent k-mers."""
+    import json
+    import subprocess
+    synth_bin = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kcftools_amd", "bin", "kcfx_synth")
+    prefix = str(tmp_path / "reads")
+    meta = json.loads(subprocess.run([synth_bin, "--out", prefix, "--ref-len", "250000", "--seed", "11", "--sample-seed", "12",
+                                      "--error-events", "37000", "--noise", "2000", "--bins", "32"],
+                                     check=True, capture_output=True, text=True).stdout.strip().splitlines()[-1])
+    assert meta["error_kmers"] > 4 * meta["sample_kmers"]
+    ref = open(prefix + ".ref.txt", "rb").read()
+    monkeypatch.setenv("KCFX_TABLE_LBITS", str(lbits))
+    db = engine.KmcDb.open(prefix)
+    assert db.info.table_format == 1 and db.info.table_lines == 1 << lbits
+    assert db.info.stash_kmers > 0.2 * db.info.total_kmers                        # (1.4 M k-mers; 2.1 M cells at lbits 17)
+    odb = oracle.OracleDb(prefix)
+    s, e = engine.windows(len(ref), 5_000, 0, 31)
+    for c in (1, 2):
+        assert_same(db.screen(ref, s, e - s, c), odb.screen(ref, s, e - s, c, threads=8), f"lbits {lbits} -c {c}")
+    km, ct = odb.dump()
+    rng = np.random.default_rng(lbits)
+    pick = rng.choice(len(km), 20_000, replace=False)
+    flipped = km[pick[:5000]] ^ (np.uint64(1) << np.uint64(40))                   # single-base neighbours, mostly absent
+    flipped = np.minimum(flipped, synth.revcomp(flipped, 31))
+    keys = np.concatenate([km[pick], flipped])
+    want = np.array([odb.get_count(int(x)) for x in keys[-5000:]], dtype=np.int32)
+    got = db.lookup(keys)
+    assert np.array_equal(got[:20_000], ct[pick]) and np.array_equal(got[20_000:], want)
+
+
 def test_async_device_output_on_torch_stream(oracle, tmp_path):
     import torch
     k = 31
