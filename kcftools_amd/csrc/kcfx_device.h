@@ -223,8 +223,9 @@ KCFX_HD uint32_t cell_rmask(int32_t lbits) { return (0xFFFFFFFFu >> lbits) | CEL
 KCFX_HD uint32_t cell_spare_bits(int32_t lbits) { return (uint32_t)(lbits - 17); }
 // bit position inside r of the filter bit of a k-mer with flank w (meaningful only when cell_spare_bits(lbits) > 0)
 KCFX_HD uint32_t cell_filter_pos(uint32_t w, int32_t lbits) {
-    const uint32_t h = (w >> 2) * 0x9E3779B1u;                  // single-base neighbours must spread: multiplicative hash
-    return (uint32_t)(32 - lbits) + (uint32_t)(((uint64_t)h * cell_spare_bits(lbits)) >> 32);
+    const uint32_t h = w * 0x9E3779B1u;                         // single-base neighbours must spread: multiplicative hash
+    const uint32_t rb = (uint32_t)(32 - lbits);
+    return rb + (uint32_t)(((uint64_t)h * cell_spare_bits(lbits)) >> 32);
 }
 // the bits of a 64-bit cell word that identify the k-mer and carry its counter (flags and filter bits excluded)
 KCFX_HD uint64_t cell_keycount_mask(int32_t lbits) {

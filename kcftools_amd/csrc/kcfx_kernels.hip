@@ -1008,13 +1008,19 @@ __device__ __forceinline__ void cells_match(const CellWord& cw, int32_t lbits, u
     const bool valid = __builtin_amdgcn_inverse_ballot_w64(cw.V);
     const uint32_t rmask = cell_rmask(lbits);                   // (wave-uniform: scalar registers)
     const bool filtered = cell_spare_bits(lbits) > 0;
+    // (cell_filter_pos with its two wave-uniform terms pinned to scalar registers: one v_add instead of a sub + add pair)
+    uint32_t rb = (uint32_t)(32 - lbits);
+    asm volatile("" : "+s"(rb));
+    const uint32_t nspare = cell_spare_bits(lbits);
     if (valid) {
         const uint32_t x = cw.cell.x, y = cw.cell.y, xa = cw.alt.x, ya = cw.alt.y;
-        const bool first = ((x ^ cw.w) <= CELL_FLAG_MASK) && ((uint16_t)(y & rmask) == (uint16_t)cw.r);
-        const bool second = ((xa ^ cw.w) <= CELL_FLAG_MASK) && ((uint16_t)(ya & rmask) == (uint16_t)(cw.r | CELL_R_ALT));
+        // (cw.r has no bits outside rmask and bit 15 clear; xor + and fuse into one v_bitop3)
+        const bool first = ((x ^ cw.w) <= CELL_FLAG_MASK) && (((y ^ cw.r) & rmask) == 0);
+        const uint32_t r_alt = cw.r ^ CELL_R_ALT;
+        const bool second = ((xa ^ cw.w) <= CELL_FLAG_MASK) && (((ya ^ r_alt) & rmask) == 0);
         cnt = first ? (y >> 16) : second ? (ya >> 16) : 0u;
         // the stash only if the cell is flagged AND (when the table has filter bits) the bit of this flank is set
-        const uint32_t mine = filtered ? ((y >> cell_filter_pos(cw.w, lbits)) & 1u) : 1u;
+        const uint32_t mine = filtered ? ((y >> (rb + __umulhi(cw.w * 0x9E3779B1u, nspare))) & 1u) : 1u;
         pend = (first || second) ? 0u : (x & CELL_FLAG_STASH & mine);
     }
 }
