@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void gather_coop(const uint8_t* __restrict__ b
 
 // the access pattern of screen_k31c: RUN consecutive lanes read one 8-byte cell each (consecutive cells) of the same random
 // 128-byte line, LOADS of them per lane (the second 8 cells further, mod 16), ILP independent words per trip
-template <int RUN, int LOADS, int ILP>
+template <int RUN, int LOADS, int ILP, bool NT = false>
 __global__ __launch_bounds__(256) void gather_runs(const uint8_t* __restrict__ buf, uint32_t n_lines, uint64_t n_acc, uint32_t* out) {
     const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     uint64_t i = tid;                                   // one access = one lane's cell(s)
@@ -74,7 +74,11 @@ __global__ __launch_bounds__(256) void gather_runs(const uint8_t* __restrict__ b
             const uint32_t cell = (uint32_t)(a % RUN + (a / RUN) * 5) & 15u;
             const uint8_t* p = buf + (size_t)line * 128;
 #pragma unroll
-            for (int l = 0; l < LOADS; ++l) v[u][l] = *reinterpret_cast<const uint2*>(p + 8 * ((cell + 8 * l) & 15u));
+            for (int l = 0; l < LOADS; ++l) {
+                const uint64_t* q = reinterpret_cast<const uint64_t*>(p + 8 * ((cell + 8 * l) & 15u));
+                const uint64_t w = NT ? __builtin_nontemporal_load(q) : *q;      // NT: "nt" cache-policy bit on the load
+                v[u][l] = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
+            }
         }
 #pragma unroll
         for (int u = 0; u < ILP; ++u)
@@ -140,6 +144,9 @@ int main(int argc, char** argv) {
     if (argc > 3) {     // "runs": only the screen_k31c pattern; rates are per lane access -- lines/s = accesses/s / RUN
 #define RUNS(R, L, I) timeit("runs of " #R " lanes x8B, " #L " load(s), ILP " #I, (double)n_acc, 8 * L, [&] { \
         hipLaunchKernelGGL((gather_runs<R, L, I>), g, b, 0, 0, buf, (uint32_t)(bytes / 128), n_acc, out); });
+#define RUNS_NT(R, L, I) timeit("runs of " #R " lanes x8B, " #L " load(s), ILP " #I ", non-temporal", (double)n_acc, 8 * L, [&] { \
+        hipLaunchKernelGGL((gather_runs<R, L, I, true>), g, b, 0, 0, buf, (uint32_t)(bytes / 128), n_acc, out); });
+        RUNS_NT(8, 2, 1) RUNS_NT(8, 1, 2)
         RUNS(8, 1, 1) RUNS(8, 2, 1) RUNS(8, 1, 2) RUNS(8, 2, 2) RUNS(8, 2, 4) RUNS(4, 1, 2) RUNS(16, 1, 2) RUNS(1, 1, 1) RUNS(1, 1, 4)
         return 0;
     }
