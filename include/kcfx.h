@@ -144,8 +144,9 @@ int32_t kcfx_screen_ref_async(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count
 /* Several samples, ONE pass over the reference (SURVEY f-4): what the reference does as S getVariations runs followed by
  * `cohort` (run_kcftools.sh:124-140, Plugins/Cohort.java:71-119). out[s * n_windows + w] = sample s (input order),
  * window w; each slice equals kcfx_screen_ref(dbs[s], ...). Databases must live on ref's device and share its k;
- * k = 31 minimizer tables with counters of at most 2 bytes are screened up to 8 at a time by one kernel, the rest one by
- * one (same results either way). */
+ * cell tables (the default for k = 27 .. 31 canonical databases) are screened one launch per sample and reduced together;
+ * 12-slot line tables of k = 31 with counters of at most 2 bytes are screened up to 8 at a time by one kernel (same
+ * results either way). */
 int32_t kcfx_screen_ref_multi(kcfx_db* const* dbs, int32_t n_db, kcfx_ref* ref, int32_t min_kmer_count, kcfx_result* out);
 /* Same, asynchronous on `hip_stream`, results left in device memory (n_db * n_windows records). Databases that the
  * multi-sample kernel takes (12-slot line tables) need scratch of 512 B per tile and sample on the reference: it is allocated

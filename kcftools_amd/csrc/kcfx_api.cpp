@@ -343,13 +343,14 @@ int32_t minimizer_len(int32_t k, int64_t n_keys) {
 int32_t cells_lbits_cap(int32_t k) { return std::min<int32_t>(CELL_LBITS_MAX, 2 * (k - 15) - 2); }
 
 // FORMAT_CELLS (kcfx_internal.h) is what the BASELINE configuration gets: k = 27 .. 31 (31 in BASELINE.json), both strands,
-// counters of at most 2 bytes, minimizer bucketing. KCFX_TABLE_FORMAT=lines keeps the 12-slot line table (A/B and test
+// any counter size, minimizer bucketing. KCFX_TABLE_FORMAT=lines keeps the 12-slot line table (A/B and test
 // hook, read at open time).
 bool cells_eligible(const kcfx_db* db, int32_t counter_size) {
     const char* s = getenv("KCFX_TABLE_FORMAT");
     if (s && !strcmp(s, "lines")) return false;
     const int32_t k = db->info.kmer_length;
-    if (k < CELL_K_MIN || k > CELL_K_MAX || !db->info.both_strands || counter_size > 2 || table_mode() != MODE_MINIMIZER ||
+    // (3- and 4-byte counters too: a counter beyond 65535 does not fit a cell, that k-mer lives in the stash)
+    if (k < CELL_K_MIN || k > CELL_K_MAX || !db->info.both_strands || table_mode() != MODE_MINIMIZER ||
         getenv("KCFX_MM_LEN") != nullptr)
         return false;
     // the minimizer is k - 15 bases: a line number cannot carry more than its 2 (k - 15) bits

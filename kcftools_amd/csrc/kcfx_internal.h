@@ -43,7 +43,7 @@ constexpr uint32_t BUILD_COUNT_MASK = 0x00FFFFFFu, BUILD_HEAVY = 0x80000000u;
 constexpr int MODE_KEYHASH = 0, MODE_MINIMIZER = 1;
 
 // ----------------------------------------------------------------------------------------------------
-// FORMAT_CELLS (k = 27 .. 31, both-strands databases, counters of at most 2 bytes -- BASELINE.json's k = 31 among them):
+// FORMAT_CELLS (k = 27 .. 31, both-strands databases -- BASELINE.json's k = 31 among them):
 // the line a k-mer lives in is still chosen by its minimizer (M = k - 15, so that a k-mer spans exactly 16 M-mers), but INSIDE the line the k-mer has exactly one
 // cell: cell index = offset of the minimizer in the k-mer, read on the strand where the minimizer 16-mer is in
 // canonical form ("N orientation"). The 16 k-mers that can share a minimizer occurrence have 16 distinct offsets, so a
@@ -60,7 +60,9 @@ constexpr int MODE_KEYHASH = 0, MODE_MINIMIZER = 1;
 //             between: in a cell flagged for the stash, a one-hash Bloom filter of the flanks of the k-mers that went
 //             there (cell_filter_pos) -- a query that misses in a flagged cell looks into the stash only if its bit is set
 //     count = the stored counter; 0 = empty cell (a k-mer whose counter is 0 can never be observed -- GetVariants.java:224
-//             needs count >= -c >= 1 -- so it is not stored)
+//             needs count >= -c >= 1 -- so it is not stored). A counter beyond 65535 (3- / 4-byte counters only) does not
+//             fit: that k-mer never takes a cell, it flags the cell(s) it would have -- occupied or empty -- and lives in
+//             the stash, whose entries carry 32-bit counts
 //   (line, cell, w, r) -> N -> canonical k-mer is injective, so equality of (w, r) in the k-mer's cell IS equality of
 //   the k-mer. When several k-mers want one cell, a k-mer whose minimizer is shared by >= 3 k-mers of the database
 //   (the genome's runs -- what a reference window asks for) beats an isolated one, then the larger counter wins (64-bit

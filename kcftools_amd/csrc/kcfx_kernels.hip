@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256) void lookup_kernel(TableView tv, int32_t k, co
 // the minimizer's mix), then the larger counter. Exactness never depends on this -- it only decides who lives in a cell and
 // who in the stash; on the bench database it halves the stash look-ups of a screening pass.
 constexpr uint32_t CELL_CROWD = 3;
+constexpr uint32_t CELL_COUNT_MAX = 0xFFFFu;                // what the 16-bit count field of a cell holds
 constexpr uint32_t CELL_FLAG_CROWDED = 2u;                  // bit 1 of w: the occupant is of the crowded class
 __host__ __device__ inline int cell_sub_bits(int32_t lbits) { return lbits <= 30 ? 2 : 32 - lbits; }
 __device__ __forceinline__ uint64_t cell_sub_bucket(const CellProbe& p, int32_t lbits) {
@@ -211,7 +212,7 @@ __global__ void cells_count_kernel(uint32_t* pop32, int32_t k, int32_t lbits, co
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
-        if ((counts[i] & 0xFFFFu) == 0) continue;
+        if (counts[i] == 0) continue;
         CellProbe cand[CELL_MAX_CANDS];
         cells_of_key(keys[i], k, lbits, cand);
         const uint64_t sub = cell_sub_bucket(cand[0], lbits);
@@ -228,8 +229,9 @@ __global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
-        const uint32_t c = counts[i] & 0xFFFFu;
+        const uint32_t c = counts[i];
         if (c == 0) continue;                       // can never be observed (count >= -c >= 1 is needed): not stored
+        if (c > CELL_COUNT_MAX) continue;           // a 3- / 4-byte counter that does not fit a cell: lives in the stash (settle)
         CellProbe cand[CELL_MAX_CANDS];
         const int nc = cells_of_key(keys[i], k, lbits, cand);
         const uint64_t sub = cell_sub_bucket(cand[0], lbits);
@@ -273,12 +275,24 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, co
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     uint32_t n_lost = 0, n_stored = 0, n_multi = 0, n_second = 0;      // per lane; one atomic per wave at the end
     for (; i < n; i += stride) {
-        const uint32_t c = counts[i] & 0xFFFFu;
+        const uint32_t c = counts[i];
         if (c == 0) continue;
         CellProbe cand[CELL_MAX_CANDS];
         const int nc = cells_of_key(keys[i], k, lbits, cand);
         bool lost = false;
         const uint64_t kc = cell_keycount_mask(lbits);
+        if (c > CELL_COUNT_MAX) {
+            // never bid: every cell a query could derive for it is flagged (whoever lives there, or nobody), with its filter bit
+            for (int a = 0; a < nc; ++a) {
+                unsigned long long mark = CELL_FLAG_STASH;
+                if (cell_spare_bits(lbits) > 0) mark |= 1ull << (32 + cell_filter_pos(cand[a].w, lbits));
+                atomicOr(reinterpret_cast<unsigned long long*>(lines + (size_t)cand[a].line * LINE_BYTES + 4 * cand[a].sh), mark);
+            }
+            ++n_lost;
+            ++n_stored;
+            n_multi += nc > 1 ? 1u : 0u;
+            continue;
+        }
         for (int a = 0; a < nc; ++a) {
             if (cell_standing(lines, cand[a], c, lbits) != 2) continue;     // (1: the same word twice in the input)
             uint8_t* line = lines + (size_t)cand[a].line * LINE_BYTES;
@@ -323,13 +337,15 @@ __global__ void cells_stash_kernel(const uint8_t* __restrict__ lines, int32_t k,
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
-        const uint32_t c = counts[i] & 0xFFFFu;
+        const uint32_t c = counts[i];
         if (c == 0) continue;
         const uint64_t key = keys[i];
-        CellProbe cand[CELL_MAX_CANDS];
-        const int nc = cells_of_key(key, k, lbits, cand);
-        bool lost = false;
-        for (int a = 0; a < nc; ++a) lost |= cell_standing(lines, cand[a], c, lbits) == 2;
+        bool lost = c > CELL_COUNT_MAX;                 // (counters wider than a cell's 16 bits)
+        if (!lost) {
+            CellProbe cand[CELL_MAX_CANDS];
+            const int nc = cells_of_key(key, k, lbits, cand);
+            for (int a = 0; a < nc; ++a) lost |= cell_standing(lines, cand[a], c, lbits) == 2;
+        }
         if (!lost) continue;
         uint32_t slot = stash_slot(key, mask);
         for (;;) {
@@ -373,9 +389,9 @@ __global__ __launch_bounds__(256) void lookup_cells_kernel(TableView tv, int32_t
             const uint64_t first = *reinterpret_cast<const uint64_t*>(line + 4 * cand[0].sh);
             const uint64_t second = *reinterpret_cast<const uint64_t*>(line + 4 * cell_alt_sh(cand[0].sh, cand[0].w));
             const uint64_t KEY_BITS = cell_keycount_mask(tv.lbits) & 0x0000FFFFFFFFFFFFull;     // w without the flags, r without the filter
-            if (((first ^ cell_word(cand[0].w, cand[0].r, 0)) & KEY_BITS) == 0)
+            if (((first ^ cell_word(cand[0].w, cand[0].r, 0)) & KEY_BITS) == 0 && (first >> 48) != 0)
                 result = (int32_t)(first >> 48);
-            else if (((second ^ cell_word(cand[0].w, cand[0].r | CELL_R_ALT, 0)) & KEY_BITS) == 0)
+            else if (((second ^ cell_word(cand[0].w, cand[0].r | CELL_R_ALT, 0)) & KEY_BITS) == 0 && (second >> 48) != 0)
                 result = (int32_t)(second >> 48);
             else if ((first & CELL_FLAG_STASH) &&
                      (cell_spare_bits(tv.lbits) == 0 || ((first >> (32 + cell_filter_pos(cand[0].w, tv.lbits))) & 1)))
@@ -1019,9 +1035,11 @@ __device__ __forceinline__ void cells_match(const CellWord& cw, int32_t lbits, u
         const uint32_t r_alt = cw.r ^ CELL_R_ALT;
         const bool second = ((xa ^ cw.w) <= CELL_FLAG_MASK) && (((ya ^ r_alt) & rmask) == 0);
         cnt = first ? (y >> 16) : second ? (ya >> 16) : 0u;
-        // the stash only if the cell is flagged AND (when the table has filter bits) the bit of this flank is set
+        // the stash only if the cell is flagged AND (when the table has filter bits) the bit of this flank is set.
+        // "cnt == 0", not "no match": an EMPTY cell can be flagged (a k-mer whose counter does not fit 16 bits never takes
+        // a cell) and would "match" the k-mer whose w and r are all zero
         const uint32_t mine = filtered ? ((y >> (rb + __umulhi(cw.w * 0x9E3779B1u, nspare))) & 1u) : 1u;
-        pend = (first || second) ? 0u : (x & CELL_FLAG_STASH & mine);
+        pend = cnt != 0u ? 0u : (x & CELL_FLAG_STASH & mine);
     }
 }
 
@@ -1042,7 +1060,7 @@ __device__ __forceinline__ uint64_t k31_canonical_at(const K31Pack& sh, int q) {
 // holds where they sit); returns the new qn.
 template <int K>
 __device__ __forceinline__ int k31c_stash_round(const TableView& tv, const K31Pack& sh, K31CQueue& q, int lane, int qn, int pos0,
-                                                int32_t min_count, uint32_t& sum_acc) {
+                                                int32_t min_count, uint32_t& sum_acc, int64_t& big_acc) {
     const int nb = min(qn, 64), rest = qn - nb;
     const uint32_t id = q.id[lane];
     const uint32_t i2 = q.id[64 + lane];
@@ -1052,7 +1070,9 @@ __device__ __forceinline__ int k31c_stash_round(const TableView& tv, const K31Pa
     if (lane < nb) cnt = stash_find(tv, k31_canonical_at<K>(sh, pos0 + (int)id));
     const bool hit = (int32_t)cnt >= min_count;             // cnt is 0 unless found; GetVariants.java:224
     if (hit) atomicOr(&q.hit[id >> 6], 1ull << (id & 63));
-    sum_acc += hit ? cnt : 0u;                              // GetVariants.java:226
+    const bool big = cnt > CELL_COUNT_MAX;                  // only a 3- / 4-byte counter: its own 64-bit sum (GetVariants.java:226)
+    sum_acc += (hit && !big) ? cnt : 0u;
+    big_acc += (hit && big) ? (int64_t)(int32_t)cnt : (int64_t)0;
     wave_lds_fence();
     return rest;
 }
@@ -1077,6 +1097,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const int pos0 = off + w_begin * 64;                    // packed position of the wave's first k-mer
 
     uint32_t sum_acc = 0;                                   // per lane; u16 counters: fits (static_assert in screen_k31_kernel)
+    int64_t big_acc = 0;                                    // counters beyond 16 bits come from the stash only, rarely
     uint64_t* my_bits = bits + (size_t)blockIdx.x * TILE_BITS_U64;
     K31Words<true, K> words;
     if (w_begin < w_end) words.start(sh, off, td.n_kmers, lane, w_begin);
@@ -1108,7 +1129,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             qn += __popcll(PM);
         }
         wave_lds_fence();
-        while (qn >= 64) qn = k31c_stash_round<K>(tv, sh, q, lane, qn, pos0, min_count, sum_acc);
+        while (qn >= 64) qn = k31c_stash_round<K>(tv, sh, q, lane, qn, pos0, min_count, sum_acc, big_acc);
     };
     // Two words per trip so that the two CellWords stay in fixed registers; the steady-state trip has no condition around
     // an issue (see cells_issue), the last one or two words are peeled.
@@ -1130,13 +1151,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             retire(w, a);
         }
     }
-    while (qn > 0) qn = k31c_stash_round<K>(tv, sh, q, lane, qn, pos0, min_count, sum_acc);
+    while (qn > 0) qn = k31c_stash_round<K>(tv, sh, q, lane, qn, pos0, min_count, sum_acc, big_acc);
     if (lane < w_end - w_begin) {                           // the wave's words of the window's bitmap
         my_bits[w_begin + lane] = q.vw[lane];
         my_bits[TILE_WORDS + w_begin + lane] = q.hit[lane];
     }
 
-    const int64_t count_sum = (int64_t)wave_sum_u32_dpp(sum_acc);
+    const int64_t count_sum = (int64_t)wave_sum_u32_dpp(sum_acc) + wave_sum_i64(big_acc);
     if (lane == 0) sh.sum[wave] = count_sum;
     __syncthreads();
     if (tid == 0) {

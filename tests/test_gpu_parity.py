@@ -49,7 +49,7 @@ CONFIGS = [
     (23, 3, 2, 5, 7, True),
     (15, 3, 1, 5, 3, False),
     (32, 4, 2, 7, 4, True),
-    # k = 27 .. 30 on canonical databases with narrow counters take the cell table too (minimizer length k - 15)
+    # k = 27 .. 30 on canonical databases take the cell table too (minimizer length k - 15)
     (30, 2, 2, 7, 4, True),
     (29, 5, 1, 7, 3, True),
     (28, 4, 2, 5, 4, True),
@@ -66,7 +66,7 @@ def test_lookup_matches_getcount(oracle, tmp_path, k, p, cs, m, bins, both):
     odb = oracle.OracleDb(prefix)
     i = db.info
     assert (i.kmer_length, i.lut_prefix_length, i.counter_size, i.signature_length, i.n_bins) == (k, p, cs, m, bins)
-    assert i.table_format == (1 if (27 <= k <= 31 and both and cs <= 2) else 0)
+    assert i.table_format == (1 if (27 <= k <= 31 and both) else 0)
     assert i.minimizer_length == k - 15 if i.table_format == 1 else True
     assert bool(i.both_strands) == both and i.total_kmers == len(kmers) and i.version == 0x200
     assert i.min_count == prm.min_count and i.max_count == int(np.int32(np.uint32(prm.max_count)))   # Java int (KMC.java:131)
@@ -207,6 +207,39 @@ def test_java_int_counts(oracle, tmp_path):
     synth.write_kmc(prefix0, kmers, np.zeros(len(kmers), dtype=np.uint64), prm0)
     db0 = engine.KmcDb.open(prefix0)
     assert_same(db0.screen(ref, [0], [len(ref)], 1), oracle.OracleDb(prefix0).screen(ref, [0], [len(ref)], 1), "cs0")
+
+
+@pytest.mark.parametrize("cs", [3, 4])
+def test_wide_counters_in_a_cell_table(oracle, tmp_path, cs):
+    """3- and 4-byte counters take the cell table too: a counter beyond 65535 does not fit a cell's 16 bits, so that k-mer
+    lives in the stash (32-bit counts) and flags the cell it would have had -- occupied or EMPTY. Counts straddle the
+    boundary (65535 / 65536), include 2^24 - 1, negative Java ints (cs 4) and 0; the poly-A k-mer (w = r = 0, which an empty
+    cell "matches") is one of the wide ones. KD sums exceed 32 bits."""
+    k = 31
+    ref = bytearray(synth.random_reference(60_000, 23, n_run_every=0, lower_frac=0, iupac_rate=0))
+    ref[30_000:30_200] = b"A" * 200
+    ref = bytes(ref)
+    kmers = np.unique(synth.kmers_of_text(ref, k, True))
+    top = (1 << (8 * cs)) - 1
+    pattern = np.array([65535, 65536, 7, top, 70_000, 0, 1, 0x80000005 & top, 65534, 3_000_000], dtype=np.uint64)
+    counts = pattern[np.arange(len(kmers)) % len(pattern)]
+    counts[kmers == 0] = 1_000_000                        # AAAA...A: canonical word 0
+    assert (kmers == 0).any()
+    prm = synth.KmcParams(k=k, p=3, counter_size=cs, sig_len=7, n_bins=4, max_count=top)
+    prefix = str(tmp_path / f"wide{cs}")
+    synth.write_kmc(prefix, kmers, counts, prm)
+    db = engine.KmcDb.open(prefix)
+    assert db.info.table_format == 1 and db.info.stash_kmers >= int((counts > 65535).sum())
+    odb = oracle.OracleDb(prefix)
+    assert np.array_equal(db.lookup(kmers), counts.astype(np.uint32).astype(np.int32))
+    s, e = engine.windows(len(ref), 7_000, 0, k)
+    for c in (1, 8, 65536, 70_001):
+        got, want = db.screen(ref, s, e - s, c), odb.screen(ref, s, e - s, c, threads=4)
+        assert_same(got, want, f"cs {cs} -c {c}")
+    assert int(db.screen(ref, [0], [len(ref)], 1)["kmer_count_sum"][0]) > 1 << 32
+    db2 = engine.KmcDb.build(kmers, counts, k, cs, True)
+    assert db2.info.table_format == 1
+    assert_same(db2.screen(ref, s, e - s, 1), odb.screen(ref, s, e - s, 1, threads=4), "array build")
 
 
 def test_config1_scale(oracle, tmp_path):
@@ -375,7 +408,7 @@ def test_k31_specialised_and_generic_kernels_agree(oracle, tmp_path, cs, both, m
     prefix, *_ = make_db(tmp_path, "both", ref, 9, k=k, p=3, cs=cs, m=7, bins=8, both=both, noise=20_000)
     db = engine.KmcDb.open(prefix)
     assert db.info.minimizer_length == 16
-    assert db.info.table_format == (1 if (both and cs <= 2) else 0)
+    assert db.info.table_format == (1 if both else 0)
     odb = oracle.OracleDb(prefix)
     begins = np.concatenate([np.arange(0, 390_000, 7_777), [399_000, 399_969, 399_970]]).astype(np.int64)
     lens = np.minimum(len(ref) - begins, 9_999).astype(np.int32)
@@ -440,7 +473,7 @@ def test_fuzz_window_geometry_against_oracle(oracle, tmp_path, seed, kernel, mon
     """Random databases x windows whose lengths sit on the kernel's internal borders (k-mer count 0 / 1 / 63 / 64 / 65,
     one tile +-1, several tiles +-1, word-aligned and not), random offsets (every alignment of the 32-base pack chunks),
     N runs crossing window and tile borders, soft-masked stretches. k = 31 runs screen_k31c_kernel on a cell table when the
-    database is canonical with counters of at most 2 bytes, else screen_k31_kernel on a line table ("lines" forces that
+    database is canonical, else screen_k31_kernel on a line table ("lines" forces that
     one, "generic" the general screen_tiles_kernel); both strandedness and all counter widths come up over the seeds."""
     if kernel == "generic":
         monkeypatch.setenv("KCFX_GENERIC_KERNEL", "1")
@@ -461,7 +494,7 @@ def test_fuzz_window_geometry_against_oracle(oracle, tmp_path, seed, kernel, mon
     ref = bytes(ref)
     cs = int(rng.choice([1, 2, 4]))
     both = bool(rng.integers(0, 2))
-    if kernel == "default":                 # always the cell table (canonical, narrow counters)
+    if kernel == "default":                 # always the cell table (canonical)
         cs, both = 1 + seed % 2, True
     p_of_k = {31: int(rng.choice([3, 7])), 30: 2, 29: 5, 28: 4, 27: 3}
     prefix, *_ = make_db(tmp_path, "fz", ref, 300 + seed, k=k, p=p_of_k[k], cs=cs, m=7, bins=4, both=both, noise=5_000)
