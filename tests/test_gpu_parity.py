@@ -494,10 +494,17 @@ def test_fuzz_window_geometry_against_oracle(oracle, tmp_path, seed, kernel, mon
     ref = bytes(ref)
     cs = int(rng.choice([1, 2, 4]))
     both = bool(rng.integers(0, 2))
-    if kernel == "default":                 # always the cell table (canonical)
-        cs, both = 1 + seed % 2, True
+    noise = 5_000
+    if kernel == "default":                 # always the cell table (canonical); all counter widths
+        cs, both = 1 + seed % 4, True
+        if seed % 3 == 1:                   # a crowded table: 2^17 lines for ~1.4 M k-mers, most of them in second choices / the stash
+            monkeypatch.setenv("KCFX_TABLE_LBITS", "17")
+            noise = 1_200_000
+        elif seed % 3 == 2:                 # a few filter bits
+            monkeypatch.setenv("KCFX_TABLE_LBITS", str(18 + seed % 4))
+            noise = 300_000
     p_of_k = {31: int(rng.choice([3, 7])), 30: 2, 29: 5, 28: 4, 27: 3}
-    prefix, *_ = make_db(tmp_path, "fz", ref, 300 + seed, k=k, p=p_of_k[k], cs=cs, m=7, bins=4, both=both, noise=5_000)
+    prefix, *_ = make_db(tmp_path, "fz", ref, 300 + seed, k=k, p=p_of_k[k], cs=cs, m=7, bins=4, both=both, noise=noise)
     db = engine.KmcDb.open(prefix)
     assert db.info.table_format == (1 if kernel == "default" else 0)
     odb = oracle.OracleDb(prefix)
@@ -508,9 +515,10 @@ def test_fuzz_window_geometry_against_oracle(oracle, tmp_path, seed, kernel, mon
     begins = [int(rng.integers(0, L - ln + 1)) for ln in lens]
     begins = np.array(begins, dtype=np.int64)
     lens = np.array(lens, dtype=np.int32)
-    got = db.screen(ref, begins, lens, 1)
-    want = odb.screen(ref, begins, lens, 1, threads=4)
-    assert_same(got, want, f"fuzz seed {seed} (cs={cs}, both={both})")
+    minc = int(rng.choice([1, 1, 2, 5]))
+    got = db.screen(ref, begins, lens, minc)
+    want = odb.screen(ref, begins, lens, minc, threads=4)
+    assert_same(got, want, f"fuzz seed {seed} (k={k}, cs={cs}, both={both}, -c {minc}, table 2^{int(np.log2(max(1, db.info.table_lines)))})")
     assert_scores(oracle, got, want)
 
 
