@@ -116,6 +116,12 @@ int32_t kcfx_db_header(const char* kmc_prefix, kcfx_db_info_t* info);
 int32_t kcfx_db_lookup(kcfx_db* db, const uint64_t* kmers, int64_t n, int32_t* counts_out);
 
 void kcfx_db_close(kcfx_db* db);
+/* Large device buffers of closed databases and destroyed references (tables, stashes, reference text) are kept, per
+ * device, for the next handle of the same size: a run over many samples opens one database after the other, and on this
+ * platform hipMalloc of a table that follows the hipFree of the previous one costs up to 2 s (KMC.java:412-420 has no
+ * counterpart: the JVM unmaps). At most 8 blocks and 40 % of the device; given back by themselves when an allocation of the
+ * library fails, by this call (device < 0: all devices), never kept with KCFX_NO_POOL=1 in the environment. */
+int32_t kcfx_release_cached(int32_t device);
 
 /* ---- reference text + windows ---------------------------------------------------------------------- */
 

@@ -43,6 +43,10 @@ JNIEXPORT void JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_dbClose(JNIEnv*, jcl
     kcfx_db_close(reinterpret_cast<kcfx_db*>(db));
 }
 
+JNIEXPORT jint JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_releaseCached(JNIEnv*, jclass, jint device) {
+    return kcfx_release_cached(device);
+}
+
 // void screen(long db, ByteBuffer text, long[] winBegin, int[] winLen, int minKmerCount, ByteBuffer results)
 // `text` and `results` are direct buffers; results receives nWindows * 40 bytes (kcfx_result, little-endian).
 JNIEXPORT void JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_screen(JNIEnv* env, jclass, jlong db, jobject text,

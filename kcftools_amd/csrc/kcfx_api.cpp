@@ -304,8 +304,7 @@ double table_load_factor(int64_t n_keys, int slots) {
         const double a = atof(s);
         if (a >= 0.05 && a <= 0.9) return a;
     }
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)256 << 30;
+    const size_t free_b = free_device_bytes();
     const double GiB = (double)(1ull << 30);
     const double room = 0.6 * (double)free_b;
     auto bytes_at = [&](double a) { return (double)n_keys / (slots * a) * LINE_BYTES; };
@@ -365,8 +364,7 @@ int32_t cells_lbits(int64_t n_keys, int32_t k) {
     const int32_t cap = cells_lbits_cap(k);
     const char* s = getenv("KCFX_TABLE_LBITS");
     if (s && atoi(s) >= CELL_LBITS_MIN && atoi(s) <= cap) return atoi(s);
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)256 << 30;
+    const size_t free_b = free_device_bytes();
     const double room = std::min(48.0 * (double)(1ull << 30), 0.5 * (double)free_b);
     int32_t L = CELL_LBITS_MIN;
     while (L < cap && 16.0 * (double)(1ull << L) * 0.075 < (double)n_keys) ++L;
@@ -386,7 +384,7 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys) {
     for (int32_t L = cells_lbits(n_keys, db->info.kmer_length); L >= CELL_LBITS_MIN; --L) {
         if ((double)n_keys > 16.0 * (double)(1ull << L))            // fewer cells than k-mers: not a cell table any more
             return fail(KCFX_ERR_DEVICE, "no cell table of 2^" + std::to_string(L) + " or more lines fits the device memory (or KCFX_TABLE_LBITS)");
-        e = hipMalloc(&db->d_lines, (size_t)LINE_BYTES << L);
+        e = dev_alloc(&db->d_lines, (size_t)LINE_BYTES << L);
         if (e == hipErrorOutOfMemory) {                     // denser tables before giving up
             (void)hipGetLastError();
             db->d_lines = nullptr;
@@ -398,9 +396,9 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys) {
     if (e != hipSuccess) return hip_fail(e, "hipMalloc of the k-mer table");
     db->n_lines = 1u << db->lbits;
     KCFX_HIP(hipMemsetAsync(db->d_lines, 0, (size_t)LINE_BYTES << db->lbits, db->stream));
-    KCFX_HIP(hipMalloc(&db->d_stats, 4 * sizeof(unsigned long long)));
+    KCFX_HIP(dev_alloc(&db->d_stats, 4 * sizeof(unsigned long long)));
     KCFX_HIP(hipMemsetAsync(db->d_stats, 0, 4 * sizeof(unsigned long long), db->stream));
-    KCFX_HIP(hipMalloc(&db->d_pop, cells_pop_bytes(db->lbits)));
+    KCFX_HIP(dev_alloc(&db->d_pop, cells_pop_bytes(db->lbits)));
     KCFX_HIP(hipMemsetAsync(db->d_pop, 0, cells_pop_bytes(db->lbits), db->stream));
     db->info.table_bytes = (int64_t)LINE_BYTES << db->lbits;
     db->info.table_lines = db->n_lines;
@@ -420,8 +418,7 @@ int32_t cells_stash_alloc(kcfx_db* db) {
     db->info.stored_kmers = (int64_t)h[1];
     db->info.multi_cell_kmers = (int64_t)h[2];
     db->info.second_choice_kmers = (int64_t)h[3];
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)256 << 30;
+    const size_t free_b = free_device_bytes();
     double budget = 0.5 * (double)free_b;
     if (const char* s = getenv("KCFX_STASH_BUDGET")) budget = std::max(0.0, atof(s));
     uint64_t slots = 1024;
@@ -431,7 +428,7 @@ int32_t cells_stash_alloc(kcfx_db* db) {
         return fail(KCFX_ERR_DEVICE, "the stash of the cell table (" + std::to_string(h[0]) + " k-mers) does not fit the device memory budget");
     if (slots > (1ull << 32)) return fail(KCFX_ERR_DEVICE, "stash too large for a 32-bit slot index");
     db->stash_mask = (uint32_t)(slots - 1);
-    KCFX_HIP(hipMalloc(&db->d_stash, (size_t)slots * sizeof(uint4)));
+    KCFX_HIP(dev_alloc(&db->d_stash, (size_t)slots * sizeof(uint4)));
     KCFX_HIP(hipMemsetAsync(db->d_stash, 0xFF, (size_t)slots * sizeof(uint4), db->stream));
     db->info.stash_bytes = (int64_t)(slots * sizeof(uint4));
     db->info.table_bytes += db->info.stash_bytes;
@@ -441,10 +438,10 @@ int32_t cells_stash_alloc(kcfx_db* db) {
 // back to "no table" (the handle keeps its stream and header fields): before a rebuild in the other format
 void table_release(kcfx_db* db) {
     (void)hipStreamSynchronize(db->stream);
-    if (db->d_lines) (void)hipFree(db->d_lines);
-    if (db->d_stash) (void)hipFree(db->d_stash);
-    if (db->d_stats) (void)hipFree(db->d_stats);
-    if (db->d_pop) (void)hipFree(db->d_pop);
+    if (db->d_lines) (void)dev_free(db->d_lines);
+    if (db->d_stash) (void)dev_free(db->d_stash);
+    if (db->d_stats) (void)dev_free(db->d_stats);
+    if (db->d_pop) (void)dev_free(db->d_pop);
     db->d_lines = nullptr;
     db->d_stash = nullptr;
     db->d_stats = nullptr;
@@ -478,7 +475,7 @@ int32_t table_alloc(kcfx_db* db, int64_t n_keys, int32_t counter_size, bool allo
         if (want < 64) want = 64;
         if (want > 4294967295.0) return fail(KCFX_ERR_ARG, "database too large for a 32-bit line index");
         db->n_lines = (uint32_t)want + 1;
-        e = hipMalloc(&db->d_lines, (size_t)db->n_lines * LINE_BYTES);
+        e = dev_alloc(&db->d_lines, (size_t)db->n_lines * LINE_BYTES);
         if (e == hipErrorOutOfMemory) {
             (void)hipGetLastError();
             db->d_lines = nullptr;
@@ -498,20 +495,20 @@ int32_t table_alloc(kcfx_db* db, int64_t n_keys, int32_t counter_size, bool allo
 int32_t table_finish(kcfx_db* db) {
     if (db->fmt == FORMAT_CELLS) {
         KCFX_HIP(hipStreamSynchronize(db->stream));
-        if (db->d_stats) (void)hipFree(db->d_stats);
-        if (db->d_pop) (void)hipFree(db->d_pop);
+        if (db->d_stats) (void)dev_free(db->d_stats);
+        if (db->d_pop) (void)dev_free(db->d_pop);
         db->d_stats = nullptr;
         db->d_pop = nullptr;
         return KCFX_OK;
     }
     unsigned long long* d_stats = nullptr;
     unsigned long long h_stats[2] = {0, 0};
-    KCFX_HIP(hipMalloc(&d_stats, sizeof h_stats));
+    KCFX_HIP(dev_alloc(&d_stats, sizeof h_stats));
     hipError_t e = hipMemsetAsync(d_stats, 0, sizeof h_stats, db->stream);
     if (e == hipSuccess) e = launch_table_finalize(db->d_lines, db->n_lines, db->wide, d_stats, db->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(h_stats, d_stats, sizeof h_stats, hipMemcpyDeviceToHost, db->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(db->stream);
-    (void)hipFree(d_stats);
+    (void)dev_free(d_stats);
     if (e != hipSuccess) return hip_fail(e, "table_finalize");
     db->info.heavy_lines = (int64_t)h_stats[0];
     db->info.overflow_lines = (int64_t)h_stats[1];
@@ -522,10 +519,10 @@ void db_free(kcfx_db* db) {
     if (!db) return;
     DeviceGuard g(db->device);
     if (db->stream) (void)hipStreamSynchronize(db->stream);   // shared per device (db_stream), never destroyed
-    if (db->d_lines) (void)hipFree(db->d_lines);
-    if (db->d_stash) (void)hipFree(db->d_stash);
-    if (db->d_stats) (void)hipFree(db->d_stats);
-    if (db->d_pop) (void)hipFree(db->d_pop);
+    if (db->d_lines) (void)dev_free(db->d_lines);
+    if (db->d_stash) (void)dev_free(db->d_stash);
+    if (db->d_stats) (void)dev_free(db->d_stats);
+    if (db->d_pop) (void)dev_free(db->d_pop);
     delete db;
 }
 
@@ -536,15 +533,15 @@ void ref_free(kcfx_ref* r) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
     }
-    if (r->d_text) (void)hipFree(r->d_text);
-    if (r->d_tiles) (void)hipFree(r->d_tiles);
-    if (r->d_win_tile0) (void)hipFree(r->d_win_tile0);
-    if (r->d_bits) (void)hipFree(r->d_bits);
-    if (r->d_csum) (void)hipFree(r->d_csum);
-    if (r->d_res) (void)hipFree(r->d_res);
-    if (r->d_mbits) (void)hipFree(r->d_mbits);
-    if (r->d_mcsum) (void)hipFree(r->d_mcsum);
-    if (r->d_mres) (void)hipFree(r->d_mres);
+    if (r->d_text) (void)dev_free(r->d_text);
+    if (r->d_tiles) (void)dev_free(r->d_tiles);
+    if (r->d_win_tile0) (void)dev_free(r->d_win_tile0);
+    if (r->d_bits) (void)dev_free(r->d_bits);
+    if (r->d_csum) (void)dev_free(r->d_csum);
+    if (r->d_res) (void)dev_free(r->d_res);
+    if (r->d_mbits) (void)dev_free(r->d_mbits);
+    if (r->d_mcsum) (void)dev_free(r->d_mcsum);
+    if (r->d_mres) (void)dev_free(r->d_mres);
     stream_release(r->device, r->stream);
     delete r;
 }
@@ -591,12 +588,12 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     auto cleanup = [&]() {
         for (int i = 0; i < 2; ++i) {
             if (h_buf[i]) (void)hipHostFree(h_buf[i]);
-            if (d_rec[i]) (void)hipFree(d_rec[i]);
+            if (d_rec[i]) (void)dev_free(d_rec[i]);
             if (done[i]) (void)hipEventDestroy(done[i]);
         }
-        if (d_lut) (void)hipFree(d_lut);
-        if (d_keys) (void)hipFree(d_keys);
-        if (d_counts) (void)hipFree(d_counts);
+        if (d_lut) (void)dev_free(d_lut);
+        if (d_keys) (void)dev_free(d_keys);
+        if (d_counts) (void)dev_free(d_counts);
         close(fd);
     };
 #define LOAD_HIP(call)                                  \
@@ -611,20 +608,19 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     const bool cells = (db->fmt == FORMAT_CELLS);
     const bool two_phase = (db->mode == MODE_MINIMIZER);
     // keep every decoded record resident between the phases?
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    const size_t free_b = free_device_bytes();
     const bool resident = two_phase && getenv("KCFX_LOAD_STREAM_TWICE") == nullptr &&
                           (double)h.total * 12.0 + (double)(2 * chunk_bytes) + (double)(64 << 20) < 0.5 * (double)free_b;
     const int64_t n_chunk_max = std::min<int64_t>(CH, std::max<int64_t>(h.total, 1));
     const int64_t n_keys_buf = resident ? std::max<int64_t>(h.total, 1) : n_chunk_max;
     for (int i = 0; i < 2; ++i) {
         LOAD_HIP(hipHostMalloc(&h_buf[i], (size_t)std::min(chunk_bytes, std::max<int64_t>(h.total * h.record_size, 16)), hipHostMallocDefault));
-        LOAD_HIP(hipMalloc(&d_rec[i], (size_t)n_chunk_max * h.record_size + 16));
+        LOAD_HIP(dev_alloc(&d_rec[i], (size_t)n_chunk_max * h.record_size + 16));
         LOAD_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
     }
-    LOAD_HIP(hipMalloc(&d_lut, (size_t)std::max<int64_t>(h.lut_entries, 1) * 8));
-    LOAD_HIP(hipMalloc(&d_keys, (size_t)n_keys_buf * 8));
-    LOAD_HIP(hipMalloc(&d_counts, (size_t)n_keys_buf * 4));
+    LOAD_HIP(dev_alloc(&d_lut, (size_t)std::max<int64_t>(h.lut_entries, 1) * 8));
+    LOAD_HIP(dev_alloc(&d_keys, (size_t)n_keys_buf * 8));
+    LOAD_HIP(dev_alloc(&d_counts, (size_t)n_keys_buf * 4));
     if (h.lut_entries) LOAD_HIP(hipMemcpyAsync(d_lut, h.lut_bytes, (size_t)h.lut_entries * 8, hipMemcpyHostToDevice, db->stream));
     tr.mark("buffers + LUT upload");
 
@@ -821,8 +817,8 @@ int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, 
         uint64_t* keys = nullptr;
         uint32_t* counts = nullptr;
         ~Scratch() {
-            if (keys) (void)hipFree(keys);
-            if (counts) (void)hipFree(counts);
+            if (keys) (void)dev_free(keys);
+            if (counts) (void)dev_free(counts);
         }
     } scratch;
     uint64_t*& d_keys = scratch.keys;
@@ -840,7 +836,7 @@ int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, 
             for (int64_t i = 0; i < n; ++i) masked[(size_t)i] = counts[i] & mask;
             src = masked.data();
         }
-        if ((e = hipMalloc(&d_keys, (size_t)n * 8)) != hipSuccess || (e = hipMalloc(&d_counts, (size_t)n * 4)) != hipSuccess ||
+        if ((e = dev_alloc(&d_keys, (size_t)n * 8)) != hipSuccess || (e = dev_alloc(&d_counts, (size_t)n * 4)) != hipSuccess ||
             (e = hipMemcpyAsync(d_keys, kmers, (size_t)n * 8, hipMemcpyHostToDevice, db->stream)) != hipSuccess ||
             (e = hipMemcpyAsync(d_counts, src, (size_t)n * 4, hipMemcpyHostToDevice, db->stream)) != hipSuccess ||
             (e = hipStreamSynchronize(db->stream)) != hipSuccess)            // (`masked` goes out of scope below)
@@ -905,18 +901,23 @@ int32_t kcfx_db_lookup(kcfx_db* db, const uint64_t* kmers, int64_t n, int32_t* c
     int32_t* d_c = nullptr;
     hipError_t e;
     int32_t rc = KCFX_OK;
-    if ((e = hipMalloc(&d_k, (size_t)n * 8)) != hipSuccess || (e = hipMalloc(&d_c, (size_t)n * 4)) != hipSuccess ||
+    if ((e = dev_alloc(&d_k, (size_t)n * 8)) != hipSuccess || (e = dev_alloc(&d_c, (size_t)n * 4)) != hipSuccess ||
         (e = hipMemcpyAsync(d_k, kmers, (size_t)n * 8, hipMemcpyHostToDevice, db->stream)) != hipSuccess ||
         (e = launch_lookup(db->view(), db->info.kmer_length, d_k, n, d_c, db->stream)) != hipSuccess ||
         (e = hipMemcpyAsync(counts_out, d_c, (size_t)n * 4, hipMemcpyDeviceToHost, db->stream)) != hipSuccess ||
         (e = hipStreamSynchronize(db->stream)) != hipSuccess)
         rc = hip_fail(e, "kcfx_db_lookup");
-    if (d_k) (void)hipFree(d_k);
-    if (d_c) (void)hipFree(d_c);
+    if (d_k) (void)dev_free(d_k);
+    if (d_c) (void)dev_free(d_c);
     return rc;
 } KCFX_CATCH("kcfx_db_lookup")
 
 void kcfx_db_close(kcfx_db* db) { db_free(db); }
+
+int32_t kcfx_release_cached(int32_t device) try {
+    kcfx::pool_release(device);
+    return KCFX_OK;
+} KCFX_CATCH("kcfx_release_cached")
 
 int32_t kcfx_ref_create(int32_t device, int32_t kmer_length, const uint8_t* text, int64_t text_len,
                         const int64_t* win_begin, const int32_t* win_len, int32_t n_windows, kcfx_ref** out) try {
@@ -963,14 +964,14 @@ int32_t kcfx_ref_create(int32_t device, int32_t kmer_length, const uint8_t* text
     const size_t text_alloc = (size_t)text_len + 128;   // the pack phase reads whole 32-byte chunks
     hipError_t e;
     if ((e = stream_acquire(device, &r->stream)) != hipSuccess ||
-        (e = hipMalloc(&r->d_text, text_alloc)) != hipSuccess ||
+        (e = dev_alloc(&r->d_text, text_alloc)) != hipSuccess ||
         (e = hipMemsetAsync(r->d_text + text_len, 0, 128, r->stream)) != hipSuccess ||
         (text_len > 0 && (e = hipMemcpyAsync(r->d_text, text, (size_t)text_len, hipMemcpyHostToDevice, r->stream)) != hipSuccess) ||
-        (e = hipMalloc(&r->d_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(TileDesc))) != hipSuccess ||
-        (e = hipMalloc(&r->d_win_tile0, win_tile0.size() * 4)) != hipSuccess ||
-        (e = hipMalloc(&r->d_bits, std::max<size_t>(tiles.size(), 1) * TILE_BITS_U64 * 8)) != hipSuccess ||
-        (e = hipMalloc(&r->d_csum, std::max<size_t>(tiles.size(), 1) * 8)) != hipSuccess ||
-        (e = hipMalloc(&r->d_res, std::max<size_t>((size_t)n_windows, 1) * sizeof(kcfx_result))) != hipSuccess ||
+        (e = dev_alloc(&r->d_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(TileDesc))) != hipSuccess ||
+        (e = dev_alloc(&r->d_win_tile0, win_tile0.size() * 4)) != hipSuccess ||
+        (e = dev_alloc(&r->d_bits, std::max<size_t>(tiles.size(), 1) * TILE_BITS_U64 * 8)) != hipSuccess ||
+        (e = dev_alloc(&r->d_csum, std::max<size_t>(tiles.size(), 1) * 8)) != hipSuccess ||
+        (e = dev_alloc(&r->d_res, std::max<size_t>((size_t)n_windows, 1) * sizeof(kcfx_result))) != hipSuccess ||
         (!tiles.empty() && (e = hipMemcpyAsync(r->d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, r->stream)) != hipSuccess) ||
         (e = hipMemcpyAsync(r->d_win_tile0, win_tile0.data(), win_tile0.size() * 4, hipMemcpyHostToDevice, r->stream)) != hipSuccess ||
         (e = hipStreamSynchronize(r->stream)) != hipSuccess)
@@ -1084,14 +1085,14 @@ int32_t kcfx_ref_reserve_multi(kcfx_ref* ref, int32_t n_samples) try {
     const int32_t want = std::min<int32_t>(n_samples, SCREEN_MULTI_MAX);
     if (want <= ref->multi_cap) return KCFX_OK;
     DeviceGuard g(ref->device);
-    if (ref->d_mbits) (void)hipFree(ref->d_mbits);
-    if (ref->d_mcsum) (void)hipFree(ref->d_mcsum);
+    if (ref->d_mbits) (void)dev_free(ref->d_mbits);
+    if (ref->d_mcsum) (void)dev_free(ref->d_mcsum);
     ref->d_mbits = nullptr;
     ref->d_mcsum = nullptr;
     ref->multi_cap = 0;
     const size_t nt = std::max<size_t>(ref->n_tiles, 1);
-    KCFX_HIP(hipMalloc(&ref->d_mbits, nt * (size_t)want * TILE_BITS_U64 * 8));
-    KCFX_HIP(hipMalloc(&ref->d_mcsum, nt * (size_t)want * sizeof(int64_t)));
+    KCFX_HIP(dev_alloc(&ref->d_mbits, nt * (size_t)want * TILE_BITS_U64 * 8));
+    KCFX_HIP(dev_alloc(&ref->d_mcsum, nt * (size_t)want * sizeof(int64_t)));
     ref->multi_cap = want;
     return KCFX_OK;
 } KCFX_CATCH("kcfx_ref_reserve_multi")
@@ -1106,10 +1107,10 @@ int32_t kcfx_screen_ref_multi(kcfx_db* const* dbs, int32_t n_db, kcfx_ref* ref, 
     DeviceGuard g(ref->device);
     const size_t bytes = (size_t)n_db * ref->n_windows * sizeof(kcfx_result);
     if (ref->mres_bytes < bytes) {          // sized for the largest n_db seen so far
-        if (ref->d_mres) (void)hipFree(ref->d_mres);
+        if (ref->d_mres) (void)dev_free(ref->d_mres);
         ref->d_mres = nullptr;
         ref->mres_bytes = 0;
-        KCFX_HIP(hipMalloc(&ref->d_mres, bytes));
+        KCFX_HIP(dev_alloc(&ref->d_mres, bytes));
         ref->mres_bytes = bytes;
     }
     if (int32_t rc = kcfx_screen_ref_multi_async(dbs, n_db, ref, min_kmer_count, ref->d_mres, ref->stream)) return rc;

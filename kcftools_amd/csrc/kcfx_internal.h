@@ -201,7 +201,14 @@ __host__ __device__ inline kcfx_result summary_finalize(const TileSummary& s, in
 // ---- error plumbing ---------------------------------------------------------------------------------
 void set_error(const std::string& msg);
 int32_t hip_fail(hipError_t e, const char* what);
-int32_t exception_to_status(const char* fn) noexcept;    // inside catch (...): last_error := what was thrown, returns KCFX_ERR_HOST
+int32_t exception_to_status(const char* fn) noexcept;
+// kcfx_pool.cpp: hipMalloc / hipFree with large released blocks kept per device for the next database (see there)
+hipError_t dev_alloc(void** p, size_t bytes);
+template <class T> inline hipError_t dev_alloc(T** p, size_t bytes) { return dev_alloc(reinterpret_cast<void**>(p), bytes); }
+hipError_t dev_free(void* p);
+size_t free_device_bytes();                  // hipMemGetInfo's free + what the pool keeps on the current device
+size_t pooled_device_bytes(int dev);
+void pool_release(int dev);                  // dev < 0: every device    // inside catch (...): last_error := what was thrown, returns KCFX_ERR_HOST
 
 #define KCFX_HIP(call)                                         \
     do {                                                       \

@@ -1,0 +1,177 @@
+// kcfx_pool.cpp -- device memory for the library's large buffers (tables, stashes, decoded records, reference text).
+//
+// A run over many samples opens and closes one database after the other on the same device, each with a table of the
+// same size (2^lbits lines). hipFree / hipMalloc of 16 GiB is not free on this platform: measured on MI355X, every
+// second or third hipMalloc of a 16 GiB table that follows the hipFree of the previous one takes 1.5 - 1.9 s (the driver
+// hands the pages back cleared), against a 0.1 s database load. So large blocks that are released are kept, per device, and
+// handed out again when a request of (about) the same size comes; everything the library clears or overwrites before use
+// anyway. Bounded (POOL_MAX_BLOCKS, POOL_MAX_FRACTION of the device), emptied when an allocation fails, released on
+// request (kcfx_release_cached), disabled by KCFX_NO_POOL. Memory policies that look at the free device memory count the
+// kept blocks as free (free_device_bytes).
+#include <algorithm>
+#include <cstdlib>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "kcfx_internal.h"
+
+namespace kcfx {
+
+namespace {
+
+constexpr size_t POOL_MIN_BYTES = (size_t)64 << 20;     // smaller requests go straight to hipMalloc
+constexpr size_t POOL_MAX_BLOCKS = 8;                   // kept blocks per device
+constexpr double POOL_MAX_FRACTION = 0.4;               // of the device's memory
+
+struct Block {
+    void* p;
+    size_t bytes;
+    int dev;
+};
+
+std::mutex g_mu;
+std::unordered_map<void*, Block> g_live;                // large blocks in use
+std::vector<Block> g_spare;                             // large blocks kept (oldest first)
+
+bool pool_on() {
+    static const bool on = getenv("KCFX_NO_POOL") == nullptr;
+    return on;
+}
+
+struct OnDevice {
+    int prev = -1;
+    explicit OnDevice(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        (void)hipSetDevice(dev);
+    }
+    ~OnDevice() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// (the device is idle with respect to the block: the callers release after their stream is done, and hipFree -- which this
+// replaces -- synchronises the whole device anyway)
+void really_free(const Block& b) {
+    OnDevice g(b.dev);
+    (void)hipFree(b.p);
+}
+
+size_t pooled_locked(int dev) {
+    size_t s = 0;
+    for (const Block& b : g_spare)
+        if (b.dev == dev) s += b.bytes;
+    return s;
+}
+
+}  // namespace
+
+size_t pooled_device_bytes(int dev) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return pooled_locked(dev);
+}
+
+void pool_release(int dev) {
+    std::vector<Block> out;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (size_t i = 0; i < g_spare.size();) {
+            if (dev < 0 || g_spare[i].dev == dev) {
+                out.push_back(g_spare[i]);
+                g_spare.erase(g_spare.begin() + (long)i);
+            } else {
+                ++i;
+            }
+        }
+    }
+    for (const Block& b : out) really_free(b);
+}
+
+size_t free_device_bytes() {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (size_t)256 << 30;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return free_b;
+    return free_b + pooled_device_bytes(dev);
+}
+
+hipError_t dev_alloc(void** p, size_t bytes) {
+    *p = nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const bool big = pool_on() && bytes >= POOL_MIN_BYTES;
+    if (big) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        long best = -1;                                   // smallest kept block that fits without wasting a quarter
+        for (size_t i = 0; i < g_spare.size(); ++i) {
+            const Block& b = g_spare[i];
+            if (b.dev == dev && b.bytes >= bytes && b.bytes - bytes <= bytes / 4 && (best < 0 || b.bytes < g_spare[(size_t)best].bytes))
+                best = (long)i;
+        }
+        if (best >= 0) {
+            const Block b = g_spare[(size_t)best];
+            g_spare.erase(g_spare.begin() + best);
+            g_live[b.p] = b;
+            *p = b.p;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory && pooled_device_bytes(dev) > 0) {
+        (void)hipGetLastError();
+        pool_release(dev);                               // what is kept must never be the reason for a failure
+        e = hipMalloc(p, bytes);
+    }
+    if (e == hipSuccess && big) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_live[*p] = Block{*p, bytes, dev};
+    }
+    return e;
+}
+
+hipError_t dev_free(void* p) {
+    if (!p) return hipSuccess;
+    Block b{nullptr, 0, 0};
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_live.find(p);
+        if (it != g_live.end()) {
+            b = it->second;
+            g_live.erase(it);
+        }
+    }
+    if (!b.p) return hipFree(p);                         // a small block
+    {
+        OnDevice g(b.dev);
+        (void)hipDeviceSynchronize();                    // as hipFree would have: nothing queued may still touch the block
+    }
+    size_t total_b = 0, free_b = 0;
+    {
+        OnDevice g(b.dev);
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = (size_t)256 << 30;
+    }
+    std::vector<Block> out;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_spare.push_back(b);
+        // over the bounds: the oldest blocks of this device go
+        for (;;) {
+            size_t n = 0;
+            for (const Block& s : g_spare) n += s.dev == b.dev ? 1 : 0;
+            if (n <= POOL_MAX_BLOCKS && (double)pooled_locked(b.dev) <= POOL_MAX_FRACTION * (double)total_b) break;
+            bool dropped = false;
+            for (size_t i = 0; i < g_spare.size(); ++i)
+                if (g_spare[i].dev == b.dev) {
+                    out.push_back(g_spare[i]);
+                    g_spare.erase(g_spare.begin() + (long)i);
+                    dropped = true;
+                    break;
+                }
+            if (!dropped) break;
+        }
+    }
+    for (const Block& s : out) really_free(s);
+    return hipSuccess;
+}
+
+}  // namespace kcfx

@@ -24,6 +24,7 @@ assert RESULT_DTYPE.itemsize == 40
 # every symbol include/kcfx.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
     "kcfx_db_open", "kcfx_db_build", "kcfx_db_info", "kcfx_db_header", "kcfx_db_lookup", "kcfx_db_close",
+    "kcfx_release_cached",
     "kcfx_ref_create", "kcfx_ref_n_windows", "kcfx_ref_n_kmer_slots", "kcfx_ref_destroy",
     "kcfx_screen_ref", "kcfx_screen_ref_async", "kcfx_screen_ref_multi", "kcfx_screen_ref_multi_async", "kcfx_screen",
     "kcfx_ref_reserve_multi",
@@ -109,6 +110,7 @@ def lib() -> C.CDLL:
         L.kcfx_db_lookup.argtypes = [vp, vp, i64, vp]
         L.kcfx_db_close.argtypes = [vp]
         L.kcfx_db_close.restype = None
+        L.kcfx_release_cached.argtypes = [i32]
         L.kcfx_ref_create.argtypes = [i32, i32, vp, i64, vp, vp, i32, C.POINTER(vp)]
         L.kcfx_ref_n_windows.argtypes = [vp]
         L.kcfx_ref_n_kmer_slots.argtypes = [vp]
@@ -132,6 +134,11 @@ def lib() -> C.CDLL:
 def _check(rc: int) -> None:
     if rc != 0:
         raise KcfxError(rc, lib().kcfx_last_error().decode(errors="replace"))
+
+
+def release_cached(device: int = -1) -> None:
+    """Give the device buffers that closed databases / destroyed references left behind back to the driver."""
+    _check(lib().kcfx_release_cached(device))
 
 
 def device_count() -> int:

@@ -1,6 +1,8 @@
 """kcfx_ctx_create + kcfx_screen_sharded (the multi-GPU entry of the C ABI) on ONE GPU: the same device listed two or
 three times gives two or three worker threads, each with its own resident reference -- the control flow of a node with
 several GPUs. Every slice must equal the unsharded kcfx_screen_ref and the oracle, in both partitionings."""
+import os
+
 import numpy as np
 import pytest
 
@@ -65,3 +67,36 @@ def test_sharded_edge_cases_and_errors(job, tmp_path):
         engine.screen_sharded(prefixes[:1], k, ref, begins, lens, 0, devices=(0,))
     with pytest.raises(engine.KcfxError):
         engine.screen_sharded(prefixes[:1], k, ref, begins, lens, 1, devices=(0, 99))
+
+
+def test_closed_tables_are_kept_for_the_next_database_and_released_on_request(oracle, tmp_path):
+    """kcfx_pool.cpp: the table of a closed database stays with the library for the next database of the same size (a run over
+    many samples; hipMalloc after hipFree of 16 GiB stalls for seconds on this platform) and goes back to the driver with
+    kcfx_release_cached -- or by itself when an allocation would fail otherwise."""
+    import gc
+    import torch
+    ref = synth.random_reference(300_000, 3)
+    sample = synth.mutate_sample(ref, 4)
+    prm = synth.KmcParams(k=31, p=3, counter_size=2, sig_len=7, n_bins=4, max_count=65535)
+    kmers, counts = synth.build_sample_db(sample, prm, 5, noise_kmers=1000)
+    prefix = str(tmp_path / "db")
+    synth.write_kmc(prefix, kmers, counts, prm)
+    os.environ["KCFX_TABLE_LBITS"] = "21"            # a 256 MiB table: large enough to be kept
+    try:
+        engine.release_cached()
+        free0 = torch.cuda.mem_get_info()[0]
+        s, e = engine.windows(len(ref), 10_000, 0, 31)
+        want = oracle.OracleDb(prefix).screen(ref, s, e - s, 1)
+        for _ in range(3):                           # the same block serves all three
+            db = engine.KmcDb.open(prefix)
+            assert db.info.table_bytes >= 256 << 20
+            got = db.screen(ref, s, e - s, 1)
+            assert all(np.array_equal(got[f], want[f]) for f in engine.INT_FIELDS)
+            del db
+            gc.collect()
+        kept = free0 - torch.cuda.mem_get_info()[0]
+        assert kept >= 256 << 20, kept
+        engine.release_cached()
+        assert free0 - torch.cuda.mem_get_info()[0] < 64 << 20
+    finally:
+        del os.environ["KCFX_TABLE_LBITS"]
