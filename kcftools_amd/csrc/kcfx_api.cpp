@@ -79,7 +79,8 @@ static uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v;
 // pread `bytes` at `offset` into dst with a few threads (page cache -> pinned memory is a memcpy: one thread moves
 // ~5 GB/s, the .kmc_suf of a 150 M-k-mer sample is 1.2 GB)
 static bool parallel_pread(int fd, uint8_t* dst, int64_t bytes, int64_t offset) {
-    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(8, bytes >> 22));      // >= 4 MiB per thread
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(8, bytes >> 22));      // >= 4 MiB per thread (4 .. 32 threads measure the same:
+                                                                                     // the upload over PCIe, not this copy, paces a load)
     std::atomic<bool> ok{true};
     auto work = [&](int t) {
         const int64_t lo = bytes * t / T, hi = bytes * (t + 1) / T;
@@ -587,7 +588,7 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     int32_t rc = KCFX_OK;
     auto cleanup = [&]() {
         for (int i = 0; i < 2; ++i) {
-            if (h_buf[i]) (void)hipHostFree(h_buf[i]);
+            if (h_buf[i]) (void)host_free(h_buf[i]);
             if (d_rec[i]) (void)dev_free(d_rec[i]);
             if (done[i]) (void)hipEventDestroy(done[i]);
         }
@@ -614,7 +615,7 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     const int64_t n_chunk_max = std::min<int64_t>(CH, std::max<int64_t>(h.total, 1));
     const int64_t n_keys_buf = resident ? std::max<int64_t>(h.total, 1) : n_chunk_max;
     for (int i = 0; i < 2; ++i) {
-        LOAD_HIP(hipHostMalloc(&h_buf[i], (size_t)std::min(chunk_bytes, std::max<int64_t>(h.total * h.record_size, 16)), hipHostMallocDefault));
+        LOAD_HIP(host_alloc(&h_buf[i], (size_t)std::min(chunk_bytes, std::max<int64_t>(h.total * h.record_size, 16))));
         LOAD_HIP(dev_alloc(&d_rec[i], (size_t)n_chunk_max * h.record_size + 16));
         LOAD_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
     }
@@ -916,6 +917,7 @@ void kcfx_db_close(kcfx_db* db) { db_free(db); }
 
 int32_t kcfx_release_cached(int32_t device) try {
     kcfx::pool_release(device);
+    kcfx::host_pool_release();
     return KCFX_OK;
 } KCFX_CATCH("kcfx_release_cached")
 

@@ -208,7 +208,11 @@ template <class T> inline hipError_t dev_alloc(T** p, size_t bytes) { return dev
 hipError_t dev_free(void* p);
 size_t free_device_bytes();                  // hipMemGetInfo's free + what the pool keeps on the current device
 size_t pooled_device_bytes(int dev);
-void pool_release(int dev);                  // dev < 0: every device    // inside catch (...): last_error := what was thrown, returns KCFX_ERR_HOST
+void pool_release(int dev);                  // dev < 0: every device
+hipError_t host_alloc(void** p, size_t bytes);    // pinned staging buffers, a few kept
+template <class T> inline hipError_t host_alloc(T** p, size_t bytes) { return host_alloc(reinterpret_cast<void**>(p), bytes); }
+hipError_t host_free(void* p);
+void host_pool_release();    // inside catch (...): last_error := what was thrown, returns KCFX_ERR_HOST
 
 #define KCFX_HIP(call)                                         \
     do {                                                       \

@@ -20,8 +20,8 @@ namespace kcfx {
 
 namespace {
 
-constexpr size_t POOL_MIN_BYTES = (size_t)64 << 20;     // smaller requests go straight to hipMalloc
-constexpr size_t POOL_MAX_BLOCKS = 8;                   // kept blocks per device
+constexpr size_t POOL_MIN_BYTES = (size_t)8 << 20;      // smaller requests go straight to hipMalloc
+constexpr size_t POOL_MAX_BLOCKS = 16;                  // kept blocks per device
 constexpr double POOL_MAX_FRACTION = 0.4;               // of the device's memory
 
 struct Block {
@@ -172,6 +172,63 @@ hipError_t dev_free(void* p) {
     }
     for (const Block& s : out) really_free(s);
     return hipSuccess;
+}
+
+// Pinned host staging buffers of the database loader (two per load, a few tens of MB): hipHostMalloc / hipHostFree cost
+// milliseconds each, so up to four released ones are kept for the next load (any device).
+namespace {
+struct HostBlock {
+    void* p;
+    size_t bytes;
+};
+std::vector<HostBlock> g_host_spare;
+std::unordered_map<void*, size_t> g_host_live;
+}  // namespace
+
+hipError_t host_alloc(void** p, size_t bytes) {
+    *p = nullptr;
+    if (pool_on()) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (size_t i = 0; i < g_host_spare.size(); ++i)
+            if (g_host_spare[i].bytes >= bytes && g_host_spare[i].bytes <= 2 * bytes) {
+                *p = g_host_spare[i].p;
+                g_host_live[*p] = g_host_spare[i].bytes;
+                g_host_spare.erase(g_host_spare.begin() + (long)i);
+                return hipSuccess;
+            }
+    }
+    const hipError_t e = hipHostMalloc(p, bytes, hipHostMallocDefault);
+    if (e == hipSuccess && pool_on()) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_host_live[*p] = bytes;
+    }
+    return e;
+}
+
+hipError_t host_free(void* p) {
+    if (!p) return hipSuccess;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_host_live.find(p);
+        if (it != g_host_live.end()) {
+            const size_t bytes = it->second;
+            g_host_live.erase(it);
+            if (g_host_spare.size() < 4) {
+                g_host_spare.push_back(HostBlock{p, bytes});
+                return hipSuccess;
+            }
+        }
+    }
+    return hipHostFree(p);
+}
+
+void host_pool_release() {
+    std::vector<HostBlock> out;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        out.swap(g_host_spare);
+    }
+    for (const HostBlock& b : out) (void)hipHostFree(b.p);
 }
 
 }  // namespace kcfx
