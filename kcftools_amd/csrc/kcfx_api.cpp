@@ -241,7 +241,7 @@ struct kcfx_db {
     unsigned long long* d_stats = nullptr;   // FORMAT_CELLS build counters (cells_settle_kernel)
     uint32_t* d_pop = nullptr;               // FORMAT_CELLS build scratch: k-mers per minimizer sub-bucket (freed after the build)
     hipStream_t stream = nullptr;
-    TableView view() const { return TableView{d_lines, n_lines, wide, mode, mm_len, fmt, lbits, stash_mask, d_stash, generic}; }
+    TableView view() const { return TableView{d_lines, n_lines, wide, mode, mm_len, fmt, lbits, stash_mask, d_stash, generic, info.both_strands}; }
 };
 
 struct kcfx_ref {
@@ -342,7 +342,7 @@ int32_t minimizer_len(int32_t k, int64_t n_keys) {
 // largest lbits a k-mer length allows: the line number is the top of a 32-bit mix of the (k - 15)-base minimizer
 int32_t cells_lbits_cap(int32_t k) { return std::min<int32_t>(CELL_LBITS_MAX, 2 * (k - 15) - 2); }
 
-// FORMAT_CELLS (kcfx_internal.h) is what the BASELINE configuration gets: k = 27 .. 31 (31 in BASELINE.json), both strands,
+// FORMAT_CELLS (kcfx_internal.h) is what the BASELINE configuration gets: k = 27 .. 31 (31 in BASELINE.json), both strands or forward-only,
 // any counter size, minimizer bucketing. KCFX_TABLE_FORMAT=lines keeps the 12-slot line table (A/B and test
 // hook, read at open time).
 bool cells_eligible(const kcfx_db* db, int32_t counter_size) {
@@ -350,7 +350,8 @@ bool cells_eligible(const kcfx_db* db, int32_t counter_size) {
     if (s && !strcmp(s, "lines")) return false;
     const int32_t k = db->info.kmer_length;
     // (3- and 4-byte counters too: a counter beyond 65535 does not fit a cell, that k-mer lives in the stash)
-    if (k < CELL_K_MIN || k > CELL_K_MAX || !db->info.both_strands || table_mode() != MODE_MINIMIZER ||
+    // (forward-only databases too: bit 14 of r tells a k-mer from its reverse complement)
+    if (k < CELL_K_MIN || k > CELL_K_MAX || table_mode() != MODE_MINIMIZER ||
         getenv("KCFX_MM_LEN") != nullptr)
         return false;
     // the minimizer is k - 15 bases: a line number cannot carry more than its 2 (k - 15) bits
@@ -361,15 +362,16 @@ bool cells_eligible(const kcfx_db* db, int32_t counter_size) {
 // workload, 150 M k-mers: 9.7 % at 2^26 lines, 6.2 % at 2^27), and every stash lookup is a random 16-byte fetch of its own:
 // aim at ~0.075 k-mers per cell while that stays under 48 GiB and 50 % of the free memory, else halve down to ~1 per cell.
 // KCFX_TABLE_LBITS overrides.
-int32_t cells_lbits(int64_t n_keys, int32_t k) {
+int32_t cells_lbits(int64_t n_keys, int32_t k, bool both) {
     const int32_t cap = cells_lbits_cap(k);
+    const int32_t lmin = cell_lbits_min(both);
     const char* s = getenv("KCFX_TABLE_LBITS");
-    if (s && atoi(s) >= CELL_LBITS_MIN && atoi(s) <= cap) return atoi(s);
+    if (s && atoi(s) >= lmin && atoi(s) <= cap) return atoi(s);
     const size_t free_b = free_device_bytes();
     const double room = std::min(48.0 * (double)(1ull << 30), 0.5 * (double)free_b);
-    int32_t L = CELL_LBITS_MIN;
+    int32_t L = lmin;
     while (L < cap && 16.0 * (double)(1ull << L) * 0.075 < (double)n_keys) ++L;
-    while (L > CELL_LBITS_MIN && (double)(1ull << L) * LINE_BYTES > room && 16.0 * (double)(1ull << (L - 1)) >= (double)n_keys) --L;
+    while (L > lmin && (double)(1ull << L) * LINE_BYTES > room && 16.0 * (double)(1ull << (L - 1)) >= (double)n_keys) --L;
     return L;
 }
 
@@ -382,7 +384,8 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys) {
     db->info.minimizer_length = db->mm_len;
     db->info.table_format = FORMAT_CELLS;
     hipError_t e = hipErrorOutOfMemory;
-    for (int32_t L = cells_lbits(n_keys, db->info.kmer_length); L >= CELL_LBITS_MIN; --L) {
+    const bool both = db->info.both_strands != 0;
+    for (int32_t L = cells_lbits(n_keys, db->info.kmer_length, both); L >= cell_lbits_min(both); --L) {
         if ((double)n_keys > 16.0 * (double)(1ull << L))            // fewer cells than k-mers: not a cell table any more
             return fail(KCFX_ERR_DEVICE, "no cell table of 2^" + std::to_string(L) + " or more lines fits the device memory (or KCFX_TABLE_LBITS)");
         e = dev_alloc(&db->d_lines, (size_t)LINE_BYTES << L);
@@ -631,10 +634,10 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     auto apply = [&](int phase, const uint64_t* keys, const uint32_t* counts, int64_t n) -> hipError_t {
         if (cells) {
             const int32_t kk = db->info.kmer_length;
-            if (phase == 0) return launch_cells_count(db->d_pop, kk, db->lbits, keys, counts, n, db->stream);
-            if (phase == 1 || phase == 2) return launch_cells_insert(db->d_lines, db->d_pop, phase == 1 ? 1 : 0, kk, db->lbits, keys, counts, n, db->stream);
-            if (phase == 3) return launch_cells_settle(db->d_lines, kk, db->lbits, keys, counts, n, db->d_stats, db->stream);
-            return launch_cells_stash(db->d_lines, kk, db->lbits, keys, counts, n, db->d_stash, db->stash_mask, db->stream);
+            if (phase == 0) return launch_cells_count(db->d_pop, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream);
+            if (phase == 1 || phase == 2) return launch_cells_insert(db->d_lines, db->d_pop, phase == 1 ? 1 : 0, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream);
+            if (phase == 3) return launch_cells_settle(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stats, db->stream);
+            return launch_cells_stash(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stash, db->stash_mask, db->stream);
         }
         if (phase == 0) return launch_table_count(db->d_lines, db->view(), h.k, keys, n, db->stream);
         return launch_table_insert(db->d_lines, db->view(), h.k, keys, counts, n, db->stream);
@@ -847,13 +850,13 @@ int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, 
         int32_t rc = table_alloc(db, n, counter_size, allow_cells);
         if (rc || n == 0) return rc;
         if (db->fmt == FORMAT_CELLS) {
-            if ((e = launch_cells_count(db->d_pop, kmer_length, db->lbits, d_keys, d_counts, n, db->stream)) != hipSuccess ||
-                (e = launch_cells_insert(db->d_lines, db->d_pop, 1, kmer_length, db->lbits, d_keys, d_counts, n, db->stream)) != hipSuccess ||
-                (e = launch_cells_insert(db->d_lines, db->d_pop, 0, kmer_length, db->lbits, d_keys, d_counts, n, db->stream)) != hipSuccess ||
-                (e = launch_cells_settle(db->d_lines, kmer_length, db->lbits, d_keys, d_counts, n, db->d_stats, db->stream)) != hipSuccess)
+            if ((e = launch_cells_count(db->d_pop, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream)) != hipSuccess ||
+                (e = launch_cells_insert(db->d_lines, db->d_pop, 1, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream)) != hipSuccess ||
+                (e = launch_cells_insert(db->d_lines, db->d_pop, 0, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream)) != hipSuccess ||
+                (e = launch_cells_settle(db->d_lines, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->d_stats, db->stream)) != hipSuccess)
                 return hip_fail(e, "kcfx_db_build insert");
             if ((rc = cells_stash_alloc(db))) return rc;
-            if ((e = launch_cells_stash(db->d_lines, db->info.kmer_length, db->lbits, d_keys, d_counts, n, db->d_stash, db->stash_mask, db->stream)) != hipSuccess ||
+            if ((e = launch_cells_stash(db->d_lines, db->info.kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->d_stash, db->stash_mask, db->stream)) != hipSuccess ||
                 (e = hipStreamSynchronize(db->stream)) != hipSuccess)
                 return hip_fail(e, "kcfx_db_build stash");
         } else {

@@ -219,17 +219,24 @@ KCFX_HD uint32_t cell_alt_sh(uint32_t sh, uint32_t w) { return sh ^ (((w >> 27) 
 // another k-mer goes to the stash only if its own bit is set -- in a k-mer count of sequencing reads nearly every genomic
 // cell is flagged (the error neighbours of the genomic k-mer want the same cell and lose to its larger counter), and
 // every absent reference k-mer would otherwise cost a stash look-up.
-KCFX_HD uint32_t cell_rmask(int32_t lbits) { return (0xFFFFFFFFu >> lbits) | CELL_R_ALT; }       // the bits of r that identify
-KCFX_HD uint32_t cell_spare_bits(int32_t lbits) { return (uint32_t)(lbits - 17); }
-// bit position inside r of the filter bit of a k-mer with flank w (meaningful only when cell_spare_bits(lbits) > 0)
-KCFX_HD uint32_t cell_filter_pos(uint32_t w, int32_t lbits) {
+// A forward-only database (header byte != 0, KMC.java:133; Kmer.java:57-65 then looks k-mers up as the text reads them)
+// may hold a k-mer AND its reverse complement as two records: both have the same N orientation, line, cell, w and
+// rest of G32, so bit 14 of r says which of the two this is (CELL_R_FLIP: the stored word is the reverse complement of
+// N). Such a table needs lbits >= 18 and has one filter bit less. `both` = the database is canonical (both strands).
+constexpr uint32_t CELL_R_FLIP = 0x4000u;
+KCFX_HD uint32_t cell_rmask(int32_t lbits, bool both) {          // the bits of r that identify
+    return (0xFFFFFFFFu >> lbits) | CELL_R_ALT | (both ? 0u : CELL_R_FLIP);
+}
+KCFX_HD uint32_t cell_spare_bits(int32_t lbits, bool both) { return (uint32_t)(lbits - cell_lbits_min(both)); }
+// bit position inside r of the filter bit of a k-mer with flank w (meaningful only when cell_spare_bits() > 0)
+KCFX_HD uint32_t cell_filter_pos(uint32_t w, int32_t lbits, bool both) {
     const uint32_t h = w * 0x9E3779B1u;                         // single-base neighbours must spread: multiplicative hash
     const uint32_t rb = (uint32_t)(32 - lbits);
-    return rb + (uint32_t)(((uint64_t)h * cell_spare_bits(lbits)) >> 32);
+    return rb + (uint32_t)(((uint64_t)h * cell_spare_bits(lbits, both)) >> 32);
 }
 // the bits of a 64-bit cell word that identify the k-mer and carry its counter (flags and filter bits excluded)
-KCFX_HD uint64_t cell_keycount_mask(int32_t lbits) {
-    return 0xFFFF0000FFFFFFFCull | ((uint64_t)cell_rmask(lbits) << 32);
+KCFX_HD uint64_t cell_keycount_mask(int32_t lbits, bool both) {
+    return 0xFFFF0000FFFFFFFCull | ((uint64_t)cell_rmask(lbits, both) << 32);
 }
 
 // Cell tables exist for k = 27 .. 31: the minimizer length is M = k - 15, so that a k-mer always spans 16 M-mers (one DPP
@@ -258,7 +265,7 @@ struct CellProbe {
 
 // Query side, one lane: F / R = the k-mer as the text reads it and its reverse complement, mn = the tagged minimum over
 // the k-mer's 16 M-mers, lane = this lane's position label base (mm27_tagged was fed (lane + offset) & 15).
-KCFX_HD CellProbe cell_probe_of(uint64_t F, uint64_t R, uint32_t mn, uint32_t lane, int32_t lbits, int M) {
+KCFX_HD CellProbe cell_probe_of(uint64_t F, uint64_t R, uint32_t mn, uint32_t lane, int32_t lbits, int M, bool both) {
     const bool flip = (mn & 16u) != 0;                        // the minimizer is canonical on the other strand
     const uint64_t N = flip ? R : F;
     uint32_t sh = ((mn - lane) << 1) & 30u;                   // 2 * offset of the minimizer in F
@@ -269,16 +276,18 @@ KCFX_HD CellProbe cell_probe_of(uint64_t F, uint64_t R, uint32_t mn, uint32_t la
     const uint32_t g = cell_g32(cm);
     p.sh = sh;
     p.line = g >> (32 - lbits);
-    p.r = g & (0xFFFFFFFFu >> lbits);
+    p.r = (g & (0xFFFFFFFFu >> lbits)) | ((!both && flip) ? CELL_R_FLIP : 0u);     // forward-only: F itself is looked up
     return p;
 }
 
-// Build side: every cell a stored canonical k-mer C must be findable in. Normally one; several when the minimum hash
+// Build side: every cell a stored k-mer C (canonical in a both-strands database) must be findable in. Normally one; several when the minimum hash
 // is attained at more than one offset (a repeated M-mer, or two M-mers that agree in their leading 27 hash bits --
 // the query's tie-break depends on the k-mer's alignment in the text, so every tied offset gets a copy), two per offset
-// when the M-mer is its own reverse complement (either strand may be the one the text reads).
+// when the M-mer is its own reverse complement (either strand may be the one the text reads). A forward-only database is
+// asked for C exactly as stored: one orientation per tied offset (the one the query's tag bit selects: rc(m) < m), marked
+// with CELL_R_FLIP when that is the reverse complement.
 constexpr int CELL_MAX_CANDS = 32;
-KCFX_HD int cells_of_key(uint64_t C, int32_t k, int32_t lbits, CellProbe* out) {
+KCFX_HD int cells_of_key(uint64_t C, int32_t k, int32_t lbits, CellProbe* out, bool both) {
     const int M = cell_mlen(k);
     const uint64_t Rc = revcomp_word(C, k);
     uint32_t best = 0xFFFFFFFFu;
@@ -295,6 +304,7 @@ KCFX_HD int cells_of_key(uint64_t C, int32_t k, int32_t lbits, CellProbe* out) {
         for (int strand = 0; strand < 2; ++strand) {
             // strand 0: N = C (needs m canonical), strand 1: N = revcomp(C) (needs rc(m) canonical)
             if (strand == 0 ? (m > r) : (r > m)) continue;
+            if (!both && strand == 1 && r == m) continue;     // (a palindromic M-mer: the query reads it on strand 0)
             const uint64_t N = strand ? Rc : C;
             const uint32_t sh = 2u * (uint32_t)(strand ? 15 - j : j);
             CellProbe p;
@@ -303,7 +313,7 @@ KCFX_HD int cells_of_key(uint64_t C, int32_t k, int32_t lbits, CellProbe* out) {
             const uint32_t g = cell_g32(cm);
             p.sh = sh;
             p.line = g >> (32 - lbits);
-            p.r = g & (0xFFFFFFFFu >> lbits);
+            p.r = (g & (0xFFFFFFFFu >> lbits)) | ((!both && strand == 1) ? CELL_R_FLIP : 0u);
             out[n++] = p;
         }
     }

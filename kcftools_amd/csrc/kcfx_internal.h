@@ -43,7 +43,7 @@ constexpr uint32_t BUILD_COUNT_MASK = 0x00FFFFFFu, BUILD_HEAVY = 0x80000000u;
 constexpr int MODE_KEYHASH = 0, MODE_MINIMIZER = 1;
 
 // ----------------------------------------------------------------------------------------------------
-// FORMAT_CELLS (k = 27 .. 31, both-strands databases -- BASELINE.json's k = 31 among them):
+// FORMAT_CELLS (k = 27 .. 31 -- BASELINE.json's canonical k = 31 among them; forward-only databases: CELL_R_FLIP in kcfx_device.h):
 // the line a k-mer lives in is still chosen by its minimizer (M = k - 15, so that a k-mer spans exactly 16 M-mers), but INSIDE the line the k-mer has exactly one
 // cell: cell index = offset of the minimizer in the k-mer, read on the strand where the minimizer 16-mer is in
 // canonical form ("N orientation"). The 16 k-mers that can share a minimizer occurrence have 16 distinct offsets, so a
@@ -74,6 +74,8 @@ constexpr int MODE_KEYHASH = 0, MODE_MINIMIZER = 1;
 constexpr int FORMAT_LINES = 0, FORMAT_CELLS = 1;
 constexpr int CELL_K_MIN = 27, CELL_K_MAX = 31;               // cell tables: minimizer length k - 15, so that a k-mer spans 16 of them
 constexpr int CELL_LBITS_MIN = 17, CELL_LBITS_MAX = 31;     // r must fit 15 bits (bit 15 marks a second-choice cell); n_lines fits 32
+                                                            // (forward-only databases: 18, bit 14 of r is taken too -- cell_lbits_min)
+__host__ __device__ inline int32_t cell_lbits_min(bool both) { return both ? CELL_LBITS_MIN : CELL_LBITS_MIN + 1; }
 constexpr uint32_t CELL_FLAG_STASH = 1u, CELL_FLAG_MASK = 3u;
 // a cell as one 64-bit word: w in bits 0..31, r in 32..47, count in 48..63
 __host__ __device__ inline uint64_t cell_word(uint32_t w, uint32_t r, uint32_t count) {
@@ -91,6 +93,7 @@ struct TableView {
     uint32_t stash_mask; // FORMAT_CELLS: stash slots - 1 (a power of two)
     const uint4* stash;
     int32_t generic;     // screen with the general kernel whatever k / M (test and A/B hook, fixed when the handle is made)
+    int32_t both;        // the database is canonical (both strands); 0: k-mers are looked up as the text reads them
 };
 
 // ----------------------------------------------------------------------------------------------------
@@ -236,12 +239,14 @@ hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide,
 // (cells_pop_bytes of zeroed scratch), bids of the crowded class (cls 1), bids of the others (cls 0), settle the losers into
 // second-choice cells or flag them for the stash (stats[0] = how many), fill the stash
 size_t cells_pop_bytes(int32_t lbits);
-hipError_t launch_cells_count(uint32_t* pop32, int32_t k, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n, hipStream_t st);
-hipError_t launch_cells_insert(uint8_t* lines, const uint32_t* pop32, int32_t cls, int32_t k, int32_t lbits, const uint64_t* keys,
+// (both = the database is canonical; see CELL_R_FLIP in kcfx_device.h for what a forward-only one changes)
+hipError_t launch_cells_count(uint32_t* pop32, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
+                              hipStream_t st);
+hipError_t launch_cells_insert(uint8_t* lines, const uint32_t* pop32, int32_t cls, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys,
                                const uint32_t* counts, int64_t n, hipStream_t st);
-hipError_t launch_cells_settle(uint8_t* lines, int32_t k, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n,
+hipError_t launch_cells_settle(uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
                                unsigned long long* stats, hipStream_t st);
-hipError_t launch_cells_stash(const uint8_t* lines, int32_t k, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n,
+hipError_t launch_cells_stash(const uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
                               uint4* stash, uint32_t stash_mask, hipStream_t st);
 // lookup
 hipError_t launch_lookup(TableView tv, int32_t k, const uint64_t* keys, int64_t n, int32_t* counts_out, hipStream_t st);

@@ -207,14 +207,14 @@ __device__ __forceinline__ uint64_t cell_sub_bucket(const CellProbe& p, int32_t 
 
 // Pass 0: k-mers per sub-bucket, one byte each (a byte that overflows spills into its neighbour: the classes are a
 // heuristic, see above)
-__global__ void cells_count_kernel(uint32_t* pop32, int32_t k, int32_t lbits, const uint64_t* __restrict__ keys,
+__global__ void cells_count_kernel(uint32_t* pop32, int32_t k, int32_t lbits, int32_t both, const uint64_t* __restrict__ keys,
                                    const uint32_t* __restrict__ counts, int64_t n) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         if (counts[i] == 0) continue;
         CellProbe cand[CELL_MAX_CANDS];
-        cells_of_key(keys[i], k, lbits, cand);
+        cells_of_key(keys[i], k, lbits, cand, both != 0);
         const uint64_t sub = cell_sub_bucket(cand[0], lbits);
         atomicAdd(&pop32[sub >> 2], 1u << (8 * (uint32_t)(sub & 3)));
     }
@@ -224,7 +224,7 @@ __global__ void cells_count_kernel(uint32_t* pop32, int32_t k, int32_t lbits, co
 // cell(s). Crowded k-mers bid with a 64-bit atomic max -- the count is the most significant field, so the most abundant
 // one gets the cell whatever the arrival order. The others do the same among themselves (a CAS loop), but never replace a
 // crowded occupant.
-__global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__ pop32, int32_t cls, int32_t k, int32_t lbits,
+__global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__ pop32, int32_t cls, int32_t k, int32_t lbits, int32_t both,
                                     const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, int64_t n) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -233,7 +233,7 @@ __global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__
         if (c == 0) continue;                       // can never be observed (count >= -c >= 1 is needed): not stored
         if (c > CELL_COUNT_MAX) continue;           // a 3- / 4-byte counter that does not fit a cell: lives in the stash (settle)
         CellProbe cand[CELL_MAX_CANDS];
-        const int nc = cells_of_key(keys[i], k, lbits, cand);
+        const int nc = cells_of_key(keys[i], k, lbits, cand, both != 0);
         const uint64_t sub = cell_sub_bucket(cand[0], lbits);
         const bool crowded = ((pop32[sub >> 2] >> (8 * (uint32_t)(sub & 3))) & 0xFFu) >= CELL_CROWD;
         if ((int32_t)crowded != cls) continue;
@@ -255,8 +255,8 @@ __global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__
 }
 
 // where a k-mer stands after the bidding: in its first-choice cell, in its second-choice cell, or in neither
-__device__ __forceinline__ int cell_standing(const uint8_t* lines, const CellProbe& p, uint32_t c, int32_t lbits) {
-    const uint64_t kc = cell_keycount_mask(lbits);              // (flags and stash-filter bits are not part of the k-mer)
+__device__ __forceinline__ int cell_standing(const uint8_t* lines, const CellProbe& p, uint32_t c, int32_t lbits, bool both) {
+    const uint64_t kc = cell_keycount_mask(lbits, both);              // (flags and stash-filter bits are not part of the k-mer)
     const uint8_t* line = lines + (size_t)p.line * LINE_BYTES;
     const uint64_t first = __atomic_load_n(reinterpret_cast<const uint64_t*>(line + 4 * p.sh), __ATOMIC_RELAXED);
     if ((first & kc) == cell_word(p.w, p.r, c)) return 0;
@@ -269,23 +269,24 @@ __device__ __forceinline__ int cell_standing(const uint8_t* lines, const CellPro
 // k-mer has it as first choice then), else it flags its first-choice cell -- "someone who belongs here lives in the
 // stash", and which filter bit that someone has (cell_filter_pos) -- and is counted. stats[0] = k-mers for the stash, [1] = k-mers stored (count != 0), [2] = k-mers with more
 // than one first-choice cell, [3] = second-choice placements
-__global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, const uint64_t* __restrict__ keys,
+__global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, int32_t both_i, const uint64_t* __restrict__ keys,
                                     const uint32_t* __restrict__ counts, int64_t n, unsigned long long* stats) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     uint32_t n_lost = 0, n_stored = 0, n_multi = 0, n_second = 0;      // per lane; one atomic per wave at the end
+    const bool both = both_i != 0;
     for (; i < n; i += stride) {
         const uint32_t c = counts[i];
         if (c == 0) continue;
         CellProbe cand[CELL_MAX_CANDS];
-        const int nc = cells_of_key(keys[i], k, lbits, cand);
+        const int nc = cells_of_key(keys[i], k, lbits, cand, both);
         bool lost = false;
-        const uint64_t kc = cell_keycount_mask(lbits);
+        const uint64_t kc = cell_keycount_mask(lbits, both);
         if (c > CELL_COUNT_MAX) {
             // never bid: every cell a query could derive for it is flagged (whoever lives there, or nobody), with its filter bit
             for (int a = 0; a < nc; ++a) {
                 unsigned long long mark = CELL_FLAG_STASH;
-                if (cell_spare_bits(lbits) > 0) mark |= 1ull << (32 + cell_filter_pos(cand[a].w, lbits));
+                if (cell_spare_bits(lbits, both) > 0) mark |= 1ull << (32 + cell_filter_pos(cand[a].w, lbits, both));
                 atomicOr(reinterpret_cast<unsigned long long*>(lines + (size_t)cand[a].line * LINE_BYTES + 4 * cand[a].sh), mark);
             }
             ++n_lost;
@@ -294,7 +295,7 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, co
             continue;
         }
         for (int a = 0; a < nc; ++a) {
-            if (cell_standing(lines, cand[a], c, lbits) != 2) continue;     // (1: the same word twice in the input)
+            if (cell_standing(lines, cand[a], c, lbits, both) != 2) continue;     // (1: the same word twice in the input)
             uint8_t* line = lines + (size_t)cand[a].line * LINE_BYTES;
             unsigned long long* alt = reinterpret_cast<unsigned long long*>(line + 4 * cell_alt_sh(cand[a].sh, cand[a].w));
             const unsigned long long mine = cell_word(cand[a].w, cand[a].r | CELL_R_ALT, c);
@@ -312,7 +313,7 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, co
                 ++n_second;
             } else if ((old & kc) != mine) {
                 unsigned long long mark = CELL_FLAG_STASH;
-                if (cell_spare_bits(lbits) > 0) mark |= 1ull << (32 + cell_filter_pos(cand[a].w, lbits));
+                if (cell_spare_bits(lbits, both) > 0) mark |= 1ull << (32 + cell_filter_pos(cand[a].w, lbits, both));
                 atomicOr(reinterpret_cast<unsigned long long*>(line + 4 * cand[a].sh), mark);
                 lost = true;
             }
@@ -332,7 +333,7 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, co
 }
 
 // Pass 3 (after pass 2 has completed): a k-mer that stands in neither cell of one of its candidates goes to the stash.
-__global__ void cells_stash_kernel(const uint8_t* __restrict__ lines, int32_t k, int32_t lbits, const uint64_t* __restrict__ keys,
+__global__ void cells_stash_kernel(const uint8_t* __restrict__ lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* __restrict__ keys,
                                    const uint32_t* __restrict__ counts, int64_t n, uint4* stash, uint32_t mask) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -343,8 +344,8 @@ __global__ void cells_stash_kernel(const uint8_t* __restrict__ lines, int32_t k,
         bool lost = c > CELL_COUNT_MAX;                 // (counters wider than a cell's 16 bits)
         if (!lost) {
             CellProbe cand[CELL_MAX_CANDS];
-            const int nc = cells_of_key(key, k, lbits, cand);
-            for (int a = 0; a < nc; ++a) lost |= cell_standing(lines, cand[a], c, lbits) == 2;
+            const int nc = cells_of_key(key, k, lbits, cand, both != 0);
+            for (int a = 0; a < nc; ++a) lost |= cell_standing(lines, cand[a], c, lbits, both != 0) == 2;
         }
         if (!lost) continue;
         uint32_t slot = stash_slot(key, mask);
@@ -374,27 +375,28 @@ __device__ __forceinline__ uint32_t stash_find(const TableView& tv, uint64_t key
 }
 
 // batched KMC.getCount on a FORMAT_CELLS table, one lane per key (utility path)
-__global__ __launch_bounds__(256) void lookup_cells_kernel(TableView tv, int32_t k, const uint64_t* __restrict__ keys, int64_t n,
+__global__ __launch_bounds__(256) void lookup_cells_kernel(TableView tv, int32_t k, int32_t both_i, const uint64_t* __restrict__ keys, int64_t n,
                                                            int32_t* __restrict__ out) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         const uint64_t key = keys[i];
         int32_t result = 0;
-        // only canonical words are stored (both-strands database); a k-mer word has its low 64 - 2k bits clear
-        if (key <= revcomp_word(key, k) && (key & ~(~0ull << (64 - 2 * k))) == 0) {
+        // a both-strands database stores only canonical words; a k-mer word has its low 64 - 2k bits clear
+        const bool both = both_i != 0;
+        if ((!both || key <= revcomp_word(key, k)) && (key & ~(~0ull << (64 - 2 * k))) == 0) {
             CellProbe cand[CELL_MAX_CANDS];
-            cells_of_key(key, k, tv.lbits, cand);               // any one of its cells decides
+            cells_of_key(key, k, tv.lbits, cand, both);         // any one of its cells decides
             const uint8_t* line = tv.lines + (size_t)cand[0].line * LINE_BYTES;
             const uint64_t first = *reinterpret_cast<const uint64_t*>(line + 4 * cand[0].sh);
             const uint64_t second = *reinterpret_cast<const uint64_t*>(line + 4 * cell_alt_sh(cand[0].sh, cand[0].w));
-            const uint64_t KEY_BITS = cell_keycount_mask(tv.lbits) & 0x0000FFFFFFFFFFFFull;     // w without the flags, r without the filter
+            const uint64_t KEY_BITS = cell_keycount_mask(tv.lbits, both) & 0x0000FFFFFFFFFFFFull;     // w without the flags, r without the filter
             if (((first ^ cell_word(cand[0].w, cand[0].r, 0)) & KEY_BITS) == 0 && (first >> 48) != 0)
                 result = (int32_t)(first >> 48);
             else if (((second ^ cell_word(cand[0].w, cand[0].r | CELL_R_ALT, 0)) & KEY_BITS) == 0 && (second >> 48) != 0)
                 result = (int32_t)(second >> 48);
             else if ((first & CELL_FLAG_STASH) &&
-                     (cell_spare_bits(tv.lbits) == 0 || ((first >> (32 + cell_filter_pos(cand[0].w, tv.lbits))) & 1)))
+                     (cell_spare_bits(tv.lbits, both) == 0 || ((first >> (32 + cell_filter_pos(cand[0].w, tv.lbits, both))) & 1)))
                 result = (int32_t)stash_find(tv, key);
         }
         out[i] = result;
@@ -1020,14 +1022,15 @@ __device__ __forceinline__ void cells_issue(const TableView& tv, uint64_t V, con
 
 // stage B: cnt = the stored counter if the cell holds this lane's k-mer (else 0), pend != 0 if it does not and the cell is
 // flagged for the stash
+template <bool BOTH>
 __device__ __forceinline__ void cells_match(const CellWord& cw, int32_t lbits, uint32_t& cnt, uint32_t& pend) {
     const bool valid = __builtin_amdgcn_inverse_ballot_w64(cw.V);
-    const uint32_t rmask = cell_rmask(lbits);                   // (wave-uniform: scalar registers)
-    const bool filtered = cell_spare_bits(lbits) > 0;
+    const uint32_t rmask = cell_rmask(lbits, BOTH);             // (wave-uniform: scalar registers)
+    const bool filtered = cell_spare_bits(lbits, BOTH) > 0;
     // (cell_filter_pos with its two wave-uniform terms pinned to scalar registers: one v_add instead of a sub + add pair)
     uint32_t rb = (uint32_t)(32 - lbits);
     asm volatile("" : "+s"(rb));
-    const uint32_t nspare = cell_spare_bits(lbits);
+    const uint32_t nspare = cell_spare_bits(lbits, BOTH);
     if (valid) {
         const uint32_t x = cw.cell.x, y = cw.cell.y, xa = cw.alt.x, ya = cw.alt.y;
         // (cw.r has no bits outside rmask and bit 15 clear; xor + and fuse into one v_bitop3)
@@ -1043,8 +1046,9 @@ __device__ __forceinline__ void cells_match(const CellWord& cw, int32_t lbits, u
     }
 }
 
-// canonical k-mer (Kmer.java:72-79) at packed position q of the tile, from the interleaved code words
-template <int K>
+// the k-mer as the database stores it -- canonical (Kmer.java:72-79), or as the text reads it in a forward-only database
+// (Kmer.java:57-65) -- at packed position q of the tile, from the interleaved code words
+template <int K, bool BOTH>
 __device__ __forceinline__ uint64_t k31_canonical_at(const K31Pack& sh, int q) {
     constexpr uint32_t lo_mask = ~0u << (64 - 2 * K);
     const int b0 = 2 * q - 1;
@@ -1053,12 +1057,12 @@ __device__ __forceinline__ uint64_t k31_canonical_at(const K31Pack& sh, int q) {
     const uint2 x = p[0], y = p[1], z = p[2];
     const uint64_t fwd = u64_of(alignbit32(y.x, z.x, s) & lo_mask, alignbit32(x.x, y.x, s));
     const uint64_t rc = u64_of(brev32(alignbit32(x.y, y.y, s)), brev32(alignbit32(y.y, z.y, s) & lo_mask)) << (64 - 2 * K);
-    return rc < fwd ? rc : fwd;
+    return (BOTH && rc < fwd) ? rc : fwd;
 }
 
 // Stash lookups for the first min(qn, 64) queued k-mers (their keys are re-derived from the packed tile: the queue only
 // holds where they sit); returns the new qn.
-template <int K>
+template <int K, bool BOTH>
 __device__ __forceinline__ int k31c_stash_round(const TableView& tv, const K31Pack& sh, K31CQueue& q, int lane, int qn, int pos0,
                                                 int32_t min_count, uint32_t& sum_acc, int64_t& big_acc) {
     const int nb = min(qn, 64), rest = qn - nb;
@@ -1067,7 +1071,7 @@ __device__ __forceinline__ int k31c_stash_round(const TableView& tv, const K31Pa
     wave_lds_fence();
     if (lane < rest) q.id[lane] = i2;                       // the entries behind the batch move to the front
     uint32_t cnt = 0;
-    if (lane < nb) cnt = stash_find(tv, k31_canonical_at<K>(sh, pos0 + (int)id));
+    if (lane < nb) cnt = stash_find(tv, k31_canonical_at<K, BOTH>(sh, pos0 + (int)id));
     const bool hit = (int32_t)cnt >= min_count;             // cnt is 0 unless found; GetVariants.java:224
     if (hit) atomicOr(&q.hit[id >> 6], 1ull << (id & 63));
     const bool big = cnt > CELL_COUNT_MAX;                  // only a 3- / 4-byte counter: its own 64-bit sum (GetVariants.java:226)
@@ -1077,7 +1081,7 @@ __device__ __forceinline__ int k31c_stash_round(const TableView& tv, const K31Pa
     return rest;
 }
 
-template <int K>
+template <int K, bool BOTH>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void screen_k31c_kernel(
     const uint8_t* __restrict__ text, const TileDesc* __restrict__ tiles, TableView tv, int32_t min_count,
     uint64_t* __restrict__ bits, int64_t* __restrict__ count_sums) {
@@ -1107,13 +1111,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         uint64_t fwd, rc, V;
         uint32_t mn;
         words.next(w, fwd, rc, mn, V);
-        const CellProbe p = cell_probe_of(fwd, rc, mn, (uint32_t)lane, tv.lbits, cell_mlen(K));
+        const CellProbe p = cell_probe_of(fwd, rc, mn, (uint32_t)lane, tv.lbits, cell_mlen(K), BOTH);
         cells_issue(tv, V, p, cw);
     };
     // stage B of word w: cells matched, ballots out, stash candidates queued
     auto retire = [&](int w, const CellWord& cw) {
         uint32_t cnt = 0, pend = 0;
-        cells_match(cw, tv.lbits, cnt, pend);
+        cells_match<BOTH>(cw, tv.lbits, cnt, pend);
         // cnt is 0 unless the k-mer was found and min_count >= 1 (checked by the API), so this is "found && count >= -c"
         const bool hit = (int32_t)cnt >= min_count;                         // GetVariants.java:224
         const uint64_t H = wave_ballot(hit);
@@ -1129,7 +1133,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             qn += __popcll(PM);
         }
         wave_lds_fence();
-        while (qn >= 64) qn = k31c_stash_round<K>(tv, sh, q, lane, qn, pos0, min_count, sum_acc, big_acc);
+        while (qn >= 64) qn = k31c_stash_round<K, BOTH>(tv, sh, q, lane, qn, pos0, min_count, sum_acc, big_acc);
     };
     // Two words per trip so that the two CellWords stay in fixed registers; the steady-state trip has no condition around
     // an issue (see cells_issue), the last one or two words are peeled.
@@ -1151,7 +1155,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             retire(w, a);
         }
     }
-    while (qn > 0) qn = k31c_stash_round<K>(tv, sh, q, lane, qn, pos0, min_count, sum_acc, big_acc);
+    while (qn > 0) qn = k31c_stash_round<K, BOTH>(tv, sh, q, lane, qn, pos0, min_count, sum_acc, big_acc);
     if (lane < w_end - w_begin) {                           // the wave's words of the window's bitmap
         my_bits[w_begin + lane] = q.vw[lane];
         my_bits[TILE_WORDS + w_begin + lane] = q.hit[lane];
@@ -1480,32 +1484,33 @@ hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide,
     return hipGetLastError();
 }
 
-hipError_t launch_cells_count(uint32_t* pop32, int32_t k, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n, hipStream_t st) {
+hipError_t launch_cells_count(uint32_t* pop32, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
+                              hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(cells_count_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, pop32, k, lbits, keys, counts, n);
+    hipLaunchKernelGGL(cells_count_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, pop32, k, lbits, both, keys, counts, n);
     return hipGetLastError();
 }
 
-hipError_t launch_cells_insert(uint8_t* lines, const uint32_t* pop32, int32_t cls, int32_t k, int32_t lbits, const uint64_t* keys,
+hipError_t launch_cells_insert(uint8_t* lines, const uint32_t* pop32, int32_t cls, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys,
                                const uint32_t* counts, int64_t n, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(cells_insert_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, pop32, cls, k, lbits, keys, counts, n);
+    hipLaunchKernelGGL(cells_insert_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, pop32, cls, k, lbits, both, keys, counts, n);
     return hipGetLastError();
 }
 
 size_t cells_pop_bytes(int32_t lbits) { return (size_t)1 << (lbits + cell_sub_bits(lbits)); }
 
-hipError_t launch_cells_settle(uint8_t* lines, int32_t k, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n,
+hipError_t launch_cells_settle(uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
                                unsigned long long* stats, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(cells_settle_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, k, lbits, keys, counts, n, stats);
+    hipLaunchKernelGGL(cells_settle_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, k, lbits, both, keys, counts, n, stats);
     return hipGetLastError();
 }
 
-hipError_t launch_cells_stash(const uint8_t* lines, int32_t k, int32_t lbits, const uint64_t* keys, const uint32_t* counts, int64_t n,
+hipError_t launch_cells_stash(const uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
                               uint4* stash, uint32_t stash_mask, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(cells_stash_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, k, lbits, keys, counts, n, stash,
+    hipLaunchKernelGGL(cells_stash_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, k, lbits, both, keys, counts, n, stash,
                        stash_mask);
     return hipGetLastError();
 }
@@ -1513,7 +1518,7 @@ hipError_t launch_cells_stash(const uint8_t* lines, int32_t k, int32_t lbits, co
 hipError_t launch_lookup(TableView tv, int32_t k, const uint64_t* keys, int64_t n, int32_t* counts_out, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     if (tv.fmt == FORMAT_CELLS) {
-        hipLaunchKernelGGL(lookup_cells_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, tv, k, keys, n, counts_out);
+        hipLaunchKernelGGL(lookup_cells_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, tv, k, tv.both, keys, n, counts_out);
         return hipGetLastError();
     }
     const dim3 g(grid_for(n * 8, 256, 256 * 16)), b(256);
@@ -1547,7 +1552,13 @@ hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32
     hipExtLaunchKernelGGL((screen_k31_kernel<W, BS>), g, b, 0, st, ev_start, ev_stop, 0, text, tiles, tv, min_count, bits, count_sums)
     const bool generic_only = tv.generic != 0;                                      // A/B and test hook, fixed at kcfx_db_open
     if (tv.fmt == FORMAT_CELLS) {
-#define KCFX_LAUNCHC(KK) hipExtLaunchKernelGGL((screen_k31c_kernel<KK>), g, b, 0, st, ev_start, ev_stop, 0, text, tiles, tv, min_count, bits, count_sums)
+#define KCFX_LAUNCHC(KK)                                                                                                                  \
+    do {                                                                                                                                  \
+        if (both_strands)                                                                                                                 \
+            hipExtLaunchKernelGGL((screen_k31c_kernel<KK, true>), g, b, 0, st, ev_start, ev_stop, 0, text, tiles, tv, min_count, bits, count_sums);  \
+        else                                                                                                                              \
+            hipExtLaunchKernelGGL((screen_k31c_kernel<KK, false>), g, b, 0, st, ev_start, ev_stop, 0, text, tiles, tv, min_count, bits, count_sums); \
+    } while (0)
         switch (k) {
             case 27: KCFX_LAUNCHC(27); break;
             case 28: KCFX_LAUNCHC(28); break;

@@ -149,7 +149,8 @@ int harness_minimizers(const uint8_t* text, int64_t text_off, int n_kmers, int k
 // hashes, sliding minimum, cell_probe_of -- what screen_k31c_kernel does in registers) must be one of the cells the
 // build side stores the canonical k-mer in (cells_of_key). Returns the number of positions where it is not (0 = pass);
 // n_cands_out[j] = number of build-side candidates, probe_out[4 j ..] = the query-side (line, sh, w, r).
-int harness_cells(const uint8_t* text, int64_t text_off, int n_kmers, int k, int lbits, int32_t* n_cands_out, uint32_t* probe_out) {
+// both = 0: a forward-only database -- the k-mer is stored, and looked up, exactly as the text reads it.
+int harness_cells(const uint8_t* text, int64_t text_off, int n_kmers, int k, int lbits, int both, int32_t* n_cands_out, uint32_t* probe_out) {
     const int M = cell_mlen(k);
     Packed P = pack_tile(text, text_off, n_kmers, k);
     std::vector<uint32_t> h(n_kmers + 16);
@@ -164,9 +165,9 @@ int harness_cells(const uint8_t* text, int64_t text_off, int n_kmers, int k, int
         for (int t = 1; t < 16; ++t) mn = std::min(mn, h[j + t]);
         uint64_t F, R;
         extract_pair(P.fw(), P.cw(), P.off + j, k, F, R);
-        const CellProbe q = cell_probe_of(F, R, mn, (uint32_t)j & 63u, lbits, M);
+        const CellProbe q = cell_probe_of(F, R, mn, (uint32_t)j & 63u, lbits, M, both != 0);
         CellProbe c[CELL_MAX_CANDS];
-        const int n = cells_of_key(F < R ? F : R, k, lbits, c);
+        const int n = cells_of_key((both && R < F) ? R : F, k, lbits, c, both != 0);
         bool ok = false;
         for (int i = 0; i < n; ++i) ok |= c[i].line == q.line && c[i].sh == q.sh && c[i].w == q.w && c[i].r == q.r;
         if (!ok) ++bad;
@@ -179,9 +180,9 @@ int harness_cells(const uint8_t* text, int64_t text_off, int n_kmers, int k, int
     return bad;
 }
 // injectivity spot check: the cells of two different canonical k-mers never coincide in (line, sh, w, r)
-int harness_cells_of_key(uint64_t C, int k, int lbits, uint32_t* out) {
+int harness_cells_of_key(uint64_t C, int k, int lbits, int both, uint32_t* out) {
     CellProbe c[CELL_MAX_CANDS];
-    const int n = cells_of_key(C, k, lbits, c);
+    const int n = cells_of_key(C, k, lbits, c, both != 0);
     for (int i = 0; i < n; ++i) {
         out[4 * i] = c[i].line;
         out[4 * i + 1] = c[i].sh;

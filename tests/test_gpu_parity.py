@@ -66,7 +66,7 @@ def test_lookup_matches_getcount(oracle, tmp_path, k, p, cs, m, bins, both):
     odb = oracle.OracleDb(prefix)
     i = db.info
     assert (i.kmer_length, i.lut_prefix_length, i.counter_size, i.signature_length, i.n_bins) == (k, p, cs, m, bins)
-    assert i.table_format == (1 if (27 <= k <= 31 and both) else 0)
+    assert i.table_format == (1 if 27 <= k <= 31 else 0)
     assert i.minimizer_length == k - 15 if i.table_format == 1 else True
     assert bool(i.both_strands) == both and i.total_kmers == len(kmers) and i.version == 0x200
     assert i.min_count == prm.min_count and i.max_count == int(np.int32(np.uint32(prm.max_count)))   # Java int (KMC.java:131)
@@ -242,6 +242,46 @@ def test_wide_counters_in_a_cell_table(oracle, tmp_path, cs):
     assert_same(db2.screen(ref, s, e - s, 1), odb.screen(ref, s, e - s, 1, threads=4), "array build")
 
 
+def test_forward_only_database_holds_a_kmer_and_its_reverse_complement(oracle, tmp_path):
+    """Header byte != 0 (KMC.java:133): k-mers are looked up as the text reads them (Kmer.java:57-65), and the database may
+    hold a k-mer AND its reverse complement as two records with different counters. In a cell table both have the same
+    line, cell, flank and rest of the hash; bit 14 of r tells them apart. Here every k-mer of the text is stored with one
+    counter and its reverse complement with another (some only one way round), and the text is screened on both strands."""
+    k = 31
+    fwd = bytearray(synth.random_reference(40_000, 41, n_run_every=0, lower_frac=0, iupac_rate=0))
+    fwd[5_000:5_016] = b"ACGTACGTACGTACGT"                 # a reverse-palindromic 16-mer as a minimizer candidate
+    fwd[9_000:9_060] = b"A" * 60
+    fwd = bytes(fwd)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    text = fwd + b"N" + fwd.translate(comp)[::-1]
+    a = np.unique(synth.kmers_of_text(fwd, k, False))
+    b = synth.revcomp(a, k)
+    keep_a = (np.arange(len(a)) % 5) != 0                  # a fifth of them only as reverse complement ...
+    keep_b = (np.arange(len(a)) % 7) != 0                  # ... a seventh only forward
+    kmers = np.concatenate([a[keep_a], b[keep_b]])
+    counts = np.concatenate([np.full(int(keep_a.sum()), 11), 100 + (np.arange(int(keep_b.sum())) % 50)]).astype(np.uint64)
+    kmers, first = np.unique(kmers, return_index=True)     # (a k-mer that is its own reverse complement cannot occur: k is odd)
+    counts = counts[first]
+    for cs in (1, 4):
+        prm = synth.KmcParams(k=k, p=3, counter_size=cs, sig_len=7, n_bins=4, both_strands=False, max_count=(1 << (8 * cs)) - 1)
+        prefix = str(tmp_path / f"fwd{cs}")
+        synth.write_kmc(prefix, kmers, counts, prm)
+        db = engine.KmcDb.open(prefix)
+        assert db.info.table_format == 1 and not db.info.both_strands and db.info.table_lines >= 1 << 18
+        odb = oracle.OracleDb(prefix)
+        assert np.array_equal(db.lookup(kmers), counts.astype(np.int32))
+        absent = a[~keep_a][:2000]
+        assert not db.lookup(absent).any() and not db.lookup(b[~keep_b][:2000]).any()
+        s, e = engine.windows(len(text), 3_000, 0, k)
+        for c in (1, 12, 120):
+            assert_same(db.screen(text, s, e - s, c), odb.screen(text, s, e - s, c, threads=4), f"forward-only cs {cs} -c {c}")
+        got = db.screen(text, [0, len(fwd) + 1], [len(fwd), len(fwd)], 1)
+        assert got["kmer_count_sum"][0] != got["kmer_count_sum"][1]          # the two strands see different counters
+        db2 = engine.KmcDb.build(kmers, counts, k, cs, False)
+        assert db2.info.table_format == 1
+        assert_same(db2.screen(text, s, e - s, 1), odb.screen(text, s, e - s, 1, threads=4), "array build")
+
+
 def test_config1_scale(oracle, tmp_path):
     """BASELINE.json configs[0]: synthetic 1 Mb FASTA, 1 KMC sample, k=31, 10 kb windows (101 windows), full compare"""
     k = 31
@@ -408,7 +448,7 @@ def test_k31_specialised_and_generic_kernels_agree(oracle, tmp_path, cs, both, m
     prefix, *_ = make_db(tmp_path, "both", ref, 9, k=k, p=3, cs=cs, m=7, bins=8, both=both, noise=20_000)
     db = engine.KmcDb.open(prefix)
     assert db.info.minimizer_length == 16
-    assert db.info.table_format == (1 if both else 0)
+    assert db.info.table_format == 1
     odb = oracle.OracleDb(prefix)
     begins = np.concatenate([np.arange(0, 390_000, 7_777), [399_000, 399_969, 399_970]]).astype(np.int64)
     lens = np.minimum(len(ref) - begins, 9_999).astype(np.int32)
@@ -472,9 +512,8 @@ def test_multi_sample_pass_equals_single_sample_passes(oracle, tmp_path):
 def test_fuzz_window_geometry_against_oracle(oracle, tmp_path, seed, kernel, monkeypatch):
     """Random databases x windows whose lengths sit on the kernel's internal borders (k-mer count 0 / 1 / 63 / 64 / 65,
     one tile +-1, several tiles +-1, word-aligned and not), random offsets (every alignment of the 32-base pack chunks),
-    N runs crossing window and tile borders, soft-masked stretches. k = 31 runs screen_k31c_kernel on a cell table when the
-    database is canonical, else screen_k31_kernel on a line table ("lines" forces that
-    one, "generic" the general screen_tiles_kernel); both strandedness and all counter widths come up over the seeds."""
+    N runs crossing window and tile borders, soft-masked stretches. k = 27 .. 31 runs screen_k31c_kernel on a cell table
+    ("lines" forces screen_k31_kernel on a 12-slot line table, "generic" the general screen_tiles_kernel); both strandedness and all counter widths come up over the seeds."""
     if kernel == "generic":
         monkeypatch.setenv("KCFX_GENERIC_KERNEL", "1")
     if kernel == "lines":
@@ -495,10 +534,10 @@ def test_fuzz_window_geometry_against_oracle(oracle, tmp_path, seed, kernel, mon
     cs = int(rng.choice([1, 2, 4]))
     both = bool(rng.integers(0, 2))
     noise = 5_000
-    if kernel == "default":                 # always the cell table (canonical); all counter widths
-        cs, both = 1 + seed % 4, True
-        if seed % 3 == 1:                   # a crowded table: 2^17 lines for ~1.4 M k-mers, most of them in second choices / the stash
-            monkeypatch.setenv("KCFX_TABLE_LBITS", "17")
+    if kernel == "default":                 # always the cell table; all counter widths, canonical and forward-only
+        cs, both = 1 + seed % 4, (seed // 2) % 3 != 0
+        if seed % 3 == 1:                   # a crowded table: 2^17 (2^18) lines for ~1.4 M k-mers, most of them in second choices / the stash
+            monkeypatch.setenv("KCFX_TABLE_LBITS", "17" if both else "18")
             noise = 1_200_000
         elif seed % 3 == 2:                 # a few filter bits
             monkeypatch.setenv("KCFX_TABLE_LBITS", str(18 + seed % 4))

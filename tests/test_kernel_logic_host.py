@@ -47,8 +47,8 @@ def harness():
     L.harness_revcomp_word.argtypes = [C.c_uint64, C.c_int]
     L.harness_revcomp_word.restype = C.c_uint64
     L.harness_gap_both.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p]
-    L.harness_cells.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    L.harness_cells_of_key.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_void_p]
+    L.harness_cells.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.harness_cells_of_key.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p]
     return L
 
 
@@ -239,26 +239,32 @@ def test_cell_table_build_side_covers_query_side(harness, oracle):
             text[1600:1700] + pal2 * 3 + text[1700:2500] + text[2000:2300] + b"N" + text[2500:])
     buf = padded(text)
     seen = {}
-    for k, lbits in ((31, 17), (31, 19), (31, 27), (31, 30), (30, 21), (29, 19), (29, 26), (28, 20), (27, 17), (27, 22)):
+    # both = 0: a forward-only database stores (and is asked for) the k-mer as the text reads it; bit 14 of r tells it from
+    # its reverse complement, so such a table starts at lbits 18
+    for k, lbits, both in ((31, 17, 1), (31, 19, 1), (31, 27, 1), (31, 30, 1), (30, 21, 1), (29, 19, 1), (29, 26, 1), (28, 20, 1),
+                           (27, 17, 1), (27, 22, 1), (31, 18, 0), (31, 19, 0), (31, 30, 0), (29, 19, 0), (27, 18, 0), (28, 24, 0)):
         for begin in (0, 1, 7, 33, 64, 501):
             n = min(2048, len(text) - begin - k + 1)
             ncand = np.zeros(n, dtype=np.int32)
             probe = np.zeros(4 * n, dtype=np.uint32)
-            bad = harness.harness_cells(buf.ctypes.data, begin, n, k, lbits, ncand.ctypes.data, probe.ctypes.data)
-            assert bad == 0, (k, lbits, begin)
+            bad = harness.harness_cells(buf.ctypes.data, begin, n, k, lbits, both, ncand.ctypes.data, probe.ctypes.data)
+            assert bad == 0, (k, lbits, both, begin)
             assert ncand.min() >= 1 and ncand.max() <= 32
             if lbits == 19:
-                assert (ncand > 1).sum() > 50          # the tie / palindrome paths were exercised
+                assert (ncand > 1).sum() > (50 if both else 25)          # the tie / palindrome paths were exercised
                 assert (ncand == 1).mean() > 0.8
     # injectivity over every cell of every distinct canonical k-mer of the text (valid positions only)
     out = np.zeros(4 * 32, dtype=np.uint32)
-    for k, lbits in ((31, 17), (31, 24), (29, 20), (27, 18)):
+    for k, lbits, both in ((31, 17, 1), (31, 24, 1), (29, 20, 1), (27, 18, 1), (31, 18, 0), (29, 21, 0)):
         lst = np.zeros(len(text), dtype=np.uint64)
         m = oracle.lib().kcfo_kmers_list(text, len(text), k, lst.ctypes.data)
-        canon = np.unique(np.minimum(lst[:m], synth.revcomp(lst[:m], k)))
+        if both:
+            canon = np.unique(np.minimum(lst[:m], synth.revcomp(lst[:m], k)))
+        else:                                          # a forward-only database may hold a k-mer AND its reverse complement
+            canon = np.unique(np.concatenate([lst[:m], synth.revcomp(lst[:m], k)]))
         seen = {}
         for c in canon:
-            nc = harness.harness_cells_of_key(int(c), k, lbits, out.ctypes.data)
+            nc = harness.harness_cells_of_key(int(c), k, lbits, both, out.ctypes.data)
             for i in range(nc):
                 cell = tuple(int(x) for x in out[4 * i:4 * i + 4])
                 assert seen.setdefault(cell, int(c)) == int(c), (k, lbits, hex(int(c)), hex(seen[cell]))
