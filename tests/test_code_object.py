@@ -1,0 +1,56 @@
+"""What hipcc made of the kernels, read from the gfx950 code object inside libkcfx.so (no GPU needed): the screening
+kernels must not spill (no scratch), must fit the register budget their occupancy is planned with (<= 64 VGPRs = 8 waves per
+SIMD) and the LDS a workgroup takes must allow 8 workgroups per CU. A change that silently breaks one
+of these costs tens of per cent on the GPU and is invisible to the parity tests."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from kcftools_amd import engine
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    objdump, readelf = os.path.join(LLVM, "llvm-objdump"), os.path.join(LLVM, "llvm-readelf")
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("llvm-objdump / llvm-readelf of the ROCm toolchain not found")
+    d = tmp_path_factory.mktemp("co")
+    so = shutil.copy(engine.LIB_PATH, d / "libkcfx.so")
+    subprocess.run([objdump, "--offloading", str(so)], check=True, capture_output=True, cwd=d)
+    co = [f for f in os.listdir(d) if "gfx950" in f]
+    assert len(co) == 1, os.listdir(d)                     # one architecture, one code object: gfx950 only
+    notes = subprocess.run([readelf, "--notes", str(d / co[0])], check=True, capture_output=True, text=True).stdout
+    out = {}
+    for block in notes.split("- .agpr_count")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        out[name] = {k: int(re.search(r"\." + k + r":\s+(\d+)", block).group(1))
+                     for k in ("vgpr_count", "sgpr_count", "private_segment_fixed_size", "group_segment_fixed_size")}
+    return out
+
+
+def test_screening_kernels_do_not_spill_and_fit_their_occupancy(kernels):
+    hot = {n: m for n, m in kernels.items() if re.search(r"screen_k31c_kernel|screen_k31_kernel|screen_k31_multi|screen_tiles_kernel|reduce_windows", n)}
+    # k = 27 .. 31 x canonical / forward-only, the line-table kernels, the general kernel, the reduction
+    assert sum("screen_k31c_kernel" in n for n in hot) == 10 and len(hot) >= 20
+    for name, m in hot.items():
+        assert m["private_segment_fixed_size"] == 0, (name, m)           # no scratch
+        # 8 waves per SIMD; the multi-sample line-table kernel is planned for 6 (amdgpu_waves_per_eu(6, 8): <= 80 VGPRs)
+        assert m["vgpr_count"] <= (80 if "screen_k31_multi" in name else 64), (name, m)
+    for name, m in hot.items():
+        if "screen_k31c_kernel" in name:
+            assert m["vgpr_count"] <= 48 and m["group_segment_fixed_size"] <= 8192, (name, m)
+        elif "screen_" in name:
+            assert m["group_segment_fixed_size"] <= 20480, (name, m)     # 160 KB LDS per CU / 8 workgroups
+
+
+def test_only_the_table_build_kernels_use_scratch(kernels):
+    """cells_* (build) and lookup_cells keep a k-mer's candidate cells (CellProbe[32], 512 bytes) in private memory -- load
+    time, not the hot path; nothing else may."""
+    assert len(kernels) > 30
+    spilling = {n: m["private_segment_fixed_size"] for n, m in kernels.items() if m["private_segment_fixed_size"]}
+    assert all(re.search(r"cells_(count|insert|settle|stash)_kernel|lookup_cells_kernel", n) and b <= 1024 for n, b in spilling.items()), spilling
