@@ -340,7 +340,7 @@ int32_t minimizer_len(int32_t k, int64_t n_keys) {
 }
 
 // largest lbits a k-mer length allows: the line number is the top of a 32-bit mix of the (k - 15)-base minimizer
-int32_t cells_lbits_cap(int32_t k) { return std::min<int32_t>(CELL_LBITS_MAX, 2 * (k - 15) - 2); }
+int32_t cells_lbits_cap(int32_t) { return std::min<int32_t>(CELL_LBITS_MAX, 2 * 16 - 2); }
 
 // FORMAT_CELLS (kcfx_internal.h) is what the BASELINE configuration gets: k = 27 .. 31 (31 in BASELINE.json), both strands or forward-only,
 // any counter size, minimizer bucketing. KCFX_TABLE_FORMAT=lines keeps the 12-slot line table (A/B and test
@@ -379,7 +379,7 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys) {
     db->fmt = FORMAT_CELLS;
     db->wide = 0;
     db->mode = MODE_MINIMIZER;
-    db->mm_len = db->info.kmer_length - 15;
+    db->mm_len = 16;                                  // cell tables: 16-base minimizers whatever k (k - 15 of them per k-mer)
     db->info.table_mode = MODE_MINIMIZER;
     db->info.minimizer_length = db->mm_len;
     db->info.table_format = FORMAT_CELLS;

@@ -241,7 +241,8 @@ KCFX_HD uint64_t cell_keycount_mask(int32_t lbits, bool both) {
 
 // Cell tables exist for k = 27 .. 31: the minimizer length is M = k - 15, so that a k-mer always spans 16 M-mers (one DPP
 // row, 16 cells per line) and its flank is always 15 bases = 30 bits. M-mers are kept left-aligned in 32 bits.
-KCFX_HD constexpr int cell_mlen(int k) { return k - 15; }
+KCFX_HD constexpr int cell_mlen(int) { return 16; }
+KCFX_HD constexpr int cell_nw(int k) { return k - 15; }       // 16-mers per k-mer = cells of a line a k-mer can sit in
 KCFX_HD constexpr uint32_t cell_mmask(int M) { return 0xFFFFFFFFu << (32 - 2 * M); }
 
 // reverse complement of a left-aligned M-mer (comp_swap also complements the padding; the shift drops it)
@@ -265,11 +266,11 @@ struct CellProbe {
 
 // Query side, one lane: F / R = the k-mer as the text reads it and its reverse complement, mn = the tagged minimum over
 // the k-mer's 16 M-mers, lane = this lane's position label base (mm27_tagged was fed (lane + offset) & 15).
-KCFX_HD CellProbe cell_probe_of(uint64_t F, uint64_t R, uint32_t mn, uint32_t lane, int32_t lbits, int M, bool both) {
+KCFX_HD CellProbe cell_probe_of(uint64_t F, uint64_t R, uint32_t mn, uint32_t lane, int32_t lbits, int M, bool both, int W = 16) {
     const bool flip = (mn & 16u) != 0;                        // the minimizer is canonical on the other strand
     const uint64_t N = flip ? R : F;
     uint32_t sh = ((mn - lane) << 1) & 30u;                   // 2 * offset of the minimizer in F
-    sh ^= flip ? 30u : 0u;                                    // in R it sits at 15 - offset
+    sh = flip ? 2u * (uint32_t)(W - 1) - sh : sh;             // in R it sits at W - 1 - offset
     CellProbe p;
     uint32_t cm;
     p.w = cell_flank(N, sh, M, &cm);
@@ -288,16 +289,16 @@ KCFX_HD CellProbe cell_probe_of(uint64_t F, uint64_t R, uint32_t mn, uint32_t la
 // with CELL_R_FLIP when that is the reverse complement.
 constexpr int CELL_MAX_CANDS = 32;
 KCFX_HD int cells_of_key(uint64_t C, int32_t k, int32_t lbits, CellProbe* out, bool both) {
-    const int M = cell_mlen(k);
+    const int M = cell_mlen(k), W = cell_nw(k);
     const uint64_t Rc = revcomp_word(C, k);
     uint32_t best = 0xFFFFFFFFu;
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < W; ++j) {
         const uint32_t m = (uint32_t)((C << (2 * j)) >> 32) & cell_mmask(M), r = rc_mmer(m, M);
         const uint32_t h = mm27(m < r ? m : r);
         best = h < best ? h : best;
     }
     int n = 0;
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < W; ++j) {
         const uint32_t m = (uint32_t)((C << (2 * j)) >> 32) & cell_mmask(M), r = rc_mmer(m, M);
         const uint32_t cm = m < r ? m : r;
         if (mm27(cm) != best) continue;
@@ -306,7 +307,7 @@ KCFX_HD int cells_of_key(uint64_t C, int32_t k, int32_t lbits, CellProbe* out, b
             if (strand == 0 ? (m > r) : (r > m)) continue;
             if (!both && strand == 1 && r == m) continue;     // (a palindromic M-mer: the query reads it on strand 0)
             const uint64_t N = strand ? Rc : C;
-            const uint32_t sh = 2u * (uint32_t)(strand ? 15 - j : j);
+            const uint32_t sh = 2u * (uint32_t)(strand ? W - 1 - j : j);
             CellProbe p;
             uint32_t got;
             p.w = cell_flank(N, sh, M, &got);

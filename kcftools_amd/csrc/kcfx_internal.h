@@ -72,7 +72,7 @@ constexpr int MODE_KEYHASH = 0, MODE_MINIMIZER = 1;
 //   slot = hash32(key) & mask, probed by the lanes individually.
 // ----------------------------------------------------------------------------------------------------
 constexpr int FORMAT_LINES = 0, FORMAT_CELLS = 1;
-constexpr int CELL_K_MIN = 27, CELL_K_MAX = 31;               // cell tables: minimizer length k - 15, so that a k-mer spans 16 of them
+constexpr int CELL_K_MIN = 23, CELL_K_MAX = 31;               // cell tables: 16-base minimizers, k - 15 = 8 .. 16 of them per k-mer
 constexpr int CELL_LBITS_MIN = 17, CELL_LBITS_MAX = 31;     // r must fit 15 bits (bit 15 marks a second-choice cell); n_lines fits 32
                                                             // (forward-only databases: 18, bit 14 of r is taken too -- cell_lbits_min)
 __host__ __device__ inline int32_t cell_lbits_min(bool both) { return both ? CELL_LBITS_MIN : CELL_LBITS_MIN + 1; }

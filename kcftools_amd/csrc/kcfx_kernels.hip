@@ -784,17 +784,43 @@ struct K31Words {
     int n_kmers, lane, next15;
     bool clean;                 // no invalid base anywhere in the tile: validity = "inside the tile"
     uint32_t Fc, Cc, Pc, Sc;
+    uint32_t Hc;                // (NW < 16 only) the hash this lane's position feeds into the sliding minimum
+    // a k-mer spans NW 16-mers: 16 for k = 31 (one DPP row: the van Herk scans below), k - 15 for the shorter k of a cell table
+    static constexpr int NW = CELLS ? cell_nw(K) : 16;
+
+    // min(E[lane .. lane + NW - 1]) over E = hc (this word's 64 positions) ++ hn (the next word's), NW = 2 .. 15, by doubling:
+    // dc[p] = min(E[p .. p + span - 1]) with span = 1, 2, 4, 8, then one overlapping step for the rest. Two bpermutes per step
+    // (the same lane address serves both halves); dn only ever needs its low lanes, which never look past hn.
+    __device__ __forceinline__ uint32_t window_min(uint32_t hc, uint32_t hn) const {
+        uint32_t dc = hc, dn = hn;
+        int span = 1;
+#pragma unroll
+        for (int d = 1; 2 * d <= NW; d <<= 1) {
+            const int addr = ((lane + d) & 63) << 2;
+            const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)dc);
+            const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)dn);
+            dc = min(dc, lane + d < 64 ? a : b);
+            dn = min(dn, b);
+            span = 2 * d;
+        }
+        if (span < NW) {
+            const int d = NW - span;
+            const int addr = ((lane + d) & 63) << 2;
+            const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)dc);
+            const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)dn);
+            dc = min(dc, lane + d < 64 ? a : b);
+        }
+        return dc;
+    }
 
     // what a position feeds into the sliding minimum, from the leading 32 code bits of both strands: the hash of its canonical
     // 16-mer; FORMAT_CELLS tables tag it with the strand and the position (mm27_tagged) so that the minimum also says where
     // the minimizer sits in each k-mer
     __device__ __forceinline__ uint32_t mmer_of(uint32_t f0, uint32_t c0) const {
         if constexpr (CELLS) {
-            // the M-mer (M = K - 15) is the leading 2M bits; its reverse complement comes from the same bits of the
-            // complement-swapped stream, reversed (for M = 16 the masks and the shift vanish)
-            constexpr int M = cell_mlen(K);
-            constexpr uint32_t mm = cell_mmask(M);
-            return mm27_tagged(f0 & mm, brev32(c0 & mm) << (32 - 2 * M), (uint32_t)lane & 15u);
+            // the 16-mer is the leading 32 code bits; its reverse complement the same bits of the complement-swapped
+            // stream, reversed
+            return mm27_tagged(f0, brev32(c0), (uint32_t)lane & 15u);
         } else {
             return mhash32(((uint64_t)min(f0, brev32(c0))) << 32);
         }
@@ -814,7 +840,8 @@ struct K31Words {
         const uint2 x = p_fc[0], y = p_fc[1];
         Fc = alignbit32(x.x, y.x, sh_fc);
         Cc = alignbit32(x.y, y.y, sh_fc);
-        row_scan_min(mmer_of(Fc, Cc), Pc, Sc);
+        if constexpr (NW == 16) row_scan_min(mmer_of(Fc, Cc), Pc, Sc);
+        else Hc = mmer_of(Fc, Cc);
     }
     // word w (call with consecutive w): the k-mer as the text reads it and its reverse complement (Kmer.java:232-252,
     // :300-338), the minimum over its 16 M-mers, validity
@@ -828,8 +855,9 @@ struct K31Words {
         const uint32_t c1 = alignbit32(x0.y, x1.y, sh_fc) & lo_mask;
         const uint32_t Fn = alignbit32(x3.x, x4.x, sh_fc);
         const uint32_t Cn = alignbit32(x3.y, x4.y, sh_fc);
-        uint32_t Pn, Sn;
-        row_scan_min(mmer_of(Fn, Cn), Pn, Sn);
+        uint32_t Pn = 0, Sn = 0, Hn = 0;
+        if constexpr (NW == 16) row_scan_min(mmer_of(Fn, Cn), Pn, Sn);
+        else Hn = mmer_of(Fn, Cn);
         // extract_kmer (kcfx_device.h) from the four halves
         fwd = u64_of(f1, Fc);
         rc = u64_of(brev32(Cc), brev32(c1)) << (64 - 2 * k);
@@ -838,14 +866,19 @@ struct K31Words {
         const int rem = n_kmers - w * 64;
         V = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
         if (!clean) V &= wave_ballot((alignbit32(p_vb[0], p_vb[1], sh_vb) >> (32 - k)) == (uint32_t)((1ull << k) - 1));
-        // minimum over the k-mer's 16 M-mers = min(S[lane], P[lane + 15])
-        const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(next15, (int)Pc);
-        const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute(next15, (int)Pn);
-        mn = min(Sc, lane < 49 ? pa : pb);
+        if constexpr (NW == 16) {
+            // minimum over the k-mer's 16 M-mers = min(S[lane], P[lane + 15])
+            const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(next15, (int)Pc);
+            const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute(next15, (int)Pn);
+            mn = min(Sc, lane < 49 ? pa : pb);
+        } else {
+            mn = window_min(Hc, Hn);
+        }
         Fc = Fn;
         Cc = Cn;
         Pc = Pn;
         Sc = Sn;
+        Hc = Hn;
         p_fc += 4;
         p_vb += 2;
     }
@@ -1111,7 +1144,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         uint64_t fwd, rc, V;
         uint32_t mn;
         words.next(w, fwd, rc, mn, V);
-        const CellProbe p = cell_probe_of(fwd, rc, mn, (uint32_t)lane, tv.lbits, cell_mlen(K), BOTH);
+        const CellProbe p = cell_probe_of(fwd, rc, mn, (uint32_t)lane, tv.lbits, cell_mlen(K), BOTH, cell_nw(K));
         cells_issue(tv, V, p, cw);
     };
     // stage B of word w: cells matched, ballots out, stash candidates queued
@@ -1560,6 +1593,10 @@ hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32
             hipExtLaunchKernelGGL((screen_k31c_kernel<KK, false>), g, b, 0, st, ev_start, ev_stop, 0, text, tiles, tv, min_count, bits, count_sums); \
     } while (0)
         switch (k) {
+            case 23: KCFX_LAUNCHC(23); break;
+            case 24: KCFX_LAUNCHC(24); break;
+            case 25: KCFX_LAUNCHC(25); break;
+            case 26: KCFX_LAUNCHC(26); break;
             case 27: KCFX_LAUNCHC(27); break;
             case 28: KCFX_LAUNCHC(28); break;
             case 29: KCFX_LAUNCHC(29); break;

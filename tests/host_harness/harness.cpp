@@ -151,7 +151,7 @@ int harness_minimizers(const uint8_t* text, int64_t text_off, int n_kmers, int k
 // n_cands_out[j] = number of build-side candidates, probe_out[4 j ..] = the query-side (line, sh, w, r).
 // both = 0: a forward-only database -- the k-mer is stored, and looked up, exactly as the text reads it.
 int harness_cells(const uint8_t* text, int64_t text_off, int n_kmers, int k, int lbits, int both, int32_t* n_cands_out, uint32_t* probe_out) {
-    const int M = cell_mlen(k);
+    const int M = cell_mlen(k), W = cell_nw(k);
     Packed P = pack_tile(text, text_off, n_kmers, k);
     std::vector<uint32_t> h(n_kmers + 16);
     for (int p = 0; p < n_kmers + 15; ++p) {
@@ -162,10 +162,10 @@ int harness_cells(const uint8_t* text, int64_t text_off, int n_kmers, int k, int
     int bad = 0;
     for (int j = 0; j < n_kmers; ++j) {
         uint32_t mn = h[j];
-        for (int t = 1; t < 16; ++t) mn = std::min(mn, h[j + t]);
+        for (int t = 1; t < W; ++t) mn = std::min(mn, h[j + t]);
         uint64_t F, R;
         extract_pair(P.fw(), P.cw(), P.off + j, k, F, R);
-        const CellProbe q = cell_probe_of(F, R, mn, (uint32_t)j & 63u, lbits, M, both != 0);
+        const CellProbe q = cell_probe_of(F, R, mn, (uint32_t)j & 63u, lbits, M, both != 0, W);
         CellProbe c[CELL_MAX_CANDS];
         const int n = cells_of_key((both && R < F) ? R : F, k, lbits, c, both != 0);
         bool ok = false;
