@@ -43,16 +43,17 @@ constexpr uint32_t BUILD_COUNT_MASK = 0x00FFFFFFu, BUILD_HEAVY = 0x80000000u;
 constexpr int MODE_KEYHASH = 0, MODE_MINIMIZER = 1;
 
 // ----------------------------------------------------------------------------------------------------
-// FORMAT_CELLS (k = 27 .. 31 -- BASELINE.json's canonical k = 31 among them; forward-only databases: CELL_R_FLIP in kcfx_device.h):
-// the line a k-mer lives in is still chosen by its minimizer (M = k - 15, so that a k-mer spans exactly 16 M-mers), but INSIDE the line the k-mer has exactly one
-// cell: cell index = offset of the minimizer in the k-mer, read on the strand where the minimizer 16-mer is in
-// canonical form ("N orientation"). The 16 k-mers that can share a minimizer occurrence have 16 distinct offsets, so a
+// FORMAT_CELLS (k = 23 .. 31 -- BASELINE.json's canonical k = 31 among them; forward-only databases: CELL_R_FLIP in kcfx_device.h):
+// the line a k-mer lives in is still chosen by its minimizer -- always a 16-mer: a k-mer spans W = k - 15 of them (16 for
+// k = 31, 10 for KMC's default k = 25) -- but INSIDE the line the k-mer has exactly one
+// cell: cell index = offset of the minimizer in the k-mer (0 .. W - 1), read on the strand where the minimizer 16-mer is in
+// canonical form ("N orientation"). The W k-mers that can share a minimizer occurrence have W distinct offsets, so a
 // run of consecutive reference k-mers maps onto distinct cells of ONE line, and a probe is ONE 8-byte load per lane --
 // the lanes of a run hit the same 128-byte line, which the memory pipeline fetches once -- and two compares: no
 // cooperative line fetch, no LDS staging, no 12-way 64-bit compare. A cell holds a quotiented key, exact by construction:
 //
 //   128-byte line = 16 x 8-byte cell;  cell = u32 w | u16 r | u16 count
-//     w     = the 30 flank bits (the 15 bases of N around the minimizer, left-aligned) | bit 0: some k-mer that maps
+//     w     = the flank bits (the k - 16 <= 15 bases of N around the minimizer, left-aligned in 30 bits) | bit 0: some k-mer that maps
 //             to this cell lives in the stash | bit 1: the occupant is of the "crowded" class (build time only)
 //     r     = low (32 - lbits) bits of G32 = a 32-bit mix of the canonical minimizer 16-mer; the line number is the top
 //             lbits of G32, and G32 <-> minimizer is a bijection (cell_g32)
