@@ -83,7 +83,7 @@ typedef struct {
     int32_t minimizer_length;/* M of the minimizer bucketing (0 in mode 0) */
     int64_t heavy_lines;     /* minimizer home lines whose k-mers were re-homed by key hash (low-complexity repeats) */
     int64_t overflow_lines;  /* lines that pushed k-mers to the next line */
-    int32_t table_format;    /* 0 = 12-slot lines; 1 = 16 offset-addressed cells per line + stash (the default for k = 23..31) */
+    int32_t table_format;    /* 0 = 12-slot lines; 1 = 16 offset-addressed cells per line + stash (the default for k = 19..31) */
     int32_t _pad;
     int64_t stored_kmers;    /* format 1: k-mers with a non-zero counter (the others can never be observed) */
     int64_t stash_kmers;     /* format 1: k-mers that found a cell taken and live in the stash */
@@ -149,7 +149,7 @@ int32_t kcfx_screen_ref_async(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count
 /* Several samples, ONE pass over the reference (SURVEY f-4): what the reference does as S getVariations runs followed by
  * `cohort` (run_kcftools.sh:124-140, Plugins/Cohort.java:71-119). out[s * n_windows + w] = sample s (input order),
  * window w; each slice equals kcfx_screen_ref(dbs[s], ...). Databases must live on ref's device and share its k;
- * cell tables (the default for k = 23 .. 31) are screened one launch per sample and reduced together;
+ * cell tables (the default for k = 19 .. 31) are screened one launch per sample and reduced together;
  * 12-slot line tables of k = 31 with counters of at most 2 bytes are screened up to 8 at a time by one kernel (same
  * results either way). */
 int32_t kcfx_screen_ref_multi(kcfx_db* const* dbs, int32_t n_db, kcfx_ref* ref, int32_t min_kmer_count, kcfx_result* out);

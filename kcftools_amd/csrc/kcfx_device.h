@@ -239,7 +239,7 @@ KCFX_HD uint64_t cell_keycount_mask(int32_t lbits, bool both) {
     return 0xFFFF0000FFFFFFFCull | ((uint64_t)cell_rmask(lbits, both) << 32);
 }
 
-// Cell tables exist for k = 23 .. 31: the minimizer is always a 16-mer (32 bits: G32 is a bijection of it), of which a
+// Cell tables exist for k = 19 .. 31: the minimizer is always a 16-mer (32 bits: G32 is a bijection of it), of which a
 // k-mer spans W = k - 15 (16 for k = 31: one DPP row, all 16 cells of a line); the flank is k - 16 <= 15 bases = at most 30 bits.
 KCFX_HD constexpr int cell_mlen(int) { return 16; }
 KCFX_HD constexpr int cell_nw(int k) { return k - 15; }       // 16-mers per k-mer = cells of a line a k-mer can sit in

@@ -43,7 +43,7 @@ constexpr uint32_t BUILD_COUNT_MASK = 0x00FFFFFFu, BUILD_HEAVY = 0x80000000u;
 constexpr int MODE_KEYHASH = 0, MODE_MINIMIZER = 1;
 
 // ----------------------------------------------------------------------------------------------------
-// FORMAT_CELLS (k = 23 .. 31 -- BASELINE.json's canonical k = 31 among them; forward-only databases: CELL_R_FLIP in kcfx_device.h):
+// FORMAT_CELLS (k = 19 .. 31 -- BASELINE.json's canonical k = 31 among them; forward-only databases: CELL_R_FLIP in kcfx_device.h):
 // the line a k-mer lives in is still chosen by its minimizer -- always a 16-mer: a k-mer spans W = k - 15 of them (16 for
 // k = 31, 10 for KMC's default k = 25) -- but INSIDE the line the k-mer has exactly one
 // cell: cell index = offset of the minimizer in the k-mer (0 .. W - 1), read on the strand where the minimizer 16-mer is in
@@ -73,7 +73,7 @@ constexpr int MODE_KEYHASH = 0, MODE_MINIMIZER = 1;
 //   slot = hash32(key) & mask, probed by the lanes individually.
 // ----------------------------------------------------------------------------------------------------
 constexpr int FORMAT_LINES = 0, FORMAT_CELLS = 1;
-constexpr int CELL_K_MIN = 23, CELL_K_MAX = 31;               // cell tables: 16-base minimizers, k - 15 = 8 .. 16 of them per k-mer
+constexpr int CELL_K_MIN = 19, CELL_K_MAX = 31;               // cell tables: 16-base minimizers, k - 15 = 4 .. 16 of them per k-mer
 constexpr int CELL_LBITS_MIN = 17, CELL_LBITS_MAX = 31;     // r must fit 15 bits (bit 15 marks a second-choice cell); n_lines fits 32
                                                             // (forward-only databases: 18, bit 14 of r is taken too -- cell_lbits_min)
 __host__ __device__ inline int32_t cell_lbits_min(bool both) { return both ? CELL_LBITS_MIN : CELL_LBITS_MIN + 1; }

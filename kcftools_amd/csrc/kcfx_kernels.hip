@@ -1593,6 +1593,10 @@ hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32
             hipExtLaunchKernelGGL((screen_k31c_kernel<KK, false>), g, b, 0, st, ev_start, ev_stop, 0, text, tiles, tv, min_count, bits, count_sums); \
     } while (0)
         switch (k) {
+            case 19: KCFX_LAUNCHC(19); break;
+            case 20: KCFX_LAUNCHC(20); break;
+            case 21: KCFX_LAUNCHC(21); break;
+            case 22: KCFX_LAUNCHC(22); break;
             case 23: KCFX_LAUNCHC(23); break;
             case 24: KCFX_LAUNCHC(24); break;
             case 25: KCFX_LAUNCHC(25); break;

@@ -49,13 +49,15 @@ CONFIGS = [
     (23, 3, 2, 5, 7, True),
     (15, 3, 1, 5, 3, False),
     (32, 4, 2, 7, 4, True),
-    # k = 23 .. 30 take the cell table too (16-base minimizers, k - 15 of them per k-mer)
+    # k = 19 .. 30 take the cell table too (16-base minimizers, k - 15 of them per k-mer)
     (30, 2, 2, 7, 4, True),
     (29, 5, 1, 7, 3, True),
     (28, 4, 2, 5, 4, True),
     (26, 2, 1, 7, 4, True),
     (25, 5, 2, 7, 3, False),
     (24, 4, 4, 5, 4, True),
+    (21, 5, 2, 7, 4, True),
+    (19, 3, 1, 5, 3, False),
     (27, 3, 2, 5, 3, True),
     (29, 1, 2, 7, 2, False),
 ]
@@ -69,7 +71,7 @@ def test_lookup_matches_getcount(oracle, tmp_path, k, p, cs, m, bins, both):
     odb = oracle.OracleDb(prefix)
     i = db.info
     assert (i.kmer_length, i.lut_prefix_length, i.counter_size, i.signature_length, i.n_bins) == (k, p, cs, m, bins)
-    assert i.table_format == (1 if 23 <= k <= 31 else 0)
+    assert i.table_format == (1 if 19 <= k <= 31 else 0)
     assert i.minimizer_length == 16 if i.table_format == 1 else True
     assert bool(i.both_strands) == both and i.total_kmers == len(kmers) and i.version == 0x200
     assert i.min_count == prm.min_count and i.max_count == int(np.int32(np.uint32(prm.max_count)))   # Java int (KMC.java:131)
@@ -522,8 +524,8 @@ def test_fuzz_window_geometry_against_oracle(oracle, tmp_path, seed, kernel, mon
     if kernel == "lines":
         monkeypatch.setenv("KCFX_TABLE_FORMAT", "lines")
     rng = np.random.default_rng(1000 + seed)
-    # the cell-table kernel exists for k = 23 .. 31
-    k = (31, 29, 25, 30, 27, 28, 31, 23, 26, 24)[seed % 10] if kernel == "default" else 31
+    # the cell-table kernel exists for k = 19 .. 31
+    k = (31, 29, 25, 30, 27, 28, 31, 23, 26, 24, 21, 19, 22, 20)[seed % 14] if kernel == "default" else 31
     L = 180_000
     ref = bytearray(synth.random_reference(L, 500 + seed))
     for _ in range(25):
@@ -545,7 +547,7 @@ def test_fuzz_window_geometry_against_oracle(oracle, tmp_path, seed, kernel, mon
         elif seed % 3 == 2:                 # a few filter bits
             monkeypatch.setenv("KCFX_TABLE_LBITS", str(18 + seed % 4))
             noise = 300_000
-    p_of_k = {31: int(rng.choice([3, 7])), 30: 2, 29: 5, 28: 4, 27: 3, 26: 6, 25: 5, 24: 4, 23: 3}
+    p_of_k = {31: int(rng.choice([3, 7])), 30: 2, 29: 5, 28: 4, 27: 3, 26: 6, 25: 5, 24: 4, 23: 3, 22: 2, 21: 5, 20: 4, 19: 3}
     prefix, *_ = make_db(tmp_path, "fz", ref, 300 + seed, k=k, p=p_of_k[k], cs=cs, m=7, bins=4, both=both, noise=noise)
     db = engine.KmcDb.open(prefix)
     assert db.info.table_format == (1 if kernel == "default" else 0)

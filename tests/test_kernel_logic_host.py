@@ -243,7 +243,8 @@ def test_cell_table_build_side_covers_query_side(harness, oracle):
     # its reverse complement, so such a table starts at lbits 18
     for k, lbits, both in ((31, 17, 1), (31, 19, 1), (31, 27, 1), (31, 30, 1), (30, 21, 1), (29, 19, 1), (29, 26, 1), (28, 20, 1),
                            (27, 17, 1), (27, 22, 1), (31, 18, 0), (31, 19, 0), (31, 30, 0), (29, 19, 0), (27, 18, 0), (28, 24, 0),
-                           (26, 19, 1), (25, 19, 1), (25, 28, 0), (24, 21, 1), (23, 19, 1), (23, 18, 0)):
+                           (26, 19, 1), (25, 19, 1), (25, 28, 0), (24, 21, 1), (23, 19, 1), (23, 18, 0),
+                           (22, 19, 1), (21, 19, 1), (21, 22, 0), (20, 19, 0), (19, 19, 1), (19, 18, 0)):
         for begin in (0, 1, 7, 33, 64, 501):
             n = min(2048, len(text) - begin - k + 1)
             ncand = np.zeros(n, dtype=np.int32)
@@ -256,7 +257,7 @@ def test_cell_table_build_side_covers_query_side(harness, oracle):
                 assert (ncand == 1).mean() > 0.8
     # injectivity over every cell of every distinct canonical k-mer of the text (valid positions only)
     out = np.zeros(4 * 32, dtype=np.uint32)
-    for k, lbits, both in ((31, 17, 1), (31, 24, 1), (29, 20, 1), (27, 18, 1), (31, 18, 0), (29, 21, 0), (25, 20, 1), (23, 18, 0)):
+    for k, lbits, both in ((31, 17, 1), (31, 24, 1), (29, 20, 1), (27, 18, 1), (31, 18, 0), (29, 21, 0), (25, 20, 1), (23, 18, 0), (21, 19, 1), (19, 18, 0)):
         lst = np.zeros(len(text), dtype=np.uint64)
         m = oracle.lib().kcfo_kmers_list(text, len(text), k, lst.ctypes.data)
         if both:
