@@ -288,7 +288,10 @@ KCFX_HD CellProbe cell_probe_of(uint64_t F, uint64_t R, uint32_t mn, uint32_t la
 // asked for C exactly as stored: one orientation per tied offset (the one the query's tag bit selects: rc(m) < m), marked
 // with CELL_R_FLIP when that is the reverse complement.
 constexpr int CELL_MAX_CANDS = 32;
-KCFX_HD int cells_of_key(uint64_t C, int32_t k, int32_t lbits, CellProbe* out, bool both) {
+// f(const CellProbe&, int index) for every such cell, in a fixed order; returns how many. (A visitor, not an array: the
+// kernels that walk a k-mer's cells keep nothing in private memory.)
+template <class F>
+KCFX_HD int cells_visit(uint64_t C, int32_t k, int32_t lbits, bool both, F&& f) {
     const int M = cell_mlen(k), W = cell_nw(k);
     const uint64_t Rc = revcomp_word(C, k);
     uint32_t best = 0xFFFFFFFFu;
@@ -315,10 +318,15 @@ KCFX_HD int cells_of_key(uint64_t C, int32_t k, int32_t lbits, CellProbe* out, b
             p.sh = sh;
             p.line = g >> (32 - lbits);
             p.r = (g & (0xFFFFFFFFu >> lbits)) | ((!both && strand == 1) ? CELL_R_FLIP : 0u);
-            out[n++] = p;
+            f(p, n);
+            ++n;
         }
     }
     return n;
+}
+// the same into an array of CELL_MAX_CANDS (host-side checks)
+KCFX_HD int cells_of_key(uint64_t C, int32_t k, int32_t lbits, CellProbe* out, bool both) {
+    return cells_visit(C, k, lbits, both, [&](const CellProbe& p, int i) { out[i] = p; });
 }
 
 KCFX_HD uint32_t stash_slot(uint64_t key, uint32_t mask) { return hash32(key) & mask; }

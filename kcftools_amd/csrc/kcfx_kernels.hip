@@ -213,10 +213,11 @@ __global__ void cells_count_kernel(uint32_t* pop32, int32_t k, int32_t lbits, in
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         if (counts[i] == 0) continue;
-        CellProbe cand[CELL_MAX_CANDS];
-        cells_of_key(keys[i], k, lbits, cand, both != 0);
-        const uint64_t sub = cell_sub_bucket(cand[0], lbits);
-        atomicAdd(&pop32[sub >> 2], 1u << (8 * (uint32_t)(sub & 3)));
+        cells_visit(keys[i], k, lbits, both != 0, [&](const CellProbe& p, int a) {
+            if (a != 0) return;                                 // the first of its cells names the k-mer's sub-bucket
+            const uint64_t sub = cell_sub_bucket(p, lbits);
+            atomicAdd(&pop32[sub >> 2], 1u << (8 * (uint32_t)(sub & 3)));
+        });
     }
 }
 
@@ -232,17 +233,18 @@ __global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__
         const uint32_t c = counts[i];
         if (c == 0) continue;                       // can never be observed (count >= -c >= 1 is needed): not stored
         if (c > CELL_COUNT_MAX) continue;           // a 3- / 4-byte counter that does not fit a cell: lives in the stash (settle)
-        CellProbe cand[CELL_MAX_CANDS];
-        const int nc = cells_of_key(keys[i], k, lbits, cand, both != 0);
-        const uint64_t sub = cell_sub_bucket(cand[0], lbits);
-        const bool crowded = ((pop32[sub >> 2] >> (8 * (uint32_t)(sub & 3))) & 0xFFu) >= CELL_CROWD;
-        if ((int32_t)crowded != cls) continue;
-        for (int a = 0; a < nc; ++a) {
-            unsigned long long* cell = reinterpret_cast<unsigned long long*>(lines + (size_t)cand[a].line * LINE_BYTES + 4 * cand[a].sh);
+        bool crowded = false;
+        cells_visit(keys[i], k, lbits, both != 0, [&](const CellProbe& p, int a) {
+            if (a == 0) {
+                const uint64_t sub = cell_sub_bucket(p, lbits);
+                crowded = ((pop32[sub >> 2] >> (8 * (uint32_t)(sub & 3))) & 0xFFu) >= CELL_CROWD;
+            }
+            if ((int32_t)crowded != cls) return;
+            unsigned long long* cell = reinterpret_cast<unsigned long long*>(lines + (size_t)p.line * LINE_BYTES + 4 * p.sh);
             if (crowded) {
-                atomicMax(cell, (unsigned long long)cell_word(cand[a].w | CELL_FLAG_CROWDED, cand[a].r, c));
+                atomicMax(cell, (unsigned long long)cell_word(p.w | CELL_FLAG_CROWDED, p.r, c));
             } else {
-                const unsigned long long mine = cell_word(cand[a].w, cand[a].r, c);
+                const unsigned long long mine = cell_word(p.w, p.r, c);
                 unsigned long long old = __atomic_load_n(cell, __ATOMIC_RELAXED);
                 while (!(old & CELL_FLAG_CROWDED) && old < mine) {
                     const unsigned long long prev = atomicCAS(cell, old, mine);
@@ -250,7 +252,7 @@ __global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__
                     old = prev;
                 }
             }
-        }
+        });
     }
 }
 
@@ -278,27 +280,22 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, in
     for (; i < n; i += stride) {
         const uint32_t c = counts[i];
         if (c == 0) continue;
-        CellProbe cand[CELL_MAX_CANDS];
-        const int nc = cells_of_key(keys[i], k, lbits, cand, both);
         bool lost = false;
         const uint64_t kc = cell_keycount_mask(lbits, both);
-        if (c > CELL_COUNT_MAX) {
-            // never bid: every cell a query could derive for it is flagged (whoever lives there, or nobody), with its filter bit
-            for (int a = 0; a < nc; ++a) {
-                unsigned long long mark = CELL_FLAG_STASH;
-                if (cell_spare_bits(lbits, both) > 0) mark |= 1ull << (32 + cell_filter_pos(cand[a].w, lbits, both));
-                atomicOr(reinterpret_cast<unsigned long long*>(lines + (size_t)cand[a].line * LINE_BYTES + 4 * cand[a].sh), mark);
+        const bool wide = c > CELL_COUNT_MAX;
+        const int nc = cells_visit(keys[i], k, lbits, both, [&](const CellProbe& p, int) {
+            uint8_t* line = lines + (size_t)p.line * LINE_BYTES;
+            unsigned long long mark = CELL_FLAG_STASH;
+            if (cell_spare_bits(lbits, both) > 0) mark |= 1ull << (32 + cell_filter_pos(p.w, lbits, both));
+            if (wide) {
+                // never bid: every cell a query could derive for it is flagged (whoever lives there, or nobody), with its filter bit
+                atomicOr(reinterpret_cast<unsigned long long*>(line + 4 * p.sh), mark);
+                lost = true;
+                return;
             }
-            ++n_lost;
-            ++n_stored;
-            n_multi += nc > 1 ? 1u : 0u;
-            continue;
-        }
-        for (int a = 0; a < nc; ++a) {
-            if (cell_standing(lines, cand[a], c, lbits, both) != 2) continue;     // (1: the same word twice in the input)
-            uint8_t* line = lines + (size_t)cand[a].line * LINE_BYTES;
-            unsigned long long* alt = reinterpret_cast<unsigned long long*>(line + 4 * cell_alt_sh(cand[a].sh, cand[a].w));
-            const unsigned long long mine = cell_word(cand[a].w, cand[a].r | CELL_R_ALT, c);
+            if (cell_standing(lines, p, c, lbits, both) != 2) return;     // (1: the same word twice in the input)
+            unsigned long long* alt = reinterpret_cast<unsigned long long*>(line + 4 * cell_alt_sh(p.sh, p.w));
+            const unsigned long long mine = cell_word(p.w, p.r | CELL_R_ALT, c);
             unsigned long long old = __atomic_load_n(alt, __ATOMIC_RELAXED);
             bool won = false;
             while ((old >> 48) == 0) {
@@ -312,12 +309,10 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, in
             if (won) {
                 ++n_second;
             } else if ((old & kc) != mine) {
-                unsigned long long mark = CELL_FLAG_STASH;
-                if (cell_spare_bits(lbits, both) > 0) mark |= 1ull << (32 + cell_filter_pos(cand[a].w, lbits, both));
-                atomicOr(reinterpret_cast<unsigned long long*>(line + 4 * cand[a].sh), mark);
+                atomicOr(reinterpret_cast<unsigned long long*>(line + 4 * p.sh), mark);
                 lost = true;
             }
-        }
+        });
         n_lost += lost ? 1u : 0u;
         ++n_stored;
         n_multi += nc > 1 ? 1u : 0u;
@@ -342,11 +337,8 @@ __global__ void cells_stash_kernel(const uint8_t* __restrict__ lines, int32_t k,
         if (c == 0) continue;
         const uint64_t key = keys[i];
         bool lost = c > CELL_COUNT_MAX;                 // (counters wider than a cell's 16 bits)
-        if (!lost) {
-            CellProbe cand[CELL_MAX_CANDS];
-            const int nc = cells_of_key(key, k, lbits, cand, both != 0);
-            for (int a = 0; a < nc; ++a) lost |= cell_standing(lines, cand[a], c, lbits, both != 0) == 2;
-        }
+        if (!lost)
+            cells_visit(key, k, lbits, both != 0, [&](const CellProbe& p, int) { lost |= cell_standing(lines, p, c, lbits, both != 0) == 2; });
         if (!lost) continue;
         uint32_t slot = stash_slot(key, mask);
         for (;;) {
@@ -385,18 +377,20 @@ __global__ __launch_bounds__(256) void lookup_cells_kernel(TableView tv, int32_t
         // a both-strands database stores only canonical words; a k-mer word has its low 64 - 2k bits clear
         const bool both = both_i != 0;
         if ((!both || key <= revcomp_word(key, k)) && (key & ~(~0ull << (64 - 2 * k))) == 0) {
-            CellProbe cand[CELL_MAX_CANDS];
-            cells_of_key(key, k, tv.lbits, cand, both);         // any one of its cells decides
-            const uint8_t* line = tv.lines + (size_t)cand[0].line * LINE_BYTES;
-            const uint64_t first = *reinterpret_cast<const uint64_t*>(line + 4 * cand[0].sh);
-            const uint64_t second = *reinterpret_cast<const uint64_t*>(line + 4 * cell_alt_sh(cand[0].sh, cand[0].w));
+            CellProbe c0{0, 0, 0, 0};                            // any one of its cells decides: the first
+            cells_visit(key, k, tv.lbits, both, [&](const CellProbe& p, int a) {
+                if (a == 0) c0 = p;
+            });
+            const uint8_t* line = tv.lines + (size_t)c0.line * LINE_BYTES;
+            const uint64_t first = *reinterpret_cast<const uint64_t*>(line + 4 * c0.sh);
+            const uint64_t second = *reinterpret_cast<const uint64_t*>(line + 4 * cell_alt_sh(c0.sh, c0.w));
             const uint64_t KEY_BITS = cell_keycount_mask(tv.lbits, both) & 0x0000FFFFFFFFFFFFull;     // w without the flags, r without the filter
-            if (((first ^ cell_word(cand[0].w, cand[0].r, 0)) & KEY_BITS) == 0 && (first >> 48) != 0)
+            if (((first ^ cell_word(c0.w, c0.r, 0)) & KEY_BITS) == 0 && (first >> 48) != 0)
                 result = (int32_t)(first >> 48);
-            else if (((second ^ cell_word(cand[0].w, cand[0].r | CELL_R_ALT, 0)) & KEY_BITS) == 0 && (second >> 48) != 0)
+            else if (((second ^ cell_word(c0.w, c0.r | CELL_R_ALT, 0)) & KEY_BITS) == 0 && (second >> 48) != 0)
                 result = (int32_t)(second >> 48);
             else if ((first & CELL_FLAG_STASH) &&
-                     (cell_spare_bits(tv.lbits, both) == 0 || ((first >> (32 + cell_filter_pos(cand[0].w, tv.lbits, both))) & 1)))
+                     (cell_spare_bits(tv.lbits, both) == 0 || ((first >> (32 + cell_filter_pos(c0.w, tv.lbits, both))) & 1)))
                 result = (int32_t)stash_find(tv, key);
         }
         out[i] = result;
