@@ -191,6 +191,7 @@ int harness_cells_of_key(uint64_t C, int k, int lbits, int both, uint32_t* out) 
     }
     return n;
 }
+uint32_t harness_cell_alt_sh(uint32_t sh, uint32_t w) { return cell_alt_sh(sh, w); }
 uint64_t harness_revcomp_word(uint64_t x, int len) { return revcomp_word(x, len); }
 int harness_tile_k(void) { return TILE_K; }
 

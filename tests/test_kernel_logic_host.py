@@ -49,6 +49,8 @@ def harness():
     L.harness_gap_both.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.harness_cells.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.harness_cells_of_key.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.harness_cell_alt_sh.argtypes = [C.c_uint32, C.c_uint32]
+    L.harness_cell_alt_sh.restype = C.c_uint32
     return L
 
 
@@ -264,9 +266,16 @@ def test_cell_table_build_side_covers_query_side(harness, oracle):
             canon = np.unique(np.minimum(lst[:m], synth.revcomp(lst[:m], k)))
         else:                                          # a forward-only database may hold a k-mer AND its reverse complement
             canon = np.unique(np.concatenate([lst[:m], synth.revcomp(lst[:m], k)]))
-        seen = {}
+        seen, seen_alt = {}, {}
         for c in canon:
             nc = harness.harness_cells_of_key(int(c), k, lbits, both, out.ctypes.data)
             for i in range(nc):
                 cell = tuple(int(x) for x in out[4 * i:4 * i + 4])
                 assert seen.setdefault(cell, int(c)) == int(c), (k, lbits, hex(int(c)), hex(seen[cell]))
+                # the same for second-choice entries (stored with the same (w, r) + the ALT mark in the cell cell_alt_sh names):
+                # the second-choice cell and w must give the first-choice cell back, or two k-mers with equal (w, r) at
+                # different offsets could not be told apart there
+                line, sh, w, r = cell
+                alt = (line, int(harness.harness_cell_alt_sh(sh, w)), w, r)
+                assert alt[1] != sh and alt[1] % 2 == 0 and alt[1] < 32
+                assert seen_alt.setdefault(alt, int(c)) == int(c), (k, lbits, hex(int(c)), hex(seen_alt[alt]))
