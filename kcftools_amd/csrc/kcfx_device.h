@@ -264,6 +264,35 @@ struct CellProbe {
     uint32_t r;         // low 32 - lbits bits of G32
 };
 
+// Where a k-mer's second choice is, and what identifies it there. Two schemes:
+//  * xor (always possible): the cell 1, 3, .. 15 cells away (xor) that the leading flank bits name; the entry carries
+//    (w, r | ALT), and first = second ^ f(w) gives the first-choice cell back, so it is as exact as a first-choice entry;
+//  * free cells (k <= 27 and a table with >= 4 spare r bits): a k-mer spans W = k - 15 <= 12 minimizer positions, so cells
+//    W .. 15 of every line are nobody's FIRST choice -- the second choice goes there (which of them: the leading flank
+//    bits) and succeeds unless another loser of the same line took that cell. Such a cell does not say where its tenant came
+//    from, so the entry carries its first-choice cell index in 4 of the spare r bits (never used for a stash filter there:
+//    only first-choice cells are flagged). On the bench-sized k = 25 database this takes the stash from 1.8 % to 0.4 %.
+struct CellAlt {
+    uint32_t sh;        // 2 * index of the second-choice cell
+    uint32_t r;         // the r field an entry of this k-mer has there
+    uint32_t rmask;     // the bits of r that identify it there
+};
+KCFX_HD bool cell_alt_free(int W, int32_t lbits, bool both) { return W <= 12 && cell_spare_bits(lbits, both) >= 4; }
+KCFX_HD CellAlt cell_alt_of(uint32_t sh, uint32_t w, uint32_t r, int W, int32_t lbits, bool both) {
+    CellAlt a;
+    if (cell_alt_free(W, lbits, both)) {
+        const uint32_t rb = (uint32_t)(32 - lbits);
+        a.sh = 2u * ((uint32_t)W + (((w >> 24) * (uint32_t)(16 - W)) >> 8));
+        a.r = r | CELL_R_ALT | ((sh >> 1) << rb);
+        a.rmask = cell_rmask(lbits, both) | (0xFu << rb);
+    } else {
+        a.sh = cell_alt_sh(sh, w);
+        a.r = r | CELL_R_ALT;
+        a.rmask = cell_rmask(lbits, both);
+    }
+    return a;
+}
+
 // Query side, one lane: F / R = the k-mer as the text reads it and its reverse complement, mn = the tagged minimum over
 // the k-mer's 16 M-mers, lane = this lane's position label base (mm27_tagged was fed (lane + offset) & 15).
 KCFX_HD CellProbe cell_probe_of(uint64_t F, uint64_t R, uint32_t mn, uint32_t lane, int32_t lbits, int M, bool both, int W = 16) {

@@ -257,13 +257,14 @@ __global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__
 }
 
 // where a k-mer stands after the bidding: in its first-choice cell, in its second-choice cell, or in neither
-__device__ __forceinline__ int cell_standing(const uint8_t* lines, const CellProbe& p, uint32_t c, int32_t lbits, bool both) {
+__device__ __forceinline__ int cell_standing(const uint8_t* lines, const CellProbe& p, uint32_t c, int32_t lbits, bool both, int W) {
     const uint64_t kc = cell_keycount_mask(lbits, both);              // (flags and stash-filter bits are not part of the k-mer)
     const uint8_t* line = lines + (size_t)p.line * LINE_BYTES;
     const uint64_t first = __atomic_load_n(reinterpret_cast<const uint64_t*>(line + 4 * p.sh), __ATOMIC_RELAXED);
     if ((first & kc) == cell_word(p.w, p.r, c)) return 0;
-    const uint64_t second = __atomic_load_n(reinterpret_cast<const uint64_t*>(line + 4 * cell_alt_sh(p.sh, p.w)), __ATOMIC_RELAXED);
-    if ((second & kc) == cell_word(p.w, p.r | CELL_R_ALT, c)) return 1;
+    const CellAlt a = cell_alt_of(p.sh, p.w, p.r, W, lbits, both);
+    const uint64_t second = __atomic_load_n(reinterpret_cast<const uint64_t*>(line + 4 * a.sh), __ATOMIC_RELAXED);
+    if ((second & (0xFFFF0000FFFFFFFCull | ((uint64_t)a.rmask << 32))) == cell_word(p.w, a.r, c)) return 1;
     return 2;
 }
 
@@ -281,7 +282,6 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, in
         const uint32_t c = counts[i];
         if (c == 0) continue;
         bool lost = false;
-        const uint64_t kc = cell_keycount_mask(lbits, both);
         const bool wide = c > CELL_COUNT_MAX;
         const int nc = cells_visit(keys[i], k, lbits, both, [&](const CellProbe& p, int) {
             uint8_t* line = lines + (size_t)p.line * LINE_BYTES;
@@ -293,13 +293,15 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, in
                 lost = true;
                 return;
             }
-            if (cell_standing(lines, p, c, lbits, both) != 2) return;     // (1: the same word twice in the input)
-            unsigned long long* alt = reinterpret_cast<unsigned long long*>(line + 4 * cell_alt_sh(p.sh, p.w));
-            const unsigned long long mine = cell_word(p.w, p.r | CELL_R_ALT, c);
+            if (cell_standing(lines, p, c, lbits, both, cell_nw(k)) != 2) return;     // (1: the same word twice in the input)
+            const CellAlt a = cell_alt_of(p.sh, p.w, p.r, cell_nw(k), lbits, both);
+            const unsigned long long kca = 0xFFFF0000FFFFFFFCull | ((unsigned long long)a.rmask << 32);
+            unsigned long long* alt = reinterpret_cast<unsigned long long*>(line + 4 * a.sh);
+            const unsigned long long mine = cell_word(p.w, a.r, c);
             unsigned long long old = __atomic_load_n(alt, __ATOMIC_RELAXED);
             bool won = false;
             while ((old >> 48) == 0) {
-                const unsigned long long prev = atomicCAS(alt, old, mine | (old & ~kc));
+                const unsigned long long prev = atomicCAS(alt, old, mine | (old & ~kca));
                 if (prev == old) {
                     won = true;
                     break;
@@ -308,7 +310,7 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, in
             }
             if (won) {
                 ++n_second;
-            } else if ((old & kc) != mine) {
+            } else if ((old & kca) != mine) {
                 atomicOr(reinterpret_cast<unsigned long long*>(line + 4 * p.sh), mark);
                 lost = true;
             }
@@ -338,7 +340,7 @@ __global__ void cells_stash_kernel(const uint8_t* __restrict__ lines, int32_t k,
         const uint64_t key = keys[i];
         bool lost = c > CELL_COUNT_MAX;                 // (counters wider than a cell's 16 bits)
         if (!lost)
-            cells_visit(key, k, lbits, both != 0, [&](const CellProbe& p, int) { lost |= cell_standing(lines, p, c, lbits, both != 0) == 2; });
+            cells_visit(key, k, lbits, both != 0, [&](const CellProbe& p, int) { lost |= cell_standing(lines, p, c, lbits, both != 0, cell_nw(k)) == 2; });
         if (!lost) continue;
         uint32_t slot = stash_slot(key, mask);
         for (;;) {
@@ -383,11 +385,13 @@ __global__ __launch_bounds__(256) void lookup_cells_kernel(TableView tv, int32_t
             });
             const uint8_t* line = tv.lines + (size_t)c0.line * LINE_BYTES;
             const uint64_t first = *reinterpret_cast<const uint64_t*>(line + 4 * c0.sh);
-            const uint64_t second = *reinterpret_cast<const uint64_t*>(line + 4 * cell_alt_sh(c0.sh, c0.w));
+            const CellAlt a = cell_alt_of(c0.sh, c0.w, c0.r, cell_nw(k), tv.lbits, both);
+            const uint64_t second = *reinterpret_cast<const uint64_t*>(line + 4 * a.sh);
             const uint64_t KEY_BITS = cell_keycount_mask(tv.lbits, both) & 0x0000FFFFFFFFFFFFull;     // w without the flags, r without the filter
+            const uint64_t KEY_BITS_ALT = 0x00000000FFFFFFFCull | ((uint64_t)a.rmask << 32);
             if (((first ^ cell_word(c0.w, c0.r, 0)) & KEY_BITS) == 0 && (first >> 48) != 0)
                 result = (int32_t)(first >> 48);
-            else if (((second ^ cell_word(c0.w, c0.r | CELL_R_ALT, 0)) & KEY_BITS) == 0 && (second >> 48) != 0)
+            else if (((second ^ cell_word(c0.w, a.r, 0)) & KEY_BITS_ALT) == 0 && (second >> 48) != 0)
                 result = (int32_t)(second >> 48);
             else if ((first & CELL_FLAG_STASH) &&
                      (cell_spare_bits(tv.lbits, both) == 0 || ((first >> (32 + cell_filter_pos(c0.w, tv.lbits, both))) & 1)))
@@ -1028,6 +1032,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));   // a native vector
 struct CellWord {
     uint64_t V;            // valid lanes
     uint32_t w, r;         // what this lane's cell must hold (CellProbe)
+    uint32_t r_alt;        // (k <= 27 only) what the r field of its second-choice entry must be (cell_alt_of)
     u32x2 cell, alt;       // what its first- and second-choice cells hold
 };
 
@@ -1035,21 +1040,30 @@ struct CellWord {
 // word, every lane active (an invalid lane reads line 0): the compiler can then count what is in flight -- s_waitcnt
 // vmcnt(2) where word w is consumed while word w + 1's loads stay out -- instead of falling back to vmcnt(0) as it must
 // around a conditional load.
+template <int W, bool BOTH>
 __device__ __forceinline__ void cells_issue(const TableView& tv, uint64_t V, const CellProbe& p, CellWord& cw) {
     const bool valid = __builtin_amdgcn_inverse_ballot_w64(V);
     cw.V = V;
     cw.w = p.w;
     cw.r = p.r;
+    uint32_t alt_sh;
+    if constexpr (W <= 12) {                                   // the table decides between the two second-choice schemes
+        const CellAlt a = cell_alt_of(p.sh, p.w, p.r, W, tv.lbits, BOTH);
+        alt_sh = a.sh;
+        cw.r_alt = a.r;
+    } else {
+        alt_sh = cell_alt_sh(p.sh, p.w);
+    }
     const uint32_t line = valid ? p.line : 0u;
     // lines are 128-byte aligned: the cell's offset in the line (8 * cell = 4 * sh) is OR-ed into the low dword
     const uint64_t off = (uint64_t)line << 7;
     cw.cell = *reinterpret_cast<const u32x2*>(tv.lines + (off | (uint64_t)(p.sh << 2)));
-    cw.alt = *reinterpret_cast<const u32x2*>(tv.lines + (off | (uint64_t)(cell_alt_sh(p.sh, p.w) << 2)));
+    cw.alt = *reinterpret_cast<const u32x2*>(tv.lines + (off | (uint64_t)(alt_sh << 2)));
 }
 
 // stage B: cnt = the stored counter if the cell holds this lane's k-mer (else 0), pend != 0 if it does not and the cell is
 // flagged for the stash
-template <bool BOTH>
+template <bool BOTH, int W>
 __device__ __forceinline__ void cells_match(const CellWord& cw, int32_t lbits, uint32_t& cnt, uint32_t& pend) {
     const bool valid = __builtin_amdgcn_inverse_ballot_w64(cw.V);
     const uint32_t rmask = cell_rmask(lbits, BOTH);             // (wave-uniform: scalar registers)
@@ -1062,8 +1076,12 @@ __device__ __forceinline__ void cells_match(const CellWord& cw, int32_t lbits, u
         const uint32_t x = cw.cell.x, y = cw.cell.y, xa = cw.alt.x, ya = cw.alt.y;
         // (cw.r has no bits outside rmask and bit 15 clear; xor + and fuse into one v_bitop3)
         const bool first = ((x ^ cw.w) <= CELL_FLAG_MASK) && (((y ^ cw.r) & rmask) == 0);
-        const uint32_t r_alt = cw.r ^ CELL_R_ALT;
-        const bool second = ((xa ^ cw.w) <= CELL_FLAG_MASK) && (((ya ^ r_alt) & rmask) == 0);
+        uint32_t r_alt = cw.r ^ CELL_R_ALT, rmask_alt = rmask;
+        if constexpr (W <= 12) {
+            r_alt = cw.r_alt;
+            rmask_alt = cell_alt_free(W, lbits, BOTH) ? rmask | (0xFu << (32 - lbits)) : rmask;
+        }
+        const bool second = ((xa ^ cw.w) <= CELL_FLAG_MASK) && (((ya ^ r_alt) & rmask_alt) == 0);
         cnt = first ? (y >> 16) : second ? (ya >> 16) : 0u;
         // the stash only if the cell is flagged AND (when the table has filter bits) the bit of this flank is set.
         // "cnt == 0", not "no match": an EMPTY cell can be flagged (a k-mer whose counter does not fit 16 bits never takes
@@ -1139,12 +1157,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         uint32_t mn;
         words.next(w, fwd, rc, mn, V);
         const CellProbe p = cell_probe_of(fwd, rc, mn, (uint32_t)lane, tv.lbits, cell_mlen(K), BOTH, cell_nw(K));
-        cells_issue(tv, V, p, cw);
+        cells_issue<cell_nw(K), BOTH>(tv, V, p, cw);
     };
     // stage B of word w: cells matched, ballots out, stash candidates queued
     auto retire = [&](int w, const CellWord& cw) {
         uint32_t cnt = 0, pend = 0;
-        cells_match<BOTH>(cw, tv.lbits, cnt, pend);
+        cells_match<BOTH, cell_nw(K)>(cw, tv.lbits, cnt, pend);
         // cnt is 0 unless the k-mer was found and min_count >= 1 (checked by the API), so this is "found && count >= -c"
         const bool hit = (int32_t)cnt >= min_count;                         // GetVariants.java:224
         const uint64_t H = wave_ballot(hit);

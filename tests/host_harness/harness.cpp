@@ -191,7 +191,13 @@ int harness_cells_of_key(uint64_t C, int k, int lbits, int both, uint32_t* out) 
     }
     return n;
 }
-uint32_t harness_cell_alt_sh(uint32_t sh, uint32_t w) { return cell_alt_sh(sh, w); }
+// out[0..2] = second-choice cell (2 * index), the r field of the entry there, the bits of r compared there
+void harness_cell_alt(uint32_t sh, uint32_t w, uint32_t r, int k, int lbits, int both, uint32_t* out) {
+    const CellAlt a = cell_alt_of(sh, w, r, cell_nw(k), lbits, both != 0);
+    out[0] = a.sh;
+    out[1] = a.r;
+    out[2] = a.rmask;
+}
 uint64_t harness_revcomp_word(uint64_t x, int len) { return revcomp_word(x, len); }
 int harness_tile_k(void) { return TILE_K; }
 

@@ -49,8 +49,8 @@ def harness():
     L.harness_gap_both.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.harness_cells.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.harness_cells_of_key.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p]
-    L.harness_cell_alt_sh.argtypes = [C.c_uint32, C.c_uint32]
-    L.harness_cell_alt_sh.restype = C.c_uint32
+    L.harness_cell_alt.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.harness_cell_alt.restype = None
     return L
 
 
@@ -259,7 +259,9 @@ def test_cell_table_build_side_covers_query_side(harness, oracle):
                 assert (ncand == 1).mean() > 0.8
     # injectivity over every cell of every distinct canonical k-mer of the text (valid positions only)
     out = np.zeros(4 * 32, dtype=np.uint32)
-    for k, lbits, both in ((31, 17, 1), (31, 24, 1), (29, 20, 1), (27, 18, 1), (31, 18, 0), (29, 21, 0), (25, 20, 1), (23, 18, 0), (21, 19, 1), (19, 18, 0)):
+    alt3 = np.zeros(3, dtype=np.uint32)
+    for k, lbits, both in ((31, 17, 1), (31, 24, 1), (29, 20, 1), (27, 18, 1), (31, 18, 0), (29, 21, 0), (25, 20, 1), (23, 18, 0), (21, 19, 1), (19, 18, 0),
+                           (27, 21, 1), (25, 27, 1), (25, 22, 0), (21, 24, 1), (19, 23, 0)):
         lst = np.zeros(len(text), dtype=np.uint64)
         m = oracle.lib().kcfo_kmers_list(text, len(text), k, lst.ctypes.data)
         if both:
@@ -272,10 +274,14 @@ def test_cell_table_build_side_covers_query_side(harness, oracle):
             for i in range(nc):
                 cell = tuple(int(x) for x in out[4 * i:4 * i + 4])
                 assert seen.setdefault(cell, int(c)) == int(c), (k, lbits, hex(int(c)), hex(seen[cell]))
-                # the same for second-choice entries (stored with the same (w, r) + the ALT mark in the cell cell_alt_sh names):
-                # the second-choice cell and w must give the first-choice cell back, or two k-mers with equal (w, r) at
-                # different offsets could not be told apart there
+                # the same for second-choice entries (cell_alt_of: the cell, the r field stored there, the r bits compared): what
+                # is stored there must give the first-choice cell back, or two k-mers with equal (w, r) at different offsets
+                # could not be told apart
                 line, sh, w, r = cell
-                alt = (line, int(harness.harness_cell_alt_sh(sh, w)), w, r)
-                assert alt[1] != sh and alt[1] % 2 == 0 and alt[1] < 32
+                harness.harness_cell_alt(sh, w, r, k, lbits, both, alt3.ctypes.data)
+                a_sh, a_r, a_mask = (int(x) for x in alt3)
+                assert a_sh != sh and a_sh % 2 == 0 and a_sh < 32 and a_r & 0x8000 and a_r & ~a_mask == 0
+                if k <= 27 and lbits - (17 if both else 18) >= 4:
+                    assert a_sh >= 2 * (k - 15)                      # a cell that is nobody's first choice
+                alt = (line, a_sh, w, a_r)
                 assert seen_alt.setdefault(alt, int(c)) == int(c), (k, lbits, hex(int(c)), hex(seen_alt[alt]))
