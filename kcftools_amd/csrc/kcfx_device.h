@@ -267,7 +267,7 @@ struct CellProbe {
 // Where a k-mer's second choice is, and what identifies it there. Two schemes:
 //  * xor (always possible): the cell 1, 3, .. 15 cells away (xor) that the leading flank bits name; the entry carries
 //    (w, r | ALT), and first = second ^ f(w) gives the first-choice cell back, so it is as exact as a first-choice entry;
-//  * free cells (k <= 27 and a table with >= 4 spare r bits): a k-mer spans W = k - 15 <= 12 minimizer positions, so cells
+//  * free cells (k <= 30 and a table with >= 4 spare r bits): a k-mer spans W = k - 15 <= 15 minimizer positions, so cells
 //    W .. 15 of every line are nobody's FIRST choice -- the second choice goes there (which of them: the leading flank
 //    bits) and succeeds unless another loser of the same line took that cell. Such a cell does not say where its tenant came
 //    from, so the entry carries its first-choice cell index in 4 of the spare r bits (never used for a stash filter there:
@@ -277,7 +277,8 @@ struct CellAlt {
     uint32_t r;         // the r field an entry of this k-mer has there
     uint32_t rmask;     // the bits of r that identify it there
 };
-KCFX_HD bool cell_alt_free(int W, int32_t lbits, bool both) { return W <= 12 && cell_spare_bits(lbits, both) >= 4; }
+constexpr int CELL_ALT_FREE_MAX_W = 15;       // i.e. every k < 31: even the single free cell of k = 30 beats the xor scheme (stash 1.8 % -> 1.2 %)
+KCFX_HD bool cell_alt_free(int W, int32_t lbits, bool both) { return W <= CELL_ALT_FREE_MAX_W && cell_spare_bits(lbits, both) >= 4; }
 KCFX_HD CellAlt cell_alt_of(uint32_t sh, uint32_t w, uint32_t r, int W, int32_t lbits, bool both) {
     CellAlt a;
     if (cell_alt_free(W, lbits, both)) {

@@ -1032,7 +1032,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));   // a native vector
 struct CellWord {
     uint64_t V;            // valid lanes
     uint32_t w, r;         // what this lane's cell must hold (CellProbe)
-    uint32_t r_alt;        // (k <= 27 only) what the r field of its second-choice entry must be (cell_alt_of)
+    uint32_t r_alt;        // (k <= 30 only) what the r field of its second-choice entry must be (cell_alt_of)
     u32x2 cell, alt;       // what its first- and second-choice cells hold
 };
 
@@ -1047,7 +1047,7 @@ __device__ __forceinline__ void cells_issue(const TableView& tv, uint64_t V, con
     cw.w = p.w;
     cw.r = p.r;
     uint32_t alt_sh;
-    if constexpr (W <= 12) {                                   // the table decides between the two second-choice schemes
+    if constexpr (W <= CELL_ALT_FREE_MAX_W) {                                   // the table decides between the two second-choice schemes
         const CellAlt a = cell_alt_of(p.sh, p.w, p.r, W, tv.lbits, BOTH);
         alt_sh = a.sh;
         cw.r_alt = a.r;
@@ -1077,7 +1077,7 @@ __device__ __forceinline__ void cells_match(const CellWord& cw, int32_t lbits, u
         // (cw.r has no bits outside rmask and bit 15 clear; xor + and fuse into one v_bitop3)
         const bool first = ((x ^ cw.w) <= CELL_FLAG_MASK) && (((y ^ cw.r) & rmask) == 0);
         uint32_t r_alt = cw.r ^ CELL_R_ALT, rmask_alt = rmask;
-        if constexpr (W <= 12) {
+        if constexpr (W <= CELL_ALT_FREE_MAX_W) {
             r_alt = cw.r_alt;
             rmask_alt = cell_alt_free(W, lbits, BOTH) ? rmask | (0xFu << (32 - lbits)) : rmask;
         }

@@ -281,7 +281,7 @@ def test_cell_table_build_side_covers_query_side(harness, oracle):
                 harness.harness_cell_alt(sh, w, r, k, lbits, both, alt3.ctypes.data)
                 a_sh, a_r, a_mask = (int(x) for x in alt3)
                 assert a_sh != sh and a_sh % 2 == 0 and a_sh < 32 and a_r & 0x8000 and a_r & ~a_mask == 0
-                if k <= 27 and lbits - (17 if both else 18) >= 4:
+                if k <= 30 and lbits - (17 if both else 18) >= 4:
                     assert a_sh >= 2 * (k - 15)                      # a cell that is nobody's first choice
                 alt = (line, a_sh, w, a_r)
                 assert seen_alt.setdefault(alt, int(c)) == int(c), (k, lbits, hex(int(c)), hex(seen_alt[alt]))
