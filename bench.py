@@ -73,6 +73,42 @@ def jvm_probe():
         return "present (version unreadable)"
 
 
+def pin_probe(jvm):
+    """The pin fires the moment it can: with a JVM on the box and KCFTOOLS_JAR=<kcftools jar> in the environment the nine
+    golden cases are run through the reference (tools/pin_against_jar.sh) and the outcome lands in the bench line."""
+    jar = os.environ.get("KCFTOOLS_JAR")
+    if not jvm or not jar:
+        return {"status": "unpinned", "why": ("no JVM on this box" if not jvm else "KCFTOOLS_JAR is not set")
+                + "; tools/pin_against_jar.sh is the one-command pin"}
+    try:
+        p = subprocess.run([os.path.join(ROOT, "tools", "pin_against_jar.sh")], capture_output=True, text=True, timeout=900)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("pin:")]
+        return {"status": "pinned" if p.returncode == 0 else "FAILED", "jar": jar, "cases_identical_to_oracle":
+                sum("reference == oracle" in ln for ln in lines), "cases_byte_identical_kcf": sum("byte-identical" in ln for ln in lines),
+                "tail": lines[-3:]}
+    except Exception as exc:
+        return {"status": "error", "why": str(exc)[:300]}
+
+
+def java_reference_leg(jvm, fa, prefix, window, min_count, threads, kmers_per_step):
+    """the Java reference itself, timed on this box's host cores, where a JVM and a kcftools jar exist."""
+    jar = os.environ.get("KCFTOOLS_JAR")
+    if not jvm or not jar or not os.path.exists(fa):
+        return None
+    try:
+        out = prefix + ".java.kcf"
+        t0 = time.perf_counter()
+        p = subprocess.run(["java", "-jar", jar, "getVariations", "-r", fa, "-k", prefix, "-o", out, "-s", "bench", "-f", "window",
+                            "-w", str(window), "-c", str(min_count), "-t", str(threads), "-m"], capture_output=True, text=True, timeout=3600)
+        wall = time.perf_counter() - t0
+        if p.returncode != 0:
+            return {"error": (p.stdout + p.stderr)[-300:]}
+        return {"value": kmers_per_step / wall, "unit": "k-mers/s", "cores": threads, "kind": "reference", "seconds_wall": wall,
+                "sample": "the whole step (every window), java -jar kcftools getVariations -m, database open and KCF output included"}
+    except Exception as exc:
+        return {"error": str(exc)[:300]}
+
+
 def make_dataset(synth_bin: str, workdir: str, ref_len: int, db_kmers: int, sample_seed: int, threads: int) -> tuple[str, dict]:
     """Reference text + one sample's KMC database, written by the native generator (cached per parameter set)."""
     os.makedirs(workdir, exist_ok=True)

@@ -84,7 +84,8 @@ typedef struct {
     int64_t heavy_lines;     /* minimizer home lines whose k-mers were re-homed by key hash (low-complexity repeats) */
     int64_t overflow_lines;  /* lines that pushed k-mers to the next line */
     int32_t table_format;    /* 0 = 12-slot lines; 1 = 16 offset-addressed cells per line + stash (the default for k = 19..31) */
-    int32_t _pad;
+    int32_t lut_suspect;     /* 1: the prefix LUT is not a run of prefix sums and the file was accepted only because
+                                KCFX_LENIENT_LUT=1 is set (by default such a .kmc_pre is refused with KCFX_ERR_FORMAT) */
     int64_t stored_kmers;    /* format 1: k-mers with a non-zero counter (the others can never be observed) */
     int64_t stash_kmers;     /* format 1: k-mers that found a cell taken and live in the stash */
     int64_t stash_bytes;     /* format 1: HBM bytes of the stash (included in table_bytes) */
@@ -95,7 +96,9 @@ typedef struct {
 /* ---- database ------------------------------------------------------------------------------------ */
 
 /* Parse <kmc_prefix>.kmc_pre / .kmc_suf (layout: KMC.java:107-189) and build the HBM table on `device`.
- * Fails with KCFX_ERR_FORMAT unless version == 0x200, 1 <= k <= 32 and (k - lut_prefix_length) % 4 == 0. */
+ * Fails with KCFX_ERR_FORMAT unless version == 0x200, 1 <= k <= 32, (k - lut_prefix_length) % 4 == 0 and the LUT is the
+ * non-decreasing run of record indices from 0 to at most total_kmers that a KMC writer produces (the reference reads the
+ * LUT unchecked, KMC.java:153-163; KCFX_LENIENT_LUT=1 in the environment does the same and sets lut_suspect). */
 int32_t kcfx_db_open(const char* kmc_prefix, int32_t device, kcfx_db** out);
 
 /* Build the same table from host arrays of distinct k-mer words and counts (no files). `counter_size` in

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "kcfx_internal.h"
+#include "kmc_pre.h"
 
 namespace kcfx {
 
@@ -55,126 +56,6 @@ static int32_t fail(int32_t code, const std::string& msg) {
 
 static double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
-// ------------------------------------------------------------------------------------------------------
-// KMC files (layout: KMC.java:107-189)
-// ------------------------------------------------------------------------------------------------------
-struct KmcHeader {
-    int32_t k = 0, mode = 0, counter_size = 0, p = 0, sig_len = 0, min_count = 0, max_count = 0, both = 0, version = 0;
-    int32_t n_bins = 0;
-    int64_t total = 0;
-    int32_t suffix_bytes = 0, record_size = 0;
-    // n_bins * 4^p global record indices: a view into `file` (the whole .kmc_pre, 64 MiB for p = 7; file offset 4 is not
-    // 8-byte aligned, hence the byte pointer + memcpy accessors)
-    std::unique_ptr<uint8_t[]> file;
-    const uint8_t* lut_bytes = nullptr;
-    int64_t lut_entries = 0;
-    uint64_t lut_at(int64_t i) const { uint64_t v; memcpy(&v, lut_bytes + 8 * i, 8); return v; }
-};
-
-static uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
-static uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
-
-// pread `bytes` at `offset` into dst with a few threads (page cache -> pinned memory is a memcpy: one thread moves
-// ~5 GB/s, the .kmc_suf of a 150 M-k-mer sample is 1.2 GB)
-static bool parallel_pread(int fd, uint8_t* dst, int64_t bytes, int64_t offset) {
-    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(8, bytes >> 22));      // >= 4 MiB per thread (4 .. 32 threads measure the same:
-                                                                                     // the upload over PCIe, not this copy, paces a load)
-    std::atomic<bool> ok{true};
-    auto work = [&](int t) {
-        const int64_t lo = bytes * t / T, hi = bytes * (t + 1) / T;
-        int64_t got = lo;
-        while (got < hi) {
-            const ssize_t r = pread(fd, dst + got, (size_t)(hi - got), offset + got);
-            if (r <= 0) {
-                ok = false;
-                return;
-            }
-            got += r;
-        }
-    };
-    std::vector<std::thread> th;
-    for (int t = 1; t < T; ++t) th.emplace_back(work, t);
-    work(0);
-    for (auto& x : th) x.join();
-    return ok;
-}
-
-// whole file into an uninitialised buffer (no zero-fill pass)
-static int32_t read_whole(const std::string& path, std::unique_ptr<uint8_t[]>& out, int64_t& size) {
-    const int fd = open(path.c_str(), O_RDONLY);
-    if (fd < 0) return fail(KCFX_ERR_IO, "Error reading prefix file " + path);
-    struct stat st;
-    if (fstat(fd, &st) != 0) {
-        close(fd);
-        return fail(KCFX_ERR_IO, "Error reading prefix file " + path);
-    }
-    size = (int64_t)st.st_size;
-    out.reset(new uint8_t[(size_t)std::max<int64_t>(size, 1)]);
-    const bool ok = parallel_pread(fd, out.get(), size, 0);
-    close(fd);
-    if (!ok) return fail(KCFX_ERR_IO, "short read on " + path);
-    return KCFX_OK;
-}
-
-// KMC.java:107-168 readPrefixFile
-static int32_t parse_prefix_file(const std::string& path, KmcHeader& h) {
-    int64_t size = 0;
-    if (int32_t rc = read_whole(path, h.file, size)) return rc;
-    const uint8_t* pre = h.file.get();
-    if (size < 4 + 8 + 68 + 8) return fail(KCFX_ERR_FORMAT, "prefix file too small: " + path);
-    if (memcmp(pre, "KMCP", 4) != 0 || memcmp(pre + size - 4, "KMCP", 4) != 0)
-        return fail(KCFX_ERR_FORMAT, "missing KMCP markers in " + path);
-    const int64_t header_offset = rd32(pre + size - 8);                    // :117-118
-    const int64_t pos = size - header_offset - 8;                          // :121
-    if (header_offset < 68 || pos < 4 + 8) return fail(KCFX_ERR_FORMAT, "bad header offset in " + path);
-    const uint8_t* q = pre + pos;
-    h.k = (int32_t)rd32(q + 0);                                            // :124
-    h.mode = (int32_t)rd32(q + 4);
-    h.counter_size = (int32_t)rd32(q + 8);
-    h.p = (int32_t)rd32(q + 12);
-    h.sig_len = (int32_t)rd32(q + 16);
-    h.min_count = (int32_t)rd32(q + 20);
-    h.max_count = (int32_t)rd32(q + 24);
-    h.total = (int64_t)rd64(q + 28);
-    h.both = (q[36] == 0) ? 1 : 0;                                         // :133 (inverted flag)
-    h.version = (int32_t)rd32(q + 64);                                     // :139
-    if (h.version != 0x200) return fail(KCFX_ERR_FORMAT, "KMC version is not 0x200");   // :140-142
-    if (h.k < 1 || h.k > 32) return fail(KCFX_ERR_FORMAT, "unsupported k-mer length " + std::to_string(h.k) + " (1..32)");
-    if (h.p < 0 || h.p > 15 || h.p > h.k || (h.k - h.p) % 4 != 0)
-        return fail(KCFX_ERR_FORMAT, "unsupported LUT prefix length " + std::to_string(h.p) + " for k=" + std::to_string(h.k));
-    if (h.counter_size < 0 || h.counter_size > 4) return fail(KCFX_ERR_FORMAT, "unsupported counter size");
-    if (h.sig_len < 1 || h.sig_len > 14) return fail(KCFX_ERR_FORMAT, "unsupported signature length");
-    if (h.total < 0) return fail(KCFX_ERR_FORMAT, "negative k-mer total");
-    const int64_t map_size = (1ll << (2 * h.sig_len)) + 1;                 // :145
-    const int64_t map_start = size - header_offset - 8 - map_size * 4;     // :146
-    const int64_t lut_size = 1ll << (2 * h.p);                             // :154
-    if (map_start < 4 + 8) return fail(KCFX_ERR_FORMAT, "prefix file too small for its signature map");
-    h.n_bins = (int32_t)((map_start - 8 - 4) / (lut_size * 8));            // :156
-    const int64_t entries = (int64_t)h.n_bins * lut_size;                  // :160
-    h.lut_bytes = pre + 4;                                                 // :153,:161-163
-    h.lut_entries = entries;
-    // Sanity of the LUT (prefix sums of record counts). The reference reads these values without looking at them
-    // (KMC.java:153-163), and no database written by the real `kmc` tool has been available to check the expectations
-    // against, so a violation is reported, not refused: the lookups of the affected prefixes are then as undefined here as
-    // they are in the reference.
-    uint64_t prev = 0;
-    bool monotonic = true;
-    for (int64_t i = 0; i < entries; ++i) {
-        const uint64_t v = h.lut_at(i);
-        monotonic = monotonic && v >= prev;
-        prev = v;
-    }
-    if (!monotonic) fprintf(stderr, "kcfx: warning: %s: LUT is not monotonic\n", path.c_str());
-    if (entries && h.lut_at(entries - 1) > (uint64_t)h.total)
-        fprintf(stderr, "kcfx: warning: %s: LUT points past total_kmers\n", path.c_str());
-    if (h.total > 0 && entries > 0 && h.lut_at(0) != 0)
-        fprintf(stderr, "kcfx: warning: %s: LUT does not start at record 0\n", path.c_str());
-    if (h.total > 0 && entries == 0) return fail(KCFX_ERR_FORMAT, "prefix file has no LUT");
-    h.suffix_bytes = (h.k - h.p) / 4;
-    h.record_size = h.counter_size + h.suffix_bytes;                       // :61
-    return KCFX_OK;
 }
 
 }  // namespace kcfx
@@ -723,6 +604,7 @@ static void info_from_header(const KmcHeader& h, kcfx_db_info_t& info) {
     info.version = h.version;
     info.n_bins = h.n_bins;
     info.total_kmers = h.total;
+    info.lut_suspect = h.lut_suspect ? 1 : 0;
 }
 
 // a handle under construction: freed on every exit path (error return or exception) unless released
@@ -763,7 +645,10 @@ int32_t kcfx_db_open(const char* kmc_prefix, int32_t device, kcfx_db** out) try 
     const double t0 = now_s();
     KmcHeader h;
     LoadTrace tr;
-    if (int32_t rc = parse_prefix_file(std::string(kmc_prefix) + ".kmc_pre", h)) return rc;
+    {
+        std::string perr;
+        if (int32_t rc = parse_prefix_file(std::string(kmc_prefix) + ".kmc_pre", h, perr)) return fail(rc, perr);
+    }
     tr.mark("parse .kmc_pre");
     if (int32_t rc = check_device(device)) return rc;
     DeviceGuard g(device);
@@ -785,7 +670,8 @@ int32_t kcfx_db_open(const char* kmc_prefix, int32_t device, kcfx_db** out) try 
         // the 12-slot line table stores a k-mer in 11-30 bytes instead of 100+, at ~0.55x the screening speed
         const std::string why = g_error;
         table_release(db);
-        fprintf(stderr, "kcfx: %s: cell table not built (%s); building a line table instead\n", kmc_prefix, why.c_str());
+        // (not an error and not reported on stderr -- this is a library behind a C / JNI ABI: kcfx_db_info's table_format says it)
+        if (getenv("KCFX_VERBOSE")) fprintf(stderr, "kcfx: %s: cell table not built (%s); building a line table instead\n", kmc_prefix, why.c_str());
         rc = table_alloc(db, h.total, h.counter_size, false);
         if (!rc) rc = load_suffix_file(db, std::string(kmc_prefix) + ".kmc_suf", h);
         tr.mark("rebuilt as a line table");
@@ -884,7 +770,10 @@ int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, 
 int32_t kcfx_db_header(const char* kmc_prefix, kcfx_db_info_t* info) try {
     if (!kmc_prefix || !info) return fail(KCFX_ERR_ARG, "null argument");
     KmcHeader h;
-    if (int32_t rc = parse_prefix_file(std::string(kmc_prefix) + ".kmc_pre", h)) return rc;
+    {
+        std::string perr;
+        if (int32_t rc = parse_prefix_file(std::string(kmc_prefix) + ".kmc_pre", h, perr)) return fail(rc, perr);
+    }
     memset(info, 0, sizeof *info);
     info_from_header(h, *info);
     info->device = -1;

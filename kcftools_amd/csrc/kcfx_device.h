@@ -72,6 +72,24 @@ KCFX_HD void pack4(uint32_t x, uint32_t& code8, uint32_t& valid4) {
     valid4 = ((ok * 0x08040201u) >> 24) & 0xFu;       // byte j -> bit 3-j
 }
 
+// The codes alone plus ONE word that is zero iff all four characters are A/C/G/T in either case (the per-base validity bits
+// cost 9 of pack4's 19 instructions, and all but a few chunks of a genome are clean): pack16_codes for everybody, pack16
+// only for the chunks whose word is not zero.
+KCFX_HD void pack4_codes(uint32_t x, uint32_t& code8, uint32_t& dirt) {
+    const uint32_t cb = ((x >> 1) & 0x03030303u) ^ ((x >> 2) & 0x01010101u);
+    code8 = (cb * 0x40100401u) >> 24;
+    dirt = (x & 0xDFDFDFDFu) ^ byte_select_acgt(cb);
+}
+KCFX_HD void pack16_codes(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t& code32, uint32_t& dirt) {
+    uint32_t c0, c1, c2, c3, d0, d1, d2, d3;
+    pack4_codes(x0, c0, d0);
+    pack4_codes(x1, c1, d1);
+    pack4_codes(x2, c2, d2);
+    pack4_codes(x3, c3, d3);
+    code32 = (c0 << 24) | (c1 << 16) | (c2 << 8) | c3;
+    dirt = d0 | d1 | d2 | d3;
+}
+
 // 16 ASCII bases -> 32 code bits (MSB first) + 16 validity bits (MSB first)
 KCFX_HD void pack16(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t& code32, uint32_t& valid16) {
     uint32_t c0, c1, c2, c3, v0, v1, v2, v3;

@@ -105,7 +105,14 @@ struct TableView {
 #ifndef KCFX_BLOCK
 #define KCFX_BLOCK 256
 #endif
-constexpr int BLOCK = KCFX_BLOCK;     // 4 wavefronts
+constexpr int BLOCK = KCFX_BLOCK;     // 4 wavefronts (line-table kernels)
+// The cell-table kernel runs 2 wavefronts x 16 words per tile: a wave's fixed cost (its first word's strands, scans and cell
+// loads: ~112 VALU instructions) is paid once per 16 words instead of once per 8 -- the kernel sits at the VALU issue limit,
+// and same-box A/B on the bench workload gives 0.1039 ms per launch against 0.1118 ms with 4 x 8 (profiles/r03_notes.md)
+#ifndef KCFX_CELLS_BLOCK
+#define KCFX_CELLS_BLOCK 128
+#endif
+constexpr int CELLS_BLOCK = KCFX_CELLS_BLOCK;
 #ifndef KCFX_TILE_K
 #define KCFX_TILE_K 2048
 #endif

@@ -728,6 +728,7 @@ struct K31Shared {
 };
 
 // phase 1: ASCII -> 2-bit codes + validity bits in LDS (as screen_tiles_kernel); returns the tile's bit offset `off`
+template <int NT = BLOCK>
 __device__ __forceinline__ int k31_pack_tile(K31Pack& sh, const uint8_t* __restrict__ text, const TileDesc& td, int tid) {
     constexpr int k = 31;
     const int64_t a0 = td.text_off & ~(int64_t)31;
@@ -741,14 +742,22 @@ __device__ __forceinline__ int k31_pack_tile(K31Pack& sh, const uint8_t* __restr
         sh.vbx[0] = 0;
     }
     bool bad = false;
-    for (int c = tid; c < nchunks + 2; c += BLOCK) {
+    for (int c = tid; c < nchunks + 2; c += NT) {
         uint32_t f0 = 0, f1 = 0, v0 = 0, v1 = 0;
         if (c < nchunks) {
             const uint4* p = reinterpret_cast<const uint4*>(text + a0 + 32 * (int64_t)c);
             const uint4 x = p[0], y = p[1];
-            pack16(x.x, x.y, x.z, x.w, f0, v0);
-            pack16(y.x, y.y, y.z, y.w, f1, v1);
-            bad |= ((v0 << 16) | v1) != 0xFFFFFFFFu;
+            uint32_t d0, d1;
+            pack16_codes(x.x, x.y, x.z, x.w, f0, d0);
+            pack16_codes(y.x, y.y, y.z, y.w, f1, d1);
+            v0 = 0xFFFFu;
+            v1 = 0xFFFFu;
+            if ((d0 | d1) != 0u) {                              // rare: an N, an IUPAC code, a non-letter in this chunk
+                uint32_t g0, g1;
+                pack16(x.x, x.y, x.z, x.w, g0, v0);
+                pack16(y.x, y.y, y.z, y.w, g1, v1);
+                bad = true;
+            }
         }
         s_fc[2 * c] = make_uint2(f0, comp_swap(f0));
         s_fc[2 * c + 1] = make_uint2(f1, comp_swap(f1));
@@ -762,10 +771,11 @@ __device__ __forceinline__ int k31_pack_tile(K31Pack& sh, const uint8_t* __restr
 }
 // after k31_pack_tile: every base of the tile's chunks is A/C/G/T (then validity is a matter of the tile's length only;
 // conservative: the chunks cover a few bases around the tile too)
+template <int NW = WAVES>
 __device__ __forceinline__ bool k31_tile_clean(const K31Pack& sh) {
     uint32_t d = 0;
 #pragma unroll
-    for (int i = 0; i < WAVES; ++i) d |= sh.dirty[i];
+    for (int i = 0; i < NW; ++i) d |= sh.dirty[i];
     return __builtin_amdgcn_readfirstlane((int)d) == 0;
 }
 
@@ -826,7 +836,7 @@ struct K31Words {
     __device__ __forceinline__ void start(const K31Pack& sh, int off, int n_kmers_, int lane_, int w_begin) {
         n_kmers = n_kmers_;
         lane = lane_;
-        clean = k31_tile_clean(sh);
+        clean = k31_tile_clean<CELLS ? CELLS_BLOCK / 64 : WAVES>(sh);
         next15 = ((lane + 15) & 63) << 2;                   // ds_bpermute address of lane + 15 (mod 64)
         const int q = off + w_begin * 64 + lane;
         const int b0 = 2 * q - 1;                            // bits_at(., 2q) on both strands at once
@@ -1018,10 +1028,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 // where screen_k31 runs 8 x ds_read_b128 and 12 x v_cmp_eq_u64 per round, and no second round over lines: a k-mer whose
 // cell is flagged "someone who belongs here lives in the stash" (a few per cent) is queued and looked up in the stash
 // 64 at a time, each lane fetching its own 16-byte entry.
+constexpr int CELLS_WAVES = CELLS_BLOCK / 64;
+constexpr int CELLS_WORDS_PER_WAVE = (TILE_WORDS + CELLS_WAVES - 1) / CELLS_WAVES;
+static_assert(CELLS_WAVES >= 1 && CELLS_WAVES <= WAVES && CELLS_WORDS_PER_WAVE <= 64, "cell-table kernel: workgroup shape");
 struct K31CQueue {
     uint32_t id[K31_QUEUE];                                 // (word of the wave << 6) | lane
-    unsigned long long hit[K31_WORDS_PER_WAVE];             // hit ballots of the wave's words
-    unsigned long long vw[K31_WORDS_PER_WAVE];              // their validity ballots (written out with the hits)
+    unsigned long long hit[CELLS_WORDS_PER_WAVE];           // hit ballots of the wave's words
+    unsigned long long vw[CELLS_WORDS_PER_WAVE];            // their validity ballots (written out with the hits)
 };
 
 // The probe of a word is split in two so that the cell loads of word w + 1 are in flight while word w is matched: with
@@ -1127,14 +1140,15 @@ __device__ __forceinline__ int k31c_stash_round(const TableView& tv, const K31Pa
 }
 
 template <int K, bool BOTH>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void screen_k31c_kernel(
+__global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void screen_k31c_kernel(
     const uint8_t* __restrict__ text, const TileDesc* __restrict__ tiles, TableView tv, int32_t min_count,
     uint64_t* __restrict__ bits, int64_t* __restrict__ count_sums) {
+    constexpr int WAVES = CELLS_WAVES;                      // (this kernel's own workgroup shape: kcfx_internal.h)
     __shared__ K31Pack sh;
     __shared__ K31CQueue s_queue[WAVES];
     const TileDesc td = tiles[blockIdx.x];
     const int tid = threadIdx.x;
-    const int off = k31_pack_tile(sh, text, td, tid);
+    const int off = k31_pack_tile<CELLS_BLOCK>(sh, text, td, tid);
 
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_words = (td.n_kmers + 63) >> 6;
@@ -1588,7 +1602,7 @@ hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32
                                int32_t both_strands, int32_t min_count, uint64_t* bits, int64_t* count_sums,
                                hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (n_tiles <= 0) return hipSuccess;
-    const dim3 g(n_tiles), b(BLOCK);
+    const dim3 g(n_tiles), b(BLOCK), bc(CELLS_BLOCK);
     // ev_start / ev_stop (may be null) take the kernel's own begin / end timestamps (hipExtLaunchKernelGGL), which is
     // what rocprofv3 --kernel-trace reports; events recorded around the launch would add the dispatch gaps
 #define KCFX_LAUNCH(W, MD) \
@@ -1600,9 +1614,9 @@ hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32
 #define KCFX_LAUNCHC(KK)                                                                                                                  \
     do {                                                                                                                                  \
         if (both_strands)                                                                                                                 \
-            hipExtLaunchKernelGGL((screen_k31c_kernel<KK, true>), g, b, 0, st, ev_start, ev_stop, 0, text, tiles, tv, min_count, bits, count_sums);  \
+            hipExtLaunchKernelGGL((screen_k31c_kernel<KK, true>), g, bc, 0, st, ev_start, ev_stop, 0, text, tiles, tv, min_count, bits, count_sums);  \
         else                                                                                                                              \
-            hipExtLaunchKernelGGL((screen_k31c_kernel<KK, false>), g, b, 0, st, ev_start, ev_stop, 0, text, tiles, tv, min_count, bits, count_sums); \
+            hipExtLaunchKernelGGL((screen_k31c_kernel<KK, false>), g, bc, 0, st, ev_start, ev_stop, 0, text, tiles, tv, min_count, bits, count_sums); \
     } while (0)
         switch (k) {
             case 19: KCFX_LAUNCHC(19); break;

@@ -42,7 +42,7 @@ class DbInfo(C.Structure):
                 ("slots_per_line", C.c_int32), ("device", C.c_int32), ("load_seconds", C.c_double),
                 ("table_mode", C.c_int32), ("minimizer_length", C.c_int32),
                 ("heavy_lines", C.c_int64), ("overflow_lines", C.c_int64),
-                ("table_format", C.c_int32), ("_pad", C.c_int32), ("stored_kmers", C.c_int64),
+                ("table_format", C.c_int32), ("lut_suspect", C.c_int32), ("stored_kmers", C.c_int64),
                 ("stash_kmers", C.c_int64), ("stash_bytes", C.c_int64), ("multi_cell_kmers", C.c_int64),
                 ("second_choice_kmers", C.c_int64)]
 

@@ -41,8 +41,22 @@ static Packed pack_tile(const uint8_t* text, int64_t text_off, int n_kmers, int 
         if (c < nchunks) {
             uint32_t x[8];
             memcpy(x, text + a0 + 32 * (int64_t)c, 32);
-            pack16(x[0], x[1], x[2], x[3], f0, v0);
-            pack16(x[4], x[5], x[6], x[7], f1, v1);
+            // as k31_pack_tile: codes + one "dirty" word per 16 bases, per-base validity only for dirty chunks
+            uint32_t d0, d1;
+            pack16_codes(x[0], x[1], x[2], x[3], f0, d0);
+            pack16_codes(x[4], x[5], x[6], x[7], f1, d1);
+            v0 = v1 = 0xFFFFu;
+            uint32_t g0, g1, w0, w1;
+            pack16(x[0], x[1], x[2], x[3], g0, w0);
+            pack16(x[4], x[5], x[6], x[7], g1, w1);
+            if (g0 != f0 || g1 != f1 || ((d0 | d1) == 0) != (w0 == 0xFFFFu && w1 == 0xFFFFu)) {   // the two forms must agree
+                f0 = f1 = 0xBADBAD00u;
+                v0 = v1 = 0;
+            }
+            if ((d0 | d1) != 0) {
+                v0 = w0;
+                v1 = w1;
+            }
         }
         fw[2 * c] = f0;
         fw[2 * c + 1] = f1;

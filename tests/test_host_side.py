@@ -18,8 +18,10 @@ G = os.path.join(ROOT, "tests", "golden")
 
 @pytest.fixture(scope="module")
 def host():
-    so = os.path.join(ROOT, "kcftools_amd", "libkcfhost.so")
-    subprocess.run(["make", "-C", os.path.join(ROOT, "kcftools_amd", "csrc"), "../libkcfhost.so"], check=True, capture_output=True)
+    so = os.environ.get("KCF_HOST_SO")                  # the sanitizer build (tests/test_sanitizers.py)
+    if not so:
+        so = os.path.join(ROOT, "kcftools_amd", "libkcfhost.so")
+        subprocess.run(["make", "-C", os.path.join(ROOT, "kcftools_amd", "csrc"), "../libkcfhost.so"], check=True, capture_output=True)
     L = C.CDLL(so)
     for f in ("kcfh_fmt_2f", "kcfh_double_to_string", "kcfh_float_to_string", "kcfh_faidx", "kcfh_get_sequence",
               "kcfh_gtf_windows", "kcfh_header", "kcfh_row"):

@@ -2,7 +2,8 @@
 # One-command pin of the oracle and of the GPU engine against the REAL kcftools (Java) on any machine that has a JDK 17+
 # and Maven -- the build image has neither, which is why the parity of this repository is "unpinned" (DESIGN.md section 2).
 #
-#   KCFTOOLS_SRC=/path/to/kcftools-checkout  tools/pin_against_jar.sh [--no-gpu]
+#   KCFTOOLS_SRC=/path/to/kcftools-checkout  tools/pin_against_jar.sh [--no-gpu]      (builds the jar: needs Maven too)
+#   KCFTOOLS_JAR=/path/to/kcftools-x.y.z.jar  tools/pin_against_jar.sh [--no-gpu]      (a prebuilt release jar: a JVM is enough)
 #
 # What it does, for every case of tests/golden/expected.json (3 databases x 3 window geometries, incl. -p and -c):
 #   1. builds the reference jar (mvn -q -DskipTests package in $KCFTOOLS_SRC; pom.xml:20-55 pulls picocli & co from Maven Central)
@@ -20,14 +21,19 @@ set -euo pipefail
 HERE="$(cd "$(dirname "$0")/.." && pwd)"
 GPU=1
 [ "${1:-}" = "--no-gpu" ] && GPU=0
-: "${KCFTOOLS_SRC:?set KCFTOOLS_SRC to a checkout of sivasubramanics/kcftools}"
 command -v java >/dev/null || { echo "pin: no java on PATH" >&2; exit 3; }
-command -v mvn >/dev/null || { echo "pin: no mvn on PATH" >&2; exit 3; }
 TMP="$(mktemp -d)"
 trap 'rm -rf "$TMP"' EXIT
-( cd "$KCFTOOLS_SRC" && mvn -q -DskipTests package )
-JAR="$(ls "$KCFTOOLS_SRC"/target/*.jar | grep -v original | head -1)"
-[ -f "$JAR" ] || { echo "pin: no jar under $KCFTOOLS_SRC/target" >&2; exit 3; }
+if [ -n "${KCFTOOLS_JAR:-}" ]; then
+    JAR="$KCFTOOLS_JAR"
+    [ -f "$JAR" ] || { echo "pin: KCFTOOLS_JAR=$JAR is not a file" >&2; exit 3; }
+else
+    : "${KCFTOOLS_SRC:?set KCFTOOLS_JAR to a kcftools jar, or KCFTOOLS_SRC to a checkout of sivasubramanics/kcftools}"
+    command -v mvn >/dev/null || { echo "pin: no mvn on PATH (or give a prebuilt jar: KCFTOOLS_JAR=...)" >&2; exit 3; }
+    ( cd "$KCFTOOLS_SRC" && mvn -q -DskipTests package )
+    JAR="$(ls "$KCFTOOLS_SRC"/target/*.jar | grep -v original | head -1)"
+    [ -f "$JAR" ] || { echo "pin: no jar under $KCFTOOLS_SRC/target" >&2; exit 3; }
+fi
 echo "pin: reference jar $JAR ($(java -version 2>&1 | head -1))"
 CLI="$HERE/kcftools_amd/bin/kcftools-amd"
 G="$HERE/tests/golden"
