@@ -115,6 +115,15 @@ struct kcfx_db {
     int32_t mode = MODE_MINIMIZER;
     int32_t mm_len = 0;
     int32_t generic = 0;                 // KCFX_GENERIC_KERNEL at open time: screen with the general kernel
+    int64_t expected_queries = 0;        // kcfx_db_opts: sizes the table (cells_lbits)
+    int32_t lbits_cap = 0;               // > 0: cell tables of at most 2^lbits_cap lines (a retry after the policy's size did not fit)
+    // kcfx_db_open allocates and clears the cell table (up to 48 GiB: hipMalloc alone can take a second when the driver scrubs
+    // the block first) on a thread of its own while the .kmc_suf is read, decoded and counted: nothing touches the lines
+    // before the first bidding pass, which waits for it (table_ready)
+    std::thread alloc_thread;
+    int32_t alloc_rc = KCFX_OK;          // written by alloc_thread, read after the join
+    std::string alloc_error;
+    bool alloc_oom = false;
     int32_t fmt = FORMAT_LINES;          // FORMAT_CELLS: d_lines holds 1 << lbits cell lines, d_stash the overflow k-mers
     int32_t lbits = 0;
     uint4* d_stash = nullptr;
@@ -243,20 +252,34 @@ bool cells_eligible(const kcfx_db* db, int32_t counter_size) {
 // workload, 150 M k-mers: 9.7 % at 2^26 lines, 6.2 % at 2^27), and every stash lookup is a random 16-byte fetch of its own:
 // aim at ~0.075 k-mers per cell while that stays under 48 GiB and 50 % of the free memory, else halve down to ~1 per cell.
 // KCFX_TABLE_LBITS overrides.
-int32_t cells_lbits(int64_t n_keys, int32_t k, bool both) {
+// Memory against speed (profiles/r03_density.csv, bench workload, 150 M k-mers): 0.07 / 0.14 / 0.28 / 0.56 k-mers per cell =
+// 17.4 / 9.1 / 5.4 / 4.3 GB = 1.00 / 1.04 / 1.08 / 1.33 x the screening time per k-mer. A sparse table pays for itself only
+// over many look-ups -- clearing 12 GB more costs ~4 ms (= 10^10 look-ups at the 8 % difference) when the block comes from the
+// pool, and up to a second when the driver has to scrub it first -- so a handle that is expected to serve fewer than
+// QUERIES_FOR_SPARSE look-ups (kcfx_db_opts: the command-line driver's one pass per sample) is built at ~0.3 per cell.
+constexpr double QUERIES_FOR_SPARSE = 1e10;
+int32_t cells_lbits(int64_t n_keys, int32_t k, bool both, int64_t expected_queries) {
     const int32_t cap = cells_lbits_cap(k);
     const int32_t lmin = cell_lbits_min(both);
     const char* s = getenv("KCFX_TABLE_LBITS");
     if (s && atoi(s) >= lmin && atoi(s) <= cap) return atoi(s);
     const size_t free_b = free_device_bytes();
     const double room = std::min(48.0 * (double)(1ull << 30), 0.5 * (double)free_b);
+    const double density = (expected_queries > 0 && (double)expected_queries < QUERIES_FOR_SPARSE) ? 0.30 : 0.075;
     int32_t L = lmin;
-    while (L < cap && 16.0 * (double)(1ull << L) * 0.075 < (double)n_keys) ++L;
+    while (L < cap && 16.0 * (double)(1ull << L) * density < (double)n_keys) ++L;
     while (L > lmin && (double)(1ull << L) * LINE_BYTES > room && 16.0 * (double)(1ull << (L - 1)) >= (double)n_keys) --L;
     return L;
 }
 
-int32_t cells_alloc(kcfx_db* db, int64_t n_keys) {
+// the deferred half of cells_alloc: join the allocation thread, report what it found
+int32_t table_ready(kcfx_db* db) {
+    if (db->alloc_thread.joinable()) db->alloc_thread.join();
+    if (db->alloc_rc != KCFX_OK) return fail(db->alloc_rc, db->alloc_error);
+    return KCFX_OK;
+}
+
+int32_t cells_alloc(kcfx_db* db, int64_t n_keys, bool deferred = false) {
     db->fmt = FORMAT_CELLS;
     db->wide = 0;
     db->mode = MODE_MINIMIZER;
@@ -266,7 +289,41 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys) {
     db->info.table_format = FORMAT_CELLS;
     hipError_t e = hipErrorOutOfMemory;
     const bool both = db->info.both_strands != 0;
-    for (int32_t L = cells_lbits(n_keys, db->info.kmer_length, both); L >= cell_lbits_min(both); --L) {
+    int32_t L0 = cells_lbits(n_keys, db->info.kmer_length, both, db->expected_queries);
+    if (db->lbits_cap > 0) L0 = std::min(L0, db->lbits_cap);
+    db->alloc_rc = KCFX_OK;
+    db->alloc_oom = false;
+    if (deferred && L0 >= cell_lbits_min(both) && (double)n_keys <= 16.0 * (double)(1ull << L0)) {
+        // the policy's size, allocated and cleared beside the file streaming; if it does not fit, kcfx_db_open starts over
+        // with denser tables, synchronously
+        db->lbits = L0;
+        db->n_lines = 1u << L0;
+        KCFX_HIP(dev_alloc(&db->d_stats, 4 * sizeof(unsigned long long)));
+        KCFX_HIP(hipMemsetAsync(db->d_stats, 0, 4 * sizeof(unsigned long long), db->stream));
+        KCFX_HIP(dev_alloc(&db->d_pop, cells_pop_bytes(db->lbits)));
+        KCFX_HIP(hipMemsetAsync(db->d_pop, 0, cells_pop_bytes(db->lbits), db->stream));
+        db->info.table_bytes = (int64_t)LINE_BYTES << db->lbits;
+        db->info.table_lines = db->n_lines;
+        db->info.slots_per_line = 16;
+        db->alloc_thread = std::thread([db]() {
+            try {
+                hipError_t e2 = hipSetDevice(db->device);
+                if (e2 == hipSuccess) e2 = dev_alloc(&db->d_lines, (size_t)LINE_BYTES << db->lbits);
+                if (e2 == hipSuccess) e2 = hipMemsetAsync(db->d_lines, 0, (size_t)LINE_BYTES << db->lbits, db->stream);
+                if (e2 != hipSuccess) {
+                    db->alloc_oom = (e2 == hipErrorOutOfMemory);
+                    db->alloc_rc = KCFX_ERR_DEVICE;
+                    db->alloc_error = std::string("HIP error: ") + hipGetErrorString(e2) + " in the allocation of the k-mer table";
+                    (void)hipGetLastError();
+                }
+            } catch (...) {
+                db->alloc_rc = KCFX_ERR_HOST;
+                db->alloc_error = "kcfx_db_open: exception on the table allocation thread";
+            }
+        });
+        return KCFX_OK;
+    }
+    for (int32_t L = L0; L >= cell_lbits_min(both); --L) {
         if ((double)n_keys > 16.0 * (double)(1ull << L))            // fewer cells than k-mers: not a cell table any more
             return fail(KCFX_ERR_DEVICE, "no cell table of 2^" + std::to_string(L) + " or more lines fits the device memory (or KCFX_TABLE_LBITS)");
         e = dev_alloc(&db->d_lines, (size_t)LINE_BYTES << L);
@@ -322,6 +379,7 @@ int32_t cells_stash_alloc(kcfx_db* db) {
 
 // back to "no table" (the handle keeps its stream and header fields): before a rebuild in the other format
 void table_release(kcfx_db* db) {
+    if (db->alloc_thread.joinable()) db->alloc_thread.join();
     (void)hipStreamSynchronize(db->stream);
     if (db->d_lines) (void)dev_free(db->d_lines);
     if (db->d_stash) (void)dev_free(db->d_stash);
@@ -341,9 +399,9 @@ void table_release(kcfx_db* db) {
     (void)hipGetLastError();
 }
 
-int32_t table_alloc(kcfx_db* db, int64_t n_keys, int32_t counter_size, bool allow_cells = true) {
+int32_t table_alloc(kcfx_db* db, int64_t n_keys, int32_t counter_size, bool allow_cells = true, bool deferred = false) {
     db->generic = getenv("KCFX_GENERIC_KERNEL") != nullptr;   // A/B and test hook: read when the handle is made, never per launch
-    if (allow_cells && cells_eligible(db, counter_size) && !db->generic) return cells_alloc(db, n_keys);
+    if (allow_cells && cells_eligible(db, counter_size) && !db->generic) return cells_alloc(db, n_keys, deferred);
     db->wide = counter_size > 2 ? 1 : 0;
     db->mode = table_mode();
     db->mm_len = minimizer_len(db->info.kmer_length, n_keys);
@@ -402,6 +460,7 @@ int32_t table_finish(kcfx_db* db) {
 
 void db_free(kcfx_db* db) {
     if (!db) return;
+    if (db->alloc_thread.joinable()) db->alloc_thread.join();
     DeviceGuard g(db->device);
     if (db->stream) (void)hipStreamSynchronize(db->stream);   // shared per device (db_stream), never destroyed
     if (db->d_lines) (void)dev_free(db->d_lines);
@@ -493,7 +552,9 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     const bool cells = (db->fmt == FORMAT_CELLS);
     const bool two_phase = (db->mode == MODE_MINIMIZER);
     // keep every decoded record resident between the phases?
-    const size_t free_b = free_device_bytes();
+    size_t free_b = free_device_bytes();
+    // (the table may still be on its way -- table_ready -- and must not be counted as free room: conservative when it has arrived)
+    if (db->alloc_thread.joinable()) free_b -= std::min<size_t>(free_b, (size_t)LINE_BYTES << db->lbits);
     const bool resident = two_phase && getenv("KCFX_LOAD_STREAM_TWICE") == nullptr &&
                           (double)h.total * 12.0 + (double)(2 * chunk_bytes) + (double)(64 << 20) < 0.5 * (double)free_b;
     const int64_t n_chunk_max = std::min<int64_t>(CH, std::max<int64_t>(h.total, 1));
@@ -569,6 +630,11 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
         if ((rc = stream_file(0, resident))) return rc;
         tr.mark("file -> decode -> first pass (host)");
         if (cells) {
+            if ((rc = table_ready(db))) {               // (the lines are first touched by the bids)
+                cleanup();
+                return rc;
+            }
+            tr.mark("wait for the table");
             for (int phase = 1; phase <= 3; ++phase)
                 if ((rc = later_pass(phase))) return rc;
             if ((rc = cells_stash_alloc(db))) {
@@ -639,8 +705,11 @@ int32_t kcfx_device_count(int32_t* n) {
     return KCFX_OK;
 }
 
-int32_t kcfx_db_open(const char* kmc_prefix, int32_t device, kcfx_db** out) try {
+int32_t kcfx_db_open(const char* kmc_prefix, int32_t device, kcfx_db** out) { return kcfx_db_open_opts(kmc_prefix, device, nullptr, out); }
+
+int32_t kcfx_db_open_opts(const char* kmc_prefix, int32_t device, const kcfx_db_opts* opts, kcfx_db** out) try {
     if (!kmc_prefix || !out) return fail(KCFX_ERR_ARG, "null argument");
+    if (opts && opts->expected_queries < 0) return fail(KCFX_ERR_ARG, "kcfx_db_opts: negative expected_queries");
     *out = nullptr;
     const double t0 = now_s();
     KmcHeader h;
@@ -658,14 +727,23 @@ int32_t kcfx_db_open(const char* kmc_prefix, int32_t device, kcfx_db** out) try 
     db->device = device;
     info_from_header(h, db->info);
     db->info.device = device;
+    db->expected_queries = opts ? opts->expected_queries : 0;
     hipError_t e = db_stream(device, &db->stream);
     if (e != hipSuccess) return hip_fail(e, "hipStreamCreate");
     tr.mark("device + stream");
-    int32_t rc = table_alloc(db, h.total, h.counter_size);
-    if (tr.on) (void)hipStreamSynchronize(db->stream);
-    tr.mark("table alloc + clear");
+    int32_t rc = table_alloc(db, h.total, h.counter_size, true, getenv("KCFX_SYNC_ALLOC") == nullptr);
+    tr.mark("table alloc (deferred)");
     if (!rc) rc = load_suffix_file(db, std::string(kmc_prefix) + ".kmc_suf", h);
-    if (rc == KCFX_ERR_DEVICE && db->fmt == FORMAT_CELLS) {
+    if (rc == KCFX_ERR_DEVICE && db->fmt == FORMAT_CELLS && db->alloc_oom && db->lbits - 1 >= cell_lbits_min(db->info.both_strands != 0)) {
+        // the policy's table did not fit next to what else lives on the device: denser cell tables, allocated synchronously
+        const int32_t cap = db->lbits - 1;
+        table_release(db);
+        db->lbits_cap = cap;
+        rc = table_alloc(db, h.total, h.counter_size, true, false);
+        if (!rc) rc = load_suffix_file(db, std::string(kmc_prefix) + ".kmc_suf", h);
+        tr.mark("denser cell table after an out-of-memory");
+    }
+    if (rc == KCFX_ERR_DEVICE && db->fmt == FORMAT_CELLS && !(opts && opts->no_fallback)) {
         // the cell table or its stash did not fit (a database of many billions of k-mers next to another resident one):
         // the 12-slot line table stores a k-mer in 11-30 bytes instead of 100+, at ~0.55x the screening speed
         const std::string why = g_error;

@@ -209,13 +209,15 @@ KCFX_HD uint32_t mm27(uint32_t cm) {
     u &= ~31u;
     return u * 0x85EBCA6Bu;
 }
-// What one lane feeds into the sliding minimum: hash | strand bit (bit 4: the canonical form is the reverse complement of
-// the 16-mer as the text reads it) | position label (bits 3..0, distinct within any 16 consecutive positions). The minimum
-// therefore carries where the minimizer sits and which way round it is.
-KCFX_HD uint32_t mm27_tagged(uint32_t fwd_m, uint32_t rc_m, uint32_t label) {
+// What one lane feeds into the sliding minimum: hash | position label (bits 4..1: twice the position mod 16, distinct within
+// any 16 consecutive positions) | strand bit (bit 0: the canonical form is the reverse complement of the 16-mer as the
+// text reads it). The minimum therefore carries where the minimizer sits and which way round it is; with the label
+// pre-doubled the query gets 2 * offset as (mn - 2 * lane) & 30, the strand bit riding along untouched.
+KCFX_HD uint32_t mm27_tagged(uint32_t fwd_m, uint32_t rc_m, uint32_t label2) {
     const uint32_t cm = fwd_m < rc_m ? fwd_m : rc_m;
-    return mm27(cm) | (rc_m < fwd_m ? 16u : 0u) | label;
+    return mm27(cm) | (rc_m < fwd_m ? 1u : 0u) | label2;
 }
+KCFX_HD uint32_t mm27_label2(uint32_t pos) { return (pos & 15u) << 1; }
 // canonical minimizer 16-mer -> G32: line = top lbits, r = the rest. A bijection on 32 bits (odd multiplies, right
 // xorshift), so (line, r) identify the minimizer exactly, and independent of mm27: the MINIMUM of 16 hashes is skewed towards
 // 0 and keeps only ~24 bits of entropy, which would leave most lines of a table of 2^27 or more lines unused.
@@ -314,11 +316,22 @@ KCFX_HD CellAlt cell_alt_of(uint32_t sh, uint32_t w, uint32_t r, int W, int32_t 
 
 // Query side, one lane: F / R = the k-mer as the text reads it and its reverse complement, mn = the tagged minimum over
 // the k-mer's 16 M-mers, lane = this lane's position label base (mm27_tagged was fed (lane + offset) & 15).
-KCFX_HD CellProbe cell_probe_of(uint64_t F, uint64_t R, uint32_t mn, uint32_t lane, int32_t lbits, int M, bool both, int W = 16) {
-    const bool flip = (mn & 16u) != 0;                        // the minimizer is canonical on the other strand
+// (lane2 = 2 * position, what mm27_label2 was fed -- mod 32 is enough)
+KCFX_HD CellProbe cell_probe_of(uint64_t F, uint64_t R, uint32_t mn, uint32_t lane2, int32_t lbits, int M, bool both, int W = 16) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t fm = (uint32_t)__builtin_amdgcn_sbfe((int)mn, 0, 1);
+#else
+    const uint32_t fm = 0u - (mn & 1u);                       // all ones: the minimizer is canonical on the other strand
+#endif
+    const bool flip = fm != 0;
     const uint64_t N = flip ? R : F;
-    uint32_t sh = ((mn - lane) << 1) & 30u;                   // 2 * offset of the minimizer in F
-    sh = flip ? 2u * (uint32_t)(W - 1) - sh : sh;             // in R it sits at W - 1 - offset
+    uint32_t sh;
+    if (W == 16) {
+        sh = ((mn - lane2) ^ fm) & 30u;                       // 2 * offset of the minimizer in F; in R it sits at 15 - offset
+    } else {
+        sh = (mn - lane2) & 30u;
+        sh = flip ? 2u * (uint32_t)(W - 1) - sh : sh;         // in R it sits at W - 1 - offset
+    }
     CellProbe p;
     uint32_t cm;
     p.w = cell_flank(N, sh, M, &cm);

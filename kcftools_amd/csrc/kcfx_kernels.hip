@@ -828,7 +828,7 @@ struct K31Words {
         if constexpr (CELLS) {
             // the 16-mer is the leading 32 code bits; its reverse complement the same bits of the complement-swapped
             // stream, reversed
-            return mm27_tagged(f0, brev32(c0), (uint32_t)lane & 15u);
+            return mm27_tagged(f0, brev32(c0), mm27_label2((uint32_t)lane));
         } else {
             return mhash32(((uint64_t)min(f0, brev32(c0))) << 32);
         }
@@ -1059,33 +1059,48 @@ __device__ __forceinline__ void cells_issue(const TableView& tv, uint64_t V, con
     cw.V = V;
     cw.w = p.w;
     cw.r = p.r;
-    uint32_t alt_sh;
+    uint32_t alt_sh = 0;
     if constexpr (W <= CELL_ALT_FREE_MAX_W) {                                   // the table decides between the two second-choice schemes
         const CellAlt a = cell_alt_of(p.sh, p.w, p.r, W, tv.lbits, BOTH);
         alt_sh = a.sh;
         cw.r_alt = a.r;
-    } else {
-        alt_sh = cell_alt_sh(p.sh, p.w);
     }
-    const uint32_t line = valid ? p.line : 0u;
-    // lines are 128-byte aligned: the cell's offset in the line (8 * cell = 4 * sh) is OR-ed into the low dword
-    const uint64_t off = (uint64_t)line << 7;
-    cw.cell = *reinterpret_cast<const u32x2*>(tv.lines + (off | (uint64_t)(p.sh << 2)));
-    cw.alt = *reinterpret_cast<const u32x2*>(tv.lines + (off | (uint64_t)(alt_sh << 2)));
+    uint32_t line = valid ? p.line : 0u;
+    asm volatile("" : "+v"(line));                              // (select the 32-bit line number, not the 64-bit byte offset after the shift)
+    // lines are 128-byte aligned (and so is the table): the first-choice cell's offset in the line (8 * cell = 4 * sh) is OR-ed
+    // into the low dword of the line's byte offset, and the second-choice cell of the xor scheme is the same address with
+    // 4 * (sh ^ alt_sh) -- a function of the flank alone -- xor-ed into its low dword
+    // base + ((32 * line + sh) << 2): v_lshlrev_b64, v_or, v_lshl_add_u64 (whose shift goes up to 4)
+    uint64_t l32 = ((uint64_t)line << 5) | (uint64_t)p.sh;
+    asm volatile("" : "+v"(l32));                               // (or the compiler re-associates it into a shift by 7 and two 64-bit adds)
+    const uint8_t* a0 = reinterpret_cast<const uint8_t*>(reinterpret_cast<const uint32_t*>(tv.lines) + l32);
+    cw.cell = *reinterpret_cast<const u32x2*>(a0);
+    if constexpr (W <= CELL_ALT_FREE_MAX_W) {
+        cw.alt = *reinterpret_cast<const u32x2*>(tv.lines + (((uint64_t)line << 7) | (uint64_t)(alt_sh << 2)));
+    } else {
+        // (a global-address-space pointer: through a generic one the load would be a flat_load, which the compiler cannot
+        // count in vmcnt and waits for with vmcnt(0) -- the end of the software pipeline)
+        typedef const __attribute__((address_space(1))) u32x2* gcell_ptr;
+        const uint64_t a1 = (uint64_t)a0 ^ (uint64_t)(((p.w >> 25) & 0x70u) | 8u);          // 4 * (((w >> 27) & 0x1C) | 2)
+        cw.alt = *(gcell_ptr)a1;
+    }
 }
 
-// stage B: cnt = the stored counter if the cell holds this lane's k-mer (else 0), pend != 0 if it does not and the cell is
-// flagged for the stash
+// stage B: cnt = the stored counter if the cell holds this lane's k-mer (else 0); pend != 0: the cell is flagged for the stash
+// and this flank's filter bit is set (the k-mer is looked up there if cnt == 0)
 template <bool BOTH, int W>
 __device__ __forceinline__ void cells_match(const CellWord& cw, int32_t lbits, uint32_t& cnt, uint32_t& pend) {
-    const bool valid = __builtin_amdgcn_inverse_ballot_w64(cw.V);
     const uint32_t rmask = cell_rmask(lbits, BOTH);             // (wave-uniform: scalar registers)
-    const bool filtered = cell_spare_bits(lbits, BOTH) > 0;
     // (cell_filter_pos with its two wave-uniform terms pinned to scalar registers: one v_add instead of a sub + add pair)
     uint32_t rb = (uint32_t)(32 - lbits);
     asm volatile("" : "+s"(rb));
     const uint32_t nspare = cell_spare_bits(lbits, BOTH);
-    if (valid) {
+    // a table without filter bits sends every miss in a flagged cell to the stash: OR-ed in as a scalar, so that the word loop
+    // has neither a branch nor a materialised predicate for it
+    const uint32_t unfiltered = nspare > 0 ? 0u : 1u;
+    // (every lane, valid or not -- an invalid one has loaded cell 0 of line 0: the caller masks the ballots with V, which costs
+    // scalar instructions only, where a predicated region costs the moves that initialise cnt and pend around it)
+    {
         const uint32_t x = cw.cell.x, y = cw.cell.y, xa = cw.alt.x, ya = cw.alt.y;
         // (cw.r has no bits outside rmask and bit 15 clear; xor + and fuse into one v_bitop3)
         const bool first = ((x ^ cw.w) <= CELL_FLAG_MASK) && (((y ^ cw.r) & rmask) == 0);
@@ -1099,8 +1114,8 @@ __device__ __forceinline__ void cells_match(const CellWord& cw, int32_t lbits, u
         // the stash only if the cell is flagged AND (when the table has filter bits) the bit of this flank is set.
         // "cnt == 0", not "no match": an EMPTY cell can be flagged (a k-mer whose counter does not fit 16 bits never takes
         // a cell) and would "match" the k-mer whose w and r are all zero
-        const uint32_t mine = filtered ? ((y >> (rb + __umulhi(cw.w * 0x9E3779B1u, nspare))) & 1u) : 1u;
-        pend = cnt != 0u ? 0u : (x & CELL_FLAG_STASH & mine);
+        const uint32_t mine = (y >> (rb + __umulhi(cw.w * 0x9E3779B1u, nspare))) | unfiltered;
+        pend = x & mine & CELL_FLAG_STASH;
     }
 }
 
@@ -1170,7 +1185,7 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
         uint64_t fwd, rc, V;
         uint32_t mn;
         words.next(w, fwd, rc, mn, V);
-        const CellProbe p = cell_probe_of(fwd, rc, mn, (uint32_t)lane, tv.lbits, cell_mlen(K), BOTH, cell_nw(K));
+        const CellProbe p = cell_probe_of(fwd, rc, mn, 2u * (uint32_t)lane, tv.lbits, cell_mlen(K), BOTH, cell_nw(K));
         cells_issue<cell_nw(K), BOTH>(tv, V, p, cw);
     };
     // stage B of word w: cells matched, ballots out, stash candidates queued
@@ -1178,17 +1193,18 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
         uint32_t cnt = 0, pend = 0;
         cells_match<BOTH, cell_nw(K)>(cw, tv.lbits, cnt, pend);
         // cnt is 0 unless the k-mer was found and min_count >= 1 (checked by the API), so this is "found && count >= -c"
-        const bool hit = (int32_t)cnt >= min_count;                         // GetVariants.java:224
-        const uint64_t H = wave_ballot(hit);
+        const uint64_t H = wave_ballot((int32_t)cnt >= min_count) & cw.V;   // GetVariants.java:224 (valid positions only)
+        const bool hit = __builtin_amdgcn_inverse_ballot_w64(H);
         if (lane == 0) {
             q.vw[w - w_begin] = cw.V;                                       // validity word of the window's bitmap
             q.hit[w - w_begin] = H;                                         // hits so far; queued k-mers may add theirs
         }
         sum_acc += hit ? cnt : 0u;                                          // GetVariants.java:226
-        const uint64_t PM = wave_ballot(pend != 0u);
+        const uint64_t PM = wave_ballot(pend != 0u) & wave_ballot(cnt == 0u) & cw.V;
         if (PM) {
+            const bool pending = __builtin_amdgcn_inverse_ballot_w64(PM);
             const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(PM >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)PM, 0u));
-            if (pend != 0u) q.id[pos] = (uint32_t)(((w - w_begin) << 6) | lane);
+            if (pending) q.id[pos] = (uint32_t)(((w - w_begin) << 6) | lane);
             qn += __popcll(PM);
         }
         wave_lds_fence();

@@ -171,15 +171,23 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
                 }
                 const double t1 = now_s();
                 kcfx_db* db = nullptr;
-                int32_t rc = kcfx_db_open(kmc_prefixes[wk.samples[i]], wk.device, &db);
+                // one pass of this worker's window range per database (GetVariants.java:129-159): the table is sized for that.
+                // First without the line-table fallback: a cell table that does not fit NEXT TO the database being screened
+                // (two wheat-scale tables do not always fit) is worth waiting for -- the line table screens at ~0.55x the
+                // speed and its odd size defeats the block pool. Only a database that does not fit an otherwise empty
+                // device falls back.
+                kcfx_db_opts opts;
+                opts.expected_queries = std::max<int64_t>(1, kcfx_ref_n_kmer_slots(ref));
+                opts.no_fallback = 1;
+                opts.reserved = 0;
+                int32_t rc = kcfx_db_open_opts(kmc_prefixes[wk.samples[i]], wk.device, &opts, &db);
                 if (rc == KCFX_ERR_DEVICE) {
-                    // most likely out of HBM next to the database being screened (two wheat-scale tables do not always fit):
-                    // wait until this device holds no other database of ours, then try once more with all of it
                     std::unique_lock<std::mutex> lk(mu);
                     cv.wait(lk, [&] { return stop || (in_use == 0 && ready.empty()); });
                     if (!stop) {
                         lk.unlock();
-                        rc = kcfx_db_open(kmc_prefixes[wk.samples[i]], wk.device, &db);
+                        opts.no_fallback = 0;
+                        rc = kcfx_db_open_opts(kmc_prefixes[wk.samples[i]], wk.device, &opts, &db);
                     }
                 }
                 std::lock_guard<std::mutex> lk(mu);

@@ -23,7 +23,7 @@ assert RESULT_DTYPE.itemsize == 40
 
 # every symbol include/kcfx.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
-    "kcfx_db_open", "kcfx_db_build", "kcfx_db_info", "kcfx_db_header", "kcfx_db_lookup", "kcfx_db_close",
+    "kcfx_db_open", "kcfx_db_open_opts", "kcfx_db_build", "kcfx_db_info", "kcfx_db_header", "kcfx_db_lookup", "kcfx_db_close",
     "kcfx_release_cached",
     "kcfx_ref_create", "kcfx_ref_n_windows", "kcfx_ref_n_kmer_slots", "kcfx_ref_destroy",
     "kcfx_screen_ref", "kcfx_screen_ref_async", "kcfx_screen_ref_multi", "kcfx_screen_ref_multi_async", "kcfx_screen",
@@ -54,6 +54,11 @@ class ShardStats(C.Structure):
 
 
 SHARD_AUTO, SHARD_SAMPLES, SHARD_WINDOWS = 0, 1, 2
+
+
+class DbOpts(C.Structure):
+    """kcfx_db_opts"""
+    _fields_ = [("expected_queries", C.c_int64), ("no_fallback", C.c_int32), ("reserved", C.c_int32)]
 
 
 class KcfxError(RuntimeError):
@@ -99,6 +104,7 @@ def lib() -> C.CDLL:
         L.kcfx_version.restype = C.c_char_p
         L.kcfx_device_count.argtypes = [C.POINTER(i32)]
         L.kcfx_db_open.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
+        L.kcfx_db_open_opts.argtypes = [C.c_char_p, i32, C.POINTER(DbOpts), C.POINTER(vp)]
         L.kcfx_db_build.argtypes = [vp, vp, i64, i32, i32, i32, i32, C.POINTER(vp)]
         L.kcfx_db_info.argtypes = [vp, C.POINTER(DbInfo)]
         L.kcfx_db_header.argtypes = [C.c_char_p, C.POINTER(DbInfo)]
@@ -184,9 +190,14 @@ class KmcDb:
         _check(lib().kcfx_db_info(self._h, C.byref(self.info)))
 
     @classmethod
-    def open(cls, kmc_prefix: str, device: int = 0) -> "KmcDb":
+    def open(cls, kmc_prefix: str, device: int = 0, expected_queries: int = 0, no_fallback: bool = False) -> "KmcDb":
+        """expected_queries = reference k-mers x passes this handle will serve (0 = unknown: the sparse, fastest table)."""
         h = C.c_void_p()
-        _check(lib().kcfx_db_open(os.fsencode(kmc_prefix), device, C.byref(h)))
+        if expected_queries or no_fallback:
+            opts = DbOpts(int(expected_queries), int(no_fallback), 0)
+            _check(lib().kcfx_db_open_opts(os.fsencode(kmc_prefix), device, C.byref(opts), C.byref(h)))
+        else:
+            _check(lib().kcfx_db_open(os.fsencode(kmc_prefix), device, C.byref(h)))
         return cls(h)
 
     @classmethod

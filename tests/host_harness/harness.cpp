@@ -171,7 +171,7 @@ int harness_cells(const uint8_t* text, int64_t text_off, int n_kmers, int k, int
     for (int p = 0; p < n_kmers + 15; ++p) {
         uint64_t f, r;
         extract_pair(P.fw(), P.cw(), P.off + p, M, f, r);
-        h[p] = mm27_tagged((uint32_t)(f >> 32), (uint32_t)(r >> 32), (uint32_t)p & 15u);     // extract_pair masks to M bases
+        h[p] = mm27_tagged((uint32_t)(f >> 32), (uint32_t)(r >> 32), mm27_label2((uint32_t)p));     // extract_pair masks to M bases
     }
     int bad = 0;
     for (int j = 0; j < n_kmers; ++j) {
@@ -179,7 +179,7 @@ int harness_cells(const uint8_t* text, int64_t text_off, int n_kmers, int k, int
         for (int t = 1; t < W; ++t) mn = std::min(mn, h[j + t]);
         uint64_t F, R;
         extract_pair(P.fw(), P.cw(), P.off + j, k, F, R);
-        const CellProbe q = cell_probe_of(F, R, mn, (uint32_t)j & 63u, lbits, M, both != 0, W);
+        const CellProbe q = cell_probe_of(F, R, mn, 2u * ((uint32_t)j & 63u), lbits, M, both != 0, W);
         CellProbe c[CELL_MAX_CANDS];
         const int n = cells_of_key((both && R < F) ? R : F, k, lbits, c, both != 0);
         bool ok = false;

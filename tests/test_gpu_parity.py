@@ -325,7 +325,8 @@ def test_stash_budget_and_line_table_fallback(oracle, tmp_path, monkeypatch, cap
         assert db.info.table_format == 1 and db.info.stash_kmers == n_stash
         assert 16 * n_stash / 0.8 <= db.info.stash_bytes <= roomy.info.stash_bytes // 2
         assert_same(db.screen(ref, s, e - s, 1), want, "dense stash")
-    # no budget at all: the line table takes over, with a note on stderr
+    # no budget at all: the line table takes over -- silently (a library behind a C / JNI ABI does not write to stderr; the
+    # handle's table_format says what was built), with a note on stderr only under KCFX_VERBOSE
     monkeypatch.setenv("KCFX_STASH_BUDGET", "1000")
     capfd.readouterr()
     for db in (engine.KmcDb.open(prefix), engine.KmcDb.build(kmers, counts, k, 2, True)):
@@ -333,7 +334,43 @@ def test_stash_budget_and_line_table_fallback(oracle, tmp_path, monkeypatch, cap
         assert_same(db.screen(ref, s, e - s, 1), want, "line-table fallback")
         got = db.lookup(kmers[:5000])
         assert np.array_equal(got, np.minimum(counts[:5000], 65535).astype(np.int32))
+    assert capfd.readouterr().err == ""
+    monkeypatch.setenv("KCFX_VERBOSE", "1")
+    assert engine.KmcDb.open(prefix).info.table_format == 0
     assert "building a line table instead" in capfd.readouterr().err
+
+
+def test_db_open_opts_size_the_table_for_the_expected_look_ups(oracle, tmp_path, monkeypatch):
+    """kcfx_db_open_opts: a handle that will serve one pass (the command-line driver, kcfx_screen_sharded's loader) gets a
+    table ~4x denser than the default sized for many passes -- same results; the allocation thread that runs beside the file
+    streaming and the synchronous path (KCFX_SYNC_ALLOC) build the same table; no_fallback turns the silent line-table
+    rebuild into KCFX_ERR_DEVICE."""
+    k = 31
+    ref = synth.random_reference(600_000, 21)
+    prefix, kmers, counts, prm = make_db(tmp_path, "opts", ref, 22, k=31, p=7, cs=2, m=9, bins=32, noise=1_500_000)
+    s, e = engine.windows(len(ref), 10_000, 0, k)
+    want = oracle.OracleDb(prefix).screen(ref, s, e - s, 1, threads=8)
+    sparse = engine.KmcDb.open(prefix)
+    dense = engine.KmcDb.open(prefix, expected_queries=int((e - s - k + 1).sum()))
+    many = engine.KmcDb.open(prefix, expected_queries=10**12)
+    assert sparse.info.table_format == dense.info.table_format == 1
+    assert many.info.table_lines == sparse.info.table_lines
+    assert dense.info.table_lines * 2 <= sparse.info.table_lines
+    assert 16 * dense.info.table_lines >= dense.info.total_kmers
+    for db, name in ((sparse, "sparse"), (dense, "dense"), (many, "many")):
+        assert_same(db.screen(ref, s, e - s, 1), want, name)
+    monkeypatch.setenv("KCFX_SYNC_ALLOC", "1")
+    sync = engine.KmcDb.open(prefix, expected_queries=1000)
+    assert (sync.info.table_lines, sync.info.stash_kmers, sync.info.second_choice_kmers) == \
+        (dense.info.table_lines, dense.info.stash_kmers, dense.info.second_choice_kmers)
+    assert_same(sync.screen(ref, s, e - s, 1), want, "sync alloc")
+    monkeypatch.delenv("KCFX_SYNC_ALLOC")
+    monkeypatch.setenv("KCFX_TABLE_LBITS", "17")
+    monkeypatch.setenv("KCFX_STASH_BUDGET", "1000")
+    with pytest.raises(engine.KcfxError) as err:
+        engine.KmcDb.open(prefix, no_fallback=True)
+    assert err.value.code == 4
+    assert engine.KmcDb.open(prefix).info.table_format == 0          # with the fallback: a line table, silently
 
 
 @pytest.mark.parametrize("lbits", [17, 18, 21, 25])
