@@ -136,8 +136,10 @@ void kcfx_db_close(kcfx_db* db);
 /* Large device buffers of closed databases and destroyed references (tables, stashes, reference text) are kept, per
  * device, for the next handle of the same size: a run over many samples opens one database after the other, and on this
  * platform hipMalloc of a table that follows the hipFree of the previous one costs up to 2 s (KMC.java:412-420 has no
- * counterpart: the JVM unmaps). At most 8 blocks and 40 % of the device; given back by themselves when an allocation of the
- * library fails, by this call (device < 0: all devices), never kept with KCFX_NO_POOL=1 in the environment. */
+ * counterpart: the JVM unmaps). At most 16 blocks and 40 % of the device; given back by themselves when an allocation of THIS
+ * library fails, by this call (device < 0: all devices), never kept with KCFX_NO_POOL=1 in the environment. A process that
+ * shares the device with another allocator (PyTorch, ...) should call this after closing its handles, or set KCFX_NO_POOL:
+ * the other allocator cannot see the kept blocks and may run out of memory while they sit here. */
 int32_t kcfx_release_cached(int32_t device);
 
 /* ---- reference text + windows ---------------------------------------------------------------------- */
@@ -167,7 +169,7 @@ int32_t kcfx_screen_ref_async(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count
 /* Several samples, ONE pass over the reference (SURVEY f-4): what the reference does as S getVariations runs followed by
  * `cohort` (run_kcftools.sh:124-140, Plugins/Cohort.java:71-119). out[s * n_windows + w] = sample s (input order),
  * window w; each slice equals kcfx_screen_ref(dbs[s], ...). Databases must live on ref's device and share its k;
- * cell tables (the default for k = 19 .. 31) are screened one launch per sample and reduced together;
+ * cell tables (the default for k = 19 .. 31) are screened and reduced one launch pair per sample, the reference staying resident;
  * 12-slot line tables of k = 31 with counters of at most 2 bytes are screened up to 8 at a time by one kernel (same
  * results either way). */
 int32_t kcfx_screen_ref_multi(kcfx_db* const* dbs, int32_t n_db, kcfx_ref* ref, int32_t min_kmer_count, kcfx_result* out);

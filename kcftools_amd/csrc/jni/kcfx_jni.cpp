@@ -49,9 +49,18 @@ JNIEXPORT jint JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_releaseCached(JNIEnv
 
 // void screen(long db, ByteBuffer text, long[] winBegin, int[] winLen, int minKmerCount, ByteBuffer results)
 // `text` and `results` are direct buffers; results receives nWindows * 40 bytes (kcfx_result, little-endian).
+// winBegin and winLen describe the same windows: non-null, equal lengths (else IllegalArgumentException; the C ABI trusts n)
+static bool window_arrays_ok(JNIEnv* env, jlongArray winBegin, jintArray winLen) {
+    if (winBegin && winLen && env->GetArrayLength(winBegin) == env->GetArrayLength(winLen)) return true;
+    jclass cls = env->FindClass("java/lang/IllegalArgumentException");
+    if (cls) env->ThrowNew(cls, "winBegin and winLen must be non-null arrays of the same length");
+    return false;
+}
+
 JNIEXPORT void JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_screen(JNIEnv* env, jclass, jlong db, jobject text,
                                                                    jlongArray winBegin, jintArray winLen,
                                                                    jint minKmerCount, jobject results) {
+    if (!window_arrays_ok(env, winBegin, winLen)) return;
     const auto* t = static_cast<const uint8_t*>(env->GetDirectBufferAddress(text));
     const jlong tlen = env->GetDirectBufferCapacity(text);
     auto* out = static_cast<kcfx_result*>(env->GetDirectBufferAddress(results));
@@ -137,6 +146,18 @@ JNIEXPORT jintArray JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_dbHeader(JNIEnv
 JNIEXPORT void JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_screenSharded(JNIEnv* env, jclass, jintArray devices, jobjectArray prefixes,
                                                                            jint k, jobject text, jlongArray winBegin, jintArray winLen,
                                                                            jint minKmerCount, jint shardMode, jobject results) {
+    if (!window_arrays_ok(env, winBegin, winLen)) return;
+    if (!devices || !prefixes) {
+        jclass cls = env->FindClass("java/lang/IllegalArgumentException");
+        if (cls) env->ThrowNew(cls, "devices and kmcPrefixes must not be null");
+        return;
+    }
+    for (jsize i = 0; i < env->GetArrayLength(prefixes); ++i)
+        if (!env->GetObjectArrayElement(prefixes, i)) {
+            jclass cls = env->FindClass("java/lang/IllegalArgumentException");
+            if (cls) env->ThrowNew(cls, "kmcPrefixes holds a null string");
+            return;
+        }
     const auto* t = static_cast<const uint8_t*>(env->GetDirectBufferAddress(text));
     auto* out = static_cast<kcfx_result*>(env->GetDirectBufferAddress(results));
     const jsize n = env->GetArrayLength(winLen), s = env->GetArrayLength(prefixes), g = env->GetArrayLength(devices);

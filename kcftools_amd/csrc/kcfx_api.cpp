@@ -438,8 +438,8 @@ int32_t table_alloc(kcfx_db* db, int64_t n_keys, int32_t counter_size, bool allo
 int32_t table_finish(kcfx_db* db) {
     if (db->fmt == FORMAT_CELLS) {
         KCFX_HIP(hipStreamSynchronize(db->stream));
-        if (db->d_stats) (void)dev_free(db->d_stats);
-        if (db->d_pop) (void)dev_free(db->d_pop);
+        if (db->d_stats) (void)dev_free_idle(db->d_stats);
+        if (db->d_pop) (void)dev_free_idle(db->d_pop);
         db->d_stats = nullptr;
         db->d_pop = nullptr;
         return KCFX_OK;
@@ -530,14 +530,17 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     hipEvent_t done[2] = {nullptr, nullptr};
     int32_t rc = KCFX_OK;
     auto cleanup = [&]() {
+        // the temporaries are used on db->stream only: wait for that stream, not for the device (the other worker's
+        // screening kernel, the next database's uploads)
+        (void)hipStreamSynchronize(db->stream);
         for (int i = 0; i < 2; ++i) {
             if (h_buf[i]) (void)host_free(h_buf[i]);
-            if (d_rec[i]) (void)dev_free(d_rec[i]);
+            if (d_rec[i]) (void)dev_free_idle(d_rec[i]);
             if (done[i]) (void)hipEventDestroy(done[i]);
         }
-        if (d_lut) (void)dev_free(d_lut);
-        if (d_keys) (void)dev_free(d_keys);
-        if (d_counts) (void)dev_free(d_counts);
+        if (d_lut) (void)dev_free_idle(d_lut);
+        if (d_keys) (void)dev_free_idle(d_keys);
+        if (d_counts) (void)dev_free_idle(d_counts);
         close(fd);
     };
 #define LOAD_HIP(call)                                  \

@@ -216,7 +216,8 @@ int32_t exception_to_status(const char* fn) noexcept;
 // kcfx_pool.cpp: hipMalloc / hipFree with large released blocks kept per device for the next database (see there)
 hipError_t dev_alloc(void** p, size_t bytes);
 template <class T> inline hipError_t dev_alloc(T** p, size_t bytes) { return dev_alloc(reinterpret_cast<void**>(p), bytes); }
-hipError_t dev_free(void* p);
+hipError_t dev_free(void* p);                // waits for the device first, as hipFree does
+hipError_t dev_free_idle(void* p);           // the caller has already waited for every user of the block (its own stream)
 size_t free_device_bytes();                  // hipMemGetInfo's free + what the pool keeps on the current device
 size_t pooled_device_bytes(int dev);
 void pool_release(int dev);                  // dev < 0: every device

@@ -202,7 +202,9 @@ constexpr uint32_t CELL_FLAG_CROWDED = 2u;                  // bit 1 of w: the o
 __host__ __device__ inline int cell_sub_bits(int32_t lbits) { return lbits <= 30 ? 2 : 32 - lbits; }
 __device__ __forceinline__ uint64_t cell_sub_bucket(const CellProbe& p, int32_t lbits) {
     const int sb = cell_sub_bits(lbits);
-    return ((uint64_t)p.line << sb) | (p.r >> (32 - lbits - sb));
+    // (r may carry CELL_R_FLIP above its 32 - lbits identifying bits: masked, or a forward-only database's reverse-strand k-mers
+    // would be counted in another line's sub-bucket)
+    return ((uint64_t)p.line << sb) | ((p.r & (0xFFFFFFFFu >> lbits)) >> (32 - lbits - sb));
 }
 
 // Pass 0: k-mers per sub-bucket, one byte each (a byte that overflows spills into its neighbour: the classes are a

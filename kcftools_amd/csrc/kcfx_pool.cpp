@@ -129,7 +129,13 @@ hipError_t dev_alloc(void** p, size_t bytes) {
     return e;
 }
 
-hipError_t dev_free(void* p) {
+// idle = the caller has already waited for everything that used the block (the loader's temporaries live on ONE stream, which
+// it synchronises before it frees them): no device-wide synchronisation, which would wait for the OTHER worker's screening
+// kernel and for queued uploads of the next database (kcfx_screen_sharded overlaps exactly those)
+static hipError_t dev_free_impl(void* p, bool idle);
+hipError_t dev_free(void* p) { return dev_free_impl(p, false); }
+hipError_t dev_free_idle(void* p) { return dev_free_impl(p, true); }
+static hipError_t dev_free_impl(void* p, bool idle) {
     if (!p) return hipSuccess;
     Block b{nullptr, 0, 0};
     {
@@ -141,7 +147,7 @@ hipError_t dev_free(void* p) {
         }
     }
     if (!b.p) return hipFree(p);                         // a small block
-    {
+    if (!idle) {
         OnDevice g(b.dev);
         (void)hipDeviceSynchronize();                    // as hipFree would have: nothing queued may still touch the block
     }

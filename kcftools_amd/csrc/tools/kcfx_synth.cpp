@@ -69,6 +69,7 @@ struct Opts {
     int64_t error_events = 0;              // --error-events: read-error model, see below
     int k = 31, p = 7, cs = 2, sig_len = 9, n_bins = 512, threads = 0;
     double sub_rate = 1e-2, indel_rate = 1e-3;
+    double repeats = 0.0;                  // --repeats F: fraction of the reference overwritten with repeat structure (see below)
     std::string out;
     bool fasta = false;
     std::string contig = "chr1";
@@ -85,6 +86,7 @@ int main(int argc, char** argv) {
         else if (a == "--sample-seed") o.sample_seed = strtoull(val(), nullptr, 10);
         else if (a == "--noise") o.noise = atoll(val());
         else if (a == "--error-events") o.error_events = atoll(val());
+        else if (a == "--repeats") o.repeats = atof(val());
         else if (a == "--k") o.k = atoi(val());
         else if (a == "--p") o.p = atoi(val());
         else if (a == "--cs") o.cs = atoi(val());
@@ -110,7 +112,7 @@ int main(int argc, char** argv) {
     }
     if (o.error_events > 0 && o.k > 31) { fprintf(stderr, "--error-events needs k <= 31\n"); return 2; }
     if (o.out.empty() || o.k < 9 || o.k > 32 || (o.k - o.p) % 4 != 0 || o.cs < 1 || o.cs > 4 || o.sig_len > o.k) {
-        fprintf(stderr, "usage: kcfx_synth --out PREFIX [--ref-len N --seed S --sample-seed S --noise N --error-events N --k 31 --p 7 --cs 2 --bins 512 --threads T --fasta]\n");
+        fprintf(stderr, "usage: kcfx_synth --out PREFIX [--ref-len N --seed S --sample-seed S --noise N --error-events N --repeats F --k 31 --p 7 --cs 2 --bins 512 --threads T --fasta]\n");
         return 2;
     }
     if (o.threads <= 0) o.threads = (int)std::max(1u, std::thread::hardware_concurrency());
@@ -136,6 +138,109 @@ int main(int argc, char** argv) {
             ref[(size_t)i] = c;
         }
     });
+    // --repeats F: genome structure on top of the uniform text (uniform text has none, and repeats are what crowds minimizers
+    // and fills lines of the cell table): a fraction F of the reference is overwritten, in this order, with
+    //   * transposable-element families (60 % of F): 48 consensus sequences of 300 bp - 8 kb, copies of 80 - 95 % identity to
+    //     their consensus (per-family divergence), half of them 5'-truncated, both orientations, Zipf-like family sizes;
+    //   * tandem satellite arrays (20 %): units of 100 - 400 bp repeated to arrays of 10 - 400 kb, 1 - 4 % divergence per copy;
+    //   * segmental duplications (15 %): 10 - 100 kb copied from elsewhere in the reference at 98 - 99.5 % identity;
+    //   * microsatellites / low-complexity runs (5 %): units of 1 - 6 bp repeated over 50 - 500 bp.
+    // The sample genome is derived from the result below, so sample and reference share the structure. Sequential and
+    // counter-based: the same seed gives the same bytes.
+    int64_t rep_bases[4] = {0, 0, 0, 0};
+    if (o.repeats > 0) {
+        const uint64_t s4 = mix64(o.seed * 0xC0FFEEull + 77);
+        uint64_t ctr = 0;
+        auto rnd = [&]() { return mix64(s4 + (ctr++)); };
+        auto subst = [&](uint8_t c, uint64_t h) -> uint8_t { return (uint8_t)"ACGT"[((c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3) + 1 + (int)(h % 3)) & 3]; };
+        auto comp = [](uint8_t c) -> uint8_t { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A'; };
+        const double F = std::min(o.repeats, 0.9);
+        // transposable elements
+        struct Family { std::vector<uint8_t> cons; double div; };
+        std::vector<Family> fam(48);
+        for (auto& f : fam) {
+            const uint64_t h = rnd();
+            f.cons.resize(300 + (size_t)(h % 7700));
+            for (auto& c : f.cons) c = (uint8_t)"ACGT"[rnd() & 3];
+            f.div = 0.05 + 0.15 * (double)((h >> 32) % 1000) / 1000.0;
+        }
+        const int64_t te_target = (int64_t)(0.60 * F * (double)L);
+        while (rep_bases[0] < te_target) {
+            const uint64_t h = rnd();
+            // Zipf-like: family index ~ floor(48 * u^2)
+            const double u = (double)(h % 1000000) / 1e6;
+            const Family& f = fam[(size_t)(48.0 * u * u)];
+            size_t len = f.cons.size(), off = 0;
+            if ((h >> 20) & 1) {                           // 5'-truncated copy
+                off = (size_t)((h >> 24) % (len * 3 / 4));
+                len -= off;
+            }
+            if ((int64_t)len >= L) continue;
+            const int64_t at = (int64_t)(rnd() % (uint64_t)(L - (int64_t)len));
+            const bool rev = (h >> 21) & 1;
+            const uint64_t thr = (uint64_t)(f.div * 4294967296.0);
+            for (size_t j = 0; j < len; ++j) {
+                uint8_t c = rev ? comp(f.cons[off + len - 1 - j]) : f.cons[off + j];
+                const uint64_t g = rnd();
+                if ((g & 0xFFFFFFFFull) < thr) c = subst(c, g >> 32);
+                ref[(size_t)at + j] = c;
+            }
+            rep_bases[0] += (int64_t)len;
+        }
+        // tandem satellite arrays
+        const int64_t sat_target = (int64_t)(0.20 * F * (double)L);
+        while (rep_bases[1] < sat_target) {
+            const uint64_t h = rnd();
+            const size_t unit = 100 + (size_t)(h % 300);
+            std::vector<uint8_t> u(unit);
+            for (auto& c : u) c = (uint8_t)"ACGT"[rnd() & 3];
+            int64_t total = 10000 + (int64_t)((h >> 16) % 390000);
+            total = std::min<int64_t>(total, L / 4);
+            if (total >= L) continue;
+            const int64_t at = (int64_t)(rnd() % (uint64_t)(L - total));
+            const uint64_t thr = (uint64_t)((0.01 + 0.03 * (double)((h >> 40) % 100) / 100.0) * 4294967296.0);
+            for (int64_t j = 0; j < total; ++j) {
+                uint8_t c = u[(size_t)(j % (int64_t)unit)];
+                const uint64_t g = rnd();
+                if ((g & 0xFFFFFFFFull) < thr) c = subst(c, g >> 32);
+                ref[(size_t)(at + j)] = c;
+            }
+            rep_bases[1] += total;
+        }
+        // segmental duplications
+        const int64_t sd_target = (int64_t)(0.15 * F * (double)L);
+        while (rep_bases[2] < sd_target && L > 400000) {
+            const uint64_t h = rnd();
+            const int64_t len = 10000 + (int64_t)(h % 90000);
+            const int64_t src = (int64_t)(rnd() % (uint64_t)(L - len)), dst = (int64_t)(rnd() % (uint64_t)(L - len));
+            if (std::llabs(src - dst) < len) continue;
+            const uint64_t thr = (uint64_t)((0.005 + 0.015 * (double)((h >> 40) % 100) / 100.0) * 4294967296.0);
+            for (int64_t j = 0; j < len; ++j) {
+                uint8_t c = ref[(size_t)(src + j)] & 0xDF;
+                const uint64_t g = rnd();
+                if (c == 'A' || c == 'C' || c == 'G' || c == 'T') {
+                    if ((g & 0xFFFFFFFFull) < thr) c = subst(c, g >> 32);
+                } else {
+                    c = (uint8_t)"ACGT"[g & 3];
+                }
+                ref[(size_t)(dst + j)] = c;
+            }
+            rep_bases[2] += len;
+        }
+        // microsatellites
+        const int64_t ms_target = (int64_t)(0.05 * F * (double)L);
+        while (rep_bases[3] < ms_target) {
+            const uint64_t h = rnd();
+            const int unit = 1 + (int)(h % 6);
+            const int64_t len = 50 + (int64_t)((h >> 8) % 450);
+            if (len >= L) break;
+            uint8_t u[6];
+            for (int j = 0; j < unit; ++j) u[j] = (uint8_t)"ACGT"[(h >> (20 + 2 * j)) & 3];
+            const int64_t at = (int64_t)(rnd() % (uint64_t)(L - len));
+            for (int64_t j = 0; j < len; ++j) ref[(size_t)(at + j)] = u[j % unit];
+            rep_bases[3] += len;
+        }
+    }
     for (int64_t blk = 0; blk * 5000 < L; ++blk) {                             // soft-masked blocks (~10 %)
         const uint64_t h = mix64(s1 ^ (0xABCDull + (uint64_t)blk * 7919));
         if (h % 10 != 0) continue;
@@ -413,9 +518,10 @@ int main(int argc, char** argv) {
     }
     const double t_end = now_s();
     printf("{\"ref_len\": %lld, \"sample_len\": %zu, \"sample_kmers\": %zu, \"noise_kmers\": %lld, \"error_kmers\": %zu, \"db_kmers\": %zu, "
-           "\"k\": %d, \"p\": %d, \"counter_size\": %d, \"n_bins\": %d, \"seed\": %llu, \"sample_seed\": %llu, \"threads\": %d, "
+           "\"repeat_bases\": {\"te\": %lld, \"satellite\": %lld, \"segdup\": %lld, \"microsat\": %lld}, \"k\": %d, \"p\": %d, \"counter_size\": %d, \"n_bins\": %d, \"seed\": %llu, \"sample_seed\": %llu, \"threads\": %d, "
            "\"seconds\": {\"ref\": %.2f, \"sample\": %.2f, \"kmers\": %.2f, \"sort\": %.2f, \"bins\": %.2f, \"write\": %.2f, \"total\": %.2f}}\n",
-           (long long)L, smp.size(), n_sample_kmers, (long long)o.noise, n_error_kmers, N, k, o.p, o.cs, o.n_bins,
+           (long long)L, smp.size(), n_sample_kmers, (long long)o.noise, n_error_kmers, N, (long long)rep_bases[0], (long long)rep_bases[1],
+           (long long)rep_bases[2], (long long)rep_bases[3], k, o.p, o.cs, o.n_bins,
            (unsigned long long)o.seed, (unsigned long long)o.sample_seed, T, t_ref - t0, t_smp - t_ref, t_km - t_smp,
            t_sort - t_km, t_bin - t_sort, t_end - t_bin, t_end - t0);
     return 0;

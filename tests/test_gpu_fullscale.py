@@ -176,21 +176,90 @@ def test_eight_samples_in_one_pass(oracle, genome, cohort):
         assert np.array_equal(np.sort(obs_col), np.sort(got[s]["obs"]))
 
 
+def test_repeat_structured_genome_at_chr1_scale(oracle, tmp_path_factory):
+    """Inputs with genome structure (kcfx_synth --repeats 0.45: TE families at 80 - 95 % identity, tandem satellite arrays,
+    segmental duplications, microsatellites -- in the reference AND the sample genome, which is derived from it) at the size of
+    BASELINE configs[1]: repeats crowd minimizers (one 16-mer is the minimizer of thousands of database k-mers), fill lines of
+    the cell table and load the stash -- none of which uniform text exercises (Fasta.java:90-127, Kmer.java:105-118 see such
+    data in every real genome). Every window against the oracle, for the sparse and a dense table; kernel time and table
+    statistics are logged for profiles/."""
+    import torch
+    d = tmp_path_factory.mktemp("repeats")
+    prefix = str(d / "rep")
+    meta = json.loads(subprocess.run([SYNTH, "--out", prefix, "--ref-len", "30427671", "--seed", "5", "--sample-seed", "6",
+                                      "--repeats", "0.45", "--noise", "20000000"], check=True, capture_output=True, text=True).stdout)
+    assert meta["repeat_bases"]["te"] > 5_000_000 and meta["db_kmers"] - meta["noise_kmers"] < 0.95 * meta["sample_kmers"]
+    text = np.fromfile(prefix + ".ref.txt", dtype=np.uint8).tobytes()
+    s, e = engine.windows(len(text), 10_000, 0, K)
+    wb, wl = s.astype(np.int64), (e - s).astype(np.int32)
+    want = oracle.OracleDb(prefix).screen(text, wb, wl, 1, threads=HOST_THREADS)
+    ref = engine.Reference(text, wb, wl, K)
+    out = torch.zeros(len(wb) * 10, dtype=torch.int32, device="cuda:0")
+    stream = torch.cuda.current_stream()
+    lines = []
+    for name, kw in (("sparse", {}), ("dense", {"expected_queries": int((wl - K + 1).clip(0).sum())})):
+        db = engine.KmcDb.open(prefix, **kw)
+        got = ref.screen(db, 1)
+        for f in FIELDS:
+            assert np.array_equal(got[f], want[f]), (name, f)
+        for _ in range(5):
+            ref.screen_async(db, out.data_ptr(), stream.cuda_stream, 1)
+        torch.cuda.synchronize()
+        ref.prof_enable(True)
+        ref.prof_read(reset=True)
+        for _ in range(50):
+            ref.screen_async(db, out.data_ptr(), stream.cuda_stream, 1)
+        torch.cuda.synchronize()
+        ms, cnt = ref.prof_read(reset=True)
+        ref.prof_enable(False)
+        i = db.info
+        nk = int(got["total_kmers"].sum())
+        lines.append(f"repeat-structured genome ({name} table: 2^{int(np.log2(i.table_lines))} lines, {i.total_kmers / (16.0 * i.table_lines):.3f} per cell, "
+                     f"{100.0 * i.stash_kmers / i.total_kmers:.2f} % of {i.total_kmers / 1e6:.1f} M k-mers in the stash, "
+                     f"{100.0 * i.second_choice_kmers / i.total_kmers:.2f} % second-choice, {i.multi_cell_kmers} in several cells): "
+                     f"kernel {ms / cnt:.4f} ms per pass of {nk / 1e6:.1f} M k-mers = {nk / (ms / cnt * 1e-3) / 1e9:.0f} G k-mers/s, "
+                     f"hit rate {got['obs'].sum() / nk:.3f}; all {len(wb)} windows bit-exact")
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "repeats_genome.log"), "a") as fh:
+        for ln in lines:
+            print(ln)
+            fh.write(ln + "\n")
+
+
+def _mem_available_bytes():
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                return int(ln.split()[1]) * 1024
+    except OSError:
+        pass
+    return 0
+
+
 def test_config5_shape_wheat_scale(oracle, genome, cohort, monkeypatch):
-    """BASELINE.json configs[4] ("wheat-scale reference, many samples, HBM-resident KMC DB stress") at a size the default
-    suite can afford: a 3.2 Gb reference (KCFX_HUGE=<bases> for more, e.g. 14.5e9: the 119 Mb genome repeated with 0.5 %
-    point mutations), 50 kb tiling windows (64 k of them), TEN samples -- the eight of the cohort, one of them a second time
-    through a table built by re-streaming its file (the path a database too large to keep decoded takes), and ONE LARGE
-    database of 2.1 G k-mers (17 GB .kmc_suf; a 2^28-line cell table at 0.5 k-mers per cell, so second-choice cells and the
-    stash carry real weight) -- through kcfx_screen_sharded (one database screened while the next is loaded) and through
-    kcfx_screen_ref_multi (ten > 8 forces a second batch; the large database is also opened as a 12-slot line table, whose
-    2^29+ lines the multi-sample kernel must refuse). 4 500 sampled windows (0.2 G k-mers) against the oracle for three of the samples."""
+    """BASELINE.json configs[4] as it is stated: a wheat-scale 14.5 Gb reference, 50 kb tiling windows (290 k of them), THIRTY-TWO
+    samples, k = 31 -- through kcfx_screen_sharded (what the command-line driver runs; two workers on the one GPU, the next
+    database loaded while the current one is screened). The reference is the 119 Mb genome repeated with 0.5 % point mutations;
+    the samples are the cohort's eight databases (~100-150 M k-mers each) in rotation plus ONE LARGE database of 2.1 G k-mers
+    (17 GB .kmc_suf; a 2^28-line cell table at 0.5 k-mers per cell). Falls back to a 3.2 Gb reference only when the box lacks
+    the host memory or scratch disk (KCFX_HUGE=<bases> overrides) and says which size ran. Also: the large database
+    * as resident handles through kcfx_screen_ref_multi (ten > 8 forces a second batch),
+    * rebuilt by re-streaming its file, and as a 12-slot line table (>= 2^29 lines, which the multi-sample kernel refuses),
+    * DENSE: a 2^27-line cell table = 0.98 k-mers per cell (KCFX_TABLE_LBITS), the regime a wheat-size sample forces -- same
+      results on every window, kernel time logged beside the 0.49-per-cell table and a sparse 150 M-k-mer sample.
+    10 000 sampled windows (0.5 G k-mers) of four samples, the large (and dense) one among them, against the oracle."""
     import shutil
-    L = int(float(os.environ.get("KCFX_HUGE", "3.2e9")))
     big_kmers = int(float(os.environ.get("KCFX_BIG_DB", "2.0e9")))
+    L = int(float(os.environ.get("KCFX_HUGE", "14.5e9")))
+    why = "KCFX_HUGE" if os.environ.get("KCFX_HUGE") else "BASELINE configs[4] size"
+    if not os.environ.get("KCFX_HUGE"):
+        need_ram, have_ram = 6 * L, _mem_available_bytes()
+        if have_ram and have_ram < need_ram:
+            L, why = int(3.2e9), f"FALLBACK: {have_ram / 1e9:.0f} GB of host memory available, 14.5 Gb needs {need_ram / 1e9:.0f} GB"
     need = big_kmers * 9 + L * 2
     if shutil.disk_usage(genome["dir"]).free < need:
         pytest.skip(f"needs {need / 1e9:.0f} GB of scratch disk for the large database")
+    N_SAMPLES = 32
     rng = np.random.default_rng(7)
     t_all = time.time()
     # ---- the large database: the cohort's first sample genome + 2 G random k-mers -------------------------------------
@@ -204,28 +273,34 @@ def test_config5_shape_wheat_scale(oracle, genome, cohort, monkeypatch):
     text = np.tile(base, (L + len(base) - 1) // len(base))[:L].copy()
     pos = rng.integers(0, L, size=L // 200)
     text[pos] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=len(pos))]
+    del pos
     W = 50_000
     starts = np.arange(0, L - K + 1, W - K + 1, dtype=np.int64)
     lens = np.minimum(W, L - starts).astype(np.int32)
     starts, lens = starts[lens >= K], lens[lens >= K]
     tbytes = text.tobytes()
     del text
-    prefixes = list(cohort) + [cohort[1], big]             # ten samples; #8 repeats #1 (re-streamed table below)
+    # 32 samples: the eight cohort databases in rotation, the large one last
+    prefixes = [cohort[i % 8] for i in range(N_SAMPLES - 1)] + [big]
+    BIG = N_SAMPLES - 1
     # ---- every GPU entry point the CLI uses: sharded over "two devices" (the one GPU twice), next database loaded during
     #      the current screening ---------------------------------------------------------------------------------------
     t0 = time.time()
     got, st = engine.screen_sharded(prefixes, K, tbytes, starts, lens, 1, devices=(0, 0))
     t_sharded = time.time() - t0
-    assert got.shape == (10, len(starts)) and st.shard_mode_used == engine.SHARD_SAMPLES
+    assert got.shape == (N_SAMPLES, len(starts)) and st.shard_mode_used == engine.SHARD_SAMPLES
     n = int(got[0]["total_kmers"].sum())
     assert n > 0.95 * L
-    for f in FIELDS:
-        assert np.array_equal(got[8][f], got[1][f]), f                                  # the same sample twice
-    assert len({int(got[s]["obs"].sum()) for s in (0, 1, 2, 3, 4, 5, 6, 7, 9)}) == 9    # nine different samples
-    assert int(got[9]["obs"].sum()) > int(got[0]["obs"].sum()) * 0.5
+    for i in range(8, N_SAMPLES - 1):                                                   # the same database again: the same records
+        for f in FIELDS:
+            assert np.array_equal(got[i][f], got[i % 8][f]), (i, f)
+    assert len({int(got[s]["obs"].sum()) for s in (0, 1, 2, 3, 4, 5, 6, 7, BIG)}) == 9   # nine different samples
+    assert int(got[BIG]["obs"].sum()) > int(got[0]["obs"].sum()) * 0.5
+    # partition identity at full size: every k-mer of the reference lies in exactly one tiling window (SURVEY a-1)
+    assert n == int(got[BIG]["total_kmers"].sum()) and np.all(got[0]["total_kmers"] <= lens - K + 1)
     # loading overlapped screening: what the screening threads waited for is less than what the loads took
     assert st.seconds_exposed_load < st.seconds_db_open_sum
-    # ---- the same ten through resident handles and kcfx_screen_ref_multi ----------------------------------------------
+    # ---- ten of them through resident handles and kcfx_screen_ref_multi -------------------------------------------------
     ref = engine.Reference(tbytes, starts, lens, K)
     t0 = time.time()
     big_db = engine.KmcDb.open(big)
@@ -238,13 +313,34 @@ def test_config5_shape_wheat_scale(oracle, genome, cohort, monkeypatch):
     restreamed = engine.KmcDb.open(cohort[1])
     monkeypatch.delenv("KCFX_LOAD_STREAM_TWICE")
     dbs = [genome["db"]] + [engine.KmcDb.open(p) for p in cohort[1:]] + [restreamed, big_db]
+    which = list(range(8)) + [1, BIG]
     t0 = time.time()
     multi = ref.screen_multi(dbs, 1)
     t_multi = time.time() - t0
-    for s in range(10):
+    for j, s in enumerate(which):
         for f in FIELDS:
-            assert np.array_equal(multi[s][f], got[s][f]), (s, f)
-    del dbs[1:8]                                            # free HBM for the line-table form of the large database
+            assert np.array_equal(multi[j][f], got[s][f]), (s, f)
+
+    def kernel_ms(db, steps=3):
+        """the screening kernel alone (HIP events on the launch, as bench.py), per pass over the whole reference"""
+        import torch
+        out = torch.zeros(len(starts) * 10, dtype=torch.int32, device="cuda:0")
+        stream = torch.cuda.current_stream()
+        ref.screen_async(db, out.data_ptr(), stream.cuda_stream, 1)
+        torch.cuda.synchronize()
+        ref.prof_enable(True)
+        ref.prof_read(reset=True)
+        for _ in range(steps):
+            ref.screen_async(db, out.data_ptr(), stream.cuda_stream, 1)
+        torch.cuda.synchronize()
+        ms, cnt = ref.prof_read(reset=True)
+        ref.prof_enable(False)
+        return ms / max(1, cnt)
+
+    ms_sparse = kernel_ms(dbs[3])
+    ms_big = kernel_ms(big_db)
+    del dbs[1:9]                                            # free HBM for the other forms of the large database
+    restreamed = None
     # ---- the large database as a 12-slot line table: >= 2^29 lines, which the multi-sample kernel refuses ---------------
     monkeypatch.setenv("KCFX_TABLE_FORMAT", "lines")
     monkeypatch.setenv("KCFX_TABLE_LOAD", "0.3")
@@ -257,24 +353,47 @@ def test_config5_shape_wheat_scale(oracle, genome, cohort, monkeypatch):
     assert big_lines.info.table_format == 0 and big_lines.info.table_lines >= 1 << 29
     pair = ref.screen_multi([small_lines, big_lines], 1)
     for f in FIELDS:
-        assert np.array_equal(pair[0][f], got[2][f]) and np.array_equal(pair[1][f], got[9][f]), f
-    del big_lines, small_lines
-    # ---- sampled windows against the oracle (2 000 per cohort sample = 100 M k-mers each; 500 for the large database) ----
+        assert np.array_equal(pair[0][f], got[2][f]) and np.array_equal(pair[1][f], got[BIG][f]), f
+    del big_lines, small_lines, pair
+    engine.release_cached()
+    # ---- DENSE: the large database at ~1 k-mer per cell (what a wheat-size sample forces) ------------------------------------
+    dense_bits = int(np.ceil(np.log2(bi.total_kmers / 16.0)))
+    monkeypatch.setenv("KCFX_TABLE_LBITS", str(dense_bits))
     t0 = time.time()
-    for s, pfx, n_check in ((0, cohort[0], 2000), (5, cohort[5], 2000), (9, big, 500)):
-        idx = np.unique(np.concatenate([rng.choice(len(starts), n_check, replace=False), [0, len(starts) - 1]]))
+    dense = engine.KmcDb.open(big, no_fallback=True)
+    t_dense_open = time.time() - t0
+    monkeypatch.delenv("KCFX_TABLE_LBITS")
+    di = dense.info
+    assert di.table_format == 1 and di.table_lines == 1 << dense_bits and di.total_kmers / (16.0 * di.table_lines) > 0.9
+    dres = ref.screen(dense, 1)
+    for f in FIELDS:
+        assert np.array_equal(dres[f], got[BIG][f]), f      # every window, every field: the dense table changes nothing
+    ms_dense = kernel_ms(dense)
+    del dense
+    # ---- 10 000 sampled windows (0.5 G k-mers) of four samples against the oracle, the large / dense one among them ----------
+    t0 = time.time()
+    n_checked = 0
+    for s, pfx, n_check in ((0, cohort[0], 3000), (3, cohort[3], 3000), (29, cohort[5], 3000), (BIG, big, 1000)):
+        idx = np.unique(np.concatenate([rng.choice(len(starts), min(n_check, len(starts)), replace=False), [0, len(starts) - 1]]))
         want = oracle.OracleDb(pfx).screen(tbytes, starts[idx], lens[idx], 1, threads=HOST_THREADS)
         for f in FIELDS:
             assert np.array_equal(want[f], got[s][f][idx]), (s, f)
+        n_checked += len(idx)
     t_oracle = time.time() - t0
-    line = (f"config-5 shape: {L / 1e9:.1f} Gb reference, {len(starts)} windows x 10 samples = {10 * n / 1e9:.1f} G k-mer probes; "
-            f"large database {bi.total_kmers / 1e9:.2f} G k-mers generated in {t_gen:.0f} s, opened in {t_big_open:.1f} s "
-            f"(cell table 2^{int(np.log2(bi.table_lines))} lines, {bi.table_bytes / 2**30:.0f} GiB incl. stash, "
-            f"{bi.second_choice_kmers / 1e6:.0f} M second-choice, {bi.stash_kmers / 1e6:.0f} M stash k-mers; as a line table "
-            f"{t_lines_open:.1f} s); kcfx_screen_sharded (2 workers, load overlapped): {t_sharded:.1f} s wall, loads "
-            f"{st.seconds_db_open_sum:.1f} s of which {st.seconds_exposed_load:.1f} s exposed, screening {st.seconds_screen_sum:.2f} s; "
-            f"kcfx_screen_ref_multi on 10 resident databases: {t_multi * 1e3:.0f} ms = {10 * n / t_multi / 1e9:.0f} G k-mers/s; "
-            f"oracle on 4 500 sampled windows {t_oracle:.0f} s; test wall {time.time() - t_all:.0f} s")
+    gk = n / 1e9
+    line = (f"config-5 ({why}): {L / 1e9:.1f} Gb reference, {len(starts)} windows x {N_SAMPLES} samples = {N_SAMPLES * n / 1e9:.0f} G k-mer probes; "
+            f"kcfx_screen_sharded (2 workers on one GPU, load overlapped): {t_sharded:.1f} s wall, loads {st.seconds_db_open_sum:.1f} s of "
+            f"which {st.seconds_exposed_load:.1f} s exposed, screening {st.seconds_screen_sum:.2f} s; large database {bi.total_kmers / 1e9:.2f} G "
+            f"k-mers generated in {t_gen:.0f} s, opened in {t_big_open:.1f} s (2^{int(np.log2(bi.table_lines))} lines = "
+            f"{bi.total_kmers / (16.0 * bi.table_lines):.2f} per cell, {bi.table_bytes / 2**30:.0f} GiB incl. stash, "
+            f"{100.0 * bi.stash_kmers / bi.total_kmers:.0f} % in the stash; as a line table {t_lines_open:.1f} s); DENSE 2^{dense_bits} lines = "
+            f"{di.total_kmers / (16.0 * di.table_lines):.2f} per cell: opened in {t_dense_open:.1f} s, {di.table_bytes / 2**30:.0f} GiB, "
+            f"{100.0 * di.stash_kmers / di.total_kmers:.0f} % in the stash, {100.0 * di.second_choice_kmers / di.total_kmers:.0f} % second-choice, "
+            f"every window identical; screening kernel per pass of {gk:.1f} G k-mers: sparse 150 M-k-mer sample {ms_sparse:.1f} ms "
+            f"({gk / ms_sparse * 1e3:.0f} G k-mers/s), large at {bi.total_kmers / (16.0 * bi.table_lines):.2f} per cell {ms_big:.1f} ms "
+            f"({gk / ms_big * 1e3:.0f} G/s), dense {ms_dense:.1f} ms ({gk / ms_dense * 1e3:.0f} G/s); kcfx_screen_ref_multi on 10 resident "
+            f"databases: {t_multi * 1e3:.0f} ms = {10 * n / t_multi / 1e9:.0f} G k-mers/s; oracle on {n_checked} sampled windows of 4 samples "
+            f"{t_oracle:.0f} s; test wall {time.time() - t_all:.0f} s")
     print(line)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "config5_shape.log"), "a") as fh:

@@ -48,3 +48,34 @@ def test_native_synth_database_is_searchable(oracle, tmp_path, k, p, cs, bins):
             a = db.process_window(ref[s:s + 5000], 1)
             b = pymodel.process_window(ref[s:s + 5000].decode("latin1"), table, k, True, 1)
             assert all(a[f] == b[f] for f in a)
+
+
+def test_native_synth_repeats_give_the_genome_structure(oracle, tmp_path):
+    """--repeats: transposable-element families, tandem satellite arrays, segmental duplications and microsatellites on top of
+    the uniform text (uniform text has no structure, and repeats are what crowd minimizers): deterministic, the sample genome
+    shares the structure, k-mers recur, and the database stays searchable by the reference's own bisection."""
+    if not os.path.exists(BIN):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "kcftools_amd", "csrc"), "../bin/kcfx_synth"], check=True, capture_output=True)
+    outs = []
+    for name in ("r1", "r2"):
+        prefix = str(tmp_path / name)
+        out = subprocess.run([BIN, "--out", prefix, "--ref-len", "1200000", "--repeats", "0.45", "--noise", "5000", "--threads", "4"],
+                             check=True, capture_output=True, text=True).stdout
+        outs.append(json.loads(out))
+    m = outs[0]
+    rb = m["repeat_bases"]
+    assert rb["te"] > 0.2 * 1_200_000 and rb["satellite"] > 0 and rb["segdup"] > 0 and rb["microsat"] > 0
+    for ext in (".kmc_pre", ".kmc_suf", ".ref.txt"):
+        assert open(str(tmp_path / "r1") + ext, "rb").read() == open(str(tmp_path / "r2") + ext, "rb").read()
+    # k-mers recur: clearly fewer distinct k-mers than k-mer positions (uniform text: practically none recur)
+    assert m["db_kmers"] - m["noise_kmers"] < 0.93 * m["sample_kmers"]
+    db = oracle.OracleDb(str(tmp_path / "r1"))
+    km, ct = db.dump()
+    assert ct.max() > 20                                     # a satellite unit's k-mers are seen many times
+    rng = np.random.default_rng(1)
+    for i in rng.integers(0, len(km), 2000):
+        assert db.get_count(int(km[i])) == int(ct[i])
+    # the reference text has the structure too: its own 31-mers recur
+    ref = np.frombuffer(open(str(tmp_path / "r1") + ".ref.txt", "rb").read(), dtype=np.uint8)
+    win = np.lib.stride_tricks.sliding_window_view(ref[:400_000], 31)
+    assert len(np.unique(win, axis=0)) < 0.97 * len(win)

@@ -31,15 +31,17 @@ def main():
     ap.add_argument("--min-count", type=int, default=1)
     ap.add_argument("--k", type=int, default=31, help="27 .. 31 take the cell table; (k - p) must be a multiple of 4")
     ap.add_argument("--p", type=int, default=0, help="LUT prefix length (default: 7, or the largest of 3 .. 7 that fits k)")
+    ap.add_argument("--repeats", type=float, default=0.0, help="kcfx_synth --repeats: fraction of the genome with repeat structure")
     args = ap.parse_args()
     K = args.k
     p = args.p or max(q for q in range(3, 8) if (K - q) % 4 == 0)
     os.makedirs(args.workdir, exist_ok=True)
     synth = os.path.join(ROOT, "kcftools_amd", "bin", "kcfx_synth")
-    prefix = os.path.join(args.workdir, f"r{args.ref_len}_e{args.error_events}_n{args.noise}_k{K}")
+    prefix = os.path.join(args.workdir, f"r{args.ref_len}_e{args.error_events}_n{args.noise}_k{K}" + (f"_rep{args.repeats}" if args.repeats else ""))
     if not os.path.exists(prefix + ".kmc_suf"):
         out = subprocess.run([synth, "--out", prefix, "--ref-len", str(args.ref_len), "--seed", "1", "--sample-seed", "2",
-                              "--error-events", str(args.error_events), "--noise", str(args.noise), "--k", str(K), "--p", str(p)],
+                              "--error-events", str(args.error_events), "--noise", str(args.noise), "--k", str(K), "--p", str(p)]
+                             + (["--repeats", str(args.repeats)] if args.repeats else []),
                              check=True, capture_output=True, text=True).stdout
         meta = json.loads(out.strip().splitlines()[-1])
         print("generated:", {k: meta[k] for k in ("sample_kmers", "noise_kmers", "error_kmers", "db_kmers")}, flush=True)
