@@ -151,6 +151,9 @@ def main():
     ap.add_argument("--samples", type=int, default=1,
                     help="samples per GPU; > 1 screens them in one pass over the reference (kcfx_screen_ref_multi, SURVEY f-4). "
                          "The default 1 is BASELINE.json's configuration")
+    ap.add_argument("--cohort", action="store_true",
+                    help="with --samples S (2 .. 8): the S samples in ONE cohort table (kcfx_cohort_open), one look-up per reference "
+                         "k-mer for all of them; algorithmic bytes per sample-k-mer = (1 + 8) / S + counter_size")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -214,7 +217,12 @@ def main():
         win_begin, win_len = win_begin[lo:hi], win_len[lo:hi]
 
     t0 = time.time()
-    dbs = [engine.KmcDb.open(pfx, device=local_rank) for pfx in prefixes]
+    cohort = None
+    if args.cohort and S > 1:
+        cohort = engine.Cohort(prefixes, device=local_rank)
+        dbs = [engine.KmcDb.open(prefixes[0], device=local_rank)]          # (the first sample on its own: the parity leg's single-sample twin)
+    else:
+        dbs = [engine.KmcDb.open(pfx, device=local_rank) for pfx in prefixes]
     db = dbs[0]
     load_s = (time.time() - t0) / S
     ref = engine.Reference(text, win_begin, win_len, K, device=local_rank)
@@ -232,7 +240,9 @@ def main():
     stream = torch.cuda.current_stream()
 
     def step():
-        if S == 1:
+        if cohort is not None:
+            cohort.screen_async(ref, out.data_ptr(), stream.cuda_stream, args.min_count)
+        elif S == 1:
             ref.screen_async(db, out.data_ptr(), stream.cuda_stream, args.min_count)
         else:
             ref.screen_multi_async(dbs, out.data_ptr(), stream.cuda_stream, args.min_count)
@@ -294,12 +304,15 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     kern_avg_ms = kernel_ms / max(1, launches)
     launches_per_step = max(1.0, launches / args.steps)                # multi-sample: one launch per <= 8 samples
-    # one ASCII base per reference position is read once for all S samples (SURVEY f-4: B_alg = 1/S + 8 + counter_size)
-    b_alg = 1.0 / S + 8 + COUNTER_SIZE
+    # one ASCII base per reference position is read once for all S samples (SURVEY f-4: B_alg = 1/S + 8 + counter_size); in a
+    # cohort table the key is compared once for all of them too: (1 + 8) / S + counter_size
+    b_alg = ((1.0 + 8.0) / S + COUNTER_SIZE) if cohort is not None else (1.0 / S + 8 + COUNTER_SIZE)
     achieved_gbs = (kmers_per_step * b_alg / launches_per_step) / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
 
     kernel_name = ("screen_k31c_kernel" if db.info.table_format == 1 else "screen_k31_kernel") if (S == 1 or db.info.table_format == 1) \
         else "screen_k31_multi_kernel"
+    if cohort is not None:
+        kernel_name = "screen_cohort_kernel"
     if os.environ.get("KCFX_GENERIC_KERNEL"):           # A/B hook: the general kernel on a line table
         kernel_name = "screen_tiles_kernel"
     # HBM traffic comes from PMC counters, which need their own rocprofv3 passes (tools/profile_round.sh): the figure below
@@ -458,7 +471,12 @@ def main():
                                    + ", no data-path collective, one final RCCL gather of 40 B records"
                                    + (" -- REHEARSAL: all ranks on one GPU over gloo, not a measurement" if rehearsal else ""))
                    if world > 1 else "single GPU",
-                   "table_bytes": int(db.info.table_bytes), "hit_rate": float(res["obs"].sum() / max(1, res["total_kmers"].sum()))},
+                   "table_bytes": int(cohort.info.table_bytes if cohort is not None else db.info.table_bytes),
+                   "cohort_table": (None if cohort is None else {"samples": S, "records": int(cohort.info.total_records),
+                                                                   "lines": int(cohort.info.table_lines),
+                                                                   "stash_records": int(cohort.info.stash_records),
+                                                                   "open_seconds": float(cohort.info.load_seconds)}),
+                   "hit_rate": float(res["obs"].sum() / max(1, res["total_kmers"].sum()))},
         "windows_per_s": (n_win_total * S if window_sharded else n_win * S * world) * args.steps / elapsed,
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

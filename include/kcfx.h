@@ -196,6 +196,37 @@ int32_t kcfx_score(const kcfx_result* res, int64_t n, double wi, double wt, doub
 int32_t kcfx_windows(int32_t seq_len, int32_t window, int32_t step, int32_t kmer_length,
                      int32_t* starts, int32_t* ends, int64_t cap, int64_t* n_out);
 
+/* ---- cohort table: S samples in ONE table ---------------------------------------------------------------------------- */
+
+/* What the reference does as S getVariations runs and a `cohort` merge (utils/run_kcftools.sh:124-160, Plugins/Cohort.java:71-119),
+ * taken into the table: the k-mers of up to KCFX_COHORT_MAX samples are re-indexed into ONE cell table whose cells carry one
+ * counter per sample, so a reference k-mer is located once for all samples (one line request per minimizer run plus the
+ * lines of the counters, instead of one per sample) and only the `count >= -c` test, the hit ballot and the count sum are
+ * per sample: algorithmic bytes per sample-k-mer = (1 + 8) / S + counter_size. Needs k = 31, counters of at most 2 bytes and
+ * one strandedness across the samples (KCFX_ERR_ARG otherwise: screen such samples through kcfx_screen_ref_multi).
+ * Memory: 8 + 2 * KCFX_COHORT_MAX bytes per cell of the union of the samples' k-mers. */
+#define KCFX_COHORT_MAX 8
+typedef struct kcfx_cohort kcfx_cohort;
+typedef struct {
+    int32_t n_samples, kmer_length, both_strands, device;
+    int64_t total_records;     /* k-mer records of all samples together (a k-mer that several samples hold counts once per sample) */
+    int64_t table_lines;       /* 128-byte key lines (16 cells each) */
+    int64_t table_bytes;       /* HBM bytes: keys + counters + stash + stash counters */
+    int64_t stash_records;     /* records whose k-mer lives in the stash */
+    double  load_seconds;
+} kcfx_cohort_info_t;
+/* opts may be NULL; opts->expected_queries sizes the key table as in kcfx_db_open_opts. */
+int32_t kcfx_cohort_open(const char* const* kmc_prefixes, int32_t n_samples, int32_t device, const kcfx_db_opts* opts,
+                         kcfx_cohort** out);
+int32_t kcfx_cohort_info(const kcfx_cohort* cohort, kcfx_cohort_info_t* info);
+void kcfx_cohort_close(kcfx_cohort* cohort);
+/* Every window of `ref` against every sample: out[s * n_windows + w] (host) = sample s (input order), window w -- each slice
+ * equals kcfx_screen_ref on that sample's own database. Synchronous. */
+int32_t kcfx_cohort_screen_ref(kcfx_cohort* cohort, kcfx_ref* ref, int32_t min_kmer_count, kcfx_result* out);
+/* Same, asynchronous on `hip_stream`, results left in device memory (n_samples * n_windows records). The reference's
+ * multi-sample scratch is allocated by the first call (kcfx_ref_reserve_multi beforehand makes the call capturable). */
+int32_t kcfx_cohort_screen_ref_async(kcfx_cohort* cohort, kcfx_ref* ref, int32_t min_kmer_count, void* out_device, void* hip_stream);
+
 /* ---- all GPUs of a node ---------------------------------------------------------------------------------- */
 
 /* The units are independent -- a (window, sample) result needs that window's text and that sample's database only

@@ -159,6 +159,15 @@ struct kcfx_ref {
     size_t events_used = 0;
 };
 
+struct kcfx_cohort {
+    int32_t device = 0;
+    int32_t n_samples = 0;
+    kcfx_db* keys = nullptr;           // the key table: an ordinary FORMAT_CELLS handle whose count fields are all 1
+    uint16_t* d_counts = nullptr;      // [16 * lines][COHORT_STRIDE]
+    uint16_t* d_scounts = nullptr;     // [stash slots][COHORT_STRIDE]
+    kcfx_cohort_info_t info{};
+};
+
 namespace {
 
 struct DeviceGuard {
@@ -659,6 +668,77 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     return KCFX_OK;
 }
 
+// One .kmc_suf decoded into device arrays (keys_out / counts_out hold h.total entries): pread -> pinned double buffer -> H2D ->
+// decode_records_kernel, on `st`. The cohort loader's form of load_suffix_file's streaming (no table pass rides on it).
+int32_t decode_file_to_device(const std::string& path, const KmcHeader& h, uint64_t* keys_out, uint32_t* counts_out, hipStream_t st) {
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return fail(KCFX_ERR_IO, "Error reading suffix buffers from file " + path);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || (int64_t)sb.st_size < 4 + h.total * h.record_size) {
+        close(fd);
+        return fail(KCFX_ERR_IO, "suffix file shorter than total_kmers * record_size: " + path);
+    }
+    char marker[4];
+    if (pread(fd, marker, 4, 0) != 4 || memcmp(marker, "KMCS", 4) != 0) {
+        close(fd);
+        return fail(KCFX_ERR_FORMAT, "missing KMCS marker in " + path);
+    }
+    const int64_t CH = 4ll << 20;
+    const int64_t n_chunk_max = std::min<int64_t>(CH, std::max<int64_t>(h.total, 1));
+    uint8_t* h_buf[2] = {nullptr, nullptr};
+    uint8_t* d_rec[2] = {nullptr, nullptr};
+    uint64_t* d_lut = nullptr;
+    hipEvent_t done[2] = {nullptr, nullptr};
+    int32_t rc = KCFX_OK;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(st);
+        for (int i = 0; i < 2; ++i) {
+            if (h_buf[i]) (void)host_free(h_buf[i]);
+            if (d_rec[i]) (void)dev_free_idle(d_rec[i]);
+            if (done[i]) (void)hipEventDestroy(done[i]);
+        }
+        if (d_lut) (void)dev_free_idle(d_lut);
+        close(fd);
+    };
+#define DEC_HIP(call)                                   \
+    do {                                                \
+        hipError_t e__ = (call);                        \
+        if (e__ != hipSuccess) {                        \
+            rc = hip_fail(e__, #call);                  \
+            cleanup();                                  \
+            return rc;                                  \
+        }                                               \
+    } while (0)
+    for (int i = 0; i < 2; ++i) {
+        DEC_HIP(host_alloc(&h_buf[i], (size_t)std::max<int64_t>(n_chunk_max * h.record_size, 16)));
+        DEC_HIP(dev_alloc(&d_rec[i], (size_t)n_chunk_max * h.record_size + 16));
+        DEC_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+    }
+    DEC_HIP(dev_alloc(&d_lut, (size_t)std::max<int64_t>(h.lut_entries, 1) * 8));
+    if (h.lut_entries) DEC_HIP(hipMemcpyAsync(d_lut, h.lut_bytes, (size_t)h.lut_entries * 8, hipMemcpyHostToDevice, st));
+    int turn = 0;
+    bool used[2] = {false, false};
+    for (int64_t first = 0; first < h.total;) {
+        const int64_t n = std::min(CH, h.total - first);
+        const int64_t bytes = n * h.record_size;
+        if (used[turn]) DEC_HIP(hipEventSynchronize(done[turn]));
+        if (!parallel_pread(fd, h_buf[turn], bytes, 4 + first * h.record_size)) {
+            cleanup();
+            return fail(KCFX_ERR_IO, "short read on " + path);
+        }
+        DEC_HIP(hipMemcpyAsync(d_rec[turn], h_buf[turn], (size_t)bytes, hipMemcpyHostToDevice, st));
+        DEC_HIP(hipEventRecord(done[turn], st));
+        used[turn] = true;
+        DEC_HIP(launch_decode_records(d_rec[turn], first, n, h.record_size, h.suffix_bytes, h.counter_size, h.p, d_lut, h.lut_entries,
+                                      keys_out + first, counts_out + first, st));
+        first += n;
+        turn ^= 1;
+    }
+#undef DEC_HIP
+    cleanup();
+    return KCFX_OK;
+}
+
 }  // namespace
 
 static void info_from_header(const KmcHeader& h, kcfx_db_info_t& info) {
@@ -1114,6 +1194,199 @@ int32_t kcfx_screen(kcfx_db* db, const uint8_t* text, int64_t text_len, const in
     kcfx_ref_destroy(ref);
     return rc;
 } KCFX_CATCH("kcfx_screen")
+
+// ---- cohort table ------------------------------------------------------------------------------------------------------
+int32_t kcfx_cohort_open(const char* const* kmc_prefixes, int32_t n_samples, int32_t device, const kcfx_db_opts* opts,
+                         kcfx_cohort** out) try {
+    if (!out || !kmc_prefixes) return fail(KCFX_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (n_samples < 1 || n_samples > KCFX_COHORT_MAX)
+        return fail(KCFX_ERR_ARG, "a cohort table holds 1 .. " + std::to_string(KCFX_COHORT_MAX) + " samples (screen larger cohorts in batches)");
+    if (opts && opts->expected_queries < 0) return fail(KCFX_ERR_ARG, "kcfx_db_opts: negative expected_queries");
+    const double t0 = now_s();
+    std::vector<KmcHeader> hs((size_t)n_samples);
+    int64_t N = 0;
+    for (int32_t s = 0; s < n_samples; ++s) {
+        if (!kmc_prefixes[s]) return fail(KCFX_ERR_ARG, "null database prefix");
+        std::string perr;
+        if (int32_t rc = parse_prefix_file(std::string(kmc_prefixes[s]) + ".kmc_pre", hs[(size_t)s], perr)) return fail(rc, perr);
+        const KmcHeader& h = hs[(size_t)s];
+        if (h.k != 31) return fail(KCFX_ERR_ARG, "cohort tables need k = 31 (" + std::string(kmc_prefixes[s]) + " has k = " + std::to_string(h.k) + ")");
+        if (h.counter_size < 1 || h.counter_size > 2)
+            return fail(KCFX_ERR_ARG, "cohort tables need counters of 1 or 2 bytes (" + std::string(kmc_prefixes[s]) + ")");
+        if (h.both != hs[0].both) return fail(KCFX_ERR_ARG, "cohort tables need one strandedness across the samples");
+        N += h.total;
+    }
+    if (int32_t rc = check_device(device)) return rc;
+    DeviceGuard g(device);
+    if (!g.ok) return fail(KCFX_ERR_DEVICE, "hipSetDevice failed");
+    struct Hold {                                          // everything built so far is released on every exit path
+        kcfx_cohort* c = nullptr;
+        uint64_t* d_keys = nullptr;
+        uint32_t* d_counts = nullptr;
+        ~Hold() {
+            if (d_keys) (void)dev_free(d_keys);
+            if (d_counts) (void)dev_free(d_counts);
+            kcfx_cohort_close(c);
+        }
+    } hold;
+    kcfx_cohort* co = hold.c = new kcfx_cohort();
+    co->device = device;
+    co->n_samples = n_samples;
+    kcfx_db* db = co->keys = new kcfx_db();
+    db->device = device;
+    info_from_header(hs[0], db->info);
+    db->info.total_kmers = N;
+    db->info.counter_size = 2;
+    db->info.device = device;
+    db->expected_queries = opts ? opts->expected_queries : 0;
+    hipError_t e = db_stream(device, &db->stream);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamCreate");
+    const size_t nn = (size_t)std::max<int64_t>(N, 1);
+    if ((e = dev_alloc(&hold.d_keys, nn * 8)) != hipSuccess || (e = dev_alloc(&hold.d_counts, nn * 4)) != hipSuccess)
+        return hip_fail(e, "kcfx_cohort_open: the decoded records of all samples (12 bytes each) must fit the device");
+    int64_t off = 0;
+    for (int32_t s = 0; s < n_samples; ++s) {
+        if (int32_t rc = decode_file_to_device(std::string(kmc_prefixes[s]) + ".kmc_suf", hs[(size_t)s], hold.d_keys + off, hold.d_counts + off, db->stream))
+            return rc;
+        off += hs[(size_t)s].total;
+    }
+    // bid ranks: how many samples hold each k-mer (a temporary open-addressing table over all records, ~2 slots per record)
+    {
+        uint64_t slots = 1024;
+        while (slots < 2 * (uint64_t)N) slots <<= 1;
+        if (slots > (1ull << 32)) slots = 1ull << 32;
+        if ((double)slots < 1.25 * (double)N) return fail(KCFX_ERR_DEVICE, "kcfx_cohort_open: too many records for the vote table");
+        uint4* d_votes = nullptr;
+        if ((e = dev_alloc(&d_votes, (size_t)slots * sizeof(uint4))) != hipSuccess) return hip_fail(e, "kcfx_cohort_open: vote table");
+        e = hipMemsetAsync(d_votes, 0xFF, (size_t)slots * sizeof(uint4), db->stream);
+        for (int phase = 0; phase < 2 && e == hipSuccess; ++phase)
+            for (int64_t first = 0; first < N && e == hipSuccess; first += (1ll << 30))
+                e = launch_cohort_votes(hold.d_keys + first, hold.d_counts + first, std::min<int64_t>(1ll << 30, N - first), d_votes,
+                                        (uint32_t)(slots - 1), phase, db->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(db->stream);
+        (void)dev_free_idle(d_votes);
+        if (e != hipSuccess) return hip_fail(e, "kcfx_cohort_open: votes");
+    }
+    // the key table: the ordinary build passes over the records of all samples; a cell's count field = the rank its k-mer bid with
+    if (int32_t rc = table_alloc(db, N, 2, true, false)) return rc;
+    if (db->fmt != FORMAT_CELLS) return fail(KCFX_ERR_ARG, "cohort tables need a cell table (KCFX_TABLE_FORMAT / KCFX_GENERIC_KERNEL / too many k-mers)");
+    const int32_t k = 31, both = db->info.both_strands;
+    auto pass = [&](int phase) -> hipError_t {
+        for (int64_t first = 0; first < N; first += (1ll << 30)) {
+            const int64_t n = std::min<int64_t>(1ll << 30, N - first);
+            const uint64_t* kk = hold.d_keys + first;
+            const uint32_t* cc = hold.d_counts + first;
+            hipError_t e2 = hipSuccess;
+            if (phase == 0) e2 = launch_cells_count(db->d_pop, k, db->lbits, both, kk, cc, n, db->stream, 1);
+            else if (phase == 1 || phase == 2) e2 = launch_cells_insert(db->d_lines, db->d_pop, phase == 1 ? 1 : 0, k, db->lbits, both, kk, cc, n, db->stream, 1);
+            else if (phase == 3) e2 = launch_cells_settle(db->d_lines, k, db->lbits, both, kk, cc, n, db->d_stats, db->stream, 1);
+            else e2 = launch_cells_stash(db->d_lines, k, db->lbits, both, kk, cc, n, db->d_stash, db->stash_mask, db->stream, 1);
+            if (e2 != hipSuccess) return e2;
+        }
+        return hipSuccess;
+    };
+    for (int phase = 0; phase <= 3; ++phase)
+        if ((e = pass(phase)) != hipSuccess) return hip_fail(e, "kcfx_cohort_open: key table pass");
+    if (int32_t rc = cells_stash_alloc(db)) return rc;       // (sized for the records that lost: a k-mer of several samples counts once per sample)
+    if ((e = pass(4)) != hipSuccess) return hip_fail(e, "kcfx_cohort_open: stash pass");
+    if (int32_t rc = table_finish(db)) return rc;
+    // the counters: COHORT_STRIDE u16 per cell and per stash slot
+    const size_t cell_bytes = ((size_t)db->n_lines * 16) * COHORT_STRIDE * 2, stash_bytes = ((size_t)db->stash_mask + 1) * COHORT_STRIDE * 2;
+    if ((e = dev_alloc(&co->d_counts, cell_bytes)) != hipSuccess || (e = dev_alloc(&co->d_scounts, stash_bytes)) != hipSuccess ||
+        (e = hipMemsetAsync(co->d_counts, 0, cell_bytes, db->stream)) != hipSuccess ||
+        (e = hipMemsetAsync(co->d_scounts, 0, stash_bytes, db->stream)) != hipSuccess)
+        return hip_fail(e, "kcfx_cohort_open: the counters (16 bytes per cell) do not fit the device");
+    off = 0;
+    for (int32_t s = 0; s < n_samples; ++s) {
+        if ((e = launch_cohort_fill(db->view(), k, both, hold.d_keys + off, hold.d_counts + off, hs[(size_t)s].total, s, co->d_counts,
+                                    co->d_scounts, db->stream)) != hipSuccess)
+            return hip_fail(e, "kcfx_cohort_open: counter pass");
+        off += hs[(size_t)s].total;
+    }
+    if ((e = hipStreamSynchronize(db->stream)) != hipSuccess) return hip_fail(e, "kcfx_cohort_open");
+    co->info.n_samples = n_samples;
+    co->info.kmer_length = k;
+    co->info.both_strands = both;
+    co->info.device = device;
+    co->info.total_records = N;
+    co->info.table_lines = db->n_lines;
+    co->info.table_bytes = db->info.table_bytes + (int64_t)cell_bytes + (int64_t)stash_bytes;
+    co->info.stash_records = db->info.stash_kmers;
+    co->info.load_seconds = now_s() - t0;
+    hold.c = nullptr;
+    *out = co;
+    return KCFX_OK;
+} KCFX_CATCH("kcfx_cohort_open")
+
+int32_t kcfx_cohort_info(const kcfx_cohort* cohort, kcfx_cohort_info_t* info) {
+    if (!cohort || !info) return fail(KCFX_ERR_ARG, "null argument");
+    *info = cohort->info;
+    return KCFX_OK;
+}
+
+void kcfx_cohort_close(kcfx_cohort* cohort) {
+    if (!cohort) return;
+    {
+        DeviceGuard g(cohort->device);
+        if (cohort->d_counts) (void)dev_free(cohort->d_counts);
+        if (cohort->d_scounts) (void)dev_free(cohort->d_scounts);
+    }
+    db_free(cohort->keys);
+    delete cohort;
+}
+
+int32_t kcfx_cohort_screen_ref_async(kcfx_cohort* cohort, kcfx_ref* ref, int32_t min_kmer_count, void* out_device, void* hip_stream) try {
+    if (!cohort || !ref || !out_device) return fail(KCFX_ERR_ARG, "null argument");
+    if (cohort->device != ref->device) return fail(KCFX_ERR_ARG, "cohort table and reference live on different devices");
+    if (ref->k != 31) return fail(KCFX_ERR_ARG, "reference was planned for a different k-mer length");
+    if (min_kmer_count < 1) return fail(KCFX_ERR_ARG, "Minimum kmer count should be at least 1");   // GetVariants.java:383-385
+    if (ref->n_windows == 0) return KCFX_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    DeviceGuard g(ref->device);
+    if (int32_t rc = kcfx_ref_reserve_multi(ref, cohort->n_samples)) return rc;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (ref->prof && ref->n_tiles > 0) {
+        if (ref->events_used == ref->events.size()) {
+            hipEvent_t a, b;
+            KCFX_HIP(hipEventCreate(&a));
+            KCFX_HIP(hipEventCreate(&b));
+            ref->events.emplace_back(a, b);
+        }
+        ev0 = ref->events[ref->events_used].first;
+        ev1 = ref->events[ref->events_used].second;
+        ref->events_used++;
+    }
+    CohortView cv{cohort->keys->view(), reinterpret_cast<const uint4*>(cohort->d_counts), reinterpret_cast<const uint4*>(cohort->d_scounts),
+                  cohort->n_samples};
+    KCFX_HIP(launch_screen_cohort(ref->d_text, ref->d_tiles, ref->n_tiles, cv, ref->k, cohort->info.both_strands, min_kmer_count,
+                                  ref->d_mbits, ref->d_mcsum, st, ev0, ev1));
+    KCFX_HIP(launch_reduce_windows(ref->d_tiles, ref->n_tiles, cohort->n_samples, ref->d_mbits, ref->d_mcsum, ref->d_win_tile0,
+                                   ref->n_windows, ref->k, reinterpret_cast<kcfx_result*>(out_device), st));
+    return KCFX_OK;
+} KCFX_CATCH("kcfx_cohort_screen_ref_async")
+
+int32_t kcfx_cohort_screen_ref(kcfx_cohort* cohort, kcfx_ref* ref, int32_t min_kmer_count, kcfx_result* out) try {
+    if (!cohort || !ref) return fail(KCFX_ERR_ARG, "null argument");
+    if (ref->n_windows == 0) {
+        if (min_kmer_count < 1) return fail(KCFX_ERR_ARG, "Minimum kmer count should be at least 1");
+        return KCFX_OK;
+    }
+    if (!out) return fail(KCFX_ERR_ARG, "null argument");
+    DeviceGuard g(ref->device);
+    const size_t bytes = (size_t)cohort->n_samples * ref->n_windows * sizeof(kcfx_result);
+    if (ref->mres_bytes < bytes) {
+        if (ref->d_mres) (void)dev_free(ref->d_mres);
+        ref->d_mres = nullptr;
+        ref->mres_bytes = 0;
+        KCFX_HIP(dev_alloc(&ref->d_mres, bytes));
+        ref->mres_bytes = bytes;
+    }
+    if (int32_t rc = kcfx_cohort_screen_ref_async(cohort, ref, min_kmer_count, ref->d_mres, ref->stream)) return rc;
+    KCFX_HIP(hipMemcpyAsync(out, ref->d_mres, bytes, hipMemcpyDeviceToHost, ref->stream));
+    KCFX_HIP(hipStreamSynchronize(ref->stream));
+    return KCFX_OK;
+} KCFX_CATCH("kcfx_cohort_screen_ref")
 
 // Data.java:87 and :95-107. Separate statements + -ffp-contract=off: strict left-to-right IEEE double, no FMA.
 int32_t kcfx_score(const kcfx_result* res, int64_t n, double wi, double wt, double wr, double* score, double* mean_count) {

@@ -98,6 +98,19 @@ struct TableView {
 };
 
 // ----------------------------------------------------------------------------------------------------
+// Cohort table (kcfx_cohort_open): ONE FORMAT_CELLS key table for S <= COHORT_STRIDE samples -- every stored k-mer's count
+// field is 1 -- and the counters beside it: counts[cell][COHORT_STRIDE] u16 (cell = 16 * line + cell index: 16 bytes per
+// cell, 256 bytes per line), stash_counts[slot][COHORT_STRIDE] u16. Counters are at most 2 bytes wide (counter_size <= 2).
+// ----------------------------------------------------------------------------------------------------
+constexpr int COHORT_STRIDE = 8;
+struct CohortView {
+    TableView tv;
+    const uint4* counts;
+    const uint4* stash_counts;
+    int32_t n_samples;
+};
+
+// ----------------------------------------------------------------------------------------------------
 // Tile plan: every window is cut into tiles of at most TILE_K consecutive k-mer start positions; one
 // workgroup screens one tile and emits its hit bitmap; reduce_windows summarises the bitmaps piecewise (TileSummary)
 // and folds a window's pieces in order.
@@ -249,14 +262,25 @@ hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide,
 // second-choice cells or flag them for the stash (stats[0] = how many), fill the stash
 size_t cells_pop_bytes(int32_t lbits);
 // (both = the database is canonical; see CELL_R_FLIP in kcfx_device.h for what a forward-only one changes)
+// (presence != 0: every non-zero counter is stored as 1 -- the key table of a cohort, kcfx_cohort_open)
 hipError_t launch_cells_count(uint32_t* pop32, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                              hipStream_t st);
+                              hipStream_t st, int32_t presence = 0);
 hipError_t launch_cells_insert(uint8_t* lines, const uint32_t* pop32, int32_t cls, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys,
-                               const uint32_t* counts, int64_t n, hipStream_t st);
+                               const uint32_t* counts, int64_t n, hipStream_t st, int32_t presence = 0);
 hipError_t launch_cells_settle(uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                               unsigned long long* stats, hipStream_t st);
+                               unsigned long long* stats, hipStream_t st, int32_t presence = 0);
 hipError_t launch_cells_stash(const uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                              uint4* stash, uint32_t stash_mask, hipStream_t st);
+                              uint4* stash, uint32_t stash_mask, hipStream_t st, int32_t presence = 0);
+// cohort tables: one sample's counters into the finished key table; S samples screened in one pass (bits / count_sums laid out
+// per sample as launch_screen_multi's: sample s at bits + s * n_tiles * TILE_BITS_U64, count_sums + s * n_tiles)
+// phase 0: every record votes for its k-mer in `votes` (2^n slots of 16 bytes, all bytes 0xFF); phase 1: the bid rank of every
+// record (samples holding its k-mer, then its counter) into the upper half of its counts word
+hipError_t launch_cohort_votes(const uint64_t* keys, uint32_t* counts, int64_t n, uint4* votes, uint32_t mask, int32_t phase, hipStream_t st);
+hipError_t launch_cohort_fill(TableView tv, int32_t k, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
+                              int32_t sample, uint16_t* cell_counts, uint16_t* stash_counts, hipStream_t st);
+hipError_t launch_screen_cohort(const uint8_t* text, const TileDesc* tiles, int32_t n_tiles, CohortView cv, int32_t k,
+                                int32_t both_strands, int32_t min_count, uint64_t* bits, int64_t* count_sums, hipStream_t st,
+                                hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // lookup
 hipError_t launch_lookup(TableView tv, int32_t k, const uint64_t* keys, int64_t n, int32_t* counts_out, hipStream_t st);
 // screen

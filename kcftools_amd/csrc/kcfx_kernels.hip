@@ -199,6 +199,24 @@ __global__ __launch_bounds__(256) void lookup_kernel(TableView tv, int32_t k, co
 constexpr uint32_t CELL_CROWD = 3;
 constexpr uint32_t CELL_COUNT_MAX = 0xFFFFu;                // what the 16-bit count field of a cell holds
 constexpr uint32_t CELL_FLAG_CROWDED = 2u;                  // bit 1 of w: the occupant is of the crowded class
+// The key table of a COHORT (one table for S samples: every sample's records go through the same passes, the counters live
+// beside the cells; presence != 0): the count field of a cell only says "present" (non-zero) and ranks the bids -- a record
+// bids with its own counter, capped at what the field holds, so that the k-mers of the genome (seen depth times in every
+// sample) keep their cells against the k-mers one sample saw once, exactly as in a single-sample table -- and the copies of a
+// k-mer that several samples hold, bidding with different counters, are ONE k-mer: identity is compared without the count.
+// The rank of a bid is not the record's own counter but (samples that hold the k-mer, then the counter), which the cohort
+// loader has put into the upper half of the counts word (cohort_prio_kernel): at a site where the samples differ, the allele
+// most samples carry -- as a rule the one the reference carries too, i.e. the one a screening pass asks for -- keeps the
+// first-choice cell; its rarer siblings (same minimizer, same offset, one base of the flank different) go to second choices
+// and the stash. (With the counter alone as the rank half of the reference's k-mers lived in the stash: 32 M HBM requests per
+// pass of the bench cohort instead of 12 M.)
+__device__ __forceinline__ uint32_t cell_build_count(uint32_t c, int32_t presence) { return presence ? (c >> 16) : c; }
+// cell word `have` (identity bits kc, flags and filter bits excluded) is the k-mer whose word is `mine`
+__device__ __forceinline__ bool cell_same(uint64_t have, uint64_t mine, uint64_t kc, int32_t presence) {
+    if (!presence) return (have & kc) == mine;
+    const uint64_t id = kc & 0x0000FFFFFFFFFFFFull;
+    return (have >> 48) != 0 && (have & id) == (mine & id);
+}
 __host__ __device__ inline int cell_sub_bits(int32_t lbits) { return lbits <= 30 ? 2 : 32 - lbits; }
 __device__ __forceinline__ uint64_t cell_sub_bucket(const CellProbe& p, int32_t lbits) {
     const int sb = cell_sub_bits(lbits);
@@ -210,11 +228,11 @@ __device__ __forceinline__ uint64_t cell_sub_bucket(const CellProbe& p, int32_t 
 // Pass 0: k-mers per sub-bucket, one byte each (a byte that overflows spills into its neighbour: the classes are a
 // heuristic, see above)
 __global__ void cells_count_kernel(uint32_t* pop32, int32_t k, int32_t lbits, int32_t both, const uint64_t* __restrict__ keys,
-                                   const uint32_t* __restrict__ counts, int64_t n) {
+                                   const uint32_t* __restrict__ counts, int64_t n, int32_t presence) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
-        if (counts[i] == 0) continue;
+        if (counts[i] == 0) continue;                           // (presence mode: the same test)
         cells_visit(keys[i], k, lbits, both != 0, [&](const CellProbe& p, int a) {
             if (a != 0) return;                                 // the first of its cells names the k-mer's sub-bucket
             const uint64_t sub = cell_sub_bucket(p, lbits);
@@ -228,11 +246,11 @@ __global__ void cells_count_kernel(uint32_t* pop32, int32_t k, int32_t lbits, in
 // one gets the cell whatever the arrival order. The others do the same among themselves (a CAS loop), but never replace a
 // crowded occupant.
 __global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__ pop32, int32_t cls, int32_t k, int32_t lbits, int32_t both,
-                                    const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, int64_t n) {
+                                    const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, int64_t n, int32_t presence) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
-        const uint32_t c = counts[i];
+        const uint32_t c = cell_build_count(counts[i], presence);
         if (c == 0) continue;                       // can never be observed (count >= -c >= 1 is needed): not stored
         if (c > CELL_COUNT_MAX) continue;           // a 3- / 4-byte counter that does not fit a cell: lives in the stash (settle)
         bool crowded = false;
@@ -259,14 +277,15 @@ __global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__
 }
 
 // where a k-mer stands after the bidding: in its first-choice cell, in its second-choice cell, or in neither
-__device__ __forceinline__ int cell_standing(const uint8_t* lines, const CellProbe& p, uint32_t c, int32_t lbits, bool both, int W) {
+__device__ __forceinline__ int cell_standing(const uint8_t* lines, const CellProbe& p, uint32_t c, int32_t lbits, bool both, int W,
+                                             int32_t presence = 0) {
     const uint64_t kc = cell_keycount_mask(lbits, both);              // (flags and stash-filter bits are not part of the k-mer)
     const uint8_t* line = lines + (size_t)p.line * LINE_BYTES;
     const uint64_t first = __atomic_load_n(reinterpret_cast<const uint64_t*>(line + 4 * p.sh), __ATOMIC_RELAXED);
-    if ((first & kc) == cell_word(p.w, p.r, c)) return 0;
+    if (cell_same(first, cell_word(p.w, p.r, c), kc, presence)) return 0;
     const CellAlt a = cell_alt_of(p.sh, p.w, p.r, W, lbits, both);
     const uint64_t second = __atomic_load_n(reinterpret_cast<const uint64_t*>(line + 4 * a.sh), __ATOMIC_RELAXED);
-    if ((second & (0xFFFF0000FFFFFFFCull | ((uint64_t)a.rmask << 32))) == cell_word(p.w, a.r, c)) return 1;
+    if (cell_same(second, cell_word(p.w, a.r, c), 0xFFFF0000FFFFFFFCull | ((uint64_t)a.rmask << 32), presence)) return 1;
     return 2;
 }
 
@@ -275,13 +294,13 @@ __device__ __forceinline__ int cell_standing(const uint8_t* lines, const CellPro
 // stash", and which filter bit that someone has (cell_filter_pos) -- and is counted. stats[0] = k-mers for the stash, [1] = k-mers stored (count != 0), [2] = k-mers with more
 // than one first-choice cell, [3] = second-choice placements
 __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, int32_t both_i, const uint64_t* __restrict__ keys,
-                                    const uint32_t* __restrict__ counts, int64_t n, unsigned long long* stats) {
+                                    const uint32_t* __restrict__ counts, int64_t n, unsigned long long* stats, int32_t presence) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     uint32_t n_lost = 0, n_stored = 0, n_multi = 0, n_second = 0;      // per lane; one atomic per wave at the end
     const bool both = both_i != 0;
     for (; i < n; i += stride) {
-        const uint32_t c = counts[i];
+        const uint32_t c = cell_build_count(counts[i], presence);
         if (c == 0) continue;
         bool lost = false;
         const bool wide = c > CELL_COUNT_MAX;
@@ -295,7 +314,7 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, in
                 lost = true;
                 return;
             }
-            if (cell_standing(lines, p, c, lbits, both, cell_nw(k)) != 2) return;     // (1: the same word twice in the input)
+            if (cell_standing(lines, p, c, lbits, both, cell_nw(k), presence) != 2) return;     // (1: the same word twice in the input)
             const CellAlt a = cell_alt_of(p.sh, p.w, p.r, cell_nw(k), lbits, both);
             const unsigned long long kca = 0xFFFF0000FFFFFFFCull | ((unsigned long long)a.rmask << 32);
             unsigned long long* alt = reinterpret_cast<unsigned long long*>(line + 4 * a.sh);
@@ -312,7 +331,7 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, in
             }
             if (won) {
                 ++n_second;
-            } else if ((old & kca) != mine) {
+            } else if (!cell_same(old, mine, kca, presence)) {
                 atomicOr(reinterpret_cast<unsigned long long*>(line + 4 * p.sh), mark);
                 lost = true;
             }
@@ -333,16 +352,16 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, in
 
 // Pass 3 (after pass 2 has completed): a k-mer that stands in neither cell of one of its candidates goes to the stash.
 __global__ void cells_stash_kernel(const uint8_t* __restrict__ lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* __restrict__ keys,
-                                   const uint32_t* __restrict__ counts, int64_t n, uint4* stash, uint32_t mask) {
+                                   const uint32_t* __restrict__ counts, int64_t n, uint4* stash, uint32_t mask, int32_t presence) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
-        const uint32_t c = counts[i];
+        const uint32_t c = cell_build_count(counts[i], presence);
         if (c == 0) continue;
         const uint64_t key = keys[i];
         bool lost = c > CELL_COUNT_MAX;                 // (counters wider than a cell's 16 bits)
         if (!lost)
-            cells_visit(key, k, lbits, both != 0, [&](const CellProbe& p, int) { lost |= cell_standing(lines, p, c, lbits, both != 0, cell_nw(k)) == 2; });
+            cells_visit(key, k, lbits, both != 0, [&](const CellProbe& p, int) { lost |= cell_standing(lines, p, c, lbits, both != 0, cell_nw(k), presence) == 2; });
         if (!lost) continue;
         uint32_t slot = stash_slot(key, mask);
         for (;;) {
@@ -400,6 +419,98 @@ __global__ __launch_bounds__(256) void lookup_cells_kernel(TableView tv, int32_t
                 result = (int32_t)stash_find(tv, key);
         }
         out[i] = result;
+    }
+}
+
+// ---- cohort tables: S samples in ONE cell table (SURVEY f-4 taken into the table; Cohort.java:71-119, run_kcftools.sh:124-140) ----
+// The key table is an ordinary FORMAT_CELLS table built from the records of all S samples with every count field = 1
+// (presence); the counters live beside it, COHORT_STRIDE u16 per cell (one 16-byte load per lane) and per stash slot.
+// A reference k-mer is then located ONCE for all samples -- one line request per minimizer run plus the lines of the
+// counters its cells span -- instead of once per sample.
+// slot of `key` in the stash, ~0u when absent
+__device__ __forceinline__ uint32_t stash_find_slot(const TableView& tv, uint64_t key) {
+    uint32_t slot = stash_slot(key, tv.stash_mask);
+    for (;;) {
+        const uint4 e = tv.stash[slot];
+        const uint64_t ek = u64_of(e.x, e.y);
+        if (ek == key) return slot;
+        if (ek == EMPTY_KEY) return ~0u;
+        slot = (slot + 1) & tv.stash_mask;
+    }
+}
+
+// Votes: an open-addressing table {u64 key, u32 samples that hold it, u32 pad} over the records of all samples (the stash's
+// entry layout and probing), then every record's bid rank = min(samples, 15) << 12 | min(counter, 4095) into the upper half of
+// its counts word (counters of a cohort are at most 16 bits wide).
+__global__ void cohort_vote_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, int64_t n, uint4* votes, uint32_t mask) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        if (counts[i] == 0) continue;
+        const uint64_t key = keys[i];
+        uint32_t slot = stash_slot(key, mask);
+        for (;;) {
+            unsigned long long* kp = reinterpret_cast<unsigned long long*>(votes + slot);
+            const unsigned long long prev = atomicCAS(kp, (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+            if (prev == EMPTY_KEY || prev == key) {
+                atomicAdd(reinterpret_cast<uint32_t*>(kp) + 2, 1u);
+                break;
+            }
+            slot = (slot + 1) & mask;
+        }
+    }
+}
+__global__ void cohort_prio_kernel(const uint64_t* __restrict__ keys, uint32_t* counts, int64_t n, const uint4* __restrict__ votes, uint32_t mask) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const uint32_t c = counts[i] & 0xFFFFu;
+        if (c == 0) continue;
+        const uint64_t key = keys[i];
+        uint32_t slot = stash_slot(key, mask), v = 1;
+        for (;;) {
+            const uint4 e = votes[slot];
+            const uint64_t ek = u64_of(e.x, e.y);
+            if (ek == key) {
+                // entries were zero-filled apart from the key (0xFF..): the vote word started at 0xFFFFFFFF and wrapped
+                v = e.z + 1u;
+                break;
+            }
+            if (ek == EMPTY_KEY) break;
+            slot = (slot + 1) & mask;
+        }
+        counts[i] = c | ((min(v, 15u) << 12 | min(c, 4095u)) << 16);
+    }
+}
+
+// After the key table is complete: sample `s` writes its counters where its k-mers stand -- in every cell copy (a k-mer with
+// tied minimizers has several), or in the stash. Records of one sample are distinct k-mers and samples write different
+// columns, so there is no race.
+__global__ void cohort_fill_kernel(TableView tv, int32_t k, int32_t both_i, const uint64_t* __restrict__ keys,
+                                   const uint32_t* __restrict__ counts, int64_t n, int32_t sample, uint16_t* cell_counts,
+                                   uint16_t* stash_counts) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const bool both = both_i != 0;
+    for (; i < n; i += stride) {
+        const uint32_t c = counts[i] & 0xFFFFu;                 // (the upper half is the bid rank)
+        if (c == 0) continue;
+        const uint64_t key = keys[i];
+        bool stashed = false;
+        cells_visit(key, k, tv.lbits, both, [&](const CellProbe& p, int) {
+            const int st = cell_standing(tv.lines, p, 1u, tv.lbits, both, cell_nw(k), 1);
+            if (st == 2) {
+                stashed = true;
+                return;
+            }
+            const uint32_t sh = st == 0 ? p.sh : cell_alt_of(p.sh, p.w, p.r, cell_nw(k), tv.lbits, both).sh;
+            const size_t cell = (size_t)p.line * 16 + (sh >> 1);
+            cell_counts[cell * COHORT_STRIDE + sample] = (uint16_t)c;
+        });
+        if (stashed) {
+            const uint32_t slot = stash_find_slot(tv, key);
+            if (slot != ~0u) stash_counts[(size_t)slot * COHORT_STRIDE + sample] = (uint16_t)c;
+        }
     }
 }
 
@@ -1249,6 +1360,219 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
     }
 }
 
+// ======================================================================================================
+// screen_cohort: the tile walk of screen_k31c against a cohort table -- S <= 8 samples per k-mer look-up
+// ======================================================================================================
+// Three stages per word, software-pipelined: keys of word w + 2 issued | cells of word w + 1 matched and the 16 bytes of its
+// lanes' counters requested | counters of word w turned into S hit ballots and S count sums. Everything before the counters
+// is screen_k31c's code (K31Words, cell_probe_of, the two cell loads, cells_match): per sample a word costs one extract, one
+// compare, one ballot word to LDS and one masked add.
+struct CohortQueue {
+    uint32_t id[K31_QUEUE];                                           // (word of the wave << 6) | lane
+    unsigned long long vw[CELLS_WORDS_PER_WAVE];                      // validity ballots of the wave's words
+    unsigned long long hit[COHORT_STRIDE][CELLS_WORDS_PER_WAVE];      // hit ballots per sample (OR-ed: the stash adds its own)
+};
+struct CohortKeys {                       // stage 1 -> 2
+    uint64_t V;
+    uint32_t w, r;
+    uint64_t l32;                         // 32 * line + 2 * first-choice cell: byte offset of the cell / 4, and of its counters / 8
+    u32x2 cell, alt;
+};
+typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+struct CohortCounts {                     // stage 2 -> 3
+    uint64_t V, M;                        // valid lanes; lanes whose k-mer stands in a cell
+    u32x4_ c;                             // the 8 u16 counters of this lane's cell (meaningless outside M)
+};
+typedef const __attribute__((address_space(1))) u32x2* gcell_ptr_t;
+typedef u32x4_ u32x4;
+typedef const __attribute__((address_space(1))) u32x4* gcount_ptr_t;
+
+template <bool BOTH>
+__global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) void screen_cohort_kernel(
+    const uint8_t* __restrict__ text, const TileDesc* __restrict__ tiles, int32_t n_tiles, CohortView cv, int32_t min_count,
+    uint64_t* __restrict__ bits, int64_t* __restrict__ count_sums) {
+    constexpr int K = 31;
+    constexpr int WAVES = CELLS_WAVES;
+    __shared__ K31Pack sh;
+    __shared__ CohortQueue s_queue[WAVES];
+    __shared__ uint32_t s_sums[WAVES][COHORT_STRIDE];
+    const TableView& tv = cv.tv;
+    const int S = cv.n_samples;
+    const TileDesc td = tiles[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    CohortQueue& q = s_queue[wave];
+    // the hit words are OR-ed into (the stash may add a k-mer's bits before or after its word's own ballots arrive)
+    for (int i = lane; i < COHORT_STRIDE * CELLS_WORDS_PER_WAVE; i += 64) (&q.hit[0][0])[i] = 0ull;
+    const int off = k31_pack_tile<CELLS_BLOCK>(sh, text, td, tid);        // (its barrier also orders the zeroing above)
+
+    const int n_words = (td.n_kmers + 63) >> 6;
+    const int wpw = (n_words + WAVES - 1) / WAVES;
+    const int w_begin = min(wave * wpw, n_words);
+    const int w_end = min(w_begin + wpw, n_words);
+    int qn = 0;
+    const int pos0 = off + w_begin * 64;
+    uint32_t sum[COHORT_STRIDE];
+#pragma unroll
+    for (int s = 0; s < COHORT_STRIDE; ++s) sum[s] = 0;
+    K31Words<true, K> words;
+    if (w_begin < w_end) words.start(sh, off, td.n_kmers, lane, w_begin);
+    const uint8_t* const count_base = reinterpret_cast<const uint8_t*>(cv.counts);
+
+    // u16 counter s of the eight a lane has loaded
+    auto counter = [&](const u32x4& c, int s) -> uint32_t {
+        const uint32_t d = (s >> 1) == 0 ? c.x : (s >> 1) == 1 ? c.y : (s >> 1) == 2 ? c.z : c.w;
+        return (s & 1) ? (d >> 16) : (d & 0xFFFFu);
+    };
+    // stage 1: keys, minimizer, cell -> the two cell loads (cells_issue of screen_k31c, keeping the cell's offset for stage 2)
+    auto issue = [&](int w, CohortKeys& kw) {
+        uint64_t fwd, rc, V;
+        uint32_t mn;
+        words.next(w, fwd, rc, mn, V);
+        const CellProbe p = cell_probe_of(fwd, rc, mn, 2u * (uint32_t)lane, tv.lbits, 16, BOTH, 16);
+        const bool valid = __builtin_amdgcn_inverse_ballot_w64(V);
+        kw.V = V;
+        kw.w = p.w;
+        kw.r = p.r;
+        uint32_t line = valid ? p.line : 0u;
+        asm volatile("" : "+v"(line));
+        uint64_t l32 = ((uint64_t)line << 5) | (uint64_t)p.sh;
+        asm volatile("" : "+v"(l32));
+        kw.l32 = l32;
+        const uint8_t* a0 = reinterpret_cast<const uint8_t*>(reinterpret_cast<const uint32_t*>(tv.lines) + l32);
+        kw.cell = *(gcell_ptr_t)a0;
+        const uint64_t a1 = (uint64_t)a0 ^ (uint64_t)(((p.w >> 25) & 0x70u) | 8u);
+        kw.alt = *(gcell_ptr_t)a1;
+    };
+    // the queued k-mers (their cell is flagged for the stash, their filter bit is set): looked up 64 at a time, each lane
+    // fetching its own stash entry and that entry's counters
+    auto stash_round = [&]() {
+        const int nb = min(qn, 64), rest = qn - nb;
+        const uint32_t id = q.id[lane];
+        const uint32_t i2 = q.id[64 + lane];
+        wave_lds_fence();
+        if (lane < rest) q.id[lane] = i2;
+        if (lane < nb) {
+            const uint32_t slot = stash_find_slot(tv, k31_canonical_at<K, BOTH>(sh, pos0 + (int)id));
+            if (slot != ~0u) {
+                const uint4 c4 = cv.stash_counts[slot];
+                u32x4 c;
+                c.x = c4.x;
+                c.y = c4.y;
+                c.z = c4.z;
+                c.w = c4.w;
+#pragma unroll
+                for (int s = 0; s < COHORT_STRIDE; ++s) {
+                    const uint32_t cs = counter(c, s);
+                    if (s < S && (int32_t)cs >= min_count) {               // GetVariants.java:224-227
+                        atomicOr(&q.hit[s][id >> 6], 1ull << (id & 63));
+                        sum[s] += cs;
+                    }
+                }
+            }
+        }
+        wave_lds_fence();
+        qn = rest;
+    };
+    // stage 2: cells matched; the counters of every lane's cell requested (first choice unless the second one matched)
+    auto match = [&](int w, const CohortKeys& kw, CohortCounts& cw) {
+        uint32_t cnt = 0, pend = 0;
+        {
+            CellWord m;
+            m.V = kw.V;
+            m.w = kw.w;
+            m.r = kw.r;
+            m.cell = kw.cell;
+            m.alt = kw.alt;
+            cells_match<BOTH, 16>(m, tv.lbits, cnt, pend);
+        }
+        const bool first = ((kw.cell.x ^ kw.w) <= CELL_FLAG_MASK) && (((kw.cell.y ^ kw.r) & cell_rmask(tv.lbits, BOTH)) == 0);
+        cw.V = kw.V;
+        cw.M = wave_ballot(cnt != 0u) & kw.V;
+        const uint32_t x = first ? 0u : ((((kw.w >> 25) & 0x70u) | 8u) >> 2);      // sh ^ alt_sh
+        const uint64_t l32 = kw.l32 ^ (uint64_t)x;
+        cw.c = *(gcount_ptr_t)(count_base + (l32 << 3));                           // 16 bytes per cell, cell = l32 / 2
+        const uint64_t PM = wave_ballot(pend != 0u) & wave_ballot(cnt == 0u) & kw.V;
+        if (PM) {
+            const bool pending = __builtin_amdgcn_inverse_ballot_w64(PM);
+            const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(PM >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)PM, 0u));
+            if (pending) q.id[pos] = (uint32_t)(((w - w_begin) << 6) | lane);
+            qn += __popcll(PM);
+        }
+        wave_lds_fence();
+        while (qn >= 64) stash_round();
+    };
+    // stage 3: S hit ballots and count sums of the word
+    auto consume = [&](int w, const CohortCounts& cw) {
+        if (lane == 0) q.vw[w - w_begin] = cw.V;
+#pragma unroll
+        for (int s = 0; s < COHORT_STRIDE; ++s) {
+            if (s < S) {
+                const uint32_t cs = counter(cw.c, s);
+                const uint64_t H = wave_ballot((int32_t)cs >= min_count) & cw.M;   // GetVariants.java:224
+                const bool hit = __builtin_amdgcn_inverse_ballot_w64(H);
+                if (lane == 0 && H) atomicOr(&q.hit[s][w - w_begin], (unsigned long long)H);
+                sum[s] += hit ? cs : 0u;                                           // GetVariants.java:226
+            }
+        }
+    };
+    CohortKeys ka, kb;
+    CohortCounts ca, cb;
+    int w = w_begin;
+    const int nw = w_end - w_begin;
+    if (nw == 1) {
+        issue(w, ka);
+        match(w, ka, ca);
+        consume(w, ca);
+    } else if (nw > 1) {
+        issue(w, ka);
+        issue(w + 1, kb);
+        match(w, ka, ca);
+        for (; w + 3 < w_end; w += 2) {                     // at the top: keys of w + 1 (kb) and counters of w (ca) are in flight
+            issue(w + 2, ka);
+            match(w + 1, kb, cb);
+            consume(w, ca);
+            issue(w + 3, kb);
+            match(w + 2, ka, ca);
+            consume(w + 1, cb);
+        }
+        if (w + 2 < w_end) {
+            issue(w + 2, ka);
+            match(w + 1, kb, cb);
+            consume(w, ca);
+            match(w + 2, ka, ca);
+            consume(w + 1, cb);
+            consume(w + 2, ca);
+        } else {
+            match(w + 1, kb, cb);
+            consume(w, ca);
+            consume(w + 1, cb);
+        }
+    }
+    while (qn > 0) stash_round();
+    wave_lds_fence();
+    const int64_t bits_stride = (int64_t)n_tiles * TILE_BITS_U64;
+    for (int s = 0; s < S; ++s) {                           // per sample: the wave's words of the tile's bitmap (validity replicated)
+        uint64_t* my_bits = bits + (size_t)s * bits_stride + (size_t)blockIdx.x * TILE_BITS_U64;
+        if (lane < w_end - w_begin) {
+            my_bits[w_begin + lane] = q.vw[lane];
+            my_bits[TILE_WORDS + w_begin + lane] = q.hit[s][lane];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < COHORT_STRIDE; ++s) {
+        const uint32_t t = wave_sum_u32_dpp(sum[s]);
+        if (lane == 0) s_sums[wave][s] = t;
+    }
+    __syncthreads();
+    if (tid < S) {
+        uint64_t t = 0;
+#pragma unroll
+        for (int i = 0; i < WAVES; ++i) t += s_sums[i][tid];
+        count_sums[(size_t)tid * n_tiles + blockIdx.x] = (int64_t)t;
+    }
+}
+
 // ---- S samples in one pass over the reference (SURVEY f-4) ------------------------------------------------------
 // The same tile walk, but every word's keys / minimizers / validity are derived once and probed against S resident
 // tables: pack, strands, hashing and the sliding minimum are amortised over the samples. Sample s writes its own hit
@@ -1562,33 +1886,33 @@ hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide,
 }
 
 hipError_t launch_cells_count(uint32_t* pop32, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                              hipStream_t st) {
+                              hipStream_t st, int32_t presence) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(cells_count_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, pop32, k, lbits, both, keys, counts, n);
+    hipLaunchKernelGGL(cells_count_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, pop32, k, lbits, both, keys, counts, n, presence);
     return hipGetLastError();
 }
 
 hipError_t launch_cells_insert(uint8_t* lines, const uint32_t* pop32, int32_t cls, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys,
-                               const uint32_t* counts, int64_t n, hipStream_t st) {
+                               const uint32_t* counts, int64_t n, hipStream_t st, int32_t presence) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(cells_insert_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, pop32, cls, k, lbits, both, keys, counts, n);
+    hipLaunchKernelGGL(cells_insert_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, pop32, cls, k, lbits, both, keys, counts, n, presence);
     return hipGetLastError();
 }
 
 size_t cells_pop_bytes(int32_t lbits) { return (size_t)1 << (lbits + cell_sub_bits(lbits)); }
 
 hipError_t launch_cells_settle(uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                               unsigned long long* stats, hipStream_t st) {
+                               unsigned long long* stats, hipStream_t st, int32_t presence) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(cells_settle_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, k, lbits, both, keys, counts, n, stats);
+    hipLaunchKernelGGL(cells_settle_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, k, lbits, both, keys, counts, n, stats, presence);
     return hipGetLastError();
 }
 
 hipError_t launch_cells_stash(const uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                              uint4* stash, uint32_t stash_mask, hipStream_t st) {
+                              uint4* stash, uint32_t stash_mask, hipStream_t st, int32_t presence) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(cells_stash_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, k, lbits, both, keys, counts, n, stash,
-                       stash_mask);
+                       stash_mask, presence);
     return hipGetLastError();
 }
 
@@ -1663,6 +1987,36 @@ hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32
     }
 #undef KCFX_LAUNCH31
 #undef KCFX_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_cohort_votes(const uint64_t* keys, uint32_t* counts, int64_t n, uint4* votes, uint32_t mask, int32_t phase, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (phase == 0)
+        hipLaunchKernelGGL(cohort_vote_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, keys, counts, n, votes, mask);
+    else
+        hipLaunchKernelGGL(cohort_prio_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, keys, counts, n, votes, mask);
+    return hipGetLastError();
+}
+
+hipError_t launch_cohort_fill(TableView tv, int32_t k, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
+                              int32_t sample, uint16_t* cell_counts, uint16_t* stash_counts, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(cohort_fill_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, tv, k, both, keys, counts, n, sample,
+                       cell_counts, stash_counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_screen_cohort(const uint8_t* text, const TileDesc* tiles, int32_t n_tiles, CohortView cv, int32_t k,
+                                int32_t both_strands, int32_t min_count, uint64_t* bits, int64_t* count_sums, hipStream_t st,
+                                hipEvent_t ev_start, hipEvent_t ev_stop) {
+    if (n_tiles <= 0 || cv.n_samples <= 0) return hipSuccess;
+    if (k != 31 || cv.n_samples > COHORT_STRIDE || cv.tv.fmt != FORMAT_CELLS) return hipErrorInvalidValue;
+    const dim3 g(n_tiles), b(CELLS_BLOCK);
+    if (both_strands)
+        hipExtLaunchKernelGGL((screen_cohort_kernel<true>), g, b, 0, st, ev_start, ev_stop, 0, text, tiles, n_tiles, cv, min_count, bits, count_sums);
+    else
+        hipExtLaunchKernelGGL((screen_cohort_kernel<false>), g, b, 0, st, ev_start, ev_stop, 0, text, tiles, n_tiles, cv, min_count, bits, count_sums);
     return hipGetLastError();
 }
 

@@ -28,6 +28,7 @@ ABI_SYMBOLS = (
     "kcfx_ref_create", "kcfx_ref_n_windows", "kcfx_ref_n_kmer_slots", "kcfx_ref_destroy",
     "kcfx_screen_ref", "kcfx_screen_ref_async", "kcfx_screen_ref_multi", "kcfx_screen_ref_multi_async", "kcfx_screen",
     "kcfx_ref_reserve_multi",
+    "kcfx_cohort_open", "kcfx_cohort_info", "kcfx_cohort_close", "kcfx_cohort_screen_ref", "kcfx_cohort_screen_ref_async",
     "kcfx_ctx_create", "kcfx_ctx_n_devices", "kcfx_ctx_destroy", "kcfx_screen_sharded",
     "kcfx_score", "kcfx_windows",
     "kcfx_prof_enable", "kcfx_prof_read", "kcfx_last_error", "kcfx_device_count", "kcfx_version",
@@ -59,6 +60,13 @@ SHARD_AUTO, SHARD_SAMPLES, SHARD_WINDOWS = 0, 1, 2
 class DbOpts(C.Structure):
     """kcfx_db_opts"""
     _fields_ = [("expected_queries", C.c_int64), ("no_fallback", C.c_int32), ("reserved", C.c_int32)]
+
+
+class CohortInfo(C.Structure):
+    """kcfx_cohort_info_t"""
+    _fields_ = [("n_samples", C.c_int32), ("kmer_length", C.c_int32), ("both_strands", C.c_int32), ("device", C.c_int32),
+                ("total_records", C.c_int64), ("table_lines", C.c_int64), ("table_bytes", C.c_int64), ("stash_records", C.c_int64),
+                ("load_seconds", C.c_double)]
 
 
 class KcfxError(RuntimeError):
@@ -129,6 +137,12 @@ def lib() -> C.CDLL:
         L.kcfx_screen_ref_multi.argtypes = [vp, i32, vp, i32, vp]
         L.kcfx_screen_ref_multi_async.argtypes = [vp, i32, vp, i32, vp, vp]
         L.kcfx_screen.argtypes = [vp, vp, i64, vp, vp, i32, i32, vp]
+        L.kcfx_cohort_open.argtypes = [vp, i32, i32, C.POINTER(DbOpts), C.POINTER(vp)]
+        L.kcfx_cohort_info.argtypes = [vp, C.POINTER(CohortInfo)]
+        L.kcfx_cohort_close.argtypes = [vp]
+        L.kcfx_cohort_close.restype = None
+        L.kcfx_cohort_screen_ref.argtypes = [vp, vp, i32, vp]
+        L.kcfx_cohort_screen_ref_async.argtypes = [vp, vp, i32, vp, vp]
         L.kcfx_score.argtypes = [vp, i64, dbl, dbl, dbl, vp, vp]
         L.kcfx_windows.argtypes = [i32, i32, i32, i32, vp, vp, i64, C.POINTER(i64)]
         L.kcfx_prof_enable.argtypes = [vp, i32]
@@ -234,6 +248,41 @@ class KmcDb:
     def close(self) -> None:
         if self._h:
             lib().kcfx_db_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Cohort:
+    """Up to 8 samples re-indexed into ONE cell table with a counter per sample and cell (kcfx_cohort_open): what the reference
+    does as S getVariations runs + `cohort` (run_kcftools.sh:124-160, Cohort.java:71-119), located once per reference k-mer."""
+
+    def __init__(self, kmc_prefixes, device: int = 0, expected_queries: int = 0):
+        names = [os.fsencode(p) for p in kmc_prefixes]
+        arr = (C.c_char_p * max(len(names), 1))(*names)
+        opts = DbOpts(int(expected_queries), 0, 0)
+        self._h = C.c_void_p()
+        _check(lib().kcfx_cohort_open(arr, len(names), device, C.byref(opts), C.byref(self._h)))
+        self.info = CohortInfo()
+        _check(lib().kcfx_cohort_info(self._h, C.byref(self.info)))
+        self.n_samples = len(names)
+
+    def screen(self, ref: "Reference", min_count: int = 1) -> np.ndarray:
+        """array [n_samples, n_windows]; each row equals Reference.screen on that sample's own database"""
+        out = np.zeros((self.n_samples, ref.n_windows), dtype=RESULT_DTYPE)
+        _check(lib().kcfx_cohort_screen_ref(self._h, ref._h, min_count, out.ctypes.data))
+        return out
+
+    def screen_async(self, ref: "Reference", out_device_ptr: int, stream: int = 0, min_count: int = 1) -> None:
+        _check(lib().kcfx_cohort_screen_ref_async(self._h, ref._h, min_count, C.c_void_p(out_device_ptr), C.c_void_p(stream)))
+
+    def close(self) -> None:
+        if self._h:
+            lib().kcfx_cohort_close(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -1,0 +1,116 @@
+"""Cohort tables (kcfx_cohort_open: S samples in ONE cell table, SURVEY.md 8 f-4 taken into the table; the reference does S
+getVariations runs and a `cohort` merge, utils/run_kcftools.sh:124-160, Plugins/Cohort.java:71-119): every (window, sample)
+record must equal what the sample's own database gives -- through the single-sample GPU path AND the oracle -- for k-mers
+shared by all samples, by some, by one; counters of 1 and 2 bytes; -c thresholds; crowded tables whose stash carries real
+weight; forward-only databases; and the inputs the entry point must refuse."""
+import os
+
+import numpy as np
+import pytest
+
+from kcftools_amd import engine, synth
+
+pytestmark = pytest.mark.gpu
+FIELDS = engine.INT_FIELDS
+K = 31
+
+
+def make_sample(tmp_path, name, ref, seed, cs=2, both=True, noise=3000, **mut):
+    sample = synth.mutate_sample(ref, seed, **mut)
+    prm = synth.KmcParams(k=K, p=3, counter_size=cs, sig_len=7, n_bins=8, both_strands=both, max_count=(1 << (8 * cs)) - 1)
+    kmers, counts = synth.build_sample_db(sample, prm, seed + 1, noise_kmers=noise)
+    prefix = str(tmp_path / name)
+    synth.write_kmc(prefix, kmers, counts, prm)
+    return prefix
+
+
+def check(cohort_rows, prefixes, ref_text, s, lens, min_count, oracle, what):
+    for i, pfx in enumerate(prefixes):
+        want = oracle.OracleDb(pfx).screen(ref_text, s, lens, min_count, threads=8)
+        single = engine.KmcDb.open(pfx).screen(ref_text, s, lens, min_count)
+        for f in FIELDS:
+            assert np.array_equal(single[f], want[f]), (what, i, f, "single-sample path vs oracle")
+            bad = np.nonzero(cohort_rows[i][f] != want[f])[0]
+            assert len(bad) == 0, f"{what}: sample {i} field {f} differs at windows {bad[:6]}: {cohort_rows[i][f][bad[:6]]} vs {want[f][bad[:6]]}"
+
+
+@pytest.mark.parametrize("n_samples", [1, 3, 8])
+def test_cohort_rows_equal_the_single_sample_screens(oracle, tmp_path, n_samples):
+    ref = synth.random_reference(400_000, 31, n_run_every=40_000, max_n_run=300)
+    prefixes = [make_sample(tmp_path, f"s{i}", ref, 100 + 7 * i, cs=1 + (i % 2), noise=2000 + 900 * i,
+                            sub_rate=0.004 * (1 + i % 4)) for i in range(n_samples)]
+    s, e = engine.windows(len(ref), 10_000, 0, K)
+    lens = e - s
+    co = engine.Cohort(prefixes)
+    assert co.info.n_samples == n_samples and co.info.kmer_length == K and co.info.table_bytes > 0
+    r = engine.Reference(ref, s, lens, K)
+    for c in (1, 2, 5):
+        got = co.screen(r, c)
+        assert got.shape == (n_samples, len(s))
+        check(got, prefixes, ref, s, lens, c, oracle, f"S={n_samples} -c {c}")
+    if n_samples > 1:
+        assert len({int(got[i]["obs"].sum()) for i in range(n_samples)}) > 1       # the samples do differ
+    # irregular windows (gene-model-like: 0 bp .. 40 kbp, overlapping, some shorter than k)
+    rng = np.random.default_rng(5)
+    wb = np.sort(rng.integers(0, len(ref) - 40_000, 300)).astype(np.int64)
+    wl = rng.integers(0, 40_000, 300).astype(np.int32)
+    wl[::17] = rng.integers(0, K, len(wl[::17]))
+    r2 = engine.Reference(ref, wb, wl, K)
+    check(co.screen(r2, 1), prefixes, ref, wb, wl, 1, oracle, "irregular windows")
+
+
+def test_cohort_with_a_crowded_table_and_a_loaded_stash(oracle, tmp_path, monkeypatch):
+    """2^17 lines for ~2 M records: second choices and the stash (with its own counters) carry real weight."""
+    ref = synth.random_reference(500_000, 41)
+    prefixes = [make_sample(tmp_path, f"d{i}", ref, 200 + i, cs=2, noise=60_000) for i in range(4)]
+    s, e = engine.windows(len(ref), 10_000, 0, K)
+    monkeypatch.setenv("KCFX_TABLE_LBITS", "17")
+    co = engine.Cohort(prefixes)
+    monkeypatch.delenv("KCFX_TABLE_LBITS")
+    assert co.info.table_lines == 1 << 17 and co.info.stash_records > 0.05 * co.info.total_records
+    r = engine.Reference(ref, s, e - s, K)
+    check(co.screen(r, 1), prefixes, ref, s, e - s, 1, oracle, "crowded")
+    check(co.screen(r, 3), prefixes, ref, s, e - s, 3, oracle, "crowded -c 3")
+
+
+def test_cohort_of_forward_only_databases(oracle, tmp_path):
+    ref = synth.random_reference(200_000, 51)
+    prefixes = [make_sample(tmp_path, f"f{i}", ref, 300 + i, both=False) for i in range(3)]
+    s, e = engine.windows(len(ref), 10_000, 0, K)
+    co = engine.Cohort(prefixes)
+    assert co.info.both_strands == 0
+    check(co.screen(engine.Reference(ref, s, e - s, K), 1), prefixes, ref, s, e - s, 1, oracle, "forward-only")
+
+
+def test_cohort_async_on_a_torch_stream_and_what_it_refuses(oracle, tmp_path):
+    import torch
+    ref = synth.random_reference(150_000, 61)
+    prefixes = [make_sample(tmp_path, f"a{i}", ref, 400 + i) for i in range(2)]
+    s, e = engine.windows(len(ref), 10_000, 0, K)
+    co = engine.Cohort(prefixes, expected_queries=int((e - s - K + 1).sum()))
+    r = engine.Reference(ref, s, e - s, K)
+    out = torch.zeros(2 * len(s) * 10, dtype=torch.int32, device="cuda:0")
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for _ in range(3):
+            co.screen_async(r, out.data_ptr(), st.cuda_stream, 1)
+    st.synchronize()
+    got = out.cpu().numpy().view(engine.RESULT_DTYPE).reshape(2, len(s))
+    check(got, prefixes, ref, s, e - s, 1, oracle, "async")
+    # refused: more than 8 samples, k != 31, 4-byte counters, mixed strandedness, -c 0
+    with pytest.raises(engine.KcfxError) as err:
+        engine.Cohort([prefixes[0]] * 9)
+    assert err.value.code == 1
+    prm = synth.KmcParams(k=25, p=5, counter_size=2, sig_len=7, n_bins=4)
+    km, ct = synth.build_sample_db(synth.mutate_sample(ref, 9), prm, 10, noise_kmers=100)
+    synth.write_kmc(str(tmp_path / "k25"), km, ct, prm)
+    prm4 = synth.KmcParams(k=K, p=3, counter_size=4, sig_len=7, n_bins=4, max_count=2**31 - 1)
+    km, ct = synth.build_sample_db(synth.mutate_sample(ref, 9), prm4, 10, noise_kmers=100)
+    synth.write_kmc(str(tmp_path / "cs4"), km, ct, prm4)
+    fwd = make_sample(tmp_path, "fwd", ref, 77, both=False)
+    for bad in ([str(tmp_path / "k25")], [prefixes[0], str(tmp_path / "cs4")], [prefixes[0], fwd]):
+        with pytest.raises(engine.KcfxError) as err:
+            engine.Cohort(bad)
+        assert err.value.code == 1, bad
+    with pytest.raises(engine.KcfxError):
+        co.screen(r, 0)

@@ -164,6 +164,24 @@ def test_eight_samples_in_one_pass(oracle, genome, cohort):
     print(f"oracle on all 8 x {len(wb)} window-samples: {time.time() - t0:.1f} s on {HOST_THREADS} threads")
     n_kmers = int(got["total_kmers"].sum())
     print(f"8 samples x {len(wb)} windows = {n_kmers / 1e9:.2f} G k-mer probes in {wall * 1e3:.1f} ms (host call, results copied back)")
+    # the same eight samples in ONE cohort table (BASELINE configs[3] is this: whole genome, 8 samples): every (window, sample)
+    # record identical to the per-sample tables' -- which the oracle has just confirmed
+    del dbs
+    engine.release_cached()
+    t0 = time.time()
+    co = engine.Cohort(prefixes)
+    t_open = time.time() - t0
+    t0 = time.time()
+    cgot = co.screen(ref, 1)
+    t_co = time.time() - t0
+    for s in range(8):
+        for f in FIELDS:
+            assert np.array_equal(cgot[s][f], got[s][f]), ("cohort", s, f)
+    ci = co.info
+    print(f"cohort table of 8 samples: {ci.total_records / 1e6:.0f} M records, 2^{int(np.log2(ci.table_lines))} lines, "
+          f"{ci.table_bytes / 2**30:.1f} GiB, {100.0 * ci.stash_records / ci.total_records:.1f} % of the records in the stash, opened in "
+          f"{t_open:.1f} s; 8 x {len(wb)} window-samples in {t_co * 1e3:.1f} ms (host call) against {wall * 1e3:.1f} ms for 8 tables")
+    del co
     # the command-line driver on three of them: one multi-sample KCF, rows = windows, 3 sample columns
     out = os.path.join(genome["dir"], "cohort.kcf")
     p = subprocess.run([CLI, "getVariations", "-r", genome["prefix"] + ".fa", "-k", ",".join(prefixes[:3]), "-o", out,
