@@ -236,9 +236,11 @@ int32_t kcfx_ctx_create(const int32_t* devices, int32_t n_devices, kcfx_ctx** ou
 int32_t kcfx_ctx_n_devices(const kcfx_ctx* ctx);
 void kcfx_ctx_destroy(kcfx_ctx* ctx);
 
-#define KCFX_SHARD_AUTO 0      /* samples when n_samples >= devices, else windows */
+#define KCFX_SHARD_AUTO 0      /* samples when n_samples >= devices; windows for one sample; else grid */
 #define KCFX_SHARD_SAMPLES 1   /* device g screens samples g, g + G, ... against the whole window list */
 #define KCFX_SHARD_WINDOWS 2   /* device g screens a contiguous window range (equal k-mer start positions) of every sample */
+#define KCFX_SHARD_GRID 3      /* samples x windows: the sample-major sequence of (sample, window) units cut into equal contiguous
+                                  parts, one per device -- a device opens at most ceil(S / G) + 1 databases, not all S */
 
 typedef struct {
     int32_t shard_mode_used, n_devices;

@@ -47,14 +47,14 @@ struct Options {
     std::string ref, kmc, out, sample, feature, gtf;
     int threads = 2, window = 0, min_count = 1, step = 0;
     std::vector<int> devices{0};          // --device N | --devices a,b,...: the job is sharded over them (kcfx_screen_sharded)
-    int shard = KCFX_SHARD_AUTO;          // --shard auto|samples|windows
+    int shard = KCFX_SHARD_AUTO;          // --shard auto|samples|windows|grid
     bool memory = false;
     double wi = 0.3, wt = 0.3, wr = 0.4;
 };
 
 void usage() {
     std::puts("Usage: kcftools-amd getVariations -r <ref.fa> -k <kmc prefix> -o <out.kcf> -s <sample> -f window|gene|transcript\n"
-              "       [-w window] [-p step] [-g gtf] [-c min-k-count] [--wi 0.3] [--wt 0.3] [--wr 0.4] [-t threads] [-m] [--device 0 | --devices 0,1,...] [--shard auto|samples|windows]");
+              "       [-w window] [-p step] [-g gtf] [-c min-k-count] [--wi 0.3] [--wt 0.3] [--wr 0.4] [-t threads] [-m] [--device 0 | --devices 0,1,...] [--shard auto|samples|windows|grid]");
 }
 
 std::vector<std::string> split_commas(const std::string& v) {
@@ -117,6 +117,7 @@ int main(int argc, char** argv) {
             if (v == "auto") o.shard = KCFX_SHARD_AUTO;
             else if (v == "samples") o.shard = KCFX_SHARD_SAMPLES;
             else if (v == "windows") o.shard = KCFX_SHARD_WINDOWS;
+            else if (v == "grid") o.shard = KCFX_SHARD_GRID;
             else error("Invalid --shard value: " + v + " (auto, samples or windows)");
         }
         else if (a == "-h" || a == "--help") { usage(); return 0; }
@@ -262,7 +263,7 @@ int main(int argc, char** argv) {
         if (rc) error(msg);
         char line[256];
         std::snprintf(line, sizeof line, "Screened %zu sample(s) on %d device(s), %s-sharded: %.3f s (reference %.3f s, database loading %.3f s of which %.3f s not hidden behind screening, screening %.3f s)",
-                      S, st.n_devices, st.shard_mode_used == KCFX_SHARD_SAMPLES ? "sample" : "window", st.seconds_total, st.seconds_ref,
+                      S, st.n_devices, st.shard_mode_used == KCFX_SHARD_SAMPLES ? "sample" : st.shard_mode_used == KCFX_SHARD_GRID ? "sample x window" : "window", st.seconds_total, st.seconds_ref,
                       st.seconds_db_open_sum, st.seconds_exposed_load, st.seconds_screen_sum);
         info(line);
     }

@@ -5,8 +5,11 @@
 // samples as separate processes). So there is no exchange step: one worker thread per device, each with its own resident
 // reference, and either
 //   samples >= devices : sample-sharded -- device g screens samples g, g + G, ...; every device holds the whole window list
-//   samples <  devices : window-sharded -- device g screens a contiguous window range (balanced by k-mer start positions)
-//                        of every sample, and uploads only the text that range covers.
+//   one sample         : window-sharded -- device g screens a contiguous window range (balanced by k-mer start positions)
+//                        and uploads only the text that range covers.
+//   1 < samples < devices : grid -- the sample-major sequence of (sample, window) units is cut into equal contiguous parts: a
+//                        device opens at most two databases instead of all of them (KCFX_SHARD_WINDOWS, still selectable,
+//                        screens a window range of EVERY sample on every device).
 // Inside a worker the next sample's database is opened (file read, upload, table build) by a loader thread while the
 // current one is screened: at most two databases are resident per device, and a sample costs max(load, screen), not the sum.
 // Built on the public entry points only (kcfx_db_open / kcfx_ref_create / kcfx_screen_ref); HIP is never touched here.
@@ -50,10 +53,14 @@ std::vector<int32_t> window_cuts(const int32_t* win_len, int32_t n, int32_t k, i
     return cuts;
 }
 
+struct Segment {
+    int32_t sample;                   // the sample screened ...
+    int32_t w_lo, w_hi;               // ... against this window range
+};
+
 struct Worker {
     int32_t device = 0;
-    std::vector<int32_t> samples;     // the samples this device screens, in order
-    int32_t w_lo = 0, w_hi = 0;       // its window range
+    std::vector<Segment> segs;        // what this device screens, in order
     // outcome
     int32_t rc = KCFX_OK;
     std::string error;
@@ -91,7 +98,7 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
         ((int64_t)n_samples * n_windows > 0 && !out))
         return fail(KCFX_ERR_ARG, "null argument");
     if (min_kmer_count < 1) return fail(KCFX_ERR_ARG, "Minimum kmer count should be at least 1");   // GetVariants.java:383-385
-    if (shard_mode < KCFX_SHARD_AUTO || shard_mode > KCFX_SHARD_WINDOWS) return fail(KCFX_ERR_ARG, "unknown shard mode");
+    if (shard_mode < KCFX_SHARD_AUTO || shard_mode > KCFX_SHARD_GRID) return fail(KCFX_ERR_ARG, "unknown shard mode");
     for (int32_t s = 0; s < n_samples; ++s)
         if (!kmc_prefixes[s]) return fail(KCFX_ERR_ARG, "null database prefix");
     for (int32_t w = 0; w < n_windows; ++w)
@@ -100,7 +107,8 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
     const double t0 = now_s();
     const int32_t G = (int32_t)ctx->devices.size();
     int32_t mode = shard_mode;
-    if (mode == KCFX_SHARD_AUTO) mode = (n_samples >= G || n_windows == 0) ? KCFX_SHARD_SAMPLES : KCFX_SHARD_WINDOWS;
+    if (mode == KCFX_SHARD_AUTO)
+        mode = (n_samples >= G || n_windows == 0) ? KCFX_SHARD_SAMPLES : (n_samples == 1 ? KCFX_SHARD_WINDOWS : KCFX_SHARD_GRID);
     if (stats) {
         memset(stats, 0, sizeof *stats);
         stats->shard_mode_used = mode;
@@ -109,51 +117,99 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
     if (n_samples == 0 || n_windows == 0) return KCFX_OK;
 
     std::vector<Worker> workers((size_t)G);
-    const std::vector<int32_t> cuts = (mode == KCFX_SHARD_WINDOWS) ? window_cuts(win_len, n_windows, kmer_length, G) : std::vector<int32_t>();
-    for (int32_t g = 0; g < G; ++g) {
-        Worker& wk = workers[(size_t)g];
-        wk.device = ctx->devices[(size_t)g];
-        if (mode == KCFX_SHARD_SAMPLES) {
-            for (int32_t s = g; s < n_samples; s += G) wk.samples.push_back(s);
-            wk.w_lo = 0;
-            wk.w_hi = n_windows;
-        } else {
-            for (int32_t s = 0; s < n_samples; ++s) wk.samples.push_back(s);
-            wk.w_lo = cuts[(size_t)g];
-            wk.w_hi = cuts[(size_t)g + 1];
+    for (int32_t g = 0; g < G; ++g) workers[(size_t)g].device = ctx->devices[(size_t)g];
+    if (mode == KCFX_SHARD_SAMPLES) {
+        for (int32_t g = 0; g < G; ++g)
+            for (int32_t s = g; s < n_samples; s += G) workers[(size_t)g].segs.push_back(Segment{s, 0, n_windows});
+    } else if (mode == KCFX_SHARD_WINDOWS) {
+        const std::vector<int32_t> cuts = window_cuts(win_len, n_windows, kmer_length, G);
+        for (int32_t g = 0; g < G; ++g)
+            for (int32_t s = 0; s < n_samples; ++s)
+                if (cuts[(size_t)g + 1] > cuts[(size_t)g]) workers[(size_t)g].segs.push_back(Segment{s, cuts[(size_t)g], cuts[(size_t)g + 1]});
+    } else {
+        // KCFX_SHARD_GRID: the sample-major sequence of (sample, window) units -- S runs of the window list -- is cut into G
+        // contiguous parts of equal k-mer count: a device screens the tail of one sample's windows and the head of the next
+        // one's, so it opens at most ceil(S / G) + 1 databases (2 when S < G) where KCFX_SHARD_WINDOWS opens all S on every
+        // device, and the parts are as even as a single sample's window cuts
+        const std::vector<int32_t> cuts = window_cuts(win_len, n_windows, kmer_length, G * 1);
+        // cut positions in units of k-mers over S repetitions: part g = [g, g + 1) * S / G of the S-fold sequence
+        std::vector<int64_t> cum((size_t)n_windows + 1, 0);
+        for (int32_t i = 0; i < n_windows; ++i) cum[(size_t)i + 1] = cum[(size_t)i] + std::max<int64_t>(0, (int64_t)win_len[i] - kmer_length + 1);
+        const int64_t per_sample = cum[(size_t)n_windows];
+        (void)cuts;
+        auto locate = [&](int64_t pos, int32_t& samp, int32_t& w) {      // position in the S-fold k-mer sequence -> (sample, first window at or after it)
+            if (per_sample <= 0) {
+                samp = n_samples;
+                w = 0;
+                return;
+            }
+            samp = (int32_t)std::min<int64_t>(pos / per_sample, n_samples);
+            const int64_t r = pos - (int64_t)samp * per_sample;
+            w = samp >= n_samples ? 0 : (int32_t)(std::lower_bound(cum.begin(), cum.end(), r) - cum.begin());
+            if (w > n_windows) w = n_windows;
+        };
+        const int64_t total = per_sample * n_samples;
+        int32_t ps = 0, pw = 0;                                           // where the previous part ended
+        for (int32_t g = 0; g < G; ++g) {
+            int32_t es = n_samples, ew = 0;
+            if (g + 1 < G) locate(total * (g + 1) / G, es, ew);
+            if (per_sample <= 0) {                                        // no k-mers at all: device 0 takes everything
+                if (g == 0)
+                    for (int32_t s2 = 0; s2 < n_samples; ++s2) workers[0].segs.push_back(Segment{s2, 0, n_windows});
+                continue;
+            }
+            // from (ps, pw) up to (es, ew)
+            for (int32_t s2 = ps; s2 <= es && s2 < n_samples; ++s2) {
+                const int32_t lo = (s2 == ps) ? pw : 0, hi = (s2 == es) ? ew : n_windows;
+                if (hi > lo) workers[(size_t)g].segs.push_back(Segment{s2, lo, hi});
+            }
+            ps = es;
+            pw = ew;
         }
     }
 
     // (a worker never lets an exception escape its thread: it becomes the worker's status)
     auto run_body = [&](Worker& wk) {
-        const int32_t nw = wk.w_hi - wk.w_lo;
-        if (wk.samples.empty() || nw <= 0) return;
+        if (wk.segs.empty()) return;
         auto failed = [&](int32_t rc) {
             wk.rc = rc;
             wk.error = kcfx_last_error();
         };
-        // the text this window range covers (all of it when the whole list is screened here)
-        int64_t t_lo = text_len, t_hi = 0;
-        for (int32_t w = wk.w_lo; w < wk.w_hi; ++w) {
-            t_lo = std::min(t_lo, win_begin[w]);
-            t_hi = std::max(t_hi, win_begin[w] + (int64_t)win_len[w]);
-        }
-        if (t_hi < t_lo) t_lo = t_hi = 0;
-        std::vector<int64_t> wb((size_t)nw);
-        for (int32_t i = 0; i < nw; ++i) wb[(size_t)i] = win_begin[wk.w_lo + i] - t_lo;
-        double t = now_s();
+        // the resident reference of a window range: the text that range covers (all of it when the whole list is screened here);
+        // consecutive segments of one range (the sample-sharded and window-sharded modes) share it
         struct RefHold {                                 // destroyed on every exit path
             kcfx_ref* p = nullptr;
+            int32_t lo = -1, hi = -1;
             ~RefHold() { kcfx_ref_destroy(p); }
         } ref_hold;
-        if (int32_t rc = kcfx_ref_create(wk.device, kmer_length, text + t_lo, t_hi - t_lo, wb.data(), win_len + wk.w_lo, nw, &ref_hold.p)) {
-            failed(rc);
-            return;
-        }
-        kcfx_ref* const ref = ref_hold.p;
-        wk.t_ref = now_s() - t;
-
-        // loader thread: opens the databases in order, at most one ahead of the one being screened
+        auto ref_for = [&](int32_t lo, int32_t hi) -> int32_t {
+            if (ref_hold.p && ref_hold.lo == lo && ref_hold.hi == hi) return KCFX_OK;
+            kcfx_ref_destroy(ref_hold.p);
+            ref_hold.p = nullptr;
+            const int32_t nw = hi - lo;
+            int64_t t_lo = text_len, t_hi = 0;
+            for (int32_t w = lo; w < hi; ++w) {
+                t_lo = std::min(t_lo, win_begin[w]);
+                t_hi = std::max(t_hi, win_begin[w] + (int64_t)win_len[w]);
+            }
+            if (t_hi < t_lo) t_lo = t_hi = 0;
+            std::vector<int64_t> wb((size_t)nw);
+            for (int32_t i = 0; i < nw; ++i) wb[(size_t)i] = win_begin[lo + i] - t_lo;
+            const double t = now_s();
+            const int32_t rc = kcfx_ref_create(wk.device, kmer_length, text + t_lo, t_hi - t_lo, wb.data(), win_len + lo, nw, &ref_hold.p);
+            wk.t_ref += now_s() - t;
+            ref_hold.lo = lo;
+            ref_hold.hi = hi;
+            return rc;
+        };
+        // k-mer look-ups a segment's database will serve: one pass over its window range (sizes the table, kcfx_db_opts)
+        auto seg_queries = [&](const Segment& sg) {
+            int64_t q = 0;
+            for (int32_t w = sg.w_lo; w < sg.w_hi; ++w) q += std::max<int64_t>(0, (int64_t)win_len[w] - kmer_length + 1);
+            return std::max<int64_t>(1, q);
+        };
+        // consecutive segments of the same sample (none in the modes above, but harmless) would reuse the handle; the loader opens
+        // one database per segment, in order, at most one ahead of the one being screened
         std::mutex mu;
         std::condition_variable cv;
         std::deque<kcfx_db*> ready;
@@ -163,7 +219,7 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
         std::string load_error;
         std::thread loader([&]() {
             try {
-            for (size_t i = 0; i < wk.samples.size(); ++i) {
+            for (size_t i = 0; i < wk.segs.size(); ++i) {
                 {
                     std::unique_lock<std::mutex> lk(mu);
                     cv.wait(lk, [&] { return stop || ready.size() < 1; });
@@ -171,23 +227,24 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
                 }
                 const double t1 = now_s();
                 kcfx_db* db = nullptr;
-                // one pass of this worker's window range per database (GetVariants.java:129-159): the table is sized for that.
+                // one pass of this segment's window range per database (GetVariants.java:129-159): the table is sized for that.
                 // First without the line-table fallback: a cell table that does not fit NEXT TO the database being screened
                 // (two wheat-scale tables do not always fit) is worth waiting for -- the line table screens at ~0.55x the
                 // speed and its odd size defeats the block pool. Only a database that does not fit an otherwise empty
                 // device falls back.
                 kcfx_db_opts opts;
-                opts.expected_queries = std::max<int64_t>(1, kcfx_ref_n_kmer_slots(ref));
+                opts.expected_queries = seg_queries(wk.segs[i]);
                 opts.no_fallback = 1;
                 opts.reserved = 0;
-                int32_t rc = kcfx_db_open_opts(kmc_prefixes[wk.samples[i]], wk.device, &opts, &db);
+                const char* prefix = kmc_prefixes[wk.segs[i].sample];
+                int32_t rc = kcfx_db_open_opts(prefix, wk.device, &opts, &db);
                 if (rc == KCFX_ERR_DEVICE) {
                     std::unique_lock<std::mutex> lk(mu);
                     cv.wait(lk, [&] { return stop || (in_use == 0 && ready.empty()); });
                     if (!stop) {
                         lk.unlock();
                         opts.no_fallback = 0;
-                        rc = kcfx_db_open_opts(kmc_prefixes[wk.samples[i]], wk.device, &opts, &db);
+                        rc = kcfx_db_open_opts(prefix, wk.device, &opts, &db);
                     }
                 }
                 std::lock_guard<std::mutex> lk(mu);
@@ -227,7 +284,12 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
                 for (kcfx_db* db : ready) kcfx_db_close(db);
             }
         } joiner{loader, mu, cv, stop, ready};
-        for (size_t i = 0; i < wk.samples.size() && wk.rc == KCFX_OK; ++i) {
+        for (size_t i = 0; i < wk.segs.size() && wk.rc == KCFX_OK; ++i) {
+            const Segment& sg = wk.segs[i];
+            if (int32_t rc = ref_for(sg.w_lo, sg.w_hi)) {      // (beside the loader's first open)
+                failed(rc);
+                break;
+            }
             kcfx_db* db = nullptr;
             {
                 const double t1 = now_s();
@@ -250,7 +312,7 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
             if (info.kmer_length != kmer_length) {
                 wk.rc = KCFX_ERR_ARG;
                 wk.error = "Kmer size mismatch between the KMC databases";          // KCFHeader.equals (Cohort.java:71-119)
-            } else if (int32_t rc = kcfx_screen_ref(db, ref, min_kmer_count, out + (size_t)wk.samples[i] * n_windows + wk.w_lo)) {
+            } else if (int32_t rc = kcfx_screen_ref(db, ref_hold.p, min_kmer_count, out + (size_t)sg.sample * n_windows + sg.w_lo)) {
                 failed(rc);
             }
             wk.t_screen += now_s() - t1;

@@ -54,7 +54,7 @@ class ShardStats(C.Structure):
                 ("seconds_exposed_load", C.c_double)]
 
 
-SHARD_AUTO, SHARD_SAMPLES, SHARD_WINDOWS = 0, 1, 2
+SHARD_AUTO, SHARD_SAMPLES, SHARD_WINDOWS, SHARD_GRID = 0, 1, 2, 3
 
 
 class DbOpts(C.Structure):

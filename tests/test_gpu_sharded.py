@@ -30,14 +30,16 @@ def job(tmp_path_factory):
 
 
 @pytest.mark.parametrize("devices,mode", [((0, 0), engine.SHARD_SAMPLES), ((0, 0), engine.SHARD_WINDOWS), ((0, 0, 0), engine.SHARD_WINDOWS),
-                                          ((0,), engine.SHARD_AUTO), ((0, 0), engine.SHARD_AUTO), ((0,) * 7, engine.SHARD_AUTO)])
+                                          ((0,), engine.SHARD_AUTO), ((0, 0), engine.SHARD_AUTO), ((0,) * 7, engine.SHARD_AUTO),
+                                          ((0, 0, 0), engine.SHARD_GRID), ((0,) * 8, engine.SHARD_GRID), ((0,) * 11, engine.SHARD_GRID)])
 def test_sharded_equals_unsharded(oracle, job, devices, mode):
     k, ref, prefixes, begins, lens, want = job
     got, st = engine.screen_sharded(prefixes, k, ref, begins, lens, 1, devices=devices, mode=mode)
     assert got.shape == want.shape
     for i in range(len(prefixes)):
         assert_same(got[i], want[i], f"sample {i}, devices {devices}, mode {mode}")
-    auto = engine.SHARD_SAMPLES if len(prefixes) >= len(devices) else engine.SHARD_WINDOWS
+    # five samples: on 7 devices the automatic choice is the samples x windows grid (a device opens two databases, not five)
+    auto = engine.SHARD_SAMPLES if len(prefixes) >= len(devices) else engine.SHARD_GRID
     assert st.shard_mode_used == (mode or auto) and st.n_devices == len(devices)
     assert st.seconds_total > 0 and st.seconds_screen_sum > 0 and st.seconds_db_open_sum > 0
     # one sample against the oracle, to anchor the comparison
@@ -46,6 +48,13 @@ def test_sharded_equals_unsharded(oracle, job, devices, mode):
 
 def test_sharded_edge_cases_and_errors(job, tmp_path):
     k, ref, prefixes, begins, lens, want = job
+    # one sample on several devices: the automatic choice is the window-sharded mode
+    _, st1 = engine.screen_sharded(prefixes[:1], k, ref, begins, lens, 1, devices=(0, 0, 0))
+    assert st1.shard_mode_used == engine.SHARD_WINDOWS
+    # the grid with fewer window-samples than devices, and with windows that hold no k-mer at a cut
+    got, _ = engine.screen_sharded(prefixes[:3], k, ref, begins[-3:], lens[-3:], 1, devices=(0,) * 12, mode=engine.SHARD_GRID)
+    for i in range(3):
+        assert_same(got[i], want[i][-3:], "grid: 3 short windows x 3 samples on 12 shards")
     # fewer windows than devices, -c 2, no samples, no windows
     got, _ = engine.screen_sharded(prefixes[:1], k, ref, begins[:2], lens[:2], 1, devices=(0, 0, 0, 0), mode=engine.SHARD_WINDOWS)
     assert_same(got[0], want[0][:2], "2 windows on 4 shards")

@@ -12,6 +12,7 @@ import shutil
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+COHORT = "--cohort" in sys.argv          # a tools/profile_cohort.sh run: summary only, profiles/traffic.json stays the single-sample one
 src = f"gpurun_out/{tag}"
 os.makedirs("profiles", exist_ok=True)
 # the dominant kernel of the bench workload, as the bench line names it (screen_k31c_kernel on a cell table)
@@ -57,11 +58,12 @@ if fetch.get("FETCH_SIZE") is not None:
     out["hbm_read_bytes_per_launch"] = rd
     out["hbm_write_bytes_per_launch"] = wr
     cfg = bench["config"]
-    json.dump({"tag": tag, "kernel": KERNEL, "hbm_bytes_per_launch": rd + wr,
-               "rocprof_kernel_avg_ms": out.get("rocprof_kernel_avg_ms"),
-               "ref_len": 30427671, "db_kmers": 150000000, "window": 10000,
-               "note": "2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes), separate --pmc passes, averaged over launches"},
-              open("profiles/traffic.json", "w"), indent=1)
+    if not COHORT:
+        json.dump({"tag": tag, "kernel": KERNEL, "hbm_bytes_per_launch": rd + wr,
+                   "rocprof_kernel_avg_ms": out.get("rocprof_kernel_avg_ms"),
+                   "ref_len": 30427671, "db_kmers": 150000000, "window": 10000,
+                   "note": "2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes), separate --pmc passes, averaged over launches"},
+                  open("profiles/traffic.json", "w"), indent=1)
     kms = bench["roofline"]["kernel_avg_ms"]
     out["hbm_GBps_during_kernel"] = (rd + wr) / (kms * 1e-3) / 1e9
     out["algorithmic_bytes_per_launch"] = cfg["kmers_per_step_per_gpu"] * bench["roofline"]["algorithmic_bytes_per_kmer"]
