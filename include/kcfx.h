@@ -252,6 +252,14 @@ typedef struct {
                                      ran under the previous sample's screening) */
 } kcfx_shard_stats;
 
+/* The partitioning kcfx_screen_sharded would use, without touching a GPU: segment i = device seg_device[i] (index into the
+ * context's device list) screens sample seg_sample[i] against windows [seg_w_lo[i], seg_w_hi[i]); segments of one device are in
+ * execution order. Up to `cap` segments are written, *n_segments = how many there are; *mode_used = what KCFX_SHARD_AUTO chose.
+ * Every (sample, window) pair lies in exactly one segment. Output arrays may be NULL. */
+int32_t kcfx_shard_plan(int32_t shard_mode, int32_t n_devices, int32_t n_samples, const int32_t* win_len, int32_t n_windows,
+                        int32_t kmer_length, int32_t* seg_device, int32_t* seg_sample, int32_t* seg_w_lo, int32_t* seg_w_hi,
+                        int64_t cap, int64_t* n_segments, int32_t* mode_used);
+
 /* getVariations for n_samples databases against one reference, on every device of `ctx`: what the reference does as one
  * process per sample (run_kcftools.sh:124-140), each fanning its windows over a thread pool (GetVariants.java:129-151).
  * out[s * n_windows + w] (host) = sample s (input order), window w -- each slice equals kcfx_screen_ref on that sample.

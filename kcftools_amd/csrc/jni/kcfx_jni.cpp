@@ -28,6 +28,22 @@ JNIEXPORT jlong JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_dbOpen(JNIEnv* env,
     return reinterpret_cast<jlong>(db);
 }
 
+// long dbOpenFor(String kmcPrefix, int device, long expectedQueries): the same, the table sized for the look-ups the handle will
+// serve (kcfx_db_open_opts) -- getVariations makes ONE pass over its windows per database (GetVariants.java:129-159)
+JNIEXPORT jlong JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_dbOpenFor(JNIEnv* env, jclass, jstring prefix, jint device, jlong expectedQueries) {
+    if (!prefix) { throw_kcfx(env, KCFX_ERR_ARG); return 0; }
+    const char* p = env->GetStringUTFChars(prefix, nullptr);
+    kcfx_db* db = nullptr;
+    kcfx_db_opts opts;
+    opts.expected_queries = expectedQueries;
+    opts.no_fallback = 0;
+    opts.reserved = 0;
+    const int32_t rc = kcfx_db_open_opts(p, device, &opts, &db);
+    env->ReleaseStringUTFChars(prefix, p);
+    if (rc) { throw_kcfx(env, rc); return 0; }
+    return reinterpret_cast<jlong>(db);
+}
+
 // int[] dbInfo(long db): {k, mode, counterSize, lutPrefixLength, signatureLength, minCount, maxCount, bothStrands}
 JNIEXPORT jintArray JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_dbInfo(JNIEnv* env, jclass, jlong db) {
     kcfx_db_info_t info;
@@ -123,6 +139,47 @@ JNIEXPORT void JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_screenRefMulti(JNIEn
     const int32_t rc = kcfx_screen_ref_multi(reinterpret_cast<kcfx_db* const*>(h), s, r, minKmerCount, out);
     env->ReleaseLongArrayElements(dbs, h, JNI_ABORT);
     if (rc) throw_kcfx(env, rc);
+}
+
+// long cohortOpen(String[] kmcPrefixes, int device, long expectedQueries) / void cohortClose(long cohort)
+// up to 8 samples in ONE table with a counter per sample and cell (kcfx_cohort_open): what S getVariations runs + cohort do
+// (run_kcftools.sh:124-160, Cohort.java:71-119), located once per reference k-mer
+JNIEXPORT jlong JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_cohortOpen(JNIEnv* env, jclass, jobjectArray prefixes, jint device, jlong expectedQueries) {
+    if (!prefixes) { throw_kcfx(env, KCFX_ERR_ARG); return 0; }
+    const jsize s = env->GetArrayLength(prefixes);
+    for (jsize i = 0; i < s; ++i)
+        if (!env->GetObjectArrayElement(prefixes, i)) { throw_kcfx(env, KCFX_ERR_ARG); return 0; }
+    const char** names = new const char*[s > 0 ? s : 1];
+    for (jsize i = 0; i < s; ++i) names[i] = env->GetStringUTFChars(static_cast<jstring>(env->GetObjectArrayElement(prefixes, i)), nullptr);
+    kcfx_db_opts opts;
+    opts.expected_queries = expectedQueries;
+    opts.no_fallback = 0;
+    opts.reserved = 0;
+    kcfx_cohort* co = nullptr;
+    const int32_t rc = kcfx_cohort_open(names, s, device, &opts, &co);
+    for (jsize i = 0; i < s; ++i) env->ReleaseStringUTFChars(static_cast<jstring>(env->GetObjectArrayElement(prefixes, i)), names[i]);
+    delete[] names;
+    if (rc) { throw_kcfx(env, rc); return 0; }
+    return reinterpret_cast<jlong>(co);
+}
+JNIEXPORT void JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_cohortClose(JNIEnv*, jclass, jlong cohort) {
+    kcfx_cohort_close(reinterpret_cast<kcfx_cohort*>(cohort));
+}
+// void cohortScreenRef(long cohort, long ref, int minKmerCount, ByteBuffer results): results = samples * nWindows * 40 bytes, sample-major
+JNIEXPORT void JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_cohortScreenRef(JNIEnv* env, jclass, jlong cohort, jlong ref, jint minKmerCount,
+                                                                             jobject results) {
+    auto* co = reinterpret_cast<kcfx_cohort*>(cohort);
+    auto* r = reinterpret_cast<kcfx_ref*>(ref);
+    kcfx_cohort_info_t info;
+    if (int32_t rc = kcfx_cohort_info(co, &info)) { throw_kcfx(env, rc); return; }
+    auto* out = static_cast<kcfx_result*>(env->GetDirectBufferAddress(results));
+    const jlong need = (jlong)info.n_samples * (jlong)kcfx_ref_n_windows(r) * (jlong)sizeof(kcfx_result);
+    if (!out || env->GetDirectBufferCapacity(results) < need) {
+        jclass cls = env->FindClass("java/lang/IllegalArgumentException");
+        if (cls) env->ThrowNew(cls, "results must be a direct buffer of samples * nWindows * 40 bytes");
+        return;
+    }
+    if (int32_t rc = kcfx_cohort_screen_ref(co, r, minKmerCount, out)) throw_kcfx(env, rc);
 }
 
 // int[] dbHeader(String kmcPrefix): the dbInfo fields from the header alone, no GPU (KMC.java:107-168; GetVariants.java:96,103)

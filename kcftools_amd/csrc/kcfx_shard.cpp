@@ -67,6 +67,64 @@ struct Worker {
     double t_ref = 0, t_open = 0, t_screen = 0, t_wait = 0;
 };
 
+// Who screens what: plan[g] = the (sample, window range) segments of device g, in order. Pure host arithmetic (also behind
+// kcfx_shard_plan, which the CPU tests drive): every (sample, window) pair lies in exactly one segment.
+std::vector<std::vector<Segment>> plan_segments(int32_t mode, int32_t G, int32_t n_samples, const int32_t* win_len, int32_t n_windows,
+                                                int32_t kmer_length) {
+    std::vector<std::vector<Segment>> plan((size_t)G);
+    if (mode == KCFX_SHARD_SAMPLES) {
+        for (int32_t g = 0; g < G; ++g)
+            for (int32_t s = g; s < n_samples; s += G) plan[(size_t)g].push_back(Segment{s, 0, n_windows});
+    } else if (mode == KCFX_SHARD_WINDOWS) {
+        const std::vector<int32_t> cuts = window_cuts(win_len, n_windows, kmer_length, G);
+        for (int32_t g = 0; g < G; ++g)
+            for (int32_t s = 0; s < n_samples; ++s)
+                if (cuts[(size_t)g + 1] > cuts[(size_t)g]) plan[(size_t)g].push_back(Segment{s, cuts[(size_t)g], cuts[(size_t)g + 1]});
+    } else {
+        // KCFX_SHARD_GRID: the sample-major sequence of (sample, window) units -- S runs of the window list -- is cut into G
+        // contiguous parts of equal k-mer count: a device screens the tail of one sample's windows and the head of the next
+        // one's, so it opens at most ceil(S / G) + 1 databases (2 when S < G) where KCFX_SHARD_WINDOWS opens all S on every
+        // device, and the parts are as even as a single sample's window cuts
+        const std::vector<int32_t> cuts = window_cuts(win_len, n_windows, kmer_length, G * 1);
+        // cut positions in units of k-mers over S repetitions: part g = [g, g + 1) * S / G of the S-fold sequence
+        std::vector<int64_t> cum((size_t)n_windows + 1, 0);
+        for (int32_t i = 0; i < n_windows; ++i) cum[(size_t)i + 1] = cum[(size_t)i] + std::max<int64_t>(0, (int64_t)win_len[i] - kmer_length + 1);
+        const int64_t per_sample = cum[(size_t)n_windows];
+        (void)cuts;
+        auto locate = [&](int64_t pos, int32_t& samp, int32_t& w) {      // position in the S-fold k-mer sequence -> (sample, first window at or after it)
+            if (per_sample <= 0) {
+                samp = n_samples;
+                w = 0;
+                return;
+            }
+            samp = (int32_t)std::min<int64_t>(pos / per_sample, n_samples);
+            const int64_t r = pos - (int64_t)samp * per_sample;
+            w = samp >= n_samples ? 0 : (int32_t)(std::lower_bound(cum.begin(), cum.end(), r) - cum.begin());
+            if (w > n_windows) w = n_windows;
+        };
+        const int64_t total = per_sample * n_samples;
+        int32_t ps = 0, pw = 0;                                           // where the previous part ended
+        for (int32_t g = 0; g < G; ++g) {
+            int32_t es = n_samples, ew = 0;
+            if (g + 1 < G) locate(total * (g + 1) / G, es, ew);
+            if (per_sample <= 0) {                                        // no k-mers at all: device 0 takes everything
+                if (g == 0)
+                    for (int32_t s2 = 0; s2 < n_samples; ++s2) plan[0].push_back(Segment{s2, 0, n_windows});
+                continue;
+            }
+            // from (ps, pw) up to (es, ew)
+            for (int32_t s2 = ps; s2 <= es && s2 < n_samples; ++s2) {
+                const int32_t lo = (s2 == ps) ? pw : 0, hi = (s2 == es) ? ew : n_windows;
+                if (hi > lo) plan[(size_t)g].push_back(Segment{s2, lo, hi});
+            }
+            ps = es;
+            pw = ew;
+        }
+    }
+
+    return plan;
+}
+
 }  // namespace
 
 extern "C" {
@@ -86,6 +144,34 @@ int32_t kcfx_ctx_create(const int32_t* devices, int32_t n_devices, kcfx_ctx** ou
 } catch (...) { return kcfx::exception_to_status("kcfx_ctx_create"); }
 
 int32_t kcfx_ctx_n_devices(const kcfx_ctx* ctx) { return ctx ? (int32_t)ctx->devices.size() : 0; }
+
+int32_t kcfx_shard_plan(int32_t shard_mode, int32_t n_devices, int32_t n_samples, const int32_t* win_len, int32_t n_windows,
+                        int32_t kmer_length, int32_t* seg_device, int32_t* seg_sample, int32_t* seg_w_lo, int32_t* seg_w_hi,
+                        int64_t cap, int64_t* n_segments, int32_t* mode_used) try {
+    if (n_devices < 1 || n_samples < 0 || n_windows < 0 || kmer_length < 1 || !n_segments || (n_windows > 0 && !win_len))
+        return fail(KCFX_ERR_ARG, "kcfx_shard_plan: bad argument");
+    if (shard_mode < KCFX_SHARD_AUTO || shard_mode > KCFX_SHARD_GRID) return fail(KCFX_ERR_ARG, "unknown shard mode");
+    int32_t mode = shard_mode;
+    if (mode == KCFX_SHARD_AUTO)
+        mode = (n_samples >= n_devices || n_windows == 0) ? KCFX_SHARD_SAMPLES : (n_samples == 1 ? KCFX_SHARD_WINDOWS : KCFX_SHARD_GRID);
+    if (mode_used) *mode_used = mode;
+    int64_t n = 0;
+    if (n_samples > 0 && n_windows > 0) {
+        const std::vector<std::vector<Segment>> plan = plan_segments(mode, n_devices, n_samples, win_len, n_windows, kmer_length);
+        for (int32_t g = 0; g < n_devices; ++g)
+            for (const Segment& sg : plan[(size_t)g]) {
+                if (n < cap) {
+                    if (seg_device) seg_device[n] = g;
+                    if (seg_sample) seg_sample[n] = sg.sample;
+                    if (seg_w_lo) seg_w_lo[n] = sg.w_lo;
+                    if (seg_w_hi) seg_w_hi[n] = sg.w_hi;
+                }
+                ++n;
+            }
+    }
+    *n_segments = n;
+    return KCFX_OK;
+} catch (...) { return kcfx::exception_to_status("kcfx_shard_plan"); }
 
 void kcfx_ctx_destroy(kcfx_ctx* ctx) { delete ctx; }
 
@@ -117,54 +203,11 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
     if (n_samples == 0 || n_windows == 0) return KCFX_OK;
 
     std::vector<Worker> workers((size_t)G);
-    for (int32_t g = 0; g < G; ++g) workers[(size_t)g].device = ctx->devices[(size_t)g];
-    if (mode == KCFX_SHARD_SAMPLES) {
-        for (int32_t g = 0; g < G; ++g)
-            for (int32_t s = g; s < n_samples; s += G) workers[(size_t)g].segs.push_back(Segment{s, 0, n_windows});
-    } else if (mode == KCFX_SHARD_WINDOWS) {
-        const std::vector<int32_t> cuts = window_cuts(win_len, n_windows, kmer_length, G);
-        for (int32_t g = 0; g < G; ++g)
-            for (int32_t s = 0; s < n_samples; ++s)
-                if (cuts[(size_t)g + 1] > cuts[(size_t)g]) workers[(size_t)g].segs.push_back(Segment{s, cuts[(size_t)g], cuts[(size_t)g + 1]});
-    } else {
-        // KCFX_SHARD_GRID: the sample-major sequence of (sample, window) units -- S runs of the window list -- is cut into G
-        // contiguous parts of equal k-mer count: a device screens the tail of one sample's windows and the head of the next
-        // one's, so it opens at most ceil(S / G) + 1 databases (2 when S < G) where KCFX_SHARD_WINDOWS opens all S on every
-        // device, and the parts are as even as a single sample's window cuts
-        const std::vector<int32_t> cuts = window_cuts(win_len, n_windows, kmer_length, G * 1);
-        // cut positions in units of k-mers over S repetitions: part g = [g, g + 1) * S / G of the S-fold sequence
-        std::vector<int64_t> cum((size_t)n_windows + 1, 0);
-        for (int32_t i = 0; i < n_windows; ++i) cum[(size_t)i + 1] = cum[(size_t)i] + std::max<int64_t>(0, (int64_t)win_len[i] - kmer_length + 1);
-        const int64_t per_sample = cum[(size_t)n_windows];
-        (void)cuts;
-        auto locate = [&](int64_t pos, int32_t& samp, int32_t& w) {      // position in the S-fold k-mer sequence -> (sample, first window at or after it)
-            if (per_sample <= 0) {
-                samp = n_samples;
-                w = 0;
-                return;
-            }
-            samp = (int32_t)std::min<int64_t>(pos / per_sample, n_samples);
-            const int64_t r = pos - (int64_t)samp * per_sample;
-            w = samp >= n_samples ? 0 : (int32_t)(std::lower_bound(cum.begin(), cum.end(), r) - cum.begin());
-            if (w > n_windows) w = n_windows;
-        };
-        const int64_t total = per_sample * n_samples;
-        int32_t ps = 0, pw = 0;                                           // where the previous part ended
+    {
+        std::vector<std::vector<Segment>> plan = plan_segments(mode, G, n_samples, win_len, n_windows, kmer_length);
         for (int32_t g = 0; g < G; ++g) {
-            int32_t es = n_samples, ew = 0;
-            if (g + 1 < G) locate(total * (g + 1) / G, es, ew);
-            if (per_sample <= 0) {                                        // no k-mers at all: device 0 takes everything
-                if (g == 0)
-                    for (int32_t s2 = 0; s2 < n_samples; ++s2) workers[0].segs.push_back(Segment{s2, 0, n_windows});
-                continue;
-            }
-            // from (ps, pw) up to (es, ew)
-            for (int32_t s2 = ps; s2 <= es && s2 < n_samples; ++s2) {
-                const int32_t lo = (s2 == ps) ? pw : 0, hi = (s2 == es) ? ew : n_windows;
-                if (hi > lo) workers[(size_t)g].segs.push_back(Segment{s2, lo, hi});
-            }
-            ps = es;
-            pw = ew;
+            workers[(size_t)g].device = ctx->devices[(size_t)g];
+            workers[(size_t)g].segs = std::move(plan[(size_t)g]);
         }
     }
 

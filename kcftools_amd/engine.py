@@ -29,7 +29,7 @@ ABI_SYMBOLS = (
     "kcfx_screen_ref", "kcfx_screen_ref_async", "kcfx_screen_ref_multi", "kcfx_screen_ref_multi_async", "kcfx_screen",
     "kcfx_ref_reserve_multi",
     "kcfx_cohort_open", "kcfx_cohort_info", "kcfx_cohort_close", "kcfx_cohort_screen_ref", "kcfx_cohort_screen_ref_async",
-    "kcfx_ctx_create", "kcfx_ctx_n_devices", "kcfx_ctx_destroy", "kcfx_screen_sharded",
+    "kcfx_ctx_create", "kcfx_ctx_n_devices", "kcfx_ctx_destroy", "kcfx_screen_sharded", "kcfx_shard_plan",
     "kcfx_score", "kcfx_windows",
     "kcfx_prof_enable", "kcfx_prof_read", "kcfx_last_error", "kcfx_device_count", "kcfx_version",
 )
@@ -121,6 +121,7 @@ def lib() -> C.CDLL:
         L.kcfx_ctx_destroy.argtypes = [vp]
         L.kcfx_ctx_destroy.restype = None
         L.kcfx_screen_sharded.argtypes = [vp, vp, i32, i32, vp, i64, vp, vp, i32, i32, i32, vp, C.POINTER(ShardStats)]
+        L.kcfx_shard_plan.argtypes = [i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, i64, C.POINTER(i64), C.POINTER(i32)]
         L.kcfx_db_lookup.argtypes = [vp, vp, i64, vp]
         L.kcfx_db_close.argtypes = [vp]
         L.kcfx_db_close.restype = None
@@ -172,6 +173,18 @@ def db_header(kmc_prefix: str) -> DbInfo:
     info = DbInfo()
     _check(lib().kcfx_db_header(os.fsencode(kmc_prefix), C.byref(info)))
     return info
+
+
+def shard_plan(win_len, k: int, n_samples: int, n_devices: int, mode: int = SHARD_AUTO):
+    """kcfx_shard_plan (host only): list of (device index, sample, w_lo, w_hi) segments and the mode used."""
+    wl = np.ascontiguousarray(win_len, dtype=np.int32)
+    n, used = C.c_int64(0), C.c_int32(0)
+    _check(lib().kcfx_shard_plan(mode, n_devices, n_samples, wl.ctypes.data if len(wl) else None, len(wl), k, None, None, None, None, 0,
+                                 C.byref(n), C.byref(used)))
+    arr = [np.zeros(max(n.value, 1), dtype=np.int32) for _ in range(4)]
+    _check(lib().kcfx_shard_plan(mode, n_devices, n_samples, wl.ctypes.data if len(wl) else None, len(wl), k, arr[0].ctypes.data,
+                                 arr[1].ctypes.data, arr[2].ctypes.data, arr[3].ctypes.data, n.value, C.byref(n), C.byref(used)))
+    return [tuple(int(a[i]) for a in arr) for i in range(n.value)], used.value
 
 
 def screen_sharded(kmc_prefixes, k: int, text: bytes, win_begin, win_len, min_count: int = 1, devices=(0,),

@@ -1,0 +1,61 @@
+"""kcfx_shard_plan: the partitioning of kcfx_screen_sharded, host arithmetic only (no GPU). Every (sample, window) pair lies in
+exactly one segment whatever the mode, the devices' k-mer loads are even where the mode promises it, and the samples x windows
+grid (1 < S < G) makes a device open at most two databases where the window-sharded mode opens all S on every device."""
+import numpy as np
+from hypothesis import given, settings, strategies as st
+
+from kcftools_amd import engine
+
+K = 31
+
+
+def coverage(plan, S, W):
+    seen = np.zeros((S, W), dtype=np.int32)
+    for dev, s, lo, hi in plan:
+        assert 0 <= s < S and 0 <= lo < hi <= W, (dev, s, lo, hi)
+        seen[s, lo:hi] += 1
+    return seen
+
+
+@settings(max_examples=150, deadline=None)
+@given(st.integers(1, 12), st.integers(1, 9), st.lists(st.integers(0, 400), min_size=1, max_size=60),
+       st.sampled_from([engine.SHARD_AUTO, engine.SHARD_SAMPLES, engine.SHARD_WINDOWS, engine.SHARD_GRID]))
+def test_every_window_sample_pair_is_screened_exactly_once(G, S, lens, mode):
+    wl = np.array(lens, dtype=np.int32)
+    plan, used = engine.shard_plan(wl, K, S, G, mode)
+    assert np.all(coverage(plan, S, len(wl)) == 1)
+    assert all(0 <= dev < G for dev, *_ in plan)
+    if mode == engine.SHARD_AUTO:
+        assert used == (engine.SHARD_SAMPLES if S >= G else engine.SHARD_WINDOWS if S == 1 else engine.SHARD_GRID)
+    else:
+        assert used == mode
+
+
+def test_grid_opens_two_databases_per_device_and_balances_the_kmers():
+    rng = np.random.default_rng(3)
+    wl = rng.integers(31, 60_000, 12_000).astype(np.int32)            # gene-model-like window sizes
+    kmers = np.maximum(0, wl.astype(np.int64) - K + 1)
+    for S, G in ((2, 8), (3, 8), (5, 8), (7, 8), (2, 3)):
+        plan, used = engine.shard_plan(wl, K, S, G)
+        assert used == engine.SHARD_GRID
+        assert np.all(coverage(plan, S, len(wl)) == 1)
+        per_dev_samples = [len({s for d, s, *_ in plan if d == g}) for g in range(G)]
+        assert max(per_dev_samples) <= 2, per_dev_samples               # ... where KCFX_SHARD_WINDOWS opens all S on every device
+        load = np.zeros(G)
+        for d, s, lo, hi in plan:
+            load[d] += kmers[lo:hi].sum()
+        assert load.max() <= 1.02 * load.mean(), load
+        wplan, _ = engine.shard_plan(wl, K, S, G, engine.SHARD_WINDOWS)
+        assert min(len({s for d, s, *_ in wplan if d == g}) for g in range(G)) == S
+
+
+def test_sample_and_window_modes_keep_their_shapes():
+    wl = np.full(1000, 10_000, dtype=np.int32)
+    plan, used = engine.shard_plan(wl, K, 8, 8)
+    assert used == engine.SHARD_SAMPLES and sorted(plan) == [(g, g, 0, 1000) for g in range(8)]
+    plan, used = engine.shard_plan(wl, K, 11, 4)
+    assert used == engine.SHARD_SAMPLES and [s for d, s, *_ in plan if d == 1] == [1, 5, 9]
+    plan, used = engine.shard_plan(wl, K, 1, 4)
+    assert used == engine.SHARD_WINDOWS and [(lo, hi) for _, _, lo, hi in plan] == [(0, 250), (250, 500), (500, 750), (750, 1000)]
+    # nothing to screen: no segments
+    assert engine.shard_plan(wl, K, 0, 4)[0] == [] and engine.shard_plan(np.zeros(0, np.int32), K, 3, 4)[0] == []
