@@ -114,3 +114,46 @@ def test_cohort_async_on_a_torch_stream_and_what_it_refuses(oracle, tmp_path):
         assert err.value.code == 1, bad
     with pytest.raises(engine.KcfxError):
         co.screen(r, 0)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KCFX_FUZZ_SEEDS", "6"))))       # soak: KCFX_FUZZ_SEEDS=200
+def test_cohort_fuzz_against_the_single_sample_path(oracle, tmp_path, monkeypatch, seed):
+    """Random cohorts: 1 .. 8 samples with their own mutation rates, noise and counter widths (one database may appear twice),
+    table sizes from roomy to crowded (2^17 lines: second choices and the stash with its counters carry weight), -c 1 .. 4,
+    windows on the kernel's internal borders, N runs. Every (window, sample) record against the sample's own table; one sample
+    per case against the oracle."""
+    rng = np.random.default_rng(7000 + seed)
+    L = 150_000
+    ref = bytearray(synth.random_reference(L, 800 + seed))
+    for _ in range(12):
+        pos = int(rng.integers(0, L - 3000))
+        n = int(rng.choice([1, 2, 31, 64, 700]))
+        ref[pos:pos + n] = b"N" * n
+    ref = bytes(ref)
+    S = int(rng.integers(1, 9))
+    both = bool(seed % 4)
+    prefixes = [make_sample(tmp_path, f"z{i}", ref, 9000 + 31 * seed + i, cs=int(rng.integers(1, 3)), both=both,
+                            noise=int(rng.choice([500, 20_000, 150_000])), sub_rate=float(rng.choice([0.001, 0.01, 0.03])))
+                for i in range(S)]
+    if S > 2 and seed % 3 == 0:
+        prefixes[-1] = prefixes[0]                          # the same database twice: two identical columns
+    if seed % 2:
+        monkeypatch.setenv("KCFX_TABLE_LBITS", "17" if both else "18")
+    co = engine.Cohort(prefixes)
+    monkeypatch.delenv("KCFX_TABLE_LBITS", raising=False)
+    # window lengths on the borders: k-mer counts 0 / 1 / 63 / 64 / 65, one tile +- 1, several tiles +- 1
+    base = [0, 30, 31, 93, 94, 95, 2047 + 30, 2048 + 30, 2049 + 30, 4096 + 30, 4097 + 30, 10_000, 33_333]
+    wl = np.array([base[int(rng.integers(0, len(base)))] for _ in range(120)], dtype=np.int32)
+    wb = np.array([int(rng.integers(0, L - int(x) + 1)) for x in wl], dtype=np.int64)
+    r = engine.Reference(ref, wb, wl, K)
+    c = int(rng.integers(1, 5))
+    got = co.screen(r, c)
+    for i, pfx in enumerate(prefixes):
+        single = engine.KmcDb.open(pfx).screen(ref, wb, wl, c)
+        for f in FIELDS:
+            bad = np.nonzero(got[i][f] != single[f])[0]
+            assert len(bad) == 0, (seed, i, f, bad[:5], got[i][f][bad[:5]], single[f][bad[:5]])
+    j = int(rng.integers(0, S))
+    want = oracle.OracleDb(prefixes[j]).screen(ref, wb, wl, c, threads=4)
+    for f in FIELDS:
+        assert np.array_equal(got[j][f], want[f]), (seed, j, f)
