@@ -571,4 +571,40 @@ KCFX_HD TileSummary summarize_words(const uint64_t* Vw, const uint64_t* Hw, int 
     return s;
 }
 
+// The same over PW words that are already in registers (reduce_windows_kernel requests a piece's 2 x PW ballot words, its tile
+// descriptor and its count sum in ONE round trip instead of walking memory word by word: the kernel is a chain of dependent
+// loads, not of instructions). Fully unrolled: the arrays are never indexed dynamically.
+template <int PW>
+KCFX_HD TileSummary summarize_piece(const uint64_t (&Vw)[PW], const uint64_t (&Hw)[PW], int n_kmers, int k, int64_t count_sum) {
+    if (n_kmers <= 0) return summary_identity();
+    GapCarry carry{0, 0, false};
+    int32_t n_valid = 0, obs = 0, runs = 0, var_in = 0, inner_in = 0;
+    uint64_t prev_valid = 0, V = 0;
+#pragma unroll
+    for (int w = 0; w < PW; ++w) {
+        if (w * 64 < n_kmers) {
+            V = Vw[w];
+            const uint64_t H = Hw[w] & V;
+            const uint64_t M = V & ~H;
+            n_valid += __builtin_popcountll(V);
+            obs += __builtin_popcountll(H);
+            runs += __builtin_popcountll(V & ~((V << 1) | prev_valid));
+            prev_valid = V >> 63;
+            gap_close_scalar(V, H, M, carry, k, var_in, inner_in);          // GetVariants.java:228-244
+            gap_advance(H, M, carry);
+        }
+    }
+    TileSummary s;
+    s.n = n_valid;
+    s.obs = obs;
+    s.lead = carry.cany ? carry.lead : n_valid;
+    s.trail = carry.cany ? carry.cg : n_valid;
+    s.var_in = var_in;
+    s.inner_in = inner_in;
+    s.runs = runs;
+    s.flags = (carry.cany ? F_ANY : 0u) | ((Vw[0] & 1) ? F_FIRST : 0u) | (((V >> ((n_kmers - 1) & 63)) & 1) ? F_LAST : 0u);
+    s.count_sum = count_sum;
+    return s;
+}
+
 }  // namespace kcfx

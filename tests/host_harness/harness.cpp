@@ -2,6 +2,7 @@
 // (kcfx_device.h): base packing, k-mer extraction, ballot-style gap accounting, monoid combine.
 // TEST INFRASTRUCTURE ONLY: lets the bit logic be checked against the oracle without a GPU. The table probe is
 // replaced by a caller-provided count per position (the test computes it with the oracle).
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -105,6 +106,18 @@ int harness_screen_tile(const uint8_t* text, int64_t text_off, int n_kmers, int 
         Hw[w] = H;
     }
     *out = summarize_words(Vw.data(), Hw.data(), n_kmers, k, sum);
+    // the register-resident form reduce_windows_kernel runs on 4-word pieces must agree with the walking one, piece by piece
+    for (int p0 = 0; p0 * 256 < n_kmers; ++p0) {
+        uint64_t Vl[4] = {0, 0, 0, 0}, Hl[4] = {0, 0, 0, 0};
+        const int n_local = std::min(n_kmers - p0 * 256, 256);
+        for (int i = 0; i < 4 && (size_t)(p0 * 4 + i) < Vw.size(); ++i) {
+            Vl[i] = Vw[(size_t)(p0 * 4 + i)];
+            Hl[i] = Hw[(size_t)(p0 * 4 + i)];
+        }
+        const TileSummary a = summarize_piece<4>(Vl, Hl, n_local, k, 7);
+        const TileSummary b = summarize_words(Vw.data() + p0 * 4, Hw.data() + p0 * 4, n_local, k, 7);
+        if (memcmp(&a, &b, sizeof a) != 0) out->n = -1000000;               // poisons the comparison with the oracle
+    }
     return 0;
 }
 
