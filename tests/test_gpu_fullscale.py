@@ -100,7 +100,8 @@ def test_tilings_partition_the_genome(oracle, genome):
 
 
 def test_gene_model_windows_end_to_end(oracle, genome):
-    """configs[2]: GTF gene windows through the command-line driver; a sample of genes against the oracle + Python writer."""
+    """configs[2]: GTF gene windows through the command-line driver; EVERY gene's integers against the oracle, the full row text
+    (Python writer) for 2 000 of them."""
     contigs = [(f"chr{i + 1}", L) for i, L in enumerate(LENS)]
     gtf = os.path.join(genome["dir"], "genes.gtf")
     synth.random_gtf(gtf, contigs, 11, genes_per_mb=227.0)
@@ -120,13 +121,34 @@ def test_gene_model_windows_end_to_end(oracle, genome):
     rng = np.random.default_rng(1)
     genes = [g for c, _ in contigs for g in model.kids(c)]
     assert len(genes) == len(rows)
-    for g in rng.choice(genes, 2000, replace=False):
-        c, s, e, _ = model.loci(g)
+    # EVERY gene against the oracle: the spliced window texts (merged, start-sorted exon loci, no separator: GTF.java:223-293)
+    # concatenated into one buffer and screened in one multi-threaded call; every integer of every row must agree
+    pieces, wb, wl, off = [], [], [], 0
+    for g in genes:
         loci = model.merged_exon_loci(g, True)
         text = b"".join(pyhost.get_sequence(fa, entries[l[0]], l[1] - 1, l[2] - l[1] + 1) for l in loci)
-        res = odb.process_window(text, 1)
+        pieces.append(text)
+        wb.append(off)
+        wl.append(len(text))
+        off += len(text)
+    t1 = time.time()
+    want = odb.screen(b"".join(pieces), np.array(wb, dtype=np.int64), np.array(wl, dtype=np.int32), 1, threads=HOST_THREADS)
+    t_oracle = time.time() - t1
+    for i, g in enumerate(genes):
+        r = by_id[g]
+        info = dict(kv.split("=", 1) for kv in r[5].split(";") if "=" in kv)
+        _, va, ob, inner, ld, rd, _, _ = r[7].rstrip("\n").split(":")
+        got = (int(r[4]), int(info["EFFLEN"]), int(ob), int(va), int(inner), int(ld), int(rd))
+        exp = tuple(int(want[f][i]) for f in ("total_kmers", "eff_length", "obs", "var", "inner", "left", "right"))
+        assert got == exp, (g, got, exp)
+    # ... and the whole text of the row (INFO statistics, KD / SC formatting) for a sample of them
+    for i in rng.choice(len(genes), 2000, replace=False):
+        g = genes[i]
+        c, s, e, _ = model.loci(g)
+        res = {f: int(want[f][i]) for f in FIELDS}
         sc, md, _ = oracle.score(res)
         assert "\t".join(by_id[g]).rstrip("\n") == pyhost.kcf_row(c, s, e, g, res, sc, md)
+    print(f"oracle on all {len(genes)} gene windows ({off / 1e6:.0f} Mb of spliced text): {t_oracle:.1f} s on {HOST_THREADS} threads")
     # rows are grouped by contig in .faidx order and sorted by start inside a contig
     order = [r[0] for r in rows]
     assert [c for i, c in enumerate(order) if i == 0 or order[i - 1] != c] == [c for c, _ in contigs]
