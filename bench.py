@@ -461,7 +461,9 @@ def main():
         "data": "synthetic",
         "config": {"workload": (f"getVariations: synthetic {'chr1' if args.ref_len < 100_000_000 else 'whole-genome'}-sized reference "
                                 f"{args.ref_len} bp (BASELINE configs[{1 if args.ref_len < 100_000_000 else 3}] shape), "
-                                + (f"ONE KMC sample replicated on {world} GPUs" if window_sharded else
+                                + ((f"ONE KMC sample replicated on {world} GPUs" if S == 1 else
+                                    f"{S} KMC samples ({'one cohort table' if cohort is not None else 'one table each'}) replicated on {world} GPUs")
+                                   if window_sharded else
                                    f"{S} KMC sample{'s' if S > 1 else ''} per GPU ({S * world} in all)")
                                 + f" (k=31, counter_size {COUNTER_SIZE}, {meta['db_kmers']} k-mers each), {args.window // 1000} kb tiling "
                                 f"windows ({n_win_total} windows), -c {args.min_count}"),
