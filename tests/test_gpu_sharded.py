@@ -109,3 +109,35 @@ def test_closed_tables_are_kept_for_the_next_database_and_released_on_request(or
         assert free0 - torch.cuda.mem_get_info()[0] < 64 << 20
     finally:
         del os.environ["KCFX_TABLE_LBITS"]
+
+
+def test_kept_blocks_and_another_allocator_in_the_process(tmp_path):
+    """include/kcfx.h, kcfx_release_cached: the blocks the library keeps for the next database are invisible to another
+    allocator in the process (PyTorch here). Under memory pressure that allocator fails while the blocks sit in the pool, and
+    succeeds once kcfx_release_cached has given them back -- the documented contract, exercised."""
+    import gc
+    import torch
+    ref = synth.random_reference(200_000, 13)
+    prm = synth.KmcParams(k=31, p=3, counter_size=2, sig_len=7, n_bins=4, max_count=65535)
+    kmers, counts = synth.build_sample_db(synth.mutate_sample(ref, 14), prm, 15, noise_kmers=1000)
+    prefix = str(tmp_path / "db")
+    synth.write_kmc(prefix, kmers, counts, prm)
+    os.environ["KCFX_TABLE_LBITS"] = "26"            # an 8 GiB table
+    try:
+        engine.release_cached()
+        torch.cuda.empty_cache()
+        db = engine.KmcDb.open(prefix)
+        assert db.info.table_bytes >= 8 << 30
+        del db
+        gc.collect()                                 # closed: the 8 GiB block is kept by the library
+        free_now = torch.cuda.mem_get_info()[0]
+        want = free_now + (4 << 30)                  # more than the driver has, less than driver + pool
+        with pytest.raises(torch.OutOfMemoryError):
+            torch.empty(want, dtype=torch.uint8, device="cuda:0")
+        engine.release_cached()
+        t = torch.empty(want, dtype=torch.uint8, device="cuda:0")
+        assert t.numel() == want
+        del t
+        torch.cuda.empty_cache()
+    finally:
+        del os.environ["KCFX_TABLE_LBITS"]
