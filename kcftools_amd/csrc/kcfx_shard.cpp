@@ -85,12 +85,10 @@ std::vector<std::vector<Segment>> plan_segments(int32_t mode, int32_t G, int32_t
         // contiguous parts of equal k-mer count: a device screens the tail of one sample's windows and the head of the next
         // one's, so it opens at most ceil(S / G) + 1 databases (2 when S < G) where KCFX_SHARD_WINDOWS opens all S on every
         // device, and the parts are as even as a single sample's window cuts
-        const std::vector<int32_t> cuts = window_cuts(win_len, n_windows, kmer_length, G * 1);
         // cut positions in units of k-mers over S repetitions: part g = [g, g + 1) * S / G of the S-fold sequence
         std::vector<int64_t> cum((size_t)n_windows + 1, 0);
         for (int32_t i = 0; i < n_windows; ++i) cum[(size_t)i + 1] = cum[(size_t)i] + std::max<int64_t>(0, (int64_t)win_len[i] - kmer_length + 1);
         const int64_t per_sample = cum[(size_t)n_windows];
-        (void)cuts;
         auto locate = [&](int64_t pos, int32_t& samp, int32_t& w) {      // position in the S-fold k-mer sequence -> (sample, first window at or after it)
             if (per_sample <= 0) {
                 samp = n_samples;
