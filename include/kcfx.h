@@ -202,7 +202,8 @@ int32_t kcfx_windows(int32_t seq_len, int32_t window, int32_t step, int32_t kmer
  * taken into the table: the k-mers of up to KCFX_COHORT_MAX samples are re-indexed into ONE cell table whose cells carry one
  * counter per sample, so a reference k-mer is located once for all samples (one line request per minimizer run plus the
  * lines of the counters, instead of one per sample) and only the `count >= -c` test, the hit ballot and the count sum are
- * per sample: algorithmic bytes per sample-k-mer = (1 + 8) / S + counter_size. Needs k = 31, counters of at most 2 bytes and
+ * per sample: algorithmic bytes per sample-k-mer = (1 + 8) / S + counter_size. Needs k = 19 .. 31 (the k-mer lengths a cell
+ * table exists for; one k across the samples), counters of at most 2 bytes and
  * one strandedness across the samples (KCFX_ERR_ARG otherwise: screen such samples through kcfx_screen_ref_multi).
  * Memory: 8 + 2 * KCFX_COHORT_MAX bytes per cell of the union of the samples' k-mers. */
 #define KCFX_COHORT_MAX 8

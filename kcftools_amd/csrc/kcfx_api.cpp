@@ -1211,7 +1211,9 @@ int32_t kcfx_cohort_open(const char* const* kmc_prefixes, int32_t n_samples, int
         std::string perr;
         if (int32_t rc = parse_prefix_file(std::string(kmc_prefixes[s]) + ".kmc_pre", hs[(size_t)s], perr)) return fail(rc, perr);
         const KmcHeader& h = hs[(size_t)s];
-        if (h.k != 31) return fail(KCFX_ERR_ARG, "cohort tables need k = 31 (" + std::string(kmc_prefixes[s]) + " has k = " + std::to_string(h.k) + ")");
+        if (h.k < CELL_K_MIN || h.k > CELL_K_MAX)
+            return fail(KCFX_ERR_ARG, "cohort tables need k = 19 .. 31 (" + std::string(kmc_prefixes[s]) + " has k = " + std::to_string(h.k) + ")");
+        if (h.k != hs[0].k) return fail(KCFX_ERR_ARG, "Kmer size mismatch between the KMC databases");          // KCFHeader.equals (Cohort.java:71-119)
         if (h.counter_size < 1 || h.counter_size > 2)
             return fail(KCFX_ERR_ARG, "cohort tables need counters of 1 or 2 bytes (" + std::string(kmc_prefixes[s]) + ")");
         if (h.both != hs[0].both) return fail(KCFX_ERR_ARG, "cohort tables need one strandedness across the samples");
@@ -1271,7 +1273,7 @@ int32_t kcfx_cohort_open(const char* const* kmc_prefixes, int32_t n_samples, int
     // the key table: the ordinary build passes over the records of all samples; a cell's count field = the rank its k-mer bid with
     if (int32_t rc = table_alloc(db, N, 2, true, false)) return rc;
     if (db->fmt != FORMAT_CELLS) return fail(KCFX_ERR_ARG, "cohort tables need a cell table (KCFX_TABLE_FORMAT / KCFX_GENERIC_KERNEL / too many k-mers)");
-    const int32_t k = 31, both = db->info.both_strands;
+    const int32_t k = hs[0].k, both = db->info.both_strands;
     auto pass = [&](int phase) -> hipError_t {
         for (int64_t first = 0; first < N; first += (1ll << 30)) {
             const int64_t n = std::min<int64_t>(1ll << 30, N - first);
@@ -1339,7 +1341,7 @@ void kcfx_cohort_close(kcfx_cohort* cohort) {
 int32_t kcfx_cohort_screen_ref_async(kcfx_cohort* cohort, kcfx_ref* ref, int32_t min_kmer_count, void* out_device, void* hip_stream) try {
     if (!cohort || !ref || !out_device) return fail(KCFX_ERR_ARG, "null argument");
     if (cohort->device != ref->device) return fail(KCFX_ERR_ARG, "cohort table and reference live on different devices");
-    if (ref->k != 31) return fail(KCFX_ERR_ARG, "reference was planned for a different k-mer length");
+    if (ref->k != cohort->info.kmer_length) return fail(KCFX_ERR_ARG, "reference was planned for a different k-mer length");
     if (min_kmer_count < 1) return fail(KCFX_ERR_ARG, "Minimum kmer count should be at least 1");   // GetVariants.java:383-385
     if (ref->n_windows == 0) return KCFX_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);

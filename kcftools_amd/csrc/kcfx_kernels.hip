@@ -1375,6 +1375,8 @@ struct CohortQueue {
 struct CohortKeys {                       // stage 1 -> 2
     uint64_t V;
     uint32_t w, r;
+    uint32_t r_alt;                       // (k <= 30 only) the r field of the second-choice entry (cell_alt_of)
+    uint32_t dsh;                         // sh ^ alt_sh
     uint64_t l32;                         // 32 * line + 2 * first-choice cell: byte offset of the cell / 4, and of its counters / 8
     u32x2 cell, alt;
 };
@@ -1387,11 +1389,11 @@ typedef const __attribute__((address_space(1))) u32x2* gcell_ptr_t;
 typedef u32x4_ u32x4;
 typedef const __attribute__((address_space(1))) u32x4* gcount_ptr_t;
 
-template <bool BOTH>
+template <int K, bool BOTH>
 __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) void screen_cohort_kernel(
     const uint8_t* __restrict__ text, const TileDesc* __restrict__ tiles, int32_t n_tiles, CohortView cv, int32_t min_count,
     uint64_t* __restrict__ bits, int64_t* __restrict__ count_sums) {
-    constexpr int K = 31;
+    constexpr int W = cell_nw(K);                           // 16-mers per k-mer = cells of a line a k-mer can sit in
     constexpr int WAVES = CELLS_WAVES;
     __shared__ K31Pack sh;
     __shared__ CohortQueue s_queue[WAVES];
@@ -1429,7 +1431,7 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 
         uint64_t fwd, rc, V;
         uint32_t mn;
         words.next(w, fwd, rc, mn, V);
-        const CellProbe p = cell_probe_of(fwd, rc, mn, 2u * (uint32_t)lane, tv.lbits, 16, BOTH, 16);
+        const CellProbe p = cell_probe_of(fwd, rc, mn, 2u * (uint32_t)lane, tv.lbits, 16, BOTH, W);
         const bool valid = __builtin_amdgcn_inverse_ballot_w64(V);
         kw.V = V;
         kw.w = p.w;
@@ -1441,7 +1443,15 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 
         kw.l32 = l32;
         const uint8_t* a0 = reinterpret_cast<const uint8_t*>(reinterpret_cast<const uint32_t*>(tv.lines) + l32);
         kw.cell = *(gcell_ptr_t)a0;
-        const uint64_t a1 = (uint64_t)a0 ^ (uint64_t)(((p.w >> 25) & 0x70u) | 8u);
+        // the second-choice cell differs from the first in the cell index only: sh ^ alt_sh, in units of 4 bytes
+        if constexpr (W <= CELL_ALT_FREE_MAX_W) {           // k < 31: the table decides between the two second-choice schemes
+            const CellAlt a = cell_alt_of(p.sh, p.w, p.r, W, tv.lbits, BOTH);
+            kw.r_alt = a.r;
+            kw.dsh = p.sh ^ a.sh;
+        } else {
+            kw.dsh = ((p.w >> 27) & 0x1Cu) | 2u;
+        }
+        const uint64_t a1 = (uint64_t)a0 ^ (uint64_t)(kw.dsh << 2);
         kw.alt = *(gcell_ptr_t)a1;
     };
     // the queued k-mers (their cell is flagged for the stash, their filter bit is set): looked up 64 at a time, each lane
@@ -1482,14 +1492,15 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 
             m.V = kw.V;
             m.w = kw.w;
             m.r = kw.r;
+            m.r_alt = kw.r_alt;
             m.cell = kw.cell;
             m.alt = kw.alt;
-            cells_match<BOTH, 16>(m, tv.lbits, cnt, pend);
+            cells_match<BOTH, W>(m, tv.lbits, cnt, pend);
         }
         const bool first = ((kw.cell.x ^ kw.w) <= CELL_FLAG_MASK) && (((kw.cell.y ^ kw.r) & cell_rmask(tv.lbits, BOTH)) == 0);
         cw.V = kw.V;
         cw.M = wave_ballot(cnt != 0u) & kw.V;
-        const uint32_t x = first ? 0u : ((((kw.w >> 25) & 0x70u) | 8u) >> 2);      // sh ^ alt_sh
+        const uint32_t x = first ? 0u : kw.dsh;                                    // sh ^ alt_sh
         const uint64_t l32 = kw.l32 ^ (uint64_t)x;
         cw.c = *(gcount_ptr_t)(count_base + (l32 << 3));                           // 16 bytes per cell, cell = l32 / 2
         const uint64_t PM = wave_ballot(pend != 0u) & wave_ballot(cnt == 0u) & kw.V;
@@ -2023,12 +2034,32 @@ hipError_t launch_screen_cohort(const uint8_t* text, const TileDesc* tiles, int3
                                 int32_t both_strands, int32_t min_count, uint64_t* bits, int64_t* count_sums, hipStream_t st,
                                 hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (n_tiles <= 0 || cv.n_samples <= 0) return hipSuccess;
-    if (k != 31 || cv.n_samples > COHORT_STRIDE || cv.tv.fmt != FORMAT_CELLS) return hipErrorInvalidValue;
+    if (cv.n_samples > COHORT_STRIDE || cv.tv.fmt != FORMAT_CELLS) return hipErrorInvalidValue;
     const dim3 g(n_tiles), b(CELLS_BLOCK);
-    if (both_strands)
-        hipExtLaunchKernelGGL((screen_cohort_kernel<true>), g, b, 0, st, ev_start, ev_stop, 0, text, tiles, n_tiles, cv, min_count, bits, count_sums);
-    else
-        hipExtLaunchKernelGGL((screen_cohort_kernel<false>), g, b, 0, st, ev_start, ev_stop, 0, text, tiles, n_tiles, cv, min_count, bits, count_sums);
+#define KCFX_LAUNCHCO(KK)                                                                                                                  \
+    do {                                                                                                                                  \
+        if (both_strands)                                                                                                                 \
+            hipExtLaunchKernelGGL((screen_cohort_kernel<KK, true>), g, b, 0, st, ev_start, ev_stop, 0, text, tiles, n_tiles, cv, min_count, bits, count_sums);  \
+        else                                                                                                                              \
+            hipExtLaunchKernelGGL((screen_cohort_kernel<KK, false>), g, b, 0, st, ev_start, ev_stop, 0, text, tiles, n_tiles, cv, min_count, bits, count_sums); \
+    } while (0)
+    switch (k) {                                            // every k a cell table exists for
+        case 19: KCFX_LAUNCHCO(19); break;
+        case 20: KCFX_LAUNCHCO(20); break;
+        case 21: KCFX_LAUNCHCO(21); break;
+        case 22: KCFX_LAUNCHCO(22); break;
+        case 23: KCFX_LAUNCHCO(23); break;
+        case 24: KCFX_LAUNCHCO(24); break;
+        case 25: KCFX_LAUNCHCO(25); break;
+        case 26: KCFX_LAUNCHCO(26); break;
+        case 27: KCFX_LAUNCHCO(27); break;
+        case 28: KCFX_LAUNCHCO(28); break;
+        case 29: KCFX_LAUNCHCO(29); break;
+        case 30: KCFX_LAUNCHCO(30); break;
+        case 31: KCFX_LAUNCHCO(31); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef KCFX_LAUNCHCO
     return hipGetLastError();
 }
 

@@ -15,9 +15,10 @@ FIELDS = engine.INT_FIELDS
 K = 31
 
 
-def make_sample(tmp_path, name, ref, seed, cs=2, both=True, noise=3000, **mut):
+def make_sample(tmp_path, name, ref, seed, cs=2, both=True, noise=3000, k=K, **mut):
     sample = synth.mutate_sample(ref, seed, **mut)
-    prm = synth.KmcParams(k=K, p=3, counter_size=cs, sig_len=7, n_bins=8, both_strands=both, max_count=(1 << (8 * cs)) - 1)
+    p = max(q for q in range(2, 8) if (k - q) % 4 == 0)
+    prm = synth.KmcParams(k=k, p=p, counter_size=cs, sig_len=7, n_bins=8, both_strands=both, max_count=(1 << (8 * cs)) - 1)
     kmers, counts = synth.build_sample_db(sample, prm, seed + 1, noise_kmers=noise)
     prefix = str(tmp_path / name)
     synth.write_kmc(prefix, kmers, counts, prm)
@@ -59,6 +60,26 @@ def test_cohort_rows_equal_the_single_sample_screens(oracle, tmp_path, n_samples
     check(co.screen(r2, 1), prefixes, ref, wb, wl, 1, oracle, "irregular windows")
 
 
+@pytest.mark.parametrize("k,both", [(19, True), (22, True), (25, True), (25, False), (28, True), (30, True), (27, False)])
+def test_cohort_tables_for_the_other_kmer_lengths(oracle, tmp_path, monkeypatch, k, both):
+    """k = 19 .. 30 (KMC's default 25 among them): a k-mer spans W = k - 15 minimizer positions, second choices go to the cells
+    nobody has as first choice (or by xor on small tables) -- the cohort kernel takes both schemes from the key table."""
+    ref = synth.random_reference(250_000, 90 + k, n_run_every=50_000, max_n_run=200)
+    prefixes = [make_sample(tmp_path, f"k{k}_{i}", ref, 500 + 11 * i + k, cs=1 + (i % 2), both=both, noise=4000, k=k) for i in range(3)]
+    s, e = engine.windows(len(ref), 10_000, 0, k)
+    for lbits in (None, "18"):                               # roomy (free-cell second choices) and crowded (few spare r bits: xor scheme)
+        if lbits:
+            monkeypatch.setenv("KCFX_TABLE_LBITS", lbits)
+        co = engine.Cohort(prefixes)
+        monkeypatch.delenv("KCFX_TABLE_LBITS", raising=False)
+        assert co.info.kmer_length == k
+        got = co.screen(engine.Reference(ref, s, e - s, k), 1)
+        for i, pfx in enumerate(prefixes):
+            want = oracle.OracleDb(pfx).screen(ref, s, e - s, 1, threads=8)
+            for f in FIELDS:
+                assert np.array_equal(got[i][f], want[f]), (k, both, lbits, i, f)
+
+
 def test_cohort_with_a_crowded_table_and_a_loaded_stash(oracle, tmp_path, monkeypatch):
     """2^17 lines for ~2 M records: second choices and the stash (with its own counters) carry real weight."""
     ref = synth.random_reference(500_000, 41)
@@ -97,18 +118,19 @@ def test_cohort_async_on_a_torch_stream_and_what_it_refuses(oracle, tmp_path):
     st.synchronize()
     got = out.cpu().numpy().view(engine.RESULT_DTYPE).reshape(2, len(s))
     check(got, prefixes, ref, s, e - s, 1, oracle, "async")
-    # refused: more than 8 samples, k != 31, 4-byte counters, mixed strandedness, -c 0
+    # refused: more than 8 samples, k outside 19 .. 31, mixed k, 4-byte counters, mixed strandedness, -c 0
     with pytest.raises(engine.KcfxError) as err:
         engine.Cohort([prefixes[0]] * 9)
     assert err.value.code == 1
-    prm = synth.KmcParams(k=25, p=5, counter_size=2, sig_len=7, n_bins=4)
+    prm = synth.KmcParams(k=15, p=3, counter_size=2, sig_len=7, n_bins=4)              # k outside 19 .. 31: no cell table
     km, ct = synth.build_sample_db(synth.mutate_sample(ref, 9), prm, 10, noise_kmers=100)
-    synth.write_kmc(str(tmp_path / "k25"), km, ct, prm)
+    synth.write_kmc(str(tmp_path / "k15"), km, ct, prm)
+    k25 = make_sample(tmp_path, "k25", ref, 78, k=25)                                   # fine alone, not next to k = 31
     prm4 = synth.KmcParams(k=K, p=3, counter_size=4, sig_len=7, n_bins=4, max_count=2**31 - 1)
     km, ct = synth.build_sample_db(synth.mutate_sample(ref, 9), prm4, 10, noise_kmers=100)
     synth.write_kmc(str(tmp_path / "cs4"), km, ct, prm4)
     fwd = make_sample(tmp_path, "fwd", ref, 77, both=False)
-    for bad in ([str(tmp_path / "k25")], [prefixes[0], str(tmp_path / "cs4")], [prefixes[0], fwd]):
+    for bad in ([str(tmp_path / "k15")], [prefixes[0], k25], [prefixes[0], str(tmp_path / "cs4")], [prefixes[0], fwd]):
         with pytest.raises(engine.KcfxError) as err:
             engine.Cohort(bad)
         assert err.value.code == 1, bad
@@ -132,7 +154,8 @@ def test_cohort_fuzz_against_the_single_sample_path(oracle, tmp_path, monkeypatc
     ref = bytes(ref)
     S = int(rng.integers(1, 9))
     both = bool(seed % 4)
-    prefixes = [make_sample(tmp_path, f"z{i}", ref, 9000 + 31 * seed + i, cs=int(rng.integers(1, 3)), both=both,
+    k = (31, 25, 29, 31, 27, 23, 31, 30, 21, 19)[seed % 10]
+    prefixes = [make_sample(tmp_path, f"z{i}", ref, 9000 + 31 * seed + i, cs=int(rng.integers(1, 3)), both=both, k=k,
                             noise=int(rng.choice([500, 20_000, 150_000])), sub_rate=float(rng.choice([0.001, 0.01, 0.03])))
                 for i in range(S)]
     if S > 2 and seed % 3 == 0:
@@ -142,10 +165,10 @@ def test_cohort_fuzz_against_the_single_sample_path(oracle, tmp_path, monkeypatc
     co = engine.Cohort(prefixes)
     monkeypatch.delenv("KCFX_TABLE_LBITS", raising=False)
     # window lengths on the borders: k-mer counts 0 / 1 / 63 / 64 / 65, one tile +- 1, several tiles +- 1
-    base = [0, 30, 31, 93, 94, 95, 2047 + 30, 2048 + 30, 2049 + 30, 4096 + 30, 4097 + 30, 10_000, 33_333]
+    base = [0, k - 1, k, k + 62, k + 63, k + 64, 2047 + k - 1, 2048 + k - 1, 2049 + k - 1, 4096 + k - 1, 4097 + k - 1, 10_000, 33_333]
     wl = np.array([base[int(rng.integers(0, len(base)))] for _ in range(120)], dtype=np.int32)
     wb = np.array([int(rng.integers(0, L - int(x) + 1)) for x in wl], dtype=np.int64)
-    r = engine.Reference(ref, wb, wl, K)
+    r = engine.Reference(ref, wb, wl, k)
     c = int(rng.integers(1, 5))
     got = co.screen(r, c)
     for i, pfx in enumerate(prefixes):
