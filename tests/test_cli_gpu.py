@@ -142,6 +142,33 @@ def test_multi_sample_equals_cohort_of_single_sample_runs(oracle, tmp_path):
     assert "differ" in log
 
 
+def test_cohort_table_option_gives_the_same_file(tmp_path):
+    """`--cohort-table`: the samples in ONE table (kcfx_cohort_open), one look-up per reference k-mer for all of them -- the
+    multi-sample KCF must be the file the per-sample tables give, byte for byte (##CMD / ##date aside). Golden databases of
+    one k and strandedness; a mixed pair is refused with the library's message."""
+    fa = str(tmp_path / "ref.fa")
+    shutil.copy(os.path.join(G, "ref.fa"), fa)
+    ref = open(os.path.join(G, "ref.fa"), "rb").read()
+    text = b"".join(l for l in ref.split(b"\n") if not l.startswith(b">"))
+    prm = synth.KmcParams(k=31, p=3, counter_size=2, sig_len=7, n_bins=4, max_count=65535)
+    prefixes = []
+    for i in range(3):
+        km, ct = synth.build_sample_db(synth.mutate_sample(text, 40 + i), prm, 50 + i, noise_kmers=500)
+        pfx = str(tmp_path / f"c{i}")
+        synth.write_kmc(pfx, km, ct, prm)
+        prefixes.append(pfx)
+    outs = []
+    for extra in ([], ["--cohort-table"]):
+        out = str(tmp_path / f"o{len(outs)}.kcf")
+        log = run_cli(["-r", fa, "-k", ",".join(prefixes), "-o", out, "-s", "A,B,C", "-f", "window", "-w", "3000"] + extra)
+        assert ("one cohort table" in log) == bool(extra)
+        outs.append([l for l in open(out).read().split("\n") if not l.startswith("##CMD") and not l.startswith("##date")])
+    assert outs[0] == outs[1] and len(outs[0]) > 20
+    log = run_cli(["-r", fa, "-k", prefixes[0] + "," + os.path.join(G, "db_fwd_k31_p7_cs1_m7"), "-o", str(tmp_path / "x.kcf"), "-s", "A,B",
+                   "-f", "window", "-w", "3000", "--cohort-table"], expect_rc=1)
+    assert "strandedness" in log
+
+
 def test_samples_sharded_over_devices_give_the_same_file(tmp_path):
     """`--devices a,b,...` shards the samples over GPUs (sample s on device s mod G, one worker thread each, own resident
     reference, no exchange). A one-GPU box can only check the threading: `--devices 0,0,0` runs three workers against the
