@@ -321,6 +321,7 @@ def main():
     traffic = None
     traffic_source = None
     rocprof_ms = None
+    requests = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
@@ -328,6 +329,7 @@ def main():
             if (S == 1 and world == 1 and tj.get("kernel") == kernel_name and tj.get("ref_len") == args.ref_len
                     and tj.get("db_kmers") == args.db_kmers and tj.get("window") == args.window):
                 traffic = tj.get("hbm_bytes_per_launch")
+                requests = tj.get("hbm_read_requests_per_launch")
                 rocprof_ms = tj.get("rocprof_kernel_avg_ms")    # the committed rocprofv3 --stats average of the same kernel
                 traffic_source = (f"profiles/traffic.json (committed rocprofv3 --pmc passes, tag {tj.get('tag')}, kernel "
                                   f"{tj.get('kernel')}; not measured in this run)")
@@ -441,6 +443,20 @@ def main():
         except Exception as exc:
             cpu_e2e = {"error": str(exc)[:300]}
 
+    # ---- this box's own random-request rate (the wall the kernel runs against differs by +- 8 % between boxes) ----------
+    box = None
+    if world == 1 and S == 1 and not args.no_end_to_end:
+        try:
+            mb = os.path.join(ROOT, "kcftools_amd", "bin", "kcfx_membench")
+            pr = subprocess.run([mb, "16", "128", "box"], capture_output=True, text=True, timeout=120)
+            box = json.loads(pr.stdout.strip().splitlines()[-1])
+            if requests and kern_avg_ms > 0:
+                box["kernel_G_requests_per_s"] = requests / (kern_avg_ms * 1e-3) / 1e9
+                box["kernel_fraction_of_the_request_rate"] = box["kernel_G_requests_per_s"] / box["G_lines_per_s"]
+                box["requests_per_launch_source"] = "profiles/traffic.json (TCC_EA0_RDREQ_sum of the committed --pmc pass)"
+        except Exception as exc:
+            box = {"error": str(exc)[:200]}
+
     jvm = jvm_probe()
     java_leg = None
     if world == 1 and S == 1:
@@ -488,6 +504,7 @@ def main():
         "cpu_baseline": cpu,
         "end_to_end": e2e,
         "cpu_end_to_end": cpu_e2e,
+        "box": box,
         "jvm": jvm,
         "java_reference": java_leg,
         "pin": pin_probe(jvm) if world == 1 else None,

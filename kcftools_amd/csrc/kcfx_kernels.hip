@@ -1349,7 +1349,10 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
         my_bits[TILE_WORDS + w_begin + lane] = q.hit[lane];
     }
 
-    const int64_t count_sum = (int64_t)wave_sum_u32_dpp(sum_acc) + wave_sum_i64(big_acc);
+    // (counters beyond 16 bits exist only in 3- / 4-byte-counter databases: their 64-bit wave sum -- twelve cross-lane moves --
+    // is taken only when some lane has one)
+    int64_t count_sum = (int64_t)wave_sum_u32_dpp(sum_acc);
+    if (wave_ballot(big_acc != 0) != 0) count_sum += wave_sum_i64(big_acc);
     if (lane == 0) sh.sum[wave] = count_sum;
     __syncthreads();
     if (tid == 0) {

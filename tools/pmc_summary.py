@@ -61,6 +61,7 @@ if fetch.get("FETCH_SIZE") is not None:
     if not COHORT:
         json.dump({"tag": tag, "kernel": KERNEL, "hbm_bytes_per_launch": rd + wr,
                    "rocprof_kernel_avg_ms": out.get("rocprof_kernel_avg_ms"),
+                   "hbm_read_requests_per_launch": tcc.get("TCC_EA0_RDREQ_sum"),
                    "ref_len": 30427671, "db_kmers": 150000000, "window": 10000,
                    "note": "2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes), separate --pmc passes, averaged over launches"},
                   open("profiles/traffic.json", "w"), indent=1)
