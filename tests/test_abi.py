@@ -38,6 +38,16 @@ def test_no_gpu_means_loud_failure_not_fallback():
     with pytest.raises(engine.KcfxError) as ei:
         engine.screen_sharded(["nowhere"], 31, b"ACGT" * 20, [0], [80], devices=(0,))
     assert ei.value.code == 4 and "no CPU fallback" in str(ei.value)
+    # the entry points of round 3: a golden database parses on the host, then the device is missing -- never a CPU path
+    import os
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "db_canon_k31_p3_cs2_m9")
+    for make in (lambda: engine.KmcDb.open(golden, expected_queries=1000), lambda: engine.Cohort([golden, golden])):
+        with pytest.raises(engine.KcfxError) as ei:
+            make()
+        assert ei.value.code == 4 and "no CPU fallback" in str(ei.value)
+    # ... while the sharding plan is host arithmetic and needs no device
+    plan, used = engine.shard_plan([10_000] * 10, 31, 2, 4)
+    assert used == engine.SHARD_GRID and len(plan) >= 4
 
 
 def test_db_header_is_host_only(tmp_path):
