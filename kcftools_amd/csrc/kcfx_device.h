@@ -215,7 +215,15 @@ KCFX_HD uint32_t mm27(uint32_t cm) {
 // pre-doubled the query gets 2 * offset as (mn - 2 * lane) & 30, the strand bit riding along untouched.
 KCFX_HD uint32_t mm27_tagged(uint32_t fwd_m, uint32_t rc_m, uint32_t label2) {
     const uint32_t cm = fwd_m < rc_m ? fwd_m : rc_m;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // hash + label + (rc < fwd) as compare + add-with-carry: the three fields do not overlap. (hipcc turns every C spelling of
+    // this into v_cmp + v_cndmask + v_or3; the word loop is paid per instruction on boxes whose clock, not HBM, binds.)
+    uint32_t t;
+    asm("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %3, %4, vcc" : "=v"(t) : "v"(rc_m), "v"(fwd_m), "v"(mm27(cm)), "v"(label2) : "vcc");
+    return t;
+#else
     return mm27(cm) | (rc_m < fwd_m ? 1u : 0u) | label2;
+#endif
 }
 KCFX_HD uint32_t mm27_label2(uint32_t pos) { return (pos & 15u) << 1; }
 // canonical minimizer 16-mer -> G32: line = top lbits, r = the rest. A bijection on 32 bits (odd multiplies, right
@@ -319,7 +327,8 @@ KCFX_HD CellAlt cell_alt_of(uint32_t sh, uint32_t w, uint32_t r, int W, int32_t 
 // (lane2 = 2 * position, what mm27_label2 was fed -- mod 32 is enough)
 KCFX_HD CellProbe cell_probe_of(uint64_t F, uint64_t R, uint32_t mn, uint32_t lane2, int32_t lbits, int M, bool both, int W = 16) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t fm = (uint32_t)__builtin_amdgcn_sbfe((int)mn, 0, 1);
+    uint32_t fm;                                              // (one v_bfe_i32; hipcc rewrites the builtin into v_and + v_sub)
+    asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(fm) : "v"(mn));
 #else
     const uint32_t fm = 0u - (mn & 1u);                       // all ones: the minimizer is canonical on the other strand
 #endif
