@@ -180,3 +180,20 @@ def test_cohort_fuzz_against_the_single_sample_path(oracle, tmp_path, monkeypatc
     want = oracle.OracleDb(prefixes[j]).screen(ref, wb, wl, c, threads=4)
     for f in FIELDS:
         assert np.array_equal(got[j][f], want[f]), (seed, j, f)
+
+
+def test_cohort_of_empty_and_tiny_databases(oracle, tmp_path):
+    """Databases without a record, with one record, and a normal one in the same cohort: the empty sample's column is all misses."""
+    ref = synth.random_reference(60_000, 71)
+    prm = synth.KmcParams(k=K, p=3, counter_size=2, sig_len=7, n_bins=4, max_count=65535)
+    empty, one = str(tmp_path / "empty"), str(tmp_path / "one")
+    synth.write_kmc(empty, np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint32), prm)
+    km, ct = synth.build_sample_db(synth.mutate_sample(ref, 72), prm, 73, noise_kmers=10)
+    synth.write_kmc(one, km[:1], ct[:1], prm)
+    normal = make_sample(tmp_path, "normal", ref, 74)
+    s, e = engine.windows(len(ref), 10_000, 0, K)
+    r = engine.Reference(ref, s, e - s, K)
+    for prefixes in ([empty], [empty, empty], [empty, one, normal], [normal, empty]):
+        got = engine.Cohort(prefixes).screen(r, 1)
+        check(got, prefixes, ref, s, e - s, 1, oracle, str([os.path.basename(p) for p in prefixes]))
+    assert int(engine.Cohort([empty, normal]).screen(r, 1)[0]["obs"].sum()) == 0
