@@ -105,7 +105,7 @@ int32_t kcfx_db_open(const char* kmc_prefix, int32_t device, kcfx_db** out);
  *   expected_queries  k-mer look-ups this handle is expected to serve over its lifetime = reference k-mers x passes (the
  *                     reference runs ONE pass per database: GetVariants.java:129-159); 0 = unknown. The table is sized for
  *                     it: a handle that serves few look-ups gets a dense table (~0.3 k-mers per cell: 5 GB for 150 M k-mers,
- *                     +8 % screening time) instead of the sparse one (~0.07 per cell: 17 GB) that pays off only over
+ *                     +21 % screening time) instead of the sparse one (~0.07 per cell: 17 GB) that pays off only over
  *                     ~10^10 look-ups -- allocating and clearing 16 GiB can cost a second (profiles/r03_density.csv).
  *   no_fallback       1: a cell table that does not fit the device fails with KCFX_ERR_DEVICE instead of being rebuilt as
  *                     a 12-slot line table (callers that can free memory and retry, like kcfx_screen_sharded's loader). */

@@ -141,6 +141,14 @@ struct kcfx_ref {
     int32_t n_tiles = 0;
     int64_t n_slots = 0;
     uint8_t* d_text = nullptr;
+    uint32_t* d_codes = nullptr;       // RefPlan (k = 19 .. 31: what a cell table's look-ups need of the reference, worked out once)
+    uint8_t* d_anchors = nullptr;
+    RefPlan plan() const {
+        RefPlan p;
+        p.codes = d_codes;
+        p.anchors = d_anchors;
+        return p;
+    }
     TileDesc* d_tiles = nullptr;
     int32_t* d_win_tile0 = nullptr;
     uint64_t* d_bits = nullptr;        // per tile: valid / hit ballots of every 64-position word
@@ -262,8 +270,8 @@ bool cells_eligible(const kcfx_db* db, int32_t counter_size) {
 // aim at ~0.075 k-mers per cell while that stays under 48 GiB and 50 % of the free memory, else halve down to ~1 per cell.
 // KCFX_TABLE_LBITS overrides.
 // Memory against speed (profiles/r03_density.csv, bench workload, 150 M k-mers): 0.07 / 0.14 / 0.28 / 0.56 k-mers per cell =
-// 17.4 / 9.1 / 5.4 / 4.3 GB = 1.00 / 1.04 / 1.08 / 1.33 x the screening time per k-mer. A sparse table pays for itself only
-// over many look-ups -- clearing 12 GB more costs ~4 ms (= 10^10 look-ups at the 8 % difference) when the block comes from the
+// 17.4 / 9.1 / 5.4 / 4.3 GB = 1.00 / 1.00 / 1.21 / 1.57 x the screening time per k-mer. A sparse table pays for itself only
+// over many look-ups -- clearing 12 GB more costs ~4 ms (= 5 * 10^9 look-ups at the 21 % difference) when the block comes from the
 // pool, and up to a second when the driver has to scrub it first -- so a handle that is expected to serve fewer than
 // QUERIES_FOR_SPARSE look-ups (kcfx_db_opts: the command-line driver's one pass per sample) is built at ~0.3 per cell.
 constexpr double QUERIES_FOR_SPARSE = 1e10;
@@ -487,6 +495,8 @@ void ref_free(kcfx_ref* r) {
         (void)hipEventDestroy(ev.second);
     }
     if (r->d_text) (void)dev_free(r->d_text);
+    if (r->d_codes) (void)dev_free(r->d_codes);
+    if (r->d_anchors) (void)dev_free(r->d_anchors);
     if (r->d_tiles) (void)dev_free(r->d_tiles);
     if (r->d_win_tile0) (void)dev_free(r->d_win_tile0);
     if (r->d_bits) (void)dev_free(r->d_bits);
@@ -1029,8 +1039,20 @@ int32_t kcfx_ref_create(int32_t device, int32_t kmer_length, const uint8_t* text
         (e = dev_alloc(&r->d_res, std::max<size_t>((size_t)n_windows, 1) * sizeof(kcfx_result))) != hipSuccess ||
         (!tiles.empty() && (e = hipMemcpyAsync(r->d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, r->stream)) != hipSuccess) ||
         (e = hipMemcpyAsync(r->d_win_tile0, win_tile0.data(), win_tile0.size() * 4, hipMemcpyHostToDevice, r->stream)) != hipSuccess ||
-        (e = hipStreamSynchronize(r->stream)) != hipSuccess)
+        (e = hipSuccess) != hipSuccess)
         return hip_fail(e, "kcfx_ref_create");
+    // the plan of the reference for cell tables (k = 19 .. 31), on the same stream behind the text upload.
+    // KCFX_REF_PLAN=0 in the environment keeps the text-only reference (A/B and test hook, read here, never per launch).
+    const char* plan_env = getenv("KCFX_REF_PLAN");
+    if (k >= CELL_K_MIN && k <= CELL_K_MAX && text_len > 0 && !(plan_env && plan_env[0] == '0')) {
+        const size_t cb = ref_plan_codes_bytes(text_len), ab = ref_plan_anchor_bytes(text_len);
+        if ((e = dev_alloc(&r->d_codes, cb)) != hipSuccess || (e = dev_alloc(&r->d_anchors, ab)) != hipSuccess ||
+            (e = hipMemsetAsync(r->d_codes, 0, cb, r->stream)) != hipSuccess ||
+            (e = hipMemsetAsync(r->d_anchors, 0, ab, r->stream)) != hipSuccess ||
+            (e = launch_ref_plan(r->d_text, text_len, k, r->d_codes, r->d_anchors, r->stream)) != hipSuccess)
+            return hip_fail(e, "kcfx_ref_create (reference plan)");
+    }
+    if ((e = hipStreamSynchronize(r->stream)) != hipSuccess) return hip_fail(e, "kcfx_ref_create");
     *out = hold.release();
     return KCFX_OK;
 } KCFX_CATCH("kcfx_ref_create")
@@ -1058,7 +1080,7 @@ int32_t kcfx_screen_ref_async(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count
         ev1 = ref->events[ref->events_used].second;
         ref->events_used++;
     }
-    KCFX_HIP(launch_screen_tiles(ref->d_text, ref->d_tiles, ref->n_tiles, db->view(), ref->k, db->info.both_strands,
+    KCFX_HIP(launch_screen_tiles(ref->d_text, ref->plan(), ref->d_tiles, ref->n_tiles, db->view(), ref->k, db->info.both_strands,
                                  min_kmer_count, ref->d_bits, ref->d_csum, st, ev0, ev1));
     KCFX_HIP(launch_reduce_windows(ref->d_tiles, ref->n_tiles, 1, ref->d_bits, ref->d_csum, ref->d_win_tile0, ref->n_windows,
                                    ref->k, reinterpret_cast<kcfx_result*>(out_device), st));
@@ -1361,7 +1383,7 @@ int32_t kcfx_cohort_screen_ref_async(kcfx_cohort* cohort, kcfx_ref* ref, int32_t
     }
     CohortView cv{cohort->keys->view(), reinterpret_cast<const uint4*>(cohort->d_counts), reinterpret_cast<const uint4*>(cohort->d_scounts),
                   cohort->n_samples};
-    KCFX_HIP(launch_screen_cohort(ref->d_text, ref->d_tiles, ref->n_tiles, cv, ref->k, cohort->info.both_strands, min_kmer_count,
+    KCFX_HIP(launch_screen_cohort(ref->d_text, ref->plan(), ref->d_tiles, ref->n_tiles, cv, ref->k, cohort->info.both_strands, min_kmer_count,
                                   ref->d_mbits, ref->d_mcsum, st, ev0, ev1));
     KCFX_HIP(launch_reduce_windows(ref->d_tiles, ref->n_tiles, cohort->n_samples, ref->d_mbits, ref->d_mcsum, ref->d_win_tile0,
                                    ref->n_windows, ref->k, reinterpret_cast<kcfx_result*>(out_device), st));

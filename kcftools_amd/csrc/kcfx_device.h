@@ -209,20 +209,65 @@ KCFX_HD uint32_t mm27(uint32_t cm) {
     u &= ~31u;
     return u * 0x85EBCA6Bu;
 }
-// What one lane feeds into the sliding minimum: hash | position label (bits 4..1: twice the position mod 16, distinct within
+// ---- the ORDER that picks a k-mer's minimizer ----
+// Not the plain hash: 16-mers that are OPEN SYNCMERS (the smallest of their eleven 6-mers sits in the middle, position 5) come
+// first, CLOSED ones (it sits at either end) second, the rest last; mm27 decides inside a class. Two open syncmers cannot start
+// fewer than 6 bases apart unless they share their smallest 6-mer's neighbourhood, so consecutive k-mers agree on their
+// minimizer for longer: 0.0966 minimizer runs per k-mer instead of 0.1177 (= 2 / 17) on random text (k = 31) -- 18 % fewer table
+// lines per reference k-mer, and the line fetches ARE the screening kernel's time. The 6-mers are hashed in canonical form and the
+// classes are mirror-symmetric, so a 16-mer and its reverse complement get the same class: it is a function of the canonical
+// 16-mer like mm27, and build (cells_visit) and query (K31Words -> ref_plan_kernel) agree by construction. The price -- eleven
+// small hashes per 16-mer -- is paid once per reference position in kcfx_ref_create and once per pass and k-mer in kcfx_db_open,
+// never in a screening launch (those read the anchor bytes of the planned reference).
+KCFX_HD uint32_t smer6_hash(uint32_t x, uint32_t rcx) { return (x < rcx ? x : rcx) * 0x9E3779B1u; }   // distinct for distinct canonical 6-mers
+// u[i] = smer6_hash of the 6-mer at base offset i of the 16-mer, i = 0 .. 10
+KCFX_HD uint32_t cell_class_of(const uint32_t* u) {
+    uint32_t lo = u[0] < u[1] ? u[0] : u[1], hi = u[9] < u[10] ? u[9] : u[10], in_lo = u[1], in_hi = u[9];
+    lo = lo < u[2] ? lo : u[2];
+    lo = lo < u[3] ? lo : u[3];
+    lo = lo < u[4] ? lo : u[4];
+    hi = hi < u[8] ? hi : u[8];
+    hi = hi < u[7] ? hi : u[7];
+    hi = hi < u[6] ? hi : u[6];
+    in_lo = in_lo < u[2] ? in_lo : u[2];
+    in_lo = in_lo < u[3] ? in_lo : u[3];
+    in_lo = in_lo < u[4] ? in_lo : u[4];
+    in_hi = in_hi < u[8] ? in_hi : u[8];
+    in_hi = in_hi < u[7] ? in_hi : u[7];
+    in_hi = in_hi < u[6] ? in_hi : u[6];
+    const uint32_t sides = lo < hi ? lo : hi;
+    if (u[5] < sides) return 0u;                                   // open: a strict minimum in the middle
+    const uint32_t ends = u[0] < u[10] ? u[0] : u[10];
+    uint32_t inner = in_lo < in_hi ? in_lo : in_hi;
+    inner = inner < u[5] ? inner : u[5];
+    return ends <= inner ? 1u : 2u;                                // closed: an end holds the minimum
+}
+// 27-bit order key of a canonical 16-mer, top-aligned (low 5 bits zero): class in the top two bits, 25 hash bits below
+KCFX_HD uint32_t cell_order27(uint32_t cm, uint32_t cls) { return (cls << 30) | ((mm27(cm) >> 2) & ~31u); }
+// the class straight from a 16-mer and its reverse complement (both left-aligned, 32 bits): what a text position computes
+KCFX_HD uint32_t cell_class16(uint32_t m, uint32_t rc_m) {
+    uint32_t u[11];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 11; ++i) u[i] = smer6_hash((m >> (20 - 2 * i)) & 0xFFFu, (rc_m >> (2 * i)) & 0xFFFu);
+    return cell_class_of(u);
+}
+// What one lane feeds into the sliding minimum: order key | position label (bits 4..1: twice the position mod 16, distinct within
 // any 16 consecutive positions) | strand bit (bit 0: the canonical form is the reverse complement of the 16-mer as the
 // text reads it). The minimum therefore carries where the minimizer sits and which way round it is; with the label
 // pre-doubled the query gets 2 * offset as (mn - 2 * lane) & 30, the strand bit riding along untouched.
 KCFX_HD uint32_t mm27_tagged(uint32_t fwd_m, uint32_t rc_m, uint32_t label2) {
     const uint32_t cm = fwd_m < rc_m ? fwd_m : rc_m;
+    const uint32_t key = cell_order27(cm, cell_class16(fwd_m, rc_m));
 #if defined(__HIP_DEVICE_COMPILE__)
-    // hash + label + (rc < fwd) as compare + add-with-carry: the three fields do not overlap. (hipcc turns every C spelling of
-    // this into v_cmp + v_cndmask + v_or3; the word loop is paid per instruction on boxes whose clock, not HBM, binds.)
+    // key + label + (rc < fwd) as compare + add-with-carry: the three fields do not overlap. (hipcc turns every C spelling of
+    // this into v_cmp + v_cndmask + v_or3.)
     uint32_t t;
-    asm("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %3, %4, vcc" : "=v"(t) : "v"(rc_m), "v"(fwd_m), "v"(mm27(cm)), "v"(label2) : "vcc");
+    asm("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %3, %4, vcc" : "=v"(t) : "v"(rc_m), "v"(fwd_m), "v"(key), "v"(label2) : "vcc");
     return t;
 #else
-    return mm27(cm) | (rc_m < fwd_m ? 1u : 0u) | label2;
+    return key | (rc_m < fwd_m ? 1u : 0u) | label2;
 #endif
 }
 KCFX_HD uint32_t mm27_label2(uint32_t pos) { return (pos & 15u) << 1; }
@@ -364,17 +409,36 @@ template <class F>
 KCFX_HD int cells_visit(uint64_t C, int32_t k, int32_t lbits, bool both, F&& f) {
     const int M = cell_mlen(k), W = cell_nw(k);
     const uint64_t Rc = revcomp_word(C, k);
+    // the k-mer's k - 5 canonical 6-mer hashes, once (the 6-mer at base t of C is the reverse complement of the one at base
+    // k - 6 - t of Rc), then the order key of each of its W 16-mers. Static indices throughout: registers, not private memory.
+    uint32_t U[26], key[16];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int t = 0; t < 26; ++t) {
+        const int tr = k - 6 - t;
+        U[t] = tr >= 0 ? smer6_hash((uint32_t)(C >> (52 - 2 * t)) & 0xFFFu, (uint32_t)(Rc >> (52 - 2 * tr)) & 0xFFFu) : 0xFFFFFFFFu;
+    }
     uint32_t best = 0xFFFFFFFFu;
-    for (int j = 0; j < W; ++j) {
-        const uint32_t m = (uint32_t)((C << (2 * j)) >> 32) & cell_mmask(M), r = rc_mmer(m, M);
-        const uint32_t h = mm27(m < r ? m : r);
-        best = h < best ? h : best;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 16; ++j) {
+        key[j] = 0xFFFFFFFFu;                                 // (never a key: those end in five zero bits)
+        if (j < W) {
+            const uint32_t m = (uint32_t)((C << (2 * j)) >> 32) & cell_mmask(M), r = rc_mmer(m, M);
+            key[j] = cell_order27(m < r ? m : r, cell_class_of(U + j));
+        }
+        best = key[j] < best ? key[j] : best;
     }
     int n = 0;
-    for (int j = 0; j < W; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 16; ++j) {
+        if (key[j] != best) continue;
         const uint32_t m = (uint32_t)((C << (2 * j)) >> 32) & cell_mmask(M), r = rc_mmer(m, M);
         const uint32_t cm = m < r ? m : r;
-        if (mm27(cm) != best) continue;
         for (int strand = 0; strand < 2; ++strand) {
             // strand 0: N = C (needs m canonical), strand 1: N = revcomp(C) (needs rc(m) canonical)
             if (strand == 0 ? (m > r) : (r > m)) continue;

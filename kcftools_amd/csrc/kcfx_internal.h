@@ -126,6 +126,11 @@ constexpr int BLOCK = KCFX_BLOCK;     // 4 wavefronts (line-table kernels)
 #define KCFX_CELLS_BLOCK 128
 #endif
 constexpr int CELLS_BLOCK = KCFX_CELLS_BLOCK;
+// words of cell loads a wave of the (planned) cell-table kernel keeps in flight
+#ifndef KCFX_CELLS_PIPE
+#define KCFX_CELLS_PIPE 2
+#endif
+constexpr int CELLS_PIPE = KCFX_CELLS_PIPE;
 #ifndef KCFX_TILE_K
 #define KCFX_TILE_K 2048
 #endif
@@ -133,6 +138,15 @@ constexpr int TILE_K = KCFX_TILE_K;   // k-mer start positions per tile (multipl
 constexpr int TILE_WORDS = TILE_K / 64;
 // per tile: TILE_WORDS valid-ballots then TILE_WORDS hit-ballots (screen kernel -> reduce_windows)
 constexpr int TILE_BITS_U64 = 2 * TILE_WORDS;
+
+// The sample-independent half of a cell-table look-up, worked out once per reference (launch_ref_plan, k = 19 .. 31):
+// 2-bit codes of the text (16 bases per dword, first base in the top bits) and one anchor byte per k-mer start position
+// (bit 7 valid, bits 4..1 twice the cell index, bit 0 "the canonical strand is the reverse complement"). Both arrays are
+// readable ref_plan_*_bytes(text_len) bytes and zero behind the text.
+struct RefPlan {
+    const uint32_t* codes = nullptr;
+    const uint8_t* anchors = nullptr;
+};
 
 struct TileDesc {
     int64_t text_off;    // offset of the tile's first base in the padded device text
@@ -278,13 +292,18 @@ hipError_t launch_cells_stash(const uint8_t* lines, int32_t k, int32_t lbits, in
 hipError_t launch_cohort_votes(const uint64_t* keys, uint32_t* counts, int64_t n, uint4* votes, uint32_t mask, int32_t phase, hipStream_t st);
 hipError_t launch_cohort_fill(TableView tv, int32_t k, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
                               int32_t sample, uint16_t* cell_counts, uint16_t* stash_counts, hipStream_t st);
-hipError_t launch_screen_cohort(const uint8_t* text, const TileDesc* tiles, int32_t n_tiles, CohortView cv, int32_t k,
+hipError_t launch_screen_cohort(const uint8_t* text, RefPlan plan, const TileDesc* tiles, int32_t n_tiles, CohortView cv, int32_t k,
                                 int32_t both_strands, int32_t min_count, uint64_t* bits, int64_t* count_sums, hipStream_t st,
                                 hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// the plan of a reference (RefPlan): `text` must be readable 128 bytes past text_len (zeros), the outputs sized as below
+size_t ref_plan_codes_bytes(int64_t text_len);
+size_t ref_plan_anchor_bytes(int64_t text_len);
+hipError_t launch_ref_plan(const uint8_t* text, int64_t text_len, int32_t k, uint32_t* codes, uint8_t* anchors, hipStream_t st);
 // lookup
 hipError_t launch_lookup(TableView tv, int32_t k, const uint64_t* keys, int64_t n, int32_t* counts_out, hipStream_t st);
 // screen
-hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32_t n_tiles, TableView tv, int32_t k,
+// (plan: what kcfx_ref_create prepared for cell tables -- null members: the kernels work from the text)
+hipError_t launch_screen_tiles(const uint8_t* text, RefPlan plan, const TileDesc* tiles, int32_t n_tiles, TableView tv, int32_t k,
                                int32_t both_strands, int32_t min_count, uint64_t* bits, int64_t* count_sums,
                                hipStream_t st, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // hit bitmaps + count sums of n_samples consecutive samples -> kcfx_result per (sample, window)

@@ -1234,8 +1234,8 @@ __device__ __forceinline__ void cells_match(const CellWord& cw, int32_t lbits, u
 
 // the k-mer as the database stores it -- canonical (Kmer.java:72-79), or as the text reads it in a forward-only database
 // (Kmer.java:57-65) -- at packed position q of the tile, from the interleaved code words
-template <int K, bool BOTH>
-__device__ __forceinline__ uint64_t k31_canonical_at(const K31Pack& sh, int q) {
+template <int K, bool BOTH, class Lds>
+__device__ __forceinline__ uint64_t k31_canonical_at(const Lds& sh, int q) {
     constexpr uint32_t lo_mask = ~0u << (64 - 2 * K);
     const int b0 = 2 * q - 1;
     const uint2* p = sh.fcx + 1 + (b0 >> 5);
@@ -1246,10 +1246,101 @@ __device__ __forceinline__ uint64_t k31_canonical_at(const K31Pack& sh, int q) {
     return (BOTH && rc < fwd) ? rc : fwd;
 }
 
+// ---- the planned reference ------------------------------------------------------------------------------------------
+// Which 16-mer of a reference k-mer is its minimizer, on which strand it is canonical and whether all k bases are A/C/G/T
+// does not depend on the sample: kcfx_ref_create works it out ONCE per reference (ref_plan_kernel: the pack phase, the
+// hashes, the sliding minimum of K31Words) and keeps, beside the text,
+//   codes    2 bits per base, 16 bases per dword, first base in the top bits (what the pack phase used to rebuild in LDS
+//            for every tile of every launch), and
+//   anchors  one byte per k-mer start position: bit 7 = the k-mer is valid, bits 4..1 = 2 * (the cell index: the minimizer's
+//            offset in N), bit 0 = N is the reverse complement of the text's k-mer (cell_probe_of's sh and flip).
+// A screening launch then copies a tile's codes and anchors into LDS and starts at the flank: no ASCII, no hashes, no scans,
+// no cross-lane traffic in the word loop -- ~30 VALU instructions per word instead of 53 before the cell loads are issued,
+// and a minimizer ORDER of any cost (kcfx_device.h: cell_order27) is free for the launches that follow.
+struct K31Plan {
+    static_assert(2 * (MAX_CHUNKS + 2) > ((2 * (31 + TILE_K - 1) + 31) >> 5) + 4, "code arrays too short for unclamped reads");
+    __attribute__((aligned(8))) uint2 fcx[2 * (MAX_CHUNKS + 2) + 1];   // as K31Pack::fcx ([0] is the lead word)
+    __attribute__((aligned(16))) uint4 an[(32 + TILE_K + 15) / 16 + 1]; // anchor bytes of the tile from its 32-aligned start
+    int64_t sum[WAVES];
+};
+
+// phase 1 of a planned launch: codes (+ their complement-swapped twin) and anchor bytes of the tile into LDS; returns `off`
+template <int NT>
+__device__ __forceinline__ int k31_load_plan_tile(K31Plan& sh, const RefPlan& plan, const TileDesc& td, int k, int tid) {
+    const int64_t a0 = td.text_off & ~(int64_t)31;
+    const int off = (int)(td.text_off - a0);
+    const int nbases = off + td.n_kmers + k - 1;
+    const int nchunks = (nbases + 31) >> 5;
+    uint2* const s_fc = sh.fcx + 1;
+    if (tid == 0) sh.fcx[0] = make_uint2(0u, 0u);
+    const uint2* const codes = reinterpret_cast<const uint2*>(plan.codes) + (a0 >> 5);       // 32 bases = 8 bytes
+    for (int c = tid; c < nchunks + 2; c += NT) {
+        const uint2 x = codes[c];
+        s_fc[2 * c] = make_uint2(x.x, comp_swap(x.x));
+        s_fc[2 * c + 1] = make_uint2(x.y, comp_swap(x.y));
+    }
+    const uint4* const an = reinterpret_cast<const uint4*>(plan.anchors + a0);
+    const int n16 = (off + td.n_kmers + 15) >> 4;
+    for (int c = tid; c < n16; c += NT) sh.an[c] = an[c];
+    __syncthreads();
+    return off;
+}
+
+// The words of a tile from a planned reference: N (the strand of the k-mer on which its minimizer is canonical), 2 * the
+// minimizer's offset there, the flip mask, validity. Nothing is carried between words but two LDS addresses.
+template <int K>
+struct PlannedWords {
+    const uint2* p_fc;          // entry holding bit 2q - 1 of this lane's position q in the current word
+    const int8_t* p_an;         // this lane's anchor byte
+    uint32_t sh_fc;
+    int n_kmers;
+    __device__ __forceinline__ void start(const K31Plan& sh, int off, int n_kmers_, int lane, int w_begin) {
+        n_kmers = n_kmers_;
+        const int q = off + w_begin * 64 + lane;
+        const int b0 = 2 * q - 1;
+        p_fc = sh.fcx + 1 + (b0 >> 5);
+        sh_fc = 31u - (uint32_t)(b0 & 31);
+        p_an = reinterpret_cast<const int8_t*>(sh.an) + q;
+    }
+    __device__ __forceinline__ void next(int w, uint64_t& N, uint32_t& sh2, uint32_t& fm, uint64_t& V) {
+        constexpr uint32_t lo_mask = ~0u << (64 - 2 * K);
+        const uint2 x0 = p_fc[0], x1 = p_fc[1], x2 = p_fc[2];
+        const int32_t a = (int32_t)p_an[0];                  // sign-extended: valid <=> negative
+        const uint32_t f_hi = alignbit32(x0.x, x1.x, sh_fc);
+        const uint32_t c_hi = alignbit32(x0.y, x1.y, sh_fc);
+        const uint32_t f_lo = alignbit32(x1.x, x2.x, sh_fc) & lo_mask;
+        const uint32_t c_lo = alignbit32(x1.y, x2.y, sh_fc) & lo_mask;
+        // extract_kmer (kcfx_device.h): the k-mer as the text reads it (Kmer.java:232-252) and its reverse complement (:300-338)
+        const uint64_t rc = u64_of(brev32(c_hi), brev32(c_lo)) << (64 - 2 * K);
+        asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(fm) : "v"(a));  // all ones: N is the reverse complement
+        const uint32_t n_lo = (f_lo & ~fm) | ((uint32_t)rc & fm);            // v_bfi_b32
+        const uint32_t n_hi = (f_hi & ~fm) | ((uint32_t)(rc >> 32) & fm);
+        N = u64_of(n_lo, n_hi);
+        sh2 = (uint32_t)a & 30u;
+        const int rem = n_kmers - w * 64;
+        V = (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull)) & wave_ballot(a < 0);
+        p_fc += 4;
+        p_an += 64;
+    }
+};
+
+// cell_probe_of when the anchor byte has said where the minimizer sits (sh2 = 2 * its offset in N, fm = the flip mask)
+template <bool BOTH>
+__device__ __forceinline__ CellProbe cell_probe_planned(uint64_t N, uint32_t sh2, uint32_t fm, int32_t lbits) {
+    CellProbe p;
+    uint32_t cm;
+    p.w = cell_flank(N, sh2, 16, &cm);
+    const uint32_t g = cell_g32(cm);
+    p.sh = sh2;
+    p.line = g >> (32 - lbits);
+    p.r = (g & (0xFFFFFFFFu >> lbits)) | (BOTH ? 0u : (fm & CELL_R_FLIP));
+    return p;
+}
+
 // Stash lookups for the first min(qn, 64) queued k-mers (their keys are re-derived from the packed tile: the queue only
 // holds where they sit); returns the new qn.
-template <int K, bool BOTH>
-__device__ __forceinline__ int k31c_stash_round(const TableView& tv, const K31Pack& sh, K31CQueue& q, int lane, int qn, int pos0,
+template <int K, bool BOTH, class Lds>
+__device__ __forceinline__ int k31c_stash_round(const TableView& tv, const Lds& sh, K31CQueue& q, int lane, int qn, int pos0,
                                                 int32_t min_count, uint32_t& sum_acc, int64_t& big_acc) {
     const int nb = min(qn, 64), rest = qn - nb;
     const uint32_t id = q.id[lane];
@@ -1267,16 +1358,19 @@ __device__ __forceinline__ int k31c_stash_round(const TableView& tv, const K31Pa
     return rest;
 }
 
-template <int K, bool BOTH>
+template <int K, bool BOTH, bool PLANNED>
 __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void screen_k31c_kernel(
-    const uint8_t* __restrict__ text, const TileDesc* __restrict__ tiles, TableView tv, int32_t min_count,
+    const uint8_t* __restrict__ text, RefPlan plan, const TileDesc* __restrict__ tiles, TableView tv, int32_t min_count,
     uint64_t* __restrict__ bits, int64_t* __restrict__ count_sums) {
     constexpr int WAVES = CELLS_WAVES;                      // (this kernel's own workgroup shape: kcfx_internal.h)
-    __shared__ K31Pack sh;
+    using Lds = typename std::conditional<PLANNED, K31Plan, K31Pack>::type;
+    __shared__ Lds sh;
     __shared__ K31CQueue s_queue[WAVES];
     const TileDesc td = tiles[blockIdx.x];
     const int tid = threadIdx.x;
-    const int off = k31_pack_tile<CELLS_BLOCK>(sh, text, td, tid);
+    int off;
+    if constexpr (PLANNED) off = k31_load_plan_tile<CELLS_BLOCK>(sh, plan, td, K, tid);
+    else off = k31_pack_tile<CELLS_BLOCK>(sh, text, td, tid);
 
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_words = (td.n_kmers + 63) >> 6;
@@ -1290,16 +1384,23 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
     uint32_t sum_acc = 0;                                   // per lane; u16 counters: fits (static_assert in screen_k31_kernel)
     int64_t big_acc = 0;                                    // counters beyond 16 bits come from the stash only, rarely
     uint64_t* my_bits = bits + (size_t)blockIdx.x * TILE_BITS_U64;
-    K31Words<true, K> words;
+    typename std::conditional<PLANNED, PlannedWords<K>, K31Words<true, K>>::type words;
     if (w_begin < w_end) words.start(sh, off, td.n_kmers, lane, w_begin);
 
-    // stage A of word w: keys, minimizer, cell, run list (the run lists of consecutive words alternate), fetches issued
+    // stage A of word w: keys, minimizer, cell, fetches issued
     auto issue = [&](int w, CellWord& cw) {
-        uint64_t fwd, rc, V;
-        uint32_t mn;
-        words.next(w, fwd, rc, mn, V);
-        const CellProbe p = cell_probe_of(fwd, rc, mn, 2u * (uint32_t)lane, tv.lbits, cell_mlen(K), BOTH, cell_nw(K));
-        cells_issue<cell_nw(K), BOTH>(tv, V, p, cw);
+        if constexpr (PLANNED) {
+            uint64_t N, V;
+            uint32_t sh2, fm;
+            words.next(w, N, sh2, fm, V);
+            cells_issue<cell_nw(K), BOTH>(tv, V, cell_probe_planned<BOTH>(N, sh2, fm, tv.lbits), cw);
+        } else {
+            uint64_t fwd, rc, V;
+            uint32_t mn;
+            words.next(w, fwd, rc, mn, V);
+            const CellProbe p = cell_probe_of(fwd, rc, mn, 2u * (uint32_t)lane, tv.lbits, cell_mlen(K), BOTH, cell_nw(K));
+            cells_issue<cell_nw(K), BOTH>(tv, V, p, cw);
+        }
     };
     // stage B of word w: cells matched, ballots out, stash candidates queued
     auto retire = [&](int w, const CellWord& cw) {
@@ -1323,25 +1424,27 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
         wave_lds_fence();
         while (qn >= 64) qn = k31c_stash_round<K, BOTH>(tv, sh, q, lane, qn, pos0, min_count, sum_acc, big_acc);
     };
-    // Two words per trip so that the two CellWords stay in fixed registers; the steady-state trip has no condition around
-    // an issue (see cells_issue), the last one or two words are peeled.
-    CellWord a, b;
-    int w = w_begin;
-    if (w < w_end) {
-        issue(w, a);
-        for (; w + 2 < w_end; w += 2) {
-            issue(w + 1, b);
-            retire(w, a);
-            issue(w + 2, a);
-            retire(w + 1, b);
+    // D words of cell loads in flight per wave (CELLS_PIPE): a ring of D CellWords in fixed registers -- the loop is unrolled D
+    // times -- and no condition around an issue in the steady state (see cells_issue); the first D - 1 issues and the last
+    // <= 2 D - 2 words are peeled (there a skipped issue makes the compiler wait for everything in flight, which by then is old).
+    // D = 2, 3, 4, 6 measure the same (profiles/r03_notes.md): what a CU's L1 and HBM have in flight does not depend on it.
+    constexpr int D = CELLS_PIPE;
+    CellWord cw[D];
+    int base = w_begin;
+#pragma unroll
+    for (int i = 0; i < D - 1; ++i)
+        if (w_begin + i < w_end) issue(w_begin + i, cw[i]);
+    for (; base + 2 * D - 2 < w_end; base += D) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            issue(base + i + D - 1, cw[(i + D - 1) % D]);
+            retire(base + i, cw[i]);
         }
-        if (w + 1 < w_end) {
-            issue(w + 1, b);
-            retire(w, a);
-            retire(w + 1, b);
-        } else {
-            retire(w, a);
-        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * D - 2; ++i) {
+        if (base + i + D - 1 < w_end) issue(base + i + D - 1, cw[(i + D - 1) % D]);
+        if (base + i < w_end) retire(base + i, cw[i % D]);
     }
     while (qn > 0) qn = k31c_stash_round<K, BOTH>(tv, sh, q, lane, qn, pos0, min_count, sum_acc, big_acc);
     if (lane < w_end - w_begin) {                           // the wave's words of the window's bitmap
@@ -1392,13 +1495,14 @@ typedef const __attribute__((address_space(1))) u32x2* gcell_ptr_t;
 typedef u32x4_ u32x4;
 typedef const __attribute__((address_space(1))) u32x4* gcount_ptr_t;
 
-template <int K, bool BOTH>
+template <int K, bool BOTH, bool PLANNED>
 __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) void screen_cohort_kernel(
-    const uint8_t* __restrict__ text, const TileDesc* __restrict__ tiles, int32_t n_tiles, CohortView cv, int32_t min_count,
+    const uint8_t* __restrict__ text, RefPlan plan, const TileDesc* __restrict__ tiles, int32_t n_tiles, CohortView cv, int32_t min_count,
     uint64_t* __restrict__ bits, int64_t* __restrict__ count_sums) {
     constexpr int W = cell_nw(K);                           // 16-mers per k-mer = cells of a line a k-mer can sit in
     constexpr int WAVES = CELLS_WAVES;
-    __shared__ K31Pack sh;
+    using Lds = typename std::conditional<PLANNED, K31Plan, K31Pack>::type;
+    __shared__ Lds sh;
     __shared__ CohortQueue s_queue[WAVES];
     __shared__ uint32_t s_sums[WAVES][COHORT_STRIDE];
     const TableView& tv = cv.tv;
@@ -1409,7 +1513,9 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 
     CohortQueue& q = s_queue[wave];
     // the hit words are OR-ed into (the stash may add a k-mer's bits before or after its word's own ballots arrive)
     for (int i = lane; i < COHORT_STRIDE * CELLS_WORDS_PER_WAVE; i += 64) (&q.hit[0][0])[i] = 0ull;
-    const int off = k31_pack_tile<CELLS_BLOCK>(sh, text, td, tid);        // (its barrier also orders the zeroing above)
+    int off;                                                               // (the barrier inside also orders the zeroing above)
+    if constexpr (PLANNED) off = k31_load_plan_tile<CELLS_BLOCK>(sh, plan, td, K, tid);
+    else off = k31_pack_tile<CELLS_BLOCK>(sh, text, td, tid);
 
     const int n_words = (td.n_kmers + 63) >> 6;
     const int wpw = (n_words + WAVES - 1) / WAVES;
@@ -1420,7 +1526,7 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 
     uint32_t sum[COHORT_STRIDE];
 #pragma unroll
     for (int s = 0; s < COHORT_STRIDE; ++s) sum[s] = 0;
-    K31Words<true, K> words;
+    typename std::conditional<PLANNED, PlannedWords<K>, K31Words<true, K>>::type words;
     if (w_begin < w_end) words.start(sh, off, td.n_kmers, lane, w_begin);
     const uint8_t* const count_base = reinterpret_cast<const uint8_t*>(cv.counts);
 
@@ -1431,10 +1537,19 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 
     };
     // stage 1: keys, minimizer, cell -> the two cell loads (cells_issue of screen_k31c, keeping the cell's offset for stage 2)
     auto issue = [&](int w, CohortKeys& kw) {
-        uint64_t fwd, rc, V;
-        uint32_t mn;
-        words.next(w, fwd, rc, mn, V);
-        const CellProbe p = cell_probe_of(fwd, rc, mn, 2u * (uint32_t)lane, tv.lbits, 16, BOTH, W);
+        uint64_t V;
+        CellProbe p;
+        if constexpr (PLANNED) {
+            uint64_t N;
+            uint32_t sh2, fm;
+            words.next(w, N, sh2, fm, V);
+            p = cell_probe_planned<BOTH>(N, sh2, fm, tv.lbits);
+        } else {
+            uint64_t fwd, rc;
+            uint32_t mn;
+            words.next(w, fwd, rc, mn, V);
+            p = cell_probe_of(fwd, rc, mn, 2u * (uint32_t)lane, tv.lbits, 16, BOTH, W);
+        }
         const bool valid = __builtin_amdgcn_inverse_ballot_w64(V);
         kw.V = V;
         kw.w = p.w;
@@ -1584,6 +1699,48 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 
 #pragma unroll
         for (int i = 0; i < WAVES; ++i) t += s_sums[i][tid];
         count_sums[(size_t)tid * n_tiles + blockIdx.x] = (int64_t)t;
+    }
+}
+
+// ---- kcfx_ref_create: the plan of a reference (see K31Plan) ---------------------------------------------------------
+// One workgroup per TILE_K consecutive text positions: the pack phase and the word walk of the unplanned screening kernel,
+// with the anchor byte written where that kernel would have probed. Positions whose k-mer runs past the text read the zero
+// padding behind it and come out invalid.
+template <int K>
+__global__ __launch_bounds__(CELLS_BLOCK) void ref_plan_kernel(const uint8_t* __restrict__ text, int64_t text_len,
+                                                               uint32_t* __restrict__ codes, uint8_t* __restrict__ anchors) {
+    constexpr int WAVES = CELLS_WAVES, W = cell_nw(K);
+    __shared__ K31Pack sh;
+    TileDesc td;
+    td.text_off = (int64_t)blockIdx.x * TILE_K;
+    td.n_kmers = (int32_t)min((int64_t)TILE_K, text_len - td.text_off);
+    td.window = 0;
+    const int tid = threadIdx.x;
+    const int off = k31_pack_tile<CELLS_BLOCK>(sh, text, td, tid);             // (0: tiles start on multiples of TILE_K)
+    // the tile's own 32-base chunks of codes (what lies behind the text stays zero: kcfx_ref_create clears the array)
+    for (int c = tid; c < TILE_K / 32; c += CELLS_BLOCK) {
+        uint2 v = make_uint2(0u, 0u);
+        if (32 * c < td.n_kmers) v = make_uint2(sh.fcx[1 + 2 * c].x, sh.fcx[2 + 2 * c].x);
+        reinterpret_cast<uint2*>(codes)[(td.text_off >> 5) + c] = v;
+    }
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_words = (td.n_kmers + 63) >> 6;
+    const int wpw = (n_words + WAVES - 1) / WAVES;
+    const int w_begin = min(wave * wpw, n_words);
+    const int w_end = min(w_begin + wpw, n_words);
+    if (w_begin >= w_end) return;
+    K31Words<true, K> words;
+    words.start(sh, off, td.n_kmers, lane, w_begin);
+    for (int w = w_begin; w < w_end; ++w) {
+        uint64_t fwd, rc, V;
+        uint32_t mn;
+        words.next(w, fwd, rc, mn, V);
+        // cell_probe_of's sh and flip
+        const bool flip = (mn & 1u) != 0u;
+        uint32_t sh2 = (mn - 2u * (uint32_t)lane) & 30u;
+        sh2 = flip ? 2u * (uint32_t)(W - 1) - sh2 : sh2;
+        const bool valid = __builtin_amdgcn_inverse_ballot_w64(V);
+        anchors[td.text_off + w * 64 + lane] = (uint8_t)((valid ? 0x80u : 0u) | sh2 | (flip ? 1u : 0u));
     }
 }
 
@@ -1966,7 +2123,34 @@ hipError_t launch_reduce_windows(const TileDesc* tiles, int32_t n_tiles, int32_t
     return hipGetLastError();
 }
 
-hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32_t n_tiles, TableView tv, int32_t k,
+// whole tiles of TILE_K positions + what a screening tile reads past its last k-mer (two code chunks, one 16-byte anchor piece)
+size_t ref_plan_codes_bytes(int64_t text_len) { return (size_t)((text_len + TILE_K - 1) / TILE_K * TILE_K + 256) / 4; }
+size_t ref_plan_anchor_bytes(int64_t text_len) { return (size_t)((text_len + TILE_K - 1) / TILE_K * TILE_K + 128); }
+hipError_t launch_ref_plan(const uint8_t* text, int64_t text_len, int32_t k, uint32_t* codes, uint8_t* anchors, hipStream_t st) {
+    if (text_len <= 0) return hipSuccess;
+    const dim3 g((unsigned)((text_len + TILE_K - 1) / TILE_K)), b(CELLS_BLOCK);
+#define KCFX_LAUNCHP(KK) hipLaunchKernelGGL((ref_plan_kernel<KK>), g, b, 0, st, text, text_len, codes, anchors)
+    switch (k) {
+        case 19: KCFX_LAUNCHP(19); break;
+        case 20: KCFX_LAUNCHP(20); break;
+        case 21: KCFX_LAUNCHP(21); break;
+        case 22: KCFX_LAUNCHP(22); break;
+        case 23: KCFX_LAUNCHP(23); break;
+        case 24: KCFX_LAUNCHP(24); break;
+        case 25: KCFX_LAUNCHP(25); break;
+        case 26: KCFX_LAUNCHP(26); break;
+        case 27: KCFX_LAUNCHP(27); break;
+        case 28: KCFX_LAUNCHP(28); break;
+        case 29: KCFX_LAUNCHP(29); break;
+        case 30: KCFX_LAUNCHP(30); break;
+        case 31: KCFX_LAUNCHP(31); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef KCFX_LAUNCHP
+    return hipGetLastError();
+}
+
+hipError_t launch_screen_tiles(const uint8_t* text, RefPlan plan, const TileDesc* tiles, int32_t n_tiles, TableView tv, int32_t k,
                                int32_t both_strands, int32_t min_count, uint64_t* bits, int64_t* count_sums,
                                hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (n_tiles <= 0) return hipSuccess;
@@ -1979,12 +2163,12 @@ hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32
     hipExtLaunchKernelGGL((screen_k31_kernel<W, BS>), g, b, 0, st, ev_start, ev_stop, 0, text, tiles, tv, min_count, bits, count_sums)
     const bool generic_only = tv.generic != 0;                                      // A/B and test hook, fixed at kcfx_db_open
     if (tv.fmt == FORMAT_CELLS) {
-#define KCFX_LAUNCHC(KK)                                                                                                                  \
-    do {                                                                                                                                  \
-        if (both_strands)                                                                                                                 \
-            hipExtLaunchKernelGGL((screen_k31c_kernel<KK, true>), g, bc, 0, st, ev_start, ev_stop, 0, text, tiles, tv, min_count, bits, count_sums);  \
-        else                                                                                                                              \
-            hipExtLaunchKernelGGL((screen_k31c_kernel<KK, false>), g, bc, 0, st, ev_start, ev_stop, 0, text, tiles, tv, min_count, bits, count_sums); \
+#define KCFX_LAUNCHC1(KK, BS, PL) \
+    hipExtLaunchKernelGGL((screen_k31c_kernel<KK, BS, PL>), g, bc, 0, st, ev_start, ev_stop, 0, text, plan, tiles, tv, min_count, bits, count_sums)
+#define KCFX_LAUNCHC(KK)                                                                  \
+    do {                                                                                  \
+        if (plan.codes) { if (both_strands) KCFX_LAUNCHC1(KK, true, true); else KCFX_LAUNCHC1(KK, false, true); }   \
+        else            { if (both_strands) KCFX_LAUNCHC1(KK, true, false); else KCFX_LAUNCHC1(KK, false, false); } \
     } while (0)
         switch (k) {
             case 19: KCFX_LAUNCHC(19); break;
@@ -2003,6 +2187,7 @@ hipError_t launch_screen_tiles(const uint8_t* text, const TileDesc* tiles, int32
             default: return hipErrorInvalidValue;
         }
 #undef KCFX_LAUNCHC
+#undef KCFX_LAUNCHC1
     } else if (tv.mode == MODE_MINIMIZER && k == 31 && tv.mm_len == 16 && !generic_only) {
         if (tv.wide) { if (both_strands) KCFX_LAUNCH31(true, true); else KCFX_LAUNCH31(true, false); }
         else         { if (both_strands) KCFX_LAUNCH31(false, true); else KCFX_LAUNCH31(false, false); }
@@ -2033,18 +2218,18 @@ hipError_t launch_cohort_fill(TableView tv, int32_t k, int32_t both, const uint6
     return hipGetLastError();
 }
 
-hipError_t launch_screen_cohort(const uint8_t* text, const TileDesc* tiles, int32_t n_tiles, CohortView cv, int32_t k,
+hipError_t launch_screen_cohort(const uint8_t* text, RefPlan plan, const TileDesc* tiles, int32_t n_tiles, CohortView cv, int32_t k,
                                 int32_t both_strands, int32_t min_count, uint64_t* bits, int64_t* count_sums, hipStream_t st,
                                 hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (n_tiles <= 0 || cv.n_samples <= 0) return hipSuccess;
     if (cv.n_samples > COHORT_STRIDE || cv.tv.fmt != FORMAT_CELLS) return hipErrorInvalidValue;
     const dim3 g(n_tiles), b(CELLS_BLOCK);
-#define KCFX_LAUNCHCO(KK)                                                                                                                  \
-    do {                                                                                                                                  \
-        if (both_strands)                                                                                                                 \
-            hipExtLaunchKernelGGL((screen_cohort_kernel<KK, true>), g, b, 0, st, ev_start, ev_stop, 0, text, tiles, n_tiles, cv, min_count, bits, count_sums);  \
-        else                                                                                                                              \
-            hipExtLaunchKernelGGL((screen_cohort_kernel<KK, false>), g, b, 0, st, ev_start, ev_stop, 0, text, tiles, n_tiles, cv, min_count, bits, count_sums); \
+#define KCFX_LAUNCHCO1(KK, BS, PL) \
+    hipExtLaunchKernelGGL((screen_cohort_kernel<KK, BS, PL>), g, b, 0, st, ev_start, ev_stop, 0, text, plan, tiles, n_tiles, cv, min_count, bits, count_sums)
+#define KCFX_LAUNCHCO(KK)                                                                  \
+    do {                                                                                   \
+        if (plan.codes) { if (both_strands) KCFX_LAUNCHCO1(KK, true, true); else KCFX_LAUNCHCO1(KK, false, true); }   \
+        else            { if (both_strands) KCFX_LAUNCHCO1(KK, true, false); else KCFX_LAUNCHCO1(KK, false, false); } \
     } while (0)
     switch (k) {                                            // every k a cell table exists for
         case 19: KCFX_LAUNCHCO(19); break;
@@ -2063,6 +2248,7 @@ hipError_t launch_screen_cohort(const uint8_t* text, const TileDesc* tiles, int3
         default: return hipErrorInvalidValue;
     }
 #undef KCFX_LAUNCHCO
+#undef KCFX_LAUNCHCO1
     return hipGetLastError();
 }
 

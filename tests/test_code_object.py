@@ -35,15 +35,17 @@ def kernels(tmp_path_factory):
 
 def test_screening_kernels_do_not_spill_and_fit_their_occupancy(kernels):
     hot = {n: m for n, m in kernels.items() if re.search(r"screen_k31c_kernel|screen_k31_kernel|screen_k31_multi|screen_tiles_kernel|reduce_windows", n)}
-    # k = 19 .. 31 x canonical / forward-only, the line-table kernels, the general kernel, the reduction
-    assert sum("screen_k31c_kernel" in n for n in hot) == 26 and len(hot) >= 36
+    # k = 19 .. 31 x canonical / forward-only x planned / text-only reference, the line-table kernels, the general kernel, the reduction
+    assert sum("screen_k31c_kernel" in n for n in hot) == 52 and len(hot) >= 62
     for name, m in hot.items():
         assert m["private_segment_fixed_size"] == 0, (name, m)           # no scratch
         # 8 waves per SIMD; the multi-sample line-table kernel is planned for 6 (amdgpu_waves_per_eu(6, 8): <= 80 VGPRs)
         assert m["vgpr_count"] <= (80 if "screen_k31_multi" in name else 64), (name, m)
     for name, m in hot.items():
         if "screen_k31c_kernel" in name:
-            assert m["vgpr_count"] <= 48 and m["group_segment_fixed_size"] <= 8192, (name, m)
+            planned = re.search(r"screen_k31c_kernelILi\d+ELb[01]ELb1E", name) is not None      # <K, BOTH, PLANNED = true>
+            # (the text-only form -- KCFX_REF_PLAN=0, an A/B hook -- derives the minimizer order in the word loop: 64 is its bound)
+            assert m["vgpr_count"] <= (48 if planned else 64) and m["group_segment_fixed_size"] <= 8192, (name, m)
         elif "screen_" in name:
             assert m["group_segment_fixed_size"] <= 20480, (name, m)     # 160 KB LDS per CU / 8 workgroups
 

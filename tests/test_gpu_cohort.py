@@ -36,7 +36,7 @@ def check(cohort_rows, prefixes, ref_text, s, lens, min_count, oracle, what):
 
 
 @pytest.mark.parametrize("n_samples", [1, 3, 8])
-def test_cohort_rows_equal_the_single_sample_screens(oracle, tmp_path, n_samples):
+def test_cohort_rows_equal_the_single_sample_screens(oracle, tmp_path, monkeypatch, n_samples):
     ref = synth.random_reference(400_000, 31, n_run_every=40_000, max_n_run=300)
     prefixes = [make_sample(tmp_path, f"s{i}", ref, 100 + 7 * i, cs=1 + (i % 2), noise=2000 + 900 * i,
                             sub_rate=0.004 * (1 + i % 4)) for i in range(n_samples)]
@@ -51,6 +51,14 @@ def test_cohort_rows_equal_the_single_sample_screens(oracle, tmp_path, n_samples
         check(got, prefixes, ref, s, lens, c, oracle, f"S={n_samples} -c {c}")
     if n_samples > 1:
         assert len({int(got[i]["obs"].sum()) for i in range(n_samples)}) > 1       # the samples do differ
+    # the same from a reference without a plan (KCFX_REF_PLAN=0: the kernel derives minimizers from the text per launch)
+    monkeypatch.setenv("KCFX_REF_PLAN", "0")
+    r_text = engine.Reference(ref, s, lens, K)
+    monkeypatch.delenv("KCFX_REF_PLAN")
+    got_text = co.screen(r_text, 2)
+    got_plan = co.screen(r, 2)
+    for f in FIELDS:
+        assert np.array_equal(got_text[f], got_plan[f]), ("planned vs text-only reference", f)
     # irregular windows (gene-model-like: 0 bp .. 40 kbp, overlapping, some shorter than k)
     rng = np.random.default_rng(5)
     wb = np.sort(rng.integers(0, len(ref) - 40_000, 300)).astype(np.int64)

@@ -549,20 +549,24 @@ def test_multi_sample_pass_equals_single_sample_passes(oracle, tmp_path):
         r.screen_multi(dbs[:2], 0)
 
 
-@pytest.mark.parametrize("kernel", ["default", "lines", "generic"])
+@pytest.mark.parametrize("kernel", ["default", "lines", "generic", "text"])
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("KCFX_FUZZ_SEEDS", "6"))))   # soak: KCFX_FUZZ_SEEDS=200
 def test_fuzz_window_geometry_against_oracle(oracle, tmp_path, seed, kernel, monkeypatch):
     """Random databases x windows whose lengths sit on the kernel's internal borders (k-mer count 0 / 1 / 63 / 64 / 65,
     one tile +-1, several tiles +-1, word-aligned and not), random offsets (every alignment of the 32-base pack chunks),
-    N runs crossing window and tile borders, soft-masked stretches. k = 27 .. 31 runs screen_k31c_kernel on a cell table
-    ("lines" forces screen_k31_kernel on a 12-slot line table, "generic" the general screen_tiles_kernel); both strandedness and all counter widths come up over the seeds."""
+    N runs crossing window and tile borders, soft-masked stretches. k = 19 .. 31 runs screen_k31c_kernel on a cell table, from the
+    planned reference ("default") or from the text alone ("text"); "lines" forces screen_k31_kernel on a 12-slot line table, "generic"
+    the general screen_tiles_kernel; both strandedness and all counter widths come up over the seeds."""
     if kernel == "generic":
         monkeypatch.setenv("KCFX_GENERIC_KERNEL", "1")
     if kernel == "lines":
         monkeypatch.setenv("KCFX_TABLE_FORMAT", "lines")
+    if kernel == "text":                    # a cell table screened from the text alone: no reference plan (kcfx_ref_create reads this)
+        monkeypatch.setenv("KCFX_REF_PLAN", "0")
     rng = np.random.default_rng(1000 + seed)
     # the cell-table kernel exists for k = 19 .. 31
-    k = (31, 29, 25, 30, 27, 28, 31, 23, 26, 24, 21, 19, 22, 20)[seed % 14] if kernel == "default" else 31
+    cells = kernel in ("default", "text")
+    k = (31, 29, 25, 30, 27, 28, 31, 23, 26, 24, 21, 19, 22, 20)[(seed + (5 if kernel == "text" else 0)) % 14] if cells else 31
     L = 180_000
     ref = bytearray(synth.random_reference(L, 500 + seed))
     for _ in range(25):
@@ -576,7 +580,7 @@ def test_fuzz_window_geometry_against_oracle(oracle, tmp_path, seed, kernel, mon
     cs = int(rng.choice([1, 2, 4]))
     both = bool(rng.integers(0, 2))
     noise = 5_000
-    if kernel == "default":                 # always the cell table; all counter widths, canonical and forward-only
+    if cells:                               # always the cell table; all counter widths, canonical and forward-only
         cs, both = 1 + seed % 4, (seed // 2) % 3 != 0
         if seed % 3 == 1:                   # a crowded table: 2^17 (2^18) lines for ~1.4 M k-mers, most of them in second choices / the stash
             monkeypatch.setenv("KCFX_TABLE_LBITS", "17" if both else "18")
@@ -587,7 +591,7 @@ def test_fuzz_window_geometry_against_oracle(oracle, tmp_path, seed, kernel, mon
     p_of_k = {31: int(rng.choice([3, 7])), 30: 2, 29: 5, 28: 4, 27: 3, 26: 6, 25: 5, 24: 4, 23: 3, 22: 2, 21: 5, 20: 4, 19: 3}
     prefix, *_ = make_db(tmp_path, "fz", ref, 300 + seed, k=k, p=p_of_k[k], cs=cs, m=7, bins=4, both=both, noise=noise)
     db = engine.KmcDb.open(prefix)
-    assert db.info.table_format == (1 if kernel == "default" else 0)
+    assert db.info.table_format == (1 if cells else 0)
     odb = oracle.OracleDb(prefix)
     tile = 2048
     kmers = [0, 1, 2, 62, 63, 64, 65, 127, 128, 129, tile - 1, tile, tile + 1, tile + 63, tile + 64, 2 * tile - 1, 2 * tile,
@@ -640,3 +644,32 @@ def test_async_entry_point_is_graph_capturable(oracle, tmp_path):
     got2 = out2.cpu().numpy().view(engine.RESULT_DTYPE).reshape(3, len(s))
     for i in range(3):
         assert_same(got2[i], want2[i], f"graph replay, sample {i}")
+
+
+@pytest.mark.parametrize("k,both", [(31, True), (31, False), (25, True), (19, False)])
+def test_planned_reference_and_text_only_reference_agree(oracle, tmp_path, monkeypatch, k, both):
+    """kcfx_ref_create works the sample-independent half of a cell-table look-up out once (2-bit codes + one anchor byte per
+    k-mer: where its minimizer sits, on which strand, whether it is valid); KCFX_REF_PLAN=0 keeps the reference as text and the
+    kernel derives all of it per launch. Same windows, same tables: identical records, and identical to the oracle's -- at every
+    alignment of the text (the plan is laid out per text position, the tiles per window) and across N runs and the text's end."""
+    L = 150_000
+    ref = bytearray(synth.random_reference(L, 77 + k, n_run_every=11_000, max_n_run=300, lower_frac=0.2, iupac_rate=1e-3))
+    ref[-40:] = b"ACGTNNACGT" * 4                       # invalid bases inside the last k-mers of the text
+    ref = bytes(ref)
+    prefix, *_ = make_db(tmp_path, "pl", ref, 910 + k, k=k, p={31: 3, 25: 5, 19: 3}[k], cs=2, m=7, bins=4, both=both, noise=40_000,
+                         sub_rate=8e-3, indel_rate=1e-3)
+    db = engine.KmcDb.open(prefix)
+    assert db.info.table_format == 1
+    rng = np.random.default_rng(k)
+    lens = np.concatenate([rng.integers(1, 9000, 120), [L, k, k - 1, 2048 + k - 1, 2049 + k - 1, 64 + k - 1]]).astype(np.int32)
+    begins = np.array([int(rng.integers(0, L - int(n) + 1)) for n in lens], dtype=np.int64)
+    begins[-5:] = [L - int(n) for n in lens[-5:]]        # windows that end with the text
+    planned = engine.Reference(ref, begins, lens, k)
+    monkeypatch.setenv("KCFX_REF_PLAN", "0")
+    text_only = engine.Reference(ref, begins, lens, k)
+    monkeypatch.delenv("KCFX_REF_PLAN")
+    want = oracle.OracleDb(prefix).screen(ref, begins, lens, 1, threads=4)
+    for mc in (1, 2):
+        a, b = planned.screen(db, mc), text_only.screen(db, mc)
+        assert_same(a, b, f"planned vs text-only, -c {mc}")
+    assert_same(planned.screen(db, 1), want, "planned vs oracle")
