@@ -280,11 +280,10 @@ KCFX_HD uint32_t cell_g32(uint32_t cm) {
     return x * 0x27D4EB2Fu;
 }
 
-// Second choice: a k-mer that finds its cell taken may live in ONE other cell of the same line, 1, 3, .. 15 cells away
-// (xor) as its leading flank bits say; there it is stored with bit 15 of r set, so that it can never be mistaken for the
-// k-mer that has the same (w, r) and this cell as its first choice. sh = 2 * cell index.
+// Bit 15 of r: the entry does not sit in its first-choice cell. Such an entry can never be mistaken for the k-mer that has the
+// same (w, r) and this cell as its first choice. Two kinds, told apart by WHERE they sit (see CellAlt and cell_second_line):
+// cells W .. 15 of a line (k < 31) hold free-cell second choices, cells 0 .. W - 1 second-LINE entries.
 constexpr uint32_t CELL_R_ALT = 0x8000u;
-KCFX_HD uint32_t cell_alt_sh(uint32_t sh, uint32_t w) { return sh ^ (((w >> 27) & 0x1Cu) | 2u); }
 
 // The r field of a cell: bits 0 .. 31 - lbits carry the rest of G32, bit 15 the second-choice mark; the lbits - 17 bits in
 // between would be zero. In a cell that is flagged "someone who belongs here lives in the stash" they say WHO: every
@@ -337,34 +336,54 @@ struct CellProbe {
     uint32_t r;         // low 32 - lbits bits of G32
 };
 
-// Where a k-mer's second choice is, and what identifies it there. Two schemes:
-//  * xor (always possible): the cell 1, 3, .. 15 cells away (xor) that the leading flank bits name; the entry carries
-//    (w, r | ALT), and first = second ^ f(w) gives the first-choice cell back, so it is as exact as a first-choice entry;
-//  * free cells (k <= 30 and a table with >= 4 spare r bits): a k-mer spans W = k - 15 <= 15 minimizer positions, so cells
-//    W .. 15 of every line are nobody's FIRST choice -- the second choice goes there (which of them: the leading flank
-//    bits) and succeeds unless another loser of the same line took that cell. Such a cell does not say where its tenant came
-//    from, so the entry carries its first-choice cell index in 4 of the spare r bits (never used for a stash filter there:
-//    only first-choice cells are flagged). On the bench-sized k = 25 database this takes the stash from 1.8 % to 0.4 %.
+// Where a k-mer that lost the bid for its first-choice cell may live, in the order a query looks:
+//  * (k <= 30 and a table with >= 4 spare r bits) in a FREE CELL of the same line: a k-mer spans W = k - 15 <= 15 minimizer
+//    positions, so cells W .. 15 of every line are nobody's first choice -- which of them: the leading flank bits. Such a
+//    cell does not say where its tenant came from, so the entry carries its first-choice cell index in 4 of the spare r bits
+//    (never used for a filter there: only cells 0 .. W - 1 are flagged). Looked at in the main pass: same line, no request.
+//  * in its SECOND LINE (every k): the same cell index in the line a second mix of the minimizer names. All the losers of a
+//    minimizer move there together -- the k-mers of a locus whose minimizer 16-mer occurs at another locus too, or of a run that
+//    shares its line with another run (3 % of a genome's k-mers on the bench database) -- so the queued look-ups of a run's
+//    k-mers are ONE line request, where the stash costs one request per k-mer. The first-choice cell is flagged (with the
+//    k-mer's filter bit) so that a query knows to look on.
+//  * in the stash (then the first-choice AND the second-line cell are flagged).
 struct CellAlt {
-    uint32_t sh;        // 2 * index of the second-choice cell
+    uint32_t sh;        // 2 * index of the free cell
     uint32_t r;         // the r field an entry of this k-mer has there
     uint32_t rmask;     // the bits of r that identify it there
 };
-constexpr int CELL_ALT_FREE_MAX_W = 15;       // i.e. every k < 31: even the single free cell of k = 30 beats the xor scheme (stash 1.8 % -> 1.2 %)
+constexpr int CELL_ALT_FREE_MAX_W = 15;       // i.e. every k < 31: even the single free cell of k = 30 is worth having
 KCFX_HD bool cell_alt_free(int W, int32_t lbits, bool both) { return W <= CELL_ALT_FREE_MAX_W && cell_spare_bits(lbits, both) >= 4; }
+// (call only when cell_alt_free)
 KCFX_HD CellAlt cell_alt_of(uint32_t sh, uint32_t w, uint32_t r, int W, int32_t lbits, bool both) {
     CellAlt a;
-    if (cell_alt_free(W, lbits, both)) {
-        const uint32_t rb = (uint32_t)(32 - lbits);
-        a.sh = 2u * ((uint32_t)W + (((w >> 24) * (uint32_t)(16 - W)) >> 8));
-        a.r = r | CELL_R_ALT | ((sh >> 1) << rb);
-        a.rmask = cell_rmask(lbits, both) | (0xFu << rb);
-    } else {
-        a.sh = cell_alt_sh(sh, w);
-        a.r = r | CELL_R_ALT;
-        a.rmask = cell_rmask(lbits, both);
-    }
+    const uint32_t rb = (uint32_t)(32 - lbits);
+    a.sh = 2u * ((uint32_t)W + (((w >> 24) * (uint32_t)(16 - W)) >> 8));
+    a.r = r | CELL_R_ALT | ((sh >> 1) << rb);
+    a.rmask = cell_rmask(lbits, both) | (0xFu << rb);
     return a;
+}
+// G32 -> G32': another bijection of the minimizer (xorshifts and odd multiplies), so (second line, r there) identify it as
+// exactly as (line, r) do
+KCFX_HD uint32_t cell_g32b(uint32_t g) {
+    g ^= g >> 16;
+    g *= 0x7FEB352Du;
+    g ^= g >> 15;
+    g *= 0x846CA68Bu;
+    g ^= g >> 16;
+    return g;
+}
+// the second-line probe of a first-choice probe: same cell index and flank, line and r from G32', marked CELL_R_ALT
+// (compared under cell_rmask like a first-choice entry)
+KCFX_HD CellProbe cell_second_line(const CellProbe& p, int32_t lbits) {
+    const uint32_t idm = 0xFFFFFFFFu >> lbits;
+    const uint32_t g2 = cell_g32b((p.line << (32 - lbits)) | (p.r & idm));
+    CellProbe q;
+    q.line = g2 >> (32 - lbits);
+    q.sh = p.sh;
+    q.w = p.w;
+    q.r = (g2 & idm) | CELL_R_ALT | (p.r & CELL_R_FLIP & ~idm);    // (a canonical table of 2^17 lines has a G32 bit where FLIP would be)
+    return q;
 }
 
 // Query side, one lane: F / R = the k-mer as the text reads it and its reverse complement, mn = the tagged minimum over

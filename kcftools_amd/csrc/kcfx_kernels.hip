@@ -217,7 +217,10 @@ __device__ __forceinline__ bool cell_same(uint64_t have, uint64_t mine, uint64_t
     const uint64_t id = kc & 0x0000FFFFFFFFFFFFull;
     return (have >> 48) != 0 && (have & id) == (mine & id);
 }
-__host__ __device__ inline int cell_sub_bits(int32_t lbits) { return lbits <= 30 ? 2 : 32 - lbits; }
+// (all of G32: a sub-bucket is ONE minimizer. With line + 2 bits an isolated k-mer that shared the line of a genomic run was
+// classed with the run and, where its counter happened to be the larger, took the genomic k-mer's cell: 3.7 % of the bench
+// reference's hits came from the stash, 1.x % now -- profiles/r03_notes.md. 4 GiB of byte counters for the length of the build.)
+__host__ __device__ inline int cell_sub_bits(int32_t lbits) { return 32 - lbits; }
 __device__ __forceinline__ uint64_t cell_sub_bucket(const CellProbe& p, int32_t lbits) {
     const int sb = cell_sub_bits(lbits);
     // (r may carry CELL_R_FLIP above its 32 - lbits identifying bits: masked, or a forward-only database's reverse-strand k-mers
@@ -276,23 +279,31 @@ __global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__
     }
 }
 
-// where a k-mer stands after the bidding: in its first-choice cell, in its second-choice cell, or in neither
+// where a k-mer stands after the build passes so far: in its first-choice cell (0), in a free cell of the same line (1: k < 31,
+// cell_alt_free), in the same cell of its second line (2), or nowhere (STAND_NONE: the stash)
+constexpr int STAND_FIRST = 0, STAND_FREE = 1, STAND_SECOND_LINE = 2, STAND_NONE = 3;
 __device__ __forceinline__ int cell_standing(const uint8_t* lines, const CellProbe& p, uint32_t c, int32_t lbits, bool both, int W,
                                              int32_t presence = 0) {
-    const uint64_t kc = cell_keycount_mask(lbits, both);              // (flags and stash-filter bits are not part of the k-mer)
+    const uint64_t kc = cell_keycount_mask(lbits, both);              // (flags and filter bits are not part of the k-mer)
     const uint8_t* line = lines + (size_t)p.line * LINE_BYTES;
     const uint64_t first = __atomic_load_n(reinterpret_cast<const uint64_t*>(line + 4 * p.sh), __ATOMIC_RELAXED);
-    if (cell_same(first, cell_word(p.w, p.r, c), kc, presence)) return 0;
-    const CellAlt a = cell_alt_of(p.sh, p.w, p.r, W, lbits, both);
-    const uint64_t second = __atomic_load_n(reinterpret_cast<const uint64_t*>(line + 4 * a.sh), __ATOMIC_RELAXED);
-    if (cell_same(second, cell_word(p.w, a.r, c), 0xFFFF0000FFFFFFFCull | ((uint64_t)a.rmask << 32), presence)) return 1;
-    return 2;
+    if (cell_same(first, cell_word(p.w, p.r, c), kc, presence)) return STAND_FIRST;
+    if (cell_alt_free(W, lbits, both)) {
+        const CellAlt a = cell_alt_of(p.sh, p.w, p.r, W, lbits, both);
+        const uint64_t second = __atomic_load_n(reinterpret_cast<const uint64_t*>(line + 4 * a.sh), __ATOMIC_RELAXED);
+        if (cell_same(second, cell_word(p.w, a.r, c), 0xFFFF0000FFFFFFFCull | ((uint64_t)a.rmask << 32), presence)) return STAND_FREE;
+    }
+    const CellProbe q = cell_second_line(p, lbits);
+    const uint64_t there = __atomic_load_n(reinterpret_cast<const uint64_t*>(lines + (size_t)q.line * LINE_BYTES + 4 * q.sh), __ATOMIC_RELAXED);
+    if (cell_same(there, cell_word(q.w, q.r, c), kc, presence)) return STAND_SECOND_LINE;
+    return STAND_NONE;
 }
 
-// Pass 2 (after pass 1 has completed): a k-mer that lost a bid takes its second-choice cell if that is still empty (no
-// k-mer has it as first choice then), else it flags its first-choice cell -- "someone who belongs here lives in the
-// stash", and which filter bit that someone has (cell_filter_pos) -- and is counted. stats[0] = k-mers for the stash, [1] = k-mers stored (count != 0), [2] = k-mers with more
-// than one first-choice cell, [3] = second-choice placements
+// Pass 2 (after ALL bidding has completed): a k-mer that lost its bid takes, in this order, a free cell of its line (k < 31), the
+// same cell of its second line (flagging its first-choice cell: "someone who belongs here lives elsewhere", with its filter
+// bit, cell_filter_pos) -- each only if still empty -- or is counted for the stash (then the second-line cell is flagged
+// too). stats[0] = k-mers for the stash, [1] = k-mers stored (count != 0), [2] = k-mers with more than one first-choice cell,
+// [3] = k-mers placed outside their first-choice cell
 __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, int32_t both_i, const uint64_t* __restrict__ keys,
                                     const uint32_t* __restrict__ counts, int64_t n, unsigned long long* stats, int32_t presence) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -309,32 +320,44 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, in
             unsigned long long mark = CELL_FLAG_STASH;
             if (cell_spare_bits(lbits, both) > 0) mark |= 1ull << (32 + cell_filter_pos(p.w, lbits, both));
             if (wide) {
-                // never bid: every cell a query could derive for it is flagged (whoever lives there, or nobody), with its filter bit
+                // never bid: every cell a query could derive for it -- first choice and second line -- is flagged (whoever lives
+                // there, or nobody), with its filter bit
+                const CellProbe q = cell_second_line(p, lbits);
                 atomicOr(reinterpret_cast<unsigned long long*>(line + 4 * p.sh), mark);
+                atomicOr(reinterpret_cast<unsigned long long*>(lines + (size_t)q.line * LINE_BYTES + 4 * q.sh), mark);
                 lost = true;
                 return;
             }
-            if (cell_standing(lines, p, c, lbits, both, cell_nw(k), presence) != 2) return;     // (1: the same word twice in the input)
-            const CellAlt a = cell_alt_of(p.sh, p.w, p.r, cell_nw(k), lbits, both);
-            const unsigned long long kca = 0xFFFF0000FFFFFFFCull | ((unsigned long long)a.rmask << 32);
-            unsigned long long* alt = reinterpret_cast<unsigned long long*>(line + 4 * a.sh);
-            const unsigned long long mine = cell_word(p.w, a.r, c);
-            unsigned long long old = __atomic_load_n(alt, __ATOMIC_RELAXED);
-            bool won = false;
-            while ((old >> 48) == 0) {
-                const unsigned long long prev = atomicCAS(alt, old, mine | (old & ~kca));
-                if (prev == old) {
-                    won = true;
-                    break;
+            if (cell_standing(lines, p, c, lbits, both, cell_nw(k), presence) != STAND_NONE) return;   // (already placed: the same word twice in the input)
+            // an empty cell (count field 0: nobody's first choice landed there, no other loser took it) is taken with a CAS that
+            // keeps the flag and filter bits it may carry
+            auto take = [&](unsigned long long* cell, unsigned long long mine, unsigned long long kcm) -> bool {
+                unsigned long long old = __atomic_load_n(cell, __ATOMIC_RELAXED);
+                while ((old >> 48) == 0) {
+                    const unsigned long long prev = atomicCAS(cell, old, mine | (old & ~kcm));
+                    if (prev == old) return true;
+                    old = prev;
                 }
-                old = prev;
+                return cell_same(old, mine, kcm, presence);                   // (a copy of the same word got there first)
+            };
+            if (cell_alt_free(cell_nw(k), lbits, both)) {                    // k < 31: a free cell of the same line (looked at in the main pass)
+                const CellAlt a = cell_alt_of(p.sh, p.w, p.r, cell_nw(k), lbits, both);
+                if (take(reinterpret_cast<unsigned long long*>(line + 4 * a.sh), cell_word(p.w, a.r, c),
+                         0xFFFF0000FFFFFFFCull | ((unsigned long long)a.rmask << 32))) {
+                    ++n_second;
+                    return;
+                }
             }
-            if (won) {
+            // the same cell of its second line: the first-choice cell says "look on" (flag + filter bit)
+            const CellProbe q = cell_second_line(p, lbits);
+            unsigned long long* there = reinterpret_cast<unsigned long long*>(lines + (size_t)q.line * LINE_BYTES + 4 * q.sh);
+            atomicOr(reinterpret_cast<unsigned long long*>(line + 4 * p.sh), mark);
+            if (take(there, cell_word(q.w, q.r, c), cell_keycount_mask(lbits, both))) {
                 ++n_second;
-            } else if (!cell_same(old, mine, kca, presence)) {
-                atomicOr(reinterpret_cast<unsigned long long*>(line + 4 * p.sh), mark);
-                lost = true;
+                return;
             }
+            atomicOr(there, mark);                                           // ... and so does the second-line cell: the stash
+            lost = true;
         });
         n_lost += lost ? 1u : 0u;
         ++n_stored;
@@ -361,7 +384,7 @@ __global__ void cells_stash_kernel(const uint8_t* __restrict__ lines, int32_t k,
         const uint64_t key = keys[i];
         bool lost = c > CELL_COUNT_MAX;                 // (counters wider than a cell's 16 bits)
         if (!lost)
-            cells_visit(key, k, lbits, both != 0, [&](const CellProbe& p, int) { lost |= cell_standing(lines, p, c, lbits, both != 0, cell_nw(k), presence) == 2; });
+            cells_visit(key, k, lbits, both != 0, [&](const CellProbe& p, int) { lost |= cell_standing(lines, p, c, lbits, both != 0, cell_nw(k), presence) == STAND_NONE; });
         if (!lost) continue;
         uint32_t slot = stash_slot(key, mask);
         for (;;) {
@@ -406,17 +429,33 @@ __global__ __launch_bounds__(256) void lookup_cells_kernel(TableView tv, int32_t
             });
             const uint8_t* line = tv.lines + (size_t)c0.line * LINE_BYTES;
             const uint64_t first = *reinterpret_cast<const uint64_t*>(line + 4 * c0.sh);
-            const CellAlt a = cell_alt_of(c0.sh, c0.w, c0.r, cell_nw(k), tv.lbits, both);
-            const uint64_t second = *reinterpret_cast<const uint64_t*>(line + 4 * a.sh);
             const uint64_t KEY_BITS = cell_keycount_mask(tv.lbits, both) & 0x0000FFFFFFFFFFFFull;     // w without the flags, r without the filter
-            const uint64_t KEY_BITS_ALT = 0x00000000FFFFFFFCull | ((uint64_t)a.rmask << 32);
-            if (((first ^ cell_word(c0.w, c0.r, 0)) & KEY_BITS) == 0 && (first >> 48) != 0)
+            // "someone who belongs in this cell lives elsewhere" and, when the table has filter bits, "with my filter bit"
+            auto sent_on = [&](uint64_t cell) {
+                return (cell & CELL_FLAG_STASH) &&
+                       (cell_spare_bits(tv.lbits, both) == 0 || ((cell >> (32 + cell_filter_pos(c0.w, tv.lbits, both))) & 1));
+            };
+            bool found = false;
+            if (((first ^ cell_word(c0.w, c0.r, 0)) & KEY_BITS) == 0 && (first >> 48) != 0) {
                 result = (int32_t)(first >> 48);
-            else if (((second ^ cell_word(c0.w, a.r, 0)) & KEY_BITS_ALT) == 0 && (second >> 48) != 0)
-                result = (int32_t)(second >> 48);
-            else if ((first & CELL_FLAG_STASH) &&
-                     (cell_spare_bits(tv.lbits, both) == 0 || ((first >> (32 + cell_filter_pos(c0.w, tv.lbits, both))) & 1)))
-                result = (int32_t)stash_find(tv, key);
+                found = true;
+            } else if (cell_alt_free(cell_nw(k), tv.lbits, both)) {
+                const CellAlt a = cell_alt_of(c0.sh, c0.w, c0.r, cell_nw(k), tv.lbits, both);
+                const uint64_t second = *reinterpret_cast<const uint64_t*>(line + 4 * a.sh);
+                const uint64_t KEY_BITS_ALT = 0x00000000FFFFFFFCull | ((uint64_t)a.rmask << 32);
+                if (((second ^ cell_word(c0.w, a.r, 0)) & KEY_BITS_ALT) == 0 && (second >> 48) != 0) {
+                    result = (int32_t)(second >> 48);
+                    found = true;
+                }
+            }
+            if (!found && sent_on(first)) {
+                const CellProbe q = cell_second_line(c0, tv.lbits);
+                const uint64_t there = *reinterpret_cast<const uint64_t*>(tv.lines + (size_t)q.line * LINE_BYTES + 4 * q.sh);
+                if (((there ^ cell_word(q.w, q.r, 0)) & KEY_BITS) == 0 && (there >> 48) != 0)
+                    result = (int32_t)(there >> 48);
+                else if (sent_on(there))
+                    result = (int32_t)stash_find(tv, key);
+            }
         }
         out[i] = result;
     }
@@ -499,12 +538,13 @@ __global__ void cohort_fill_kernel(TableView tv, int32_t k, int32_t both_i, cons
         bool stashed = false;
         cells_visit(key, k, tv.lbits, both, [&](const CellProbe& p, int) {
             const int st = cell_standing(tv.lines, p, 1u, tv.lbits, both, cell_nw(k), 1);
-            if (st == 2) {
+            if (st == STAND_NONE) {
                 stashed = true;
                 return;
             }
-            const uint32_t sh = st == 0 ? p.sh : cell_alt_of(p.sh, p.w, p.r, cell_nw(k), tv.lbits, both).sh;
-            const size_t cell = (size_t)p.line * 16 + (sh >> 1);
+            const uint32_t sh = st == STAND_FREE ? cell_alt_of(p.sh, p.w, p.r, cell_nw(k), tv.lbits, both).sh : p.sh;
+            const uint32_t ln = st == STAND_SECOND_LINE ? cell_second_line(p, tv.lbits).line : p.line;
+            const size_t cell = (size_t)ln * 16 + (sh >> 1);
             cell_counts[cell * COHORT_STRIDE + sample] = (uint16_t)c;
         });
         if (stashed) {
@@ -1158,49 +1198,45 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));   // a native vector
 struct CellWord {
     uint64_t V;            // valid lanes
     uint32_t w, r;         // what this lane's cell must hold (CellProbe)
-    uint32_t r_alt;        // (k <= 30 only) what the r field of its second-choice entry must be (cell_alt_of)
-    u32x2 cell, alt;       // what its first- and second-choice cells hold
+    uint32_t anc;          // 2 * cell index | (N is the reverse complement): what a queued k-mer needs to derive its probe again
+    uint32_t r_alt;        // (k <= 30 only) what the r field of its free-cell entry must be (cell_alt_of)
+    u32x2 cell, alt;       // what its first-choice cell and (k <= 30 only) its free cell hold
 };
+constexpr uint32_t QUEUE_ANCHOR_SHIFT = 16;                 // queue id = (word of the wave << 6) | lane | anc << 16
 
-// stage A: the loads of every lane's two cells (same line), issued and not waited for. Exactly two load instructions per
-// word, every lane active (an invalid lane reads line 0): the compiler can then count what is in flight -- s_waitcnt
-// vmcnt(2) where word w is consumed while word w + 1's loads stay out -- instead of falling back to vmcnt(0) as it must
-// around a conditional load.
+// stage A: the load of every lane's cell (k <= 30: and of its free cell in the same line), issued and not waited for. The same
+// load instructions for every word, every lane active (an invalid lane reads line 0): the compiler can then count what is
+// in flight -- s_waitcnt vmcnt(n) where word w is consumed while word w + 1's loads stay out -- instead of falling back to
+// vmcnt(0) as it must around a conditional load.
 template <int W, bool BOTH>
-__device__ __forceinline__ void cells_issue(const TableView& tv, uint64_t V, const CellProbe& p, CellWord& cw) {
+__device__ __forceinline__ void cells_issue(const TableView& tv, uint64_t V, const CellProbe& p, uint32_t anc, CellWord& cw) {
     const bool valid = __builtin_amdgcn_inverse_ballot_w64(V);
     cw.V = V;
     cw.w = p.w;
     cw.r = p.r;
-    uint32_t alt_sh = 0;
-    if constexpr (W <= CELL_ALT_FREE_MAX_W) {                                   // the table decides between the two second-choice schemes
-        const CellAlt a = cell_alt_of(p.sh, p.w, p.r, W, tv.lbits, BOTH);
-        alt_sh = a.sh;
-        cw.r_alt = a.r;
-    }
+    cw.anc = anc;
     uint32_t line = valid ? p.line : 0u;
     asm volatile("" : "+v"(line));                              // (select the 32-bit line number, not the 64-bit byte offset after the shift)
-    // lines are 128-byte aligned (and so is the table): the first-choice cell's offset in the line (8 * cell = 4 * sh) is OR-ed
-    // into the low dword of the line's byte offset, and the second-choice cell of the xor scheme is the same address with
-    // 4 * (sh ^ alt_sh) -- a function of the flank alone -- xor-ed into its low dword
-    // base + ((32 * line + sh) << 2): v_lshlrev_b64, v_or, v_lshl_add_u64 (whose shift goes up to 4)
+    // lines are 128-byte aligned (and so is the table): the cell's offset in the line (8 * cell = 4 * sh) is OR-ed into the low
+    // dword of the line's byte offset: base + ((32 * line + sh) << 2) = v_lshlrev_b64, v_or, v_lshl_add_u64 (whose shift goes up to 4)
     uint64_t l32 = ((uint64_t)line << 5) | (uint64_t)p.sh;
     asm volatile("" : "+v"(l32));                               // (or the compiler re-associates it into a shift by 7 and two 64-bit adds)
     const uint8_t* a0 = reinterpret_cast<const uint8_t*>(reinterpret_cast<const uint32_t*>(tv.lines) + l32);
-    cw.cell = *reinterpret_cast<const u32x2*>(a0);
+    // (a global-address-space pointer: through a generic one the load could become a flat_load, which the compiler cannot
+    // count in vmcnt and waits for with vmcnt(0) -- the end of the software pipeline)
+    typedef const __attribute__((address_space(1))) u32x2* gcell_ptr;
+    cw.cell = *(gcell_ptr)a0;
     if constexpr (W <= CELL_ALT_FREE_MAX_W) {
-        cw.alt = *reinterpret_cast<const u32x2*>(tv.lines + (((uint64_t)line << 7) | (uint64_t)(alt_sh << 2)));
-    } else {
-        // (a global-address-space pointer: through a generic one the load would be a flat_load, which the compiler cannot
-        // count in vmcnt and waits for with vmcnt(0) -- the end of the software pipeline)
-        typedef const __attribute__((address_space(1))) u32x2* gcell_ptr;
-        const uint64_t a1 = (uint64_t)a0 ^ (uint64_t)(((p.w >> 25) & 0x70u) | 8u);          // 4 * (((w >> 27) & 0x1C) | 2)
-        cw.alt = *(gcell_ptr)a1;
+        // (on a table without the free-cell scheme this reads some cell of the line and cells_match ignores it)
+        const CellAlt a = cell_alt_of(p.sh, p.w, p.r, W, tv.lbits, BOTH);
+        cw.r_alt = a.r;
+        cw.alt = *reinterpret_cast<const u32x2*>(tv.lines + (((uint64_t)line << 7) | (uint64_t)(a.sh << 2)));
     }
 }
 
-// stage B: cnt = the stored counter if the cell holds this lane's k-mer (else 0); pend != 0: the cell is flagged for the stash
-// and this flank's filter bit is set (the k-mer is looked up there if cnt == 0)
+// stage B: cnt = the stored counter if the cell (k <= 30: or the free cell) holds this lane's k-mer (else 0); pend != 0: the cell
+// is flagged "someone who belongs here lives elsewhere" and this flank's filter bit is set (if cnt == 0 the k-mer is queued
+// and looked up in its second line, then in the stash)
 template <bool BOTH, int W>
 __device__ __forceinline__ void cells_match(const CellWord& cw, int32_t lbits, uint32_t& cnt, uint32_t& pend) {
     const uint32_t rmask = cell_rmask(lbits, BOTH);             // (wave-uniform: scalar registers)
@@ -1214,36 +1250,24 @@ __device__ __forceinline__ void cells_match(const CellWord& cw, int32_t lbits, u
     // (every lane, valid or not -- an invalid one has loaded cell 0 of line 0: the caller masks the ballots with V, which costs
     // scalar instructions only, where a predicated region costs the moves that initialise cnt and pend around it)
     {
-        const uint32_t x = cw.cell.x, y = cw.cell.y, xa = cw.alt.x, ya = cw.alt.y;
+        const uint32_t x = cw.cell.x, y = cw.cell.y;
+        [[maybe_unused]] const uint32_t xa = cw.alt.x, ya = cw.alt.y;
         // (cw.r has no bits outside rmask and bit 15 clear; xor + and fuse into one v_bitop3)
         const bool first = ((x ^ cw.w) <= CELL_FLAG_MASK) && (((y ^ cw.r) & rmask) == 0);
-        uint32_t r_alt = cw.r ^ CELL_R_ALT, rmask_alt = rmask;
         if constexpr (W <= CELL_ALT_FREE_MAX_W) {
-            r_alt = cw.r_alt;
-            rmask_alt = cell_alt_free(W, lbits, BOTH) ? rmask | (0xFu << (32 - lbits)) : rmask;
+            const bool free_scheme = cell_alt_free(W, lbits, BOTH);                              // (wave-uniform)
+            const uint32_t rmask_alt = rmask | (0xFu << (32 - lbits));
+            const bool second = free_scheme && ((xa ^ cw.w) <= CELL_FLAG_MASK) && (((ya ^ cw.r_alt) & rmask_alt) == 0);
+            cnt = first ? (y >> 16) : second ? (ya >> 16) : 0u;
+        } else {
+            cnt = first ? (y >> 16) : 0u;
         }
-        const bool second = ((xa ^ cw.w) <= CELL_FLAG_MASK) && (((ya ^ r_alt) & rmask_alt) == 0);
-        cnt = first ? (y >> 16) : second ? (ya >> 16) : 0u;
         // the stash only if the cell is flagged AND (when the table has filter bits) the bit of this flank is set.
         // "cnt == 0", not "no match": an EMPTY cell can be flagged (a k-mer whose counter does not fit 16 bits never takes
         // a cell) and would "match" the k-mer whose w and r are all zero
         const uint32_t mine = (y >> (rb + __umulhi(cw.w * 0x9E3779B1u, nspare))) | unfiltered;
         pend = x & mine & CELL_FLAG_STASH;
     }
-}
-
-// the k-mer as the database stores it -- canonical (Kmer.java:72-79), or as the text reads it in a forward-only database
-// (Kmer.java:57-65) -- at packed position q of the tile, from the interleaved code words
-template <int K, bool BOTH, class Lds>
-__device__ __forceinline__ uint64_t k31_canonical_at(const Lds& sh, int q) {
-    constexpr uint32_t lo_mask = ~0u << (64 - 2 * K);
-    const int b0 = 2 * q - 1;
-    const uint2* p = sh.fcx + 1 + (b0 >> 5);
-    const uint32_t s = 31u - (uint32_t)(b0 & 31);
-    const uint2 x = p[0], y = p[1], z = p[2];
-    const uint64_t fwd = u64_of(alignbit32(y.x, z.x, s) & lo_mask, alignbit32(x.x, y.x, s));
-    const uint64_t rc = u64_of(brev32(alignbit32(x.y, y.y, s)), brev32(alignbit32(y.y, z.y, s) & lo_mask)) << (64 - 2 * K);
-    return (BOTH && rc < fwd) ? rc : fwd;
 }
 
 // ---- the planned reference ------------------------------------------------------------------------------------------
@@ -1337,23 +1361,50 @@ __device__ __forceinline__ CellProbe cell_probe_planned(uint64_t N, uint32_t sh2
     return p;
 }
 
-// Stash lookups for the first min(qn, 64) queued k-mers (their keys are re-derived from the packed tile: the queue only
-// holds where they sit); returns the new qn.
+// A queued k-mer, derived again from the packed tile (the queue holds where it sits and its anchor bits): its probe and the
+// word the database stores it under
 template <int K, bool BOTH, class Lds>
-__device__ __forceinline__ int k31c_stash_round(const TableView& tv, const Lds& sh, K31CQueue& q, int lane, int qn, int pos0,
-                                                int32_t min_count, uint32_t& sum_acc, int64_t& big_acc) {
+__device__ __forceinline__ CellProbe k31_probe_at(const Lds& sh, int q, uint32_t anc, int32_t lbits, uint64_t& key) {
+    constexpr uint32_t lo_mask = ~0u << (64 - 2 * K);
+    const int b0 = 2 * q - 1;
+    const uint2* p = sh.fcx + 1 + (b0 >> 5);
+    const uint32_t s = 31u - (uint32_t)(b0 & 31);
+    const uint2 x = p[0], y = p[1], z = p[2];
+    const uint64_t fwd = u64_of(alignbit32(y.x, z.x, s) & lo_mask, alignbit32(x.x, y.x, s));
+    const uint64_t rc = u64_of(brev32(alignbit32(x.y, y.y, s)), brev32(alignbit32(y.y, z.y, s) & lo_mask)) << (64 - 2 * K);
+    key = (BOTH && rc < fwd) ? rc : fwd;                    // canonical (Kmer.java:72-79), or as the text reads it (:57-65)
+    const uint32_t fm = 0u - (anc & 1u);
+    return cell_probe_planned<BOTH>(fm ? rc : fwd, anc & 30u, fm, lbits);
+}
+
+// The first min(qn, 64) queued k-mers -- their first-choice cell said "someone who belongs here lives elsewhere", with their filter
+// bit: the same cell of their second line (the losers of a minimizer sit there together: neighbouring lanes, one line), and if
+// that cell sends them on too, the stash. Calls found(id, counter) for the lanes that find theirs; returns the new qn.
+template <int K, bool BOTH, class Lds, class Found>
+__device__ __forceinline__ int k31c_deferred_round(const TableView& tv, const Lds& sh, uint32_t* ids, int lane, int qn, int pos0, Found&& found) {
     const int nb = min(qn, 64), rest = qn - nb;
-    const uint32_t id = q.id[lane];
-    const uint32_t i2 = q.id[64 + lane];
+    const uint32_t id = ids[lane];
+    const uint32_t i2 = ids[64 + lane];
     wave_lds_fence();
-    if (lane < rest) q.id[lane] = i2;                       // the entries behind the batch move to the front
-    uint32_t cnt = 0;
-    if (lane < nb) cnt = stash_find(tv, k31_canonical_at<K, BOTH>(sh, pos0 + (int)id));
-    const bool hit = (int32_t)cnt >= min_count;             // cnt is 0 unless found; GetVariants.java:224
-    if (hit) atomicOr(&q.hit[id >> 6], 1ull << (id & 63));
-    const bool big = cnt > CELL_COUNT_MAX;                  // only a 3- / 4-byte counter: its own 64-bit sum (GetVariants.java:226)
-    sum_acc += (hit && !big) ? cnt : 0u;
-    big_acc += (hit && big) ? (int64_t)(int32_t)cnt : (int64_t)0;
+    if (lane < rest) ids[lane] = i2;                        // the entries behind the batch move to the front
+    if (lane < nb) {
+        uint64_t key;
+        const CellProbe p = k31_probe_at<K, BOTH>(sh, pos0 + (int)(id & 0xFFFFu), id >> QUEUE_ANCHOR_SHIFT, tv.lbits, key);
+        const CellProbe q2 = cell_second_line(p, tv.lbits);
+        const size_t cell = (size_t)q2.line * 16 + (q2.sh >> 1);
+        const uint2 e = reinterpret_cast<const uint2*>(tv.lines)[cell];
+        const uint32_t rmask = cell_rmask(tv.lbits, BOTH);
+        if (((e.x ^ q2.w) <= CELL_FLAG_MASK) && (((e.y ^ q2.r) & rmask) == 0) && (e.y >> 16) != 0u) {
+            found(id, e.y >> 16, (uint32_t)cell, false);
+        } else {
+            const uint32_t nspare = cell_spare_bits(tv.lbits, BOTH);
+            const bool on = (e.x & CELL_FLAG_STASH) && (nspare == 0 || ((e.y >> cell_filter_pos(q2.w, tv.lbits, BOTH)) & 1u));
+            if (on) {
+                const uint32_t slot = stash_find_slot(tv, key);
+                if (slot != ~0u) found(id, tv.stash[slot].z, slot, true);
+            }
+        }
+    }
     wave_lds_fence();
     return rest;
 }
@@ -1387,19 +1438,27 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
     typename std::conditional<PLANNED, PlannedWords<K>, K31Words<true, K>>::type words;
     if (w_begin < w_end) words.start(sh, off, td.n_kmers, lane, w_begin);
 
+    // a queued k-mer found in its second line or in the stash
+    auto found = [&](uint32_t id, uint32_t cnt, uint32_t, bool) {
+        if ((int32_t)cnt < min_count) return;               // GetVariants.java:224
+        atomicOr(&q.hit[(id >> 6) & 0x3FFu], 1ull << (id & 63));
+        // only a 3- / 4-byte counter (they live in the stash) exceeds 16 bits: its own 64-bit sum (GetVariants.java:226)
+        if (cnt > CELL_COUNT_MAX) big_acc += (int64_t)(int32_t)cnt;
+        else sum_acc += cnt;
+    };
     // stage A of word w: keys, minimizer, cell, fetches issued
     auto issue = [&](int w, CellWord& cw) {
         if constexpr (PLANNED) {
             uint64_t N, V;
             uint32_t sh2, fm;
             words.next(w, N, sh2, fm, V);
-            cells_issue<cell_nw(K), BOTH>(tv, V, cell_probe_planned<BOTH>(N, sh2, fm, tv.lbits), cw);
+            cells_issue<cell_nw(K), BOTH>(tv, V, cell_probe_planned<BOTH>(N, sh2, fm, tv.lbits), sh2 | (fm & 1u), cw);
         } else {
             uint64_t fwd, rc, V;
             uint32_t mn;
             words.next(w, fwd, rc, mn, V);
             const CellProbe p = cell_probe_of(fwd, rc, mn, 2u * (uint32_t)lane, tv.lbits, cell_mlen(K), BOTH, cell_nw(K));
-            cells_issue<cell_nw(K), BOTH>(tv, V, p, cw);
+            cells_issue<cell_nw(K), BOTH>(tv, V, p, p.sh | (mn & 1u), cw);
         }
     };
     // stage B of word w: cells matched, ballots out, stash candidates queued
@@ -1418,11 +1477,11 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
         if (PM) {
             const bool pending = __builtin_amdgcn_inverse_ballot_w64(PM);
             const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(PM >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)PM, 0u));
-            if (pending) q.id[pos] = (uint32_t)(((w - w_begin) << 6) | lane);
+            if (pending) q.id[pos] = (uint32_t)(((w - w_begin) << 6) | lane) | (cw.anc << QUEUE_ANCHOR_SHIFT);
             qn += __popcll(PM);
         }
         wave_lds_fence();
-        while (qn >= 64) qn = k31c_stash_round<K, BOTH>(tv, sh, q, lane, qn, pos0, min_count, sum_acc, big_acc);
+        while (qn >= 64) qn = k31c_deferred_round<K, BOTH>(tv, sh, q.id, lane, qn, pos0, found);
     };
     // D words of cell loads in flight per wave (CELLS_PIPE): a ring of D CellWords in fixed registers -- the loop is unrolled D
     // times -- and no condition around an issue in the steady state (see cells_issue); the first D - 1 issues and the last
@@ -1446,7 +1505,7 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
         if (base + i + D - 1 < w_end) issue(base + i + D - 1, cw[(i + D - 1) % D]);
         if (base + i < w_end) retire(base + i, cw[i % D]);
     }
-    while (qn > 0) qn = k31c_stash_round<K, BOTH>(tv, sh, q, lane, qn, pos0, min_count, sum_acc, big_acc);
+    while (qn > 0) qn = k31c_deferred_round<K, BOTH>(tv, sh, q.id, lane, qn, pos0, found);
     if (lane < w_end - w_begin) {                           // the wave's words of the window's bitmap
         my_bits[w_begin + lane] = q.vw[lane];
         my_bits[TILE_WORDS + w_begin + lane] = q.hit[lane];
@@ -1481,8 +1540,9 @@ struct CohortQueue {
 struct CohortKeys {                       // stage 1 -> 2
     uint64_t V;
     uint32_t w, r;
-    uint32_t r_alt;                       // (k <= 30 only) the r field of the second-choice entry (cell_alt_of)
-    uint32_t dsh;                         // sh ^ alt_sh
+    uint32_t anc;                         // anchor bits of the k-mer (CellWord::anc)
+    uint32_t r_alt;                       // (k <= 30 only) the r field of the free-cell entry (cell_alt_of)
+    uint32_t dsh;                         // (k <= 30 only) sh ^ (2 * index of the free cell)
     uint64_t l32;                         // 32 * line + 2 * first-choice cell: byte offset of the cell / 4, and of its counters / 8
     u32x2 cell, alt;
 };
@@ -1495,8 +1555,9 @@ typedef const __attribute__((address_space(1))) u32x2* gcell_ptr_t;
 typedef u32x4_ u32x4;
 typedef const __attribute__((address_space(1))) u32x4* gcount_ptr_t;
 
+// (the text-only form -- an A/B hook -- carries the minimizer machinery's registers on top: planned for 4 waves per SIMD)
 template <int K, bool BOTH, bool PLANNED>
-__global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) void screen_cohort_kernel(
+__global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(PLANNED ? 6 : 4, 8))) void screen_cohort_kernel(
     const uint8_t* __restrict__ text, RefPlan plan, const TileDesc* __restrict__ tiles, int32_t n_tiles, CohortView cv, int32_t min_count,
     uint64_t* __restrict__ bits, int64_t* __restrict__ count_sums) {
     constexpr int W = cell_nw(K);                           // 16-mers per k-mer = cells of a line a k-mer can sit in
@@ -1539,21 +1600,25 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 
     auto issue = [&](int w, CohortKeys& kw) {
         uint64_t V;
         CellProbe p;
+        uint32_t anc;
         if constexpr (PLANNED) {
             uint64_t N;
             uint32_t sh2, fm;
             words.next(w, N, sh2, fm, V);
             p = cell_probe_planned<BOTH>(N, sh2, fm, tv.lbits);
+            anc = sh2 | (fm & 1u);
         } else {
             uint64_t fwd, rc;
             uint32_t mn;
             words.next(w, fwd, rc, mn, V);
             p = cell_probe_of(fwd, rc, mn, 2u * (uint32_t)lane, tv.lbits, 16, BOTH, W);
+            anc = p.sh | (mn & 1u);
         }
         const bool valid = __builtin_amdgcn_inverse_ballot_w64(V);
         kw.V = V;
         kw.w = p.w;
         kw.r = p.r;
+        kw.anc = anc;
         uint32_t line = valid ? p.line : 0u;
         asm volatile("" : "+v"(line));
         uint64_t l32 = ((uint64_t)line << 5) | (uint64_t)p.sh;
@@ -1561,47 +1626,33 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 
         kw.l32 = l32;
         const uint8_t* a0 = reinterpret_cast<const uint8_t*>(reinterpret_cast<const uint32_t*>(tv.lines) + l32);
         kw.cell = *(gcell_ptr_t)a0;
-        // the second-choice cell differs from the first in the cell index only: sh ^ alt_sh, in units of 4 bytes
-        if constexpr (W <= CELL_ALT_FREE_MAX_W) {           // k < 31: the table decides between the two second-choice schemes
+        if constexpr (W <= CELL_ALT_FREE_MAX_W) {           // k < 31: the free cell of the same line differs in the cell index only
             const CellAlt a = cell_alt_of(p.sh, p.w, p.r, W, tv.lbits, BOTH);
             kw.r_alt = a.r;
             kw.dsh = p.sh ^ a.sh;
-        } else {
-            kw.dsh = ((p.w >> 27) & 0x1Cu) | 2u;
+            const uint64_t a1 = (uint64_t)a0 ^ (uint64_t)(kw.dsh << 2);
+            kw.alt = *(gcell_ptr_t)a1;
         }
-        const uint64_t a1 = (uint64_t)a0 ^ (uint64_t)(kw.dsh << 2);
-        kw.alt = *(gcell_ptr_t)a1;
     };
-    // the queued k-mers (their cell is flagged for the stash, their filter bit is set): looked up 64 at a time, each lane
-    // fetching its own stash entry and that entry's counters
-    auto stash_round = [&]() {
-        const int nb = min(qn, 64), rest = qn - nb;
-        const uint32_t id = q.id[lane];
-        const uint32_t i2 = q.id[64 + lane];
-        wave_lds_fence();
-        if (lane < rest) q.id[lane] = i2;
-        if (lane < nb) {
-            const uint32_t slot = stash_find_slot(tv, k31_canonical_at<K, BOTH>(sh, pos0 + (int)id));
-            if (slot != ~0u) {
-                const uint4 c4 = cv.stash_counts[slot];
-                u32x4 c;
-                c.x = c4.x;
-                c.y = c4.y;
-                c.z = c4.z;
-                c.w = c4.w;
+    // the queued k-mers (their cell sent them on, with their filter bit): looked up 64 at a time in their second line, then in
+    // the stash (k31c_deferred_round); a lane that finds its k-mer fetches the counters of that cell / stash slot
+    auto found = [&](uint32_t id, uint32_t, uint32_t where, bool in_stash) {
+        const uint4 c4 = in_stash ? cv.stash_counts[where] : cv.counts[where];
+        u32x4 c;
+        c.x = c4.x;
+        c.y = c4.y;
+        c.z = c4.z;
+        c.w = c4.w;
 #pragma unroll
-                for (int s = 0; s < COHORT_STRIDE; ++s) {
-                    const uint32_t cs = counter(c, s);
-                    if (s < S && (int32_t)cs >= min_count) {               // GetVariants.java:224-227
-                        atomicOr(&q.hit[s][id >> 6], 1ull << (id & 63));
-                        sum[s] += cs;
-                    }
-                }
+        for (int s = 0; s < COHORT_STRIDE; ++s) {
+            const uint32_t cs = counter(c, s);
+            if (s < S && (int32_t)cs >= min_count) {               // GetVariants.java:224-227
+                atomicOr(&q.hit[s][(id >> 6) & 0x3FFu], 1ull << (id & 63));
+                sum[s] += cs;
             }
         }
-        wave_lds_fence();
-        qn = rest;
     };
+    auto stash_round = [&]() { qn = k31c_deferred_round<K, BOTH>(tv, sh, q.id, lane, qn, pos0, found); };
     // stage 2: cells matched; the counters of every lane's cell requested (first choice unless the second one matched)
     auto match = [&](int w, const CohortKeys& kw, CohortCounts& cw) {
         uint32_t cnt = 0, pend = 0;
@@ -1610,22 +1661,26 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 
             m.V = kw.V;
             m.w = kw.w;
             m.r = kw.r;
-            m.r_alt = kw.r_alt;
+            if constexpr (W <= CELL_ALT_FREE_MAX_W) {
+                m.r_alt = kw.r_alt;
+                m.alt = kw.alt;
+            }
             m.cell = kw.cell;
-            m.alt = kw.alt;
             cells_match<BOTH, W>(m, tv.lbits, cnt, pend);
         }
-        const bool first = ((kw.cell.x ^ kw.w) <= CELL_FLAG_MASK) && (((kw.cell.y ^ kw.r) & cell_rmask(tv.lbits, BOTH)) == 0);
         cw.V = kw.V;
         cw.M = wave_ballot(cnt != 0u) & kw.V;
-        const uint32_t x = first ? 0u : kw.dsh;                                    // sh ^ alt_sh
-        const uint64_t l32 = kw.l32 ^ (uint64_t)x;
+        uint64_t l32 = kw.l32;
+        if constexpr (W <= CELL_ALT_FREE_MAX_W) {                                  // the counters of the free cell if the k-mer stands there
+            const bool first = ((kw.cell.x ^ kw.w) <= CELL_FLAG_MASK) && (((kw.cell.y ^ kw.r) & cell_rmask(tv.lbits, BOTH)) == 0);
+            l32 ^= (uint64_t)(first ? 0u : kw.dsh);
+        }
         cw.c = *(gcount_ptr_t)(count_base + (l32 << 3));                           // 16 bytes per cell, cell = l32 / 2
         const uint64_t PM = wave_ballot(pend != 0u) & wave_ballot(cnt == 0u) & kw.V;
         if (PM) {
             const bool pending = __builtin_amdgcn_inverse_ballot_w64(PM);
             const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(PM >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)PM, 0u));
-            if (pending) q.id[pos] = (uint32_t)(((w - w_begin) << 6) | lane);
+            if (pending) q.id[pos] = (uint32_t)(((w - w_begin) << 6) | lane) | (kw.anc << QUEUE_ANCHOR_SHIFT);
             qn += __popcll(PM);
         }
         wave_lds_fence();

@@ -218,13 +218,30 @@ int harness_cells_of_key(uint64_t C, int k, int lbits, int both, uint32_t* out) 
     }
     return n;
 }
-// out[0..2] = second-choice cell (2 * index), the r field of the entry there, the bits of r compared there
-void harness_cell_alt(uint32_t sh, uint32_t w, uint32_t r, int k, int lbits, int both, uint32_t* out) {
+// out[0..2] = free-cell second choice (2 * index), the r field of the entry there, the bits of r compared there; returns 0 when
+// the table has no free-cell scheme (k = 31, or too few spare r bits)
+int harness_cell_alt(uint32_t sh, uint32_t w, uint32_t r, int k, int lbits, int both, uint32_t* out) {
+    if (!cell_alt_free(cell_nw(k), lbits, both != 0)) return 0;
     const CellAlt a = cell_alt_of(sh, w, r, cell_nw(k), lbits, both != 0);
     out[0] = a.sh;
     out[1] = a.r;
     out[2] = a.rmask;
+    return 1;
 }
+// out[0..3] = (line, sh, w, r) of the second-line probe of a first-choice probe
+void harness_cell_second_line(uint32_t line, uint32_t sh, uint32_t w, uint32_t r, int lbits, uint32_t* out) {
+    CellProbe p;
+    p.line = line;
+    p.sh = sh;
+    p.w = w;
+    p.r = r;
+    const CellProbe q = cell_second_line(p, lbits);
+    out[0] = q.line;
+    out[1] = q.sh;
+    out[2] = q.w;
+    out[3] = q.r;
+}
+uint32_t harness_cell_rmask(int lbits, int both) { return cell_rmask(lbits, both != 0); }
 uint64_t harness_revcomp_word(uint64_t x, int len) { return revcomp_word(x, len); }
 int harness_tile_k(void) { return TILE_K; }
 

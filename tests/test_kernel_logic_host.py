@@ -50,7 +50,11 @@ def harness():
     L.harness_cells.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.harness_cells_of_key.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.harness_cell_alt.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]
-    L.harness_cell_alt.restype = None
+    L.harness_cell_alt.restype = C.c_int
+    L.harness_cell_second_line.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+    L.harness_cell_second_line.restype = None
+    L.harness_cell_rmask.argtypes = [C.c_int, C.c_int]
+    L.harness_cell_rmask.restype = C.c_uint32
     return L
 
 
@@ -268,20 +272,34 @@ def test_cell_table_build_side_covers_query_side(harness, oracle):
             canon = np.unique(np.minimum(lst[:m], synth.revcomp(lst[:m], k)))
         else:                                          # a forward-only database may hold a k-mer AND its reverse complement
             canon = np.unique(np.concatenate([lst[:m], synth.revcomp(lst[:m], k)]))
-        seen, seen_alt = {}, {}
+        seen, seen_alt, seen_2nd = {}, {}, {}
+        W = k - 15
+        free_scheme = k <= 30 and lbits - (17 if both else 18) >= 4
+        rmask = int(harness.harness_cell_rmask(lbits, both))
+        q4 = np.zeros(4, dtype=np.uint32)
         for c in canon:
             nc = harness.harness_cells_of_key(int(c), k, lbits, both, out.ctypes.data)
             for i in range(nc):
                 cell = tuple(int(x) for x in out[4 * i:4 * i + 4])
                 assert seen.setdefault(cell, int(c)) == int(c), (k, lbits, hex(int(c)), hex(seen[cell]))
-                # the same for second-choice entries (cell_alt_of: the cell, the r field stored there, the r bits compared): what
-                # is stored there must give the first-choice cell back, or two k-mers with equal (w, r) at different offsets
-                # could not be told apart
                 line, sh, w, r = cell
-                harness.harness_cell_alt(sh, w, r, k, lbits, both, alt3.ctypes.data)
-                a_sh, a_r, a_mask = (int(x) for x in alt3)
-                assert a_sh != sh and a_sh % 2 == 0 and a_sh < 32 and a_r & 0x8000 and a_r & ~a_mask == 0
-                if k <= 30 and lbits - (17 if both else 18) >= 4:
-                    assert a_sh >= 2 * (k - 15)                      # a cell that is nobody's first choice
-                alt = (line, a_sh, w, a_r)
-                assert seen_alt.setdefault(alt, int(c)) == int(c), (k, lbits, hex(int(c)), hex(seen_alt[alt]))
+                assert sh < 2 * W and r & 0x8000 == 0
+                # free-cell second choices (cell_alt_of: the cell, the r field stored there, the r bits compared): what is stored
+                # there must give the first-choice cell back, or two k-mers with equal (w, r) at different offsets of one line
+                # could not be told apart
+                has = harness.harness_cell_alt(sh, w, r, k, lbits, both, alt3.ctypes.data)
+                assert bool(has) == free_scheme
+                if has:
+                    a_sh, a_r, a_mask = (int(x) for x in alt3)
+                    assert a_sh % 2 == 0 and 2 * W <= a_sh < 32 and a_r & 0x8000 and a_r & ~a_mask == 0      # a cell that is nobody's first choice
+                    alt = (line, a_sh, w, a_r)
+                    assert seen_alt.setdefault(alt, int(c)) == int(c), (k, lbits, hex(int(c)), hex(seen_alt[alt]))
+                # second-line entries: same cell index and flank, (line, r) from a second bijection of the minimizer, marked bit 15:
+                # injective over the k-mers, never equal to a first-choice entry (those have bit 15 clear) and, sitting in a cell
+                # < W, never in a free cell
+                harness.harness_cell_second_line(line, sh, w, r, lbits, q4.ctypes.data)
+                l2, sh2, w2, r2 = (int(x) for x in q4)
+                assert (sh2, w2) == (sh, w) and r2 & 0x8000 and r2 & ~rmask == 0 and l2 < (1 << lbits)
+                assert both or (r2 & 0x4000) == (r & 0x4000)             # forward-only: the strand mark travels with the entry
+                second = (l2, sh2, w2, r2)
+                assert seen_2nd.setdefault(second, int(c)) == int(c), (k, lbits, hex(int(c)), hex(seen_2nd[second]))
