@@ -83,14 +83,14 @@ typedef struct {
     int32_t minimizer_length;/* M of the minimizer bucketing (0 in mode 0) */
     int64_t heavy_lines;     /* minimizer home lines whose k-mers were re-homed by key hash (low-complexity repeats) */
     int64_t overflow_lines;  /* lines that pushed k-mers to the next line */
-    int32_t table_format;    /* 0 = 12-slot lines; 1 = 16 offset-addressed cells per line + stash (the default for k = 19..31) */
+    int32_t table_format;    /* 0 = 12-slot lines; 1 = 16 offset-addressed cells per line, second lines, stash (the default for k = 19..31) */
     int32_t lut_suspect;     /* 1: the prefix LUT is not a run of prefix sums and the file was accepted only because
                                 KCFX_LENIENT_LUT=1 is set (by default such a .kmc_pre is refused with KCFX_ERR_FORMAT) */
     int64_t stored_kmers;    /* format 1: k-mers with a non-zero counter (the others can never be observed) */
-    int64_t stash_kmers;     /* format 1: k-mers that found a cell taken and live in the stash */
+    int64_t stash_kmers;     /* format 1: k-mers that found their cell and their second line's cell taken and live in the stash */
     int64_t stash_bytes;     /* format 1: HBM bytes of the stash (included in table_bytes) */
     int64_t multi_cell_kmers;/* format 1: k-mers stored in more than one cell (tied or palindromic minimizers) */
-    int64_t second_choice_kmers; /* format 1: placements in the second-choice cell of a line (first choice taken) */
+    int64_t second_choice_kmers; /* format 1: k-mers placed outside their first-choice cell (a free cell of the line, or the second line) */
 } kcfx_db_info_t;
 
 /* ---- database ------------------------------------------------------------------------------------ */
@@ -146,7 +146,11 @@ int32_t kcfx_release_cached(int32_t device);
 
 /* Upload newline-free, case-preserved text and a window list: window w is text[win_begin[w], win_begin[w]+win_len[w]).
  * Windows may overlap (tiling windows share k-1 bases) and gene-mode windows are pre-spliced by the caller.
- * `kmer_length` fixes the tile plan; use the database's. Host pointers; they are not retained. */
+ * `kmer_length` fixes the tile plan; use the database's. Host pointers; they are not retained.
+ * For kmer_length 19 .. 31 the call also works out, once, what a look-up in a cell table needs of the reference and no sample
+ * changes: 2-bit codes of the text and one byte per k-mer start (is it valid, which of its 16-mers is its minimizer, on which
+ * strand) -- 1.25 bytes per base beside the text, one kernel pass. Every screening launch against this reference then starts
+ * from those instead of from the ASCII (KCFX_REF_PLAN=0 in the environment: text only, the kernels derive it per launch). */
 int32_t kcfx_ref_create(int32_t device, int32_t kmer_length, const uint8_t* text, int64_t text_len,
                         const int64_t* win_begin, const int32_t* win_len, int32_t n_windows, kcfx_ref** out);
 int32_t kcfx_ref_n_windows(const kcfx_ref* ref);

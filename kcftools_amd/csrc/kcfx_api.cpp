@@ -141,8 +141,8 @@ struct kcfx_ref {
     int32_t n_tiles = 0;
     int64_t n_slots = 0;
     uint8_t* d_text = nullptr;
-    uint32_t* d_codes = nullptr;       // RefPlan (k = 19 .. 31: what a cell table's look-ups need of the reference, worked out once)
-    uint8_t* d_anchors = nullptr;
+    uint32_t* d_codes = nullptr;       // RefPlan (k = 19 .. 31: what a cell table's look-ups need of the reference, worked out once;
+    uint8_t* d_anchors = nullptr;      // both point into the block of d_text)
     RefPlan plan() const {
         RefPlan p;
         p.codes = d_codes;
@@ -495,8 +495,6 @@ void ref_free(kcfx_ref* r) {
         (void)hipEventDestroy(ev.second);
     }
     if (r->d_text) (void)dev_free(r->d_text);
-    if (r->d_codes) (void)dev_free(r->d_codes);
-    if (r->d_anchors) (void)dev_free(r->d_anchors);
     if (r->d_tiles) (void)dev_free(r->d_tiles);
     if (r->d_win_tile0) (void)dev_free(r->d_win_tile0);
     if (r->d_bits) (void)dev_free(r->d_bits);
@@ -1026,11 +1024,18 @@ int32_t kcfx_ref_create(int32_t device, int32_t kmer_length, const uint8_t* text
     r->n_windows = n_windows;
     r->n_tiles = (int32_t)tiles.size();
     r->n_slots = n_slots;
-    const size_t text_alloc = (size_t)text_len + 128;   // the pack phase reads whole 32-byte chunks
+    // One block: the text (+ 128 zero bytes: the pack phase reads whole 32-byte chunks) and, for cell tables (k = 19 .. 31), the
+    // reference plan behind it -- anchors, then codes, each 256-byte aligned. KCFX_REF_PLAN=0 in the environment keeps the
+    // text-only reference (A/B and test hook, read here, never per launch).
+    const char* plan_env = getenv("KCFX_REF_PLAN");
+    const bool planned = k >= CELL_K_MIN && k <= CELL_K_MAX && text_len > 0 && !(plan_env && plan_env[0] == '0');
+    auto up256 = [](size_t n) { return (n + 255) & ~(size_t)255; };
+    const size_t text_alloc = up256((size_t)text_len + 128);
+    const size_t ab = planned ? up256(ref_plan_anchor_bytes(text_len)) : 0, cb = planned ? up256(ref_plan_codes_bytes(text_len)) : 0;
     hipError_t e;
     if ((e = stream_acquire(device, &r->stream)) != hipSuccess ||
-        (e = dev_alloc(&r->d_text, text_alloc)) != hipSuccess ||
-        (e = hipMemsetAsync(r->d_text + text_len, 0, 128, r->stream)) != hipSuccess ||
+        (e = dev_alloc(&r->d_text, text_alloc + ab + cb)) != hipSuccess ||
+        (e = hipMemsetAsync(r->d_text + text_len, 0, text_alloc - (size_t)text_len + ab + cb, r->stream)) != hipSuccess ||
         (text_len > 0 && (e = hipMemcpyAsync(r->d_text, text, (size_t)text_len, hipMemcpyHostToDevice, r->stream)) != hipSuccess) ||
         (e = dev_alloc(&r->d_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(TileDesc))) != hipSuccess ||
         (e = dev_alloc(&r->d_win_tile0, win_tile0.size() * 4)) != hipSuccess ||
@@ -1038,18 +1043,12 @@ int32_t kcfx_ref_create(int32_t device, int32_t kmer_length, const uint8_t* text
         (e = dev_alloc(&r->d_csum, std::max<size_t>(tiles.size(), 1) * 8)) != hipSuccess ||
         (e = dev_alloc(&r->d_res, std::max<size_t>((size_t)n_windows, 1) * sizeof(kcfx_result))) != hipSuccess ||
         (!tiles.empty() && (e = hipMemcpyAsync(r->d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, r->stream)) != hipSuccess) ||
-        (e = hipMemcpyAsync(r->d_win_tile0, win_tile0.data(), win_tile0.size() * 4, hipMemcpyHostToDevice, r->stream)) != hipSuccess ||
-        (e = hipSuccess) != hipSuccess)
+        (e = hipMemcpyAsync(r->d_win_tile0, win_tile0.data(), win_tile0.size() * 4, hipMemcpyHostToDevice, r->stream)) != hipSuccess)
         return hip_fail(e, "kcfx_ref_create");
-    // the plan of the reference for cell tables (k = 19 .. 31), on the same stream behind the text upload.
-    // KCFX_REF_PLAN=0 in the environment keeps the text-only reference (A/B and test hook, read here, never per launch).
-    const char* plan_env = getenv("KCFX_REF_PLAN");
-    if (k >= CELL_K_MIN && k <= CELL_K_MAX && text_len > 0 && !(plan_env && plan_env[0] == '0')) {
-        const size_t cb = ref_plan_codes_bytes(text_len), ab = ref_plan_anchor_bytes(text_len);
-        if ((e = dev_alloc(&r->d_codes, cb)) != hipSuccess || (e = dev_alloc(&r->d_anchors, ab)) != hipSuccess ||
-            (e = hipMemsetAsync(r->d_codes, 0, cb, r->stream)) != hipSuccess ||
-            (e = hipMemsetAsync(r->d_anchors, 0, ab, r->stream)) != hipSuccess ||
-            (e = launch_ref_plan(r->d_text, text_len, k, r->d_codes, r->d_anchors, r->stream)) != hipSuccess)
+    if (planned) {                                          // on the same stream, behind the text upload
+        r->d_anchors = r->d_text + text_alloc;
+        r->d_codes = reinterpret_cast<uint32_t*>(r->d_text + text_alloc + ab);
+        if ((e = launch_ref_plan(r->d_text, text_len, k, r->d_codes, r->d_anchors, r->stream)) != hipSuccess)
             return hip_fail(e, "kcfx_ref_create (reference plan)");
     }
     if ((e = hipStreamSynchronize(r->stream)) != hipSuccess) return hip_fail(e, "kcfx_ref_create");

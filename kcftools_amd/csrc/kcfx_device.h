@@ -285,12 +285,12 @@ KCFX_HD uint32_t cell_g32(uint32_t cm) {
 // cells W .. 15 of a line (k < 31) hold free-cell second choices, cells 0 .. W - 1 second-LINE entries.
 constexpr uint32_t CELL_R_ALT = 0x8000u;
 
-// The r field of a cell: bits 0 .. 31 - lbits carry the rest of G32, bit 15 the second-choice mark; the lbits - 17 bits in
-// between would be zero. In a cell that is flagged "someone who belongs here lives in the stash" they say WHO: every
-// stashed k-mer sets the bit its flank selects (a one-hash Bloom filter per cell). A query that finds its cell taken by
-// another k-mer goes to the stash only if its own bit is set -- in a k-mer count of sequencing reads nearly every genomic
-// cell is flagged (the error neighbours of the genomic k-mer want the same cell and lose to its larger counter), and
-// every absent reference k-mer would otherwise cost a stash look-up.
+// The r field of a cell: bits 0 .. 31 - lbits carry the rest of G32 (G32' in a second-line entry), bit 15 the "not in its
+// first-choice cell" mark; the lbits - 17 bits in between would be zero. In a cell that is flagged "someone who belongs here
+// lives elsewhere" (its second line, the stash) they say WHO: every k-mer that was sent on sets the bit its flank selects (a
+// one-hash Bloom filter per cell). A query that finds its cell taken by another k-mer looks further only if its own bit is
+// set -- in a k-mer count of sequencing reads nearly every genomic cell is flagged (the error neighbours of the genomic k-mer
+// want the same cell and lose to its larger counter), and every absent reference k-mer would otherwise cost a look-up.
 // A forward-only database (header byte != 0, KMC.java:133; Kmer.java:57-65 then looks k-mers up as the text reads them)
 // may hold a k-mer AND its reverse complement as two records: both have the same N orientation, line, cell, w and
 // rest of G32, so bit 14 of r says which of the two this is (CELL_R_FLIP: the stored word is the reverse complement of

@@ -54,27 +54,31 @@ constexpr int MODE_KEYHASH = 0, MODE_MINIMIZER = 1;
 //
 //   128-byte line = 16 x 8-byte cell;  cell = u32 w | u16 r | u16 count
 //     w     = the flank bits (the k - 16 <= 15 bases of N around the minimizer, left-aligned in 30 bits) | bit 0: some k-mer that maps
-//             to this cell lives in the stash | bit 1: the occupant is of the "crowded" class (build time only)
+//             to this cell lives elsewhere (second line or stash) | bit 1: the occupant is of the "crowded" class (build time only)
 //     r     = low (32 - lbits) bits of G32 = a 32-bit mix of the canonical minimizer 16-mer; the line number is the top
 //             lbits of G32, and G32 <-> minimizer is a bijection (cell_g32)
-//             (at most 15 bits: lbits >= 17) | bit 15: this k-mer sits in its SECOND-choice cell | the lbits - 17 bits in
-//             between: in a cell flagged for the stash, a one-hash Bloom filter of the flanks of the k-mers that went
-//             there (cell_filter_pos) -- a query that misses in a flagged cell looks into the stash only if its bit is set
+//             (at most 15 bits: lbits >= 17) | bit 15: this k-mer does NOT sit in its first-choice cell | the lbits - 17 bits in
+//             between: in a flagged cell, a one-hash Bloom filter of the flanks of the k-mers that were sent on
+//             (cell_filter_pos) -- a query that misses in a flagged cell looks further only if its bit is set
 //     count = the stored counter; 0 = empty cell (a k-mer whose counter is 0 can never be observed -- GetVariants.java:224
 //             needs count >= -c >= 1 -- so it is not stored). A counter beyond 65535 (3- / 4-byte counters only) does not
-//             fit: that k-mer never takes a cell, it flags the cell(s) it would have -- occupied or empty -- and lives in
+//             fit: that k-mer never takes a cell, it flags the cells it would have -- occupied or empty -- and lives in
 //             the stash, whose entries carry 32-bit counts
 //   (line, cell, w, r) -> N -> canonical k-mer is injective, so equality of (w, r) in the k-mer's cell IS equality of
-//   the k-mer. When several k-mers want one cell, a k-mer whose minimizer is shared by >= 3 k-mers of the database
-//   (the genome's runs -- what a reference window asks for) beats an isolated one, then the larger counter wins (64-bit
-//   atomic max: deterministic, and in a real database the genomic k-mer beats its sequencing-error neighbours, which
-//   share its minimizer and offset). A loser takes its second-choice cell in the same line if that is empty
-//   (cell_alt_sh), else it goes to the stash: open addressing over 16-byte entries {u64 key, u32 count, u32 pad},
-//   slot = hash32(key) & mask, probed by the lanes individually.
+//   the k-mer. Which 16-mer of a k-mer is its minimizer: the smallest under an order that puts open syncmers first
+//   (cell_order27: 0.097 minimizer runs per k-mer instead of 0.118). When several k-mers want one cell, a k-mer whose minimizer
+//   is shared by >= 3 k-mers of the database (the genome's runs -- what a reference window asks for) beats an isolated one, then
+//   the larger counter wins (64-bit atomic max: deterministic, and in a real database the genomic k-mer beats its
+//   sequencing-error neighbours, which share its minimizer and offset). A loser takes, in this order: (k < 31, roomy tables) a
+//   free cell W .. 15 of the same line; the same cell of its SECOND LINE (top lbits of G32' = a second bijection of the
+//   minimizer, r from G32' with bit 15 set: cell_second_line) -- the losers of a minimizer meet again there, one request for
+//   all of them; the stash: open addressing over 16-byte entries {u64 key, u32 count, u32 pad}, slot = hash32(key) & mask,
+//   probed by the lanes individually. Both steps only into EMPTY cells, and each is announced in the cell before it
+//   (flag + filter bit), so a query follows exactly the path the build took.
 // ----------------------------------------------------------------------------------------------------
 constexpr int FORMAT_LINES = 0, FORMAT_CELLS = 1;
 constexpr int CELL_K_MIN = 19, CELL_K_MAX = 31;               // cell tables: 16-base minimizers, k - 15 = 4 .. 16 of them per k-mer
-constexpr int CELL_LBITS_MIN = 17, CELL_LBITS_MAX = 31;     // r must fit 15 bits (bit 15 marks a second-choice cell); n_lines fits 32
+constexpr int CELL_LBITS_MIN = 17, CELL_LBITS_MAX = 31;     // r must fit 15 bits (bit 15 marks an entry outside its first-choice cell); n_lines fits 32
                                                             // (forward-only databases: 18, bit 14 of r is taken too -- cell_lbits_min)
 __host__ __device__ inline int32_t cell_lbits_min(bool both) { return both ? CELL_LBITS_MIN : CELL_LBITS_MIN + 1; }
 constexpr uint32_t CELL_FLAG_STASH = 1u, CELL_FLAG_MASK = 3u;

@@ -19,4 +19,8 @@ timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ
 timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq2 -o q -- $Q > /dev/null 2> $OUT/pmc_sq2.err
 # calibration of FETCH_SIZE on the same access pattern with a known byte count (8 lanes x 16 B random 128-byte lines)
 timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_cal -o c -- ./kcftools_amd/bin/kcfx_membench 4 64 > $OUT/membench.log 2> $OUT/pmc_cal.err
+# the bench line that is committed: once more, now that profiles/traffic.json (roofline.traffic, the rocprof average it quotes)
+# comes from THIS box's passes
+python3 tools/pmc_summary.py $TAG > $OUT/pmc_summary.log 2>&1
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
 ls $OUT
