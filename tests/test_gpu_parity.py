@@ -675,3 +675,27 @@ def test_planned_reference_and_text_only_reference_agree(oracle, tmp_path, monke
         a, b = planned.screen(db, mc), text_only.screen(db, mc)
         assert_same(a, b, f"planned vs text-only, -c {mc}")
     assert_same(planned.screen(db, 1), want, "planned vs oracle")
+
+
+def test_planned_reference_at_the_text_lengths_where_its_arrays_end(oracle, tmp_path):
+    """The plan is laid out in whole tiles of 2 048 positions plus padding, the screening tiles read a little past their last k-mer:
+    texts whose length sits on and around those borders (and texts shorter than k), one window over the whole text and tiling
+    windows, against the oracle."""
+    k = 31
+    base = synth.random_reference(20_000, 123, n_run_every=0, lower_frac=0.1, iupac_rate=0.0)
+    prefix, *_ = make_db(tmp_path, "edge", base, 321, k=k, p=3, cs=2, m=7, bins=4, both=True, noise=20_000)
+    db = engine.KmcDb.open(prefix)
+    odb = oracle.OracleDb(prefix)
+    for L in (0, 1, k - 1, k, k + 1, 63 + k, 64 + k - 1, 2047, 2048, 2049, 2048 + k - 2, 2048 + k - 1, 2048 + k, 4095, 4096, 4096 + k,
+              6143 + k, 6144 + k - 1, 12_288, 12_289, 16_383 + 31):
+        text = base[:L]
+        wins = [(0, L)]
+        if L >= k:
+            s, e = engine.windows(L, max(k, min(1000, L)), 0, k)
+            wins += list(zip(s.tolist(), (e - s).tolist()))
+            wins += [(L - k, k), (max(0, L - 2048 - k + 1), min(L, 2048 + k - 1))]
+        begins = np.array([w[0] for w in wins], dtype=np.int64)
+        lens = np.array([w[1] for w in wins], dtype=np.int32)
+        got = db.screen(text, begins, lens, 1)
+        want = odb.screen(text, begins, lens, 1, threads=2)
+        assert_same(got, want, f"text of {L} bases")
