@@ -129,7 +129,8 @@ struct kcfx_db {
     uint4* d_stash = nullptr;
     uint32_t stash_mask = 0;
     unsigned long long* d_stats = nullptr;   // FORMAT_CELLS build counters (cells_settle_kernel)
-    uint32_t* d_pop = nullptr;               // FORMAT_CELLS build scratch: k-mers per minimizer sub-bucket (freed after the build)
+    uint32_t* d_pop = nullptr;               // FORMAT_CELLS build scratch: k-mers per minimizer (freed after the build)
+    int32_t pop_bits = 32;                   // 2^pop_bits byte counters: 32 = one per minimizer, lbits + 2 when 4 GiB cannot be had
     hipStream_t stream = nullptr;
     TableView view() const { return TableView{d_lines, n_lines, wide, mode, mm_len, fmt, lbits, stash_mask, d_stash, generic, info.both_strands}; }
 };
@@ -296,6 +297,23 @@ int32_t table_ready(kcfx_db* db) {
     return KCFX_OK;
 }
 
+// the crowding counters of the build: one byte per minimizer (4 GiB) if the device can spare them beside the table it is about
+// to hold, else one per line + 2 bits (round 2's classes)
+int32_t pop_alloc(kcfx_db* db) {
+    db->pop_bits = 32;
+    hipError_t e = hipErrorOutOfMemory;
+    // (KCFX_CROWD_PER_LINE=1: the fallback by choice -- test hook, read when the handle is made)
+    if (getenv("KCFX_CROWD_PER_LINE") == nullptr && free_device_bytes() > ((size_t)LINE_BYTES << db->lbits) + ((size_t)6 << 30))
+        e = dev_alloc(&db->d_pop, cells_pop_bytes(db->pop_bits));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        db->pop_bits = std::min(32, db->lbits + 2);
+        KCFX_HIP(dev_alloc(&db->d_pop, cells_pop_bytes(db->pop_bits)));
+    }
+    KCFX_HIP(hipMemsetAsync(db->d_pop, 0, cells_pop_bytes(db->pop_bits), db->stream));
+    return KCFX_OK;
+}
+
 int32_t cells_alloc(kcfx_db* db, int64_t n_keys, bool deferred = false) {
     db->fmt = FORMAT_CELLS;
     db->wide = 0;
@@ -317,8 +335,7 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys, bool deferred = false) {
         db->n_lines = 1u << L0;
         KCFX_HIP(dev_alloc(&db->d_stats, 4 * sizeof(unsigned long long)));
         KCFX_HIP(hipMemsetAsync(db->d_stats, 0, 4 * sizeof(unsigned long long), db->stream));
-        KCFX_HIP(dev_alloc(&db->d_pop, cells_pop_bytes(db->lbits)));
-        KCFX_HIP(hipMemsetAsync(db->d_pop, 0, cells_pop_bytes(db->lbits), db->stream));
+        if (int32_t rc = pop_alloc(db)) return rc;
         db->info.table_bytes = (int64_t)LINE_BYTES << db->lbits;
         db->info.table_lines = db->n_lines;
         db->info.slots_per_line = 16;
@@ -357,8 +374,7 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys, bool deferred = false) {
     KCFX_HIP(hipMemsetAsync(db->d_lines, 0, (size_t)LINE_BYTES << db->lbits, db->stream));
     KCFX_HIP(dev_alloc(&db->d_stats, 4 * sizeof(unsigned long long)));
     KCFX_HIP(hipMemsetAsync(db->d_stats, 0, 4 * sizeof(unsigned long long), db->stream));
-    KCFX_HIP(dev_alloc(&db->d_pop, cells_pop_bytes(db->lbits)));
-    KCFX_HIP(hipMemsetAsync(db->d_pop, 0, cells_pop_bytes(db->lbits), db->stream));
+    if (int32_t rc = pop_alloc(db)) return rc;
     db->info.table_bytes = (int64_t)LINE_BYTES << db->lbits;
     db->info.table_lines = db->n_lines;
     db->info.slots_per_line = 16;
@@ -596,8 +612,8 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     auto apply = [&](int phase, const uint64_t* keys, const uint32_t* counts, int64_t n) -> hipError_t {
         if (cells) {
             const int32_t kk = db->info.kmer_length;
-            if (phase == 0) return launch_cells_count(db->d_pop, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream);
-            if (phase == 1 || phase == 2) return launch_cells_insert(db->d_lines, db->d_pop, phase == 1 ? 1 : 0, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream);
+            if (phase == 0) return launch_cells_count(db->d_pop, db->pop_bits, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream);
+            if (phase == 1 || phase == 2) return launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, phase == 1 ? 1 : 0, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream);
             if (phase == 3) return launch_cells_settle(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stats, db->stream);
             return launch_cells_stash(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stash, db->stash_mask, db->stream);
         }
@@ -905,9 +921,9 @@ int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, 
         int32_t rc = table_alloc(db, n, counter_size, allow_cells);
         if (rc || n == 0) return rc;
         if (db->fmt == FORMAT_CELLS) {
-            if ((e = launch_cells_count(db->d_pop, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream)) != hipSuccess ||
-                (e = launch_cells_insert(db->d_lines, db->d_pop, 1, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream)) != hipSuccess ||
-                (e = launch_cells_insert(db->d_lines, db->d_pop, 0, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream)) != hipSuccess ||
+            if ((e = launch_cells_count(db->d_pop, db->pop_bits, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream)) != hipSuccess ||
+                (e = launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, 1, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream)) != hipSuccess ||
+                (e = launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, 0, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream)) != hipSuccess ||
                 (e = launch_cells_settle(db->d_lines, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->d_stats, db->stream)) != hipSuccess)
                 return hip_fail(e, "kcfx_db_build insert");
             if ((rc = cells_stash_alloc(db))) return rc;
@@ -1301,8 +1317,8 @@ int32_t kcfx_cohort_open(const char* const* kmc_prefixes, int32_t n_samples, int
             const uint64_t* kk = hold.d_keys + first;
             const uint32_t* cc = hold.d_counts + first;
             hipError_t e2 = hipSuccess;
-            if (phase == 0) e2 = launch_cells_count(db->d_pop, k, db->lbits, both, kk, cc, n, db->stream, 1);
-            else if (phase == 1 || phase == 2) e2 = launch_cells_insert(db->d_lines, db->d_pop, phase == 1 ? 1 : 0, k, db->lbits, both, kk, cc, n, db->stream, 1);
+            if (phase == 0) e2 = launch_cells_count(db->d_pop, db->pop_bits, k, db->lbits, both, kk, cc, n, db->stream, 1);
+            else if (phase == 1 || phase == 2) e2 = launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, phase == 1 ? 1 : 0, k, db->lbits, both, kk, cc, n, db->stream, 1);
             else if (phase == 3) e2 = launch_cells_settle(db->d_lines, k, db->lbits, both, kk, cc, n, db->d_stats, db->stream, 1);
             else e2 = launch_cells_stash(db->d_lines, k, db->lbits, both, kk, cc, n, db->d_stash, db->stash_mask, db->stream, 1);
             if (e2 != hipSuccess) return e2;

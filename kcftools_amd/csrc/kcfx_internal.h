@@ -278,12 +278,12 @@ hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide,
 // FORMAT_CELLS build, five passes over the k-mers, each after ALL of the one before: count per minimizer sub-bucket
 // (cells_pop_bytes of zeroed scratch), bids of the crowded class (cls 1), bids of the others (cls 0), settle the losers into
 // second-choice cells or flag them for the stash (stats[0] = how many), fill the stash
-size_t cells_pop_bytes(int32_t lbits);
+size_t cells_pop_bytes(int32_t pop_bits);          // pop_bits = 32 (one counter per minimizer) or lbits + 2
 // (both = the database is canonical; see CELL_R_FLIP in kcfx_device.h for what a forward-only one changes)
 // (presence != 0: every non-zero counter is stored as 1 -- the key table of a cohort, kcfx_cohort_open)
-hipError_t launch_cells_count(uint32_t* pop32, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
+hipError_t launch_cells_count(uint32_t* pop32, int32_t pop_bits, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
                               hipStream_t st, int32_t presence = 0);
-hipError_t launch_cells_insert(uint8_t* lines, const uint32_t* pop32, int32_t cls, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys,
+hipError_t launch_cells_insert(uint8_t* lines, const uint32_t* pop32, int32_t pop_bits, int32_t cls, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys,
                                const uint32_t* counts, int64_t n, hipStream_t st, int32_t presence = 0);
 hipError_t launch_cells_settle(uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
                                unsigned long long* stats, hipStream_t st, int32_t presence = 0);

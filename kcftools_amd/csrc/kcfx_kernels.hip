@@ -217,20 +217,20 @@ __device__ __forceinline__ bool cell_same(uint64_t have, uint64_t mine, uint64_t
     const uint64_t id = kc & 0x0000FFFFFFFFFFFFull;
     return (have >> 48) != 0 && (have & id) == (mine & id);
 }
-// (all of G32: a sub-bucket is ONE minimizer. With line + 2 bits an isolated k-mer that shared the line of a genomic run was
-// classed with the run and, where its counter happened to be the larger, took the genomic k-mer's cell: 3.7 % of the bench
-// reference's hits came from the stash, 1.x % now -- profiles/r03_notes.md. 4 GiB of byte counters for the length of the build.)
-__host__ __device__ inline int cell_sub_bits(int32_t lbits) { return 32 - lbits; }
-__device__ __forceinline__ uint64_t cell_sub_bucket(const CellProbe& p, int32_t lbits) {
-    const int sb = cell_sub_bits(lbits);
+// The crowding counters: 2^pop_bits bytes, indexed by the top pop_bits of G32. pop_bits = 32 (4 GiB for the length of the build):
+// a bucket is ONE minimizer. With line + 2 bits (round 2) an isolated k-mer that shared the line of a genomic run was classed
+// with the run and, where its counter happened to be the larger, took the genomic k-mer's cell (profiles/r03_notes.md).
+// kcfx_db_open falls back to lbits + 2 when the device cannot spare 4 GiB.
+__device__ __forceinline__ uint64_t cell_sub_bucket(const CellProbe& p, int32_t lbits, int32_t pop_bits) {
     // (r may carry CELL_R_FLIP above its 32 - lbits identifying bits: masked, or a forward-only database's reverse-strand k-mers
-    // would be counted in another line's sub-bucket)
-    return ((uint64_t)p.line << sb) | ((p.r & (0xFFFFFFFFu >> lbits)) >> (32 - lbits - sb));
+    // would be counted in another minimizer's bucket)
+    const uint32_t g = (p.line << (32 - lbits)) | (p.r & (0xFFFFFFFFu >> lbits));
+    return (uint64_t)(g >> (32 - pop_bits));
 }
 
 // Pass 0: k-mers per sub-bucket, one byte each (a byte that overflows spills into its neighbour: the classes are a
 // heuristic, see above)
-__global__ void cells_count_kernel(uint32_t* pop32, int32_t k, int32_t lbits, int32_t both, const uint64_t* __restrict__ keys,
+__global__ void cells_count_kernel(uint32_t* pop32, int32_t pop_bits, int32_t k, int32_t lbits, int32_t both, const uint64_t* __restrict__ keys,
                                    const uint32_t* __restrict__ counts, int64_t n, int32_t presence) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -238,7 +238,7 @@ __global__ void cells_count_kernel(uint32_t* pop32, int32_t k, int32_t lbits, in
         if (counts[i] == 0) continue;                           // (presence mode: the same test)
         cells_visit(keys[i], k, lbits, both != 0, [&](const CellProbe& p, int a) {
             if (a != 0) return;                                 // the first of its cells names the k-mer's sub-bucket
-            const uint64_t sub = cell_sub_bucket(p, lbits);
+            const uint64_t sub = cell_sub_bucket(p, lbits, pop_bits);
             atomicAdd(&pop32[sub >> 2], 1u << (8 * (uint32_t)(sub & 3)));
         });
     }
@@ -248,7 +248,7 @@ __global__ void cells_count_kernel(uint32_t* pop32, int32_t k, int32_t lbits, in
 // cell(s). Crowded k-mers bid with a 64-bit atomic max -- the count is the most significant field, so the most abundant
 // one gets the cell whatever the arrival order. The others do the same among themselves (a CAS loop), but never replace a
 // crowded occupant.
-__global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__ pop32, int32_t cls, int32_t k, int32_t lbits, int32_t both,
+__global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__ pop32, int32_t pop_bits, int32_t cls, int32_t k, int32_t lbits, int32_t both,
                                     const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, int64_t n, int32_t presence) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -259,7 +259,7 @@ __global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__
         bool crowded = false;
         cells_visit(keys[i], k, lbits, both != 0, [&](const CellProbe& p, int a) {
             if (a == 0) {
-                const uint64_t sub = cell_sub_bucket(p, lbits);
+                const uint64_t sub = cell_sub_bucket(p, lbits, pop_bits);
                 crowded = ((pop32[sub >> 2] >> (8 * (uint32_t)(sub & 3))) & 0xFFu) >= CELL_CROWD;
             }
             if ((int32_t)crowded != cls) return;
@@ -2123,21 +2123,21 @@ hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide,
     return hipGetLastError();
 }
 
-hipError_t launch_cells_count(uint32_t* pop32, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
+hipError_t launch_cells_count(uint32_t* pop32, int32_t pop_bits, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
                               hipStream_t st, int32_t presence) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(cells_count_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, pop32, k, lbits, both, keys, counts, n, presence);
+    hipLaunchKernelGGL(cells_count_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, pop32, pop_bits, k, lbits, both, keys, counts, n, presence);
     return hipGetLastError();
 }
 
-hipError_t launch_cells_insert(uint8_t* lines, const uint32_t* pop32, int32_t cls, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys,
+hipError_t launch_cells_insert(uint8_t* lines, const uint32_t* pop32, int32_t pop_bits, int32_t cls, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys,
                                const uint32_t* counts, int64_t n, hipStream_t st, int32_t presence) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(cells_insert_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, pop32, cls, k, lbits, both, keys, counts, n, presence);
+    hipLaunchKernelGGL(cells_insert_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, pop32, pop_bits, cls, k, lbits, both, keys, counts, n, presence);
     return hipGetLastError();
 }
 
-size_t cells_pop_bytes(int32_t lbits) { return (size_t)1 << (lbits + cell_sub_bits(lbits)); }
+size_t cells_pop_bytes(int32_t pop_bits) { return (size_t)1 << pop_bits; }
 
 hipError_t launch_cells_settle(uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
                                unsigned long long* stats, hipStream_t st, int32_t presence) {

@@ -587,6 +587,8 @@ def test_fuzz_window_geometry_against_oracle(oracle, tmp_path, seed, kernel, mon
         if seed % 3 == 1:                   # a crowded table: 2^17 (2^18) lines for ~1.4 M k-mers, most of them in second choices / the stash
             monkeypatch.setenv("KCFX_TABLE_LBITS", "17" if both else "18")
             noise = 1_200_000
+            if seed % 2:                    # ... built with the fallback crowding counters (per line + 2 bits, not per minimizer)
+                monkeypatch.setenv("KCFX_CROWD_PER_LINE", "1")
         elif seed % 3 == 2:                 # a few filter bits
             monkeypatch.setenv("KCFX_TABLE_LBITS", str(18 + seed % 4))
             noise = 300_000
