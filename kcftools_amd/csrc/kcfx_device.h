@@ -257,7 +257,7 @@ KCFX_HD uint32_t cell_class16(uint32_t m, uint32_t rc_m) {
 // any 16 consecutive positions) | strand bit (bit 0: the canonical form is the reverse complement of the 16-mer as the
 // text reads it). The minimum therefore carries where the minimizer sits and which way round it is; with the label
 // pre-doubled the query gets 2 * offset as (mn - 2 * lane) & 30, the strand bit riding along untouched.
-KCFX_HD uint32_t mm27_tagged(uint32_t fwd_m, uint32_t rc_m, uint32_t label2) {
+KCFX_HD uint32_t order27_tagged(uint32_t fwd_m, uint32_t rc_m, uint32_t label2) {
     const uint32_t cm = fwd_m < rc_m ? fwd_m : rc_m;
     const uint32_t key = cell_order27(cm, cell_class16(fwd_m, rc_m));
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -270,7 +270,7 @@ KCFX_HD uint32_t mm27_tagged(uint32_t fwd_m, uint32_t rc_m, uint32_t label2) {
     return key | (rc_m < fwd_m ? 1u : 0u) | label2;
 #endif
 }
-KCFX_HD uint32_t mm27_label2(uint32_t pos) { return (pos & 15u) << 1; }
+KCFX_HD uint32_t order27_label2(uint32_t pos) { return (pos & 15u) << 1; }
 // canonical minimizer 16-mer -> G32: line = top lbits, r = the rest. A bijection on 32 bits (odd multiplies, right
 // xorshift), so (line, r) identify the minimizer exactly, and independent of mm27: the MINIMUM of 16 hashes is skewed towards
 // 0 and keeps only ~24 bits of entropy, which would leave most lines of a table of 2^27 or more lines unused.
@@ -387,8 +387,8 @@ KCFX_HD CellProbe cell_second_line(const CellProbe& p, int32_t lbits) {
 }
 
 // Query side, one lane: F / R = the k-mer as the text reads it and its reverse complement, mn = the tagged minimum over
-// the k-mer's 16 M-mers, lane = this lane's position label base (mm27_tagged was fed (lane + offset) & 15).
-// (lane2 = 2 * position, what mm27_label2 was fed -- mod 32 is enough)
+// the k-mer's 16 M-mers, lane = this lane's position label base (order27_tagged was fed (lane + offset) & 15).
+// (lane2 = 2 * position, what order27_label2 was fed -- mod 32 is enough)
 KCFX_HD CellProbe cell_probe_of(uint64_t F, uint64_t R, uint32_t mn, uint32_t lane2, int32_t lbits, int M, bool both, int W = 16) {
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t fm;                                              // (one v_bfe_i32; hipcc rewrites the builtin into v_and + v_sub)

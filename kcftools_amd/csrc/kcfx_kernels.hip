@@ -975,13 +975,13 @@ struct K31Words {
     }
 
     // what a position feeds into the sliding minimum, from the leading 32 code bits of both strands: the hash of its canonical
-    // 16-mer; FORMAT_CELLS tables tag it with the strand and the position (mm27_tagged) so that the minimum also says where
+    // 16-mer; FORMAT_CELLS tables tag it with the strand and the position (order27_tagged) so that the minimum also says where
     // the minimizer sits in each k-mer
     __device__ __forceinline__ uint32_t mmer_of(uint32_t f0, uint32_t c0) const {
         if constexpr (CELLS) {
             // the 16-mer is the leading 32 code bits; its reverse complement the same bits of the complement-swapped
             // stream, reversed
-            return mm27_tagged(f0, brev32(c0), mm27_label2((uint32_t)lane));
+            return order27_tagged(f0, brev32(c0), order27_label2((uint32_t)lane));
         } else {
             return mhash32(((uint64_t)min(f0, brev32(c0))) << 32);
         }

@@ -184,7 +184,7 @@ int harness_cells(const uint8_t* text, int64_t text_off, int n_kmers, int k, int
     for (int p = 0; p < n_kmers + 15; ++p) {
         uint64_t f, r;
         extract_pair(P.fw(), P.cw(), P.off + p, M, f, r);
-        h[p] = mm27_tagged((uint32_t)(f >> 32), (uint32_t)(r >> 32), mm27_label2((uint32_t)p));     // extract_pair masks to M bases
+        h[p] = order27_tagged((uint32_t)(f >> 32), (uint32_t)(r >> 32), order27_label2((uint32_t)p));     // extract_pair masks to M bases
     }
     int bad = 0;
     for (int j = 0; j < n_kmers; ++j) {
