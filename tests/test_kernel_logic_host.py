@@ -303,3 +303,26 @@ def test_cell_table_build_side_covers_query_side(harness, oracle):
                 assert both or (r2 & 0x4000) == (r & 0x4000)             # forward-only: the strand mark travels with the entry
                 second = (l2, sh2, w2, r2)
                 assert seen_2nd.setdefault(second, int(c)) == int(c), (k, lbits, hex(int(c)), hex(seen_2nd[second]))
+
+
+def test_minimizer_order_keeps_runs_long(harness):
+    """The minimizer order (cell_order27: open syncmers first, closed ones second) exists to make consecutive k-mers agree on
+    their minimizer for longer: on uniform text a random order gives 2 / 17 = 0.1177 minimizer runs per 31-mer, this one
+    0.0966 (numpy simulation in profiles/r03_notes.md). Measured here on what the device code itself derives (the query side of
+    harness_cells): a run ends where (line, r) changes. A regression of the class function would show as a density near 0.118."""
+    rng = np.random.default_rng(2024)
+    text = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 40_000))
+    buf = padded(text)
+    k, lbits = 31, 27
+    runs, kmers = 0, 0
+    for begin in range(0, len(text) - 2048 - k, 2048):
+        n = 2048
+        ncand = np.zeros(n, dtype=np.int32)
+        probe = np.zeros(4 * n, dtype=np.uint32)
+        assert harness.harness_cells(buf.ctypes.data, begin, n, k, lbits, 1, ncand.ctypes.data, probe.ctypes.data) == 0
+        p = probe.reshape(n, 4)
+        ident = p[:, 0].astype(np.uint64) << np.uint64(16) | (p[:, 3] & 0x3FFF).astype(np.uint64)      # (line, rest of G32)
+        runs += 1 + int(np.count_nonzero(ident[1:] != ident[:-1]))
+        kmers += n
+    density = runs / kmers
+    assert 0.090 < density < 0.104, density
