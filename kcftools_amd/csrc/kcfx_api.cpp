@@ -302,8 +302,11 @@ int32_t table_ready(kcfx_db* db) {
 int32_t pop_alloc(kcfx_db* db) {
     db->pop_bits = 32;
     hipError_t e = hipErrorOutOfMemory;
+    // A handle that serves few look-ups (kcfx_db_opts.expected_queries: the command-line driver's one pass) takes the fallback by
+    // policy: allocating 4 GiB in a fresh process costs ~30 ms of its 0.5 s, the look-ups it saves a fraction of a millisecond.
     // (KCFX_CROWD_PER_LINE=1: the fallback by choice -- test hook, read when the handle is made)
-    if (getenv("KCFX_CROWD_PER_LINE") == nullptr && free_device_bytes() > ((size_t)LINE_BYTES << db->lbits) + ((size_t)6 << 30))
+    const bool few = db->expected_queries > 0 && (double)db->expected_queries < QUERIES_FOR_SPARSE;
+    if (!few && getenv("KCFX_CROWD_PER_LINE") == nullptr && free_device_bytes() > ((size_t)LINE_BYTES << db->lbits) + ((size_t)6 << 30))
         e = dev_alloc(&db->d_pop, cells_pop_bytes(db->pop_bits));
     if (e != hipSuccess) {
         (void)hipGetLastError();
