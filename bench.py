@@ -454,7 +454,10 @@ def main():
             box = json.loads(pr.stdout.strip().splitlines()[-1])
             if requests and kern_avg_ms > 0:
                 box["kernel_G_requests_per_s"] = requests / (kern_avg_ms * 1e-3) / 1e9
-                box["kernel_fraction_of_the_request_rate"] = box["kernel_G_requests_per_s"] / box["G_lines_per_s"]
+                # (against the better of the two gather forms: a pure gather gains nothing from the non-temporal hint -- it has no
+                # other data in the caches to protect -- which is why the kernel, which has, can come out above it)
+                box["kernel_fraction_of_the_request_rate"] = box["kernel_G_requests_per_s"] / max(
+                    box["G_lines_per_s"], box.get("G_lines_per_s_one_nontemporal_load", 0.0))
                 box["requests_per_launch_source"] = "profiles/traffic.json (TCC_EA0_RDREQ_sum of the committed --pmc pass)"
         except Exception as exc:
             box = {"error": str(exc)[:200]}

@@ -1195,6 +1195,18 @@ struct K31CQueue {
 // derives the next word leaves the memory system well below the request rate it can sustain (8 waves per SIMD is the cap).
 // Every lane loads its own 8-byte cell; the lanes of a minimizer run aim at the same 128-byte line, which goes to HBM once.
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));   // a native vector (HIP's uint2 is a union-based struct)
+typedef uint32_t u32x4n __attribute__((ext_vector_type(4)));
+// Table cells, second-line cells, stash entries and cohort counters are read ONCE per pass: loaded with the non-temporal hint
+// (`nt` on the instruction) they do not push the lines that ARE read again -- the reference plan, the tile bitmaps -- out of the L2
+// and the Infinity Cache. Same-box A/B on the bench workload: 0.0808 - 0.0845 ms against 0.0879 - 0.0918 ms per launch.
+__device__ __forceinline__ u32x2 nt_load2(const void* p) {
+    typedef const __attribute__((address_space(1))) u32x2* gp;
+    return __builtin_nontemporal_load((gp)(uint64_t)p);
+}
+__device__ __forceinline__ u32x4n nt_load4(const void* p) {
+    typedef const __attribute__((address_space(1))) u32x4n* gp;
+    return __builtin_nontemporal_load((gp)(uint64_t)p);
+}
 struct CellWord {
     uint64_t V;            // valid lanes
     uint32_t w, r;         // what this lane's cell must hold (CellProbe)
@@ -1222,10 +1234,12 @@ __device__ __forceinline__ void cells_issue(const TableView& tv, uint64_t V, con
     uint64_t l32 = ((uint64_t)line << 5) | (uint64_t)p.sh;
     asm volatile("" : "+v"(l32));                               // (or the compiler re-associates it into a shift by 7 and two 64-bit adds)
     const uint8_t* a0 = reinterpret_cast<const uint8_t*>(reinterpret_cast<const uint32_t*>(tv.lines) + l32);
-    // (a global-address-space pointer: through a generic one the load could become a flat_load, which the compiler cannot
-    // count in vmcnt and waits for with vmcnt(0) -- the end of the software pipeline)
-    typedef const __attribute__((address_space(1))) u32x2* gcell_ptr;
-    cw.cell = *(gcell_ptr)a0;
+    // (nt_load2 goes through a global-address-space pointer: through a generic one the load could become a flat_load, which the
+    // compiler cannot count in vmcnt and waits for with vmcnt(0) -- the end of the software pipeline)
+    // (k = 31 only: with a second load of the same line behind it -- the free cell of k < 31 -- the hint costs that load its hit:
+    // k = 25, 0.131 ms with it, 0.121 ms without)
+    if constexpr (W == 16) cw.cell = nt_load2(a0);
+    else cw.cell = *reinterpret_cast<const u32x2*>(a0);
     if constexpr (W <= CELL_ALT_FREE_MAX_W) {
         // (on a table without the free-cell scheme this reads some cell of the line and cells_match ignores it)
         const CellAlt a = cell_alt_of(p.sh, p.w, p.r, W, tv.lbits, BOTH);
@@ -1392,7 +1406,7 @@ __device__ __forceinline__ int k31c_deferred_round(const TableView& tv, const Ld
         const CellProbe p = k31_probe_at<K, BOTH>(sh, pos0 + (int)(id & 0xFFFFu), id >> QUEUE_ANCHOR_SHIFT, tv.lbits, key);
         const CellProbe q2 = cell_second_line(p, tv.lbits);
         const size_t cell = (size_t)q2.line * 16 + (q2.sh >> 1);
-        const uint2 e = reinterpret_cast<const uint2*>(tv.lines)[cell];
+        const uint2 e = reinterpret_cast<const uint2*>(tv.lines)[cell];      // (plain: with the non-temporal hint this one is slower)
         const uint32_t rmask = cell_rmask(tv.lbits, BOTH);
         if (((e.x ^ q2.w) <= CELL_FLAG_MASK) && (((e.y ^ q2.r) & rmask) == 0) && (e.y >> 16) != 0u) {
             found(id, e.y >> 16, (uint32_t)cell, false);
@@ -1625,7 +1639,8 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(PLA
         asm volatile("" : "+v"(l32));
         kw.l32 = l32;
         const uint8_t* a0 = reinterpret_cast<const uint8_t*>(reinterpret_cast<const uint32_t*>(tv.lines) + l32);
-        kw.cell = *(gcell_ptr_t)a0;
+        if constexpr (W == 16) kw.cell = nt_load2(a0);       // (non-temporal where nothing reads the line again: see cells_issue)
+        else kw.cell = *(gcell_ptr_t)a0;
         if constexpr (W <= CELL_ALT_FREE_MAX_W) {           // k < 31: the free cell of the same line differs in the cell index only
             const CellAlt a = cell_alt_of(p.sh, p.w, p.r, W, tv.lbits, BOTH);
             kw.r_alt = a.r;
@@ -1675,7 +1690,8 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(PLA
             const bool first = ((kw.cell.x ^ kw.w) <= CELL_FLAG_MASK) && (((kw.cell.y ^ kw.r) & cell_rmask(tv.lbits, BOTH)) == 0);
             l32 ^= (uint64_t)(first ? 0u : kw.dsh);
         }
-        cw.c = *(gcount_ptr_t)(count_base + (l32 << 3));                           // 16 bytes per cell, cell = l32 / 2
+        if constexpr (W == 16) cw.c = nt_load4(count_base + (l32 << 3));           // 16 bytes per cell, cell = l32 / 2
+        else cw.c = *(gcount_ptr_t)(count_base + (l32 << 3));
         const uint64_t PM = wave_ballot(pend != 0u) & wave_ballot(cnt == 0u) & kw.V;
         if (PM) {
             const bool pending = __builtin_amdgcn_inverse_ballot_w64(PM);
