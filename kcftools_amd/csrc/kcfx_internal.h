@@ -132,7 +132,7 @@ constexpr int BLOCK = KCFX_BLOCK;     // 4 wavefronts (line-table kernels)
 constexpr int CELLS_BLOCK = KCFX_CELLS_BLOCK;
 // words of cell loads a wave of the (planned) cell-table kernel keeps in flight
 #ifndef KCFX_CELLS_PIPE
-#define KCFX_CELLS_PIPE 2
+#define KCFX_CELLS_PIPE 4
 #endif
 constexpr int CELLS_PIPE = KCFX_CELLS_PIPE;
 #ifndef KCFX_TILE_K

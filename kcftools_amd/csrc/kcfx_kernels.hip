@@ -1500,8 +1500,9 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
     // D words of cell loads in flight per wave (CELLS_PIPE): a ring of D CellWords in fixed registers -- the loop is unrolled D
     // times -- and no condition around an issue in the steady state (see cells_issue); the first D - 1 issues and the last
     // <= 2 D - 2 words are peeled (there a skipped issue makes the compiler wait for everything in flight, which by then is old).
-    // D = 2, 3, 4, 6 measure the same (profiles/r03_notes.md): what a CU's L1 and HBM have in flight does not depend on it.
-    constexpr int D = CELLS_PIPE;
+    // Before the cell load became non-temporal D = 2, 3, 4, 6 measured the same; since then the memory system takes more than two
+    // words per wave can keep in flight: D = 2 / 3 / 4 / 5 / 6 = 0.0816 / 0.0790 / 0.0779 / 0.0783 / 0.084 ms (profiles/r03_notes.md).
+    constexpr int D = PLANNED ? CELLS_PIPE : 2;             // (the text-only form has no registers to spare)
     CellWord cw[D];
     int base = w_begin;
 #pragma unroll

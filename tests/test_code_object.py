@@ -43,9 +43,9 @@ def test_screening_kernels_do_not_spill_and_fit_their_occupancy(kernels):
         assert m["vgpr_count"] <= (80 if "screen_k31_multi" in name else 64), (name, m)
     for name, m in hot.items():
         if "screen_k31c_kernel" in name:
-            planned = re.search(r"screen_k31c_kernelILi\d+ELb[01]ELb1E", name) is not None      # <K, BOTH, PLANNED = true>
-            # (the text-only form -- KCFX_REF_PLAN=0, an A/B hook -- derives the minimizer order in the word loop: 64 is its bound)
-            assert m["vgpr_count"] <= (48 if planned else 64) and m["group_segment_fixed_size"] <= 8192, (name, m)
+            # 64 VGPRs = 8 waves per SIMD: the planned form keeps four words of cell loads in flight per wave (52 - 59 registers), the
+            # text-only form (KCFX_REF_PLAN=0, an A/B hook) two and the minimizer machinery
+            assert m["vgpr_count"] <= 64 and m["group_segment_fixed_size"] <= 8192, (name, m)
         elif "screen_" in name:
             assert m["group_segment_fixed_size"] <= 20480, (name, m)     # 160 KB LDS per CU / 8 workgroups
 
