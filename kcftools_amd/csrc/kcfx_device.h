@@ -352,7 +352,14 @@ struct CellAlt {
     uint32_t r;         // the r field an entry of this k-mer has there
     uint32_t rmask;     // the bits of r that identify it there
 };
-constexpr int CELL_ALT_FREE_MAX_W = 15;       // i.e. every k < 31: even the single free cell of k = 30 is worth having
+// RETIRED at the end of round 3 (KCFX_ALT_FREE_MAX_W = 0: no k uses it; 15 = every k < 31 brings it back): the free cell costs a
+// second load of the line per word, which keeps the first from being non-temporal -- with second lines to fall back on, every k
+// is 8 - 12 % faster without it (k = 21 / 25 / 30: 0.159 / 0.108 / 0.083 ms against 0.179 / 0.121 / 0.090; the stash grows from 0.1 to
+// 0.5 - 2 % of the database, which costs less than the load).
+#ifndef KCFX_ALT_FREE_MAX_W
+#define KCFX_ALT_FREE_MAX_W 0
+#endif
+constexpr int CELL_ALT_FREE_MAX_W = KCFX_ALT_FREE_MAX_W;
 KCFX_HD bool cell_alt_free(int W, int32_t lbits, bool both) { return W <= CELL_ALT_FREE_MAX_W && cell_spare_bits(lbits, both) >= 4; }
 // (call only when cell_alt_free)
 KCFX_HD CellAlt cell_alt_of(uint32_t sh, uint32_t w, uint32_t r, int W, int32_t lbits, bool both) {

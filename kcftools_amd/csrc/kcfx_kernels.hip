@@ -1238,7 +1238,7 @@ __device__ __forceinline__ void cells_issue(const TableView& tv, uint64_t V, con
     // compiler cannot count in vmcnt and waits for with vmcnt(0) -- the end of the software pipeline)
     // (k = 31 only: with a second load of the same line behind it -- the free cell of k < 31 -- the hint costs that load its hit:
     // k = 25, 0.131 ms with it, 0.121 ms without)
-    if constexpr (W == 16) cw.cell = nt_load2(a0);
+    if constexpr (W > CELL_ALT_FREE_MAX_W) cw.cell = nt_load2(a0);
     else cw.cell = *reinterpret_cast<const u32x2*>(a0);
     if constexpr (W <= CELL_ALT_FREE_MAX_W) {
         // (on a table without the free-cell scheme this reads some cell of the line and cells_match ignores it)
@@ -1640,7 +1640,7 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(PLA
         asm volatile("" : "+v"(l32));
         kw.l32 = l32;
         const uint8_t* a0 = reinterpret_cast<const uint8_t*>(reinterpret_cast<const uint32_t*>(tv.lines) + l32);
-        if constexpr (W == 16) kw.cell = nt_load2(a0);       // (non-temporal where nothing reads the line again: see cells_issue)
+        if constexpr (W > CELL_ALT_FREE_MAX_W) kw.cell = nt_load2(a0);       // (non-temporal where nothing reads the line again: see cells_issue)
         else kw.cell = *(gcell_ptr_t)a0;
         if constexpr (W <= CELL_ALT_FREE_MAX_W) {           // k < 31: the free cell of the same line differs in the cell index only
             const CellAlt a = cell_alt_of(p.sh, p.w, p.r, W, tv.lbits, BOTH);
@@ -1691,7 +1691,7 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(PLA
             const bool first = ((kw.cell.x ^ kw.w) <= CELL_FLAG_MASK) && (((kw.cell.y ^ kw.r) & cell_rmask(tv.lbits, BOTH)) == 0);
             l32 ^= (uint64_t)(first ? 0u : kw.dsh);
         }
-        if constexpr (W == 16) cw.c = nt_load4(count_base + (l32 << 3));           // 16 bytes per cell, cell = l32 / 2
+        if constexpr (W > CELL_ALT_FREE_MAX_W) cw.c = nt_load4(count_base + (l32 << 3));           // 16 bytes per cell, cell = l32 / 2
         else cw.c = *(gcount_ptr_t)(count_base + (l32 << 3));
         const uint64_t PM = wave_ballot(pend != 0u) & wave_ballot(cnt == 0u) & kw.V;
         if (PM) {

@@ -242,6 +242,7 @@ void harness_cell_second_line(uint32_t line, uint32_t sh, uint32_t w, uint32_t r
     out[3] = q.r;
 }
 uint32_t harness_cell_rmask(int lbits, int both) { return cell_rmask(lbits, both != 0); }
+int harness_alt_free_max_w(void) { return CELL_ALT_FREE_MAX_W; }
 uint64_t harness_revcomp_word(uint64_t x, int len) { return revcomp_word(x, len); }
 int harness_tile_k(void) { return TILE_K; }
 

@@ -274,7 +274,8 @@ def test_cell_table_build_side_covers_query_side(harness, oracle):
             canon = np.unique(np.concatenate([lst[:m], synth.revcomp(lst[:m], k)]))
         seen, seen_alt, seen_2nd = {}, {}, {}
         W = k - 15
-        free_scheme = k <= 30 and lbits - (17 if both else 18) >= 4
+        # (free-cell second choices are a build-time option, retired by default: CELL_ALT_FREE_MAX_W = 0)
+        free_scheme = k - 15 <= harness.harness_alt_free_max_w() and lbits - (17 if both else 18) >= 4
         rmask = int(harness.harness_cell_rmask(lbits, both))
         q4 = np.zeros(4, dtype=np.uint32)
         for c in canon:
