@@ -337,7 +337,7 @@ struct CellProbe {
 };
 
 // Where a k-mer that lost the bid for its first-choice cell may live, in the order a query looks:
-//  * (k <= 30 and a table with >= 4 spare r bits) in a FREE CELL of the same line: a k-mer spans W = k - 15 <= 15 minimizer
+//  * (only in builds with KCFX_ALT_FREE_MAX_W > 0 -- retired, see below; k <= 30 and a table with >= 4 spare r bits) in a FREE CELL of the same line: a k-mer spans W = k - 15 <= 15 minimizer
 //    positions, so cells W .. 15 of every line are nobody's first choice -- which of them: the leading flank bits. Such a
 //    cell does not say where its tenant came from, so the entry carries its first-choice cell index in 4 of the spare r bits
 //    (never used for a filter there: only cells 0 .. W - 1 are flagged). Looked at in the main pass: same line, no request.

@@ -69,8 +69,8 @@ constexpr int MODE_KEYHASH = 0, MODE_MINIMIZER = 1;
 //   (cell_order27: 0.097 minimizer runs per k-mer instead of 0.118). When several k-mers want one cell, a k-mer whose minimizer
 //   is shared by >= 3 k-mers of the database (the genome's runs -- what a reference window asks for) beats an isolated one, then
 //   the larger counter wins (64-bit atomic max: deterministic, and in a real database the genomic k-mer beats its
-//   sequencing-error neighbours, which share its minimizer and offset). A loser takes, in this order: (k < 31, roomy tables) a
-//   free cell W .. 15 of the same line; the same cell of its SECOND LINE (top lbits of G32' = a second bijection of the
+//   sequencing-error neighbours, which share its minimizer and offset). A loser takes, in this order: (a retired build-time
+//   option, KCFX_ALT_FREE_MAX_W: for k < 31 a free cell W .. 15 of the same line;) the same cell of its SECOND LINE (top lbits of G32' = a second bijection of the
 //   minimizer, r from G32' with bit 15 set: cell_second_line) -- the losers of a minimizer meet again there, one request for
 //   all of them; the stash: open addressing over 16-byte entries {u64 key, u32 count, u32 pad}, slot = hash32(key) & mask,
 //   probed by the lanes individually. Both steps only into EMPTY cells, and each is announced in the cell before it
