@@ -2,7 +2,10 @@
 """bench.py -- k-mers screened/s of the getVariations hot path on N MI355X (BASELINE.json metric).
 
 A "step" is one pass of the hot path over one batch: every window of the reference screened against one
-sample's KMC database (kcfx_screen_ref_async: screen_k31c + reduce_windows), inputs resident in HBM.
+sample's KMC database, inputs resident in HBM -- the reference as TEXT, the database as its table. A step is therefore K1 to K3 of
+SURVEY.md section 8(d): kcfx_ref_plan_async (2-bit pack, validity, minimizer choice: ref_plan_kernel) + kcfx_screen_ref_async
+(screen_k31c + reduce_windows). `--step amortised` leaves the plan out of the step (a job that screens MANY samples against one
+reference plans it once); the line carries both figures either way (`value` / `amortised`, `roofline.frac_one_pass` / `roofline.frac`).
 
 Workload at N=1 (BASELINE.json configs[1]): synthetic A. thaliana chr1-sized reference (30,427,671 bp, seeded),
 one synthetic KMC sample (k=31, counter_size 2, ~150 M k-mers = sample-genome k-mers + random noise k-mers),
@@ -130,6 +133,66 @@ def make_dataset(synth_bin: str, workdir: str, ref_len: int, db_kmers: int, samp
     return prefix, meta
 
 
+def launcher_command(gpus: int, argv: list[str], port: int) -> list[str]:
+    """`python bench.py --gpus N ...` run plainly: the command of the one-process-per-GPU job it stands for."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(gpus: int, argv: list[str]) -> int:
+    """Start the N ranks as a CHILD process (this process has not touched a GPU and never will), relay rank 0's JSON line on
+    stdout and everything else on stderr, return the child's exit code."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["KCFX_BENCH_CHILD"] = "1"
+    cmd = launcher_command(gpus, argv, port)
+    log("bench.py: --gpus", gpus, "without WORLD_SIZE: starting", " ".join(cmd))
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env)
+    line = None
+    for ln in p.stdout:
+        ln = ln.rstrip("\n")
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            log(ln)
+    rc = p.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        log("bench.py: the ranks exited without a bench line")
+        rc = 4
+    return rc
+
+
+def usable_cores() -> int:
+    """Host cores this process may actually run on: the affinity mask, capped by the cgroup CPU quota (a box can show 256
+    logical CPUs and grant 16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:                                                    # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:                                                # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(math.ceil(quota))))
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,7 +210,14 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the FASTA -> KCF command-line run")
     ap.add_argument("--min-count", type=int, default=1)
     ap.add_argument("--spin-ms", type=float, default=60.0,
-                    help="untimed clock ramp before the warm-up steps (setup; 0 = none)")
+                    help="clock ramp before the timed steps: untimed repetitions of the step for this long, COUNTED in the reported "
+                         "\"warmup\"; the same K steps measured before the ramp are reported beside as \"cold_start\" (0 = no ramp)")
+    ap.add_argument("--step", choices=("one-pass", "amortised"), default="one-pass",
+                    help="one-pass: plan + screen + reduce (K1 - K3, what one sample per reference costs); amortised: the plan stays "
+                         "out of the step (many samples per reference)")
+    ap.add_argument("--table", choices=("product", "sparse"), default="product",
+                    help="product: the table density the command-line driver selects for one pass (expected_queries = the step's "
+                         "k-mers); sparse: kcfx_db_open's default for an unknown / large number of look-ups")
     ap.add_argument("--samples", type=int, default=1,
                     help="samples per GPU; > 1 screens them in one pass over the reference (kcfx_screen_ref_multi, SURVEY f-4). "
                          "The default 1 is BASELINE.json's configuration")
@@ -164,9 +234,8 @@ def main():
         local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            log(f"bench.py: --gpus {args.gpus} needs torch.distributed.run (one process per GPU); see the module docstring")
-            sys.exit(2)
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not os.environ.get("KCFX_BENCH_CHILD"):
+            sys.exit(launch_ranks(args.gpus, sys.argv[1:]))  # (before torch is imported: nothing here has touched a GPU)
         args.gpus = world
 
     if args.ref_len <= 0:
@@ -189,7 +258,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     # ---- data: same reference on every rank, one sample database per rank -------------------------------
-    ncpu = os.cpu_count() or 8
+    ncpu = usable_cores()
+    ncpu_logical = os.cpu_count() or ncpu
     t0 = time.time()
     S = max(1, args.samples)
     prefixes = []
@@ -217,18 +287,22 @@ def main():
         win_begin, win_len = win_begin[lo:hi], win_len[lo:hi]
 
     t0 = time.time()
-    cohort = None
-    if args.cohort and S > 1:
-        cohort = engine.Cohort(prefixes, device=local_rank)
-        dbs = [engine.KmcDb.open(prefixes[0], device=local_rank)]          # (the first sample on its own: the parity leg's single-sample twin)
-    else:
-        dbs = [engine.KmcDb.open(pfx, device=local_rank) for pfx in prefixes]
-    db = dbs[0]
-    load_s = (time.time() - t0) / S
-    t0 = time.time()
     ref = engine.Reference(text, win_begin, win_len, K, device=local_rank)      # upload + tile plan + (k = 19 .. 31) the reference plan
     ref_s = time.time() - t0
     n_win = len(win_begin)
+    # The table a handle gets depends on the look-ups it is opened for (kcfx_db_open_opts.expected_queries): the command-line
+    # driver and kcfx_screen_sharded pass one pass over their windows, and that is what is measured here by default.
+    expected = int(ref.n_kmer_slots) if args.table == "product" else 0
+    t0 = time.time()
+    cohort = None
+    if args.cohort and S > 1:
+        cohort = engine.Cohort(prefixes, device=local_rank, expected_queries=expected)
+        dbs = [engine.KmcDb.open(prefixes[0], device=local_rank, expected_queries=expected)]   # (the first sample on its own: the parity leg's single-sample twin)
+    else:
+        dbs = [engine.KmcDb.open(pfx, device=local_rank, expected_queries=expected) for pfx in prefixes]
+    db = dbs[0]
+    load_s = (time.time() - t0) / S
+    one_pass = args.step == "one-pass" and ref.planned
 
     # every rank gathers the same number of records (a window-sharded rank's range is padded to the longest)
     n_rec = S * n_win
@@ -241,7 +315,7 @@ def main():
     gathered = [torch.zeros_like(out, device=cdev) for _ in range(world)] if (world > 1 and rank == 0) else None
     stream = torch.cuda.current_stream()
 
-    def step():
+    def screen():
         if cohort is not None:
             cohort.screen_async(ref, out.data_ptr(), stream.cuda_stream, args.min_count)
         elif S == 1:
@@ -249,21 +323,37 @@ def main():
         else:
             ref.screen_multi_async(dbs, out.data_ptr(), stream.cuda_stream, args.min_count)
 
+    def step():
+        if one_pass:
+            ref.plan_async(stream.cuda_stream)       # K1 + the minimizer choice: ref_plan_kernel over the resident text
+        screen()                                     # K2 + K3: screen_k31c / screen_cohort + reduce_windows
+
     def final_gather():
         if world > 1:
             dist.gather(out.to(cdev), gathered, dst=0)      # RCCL over xGMI: 40 B per (window, sample), once per job
 
-    # Clock ramp, part of the setup and NOT of the W warm-up steps: the driver's run is 5 + 20 steps = 3 ms of GPU work in all,
-    # which an idle GPU spends climbing out of its low-power clocks (round 2: 0.120 ms per launch there against 0.108 ms in
-    # the 500-step runs of the same binary). ~60 ms of the same step, untimed, then the contract's W steps and K timed steps.
-    spin_steps = 0
-    if args.spin_ms > 0:
-        t_spin = time.perf_counter()
-        while (time.perf_counter() - t_spin) * 1e3 < args.spin_ms:
-            for _ in range(50):
-                step()
-            torch.cuda.synchronize()
-            spin_steps += 50
+    def timed(n_steps, with_gather):
+        """the contract's timed region: barrier + synchronize on both sides of exactly n_steps steps; kernel times by HIP events"""
+        ref.prof_enable(True)
+        ref.prof_read(reset=True)
+        ref.prof_read_plan(reset=True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_a = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        if with_gather:
+            final_gather()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t_e = time.perf_counter() - t_a
+        k_ms, k_n = ref.prof_read(reset=True)
+        p_ms, p_n = ref.prof_read_plan(reset=True)
+        ref.prof_enable(False)
+        return t_e, k_ms, k_n, p_ms, p_n
+
     for _ in range(args.warmup):
         step()
     final_gather()                                 # (also warms the communicator up)
@@ -272,22 +362,62 @@ def main():
     res = res_all[0]                               # the sample checked against the oracle below
     kmers_per_step = int(res_all["total_kmers"].sum())
 
+    # Without a clock ramp: the W warm-up steps above, then K steps. The driver's run is 5 + 20 steps = 3 ms of GPU work in all,
+    # which an idle GPU spends climbing out of its low-power clocks; reported as "cold_start" beside the figures below.
+    cold = None
+    spin_steps = 0
+    if args.spin_ms > 0:
+        c_el, c_kms, c_kn, c_pms, c_pn = timed(args.steps, False)
+        cold = {"ms_per_step": c_el / args.steps * 1e3, "kernel_avg_ms": c_kms / max(1, c_kn),
+                "ref_plan_ms": (c_pms / c_pn) if c_pn else None, "warmup": args.warmup, "steps": args.steps,
+                "value": kmers_per_step * args.steps / c_el}
+        # Clock ramp: the same step, untimed, for --spin-ms; its repetitions are COUNTED in the reported "warmup".
+        t_spin = time.perf_counter()
+        while (time.perf_counter() - t_spin) * 1e3 < args.spin_ms:
+            for _ in range(50):
+                step()
+            torch.cuda.synchronize()
+            spin_steps += 50
+
     # ---- timed region -----------------------------------------------------------------------------------------
-    ref.prof_enable(True)
-    ref.prof_read(reset=True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    final_gather()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms, launches = ref.prof_read(reset=True)
-    ref.prof_enable(False)
+    elapsed, kernel_ms, launches, plan_ms_sum, plan_launches = timed(args.steps, True)
+
+    # the other form of the step, beside it (same clocks, no gather): amortised when the step is one pass and vice versa
+    other = None
+    text_only = None
+    if world == 1 and S == 1 and cohort is None and ref.planned:
+        one_pass = not one_pass
+        o_el, o_kms, o_kn, o_pms, o_pn = timed(args.steps, False)
+        one_pass = not one_pass
+        other = {"ms_per_step": o_el / args.steps * 1e3, "kernel_avg_ms": o_kms / max(1, o_kn),
+                 "ref_plan_ms": (o_pms / o_pn) if o_pn else None, "value": kmers_per_step * args.steps / o_el}
+        # ... and K1 - K3 in ONE launch: the same reference kept as text only (KCFX_REF_PLAN=0 is read by kcfx_ref_create), every
+        # tile planned inside the screening kernel
+        try:
+            os.environ["KCFX_REF_PLAN"] = "0"
+            ref_t = engine.Reference(text, win_begin, win_len, K, device=local_rank)
+        finally:
+            os.environ.pop("KCFX_REF_PLAN", None)
+        out_t = torch.zeros_like(out)
+        for _ in range(max(3, args.warmup)):
+            ref_t.screen_async(db, out_t.data_ptr(), stream.cuda_stream, args.min_count)
+        ref_t.prof_enable(True)
+        ref_t.prof_read(reset=True)
+        torch.cuda.synchronize()
+        t_a = time.perf_counter()
+        for _ in range(args.steps):
+            ref_t.screen_async(db, out_t.data_ptr(), stream.cuda_stream, args.min_count)
+        torch.cuda.synchronize()
+        t_el = time.perf_counter() - t_a
+        t_kms, t_kn = ref_t.prof_read(reset=True)
+        ref_t.prof_enable(False)
+        same = bool(torch.equal(out_t, out))
+        text_only = {"kernel_avg_ms": t_kms / max(1, t_kn), "ms_per_step": t_el / args.steps * 1e3,
+                     "value": kmers_per_step * args.steps / t_el, "identical_to_planned": same}
+        if not same:
+            log("bench.py: the text-only reference gives other results than the planned one")
+        ref_t.close()
+        del out_t
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     tot = torch.tensor([kmers_per_step], dtype=torch.int64, device=cdev)
@@ -310,6 +440,12 @@ def main():
     # cohort table the key is compared once for all of them too: (1 + 8) / S + counter_size
     b_alg = ((1.0 + 8.0) / S + COUNTER_SIZE) if cohort is not None else (1.0 / S + 8 + COUNTER_SIZE)
     achieved_gbs = (kmers_per_step * b_alg / launches_per_step) / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
+    # K1 - K3: the plan kernel + the screening kernel of the same timed region (or of the other form of the step, run beside it)
+    plan_avg_ms = (plan_ms_sum / plan_launches) if plan_launches else ((other or {}).get("ref_plan_ms"))
+    one_pass_gbs = ((kmers_per_step * b_alg / launches_per_step) / ((kern_avg_ms + plan_avg_ms) * 1e-3) / 1e9
+                    if (plan_avg_ms and kern_avg_ms > 0) else None)
+    text_only_gbs = ((kmers_per_step * b_alg) / (text_only["kernel_avg_ms"] * 1e-3) / 1e9
+                     if (text_only and text_only["kernel_avg_ms"] > 0) else None)
 
     kernel_name = ("screen_k31c_kernel" if db.info.table_format == 1 else "screen_k31_kernel") if (S == 1 or db.info.table_format == 1) \
         else "screen_k31_multi_kernel"
@@ -329,7 +465,8 @@ def main():
         try:
             tj = json.load(open(tpath))
             if (S == 1 and world == 1 and tj.get("kernel") == kernel_name and tj.get("ref_len") == args.ref_len
-                    and tj.get("db_kmers") == args.db_kmers and tj.get("window") == args.window):
+                    and tj.get("db_kmers") == args.db_kmers and tj.get("window") == args.window
+                    and tj.get("table_lines") in (None, int(db.info.table_lines))):
                 traffic = tj.get("hbm_bytes_per_launch")
                 requests = tj.get("hbm_read_requests_per_launch")
                 rocprof_ms = tj.get("rocprof_kernel_avg_ms")    # the committed rocprofv3 --stats average of the same kernel
@@ -381,7 +518,8 @@ def main():
                          f"list repeated when it is shorter than the time budget), same database files; "
                          f"oracle/kcf_oracle.c (C restatement of the Java path, KMC on-disk layout, thread pool over windows "
                          f"like GetVariants.java:129-151); the best of the thread counts in by_threads",
-               "host_cores": ncpu, "by_threads": by_threads}
+               "host_cores": ncpu, "host_cores_logical": ncpu_logical,
+               "host_cores_source": "sched_getaffinity capped by the cgroup CPU quota", "by_threads": by_threads}
         parity = {"windows_checked": int(checked), "bit_exact": bool(ok)}
         if not ok:
             log("bench.py: GPU results differ from the oracle on the baseline sample")
@@ -473,8 +611,15 @@ def main():
         "unit": "k-mers/s",
         "n_gpus": world,
         "steps": args.steps,
-        "warmup": args.warmup,
+        # (every untimed step before the timed region: the W requested + the clock ramp's; "cold_start" = W warm-up steps, no ramp)
+        "warmup": args.warmup + spin_steps + (args.steps if cold is not None else 0),
+        "warmup_requested": args.warmup,
         "ms_per_step": ms_per_step,
+        "step": ("one pass: ref_plan_kernel + screening kernel + reduce_windows (K1 - K3, reference resident as text + plan buffers)"
+                 if one_pass else "amortised: screening kernel + reduce_windows (the reference's plan made once, outside the step)"),
+        ("amortised" if one_pass else "one_pass"): other,
+        "cold_start": cold,
+        "text_only_reference": text_only,
         "higher_is_better": True,
         "scaling": "strong" if window_sharded else "weak",
         "vs_baseline": None,
@@ -505,7 +650,15 @@ def main():
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": kernel_name, "kernel_avg_ms": kern_avg_ms,
                      "launches_timed": int(launches), "algorithmic_bytes_per_kmer": b_alg if S > 1 else B_ALG,
-                     "rocprof_kernel_avg_ms": rocprof_ms},
+                     "rocprof_kernel_avg_ms": rocprof_ms,
+                     # K1 - K3 for ONE sample: the same bytes over plan + screen (two launches) and over the one launch of a
+                     # text-only reference
+                     "ref_plan_ms": plan_avg_ms, "frac_one_pass": (one_pass_gbs / HBM_PEAK_GBS) if one_pass_gbs else None,
+                     "text_only_kernel_ms": text_only["kernel_avg_ms"] if text_only else None,
+                     "frac_text_only": (text_only_gbs / HBM_PEAK_GBS) if text_only_gbs else None,
+                     "table": {"policy": args.table, "expected_queries": expected, "lines": int(db.info.table_lines),
+                               "bytes": int(db.info.table_bytes), "kmers_per_cell": float(db.info.stored_kmers) / max(1, 16 * int(db.info.table_lines)),
+                               "stash_kmers": int(db.info.stash_kmers)}},
         "cpu_baseline": cpu,
         "end_to_end": e2e,
         "cpu_end_to_end": cpu_e2e,

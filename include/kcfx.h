@@ -283,6 +283,16 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
 int32_t kcfx_prof_enable(kcfx_ref* ref, int32_t enable);
 int32_t kcfx_prof_read(kcfx_ref* ref, double* kernel_ms_sum, int64_t* launches, int32_t reset);
 
+/* The sample-independent half of a pass -- SURVEY's K1: 2-bit pack (Kmer.java:232-252), which positions start a valid k-mer
+ * (Fasta.java:90-127), and which 16-mer of each k-mer is its minimizer -- is worked out by kcfx_ref_create once per reference
+ * and shared by every sample screened against it. kcfx_ref_plan_async runs it again over the resident text on the caller's
+ * stream (idempotent; no allocation, no synchronisation): the cost a one-sample-per-reference job pays per pass, which
+ * bench.py reports beside the screening kernel (ref_plan_ms, frac_one_pass). KCFX_ERR_ARG for a text-only reference.
+ * With profiling enabled the launch is bracketed by events of its own, read by kcfx_prof_read_plan. */
+int32_t kcfx_ref_plan_async(kcfx_ref* ref, void* hip_stream);
+int32_t kcfx_ref_is_planned(const kcfx_ref* ref);     /* 1: codes + anchors resident; 0: text only (planned per launch) */
+int32_t kcfx_prof_read_plan(kcfx_ref* ref, double* kernel_ms_sum, int64_t* launches, int32_t reset);
+
 /* ---- misc --------------------------------------------------------------------------------------------- */
 const char* kcfx_last_error(void);
 int32_t kcfx_device_count(int32_t* n);

@@ -141,6 +141,7 @@ struct kcfx_ref {
     int32_t n_windows = 0;
     int32_t n_tiles = 0;
     int64_t n_slots = 0;
+    int64_t text_len = 0;
     uint8_t* d_text = nullptr;
     uint32_t* d_codes = nullptr;       // RefPlan (k = 19 .. 31: what a cell table's look-ups need of the reference, worked out once;
     uint8_t* d_anchors = nullptr;      // both point into the block of d_text)
@@ -166,6 +167,8 @@ struct kcfx_ref {
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> plan_events;     // kcfx_ref_plan_async launches, when prof is on
+    size_t plan_events_used = 0;
 };
 
 struct kcfx_cohort {
@@ -510,6 +513,10 @@ void ref_free(kcfx_ref* r) {
     if (!r) return;
     DeviceGuard g(r->device);
     for (auto& ev : r->events) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    for (auto& ev : r->plan_events) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
     }
@@ -1008,7 +1015,13 @@ int32_t kcfx_ref_create(int32_t device, int32_t kmer_length, const uint8_t* text
     *out = nullptr;
     if (kmer_length < 1 || kmer_length > 32) return fail(KCFX_ERR_FORMAT, "unsupported k-mer length (1..32)");
     const int32_t k = kmer_length;
-    // tile plan: every window is cut into near-equal tiles of <= TILE_K k-mer start positions (multiples of 64)
+    // KCFX_REF_PLAN=0 in the environment keeps the reference as text only (A/B and test hook, read here, never per launch):
+    // cell-table launches then plan every tile themselves and take tiles of at most TEXT_TILE_K k-mers (k31_plan_tile)
+    const char* plan_env = getenv("KCFX_REF_PLAN");
+    const bool cell_k = k >= CELL_K_MIN && k <= CELL_K_MAX;
+    const bool planned = cell_k && text_len > 0 && !(plan_env && plan_env[0] == '0');
+    const int64_t tile_k = (cell_k && !planned) ? TEXT_TILE_K : TILE_K;
+    // tile plan: every window is cut into near-equal tiles of <= tile_k k-mer start positions (multiples of 64)
     std::vector<TileDesc> tiles;
     std::vector<int32_t> win_tile0((size_t)n_windows + 1, 0);
     int64_t n_slots = 0;
@@ -1019,9 +1032,9 @@ int32_t kcfx_ref_create(int32_t device, int32_t kmer_length, const uint8_t* text
         const int64_t nk = (int64_t)win_len[w] - k + 1;
         if (nk <= 0) continue;
         n_slots += nk;
-        const int64_t nt = (nk + TILE_K - 1) / TILE_K;
+        const int64_t nt = (nk + tile_k - 1) / tile_k;
         int64_t per = (nk + nt - 1) / nt;
-        per = std::min<int64_t>(TILE_K, (per + 63) / 64 * 64);
+        per = std::min<int64_t>(tile_k, (per + 63) / 64 * 64);
         for (int64_t s = 0; s < nk; s += per) {
             TileDesc t;
             t.text_off = win_begin[w] + s;
@@ -1043,11 +1056,9 @@ int32_t kcfx_ref_create(int32_t device, int32_t kmer_length, const uint8_t* text
     r->n_windows = n_windows;
     r->n_tiles = (int32_t)tiles.size();
     r->n_slots = n_slots;
+    r->text_len = text_len;
     // One block: the text (+ 128 zero bytes: the pack phase reads whole 32-byte chunks) and, for cell tables (k = 19 .. 31), the
-    // reference plan behind it -- anchors, then codes, each 256-byte aligned. KCFX_REF_PLAN=0 in the environment keeps the
-    // text-only reference (A/B and test hook, read here, never per launch).
-    const char* plan_env = getenv("KCFX_REF_PLAN");
-    const bool planned = k >= CELL_K_MIN && k <= CELL_K_MAX && text_len > 0 && !(plan_env && plan_env[0] == '0');
+    // reference plan behind it -- anchors, then codes, each 256-byte aligned.
     auto up256 = [](size_t n) { return (n + 255) & ~(size_t)255; };
     const size_t text_alloc = up256((size_t)text_len + 128);
     const size_t ab = planned ? up256(ref_plan_anchor_bytes(text_len)) : 0, cb = planned ? up256(ref_plan_codes_bytes(text_len)) : 0;
@@ -1074,6 +1085,31 @@ int32_t kcfx_ref_create(int32_t device, int32_t kmer_length, const uint8_t* text
     *out = hold.release();
     return KCFX_OK;
 } KCFX_CATCH("kcfx_ref_create")
+
+// The sample-independent half of a pass (SURVEY's K1: 2-bit pack, validity, minimizer choice) over the resident text again, on
+// the caller's stream: what a job that screens ONE sample per reference pays per pass. Idempotent (same text, same plan).
+int32_t kcfx_ref_plan_async(kcfx_ref* ref, void* hip_stream) try {
+    if (!ref) return fail(KCFX_ERR_ARG, "null argument");
+    if (!ref->d_codes) return fail(KCFX_ERR_ARG, "the reference has no plan (text-only: k outside 19 .. 31, or KCFX_REF_PLAN=0)");
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    DeviceGuard g(ref->device);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (ref->prof) {
+        if (ref->plan_events_used == ref->plan_events.size()) {
+            hipEvent_t a, b;
+            KCFX_HIP(hipEventCreate(&a));
+            KCFX_HIP(hipEventCreate(&b));
+            ref->plan_events.emplace_back(a, b);
+        }
+        ev0 = ref->plan_events[ref->plan_events_used].first;
+        ev1 = ref->plan_events[ref->plan_events_used].second;
+        ref->plan_events_used++;
+    }
+    KCFX_HIP(launch_ref_plan(ref->d_text, ref->text_len, ref->k, ref->d_codes, ref->d_anchors, st, ev0, ev1));
+    return KCFX_OK;
+} KCFX_CATCH("kcfx_ref_plan_async")
+
+int32_t kcfx_ref_is_planned(const kcfx_ref* ref) { return ref && ref->d_codes ? 1 : 0; }
 
 int32_t kcfx_ref_n_windows(const kcfx_ref* ref) { return ref ? ref->n_windows : 0; }
 int64_t kcfx_ref_n_kmer_slots(const kcfx_ref* ref) { return ref ? ref->n_slots : 0; }
@@ -1494,6 +1530,22 @@ int32_t kcfx_prof_enable(kcfx_ref* ref, int32_t enable) {
     ref->prof = enable != 0;
     return KCFX_OK;
 }
+
+int32_t kcfx_prof_read_plan(kcfx_ref* ref, double* kernel_ms_sum, int64_t* launches, int32_t reset) try {
+    if (!ref) return fail(KCFX_ERR_ARG, "null argument");
+    DeviceGuard g(ref->device);
+    double sum = 0;
+    for (size_t i = 0; i < ref->plan_events_used; ++i) {
+        KCFX_HIP(hipEventSynchronize(ref->plan_events[i].second));
+        float ms = 0;
+        KCFX_HIP(hipEventElapsedTime(&ms, ref->plan_events[i].first, ref->plan_events[i].second));
+        sum += ms;
+    }
+    if (kernel_ms_sum) *kernel_ms_sum = sum;
+    if (launches) *launches = (int64_t)ref->plan_events_used;
+    if (reset) ref->plan_events_used = 0;
+    return KCFX_OK;
+} KCFX_CATCH("kcfx_prof_read_plan")
 
 int32_t kcfx_prof_read(kcfx_ref* ref, double* kernel_ms_sum, int64_t* launches, int32_t reset) try {
     if (!ref) return fail(KCFX_ERR_ARG, "null argument");

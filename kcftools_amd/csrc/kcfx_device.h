@@ -199,81 +199,71 @@ KCFX_HD bool probe_next(const TableView& tv, bool at_home, bool found, uint32_t 
 }
 
 // ---- FORMAT_CELLS (kcfx_internal.h): k = 31, M = 16 --------------------------------------------------
-// 27-bit hash of a canonical 16-mer, top-aligned (low 5 bits zero). For every fixed (cm & 31) it is a bijection of
-// cm >> 5: cm * odd = 32 (a * odd + q(b)) + r(b) for cm = 32 a + b, the right xorshift and the second odd multiply act
-// bijectively on the top 27 bits once the low 5 are cleared. Low -> high diffusion only: the ORDER of the values picks the
-// minimizer and the top bits pick the line.
-KCFX_HD uint32_t mm27(uint32_t cm) {
-    uint32_t u = cm * 0x9E3779B1u;
-    u ^= u >> 15;
-    u &= ~31u;
-    return u * 0x85EBCA6Bu;
-}
 // ---- the ORDER that picks a k-mer's minimizer ----
-// Not the plain hash: 16-mers that are OPEN SYNCMERS (the smallest of their eleven 6-mers sits in the middle, position 5) come
-// first, CLOSED ones (it sits at either end) second, the rest last; mm27 decides inside a class. Two open syncmers cannot start
-// fewer than 6 bases apart unless they share their smallest 6-mer's neighbourhood, so consecutive k-mers agree on their
-// minimizer for longer: 0.0966 minimizer runs per k-mer instead of 0.1177 (= 2 / 17) on random text (k = 31) -- 18 % fewer table
-// lines per reference k-mer, and the line fetches ARE the screening kernel's time. The 6-mers are hashed in canonical form and the
-// classes are mirror-symmetric, so a 16-mer and its reverse complement get the same class: it is a function of the canonical
-// 16-mer like mm27, and build (cells_visit) and query (K31Words -> ref_plan_kernel) agree by construction. The price -- eleven
-// small hashes per 16-mer -- is paid once per reference position in kcfx_ref_create and once per pass and k-mer in kcfx_db_open,
-// never in a screening launch (those read the anchor bytes of the planned reference).
-KCFX_HD uint32_t smer6_hash(uint32_t x, uint32_t rcx) { return (x < rcx ? x : rcx) * 0x9E3779B1u; }   // distinct for distinct canonical 6-mers
-// u[i] = smer6_hash of the 6-mer at base offset i of the 16-mer, i = 0 .. 10
-KCFX_HD uint32_t cell_class_of(const uint32_t* u) {
-    uint32_t lo = u[0] < u[1] ? u[0] : u[1], hi = u[9] < u[10] ? u[9] : u[10], in_lo = u[1], in_hi = u[9];
-    lo = lo < u[2] ? lo : u[2];
-    lo = lo < u[3] ? lo : u[3];
-    lo = lo < u[4] ? lo : u[4];
-    hi = hi < u[8] ? hi : u[8];
-    hi = hi < u[7] ? hi : u[7];
-    hi = hi < u[6] ? hi : u[6];
-    in_lo = in_lo < u[2] ? in_lo : u[2];
-    in_lo = in_lo < u[3] ? in_lo : u[3];
-    in_lo = in_lo < u[4] ? in_lo : u[4];
-    in_hi = in_hi < u[8] ? in_hi : u[8];
-    in_hi = in_hi < u[7] ? in_hi : u[7];
-    in_hi = in_hi < u[6] ? in_hi : u[6];
-    const uint32_t sides = lo < hi ? lo : hi;
-    if (u[5] < sides) return 0u;                                   // open: a strict minimum in the middle
-    const uint32_t ends = u[0] < u[10] ? u[0] : u[10];
-    uint32_t inner = in_lo < in_hi ? in_lo : in_hi;
-    inner = inner < u[5] ? inner : u[5];
-    return ends <= inner ? 1u : 2u;                                // closed: an end holds the minimum
-}
-// 27-bit order key of a canonical 16-mer, top-aligned (low 5 bits zero): class in the top two bits, 25 hash bits below
-KCFX_HD uint32_t cell_order27(uint32_t cm, uint32_t cls) { return (cls << 30) | ((mm27(cm) >> 2) & ~31u); }
-// the class straight from a 16-mer and its reverse complement (both left-aligned, 32 bits): what a text position computes
-KCFX_HD uint32_t cell_class16(uint32_t m, uint32_t rc_m) {
-    uint32_t u[11];
+// Not the plain hash: 16-mers that are OPEN SYNCMERS (the smallest of their eleven canonical 6-mers sits in the middle, position 5)
+// come first, CLOSED ones (it sits at either end) second, the rest last; inside a class a hash of the 16-mer's eleven 6-mers
+// decides. Two open syncmers cannot start fewer than 6 bases apart unless they share their smallest 6-mer's neighbourhood, so
+// consecutive k-mers agree on their minimizer for longer: 0.0965 minimizer runs per k-mer instead of 0.1177 (= 2 / 17) on random
+// text (k = 31) -- 18 % fewer table lines per reference k-mer, and the line fetches ARE the screening kernel's time.
+// Round 4: the whole key is a function of ONE hash per text position -- u[p] = hash of the canonical 6-mer at p -- so that the
+// planner (StripPlanner below, ref_plan_kernel) pays one multiply per position where round 3 hashed eleven 6-mers and the 16-mer
+// itself for every 16-mer:
+//   class   closed (1) if an end holds the minimum of the eleven (min(u0, u10) <= min(u1..u9)), else open (0) if the middle one
+//           does (u5 == min(u1..u9)), else 2. Mirror-symmetric, ties included, and the 6-mers are hashed in canonical form: a
+//           16-mer and its reverse complement get the same class;
+//   inside  the XOR of the eleven hashes (bits 29..5): a sliding xor -- hx[p + 1] = hx[p] ^ u[p] ^ u[p + 11] -- that is symmetric
+//           too. u = c6 * odd is linear over the integers, not over GF(2): the xor of eleven of them orders 16-mers as well as the
+//           two-multiply hash of the 16-mer did (numpy, 3 Mb: 0.0965 runs per k-mer either way; 1.3e-5 of the windows have two
+//           distinct 16-mers tied for the minimum -- every tied offset gets a copy of the k-mer, cells_visit).
+// Build (cells_visit: the k-mer's k - 5 hashes once, then a key per 16-mer) and query (StripPlanner) compute the same function
+// of the same canonical 6-mers and agree by construction (tests/test_kernel_logic_host.py checks every position of its texts).
+constexpr uint32_t SMER6_MUL = 0x9E3779u;                         // 24 bits: v_mul_u32_u24 (the product of a 12-bit 6-mer fits 36 bits; the low 32 are kept)
+KCFX_HD uint32_t smer6_hash(uint32_t x, uint32_t rcx) { return (x < rcx ? x : rcx) * SMER6_MUL; }   // distinct for distinct canonical 6-mers
+// (spelled out for the device: left to itself the compiler re-associates the sliding minima of kcfx_plan.h into shared pairwise
+// minima -- two v_min_u32 per element where one v_min3_u32 does -- and never forms the three-input xor)
+KCFX_HD uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) {
 #if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
+    uint32_t r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    const uint32_t m = a < b ? a : b;
+    return m < c ? m : c;
 #endif
-    for (int i = 0; i < 11; ++i) u[i] = smer6_hash((m >> (20 - 2 * i)) & 0xFFFu, (rc_m >> (2 * i)) & 0xFFFu);
-    return cell_class_of(u);
 }
-// What one lane feeds into the sliding minimum: order key | position label (bits 4..1: twice the position mod 16, distinct within
+KCFX_HD uint32_t xor3u(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    return a ^ b ^ c;
+#endif
+}
+constexpr uint32_t ORDER_HASH_MASK = 0x3FFFFFE0u;                 // the 25 hash bits of a key: class above, position label and strand below
+constexpr uint32_t ORDER_CLOSED = 1u << 30, ORDER_REST = 2u << 30;
+// class bits of a 16-mer from the hashes of its 6-mers: inner = min(u1 .. u9)
+KCFX_HD uint32_t cell_class30(uint32_t u0, uint32_t u5, uint32_t u10, uint32_t inner) {
+    const uint32_t ends = u0 < u10 ? u0 : u10;
+    return ends <= inner ? ORDER_CLOSED : (u5 == inner ? 0u : ORDER_REST);
+}
+// 27-bit order key of a 16-mer, top-aligned (low 5 bits zero), from u[i] = smer6_hash of the 6-mer at base offset i, i = 0 .. 10
+KCFX_HD uint32_t cell_order27(const uint32_t* u) {
+    const uint32_t inner = min3u(min3u(u[1], u[2], u[3]), min3u(u[4], u[5], u[6]), min3u(u[7], u[8], u[9]));
+    const uint32_t hx = u[0] ^ u[1] ^ u[2] ^ u[3] ^ u[4] ^ u[5] ^ u[6] ^ u[7] ^ u[8] ^ u[9] ^ u[10];
+    return (hx & ORDER_HASH_MASK) | cell_class30(u[0], u[5], u[10], inner);
+}
+// What a position feeds into the sliding minimum: order key | position label (bits 4..1: twice the position mod 16, distinct within
 // any 16 consecutive positions) | strand bit (bit 0: the canonical form is the reverse complement of the 16-mer as the
 // text reads it). The minimum therefore carries where the minimizer sits and which way round it is; with the label
-// pre-doubled the query gets 2 * offset as (mn - 2 * lane) & 30, the strand bit riding along untouched.
-KCFX_HD uint32_t order27_tagged(uint32_t fwd_m, uint32_t rc_m, uint32_t label2) {
-    const uint32_t cm = fwd_m < rc_m ? fwd_m : rc_m;
-    const uint32_t key = cell_order27(cm, cell_class16(fwd_m, rc_m));
-#if defined(__HIP_DEVICE_COMPILE__)
-    // key + label + (rc < fwd) as compare + add-with-carry: the three fields do not overlap. (hipcc turns every C spelling of
-    // this into v_cmp + v_cndmask + v_or3.)
-    uint32_t t;
-    asm("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %3, %4, vcc" : "=v"(t) : "v"(rc_m), "v"(fwd_m), "v"(key), "v"(label2) : "vcc");
-    return t;
-#else
+// pre-doubled the query gets 2 * offset as (mn - 2 * position) & 30, the strand bit riding along untouched.
+KCFX_HD uint32_t order27_tagged(uint32_t key, uint32_t fwd_m, uint32_t rc_m, uint32_t label2) {
     return key | (rc_m < fwd_m ? 1u : 0u) | label2;
-#endif
 }
 KCFX_HD uint32_t order27_label2(uint32_t pos) { return (pos & 15u) << 1; }
 // canonical minimizer 16-mer -> G32: line = top lbits, r = the rest. A bijection on 32 bits (odd multiplies, right
-// xorshift), so (line, r) identify the minimizer exactly, and independent of mm27: the MINIMUM of 16 hashes is skewed towards
-// 0 and keeps only ~24 bits of entropy, which would leave most lines of a table of 2^27 or more lines unused.
+// xorshift), so (line, r) identify the minimizer exactly, and independent of the order key: the MINIMUM of 16 keys is skewed
+// towards 0 and keeps only ~24 bits of entropy, which would leave most lines of a table of 2^27 or more lines unused.
 KCFX_HD uint32_t cell_g32(uint32_t cm) {
     uint32_t x = cm * 0xC2B2AE35u;
     x ^= x >> 15;
@@ -451,10 +441,7 @@ KCFX_HD int cells_visit(uint64_t C, int32_t k, int32_t lbits, bool both, F&& f) 
 #endif
     for (int j = 0; j < 16; ++j) {
         key[j] = 0xFFFFFFFFu;                                 // (never a key: those end in five zero bits)
-        if (j < W) {
-            const uint32_t m = (uint32_t)((C << (2 * j)) >> 32) & cell_mmask(M), r = rc_mmer(m, M);
-            key[j] = cell_order27(m < r ? m : r, cell_class_of(U + j));
-        }
+        if (j < W) key[j] = cell_order27(U + j);
         best = key[j] < best ? key[j] : best;
     }
     int n = 0;

@@ -142,6 +142,10 @@ constexpr int TILE_K = KCFX_TILE_K;   // k-mer start positions per tile (multipl
 constexpr int TILE_WORDS = TILE_K / 64;
 // per tile: TILE_WORDS valid-ballots then TILE_WORDS hit-ballots (screen kernel -> reduce_windows)
 constexpr int TILE_BITS_U64 = 2 * TILE_WORDS;
+// A reference that is kept as text only (KCFX_REF_PLAN=0) is planned tile by tile inside the screening launch (k31_plan_tile):
+// each of the CELLS_BLOCK / 64 waves plans 62 strips of 16 positions, which covers tiles of at most this many k-mers
+constexpr int PLAN_TILE_STRIPS = 62;
+constexpr int TEXT_TILE_K = (16 * (PLAN_TILE_STRIPS * (CELLS_BLOCK / 64) + 2) - 30 - 15) / 64 * 64;
 
 // The sample-independent half of a cell-table look-up, worked out once per reference (launch_ref_plan, k = 19 .. 31):
 // 2-bit codes of the text (16 bases per dword, first base in the top bits) and one anchor byte per k-mer start position
@@ -302,7 +306,8 @@ hipError_t launch_screen_cohort(const uint8_t* text, RefPlan plan, const TileDes
 // the plan of a reference (RefPlan): `text` must be readable 128 bytes past text_len (zeros), the outputs sized as below
 size_t ref_plan_codes_bytes(int64_t text_len);
 size_t ref_plan_anchor_bytes(int64_t text_len);
-hipError_t launch_ref_plan(const uint8_t* text, int64_t text_len, int32_t k, uint32_t* codes, uint8_t* anchors, hipStream_t st);
+hipError_t launch_ref_plan(const uint8_t* text, int64_t text_len, int32_t k, uint32_t* codes, uint8_t* anchors, hipStream_t st,
+                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // lookup
 hipError_t launch_lookup(TableView tv, int32_t k, const uint64_t* keys, int64_t n, int32_t* counts_out, hipStream_t st);
 // screen

@@ -21,6 +21,7 @@
 #include <cstdlib>
 
 #include "kcfx_device.h"
+#include "kcfx_plan.h"
 
 #include <type_traits>
 
@@ -932,10 +933,10 @@ __device__ __forceinline__ bool k31_tile_clean(const K31Pack& sh) {
     return __builtin_amdgcn_readfirstlane((int)d) == 0;
 }
 
-// The words of a tile as one wave sees them: canonical key, minimizer and validity ballot of 64 consecutive positions per
-// step, everything in registers. Carried from one word to the next: the leading code words of both strands at this lane's
-// position and the row scans of the M-mer hashes they give.
-template <bool CELLS, int K = 31>
+// The words of a tile as one wave sees them (line-table kernels): both strands of the k-mer, minimizer and validity ballot of 64
+// consecutive positions per step, everything in registers. Carried from one word to the next: the leading code words of both
+// strands at this lane's position and the row scans of the M-mer hashes they give. (Cell tables do not come through here: their
+// minimizers are the planner's business -- kcfx_plan.h -- whether the reference was planned or is planned tile by tile.)
 struct K31Words {
     // Between consecutive words every code-bit address advances by the same amount (64 positions = 4 code dwords of each
     // strand = 2 validity dwords) and the shifts do not change: the addresses are carried, not recomputed.
@@ -945,51 +946,14 @@ struct K31Words {
     int n_kmers, lane, next15;
     bool clean;                 // no invalid base anywhere in the tile: validity = "inside the tile"
     uint32_t Fc, Cc, Pc, Sc;
-    uint32_t Hc;                // (NW < 16 only) the hash this lane's position feeds into the sliding minimum
-    // a k-mer spans NW 16-mers: 16 for k = 31 (one DPP row: the van Herk scans below), k - 15 for the shorter k of a cell table
-    static constexpr int NW = CELLS ? cell_nw(K) : 16;
-
-    // min(E[lane .. lane + NW - 1]) over E = hc (this word's 64 positions) ++ hn (the next word's), NW = 2 .. 15, by doubling:
-    // dc[p] = min(E[p .. p + span - 1]) with span = 1, 2, 4, 8, then one overlapping step for the rest. Two bpermutes per step
-    // (the same lane address serves both halves); dn only ever needs its low lanes, which never look past hn.
-    __device__ __forceinline__ uint32_t window_min(uint32_t hc, uint32_t hn) const {
-        uint32_t dc = hc, dn = hn;
-        int span = 1;
-#pragma unroll
-        for (int d = 1; 2 * d <= NW; d <<= 1) {
-            const int addr = ((lane + d) & 63) << 2;
-            const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)dc);
-            const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)dn);
-            dc = min(dc, lane + d < 64 ? a : b);
-            dn = min(dn, b);
-            span = 2 * d;
-        }
-        if (span < NW) {
-            const int d = NW - span;
-            const int addr = ((lane + d) & 63) << 2;
-            const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)dc);
-            const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)dn);
-            dc = min(dc, lane + d < 64 ? a : b);
-        }
-        return dc;
-    }
 
     // what a position feeds into the sliding minimum, from the leading 32 code bits of both strands: the hash of its canonical
-    // 16-mer; FORMAT_CELLS tables tag it with the strand and the position (order27_tagged) so that the minimum also says where
-    // the minimizer sits in each k-mer
-    __device__ __forceinline__ uint32_t mmer_of(uint32_t f0, uint32_t c0) const {
-        if constexpr (CELLS) {
-            // the 16-mer is the leading 32 code bits; its reverse complement the same bits of the complement-swapped
-            // stream, reversed
-            return order27_tagged(f0, brev32(c0), order27_label2((uint32_t)lane));
-        } else {
-            return mhash32(((uint64_t)min(f0, brev32(c0))) << 32);
-        }
-    }
+    // 16-mer (its reverse complement: the same bits of the complement-swapped stream, reversed)
+    __device__ __forceinline__ uint32_t mmer_of(uint32_t f0, uint32_t c0) const { return mhash32(((uint64_t)min(f0, brev32(c0))) << 32); }
     __device__ __forceinline__ void start(const K31Pack& sh, int off, int n_kmers_, int lane_, int w_begin) {
         n_kmers = n_kmers_;
         lane = lane_;
-        clean = k31_tile_clean<CELLS ? CELLS_BLOCK / 64 : WAVES>(sh);
+        clean = k31_tile_clean<WAVES>(sh);
         next15 = ((lane + 15) & 63) << 2;                   // ds_bpermute address of lane + 15 (mod 64)
         const int q = off + w_begin * 64 + lane;
         const int b0 = 2 * q - 1;                            // bits_at(., 2q) on both strands at once
@@ -1001,13 +965,12 @@ struct K31Words {
         const uint2 x = p_fc[0], y = p_fc[1];
         Fc = alignbit32(x.x, y.x, sh_fc);
         Cc = alignbit32(x.y, y.y, sh_fc);
-        if constexpr (NW == 16) row_scan_min(mmer_of(Fc, Cc), Pc, Sc);
-        else Hc = mmer_of(Fc, Cc);
+        row_scan_min(mmer_of(Fc, Cc), Pc, Sc);
     }
     // word w (call with consecutive w): the k-mer as the text reads it and its reverse complement (Kmer.java:232-252,
     // :300-338), the minimum over its 16 M-mers, validity
     __device__ __forceinline__ void next(int w, uint64_t& fwd, uint64_t& rc, uint32_t& mn, uint64_t& V) {
-        constexpr int k = K;
+        constexpr int k = 31;
         // bits [2q+32, 2q+64) of this word (one entry on) and bits [2(q+64), 2(q+64)+32) of the next (four entries on)
         // share the carried shift
         constexpr uint32_t lo_mask = ~0u << (64 - 2 * k);
@@ -1016,9 +979,8 @@ struct K31Words {
         const uint32_t c1 = alignbit32(x0.y, x1.y, sh_fc) & lo_mask;
         const uint32_t Fn = alignbit32(x3.x, x4.x, sh_fc);
         const uint32_t Cn = alignbit32(x3.y, x4.y, sh_fc);
-        uint32_t Pn = 0, Sn = 0, Hn = 0;
-        if constexpr (NW == 16) row_scan_min(mmer_of(Fn, Cn), Pn, Sn);
-        else Hn = mmer_of(Fn, Cn);
+        uint32_t Pn = 0, Sn = 0;
+        row_scan_min(mmer_of(Fn, Cn), Pn, Sn);
         // extract_kmer (kcfx_device.h) from the four halves
         fwd = u64_of(f1, Fc);
         rc = u64_of(brev32(Cc), brev32(c1)) << (64 - 2 * k);
@@ -1027,19 +989,14 @@ struct K31Words {
         const int rem = n_kmers - w * 64;
         V = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
         if (!clean) V &= wave_ballot((alignbit32(p_vb[0], p_vb[1], sh_vb) >> (32 - k)) == (uint32_t)((1ull << k) - 1));
-        if constexpr (NW == 16) {
-            // minimum over the k-mer's 16 M-mers = min(S[lane], P[lane + 15])
-            const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(next15, (int)Pc);
-            const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute(next15, (int)Pn);
-            mn = min(Sc, lane < 49 ? pa : pb);
-        } else {
-            mn = window_min(Hc, Hn);
-        }
+        // minimum over the k-mer's 16 M-mers = min(S[lane], P[lane + 15])
+        const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(next15, (int)Pc);
+        const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute(next15, (int)Pn);
+        mn = min(Sc, lane < 49 ? pa : pb);
         Fc = Fn;
         Cc = Cn;
         Pc = Pn;
         Sc = Sn;
-        Hc = Hn;
         p_fc += 4;
         p_vb += 2;
     }
@@ -1120,7 +1077,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     static_assert((uint64_t)TILE_WORDS * 64 * 65535 < (1ull << 32), "32-bit count sums");
     typename std::conditional<WIDE, int64_t, uint32_t>::type sum_acc = 0;   // per lane
     uint64_t* my_bits = bits + (size_t)blockIdx.x * TILE_BITS_U64;
-    K31Words<false> words;
+    K31Words words;
     if (w_begin < w_end) words.start(sh.pk, off, td.n_kmers, lane, w_begin);
 
     for (int w = w_begin; w < w_end; ++w) {
@@ -1286,8 +1243,8 @@ __device__ __forceinline__ void cells_match(const CellWord& cw, int32_t lbits, u
 
 // ---- the planned reference ------------------------------------------------------------------------------------------
 // Which 16-mer of a reference k-mer is its minimizer, on which strand it is canonical and whether all k bases are A/C/G/T
-// does not depend on the sample: kcfx_ref_create works it out ONCE per reference (ref_plan_kernel: the pack phase, the
-// hashes, the sliding minimum of K31Words) and keeps, beside the text,
+// does not depend on the sample: kcfx_ref_create works it out ONCE per reference (ref_plan_kernel: StripPlanner, kcfx_plan.h)
+// and keeps, beside the text,
 //   codes    2 bits per base, 16 bases per dword, first base in the top bits (what the pack phase used to rebuild in LDS
 //            for every tile of every launch), and
 //   anchors  one byte per k-mer start position: bit 7 = the k-mer is valid, bits 4..1 = 2 * (the cell index: the minimizer's
@@ -1320,6 +1277,105 @@ __device__ __forceinline__ int k31_load_plan_tile(K31Plan& sh, const RefPlan& pl
     const uint4* const an = reinterpret_cast<const uint4*>(plan.anchors + a0);
     const int n16 = (off + td.n_kmers + 15) >> 4;
     for (int c = tid; c < n16; c += NT) sh.an[c] = an[c];
+    __syncthreads();
+    return off;
+}
+
+// ---- the planner on the device: one strip per lane, exchanges through wave-private LDS ------------------------------
+// A wave plans 64 consecutive strips; what a strip needs of its right-hand neighbour travels through a row of 16 dwords per
+// lane (the first code words: dwords 0..2; the first 10 hashes: 4..13; then, over both, the first W - 1 tagged keys). The lanes
+// of a wave execute their LDS instructions in order, so a compiler fence between a row's write and the neighbour's read is
+// all the synchronisation there is. Lane 63 has no neighbour in the wave: its results are not used, the next wave (or the next
+// workgroup) starts at its strip again -- 1 / 64 of the work, against a barrier per exchange.
+constexpr int PLAN_ROWS = 66;                               // 64 lanes + the rows lane 63 and 62 read past the end (garbage, unused)
+typedef uint32_t PlanRows[PLAN_ROWS][16];
+template <int K, int L>
+struct PlanWaveIo {
+    using P = StripPlanner<K, L>;
+    uint32_t (*rows)[16];                                   // this wave's rows
+    int lane;
+    const uint8_t* text;                                    // the strip's first base (16-byte aligned); null: behind the readable text -> zeros
+    __device__ __forceinline__ void load_text(uint32_t (&x)[L / 4]) const {
+#pragma unroll
+        for (int i = 0; i < L / 16; ++i) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (text) v = reinterpret_cast<const uint4*>(text)[i];
+            x[4 * i] = v.x;
+            x[4 * i + 1] = v.y;
+            x[4 * i + 2] = v.z;
+            x[4 * i + 3] = v.w;
+        }
+    }
+    __device__ __forceinline__ void exchange_first(const typename P::First& mine, typename P::First (&nb)[P::VN]) const {
+        *reinterpret_cast<uint4*>(rows[lane]) = make_uint4(mine.F0, mine.G0, mine.valid, 0u);
+        wave_lds_fence();
+#pragma unroll
+        for (int i = 0; i < P::VN; ++i) {
+            const uint4 v = *reinterpret_cast<const uint4*>(rows[lane + 1 + i]);
+            nb[i].F0 = v.x;
+            nb[i].G0 = v.y;
+            nb[i].valid = v.z;
+        }
+    }
+    __device__ __forceinline__ void exchange_hashes(const uint32_t (&u)[L + P::UH], uint32_t (&uh)[P::UH]) const {
+        static_assert(P::UH == 10, "row layout");
+        uint4* mine = reinterpret_cast<uint4*>(rows[lane]);
+        mine[1] = make_uint4(u[0], u[1], u[2], u[3]);
+        mine[2] = make_uint4(u[4], u[5], u[6], u[7]);
+        *reinterpret_cast<uint2*>(mine + 3) = make_uint2(u[8], u[9]);
+        wave_lds_fence();
+        const uint4* theirs = reinterpret_cast<const uint4*>(rows[lane + 1]);
+        const uint4 a = theirs[1], b = theirs[2];
+        const uint2 c = *reinterpret_cast<const uint2*>(theirs + 3);
+        uh[0] = a.x; uh[1] = a.y; uh[2] = a.z; uh[3] = a.w;
+        uh[4] = b.x; uh[5] = b.y; uh[6] = b.z; uh[7] = b.w;
+        uh[8] = c.x; uh[9] = c.y;
+    }
+    __device__ __forceinline__ void exchange_keys(const uint32_t (&t)[L + P::TH], uint32_t (&th)[P::TH]) const {
+        wave_lds_fence();                                   // (every lane has read its neighbour's hashes: the rows are free)
+        uint4* mine = reinterpret_cast<uint4*>(rows[lane]);
+#pragma unroll
+        for (int i = 0; i < (P::TH + 3) / 4; ++i)           // (t has at least L >= 16 entries: whole uint4s)
+            mine[i] = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
+        wave_lds_fence();
+        const uint4* theirs = reinterpret_cast<const uint4*>(rows[lane + 1]);
+#pragma unroll
+        for (int i = 0; i < (P::TH + 3) / 4; ++i) {
+            const uint4 v = theirs[i];
+            if (4 * i < P::TH) th[4 * i] = v.x;
+            if (4 * i + 1 < P::TH) th[4 * i + 1] = v.y;
+            if (4 * i + 2 < P::TH) th[4 * i + 2] = v.z;
+            if (4 * i + 3 < P::TH) th[4 * i + 3] = v.w;
+        }
+        wave_lds_fence();                                   // (the rows may be reused by the caller)
+    }
+    // every base this WAVE looked at is A/C/G/T: the valid-start masks are all ones (wave-uniform, so a branch costs nothing)
+    __device__ __forceinline__ bool all_clean(bool mine) const { return wave_ballot(!mine) == 0ull; }
+};
+
+// phase 1 of a launch on a text-only reference (KCFX_REF_PLAN=0, or kcfx_screen with a one-shot text): the tile is planned
+// here, straight into the LDS layout a planned reference is copied into -- K1 to K3 in one launch. Each wave plans 64 strips of
+// 16 positions from the tile's 16-aligned start, wave w from strip 62 w: with 16-position strips the last TWO lanes of a wave
+// depend on the missing neighbour (lane 63's keys need hashes of lane 64's bases, lane 62's minima need lane 63's keys), so a
+// wave yields the anchors of 62 strips and the codes of 64. Such a reference is therefore cut into tiles of at most
+// TEXT_TILE_K k-mers (kcfx_ref_create): off <= 15, and the last k-mer's 30 bases behind it must have codes.
+static_assert(PLAN_TILE_STRIPS * CELLS_WAVES == (PLAN_TILE_STRIPS * CELLS_BLOCK) / 64, "TEXT_TILE_K (kcfx_internal.h) is written in terms of CELLS_BLOCK");
+static_assert(TEXT_TILE_K <= TILE_K && TEXT_TILE_K + 15 <= 16 * PLAN_TILE_STRIPS * CELLS_WAVES, "text-only tiles: anchors for every k-mer");
+template <int K>
+__device__ __forceinline__ int k31_plan_tile(K31Plan& sh, PlanRows& rows, const uint8_t* __restrict__ text, const TileDesc& td, int tid) {
+    using P = StripPlanner<K, 16>;
+    const int64_t a0 = td.text_off & ~(int64_t)15;
+    const int off = (int)(td.text_off - a0);
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int strip = PLAN_TILE_STRIPS * wave + lane;
+    // bases the tile's k-mers, their 16-mers' keys and those keys' 6-mers reach: nothing behind them is read (the text is
+    // readable 128 bytes past its end, a tile ends at most there minus K - 1)
+    const int need = off + td.n_kmers + 30;
+    PlanWaveIo<K, 16> io{rows, lane, 16 * strip < need ? text + a0 + 16 * (int64_t)strip : nullptr};
+    const typename P::Result res = P::run(io);
+    if (tid == 0) sh.fcx[0] = make_uint2(0u, 0u);
+    if (lane < PLAN_TILE_STRIPS || wave == CELLS_WAVES - 1) sh.fcx[1 + strip] = make_uint2(res.codes[0], comp_swap(res.codes[0]));
+    if (lane < PLAN_TILE_STRIPS) sh.an[strip] = make_uint4(res.anchors[0], res.anchors[1], res.anchors[2], res.anchors[3]);
     __syncthreads();
     return off;
 }
@@ -1428,28 +1484,36 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
     const uint8_t* __restrict__ text, RefPlan plan, const TileDesc* __restrict__ tiles, TableView tv, int32_t min_count,
     uint64_t* __restrict__ bits, int64_t* __restrict__ count_sums) {
     constexpr int WAVES = CELLS_WAVES;                      // (this kernel's own workgroup shape: kcfx_internal.h)
-    using Lds = typename std::conditional<PLANNED, K31Plan, K31Pack>::type;
+    using Lds = K31Plan;
     __shared__ Lds sh;
-    __shared__ K31CQueue s_queue[WAVES];
+    // (a text-only reference is planned tile by tile: the planner's exchange rows are dead before the queues are first written)
+    union WaveScratch {
+        K31CQueue queue;
+        PlanRows rows;
+    };
+    __shared__ __attribute__((aligned(16))) typename std::conditional<PLANNED, K31CQueue, WaveScratch>::type s_scratch[WAVES];
     const TileDesc td = tiles[blockIdx.x];
     const int tid = threadIdx.x;
     int off;
     if constexpr (PLANNED) off = k31_load_plan_tile<CELLS_BLOCK>(sh, plan, td, K, tid);
-    else off = k31_pack_tile<CELLS_BLOCK>(sh, text, td, tid);
+    else off = k31_plan_tile<K>(sh, s_scratch[__builtin_amdgcn_readfirstlane(tid >> 6)].rows, text, td, tid);
 
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_words = (td.n_kmers + 63) >> 6;
     const int wpw = (n_words + WAVES - 1) / WAVES;
     const int w_begin = min(wave * wpw, n_words);
     const int w_end = min(w_begin + wpw, n_words);
-    K31CQueue& q = s_queue[wave];
+    K31CQueue* qp;
+    if constexpr (PLANNED) qp = &s_scratch[wave];
+    else qp = &s_scratch[wave].queue;
+    K31CQueue& q = *qp;
     int qn = 0;                                             // queued k-mers (wave-uniform)
     const int pos0 = off + w_begin * 64;                    // packed position of the wave's first k-mer
 
     uint32_t sum_acc = 0;                                   // per lane; u16 counters: fits (static_assert in screen_k31_kernel)
     int64_t big_acc = 0;                                    // counters beyond 16 bits come from the stash only, rarely
     uint64_t* my_bits = bits + (size_t)blockIdx.x * TILE_BITS_U64;
-    typename std::conditional<PLANNED, PlannedWords<K>, K31Words<true, K>>::type words;
+    PlannedWords<K> words;
     if (w_begin < w_end) words.start(sh, off, td.n_kmers, lane, w_begin);
 
     // a queued k-mer found in its second line or in the stash
@@ -1462,18 +1526,10 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
     };
     // stage A of word w: keys, minimizer, cell, fetches issued
     auto issue = [&](int w, CellWord& cw) {
-        if constexpr (PLANNED) {
-            uint64_t N, V;
-            uint32_t sh2, fm;
-            words.next(w, N, sh2, fm, V);
-            cells_issue<cell_nw(K), BOTH>(tv, V, cell_probe_planned<BOTH>(N, sh2, fm, tv.lbits), sh2 | (fm & 1u), cw);
-        } else {
-            uint64_t fwd, rc, V;
-            uint32_t mn;
-            words.next(w, fwd, rc, mn, V);
-            const CellProbe p = cell_probe_of(fwd, rc, mn, 2u * (uint32_t)lane, tv.lbits, cell_mlen(K), BOTH, cell_nw(K));
-            cells_issue<cell_nw(K), BOTH>(tv, V, p, p.sh | (mn & 1u), cw);
-        }
+        uint64_t N, V;
+        uint32_t sh2, fm;
+        words.next(w, N, sh2, fm, V);
+        cells_issue<cell_nw(K), BOTH>(tv, V, cell_probe_planned<BOTH>(N, sh2, fm, tv.lbits), sh2 | (fm & 1u), cw);
     };
     // stage B of word w: cells matched, ballots out, stash candidates queued
     auto retire = [&](int w, const CellWord& cw) {
@@ -1502,7 +1558,7 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
     // <= 2 D - 2 words are peeled (there a skipped issue makes the compiler wait for everything in flight, which by then is old).
     // Before the cell load became non-temporal D = 2, 3, 4, 6 measured the same; since then the memory system takes more than two
     // words per wave can keep in flight: D = 2 / 3 / 4 / 5 / 6 = 0.0816 / 0.0790 / 0.0779 / 0.0783 / 0.084 ms (profiles/r03_notes.md).
-    constexpr int D = PLANNED ? CELLS_PIPE : 2;             // (the text-only form has no registers to spare)
+    constexpr int D = CELLS_PIPE;
     CellWord cw[D];
     int base = w_begin;
 #pragma unroll
@@ -1570,28 +1626,35 @@ typedef const __attribute__((address_space(1))) u32x2* gcell_ptr_t;
 typedef u32x4_ u32x4;
 typedef const __attribute__((address_space(1))) u32x4* gcount_ptr_t;
 
-// (the text-only form -- an A/B hook -- carries the minimizer machinery's registers on top: planned for 4 waves per SIMD)
 template <int K, bool BOTH, bool PLANNED>
-__global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(PLANNED ? 6 : 4, 8))) void screen_cohort_kernel(
+__global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) void screen_cohort_kernel(
     const uint8_t* __restrict__ text, RefPlan plan, const TileDesc* __restrict__ tiles, int32_t n_tiles, CohortView cv, int32_t min_count,
     uint64_t* __restrict__ bits, int64_t* __restrict__ count_sums) {
     constexpr int W = cell_nw(K);                           // 16-mers per k-mer = cells of a line a k-mer can sit in
     constexpr int WAVES = CELLS_WAVES;
-    using Lds = typename std::conditional<PLANNED, K31Plan, K31Pack>::type;
+    using Lds = K31Plan;
     __shared__ Lds sh;
-    __shared__ CohortQueue s_queue[WAVES];
+    union WaveScratch {                                     // (text-only reference: the planner's rows are dead before the queues live)
+        CohortQueue queue;
+        PlanRows rows;
+    };
+    __shared__ __attribute__((aligned(16))) typename std::conditional<PLANNED, CohortQueue, WaveScratch>::type s_scratch[WAVES];
     __shared__ uint32_t s_sums[WAVES][COHORT_STRIDE];
     const TableView& tv = cv.tv;
     const int S = cv.n_samples;
     const TileDesc td = tiles[blockIdx.x];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    CohortQueue& q = s_queue[wave];
-    // the hit words are OR-ed into (the stash may add a k-mer's bits before or after its word's own ballots arrive)
-    for (int i = lane; i < COHORT_STRIDE * CELLS_WORDS_PER_WAVE; i += 64) (&q.hit[0][0])[i] = 0ull;
-    int off;                                                               // (the barrier inside also orders the zeroing above)
+    int off;
     if constexpr (PLANNED) off = k31_load_plan_tile<CELLS_BLOCK>(sh, plan, td, K, tid);
-    else off = k31_pack_tile<CELLS_BLOCK>(sh, text, td, tid);
+    else off = k31_plan_tile<K>(sh, s_scratch[wave].rows, text, td, tid);
+    CohortQueue* qp;
+    if constexpr (PLANNED) qp = &s_scratch[wave];
+    else qp = &s_scratch[wave].queue;
+    CohortQueue& q = *qp;
+    // the hit words are OR-ed into (the stash may add a k-mer's bits before or after its word's own ballots arrive); wave-private
+    for (int i = lane; i < COHORT_STRIDE * CELLS_WORDS_PER_WAVE; i += 64) (&q.hit[0][0])[i] = 0ull;
+    wave_lds_fence();
 
     const int n_words = (td.n_kmers + 63) >> 6;
     const int wpw = (n_words + WAVES - 1) / WAVES;
@@ -1602,7 +1665,7 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(PLA
     uint32_t sum[COHORT_STRIDE];
 #pragma unroll
     for (int s = 0; s < COHORT_STRIDE; ++s) sum[s] = 0;
-    typename std::conditional<PLANNED, PlannedWords<K>, K31Words<true, K>>::type words;
+    PlannedWords<K> words;
     if (w_begin < w_end) words.start(sh, off, td.n_kmers, lane, w_begin);
     const uint8_t* const count_base = reinterpret_cast<const uint8_t*>(cv.counts);
 
@@ -1616,18 +1679,12 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(PLA
         uint64_t V;
         CellProbe p;
         uint32_t anc;
-        if constexpr (PLANNED) {
+        {
             uint64_t N;
             uint32_t sh2, fm;
             words.next(w, N, sh2, fm, V);
             p = cell_probe_planned<BOTH>(N, sh2, fm, tv.lbits);
             anc = sh2 | (fm & 1u);
-        } else {
-            uint64_t fwd, rc;
-            uint32_t mn;
-            words.next(w, fwd, rc, mn, V);
-            p = cell_probe_of(fwd, rc, mn, 2u * (uint32_t)lane, tv.lbits, 16, BOTH, W);
-            anc = p.sh | (mn & 1u);
         }
         const bool valid = __builtin_amdgcn_inverse_ballot_w64(V);
         kw.V = V;
@@ -1775,44 +1832,35 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(PLA
 }
 
 // ---- kcfx_ref_create: the plan of a reference (see K31Plan) ---------------------------------------------------------
-// One workgroup per TILE_K consecutive text positions: the pack phase and the word walk of the unplanned screening kernel,
-// with the anchor byte written where that kernel would have probed. Positions whose k-mer runs past the text read the zero
-// padding behind it and come out invalid.
+// One WAVE per 63 strips of 32 text positions (StripPlanner<K, 32>; lane 63 only lends its first words to lane 62, see
+// PlanWaveIo): 2 016 positions per wave, four independent waves per workgroup, no barrier. The anchor bytes leave through the
+// wave's rows so that a store instruction writes 1 KB of consecutive bytes. Positions whose k-mer runs past the text read the
+// zero padding behind it (or, further out, are handed zeros) and come out invalid.
+constexpr int PLAN_BLOCK = 256, PLAN_WAVES = PLAN_BLOCK / 64, PLAN_L = 32, PLAN_WAVE_POS = 63 * PLAN_L;
 template <int K>
-__global__ __launch_bounds__(CELLS_BLOCK) void ref_plan_kernel(const uint8_t* __restrict__ text, int64_t text_len,
-                                                               uint32_t* __restrict__ codes, uint8_t* __restrict__ anchors) {
-    constexpr int WAVES = CELLS_WAVES, W = cell_nw(K);
-    __shared__ K31Pack sh;
-    TileDesc td;
-    td.text_off = (int64_t)blockIdx.x * TILE_K;
-    td.n_kmers = (int32_t)min((int64_t)TILE_K, text_len - td.text_off);
-    td.window = 0;
-    const int tid = threadIdx.x;
-    const int off = k31_pack_tile<CELLS_BLOCK>(sh, text, td, tid);             // (0: tiles start on multiples of TILE_K)
-    // the tile's own 32-base chunks of codes (what lies behind the text stays zero: kcfx_ref_create clears the array)
-    for (int c = tid; c < TILE_K / 32; c += CELLS_BLOCK) {
-        uint2 v = make_uint2(0u, 0u);
-        if (32 * c < td.n_kmers) v = make_uint2(sh.fcx[1 + 2 * c].x, sh.fcx[2 + 2 * c].x);
-        reinterpret_cast<uint2*>(codes)[(td.text_off >> 5) + c] = v;
-    }
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_words = (td.n_kmers + 63) >> 6;
-    const int wpw = (n_words + WAVES - 1) / WAVES;
-    const int w_begin = min(wave * wpw, n_words);
-    const int w_end = min(w_begin + wpw, n_words);
-    if (w_begin >= w_end) return;
-    K31Words<true, K> words;
-    words.start(sh, off, td.n_kmers, lane, w_begin);
-    for (int w = w_begin; w < w_end; ++w) {
-        uint64_t fwd, rc, V;
-        uint32_t mn;
-        words.next(w, fwd, rc, mn, V);
-        // cell_probe_of's sh and flip
-        const bool flip = (mn & 1u) != 0u;
-        uint32_t sh2 = (mn - 2u * (uint32_t)lane) & 30u;
-        sh2 = flip ? 2u * (uint32_t)(W - 1) - sh2 : sh2;
-        const bool valid = __builtin_amdgcn_inverse_ballot_w64(V);
-        anchors[td.text_off + w * 64 + lane] = (uint8_t)((valid ? 0x80u : 0u) | sh2 | (flip ? 1u : 0u));
+__global__ __launch_bounds__(PLAN_BLOCK) void ref_plan_kernel(const uint8_t* __restrict__ text, int64_t text_len, int64_t text_readable,
+                                                             uint32_t* __restrict__ codes, int64_t codes_words,
+                                                             uint8_t* __restrict__ anchors, int64_t anchor_bytes) {
+    using P = StripPlanner<K, PLAN_L>;
+    __shared__ __attribute__((aligned(16))) PlanRows s_rows[PLAN_WAVES];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t origin = ((int64_t)blockIdx.x * PLAN_WAVES + wave) * PLAN_WAVE_POS;
+    if (origin >= text_len) return;                         // (wave-uniform; the waves of a workgroup do not meet again)
+    const int64_t s0 = origin + (int64_t)lane * PLAN_L;
+    PlanWaveIo<K, PLAN_L> io{s_rows[wave], lane, s0 + PLAN_L <= text_readable ? text + s0 : nullptr};
+    const typename P::Result res = P::run(io);
+    if (lane < 63 && (s0 >> 4) + P::NF <= codes_words)
+        *reinterpret_cast<uint2*>(codes + (s0 >> 4)) = make_uint2(res.codes[0], res.codes[1]);
+    // anchors: lane l's 32 bytes to bytes 32 l .. of the rows, read back 16 bytes per lane and instruction
+    uint4* const flat = reinterpret_cast<uint4*>(s_rows[wave]);
+    flat[2 * lane] = make_uint4(res.anchors[0], res.anchors[1], res.anchors[2], res.anchors[3]);
+    flat[2 * lane + 1] = make_uint4(res.anchors[4], res.anchors[5], res.anchors[6], res.anchors[7]);
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int piece = 64 * i + lane;                    // 16-byte piece of the wave's 2 016 anchor bytes
+        const int64_t at = origin + 16 * (int64_t)piece;
+        if (piece < PLAN_WAVE_POS / 16 && at + 16 <= anchor_bytes) *reinterpret_cast<uint4*>(anchors + at) = flat[piece];
     }
 }
 
@@ -1948,7 +1996,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) v
     int qn = 0;
     if (lane < MULTI_MAX) s_msum[wave][lane] = 0;
     wave_lds_fence();
-    K31Words<false> words;
+    K31Words words;
     if (w_begin < w_end) words.start(sh.pk, off, td.n_kmers, lane, w_begin);
 
     for (int w = w_begin; w < w_end; ++w) {
@@ -2198,10 +2246,14 @@ hipError_t launch_reduce_windows(const TileDesc* tiles, int32_t n_tiles, int32_t
 // whole tiles of TILE_K positions + what a screening tile reads past its last k-mer (two code chunks, one 16-byte anchor piece)
 size_t ref_plan_codes_bytes(int64_t text_len) { return (size_t)((text_len + TILE_K - 1) / TILE_K * TILE_K + 256) / 4; }
 size_t ref_plan_anchor_bytes(int64_t text_len) { return (size_t)((text_len + TILE_K - 1) / TILE_K * TILE_K + 128); }
-hipError_t launch_ref_plan(const uint8_t* text, int64_t text_len, int32_t k, uint32_t* codes, uint8_t* anchors, hipStream_t st) {
+hipError_t launch_ref_plan(const uint8_t* text, int64_t text_len, int32_t k, uint32_t* codes, uint8_t* anchors, hipStream_t st,
+                           hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (text_len <= 0) return hipSuccess;
-    const dim3 g((unsigned)((text_len + TILE_K - 1) / TILE_K)), b(CELLS_BLOCK);
-#define KCFX_LAUNCHP(KK) hipLaunchKernelGGL((ref_plan_kernel<KK>), g, b, 0, st, text, text_len, codes, anchors)
+    const int64_t n_waves = (text_len + PLAN_WAVE_POS - 1) / PLAN_WAVE_POS;
+    const dim3 g((unsigned)((n_waves + PLAN_WAVES - 1) / PLAN_WAVES)), b(PLAN_BLOCK);
+    // (the text is readable 128 bytes past its end: kcfx_ref_create)
+    const int64_t readable = text_len + 128, cw = (int64_t)(ref_plan_codes_bytes(text_len) / 4), ab = (int64_t)ref_plan_anchor_bytes(text_len);
+#define KCFX_LAUNCHP(KK) hipExtLaunchKernelGGL((ref_plan_kernel<KK>), g, b, 0, st, ev_start, ev_stop, 0, text, text_len, readable, codes, cw, anchors, ab)
     switch (k) {
         case 19: KCFX_LAUNCHP(19); break;
         case 20: KCFX_LAUNCHP(20); break;

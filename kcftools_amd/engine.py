@@ -31,7 +31,7 @@ ABI_SYMBOLS = (
     "kcfx_cohort_open", "kcfx_cohort_info", "kcfx_cohort_close", "kcfx_cohort_screen_ref", "kcfx_cohort_screen_ref_async",
     "kcfx_ctx_create", "kcfx_ctx_n_devices", "kcfx_ctx_destroy", "kcfx_screen_sharded", "kcfx_shard_plan",
     "kcfx_score", "kcfx_windows",
-    "kcfx_prof_enable", "kcfx_prof_read", "kcfx_last_error", "kcfx_device_count", "kcfx_version",
+    "kcfx_prof_enable", "kcfx_prof_read", "kcfx_ref_plan_async", "kcfx_ref_is_planned", "kcfx_prof_read_plan", "kcfx_last_error", "kcfx_device_count", "kcfx_version",
 )
 
 
@@ -148,6 +148,9 @@ def lib() -> C.CDLL:
         L.kcfx_windows.argtypes = [i32, i32, i32, i32, vp, vp, i64, C.POINTER(i64)]
         L.kcfx_prof_enable.argtypes = [vp, i32]
         L.kcfx_prof_read.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), i32]
+        L.kcfx_prof_read_plan.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), i32]
+        L.kcfx_ref_plan_async.argtypes = [vp, vp]
+        L.kcfx_ref_is_planned.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -351,6 +354,19 @@ class Reference:
     def prof_read(self, reset: bool = True) -> tuple[float, int]:
         ms, n = C.c_double(0), C.c_int64(0)
         _check(lib().kcfx_prof_read(self._h, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
+    def plan_async(self, stream: int = 0) -> None:
+        """The sample-independent half of a pass (2-bit pack, validity, minimizer choice) over the resident text again."""
+        _check(lib().kcfx_ref_plan_async(self._h, C.c_void_p(stream)))
+
+    @property
+    def planned(self) -> bool:
+        return bool(lib().kcfx_ref_is_planned(self._h))
+
+    def prof_read_plan(self, reset: bool = True) -> tuple[float, int]:
+        ms, n = C.c_double(0), C.c_int64(0)
+        _check(lib().kcfx_prof_read_plan(self._h, C.byref(ms), C.byref(n), int(reset)))
         return ms.value, n.value
 
     def close(self) -> None:

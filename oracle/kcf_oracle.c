@@ -448,25 +448,53 @@ void kcfo_accumulate(const int32_t* counts, int32_t n, int k, int32_t min_count,
     out->kmer_count_sum = kmer_count;
 }
 
-/* GetVariants.java:202-261 processWindow */
-int kcfo_process_window(const kcfo_db* db, const char* seq, int32_t len, int32_t min_count, kcfo_result* out) {
+/* GetVariants.java:202-261 processWindow, on scratch the caller owns (a worker thread keeps its two arrays across windows:
+ * the JVM's allocator is thread-local too, and two malloc / free pairs of ~100 KB per window are not part of the algorithm) */
+typedef struct {
+    uint64_t* kmers;
+    int32_t* counts;
+    int32_t cap;
+} kcfo_scratch;
+
+static int scratch_reserve(kcfo_scratch* s, int32_t cap) {
+    if (cap <= s->cap) return 0;
+    free(s->kmers);
+    free(s->counts);
+    s->kmers = (uint64_t*)malloc((size_t)cap * 8);
+    s->counts = (int32_t*)malloc((size_t)cap * 4);
+    s->cap = (s->kmers && s->counts) ? cap : 0;
+    return s->cap ? 0 : 1;
+}
+
+static void scratch_free(kcfo_scratch* s) {
+    free(s->kmers);
+    free(s->counts);
+    s->kmers = NULL;
+    s->counts = NULL;
+    s->cap = 0;
+}
+
+static int process_window_on(const kcfo_db* db, const char* seq, int32_t len, int32_t min_count, kcfo_result* out, kcfo_scratch* s) {
     int k = db->info.kmer_length;
     memset(out, 0, sizeof *out);
     int32_t cap = len - k + 1;
-    if (cap < 0) cap = 0;
-    uint64_t* kmers = (uint64_t*)malloc((size_t)(cap ? cap : 1) * 8);
-    int32_t* counts = (int32_t*)malloc((size_t)(cap ? cap : 1) * 4);
-    if (!kmers || !counts) { free(kmers); free(counts); return fail("out of memory", NULL); }
-    int32_t n = kcfo_kmers_list(seq, len, k, kmers);                       /* :217 */
+    if (cap < 1) cap = 1;
+    if (scratch_reserve(s, cap)) return fail("out of memory", NULL);
+    int32_t n = kcfo_kmers_list(seq, len, k, s->kmers);                    /* :217 */
     for (int32_t i = 0; i < n; i++) {
-        uint64_t km = db->info.both_strands ? kcfo_kmer_canonical(kmers[i], k) : kmers[i]; /* :222 */
-        counts[i] = kcfo_get_count(db, km);                                /* :223 */
+        uint64_t km = db->info.both_strands ? kcfo_kmer_canonical(s->kmers[i], k) : s->kmers[i]; /* :222 */
+        s->counts[i] = kcfo_get_count(db, km);                             /* :223 */
     }
-    kcfo_accumulate(counts, n, k, min_count, out);                         /* :219-252 */
+    kcfo_accumulate(s->counts, n, k, min_count, out);                      /* :219-252 */
     out->eff_length = kcfo_eff_length(seq, len, k);                        /* :256 */
-    free(kmers);
-    free(counts);
     return 0;
+}
+
+int kcfo_process_window(const kcfo_db* db, const char* seq, int32_t len, int32_t min_count, kcfo_result* out) {
+    kcfo_scratch s = {NULL, NULL, 0};
+    int rc = process_window_on(db, seq, len, min_count, out, &s);
+    scratch_free(&s);
+    return rc;
 }
 
 /* Data.java:87 (meanKmerCount) and :95-107 (computeScore); weights = {wi, wt, wr} (GetVariants.java:388-390) */
@@ -535,11 +563,13 @@ typedef struct {
 
 static void* worker(void* arg) {
     job_t* j = (job_t*)arg;
+    kcfo_scratch s = {NULL, NULL, 0};
     for (;;) {
         int32_t w = __sync_fetch_and_add(j->next, 1);
         if (w >= j->n_windows) break;
-        if (kcfo_process_window(j->db, j->text + j->win_begin[w], j->win_len[w], j->min_count, &j->out[w])) j->rc = 1;
+        if (process_window_on(j->db, j->text + j->win_begin[w], j->win_len[w], j->min_count, &j->out[w], &s)) j->rc = 1;
     }
+    scratch_free(&s);
     return NULL;
 }
 

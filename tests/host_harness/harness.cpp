@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../kcftools_amd/csrc/kcfx_device.h"
+#include "../../kcftools_amd/csrc/kcfx_plan.h"
 
 using namespace kcfx;
 
@@ -180,11 +181,18 @@ int harness_minimizers(const uint8_t* text, int64_t text_off, int n_kmers, int k
 int harness_cells(const uint8_t* text, int64_t text_off, int n_kmers, int k, int lbits, int both, int32_t* n_cands_out, uint32_t* probe_out) {
     const int M = cell_mlen(k), W = cell_nw(k);
     Packed P = pack_tile(text, text_off, n_kmers, k);
-    std::vector<uint32_t> h(n_kmers + 16);
+    // position by position, straight from the definition (kcfx_device.h): u = hash of the canonical 6-mer at every position,
+    // the 16-mer's key from its eleven, tagged with strand and position
+    std::vector<uint32_t> u(n_kmers + 32), h(n_kmers + 16);
+    for (int p = 0; p < n_kmers + 15 + 10; ++p) {
+        uint64_t f, r;
+        extract_pair(P.fw(), P.cw(), P.off + p, 6, f, r);
+        u[p] = smer6_hash((uint32_t)(f >> 52), (uint32_t)(r >> 52));
+    }
     for (int p = 0; p < n_kmers + 15; ++p) {
         uint64_t f, r;
         extract_pair(P.fw(), P.cw(), P.off + p, M, f, r);
-        h[p] = order27_tagged((uint32_t)(f >> 32), (uint32_t)(r >> 32), order27_label2((uint32_t)p));     // extract_pair masks to M bases
+        h[p] = order27_tagged(cell_order27(u.data() + p), (uint32_t)(f >> 32), (uint32_t)(r >> 32), order27_label2((uint32_t)p));     // extract_pair masks to M bases
     }
     int bad = 0;
     for (int j = 0; j < n_kmers; ++j) {
@@ -246,4 +254,114 @@ int harness_alt_free_max_w(void) { return CELL_ALT_FREE_MAX_W; }
 uint64_t harness_revcomp_word(uint64_t x, int len) { return revcomp_word(x, len); }
 int harness_tile_k(void) { return TILE_K; }
 
+}
+
+// ---- the strip planner (kcfx_plan.h), emulated: `n_strips` consecutive strips of L positions from text + origin, processed from
+// the last to the first so that every strip finds what its right-hand neighbour published (the device runs them in lockstep
+// with the same three exchanges). Strips past the last have published nothing: zeros, as the device reads unwritten rows.
+template <int K, int L>
+struct HostStripIo {
+    using P = StripPlanner<K, L>;
+    struct Pub {
+        typename P::First first{0, 0, 0};
+        uint32_t u[P::UH] = {0};
+        uint32_t t[16] = {0};
+    };
+    std::vector<Pub>* pub;
+    int strip;
+    const uint8_t* text;      // null: zeros
+    void load_text(uint32_t (&x)[L / 4]) const {
+        if (text) memcpy(x, text, L); else memset(x, 0, L);
+    }
+    void exchange_first(const typename P::First& mine, typename P::First (&nb)[P::VN]) const {
+        (*pub)[strip].first = mine;
+        for (int i = 0; i < P::VN; ++i) nb[i] = (*pub)[strip + 1 + i].first;
+    }
+    void exchange_hashes(const uint32_t (&u)[L + P::UH], uint32_t (&uh)[P::UH]) const {
+        for (int i = 0; i < P::UH; ++i) (*pub)[strip].u[i] = u[i];
+        for (int i = 0; i < P::UH; ++i) uh[i] = (*pub)[strip + 1].u[i];
+    }
+    void exchange_keys(const uint32_t (&t)[L + P::TH], uint32_t (&th)[P::TH]) const {
+        for (int i = 0; i < P::TH; ++i) (*pub)[strip].t[i] = t[i];
+        for (int i = 0; i < P::TH; ++i) th[i] = (*pub)[strip + 1].t[i];
+    }
+    bool all_clean(bool mine) const { return mine; }
+};
+// exchange 0 must be complete for strips to the right before a strip hashes: on the device every lane packs first. Here: a
+// first pass that only publishes `first`, then the full pass from right to left (run() publishes the same `first` again).
+template <int K, int L>
+static void plan_strips(const uint8_t* text, int64_t readable, int64_t origin, int n_strips, uint32_t* codes_out, uint8_t* anchors_out) {
+    using P = StripPlanner<K, L>;
+    std::vector<typename HostStripIo<K, L>::Pub> pub(n_strips + 3);
+    auto strip_text = [&](int s) -> const uint8_t* { return origin + (int64_t)(s + 1) * L <= readable ? text + origin + (int64_t)s * L : nullptr; };
+    for (int s = 0; s < n_strips; ++s) {
+        uint32_t x[L / 4];
+        HostStripIo<K, L> io{&pub, s, strip_text(s)};
+        io.load_text(x);
+        uint32_t valid = 0, F0 = 0, G0 = 0;
+        for (int i = 0; i < L / 16; ++i) {
+            uint32_t c, v;
+            pack16(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3], c, v);
+            if (i == 0) {
+                F0 = c;
+                G0 = brev32(comp_swap(c));
+            }
+            valid = (valid << 16) | v;
+        }
+        pub[s].first = typename P::First{F0, G0, valid};
+    }
+    for (int s = n_strips - 1; s >= 0; --s) {
+        HostStripIo<K, L> io{&pub, s, strip_text(s)};
+        const typename P::Result r = P::run(io);
+        for (int i = 0; i < P::NF; ++i) codes_out[(size_t)s * P::NF + i] = r.codes[i];
+        memcpy(anchors_out + (size_t)s * L, r.anchors, L);
+    }
+}
+template <int L>
+static int plan_strips_k(int k, const uint8_t* text, int64_t readable, int64_t origin, int n_strips, uint32_t* codes_out, uint8_t* anchors_out) {
+    switch (k) {
+#define KCFX_CASE(KK) case KK: plan_strips<KK, L>(text, readable, origin, n_strips, codes_out, anchors_out); return 0;
+        KCFX_CASE(19) KCFX_CASE(20) KCFX_CASE(21) KCFX_CASE(22) KCFX_CASE(23) KCFX_CASE(24) KCFX_CASE(25)
+        KCFX_CASE(26) KCFX_CASE(27) KCFX_CASE(28) KCFX_CASE(29) KCFX_CASE(30) KCFX_CASE(31)
+#undef KCFX_CASE
+    }
+    return 1;
+}
+extern "C" {
+// codes_out: n_strips * L / 16 words, anchors_out: n_strips * L bytes. The LAST strips depend on neighbours that do not exist
+// (L = 32: the last one; L = 16: the last two) exactly as the last lanes of a wave do on the device.
+int harness_plan_strips(const uint8_t* text, int64_t readable, int64_t origin, int n_strips, int k, int L, uint32_t* codes_out, uint8_t* anchors_out) {
+    if (L == 32) return plan_strips_k<32>(k, text, readable, origin, n_strips, codes_out, anchors_out);
+    if (L == 16) return plan_strips_k<16>(k, text, readable, origin, n_strips, codes_out, anchors_out);
+    return 1;
+}
+// what the planner must produce for the k-mer at text position pos, from the definition: bit 7 valid, bits 4..1 = 2 * offset of
+// the minimizer in N, bit 0 = N is the reverse complement. Returns how many anchors are acceptable (cands[0 ..]): more than one
+// when the minimum key is attained at several offsets -- the planner breaks such ties by position labels relative to its
+// origin, and the build side stores the k-mer at every tied offset (cells_visit).
+int harness_anchor_reference(const uint8_t* text, int64_t pos, int k, int* cands) {
+    const int W = cell_nw(k);
+    Packed P = pack_tile(text, pos, 1, k);
+    const bool valid = kmer_valid(P.vb(), P.off, k);
+    uint32_t u[32], key[16], best = 0xFFFFFFFFu;
+    for (int i = 0; i < W + 10; ++i) {
+        uint64_t f, r;
+        extract_pair(P.fw(), P.cw(), P.off + i, 6, f, r);
+        u[i] = smer6_hash((uint32_t)(f >> 52), (uint32_t)(r >> 52));
+    }
+    for (int j = 0; j < W; ++j) {
+        key[j] = cell_order27(u + j);
+        if (key[j] < best) best = key[j];
+    }
+    int n = 0;
+    for (int j = 0; j < W; ++j) {
+        if (key[j] != best) continue;
+        uint64_t f, r;
+        extract_pair(P.fw(), P.cw(), P.off + j, 16, f, r);
+        const bool flip = r < f;
+        const int off = flip ? W - 1 - j : j;
+        cands[n++] = (valid ? 0x80 : 0) | (2 * off) | (flip ? 1 : 0);
+    }
+    return n;
+}
 }

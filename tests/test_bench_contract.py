@@ -39,3 +39,48 @@ def test_committed_bench_line_has_the_contract_fields():
     s = json.load(open(os.path.join(ROOT, "profiles", "r02_summary.json")))
     assert abs(s["rocprof_kernel_avg_ms"] - r["kernel_avg_ms"]) < 0.1 * r["kernel_avg_ms"]
     assert r["traffic"] is None or r["traffic"] > alg      # HBM traffic by PMC is above the algorithmic bytes
+
+
+def test_gpus_n_run_plainly_starts_the_ranks_as_a_child(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE must not die on argument handling: it starts
+    `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process (before anything imports torch or
+    touches a GPU), relays rank 0's JSON line on stdout and returns the child's exit code."""
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.launcher_command(4, ["--gpus", "4", "--steps", "20"], 29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29511" and cmd[-4:] == ["--gpus", "4", "--steps", "20"]
+    assert os.path.samefile(cmd[cmd.index("--master-port") + 2], os.path.join(ROOT, "bench.py"))
+
+    # the relay, with a stand-in for the ranks: a fake `torch.distributed.run` module earlier on the path
+    pkg = tmp_path / "torch" / "distributed"
+    pkg.mkdir(parents=True)
+    (tmp_path / "torch" / "__init__.py").write_text("")
+    (pkg / "__init__.py").write_text("")
+    (pkg / "run.py").write_text(
+        "import os, sys\n"
+        "assert os.environ.get('KCFX_BENCH_CHILD') == '1' and os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY') == '0'\n"
+        "print('rank chatter')\n"
+        "print('{\"metric\": \"k-mers screened/sec, getVariations k=31\", \"value\": 1.0, \"n_gpus\": 2}')\n"
+        "sys.exit(int(os.environ.get('FAKE_RC', '0')))\n")
+    env = dict(os.environ, PYTHONPATH=str(tmp_path))
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3"], capture_output=True, text=True, env=env)
+    assert p.returncode == 0, p.stderr
+    out = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(out) == 1 and json.loads(out[0])["n_gpus"] == 2            # ONE JSON line on stdout ...
+    assert "rank chatter" in p.stderr                                     # ... the rest on stderr
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       env=dict(env, FAKE_RC="7"))
+    assert p.returncode == 7                                              # a failing job fails the command
+
+
+def test_usable_cores_is_the_affinity_mask_not_the_logical_count():
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    n = bench.usable_cores()
+    assert 1 <= n <= len(os.sched_getaffinity(0))

@@ -43,9 +43,11 @@ def test_screening_kernels_do_not_spill_and_fit_their_occupancy(kernels):
         assert m["vgpr_count"] <= (80 if "screen_k31_multi" in name else 64), (name, m)
     for name, m in hot.items():
         if "screen_k31c_kernel" in name:
-            # 64 VGPRs = 8 waves per SIMD: the planned form keeps four words of cell loads in flight per wave (52 - 59 registers), the
-            # text-only form (KCFX_REF_PLAN=0, an A/B hook) two and the minimizer machinery
-            assert m["vgpr_count"] <= 64 and m["group_segment_fixed_size"] <= 8192, (name, m)
+            # 64 VGPRs = 8 waves per SIMD: four words of cell loads in flight per wave (52 - 59 registers). The text-only form
+            # (KCFX_REF_PLAN=0: every tile planned inside the launch, kcfx_plan.h) carries the planner's exchange rows in LDS on
+            # top (a union with the queues): 12 KB per workgroup of two waves = 13 workgroups per CU, 6.5 waves per SIMD
+            text_only = name.endswith("Lb0EEEvPKhNS_7RefPlanEPKNS_8TileDescENS_9TableViewEiPmPl")
+            assert m["vgpr_count"] <= 64 and m["group_segment_fixed_size"] <= (12288 if text_only else 8192), (name, m)
         elif "screen_" in name:
             assert m["group_segment_fixed_size"] <= 20480, (name, m)     # 160 KB LDS per CU / 8 workgroups
 

@@ -55,6 +55,8 @@ def harness():
     L.harness_cell_second_line.restype = None
     L.harness_cell_rmask.argtypes = [C.c_int, C.c_int]
     L.harness_cell_rmask.restype = C.c_uint32
+    L.harness_plan_strips.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.harness_anchor_reference.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
     return L
 
 
@@ -306,10 +308,61 @@ def test_cell_table_build_side_covers_query_side(harness, oracle):
                 assert seen_2nd.setdefault(second, int(c)) == int(c), (k, lbits, hex(int(c)), hex(seen_2nd[second]))
 
 
+def _planner_text(rng):
+    acgt = np.frombuffer(b"ACGTacgt", dtype=np.uint8)
+    pal = b"ACGTACGTACGTACGT"
+    text = bytes(rng.choice(acgt, 9000))
+    return (text[:700] + b"A" * 90 + b"AT" * 45 + b"ACG" * 33 + text[700:1500] + pal + text[1500:1600] + pal * 2 + b"N" + text[1600:2500] +
+            b"NNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNN" + text[2500:4000] + b"R" + text[4000:4016] + b"y" + text[4016:6000] + text[3000:3400] + b"\xff" +
+            text[6000:])
+
+
+@pytest.mark.parametrize("L", [32, 16])
+def test_strip_planner_matches_the_definition(harness, L):
+    """kcfx_plan.h (the code ref_plan_kernel and the text-only screening kernels run, strip by strip with the device's three
+    neighbour exchanges emulated): every anchor byte -- valid bit, minimizer offset in N, strand -- against the position-by-
+    position definition (cell_order27 over the k-mer's 16-mers, the one cells_visit builds the table with), and the codes against
+    pack16. Origins at every alignment a tile can have, every k a cell table exists for, N-runs, IUPAC codes, soft-masking,
+    low-complexity runs and palindromes, the end of the text (zero padding) included."""
+    rng = np.random.default_rng(77)
+    text = _planner_text(rng)
+    buf = padded(text)
+    readable = len(text) + 128
+    cands = np.zeros(16, dtype=np.int32)
+    for k in (31, 30, 27, 25, 22, 21, 19):
+        for origin in ((0, 16, 48, 1008, 2016) if L == 16 else (0, 32, 2016, 4032)):
+            n_strips = 64
+            codes = np.zeros(n_strips * L // 16, dtype=np.uint32)
+            anchors = np.zeros(n_strips * L, dtype=np.uint8)
+            assert harness.harness_plan_strips(buf.ctypes.data, readable, origin, n_strips, k, L, codes.ctypes.data, anchors.ctypes.data) == 0
+            good = n_strips - (1 if L == 32 else 2)             # the last strips miss their neighbours, as the last lanes of a wave do
+            n_tied = 0
+            for j in range(good * L):
+                pos = origin + j
+                if pos + k > len(text):
+                    assert anchors[j] & 0x80 == 0, (k, origin, j)
+                    continue
+                n = harness.harness_anchor_reference(buf.ctypes.data, pos, k, cands.ctypes.data)
+                assert n >= 1
+                if cands[0] & 0x80:
+                    assert int(anchors[j]) in set(int(c) for c in cands[:n]), (k, L, origin, j, hex(anchors[j]), [hex(int(c)) for c in cands[:n]])
+                else:
+                    assert anchors[j] & 0x80 == 0, (k, origin, j)
+                n_tied += n > 1
+            assert n_tied < 0.25 * good * L                     # (the text starts with low-complexity runs: ties are the point there)
+            # codes: 16 bases per word, first base in the top bits, A C G T = 0 1 2 3 whatever the case
+            code_of = {65: 0, 67: 1, 71: 2, 84: 3, 97: 0, 99: 1, 103: 2, 116: 3}
+            for w in range(n_strips * L // 16):
+                for i in range(16):
+                    p0 = origin + 16 * w + i
+                    if p0 < len(text) and text[p0] in code_of:
+                        assert (int(codes[w]) >> (30 - 2 * i)) & 3 == code_of[text[p0]]
+
+
 def test_minimizer_order_keeps_runs_long(harness):
     """The minimizer order (cell_order27: open syncmers first, closed ones second) exists to make consecutive k-mers agree on
     their minimizer for longer: on uniform text a random order gives 2 / 17 = 0.1177 minimizer runs per 31-mer, this one
-    0.0966 (numpy simulation in profiles/r03_notes.md). Measured here on what the device code itself derives (the query side of
+    0.0965 (numpy simulation in profiles/r03_notes.md, r04_notes.md). Measured here on what the device code itself derives (the query side of
     harness_cells): a run ends where (line, r) changes. A regression of the class function would show as a density near 0.118."""
     rng = np.random.default_rng(2024)
     text = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 40_000))
