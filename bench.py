@@ -199,9 +199,11 @@ def main():
     ap.add_argument("--steps", type=int, default=500, help="default sized for a timed region of ~0.1 s")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--ref-len", type=int, default=0, help="0 = 30,427,671 (configs[1]) on one GPU, 119,667,750 (configs[3]) on several")
-    ap.add_argument("--shard", choices=("samples", "windows"), default="samples",
+    ap.add_argument("--shard", choices=("samples", "windows", "cohort"), default="samples",
                     help="N > 1: one sample per GPU against the whole window list (weak scaling, configs[3]) or one sample "
-                         "replicated and the windows split (strong scaling, the S < G case)")
+                         "replicated and the windows split (strong scaling, the S < G case); cohort = --samples S (the JOB's samples) "
+                         "in cohort tables of eight, tables x window ranges over the GPUs (kcfx_shard_plan, KCFX_SHARD_COHORT: "
+                         "8 samples on 8 GPUs = every GPU the same table and an eighth of the windows; 32 = four tables, two GPUs each)")
     ap.add_argument("--db-kmers", type=int, default=150_000_000)
     ap.add_argument("--window", type=int, default=10_000)
     ap.add_argument("--workdir", default=os.environ.get("KCFX_BENCH_DIR", "/tmp/kcfx_bench"))
@@ -240,7 +242,10 @@ def main():
 
     if args.ref_len <= 0:
         args.ref_len = 30_427_671 if world == 1 else 119_667_750
-    window_sharded = world > 1 and args.shard == "windows"
+    cohort_sharded = world > 1 and args.shard == "cohort"
+    if cohort_sharded:
+        args.cohort = True
+    window_sharded = world > 1 and args.shard in ("windows", "cohort")      # (the samples are the same on every rank, the windows are cut)
     synth_bin = ensure_built()
     import torch
     import torch.distributed as dist
@@ -281,7 +286,20 @@ def main():
     win_begin = starts.astype(np.int64)
     win_len = (ends - starts).astype(np.int32)
     n_win_total = len(win_begin)
-    if window_sharded:
+    if cohort_sharded:
+        # this rank's unit of the cohort plan: a group of up to eight of the job's samples and a window range
+        from kcftools_amd import shard
+        segs = shard.cohort_segments_of_rank(win_len, K, S, world, rank)
+        if len(segs) != 1:
+            log(f"bench.py: --shard cohort with {S} samples on {world} GPUs gives rank {rank} {len(segs)} units; use a GPU count that is "
+                f"a multiple of the {-(-S // 8)} table(s)")
+            sys.exit(2)
+        first, n_grp, lo, hi = segs[0]
+        prefixes = prefixes[first:first + n_grp]
+        prefix = prefixes[0]
+        S = n_grp
+        win_begin, win_len = win_begin[lo:hi], win_len[lo:hi]
+    elif window_sharded:
         from kcftools_amd import shard
         lo, hi = shard.window_range_of_rank(win_len, K, world, rank)
         win_begin, win_len = win_begin[lo:hi], win_len[lo:hi]
@@ -295,7 +313,7 @@ def main():
     expected = int(ref.n_kmer_slots) if args.table == "product" else 0
     t0 = time.time()
     cohort = None
-    if args.cohort and S > 1:
+    if args.cohort and (S > 1 or cohort_sharded):
         cohort = engine.Cohort(prefixes, device=local_rank, expected_queries=expected)
         dbs = [engine.KmcDb.open(prefixes[0], device=local_rank, expected_queries=expected)]   # (the first sample on its own: the parity leg's single-sample twin)
     else:
@@ -645,7 +663,7 @@ def main():
                                                                    "stash_records": int(cohort.info.stash_records),
                                                                    "open_seconds": float(cohort.info.load_seconds)}),
                    "hit_rate": float(res["obs"].sum() / max(1, res["total_kmers"].sum()))},
-        "windows_per_s": (n_win_total * S if window_sharded else n_win * S * world) * args.steps / elapsed,
+        "windows_per_s": (n_win_total * max(1, args.samples) if window_sharded else n_win * S * world) * args.steps / elapsed,
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": kernel_name, "kernel_avg_ms": kern_avg_ms,

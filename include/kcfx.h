@@ -246,6 +246,16 @@ void kcfx_ctx_destroy(kcfx_ctx* ctx);
 #define KCFX_SHARD_WINDOWS 2   /* device g screens a contiguous window range (equal k-mer start positions) of every sample */
 #define KCFX_SHARD_GRID 3      /* samples x windows: the sample-major sequence of (sample, window) units cut into equal contiguous
                                   parts, one per device -- a device opens at most ceil(S / G) + 1 databases, not all S */
+#define KCFX_SHARD_COHORT 4    /* cohort tables across the devices (never chosen by AUTO): the samples in groups of KCFX_COHORT_MAX
+                                  consecutive ones, each group ONE cohort table (kcfx_cohort_open: one look-up per reference k-mer
+                                  for the whole group -- what run_kcftools.sh:124-160 + Cohort.java:71-119 produce from S runs); the
+                                  group-major sequence of (group, window) units is cut into equal contiguous parts like the grid's.
+                                  8 samples on 8 devices: every device builds the same table and screens an eighth of the windows;
+                                  32 samples: four tables, two devices each. A group whose table cannot be built (3- / 4-byte
+                                  counters, mixed strandedness, k outside 19 .. 31, no room: key table + 16 B of counters per cell,
+                                  ~0.85 GiB per million k-mers of the union at the one-pass density) is screened sample by sample.
+                                  kcfx_shard_plan reports a group as seg_sample = its first sample; it spans
+                                  min(KCFX_COHORT_MAX, n_samples - seg_sample) samples */
 
 typedef struct {
     int32_t shard_mode_used, n_devices;

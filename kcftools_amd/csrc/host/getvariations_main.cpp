@@ -49,14 +49,15 @@ struct Options {
     int threads = 2, window = 0, min_count = 1, step = 0;
     std::vector<int> devices{0};          // --device N | --devices a,b,...: the job is sharded over them (kcfx_screen_sharded)
     int shard = KCFX_SHARD_AUTO;          // --shard auto|samples|windows|grid
-    bool cohort_table = false;            // --cohort-table: 2 .. 8 samples in ONE table on the first device (kcfx_cohort_open)
+    bool cohort_table = false;            // --cohort-table (= --shard cohort): the samples in cohort tables of up to 8, tables x window
+                                          // ranges over the devices (KCFX_SHARD_COHORT)
     bool memory = false;
     double wi = 0.3, wt = 0.3, wr = 0.4;
 };
 
 void usage() {
     std::puts("Usage: kcftools-amd getVariations -r <ref.fa> -k <kmc prefix> -o <out.kcf> -s <sample> -f window|gene|transcript\n"
-              "       [-w window] [-p step] [-g gtf] [-c min-k-count] [--wi 0.3] [--wt 0.3] [--wr 0.4] [-t threads] [-m] [--device 0 | --devices 0,1,...] [--shard auto|samples|windows|grid] [--cohort-table]");
+              "       [-w window] [-p step] [-g gtf] [-c min-k-count] [--wi 0.3] [--wt 0.3] [--wr 0.4] [-t threads] [-m] [--device 0 | --devices 0,1,...] [--shard auto|samples|windows|grid|cohort] [--cohort-table]");
 }
 
 std::vector<std::string> split_commas(const std::string& v) {
@@ -120,7 +121,8 @@ int main(int argc, char** argv) {
             else if (v == "samples") o.shard = KCFX_SHARD_SAMPLES;
             else if (v == "windows") o.shard = KCFX_SHARD_WINDOWS;
             else if (v == "grid") o.shard = KCFX_SHARD_GRID;
-            else error("Invalid --shard value: " + v + " (auto, samples or windows)");
+            else if (v == "cohort") o.shard = KCFX_SHARD_COHORT;
+            else error("Invalid --shard value: " + v + " (auto, samples, windows, grid or cohort)");
         }
         else if (a == "--cohort-table") o.cohort_table = true;
         else if (a == "-h" || a == "--help") { usage(); return 0; }
@@ -252,33 +254,12 @@ int main(int argc, char** argv) {
     const size_t S = kmc_list.size();
     std::vector<kcfx_result> all(S * (size_t)n);
     std::vector<std::vector<double>> score(S, std::vector<double>((size_t)n)), depth(S, std::vector<double>((size_t)n));
-    if (o.cohort_table && S >= 2 && S <= KCFX_COHORT_MAX) {
-        // the samples in ONE table with a counter per sample and cell, one look-up per reference k-mer for all of them
-        // (kcfx_cohort_open). It opens more slowly than S tables and screens S x faster: worth it for a large reference.
-        std::vector<const char*> prefixes;
-        for (const auto& p : kmc_list) prefixes.push_back(p.c_str());
-        const auto t0 = std::chrono::steady_clock::now();
-        kcfx_db_opts opts;
-        opts.expected_queries = (int64_t)text.size();
-        opts.no_fallback = 0;
-        opts.reserved = 0;
-        kcfx_cohort* co = nullptr;
-        kcfx_ref* ref = nullptr;
-        if (kcfx_cohort_open(prefixes.data(), (int32_t)S, o.devices[0], &opts, &co)) error(kcfx_last_error());
-        const auto t1 = std::chrono::steady_clock::now();
-        int32_t rc = kcfx_ref_create(o.devices[0], k, reinterpret_cast<const uint8_t*>(text.data()), (int64_t)text.size(), wb.data(), wl.data(), n, &ref);
-        if (!rc) rc = kcfx_cohort_screen_ref(co, ref, o.min_count, all.data());
-        const std::string msg = rc ? kcfx_last_error() : "";
-        kcfx_ref_destroy(ref);
-        kcfx_cohort_close(co);
-        if (rc) error(msg);
-        const auto t2 = std::chrono::steady_clock::now();
-        char line[256];
-        std::snprintf(line, sizeof line, "Screened %zu sample(s) in one cohort table on device %d: %.3f s (table %.3f s, reference + screening %.3f s)", S,
-                      o.devices[0], std::chrono::duration<double>(t2 - t0).count(), std::chrono::duration<double>(t1 - t0).count(),
-                      std::chrono::duration<double>(t2 - t1).count());
-        info(line);
-    } else {
+    // --cohort-table: the samples in ONE table per group of eight, a counter per sample and cell, one look-up per reference k-mer for
+    // the whole group (kcfx_cohort_open) -- tables x window ranges over the listed devices. A table opens more slowly than its
+    // samples' own tables and screens them S x faster: worth it for a large reference. A group that cannot have one (3- / 4-byte
+    // counters, mixed strandedness, no room) is screened sample by sample inside the same call.
+    if (o.cohort_table && S >= 2) o.shard = KCFX_SHARD_COHORT;
+    {
         std::vector<int32_t> devices(o.devices.begin(), o.devices.end());
         std::vector<const char*> prefixes;
         for (const auto& p : kmc_list) prefixes.push_back(p.c_str());
@@ -292,7 +273,8 @@ int main(int argc, char** argv) {
         if (rc) error(msg);
         char line[256];
         std::snprintf(line, sizeof line, "Screened %zu sample(s) on %d device(s), %s-sharded: %.3f s (reference %.3f s, database loading %.3f s of which %.3f s not hidden behind screening, screening %.3f s)",
-                      S, st.n_devices, st.shard_mode_used == KCFX_SHARD_SAMPLES ? "sample" : st.shard_mode_used == KCFX_SHARD_GRID ? "sample x window" : "window", st.seconds_total, st.seconds_ref,
+                      S, st.n_devices, st.shard_mode_used == KCFX_SHARD_SAMPLES ? "sample" : st.shard_mode_used == KCFX_SHARD_GRID ? "sample x window" :
+                      st.shard_mode_used == KCFX_SHARD_COHORT ? "cohort-table x window" : "window", st.seconds_total, st.seconds_ref,
                       st.seconds_db_open_sum, st.seconds_exposed_load, st.seconds_screen_sum);
         info(line);
     }

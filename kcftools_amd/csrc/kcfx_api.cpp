@@ -120,6 +120,7 @@ struct kcfx_db {
     // kcfx_db_open allocates and clears the cell table (up to 48 GiB: hipMalloc alone can take a second when the driver scrubs
     // the block first) on a thread of its own while the .kmc_suf is read, decoded and counted: nothing touches the lines
     // before the first bidding pass, which waits for it (table_ready)
+    int32_t line_footprint = LINE_BYTES;   // bytes per table line the handle will hold in all (a cohort's key table: + 256 B of counters)
     std::thread alloc_thread;
     int32_t alloc_rc = KCFX_OK;          // written by alloc_thread, read after the join
     std::string alloc_error;
@@ -274,22 +275,24 @@ bool cells_eligible(const kcfx_db* db, int32_t counter_size) {
 // aim at ~0.075 k-mers per cell while that stays under 48 GiB and 50 % of the free memory, else halve down to ~1 per cell.
 // KCFX_TABLE_LBITS overrides.
 // Memory against speed (profiles/r03_density.csv, bench workload, 150 M k-mers): 0.07 / 0.14 / 0.28 / 0.56 k-mers per cell =
-// 17.4 / 9.1 / 5.4 / 4.3 GB = 1.00 / 1.00 / 1.21 / 1.57 x the screening time per k-mer. A sparse table pays for itself only
-// over many look-ups -- clearing 12 GB more costs ~4 ms (= 5 * 10^9 look-ups at the 21 % difference) when the block comes from the
-// pool, and up to a second when the driver has to scrub it first -- so a handle that is expected to serve fewer than
-// QUERIES_FOR_SPARSE look-ups (kcfx_db_opts: the command-line driver's one pass per sample) is built at ~0.3 per cell.
+// 17.4 / 9.1 / 5.4 / 4.3 GB = 1.00 / 1.00 / 1.21 / 1.57 x the screening time per k-mer (round 4, same box: 0.0844 / 0.0841 /
+// 0.1000 ms per pass). 0.14 per cell is the knee: a handle that is expected to serve fewer than QUERIES_FOR_SPARSE look-ups
+// (kcfx_db_opts: the command-line driver's one pass per sample) is built there -- half the memory of the sparse table at its
+// speed. (Round 3 built such handles at ~0.3 per cell to save the clearing of 4 GB more; under the command-line driver the
+// three sizes are indistinguishable end to end -- profiles/r04_notes.md: 0.44 - 0.55 s each over six rounds -- and the screening
+// pass is 16 % slower at 0.28.)
 constexpr double QUERIES_FOR_SPARSE = 1e10;
-int32_t cells_lbits(int64_t n_keys, int32_t k, bool both, int64_t expected_queries) {
+int32_t cells_lbits(int64_t n_keys, int32_t k, bool both, int64_t expected_queries, int32_t line_footprint = LINE_BYTES) {
     const int32_t cap = cells_lbits_cap(k);
     const int32_t lmin = cell_lbits_min(both);
     const char* s = getenv("KCFX_TABLE_LBITS");
     if (s && atoi(s) >= lmin && atoi(s) <= cap) return atoi(s);
     const size_t free_b = free_device_bytes();
     const double room = std::min(48.0 * (double)(1ull << 30), 0.5 * (double)free_b);
-    const double density = (expected_queries > 0 && (double)expected_queries < QUERIES_FOR_SPARSE) ? 0.30 : 0.075;
+    const double density = (expected_queries > 0 && (double)expected_queries < QUERIES_FOR_SPARSE) ? 0.15 : 0.075;
     int32_t L = lmin;
     while (L < cap && 16.0 * (double)(1ull << L) * density < (double)n_keys) ++L;
-    while (L > lmin && (double)(1ull << L) * LINE_BYTES > room && 16.0 * (double)(1ull << (L - 1)) >= (double)n_keys) --L;
+    while (L > lmin && (double)(1ull << L) * line_footprint > room && 16.0 * (double)(1ull << (L - 1)) >= (double)n_keys) --L;
     return L;
 }
 
@@ -330,7 +333,7 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys, bool deferred = false) {
     db->info.table_format = FORMAT_CELLS;
     hipError_t e = hipErrorOutOfMemory;
     const bool both = db->info.both_strands != 0;
-    int32_t L0 = cells_lbits(n_keys, db->info.kmer_length, both, db->expected_queries);
+    int32_t L0 = cells_lbits(n_keys, db->info.kmer_length, both, db->expected_queries, db->line_footprint);
     if (db->lbits_cap > 0) L0 = std::min(L0, db->lbits_cap);
     db->alloc_rc = KCFX_OK;
     db->alloc_oom = false;
@@ -851,7 +854,11 @@ int32_t kcfx_db_open_opts(const char* kmc_prefix, int32_t device, const kcfx_db_
     int32_t rc = table_alloc(db, h.total, h.counter_size, true, getenv("KCFX_SYNC_ALLOC") == nullptr);
     tr.mark("table alloc (deferred)");
     if (!rc) rc = load_suffix_file(db, std::string(kmc_prefix) + ".kmc_suf", h);
-    if (rc == KCFX_ERR_DEVICE && db->fmt == FORMAT_CELLS && db->alloc_oom && db->lbits - 1 >= cell_lbits_min(db->info.both_strands != 0)) {
+    // (the allocation thread may still be running when the streaming failed first -- an I/O error, or the decoded arrays lost the
+    // race for the memory to the table: join it before its outcome is read)
+    if (rc && db->alloc_thread.joinable()) db->alloc_thread.join();
+    if (rc == KCFX_ERR_DEVICE && db->fmt == FORMAT_CELLS && db->lbits - 1 >= cell_lbits_min(db->info.both_strands != 0) &&
+        (db->alloc_oom || db->alloc_rc == KCFX_OK)) {
         // the policy's table did not fit next to what else lives on the device: denser cell tables, allocated synchronously
         const int32_t cap = db->lbits - 1;
         table_release(db);
@@ -1034,7 +1041,7 @@ int32_t kcfx_ref_create(int32_t device, int32_t kmer_length, const uint8_t* text
         n_slots += nk;
         const int64_t nt = (nk + tile_k - 1) / tile_k;
         int64_t per = (nk + nt - 1) / nt;
-        per = std::min<int64_t>(tile_k, (per + 63) / 64 * 64);
+        if ((per + 63) / 64 * 64 <= tile_k) per = (per + 63) / 64 * 64;       // whole words where that fits (only a tile's last word may be ragged)
         for (int64_t s = 0; s < nk; s += per) {
             TileDesc t;
             t.text_off = win_begin[w] + s;
@@ -1318,6 +1325,7 @@ int32_t kcfx_cohort_open(const char* const* kmc_prefixes, int32_t n_samples, int
     db->info.counter_size = 2;
     db->info.device = device;
     db->expected_queries = opts ? opts->expected_queries : 0;
+    db->line_footprint = LINE_BYTES + 16 * COHORT_STRIDE * 2;       // cells + 16 bytes of counters per cell: the size policy budgets both
     hipError_t e = db_stream(device, &db->stream);
     if (e != hipSuccess) return hip_fail(e, "hipStreamCreate");
     const size_t nn = (size_t)std::max<int64_t>(N, 1);
@@ -1343,7 +1351,8 @@ int32_t kcfx_cohort_open(const char* const* kmc_prefixes, int32_t n_samples, int
                 e = launch_cohort_votes(hold.d_keys + first, hold.d_counts + first, std::min<int64_t>(1ll << 30, N - first), d_votes,
                                         (uint32_t)(slots - 1), phase, db->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(db->stream);
-        (void)dev_free_idle(d_votes);
+        else (void)hipStreamSynchronize(db->stream);       // (a failed launch: earlier kernels may still be writing the block)
+        (void)dev_free(d_votes);                           // (64 GiB at most: straight back to the driver, the counters below need the room)
         if (e != hipSuccess) return hip_fail(e, "kcfx_cohort_open: votes");
     }
     // the key table: the ordinary build passes over the records of all samples; a cell's count field = the rank its k-mer bid with

@@ -143,9 +143,10 @@ constexpr int TILE_WORDS = TILE_K / 64;
 // per tile: TILE_WORDS valid-ballots then TILE_WORDS hit-ballots (screen kernel -> reduce_windows)
 constexpr int TILE_BITS_U64 = 2 * TILE_WORDS;
 // A reference that is kept as text only (KCFX_REF_PLAN=0) is planned tile by tile inside the screening launch (k31_plan_tile):
-// each of the CELLS_BLOCK / 64 waves plans 62 strips of 16 positions, which covers tiles of at most this many k-mers
-constexpr int PLAN_TILE_STRIPS = 62;
-constexpr int TEXT_TILE_K = (16 * (PLAN_TILE_STRIPS * (CELLS_BLOCK / 64) + 2) - 30 - 15) / 64 * 64;
+// every thread of the workgroup plans a strip of 16 positions, the last two strips only lend to their neighbours -- which
+// covers tiles of at most this many k-mers (up to 15 bases of alignment in front). Not a multiple of 64: a 10 kb window is
+// 5 x 1 994 k-mers, and only a tile's LAST word has to be ragged.
+constexpr int TEXT_TILE_K = 16 * (CELLS_BLOCK - 2) - 15;
 
 // The sample-independent half of a cell-table look-up, worked out once per reference (launch_ref_plan, k = 19 .. 31):
 // 2-bit codes of the text (16 bases per dword, first base in the top bits) and one anchor byte per k-mer start position

@@ -1222,12 +1222,12 @@ __device__ __forceinline__ void cells_match(const CellWord& cw, int32_t lbits, u
     // scalar instructions only, where a predicated region costs the moves that initialise cnt and pend around it)
     {
         const uint32_t x = cw.cell.x, y = cw.cell.y;
-        [[maybe_unused]] const uint32_t xa = cw.alt.x, ya = cw.alt.y;
         // (cw.r has no bits outside rmask and bit 15 clear; xor + and fuse into one v_bitop3)
         const bool first = ((x ^ cw.w) <= CELL_FLAG_MASK) && (((y ^ cw.r) & rmask) == 0);
         if constexpr (W <= CELL_ALT_FREE_MAX_W) {
             const bool free_scheme = cell_alt_free(W, lbits, BOTH);                              // (wave-uniform)
             const uint32_t rmask_alt = rmask | (0xFu << (32 - lbits));
+            const uint32_t xa = cw.alt.x, ya = cw.alt.y;        // (only loaded in builds with the free-cell scheme)
             const bool second = free_scheme && ((xa ^ cw.w) <= CELL_FLAG_MASK) && (((ya ^ cw.r_alt) & rmask_alt) == 0);
             cnt = first ? (y >> 16) : second ? (ya >> 16) : 0u;
         } else {
@@ -1287,13 +1287,21 @@ __device__ __forceinline__ int k31_load_plan_tile(K31Plan& sh, const RefPlan& pl
 // of a wave execute their LDS instructions in order, so a compiler fence between a row's write and the neighbour's read is
 // all the synchronisation there is. Lane 63 has no neighbour in the wave: its results are not used, the next wave (or the next
 // workgroup) starts at its strip again -- 1 / 64 of the work, against a barrier per exchange.
+// (BLOCKWIDE: the strips of a whole workgroup are neighbours -- thread t's right-hand neighbour is thread t + 1, across the
+// wave boundary too -- and a barrier stands where the wave-private form has a fence: the text-only screening kernels, whose
+// tile is ONE run of strips.)
 constexpr int PLAN_ROWS = 66;                               // 64 lanes + the rows lane 63 and 62 read past the end (garbage, unused)
 typedef uint32_t PlanRows[PLAN_ROWS][16];
-template <int K, int L>
+typedef uint32_t PlanRowsBlock[CELLS_BLOCK + 2][16];
+template <int K, int L, bool BLOCKWIDE = false>
 struct PlanWaveIo {
     using P = StripPlanner<K, L>;
-    uint32_t (*rows)[16];                                   // this wave's rows
-    int lane;
+    uint32_t (*rows)[16];                                   // this wave's rows (BLOCKWIDE: the workgroup's)
+    int lane;                                               // (BLOCKWIDE: the thread index)
+    static __device__ __forceinline__ void sync() {
+        if constexpr (BLOCKWIDE) __syncthreads();
+        else wave_lds_fence();
+    }
     const uint8_t* text;                                    // the strip's first base (16-byte aligned); null: behind the readable text -> zeros
     __device__ __forceinline__ void load_text(uint32_t (&x)[L / 4]) const {
 #pragma unroll
@@ -1308,7 +1316,7 @@ struct PlanWaveIo {
     }
     __device__ __forceinline__ void exchange_first(const typename P::First& mine, typename P::First (&nb)[P::VN]) const {
         *reinterpret_cast<uint4*>(rows[lane]) = make_uint4(mine.F0, mine.G0, mine.valid, 0u);
-        wave_lds_fence();
+        sync();
 #pragma unroll
         for (int i = 0; i < P::VN; ++i) {
             const uint4 v = *reinterpret_cast<const uint4*>(rows[lane + 1 + i]);
@@ -1323,7 +1331,7 @@ struct PlanWaveIo {
         mine[1] = make_uint4(u[0], u[1], u[2], u[3]);
         mine[2] = make_uint4(u[4], u[5], u[6], u[7]);
         *reinterpret_cast<uint2*>(mine + 3) = make_uint2(u[8], u[9]);
-        wave_lds_fence();
+        sync();
         const uint4* theirs = reinterpret_cast<const uint4*>(rows[lane + 1]);
         const uint4 a = theirs[1], b = theirs[2];
         const uint2 c = *reinterpret_cast<const uint2*>(theirs + 3);
@@ -1332,12 +1340,12 @@ struct PlanWaveIo {
         uh[8] = c.x; uh[9] = c.y;
     }
     __device__ __forceinline__ void exchange_keys(const uint32_t (&t)[L + P::TH], uint32_t (&th)[P::TH]) const {
-        wave_lds_fence();                                   // (every lane has read its neighbour's hashes: the rows are free)
+        sync();                                   // (every lane has read its neighbour's hashes: the rows are free)
         uint4* mine = reinterpret_cast<uint4*>(rows[lane]);
 #pragma unroll
         for (int i = 0; i < (P::TH + 3) / 4; ++i)           // (t has at least L >= 16 entries: whole uint4s)
             mine[i] = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
-        wave_lds_fence();
+        sync();
         const uint4* theirs = reinterpret_cast<const uint4*>(rows[lane + 1]);
 #pragma unroll
         for (int i = 0; i < (P::TH + 3) / 4; ++i) {
@@ -1347,35 +1355,33 @@ struct PlanWaveIo {
             if (4 * i + 2 < P::TH) th[4 * i + 2] = v.z;
             if (4 * i + 3 < P::TH) th[4 * i + 3] = v.w;
         }
-        wave_lds_fence();                                   // (the rows may be reused by the caller)
+        sync();                                   // (the rows may be reused by the caller)
     }
     // every base this WAVE looked at is A/C/G/T: the valid-start masks are all ones (wave-uniform, so a branch costs nothing)
     __device__ __forceinline__ bool all_clean(bool mine) const { return wave_ballot(!mine) == 0ull; }
 };
 
 // phase 1 of a launch on a text-only reference (KCFX_REF_PLAN=0, or kcfx_screen with a one-shot text): the tile is planned
-// here, straight into the LDS layout a planned reference is copied into -- K1 to K3 in one launch. Each wave plans 64 strips of
-// 16 positions from the tile's 16-aligned start, wave w from strip 62 w: with 16-position strips the last TWO lanes of a wave
-// depend on the missing neighbour (lane 63's keys need hashes of lane 64's bases, lane 62's minima need lane 63's keys), so a
-// wave yields the anchors of 62 strips and the codes of 64. Such a reference is therefore cut into tiles of at most
-// TEXT_TILE_K k-mers (kcfx_ref_create): off <= 15, and the last k-mer's 30 bases behind it must have codes.
-static_assert(PLAN_TILE_STRIPS * CELLS_WAVES == (PLAN_TILE_STRIPS * CELLS_BLOCK) / 64, "TEXT_TILE_K (kcfx_internal.h) is written in terms of CELLS_BLOCK");
-static_assert(TEXT_TILE_K <= TILE_K && TEXT_TILE_K + 15 <= 16 * PLAN_TILE_STRIPS * CELLS_WAVES, "text-only tiles: anchors for every k-mer");
+// here, straight into the LDS layout a planned reference is copied into -- K1 to K3 in one launch. The workgroup's threads
+// plan one strip of 16 positions each from the tile's 16-aligned start, neighbours across the wave boundary (PlanWaveIo,
+// BLOCKWIDE). The last TWO strips depend on neighbours that do not exist (the last one's keys need hashes of bases behind it, the
+// one before needs the last one's keys): anchors for 16 (CELLS_BLOCK - 2) positions, codes for 16 CELLS_BLOCK bases. Such a
+// reference is therefore cut into tiles of at most TEXT_TILE_K k-mers (kcfx_ref_create): off <= 15 in front, and the last
+// k-mer's 30 bases behind it must have codes.
+static_assert(TEXT_TILE_K + 15 <= 16 * (CELLS_BLOCK - 2) && TEXT_TILE_K + 15 + 30 <= 16 * CELLS_BLOCK && TEXT_TILE_K <= TILE_K, "text-only tiles");
 template <int K>
-__device__ __forceinline__ int k31_plan_tile(K31Plan& sh, PlanRows& rows, const uint8_t* __restrict__ text, const TileDesc& td, int tid) {
+__device__ __forceinline__ int k31_plan_tile(K31Plan& sh, PlanRowsBlock& rows, const uint8_t* __restrict__ text, const TileDesc& td, int tid) {
     using P = StripPlanner<K, 16>;
     const int64_t a0 = td.text_off & ~(int64_t)15;
     const int off = (int)(td.text_off - a0);
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int strip = PLAN_TILE_STRIPS * wave + lane;
     // bases the tile's k-mers, their 16-mers' keys and those keys' 6-mers reach: nothing behind them is read (the text is
     // readable 128 bytes past its end, a tile ends at most there minus K - 1)
     const int need = off + td.n_kmers + 30;
-    PlanWaveIo<K, 16> io{rows, lane, 16 * strip < need ? text + a0 + 16 * (int64_t)strip : nullptr};
+    PlanWaveIo<K, 16, true> io{rows, tid, 16 * tid < need ? text + a0 + 16 * (int64_t)tid : nullptr};
     const typename P::Result res = P::run(io);
     if (tid == 0) sh.fcx[0] = make_uint2(0u, 0u);
-    if (lane < PLAN_TILE_STRIPS || wave == CELLS_WAVES - 1) sh.fcx[1 + strip] = make_uint2(res.codes[0], comp_swap(res.codes[0]));
-    if (lane < PLAN_TILE_STRIPS) sh.an[strip] = make_uint4(res.anchors[0], res.anchors[1], res.anchors[2], res.anchors[3]);
+    sh.fcx[1 + tid] = make_uint2(res.codes[0], comp_swap(res.codes[0]));
+    if (tid < CELLS_BLOCK - 2) sh.an[tid] = make_uint4(res.anchors[0], res.anchors[1], res.anchors[2], res.anchors[3]);
     __syncthreads();
     return off;
 }
@@ -1487,26 +1493,23 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
     using Lds = K31Plan;
     __shared__ Lds sh;
     // (a text-only reference is planned tile by tile: the planner's exchange rows are dead before the queues are first written)
-    union WaveScratch {
-        K31CQueue queue;
-        PlanRows rows;
+    union Scratch {
+        K31CQueue queue[WAVES];
+        typename std::conditional<PLANNED, uint32_t, PlanRowsBlock>::type rows;
     };
-    __shared__ __attribute__((aligned(16))) typename std::conditional<PLANNED, K31CQueue, WaveScratch>::type s_scratch[WAVES];
+    __shared__ __attribute__((aligned(16))) Scratch s_scratch;
     const TileDesc td = tiles[blockIdx.x];
     const int tid = threadIdx.x;
     int off;
     if constexpr (PLANNED) off = k31_load_plan_tile<CELLS_BLOCK>(sh, plan, td, K, tid);
-    else off = k31_plan_tile<K>(sh, s_scratch[__builtin_amdgcn_readfirstlane(tid >> 6)].rows, text, td, tid);
+    else off = k31_plan_tile<K>(sh, s_scratch.rows, text, td, tid);
 
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_words = (td.n_kmers + 63) >> 6;
     const int wpw = (n_words + WAVES - 1) / WAVES;
     const int w_begin = min(wave * wpw, n_words);
     const int w_end = min(w_begin + wpw, n_words);
-    K31CQueue* qp;
-    if constexpr (PLANNED) qp = &s_scratch[wave];
-    else qp = &s_scratch[wave].queue;
-    K31CQueue& q = *qp;
+    K31CQueue& q = s_scratch.queue[wave];
     int qn = 0;                                             // queued k-mers (wave-uniform)
     const int pos0 = off + w_begin * 64;                    // packed position of the wave's first k-mer
 
@@ -1634,11 +1637,11 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 
     constexpr int WAVES = CELLS_WAVES;
     using Lds = K31Plan;
     __shared__ Lds sh;
-    union WaveScratch {                                     // (text-only reference: the planner's rows are dead before the queues live)
-        CohortQueue queue;
-        PlanRows rows;
+    union Scratch {                                         // (text-only reference: the planner's rows are dead before the queues live)
+        CohortQueue queue[WAVES];
+        typename std::conditional<PLANNED, uint32_t, PlanRowsBlock>::type rows;
     };
-    __shared__ __attribute__((aligned(16))) typename std::conditional<PLANNED, CohortQueue, WaveScratch>::type s_scratch[WAVES];
+    __shared__ __attribute__((aligned(16))) Scratch s_scratch;
     __shared__ uint32_t s_sums[WAVES][COHORT_STRIDE];
     const TableView& tv = cv.tv;
     const int S = cv.n_samples;
@@ -1647,11 +1650,8 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int off;
     if constexpr (PLANNED) off = k31_load_plan_tile<CELLS_BLOCK>(sh, plan, td, K, tid);
-    else off = k31_plan_tile<K>(sh, s_scratch[wave].rows, text, td, tid);
-    CohortQueue* qp;
-    if constexpr (PLANNED) qp = &s_scratch[wave];
-    else qp = &s_scratch[wave].queue;
-    CohortQueue& q = *qp;
+    else off = k31_plan_tile<K>(sh, s_scratch.rows, text, td, tid);
+    CohortQueue& q = s_scratch.queue[wave];
     // the hit words are OR-ed into (the stash may add a k-mer's bits before or after its word's own ballots arrive); wave-private
     for (int i = lane; i < COHORT_STRIDE * CELLS_WORDS_PER_WAVE; i += 64) (&q.hit[0][0])[i] = 0ull;
     wave_lds_fence();
@@ -2255,6 +2255,7 @@ hipError_t launch_ref_plan(const uint8_t* text, int64_t text_len, int32_t k, uin
     const int64_t readable = text_len + 128, cw = (int64_t)(ref_plan_codes_bytes(text_len) / 4), ab = (int64_t)ref_plan_anchor_bytes(text_len);
 #define KCFX_LAUNCHP(KK) hipExtLaunchKernelGGL((ref_plan_kernel<KK>), g, b, 0, st, ev_start, ev_stop, 0, text, text_len, readable, codes, cw, anchors, ab)
     switch (k) {
+#ifndef KCFX_ONLY_K31
         case 19: KCFX_LAUNCHP(19); break;
         case 20: KCFX_LAUNCHP(20); break;
         case 21: KCFX_LAUNCHP(21); break;
@@ -2267,6 +2268,7 @@ hipError_t launch_ref_plan(const uint8_t* text, int64_t text_len, int32_t k, uin
         case 28: KCFX_LAUNCHP(28); break;
         case 29: KCFX_LAUNCHP(29); break;
         case 30: KCFX_LAUNCHP(30); break;
+#endif
         case 31: KCFX_LAUNCHP(31); break;
         default: return hipErrorInvalidValue;
     }
@@ -2295,6 +2297,7 @@ hipError_t launch_screen_tiles(const uint8_t* text, RefPlan plan, const TileDesc
         else            { if (both_strands) KCFX_LAUNCHC1(KK, true, false); else KCFX_LAUNCHC1(KK, false, false); } \
     } while (0)
         switch (k) {
+#ifndef KCFX_ONLY_K31
             case 19: KCFX_LAUNCHC(19); break;
             case 20: KCFX_LAUNCHC(20); break;
             case 21: KCFX_LAUNCHC(21); break;
@@ -2307,6 +2310,7 @@ hipError_t launch_screen_tiles(const uint8_t* text, RefPlan plan, const TileDesc
             case 28: KCFX_LAUNCHC(28); break;
             case 29: KCFX_LAUNCHC(29); break;
             case 30: KCFX_LAUNCHC(30); break;
+#endif
             case 31: KCFX_LAUNCHC(31); break;
             default: return hipErrorInvalidValue;
         }
@@ -2356,6 +2360,7 @@ hipError_t launch_screen_cohort(const uint8_t* text, RefPlan plan, const TileDes
         else            { if (both_strands) KCFX_LAUNCHCO1(KK, true, false); else KCFX_LAUNCHCO1(KK, false, false); } \
     } while (0)
     switch (k) {                                            // every k a cell table exists for
+#ifndef KCFX_ONLY_K31
         case 19: KCFX_LAUNCHCO(19); break;
         case 20: KCFX_LAUNCHCO(20); break;
         case 21: KCFX_LAUNCHCO(21); break;
@@ -2368,6 +2373,7 @@ hipError_t launch_screen_cohort(const uint8_t* text, RefPlan plan, const TileDes
         case 28: KCFX_LAUNCHCO(28); break;
         case 29: KCFX_LAUNCHCO(29); break;
         case 30: KCFX_LAUNCHCO(30); break;
+#endif
         case 31: KCFX_LAUNCHCO(31); break;
         default: return hipErrorInvalidValue;
     }

@@ -10,12 +10,18 @@
 //   1 < samples < devices : grid -- the sample-major sequence of (sample, window) units is cut into equal contiguous parts: a
 //                        device opens at most two databases instead of all of them (KCFX_SHARD_WINDOWS, still selectable,
 //                        screens a window range of EVERY sample on every device).
+//   cohort tables       : (KCFX_SHARD_COHORT, on request) the samples in groups of eight, each group ONE cohort table
+//                        (kcfx_cohort_open: one look-up per reference k-mer for the eight); the group-major sequence of
+//                        (group, window) units is cut like the grid's. 8 samples on 8 devices: every device the same table and
+//                        an eighth of the windows; 32 samples: four tables, two devices each.
 // Inside a worker the next sample's database is opened (file read, upload, table build) by a loader thread while the
 // current one is screened: at most two databases are resident per device, and a sample costs max(load, screen), not the sum.
 // Built on the public entry points only (kcfx_db_open / kcfx_ref_create / kcfx_screen_ref); HIP is never touched here.
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -54,8 +60,9 @@ std::vector<int32_t> window_cuts(const int32_t* win_len, int32_t n, int32_t k, i
 }
 
 struct Segment {
-    int32_t sample;                   // the sample screened ...
+    int32_t sample;                   // the sample screened (cohort mode: the first of the group) ...
     int32_t w_lo, w_hi;               // ... against this window range
+    int32_t n = 1;                    // samples of the unit: 1, or the 2 .. KCFX_COHORT_MAX of a cohort table
 };
 
 struct Worker {
@@ -84,36 +91,48 @@ std::vector<std::vector<Segment>> plan_segments(int32_t mode, int32_t G, int32_t
         // KCFX_SHARD_GRID: the sample-major sequence of (sample, window) units -- S runs of the window list -- is cut into G
         // contiguous parts of equal k-mer count: a device screens the tail of one sample's windows and the head of the next
         // one's, so it opens at most ceil(S / G) + 1 databases (2 when S < G) where KCFX_SHARD_WINDOWS opens all S on every
-        // device, and the parts are as even as a single sample's window cuts
-        // cut positions in units of k-mers over S repetitions: part g = [g, g + 1) * S / G of the S-fold sequence
+        // device, and the parts are as even as a single sample's window cuts.
+        // KCFX_SHARD_COHORT: the same over GROUPS of up to KCFX_COHORT_MAX consecutive samples, each screened as one cohort
+        // table (a look-up costs about the same whatever the group's size: the units weigh what their windows weigh).
+        const int32_t per_unit = mode == KCFX_SHARD_COHORT ? KCFX_COHORT_MAX : 1;
+        const int32_t n_units = (n_samples + per_unit - 1) / per_unit;
+        // cut positions in units of k-mers over n_units repetitions: part g = [g, g + 1) * n_units / G of the n_units-fold sequence
         std::vector<int64_t> cum((size_t)n_windows + 1, 0);
         for (int32_t i = 0; i < n_windows; ++i) cum[(size_t)i + 1] = cum[(size_t)i] + std::max<int64_t>(0, (int64_t)win_len[i] - kmer_length + 1);
         const int64_t per_sample = cum[(size_t)n_windows];
-        auto locate = [&](int64_t pos, int32_t& samp, int32_t& w) {      // position in the S-fold k-mer sequence -> (sample, first window at or after it)
+        auto locate = [&](int64_t pos, int32_t& unit, int32_t& w) {      // position in the n_units-fold k-mer sequence -> (unit, first window at or after it)
             if (per_sample <= 0) {
-                samp = n_samples;
+                unit = n_units;
                 w = 0;
                 return;
             }
-            samp = (int32_t)std::min<int64_t>(pos / per_sample, n_samples);
-            const int64_t r = pos - (int64_t)samp * per_sample;
-            w = samp >= n_samples ? 0 : (int32_t)(std::lower_bound(cum.begin(), cum.end(), r) - cum.begin());
+            unit = (int32_t)std::min<int64_t>(pos / per_sample, n_units);
+            const int64_t r = pos - (int64_t)unit * per_sample;
+            w = unit >= n_units ? 0 : (int32_t)(std::lower_bound(cum.begin(), cum.end(), r) - cum.begin());
             if (w > n_windows) w = n_windows;
         };
-        const int64_t total = per_sample * n_samples;
+        auto segment_of = [&](int32_t unit, int32_t lo, int32_t hi) {
+            Segment sg;
+            sg.sample = unit * per_unit;
+            sg.w_lo = lo;
+            sg.w_hi = hi;
+            sg.n = std::min(per_unit, n_samples - sg.sample);
+            return sg;
+        };
+        const int64_t total = per_sample * n_units;
         int32_t ps = 0, pw = 0;                                           // where the previous part ended
         for (int32_t g = 0; g < G; ++g) {
-            int32_t es = n_samples, ew = 0;
+            int32_t es = n_units, ew = 0;
             if (g + 1 < G) locate(total * (g + 1) / G, es, ew);
             if (per_sample <= 0) {                                        // no k-mers at all: device 0 takes everything
                 if (g == 0)
-                    for (int32_t s2 = 0; s2 < n_samples; ++s2) plan[0].push_back(Segment{s2, 0, n_windows});
+                    for (int32_t u = 0; u < n_units; ++u) plan[0].push_back(segment_of(u, 0, n_windows));
                 continue;
             }
             // from (ps, pw) up to (es, ew)
-            for (int32_t s2 = ps; s2 <= es && s2 < n_samples; ++s2) {
-                const int32_t lo = (s2 == ps) ? pw : 0, hi = (s2 == es) ? ew : n_windows;
-                if (hi > lo) plan[(size_t)g].push_back(Segment{s2, lo, hi});
+            for (int32_t u = ps; u <= es && u < n_units; ++u) {
+                const int32_t lo = (u == ps) ? pw : 0, hi = (u == es) ? ew : n_windows;
+                if (hi > lo) plan[(size_t)g].push_back(segment_of(u, lo, hi));
             }
             ps = es;
             pw = ew;
@@ -148,7 +167,7 @@ int32_t kcfx_shard_plan(int32_t shard_mode, int32_t n_devices, int32_t n_samples
                         int64_t cap, int64_t* n_segments, int32_t* mode_used) try {
     if (n_devices < 1 || n_samples < 0 || n_windows < 0 || kmer_length < 1 || !n_segments || (n_windows > 0 && !win_len))
         return fail(KCFX_ERR_ARG, "kcfx_shard_plan: bad argument");
-    if (shard_mode < KCFX_SHARD_AUTO || shard_mode > KCFX_SHARD_GRID) return fail(KCFX_ERR_ARG, "unknown shard mode");
+    if (shard_mode < KCFX_SHARD_AUTO || shard_mode > KCFX_SHARD_COHORT) return fail(KCFX_ERR_ARG, "unknown shard mode");
     int32_t mode = shard_mode;
     if (mode == KCFX_SHARD_AUTO)
         mode = (n_samples >= n_devices || n_windows == 0) ? KCFX_SHARD_SAMPLES : (n_samples == 1 ? KCFX_SHARD_WINDOWS : KCFX_SHARD_GRID);
@@ -182,7 +201,7 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
         ((int64_t)n_samples * n_windows > 0 && !out))
         return fail(KCFX_ERR_ARG, "null argument");
     if (min_kmer_count < 1) return fail(KCFX_ERR_ARG, "Minimum kmer count should be at least 1");   // GetVariants.java:383-385
-    if (shard_mode < KCFX_SHARD_AUTO || shard_mode > KCFX_SHARD_GRID) return fail(KCFX_ERR_ARG, "unknown shard mode");
+    if (shard_mode < KCFX_SHARD_AUTO || shard_mode > KCFX_SHARD_COHORT) return fail(KCFX_ERR_ARG, "unknown shard mode");
     for (int32_t s = 0; s < n_samples; ++s)
         if (!kmc_prefixes[s]) return fail(KCFX_ERR_ARG, "null database prefix");
     for (int32_t w = 0; w < n_windows; ++w)
@@ -253,7 +272,13 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
         // one database per segment, in order, at most one ahead of the one being screened
         std::mutex mu;
         std::condition_variable cv;
-        std::deque<kcfx_db*> ready;
+        struct Loaded {                                  // what the loader hands over for a segment
+            kcfx_db* db = nullptr;                       // a sample's table, or
+            kcfx_cohort* co = nullptr;                   // a group's cohort table, or
+            bool one_by_one = false;                     // neither: the cohort table could not be built -- screen the group's samples singly
+            std::string why;
+        };
+        std::deque<Loaded> ready;
         bool stop = false, loader_done = false;
         int in_use = 0;                                  // databases the screening thread holds (0 or 1)
         int32_t load_rc = KCFX_OK;
@@ -268,6 +293,7 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
                 }
                 const double t1 = now_s();
                 kcfx_db* db = nullptr;
+                Loaded ld;
                 // one pass of this segment's window range per database (GetVariants.java:129-159): the table is sized for that.
                 // First without the line-table fallback: a cell table that does not fit NEXT TO the database being screened
                 // (two wheat-scale tables do not always fit) is worth waiting for -- the line table screens at ~0.55x the
@@ -278,15 +304,39 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
                 opts.no_fallback = 1;
                 opts.reserved = 0;
                 const char* prefix = kmc_prefixes[wk.segs[i].sample];
-                int32_t rc = kcfx_db_open_opts(prefix, wk.device, &opts, &db);
-                if (rc == KCFX_ERR_DEVICE) {
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return stop || (in_use == 0 && ready.empty()); });
-                    if (!stop) {
-                        lk.unlock();
-                        opts.no_fallback = 0;
-                        rc = kcfx_db_open_opts(prefix, wk.device, &opts, &db);
+                int32_t rc;
+                if (wk.segs[i].n > 1) {
+                    // a cohort table for the group (key table + 16 bytes of counters per cell: ~3 x a single table of the union).
+                    // If the device cannot hold it beside the one being screened: once more when that one is gone. If it cannot
+                    // be built at all (3- / 4-byte counters, mixed strandedness, k outside 19 .. 31, too large): the group's
+                    // samples are screened one by one, which is what the other modes do.
+                    opts.no_fallback = 0;
+                    rc = kcfx_cohort_open(kmc_prefixes + wk.segs[i].sample, wk.segs[i].n, wk.device, &opts, &ld.co);
+                    if (rc == KCFX_ERR_DEVICE) {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return stop || (in_use == 0 && ready.empty()); });
+                        if (!stop) {
+                            lk.unlock();
+                            rc = kcfx_cohort_open(kmc_prefixes + wk.segs[i].sample, wk.segs[i].n, wk.device, &opts, &ld.co);
+                        }
                     }
+                    if (rc == KCFX_ERR_DEVICE || rc == KCFX_ERR_ARG) {
+                        ld.one_by_one = true;
+                        ld.why = kcfx_last_error();
+                        rc = KCFX_OK;
+                    }
+                } else {
+                    rc = kcfx_db_open_opts(prefix, wk.device, &opts, &db);
+                    if (rc == KCFX_ERR_DEVICE) {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return stop || (in_use == 0 && ready.empty()); });
+                        if (!stop) {
+                            lk.unlock();
+                            opts.no_fallback = 0;
+                            rc = kcfx_db_open_opts(prefix, wk.device, &opts, &db);
+                        }
+                    }
+                    ld.db = db;
                 }
                 std::lock_guard<std::mutex> lk(mu);
                 wk.t_open += now_s() - t1;
@@ -295,7 +345,7 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
                     load_error = kcfx_last_error();
                     break;
                 }
-                ready.push_back(db);
+                ready.push_back(ld);
                 cv.notify_all();
             }
             } catch (...) {
@@ -314,7 +364,7 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
             std::mutex& mu;
             std::condition_variable& cv;
             bool& stop;
-            std::deque<kcfx_db*>& ready;
+            std::deque<Loaded>& ready;
             ~Joiner() {
                 {
                     std::lock_guard<std::mutex> lk(mu);
@@ -322,7 +372,10 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
                     cv.notify_all();
                 }
                 if (t.joinable()) t.join();
-                for (kcfx_db* db : ready) kcfx_db_close(db);
+                for (Loaded& ld : ready) {
+                    kcfx_db_close(ld.db);
+                    kcfx_cohort_close(ld.co);
+                }
             }
         } joiner{loader, mu, cv, stop, ready};
         for (size_t i = 0; i < wk.segs.size() && wk.rc == KCFX_OK; ++i) {
@@ -331,7 +384,7 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
                 failed(rc);
                 break;
             }
-            kcfx_db* db = nullptr;
+            Loaded ld;
             {
                 const double t1 = now_s();
                 std::unique_lock<std::mutex> lk(mu);
@@ -342,22 +395,63 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
                     wk.error = load_error;
                     break;
                 }
-                db = ready.front();
+                ld = ready.front();
                 ready.pop_front();
                 in_use = 1;
                 cv.notify_all();
             }
-            kcfx_db_info_t info;
-            kcfx_db_info(db, &info);
             const double t1 = now_s();
-            if (info.kmer_length != kmer_length) {
-                wk.rc = KCFX_ERR_ARG;
-                wk.error = "Kmer size mismatch between the KMC databases";          // KCFHeader.equals (Cohort.java:71-119)
-            } else if (int32_t rc = kcfx_screen_ref(db, ref_hold.p, min_kmer_count, out + (size_t)sg.sample * n_windows + sg.w_lo)) {
-                failed(rc);
+            auto screen_one = [&](kcfx_db* db, int32_t sample) {
+                kcfx_db_info_t info;
+                kcfx_db_info(db, &info);
+                if (info.kmer_length != kmer_length) {
+                    wk.rc = KCFX_ERR_ARG;
+                    wk.error = "Kmer size mismatch between the KMC databases";          // KCFHeader.equals (Cohort.java:71-119)
+                } else if (int32_t rc = kcfx_screen_ref(db, ref_hold.p, min_kmer_count, out + (size_t)sample * n_windows + sg.w_lo)) {
+                    failed(rc);
+                }
+            };
+            if (ld.co) {
+                // one look-up per reference k-mer for the whole group; the table's rows go to the group's rows of `out`
+                kcfx_cohort_info_t ci;
+                kcfx_cohort_info(ld.co, &ci);
+                const size_t nw = (size_t)(sg.w_hi - sg.w_lo);
+                std::vector<kcfx_result> rows((size_t)sg.n * nw);
+                if (ci.kmer_length != kmer_length) {
+                    wk.rc = KCFX_ERR_ARG;
+                    wk.error = "Kmer size mismatch between the KMC databases";
+                } else if (int32_t rc = kcfx_cohort_screen_ref(ld.co, ref_hold.p, min_kmer_count, rows.data())) {
+                    failed(rc);
+                } else {
+                    for (int32_t j = 0; j < sg.n; ++j)
+                        memcpy(out + (size_t)(sg.sample + j) * n_windows + sg.w_lo, rows.data() + (size_t)j * nw, nw * sizeof(kcfx_result));
+                }
+                wk.t_screen += now_s() - t1;
+                kcfx_cohort_close(ld.co);
+            } else if (ld.one_by_one) {
+                if (getenv("KCFX_VERBOSE")) fprintf(stderr, "[kcfx] no cohort table for samples %d .. %d (%s): screened one by one\n", sg.sample, sg.sample + sg.n - 1, ld.why.c_str());
+                for (int32_t j = 0; j < sg.n && wk.rc == KCFX_OK; ++j) {
+                    kcfx_db_opts opts;
+                    opts.expected_queries = seg_queries(sg);
+                    opts.no_fallback = 0;
+                    opts.reserved = 0;
+                    kcfx_db* db = nullptr;
+                    const double t2 = now_s();
+                    if (int32_t rc = kcfx_db_open_opts(kmc_prefixes[sg.sample + j], wk.device, &opts, &db)) {
+                        failed(rc);
+                        break;
+                    }
+                    wk.t_open += now_s() - t2;
+                    wk.t_wait += now_s() - t2;
+                    screen_one(db, sg.sample + j);
+                    kcfx_db_close(db);
+                }
+                wk.t_screen += now_s() - t1;
+            } else {
+                screen_one(ld.db, sg.sample);
+                wk.t_screen += now_s() - t1;
+                kcfx_db_close(ld.db);
             }
-            wk.t_screen += now_s() - t1;
-            kcfx_db_close(db);
             {
                 std::lock_guard<std::mutex> lk(mu);
                 in_use = 0;

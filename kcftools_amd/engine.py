@@ -54,7 +54,8 @@ class ShardStats(C.Structure):
                 ("seconds_exposed_load", C.c_double)]
 
 
-SHARD_AUTO, SHARD_SAMPLES, SHARD_WINDOWS, SHARD_GRID = 0, 1, 2, 3
+SHARD_AUTO, SHARD_SAMPLES, SHARD_WINDOWS, SHARD_GRID, SHARD_COHORT = 0, 1, 2, 3, 4
+COHORT_MAX = 8
 
 
 class DbOpts(C.Structure):

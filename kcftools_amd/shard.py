@@ -9,6 +9,11 @@ runs samples in separate processes) -- so there is NO data-path collective. Two 
   * samples <  ranks : window-sharded. Contiguous window ranges balanced by the number of k-mer start positions;
                        the sample database is replicated.
 
+  * cohort tables   : (on request) the samples in groups of eight, each group ONE cohort table (kcfx_cohort_open); the
+                       group-major sequence of (group, window) units is cut into equal contiguous parts, one per rank --
+                       8 samples on 8 ranks: every rank the same table and an eighth of the windows; 32 samples: four tables,
+                       two ranks each. The plan is kcfx_shard_plan's (KCFX_SHARD_COHORT), host arithmetic inside libkcfx.
+
 The only exchange is the final gather of the 40-byte per-(window, sample) records to rank 0.
 """
 from __future__ import annotations
@@ -69,3 +74,26 @@ def gather_results(local, dst: int = 0, group=None):
 def merge_window_shards(parts: list[np.ndarray]) -> np.ndarray:
     """Window-sharded run: concatenate the per-rank record arrays in rank order (ranges are contiguous)."""
     return np.concatenate(parts) if parts else np.zeros(0)
+
+
+def cohort_segments_of_rank(win_len: np.ndarray, k: int, n_samples: int, world: int, rank: int) -> list[tuple[int, int, int, int]]:
+    """The (first sample, samples in the group, w_lo, w_hi) units rank `rank` screens when the samples are held in cohort
+    tables (kcfx_shard_plan, KCFX_SHARD_COHORT: the partitioning kcfx_screen_sharded uses inside one process)."""
+    from . import engine
+    plan, _ = engine.shard_plan(win_len, k, n_samples, world, engine.SHARD_COHORT)
+    return [(s, min(engine.COHORT_MAX, n_samples - s), lo, hi) for dev, s, lo, hi in plan if dev == rank]
+
+
+def assemble_cohort_shards(parts: list[np.ndarray], segments: list[list[tuple[int, int, int, int]]], n_samples: int,
+                           n_windows: int) -> np.ndarray:
+    """Rank r's records = its segments in order, each [samples of the group, windows of the range] row-major: back into one
+    [n_samples, n_windows] array."""
+    out = np.zeros((n_samples, n_windows), dtype=parts[0].dtype if parts else np.int32)
+    for part, segs in zip(parts, segments):
+        at = 0
+        for first, n, lo, hi in segs:
+            m = n * (hi - lo)
+            out[first:first + n, lo:hi] = part[at:at + m].reshape(n, hi - lo)
+            at += m
+        assert at == len(part)
+    return out

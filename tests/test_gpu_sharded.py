@@ -141,3 +141,33 @@ def test_kept_blocks_and_another_allocator_in_the_process(tmp_path):
         torch.cuda.empty_cache()
     finally:
         del os.environ["KCFX_TABLE_LBITS"]
+
+
+@pytest.mark.parametrize("devices", [(0,), (0, 0), (0, 0, 0)])
+def test_cohort_tables_across_devices(oracle, tmp_path_factory, devices):
+    """KCFX_SHARD_COHORT: the samples in cohort tables of up to eight, tables x window ranges over the devices -- eleven samples =
+    one table of eight + one of three; on (0, 0) each worker builds one, on (0, 0, 0) a worker builds two. Every (window, sample)
+    result must equal the single-sample path and the oracle. A group that cannot have a cohort table (a 4-byte-counter sample in
+    it) is screened sample by sample inside the same call."""
+    tmp = tmp_path_factory.mktemp("cohort_sharded")
+    k = 31
+    ref = synth.random_reference(260_000, 81, n_run_every=50_000, max_n_run=600)
+    prefixes = [make_db(tmp, f"c{i}", ref, 700 + i, k=k, p=3, cs=2 if i % 3 else 1, m=7, bins=4, both=True, noise=3_000)[0] for i in range(11)]
+    s, e = engine.windows(len(ref), 10_000, 0, k)
+    rng = np.random.default_rng(6)
+    lens = np.concatenate([e - s, rng.integers(0, 7_000, 25), [0, 30, 31]])
+    begins = np.concatenate([s, rng.integers(0, len(ref) - 7_000, 25), [5, 77, 123]])
+    want = np.stack([engine.KmcDb.open(p).screen(ref, begins, lens, 1) for p in prefixes])
+    got, st = engine.screen_sharded(prefixes, k, ref, begins, lens, 1, devices=devices, mode=engine.SHARD_COHORT)
+    assert st.shard_mode_used == engine.SHARD_COHORT and got.shape == want.shape
+    for i in range(len(prefixes)):
+        assert_same(got[i], want[i], f"cohort-sharded, sample {i}, devices {devices}")
+    assert_same(got[9], oracle.OracleDb(prefixes[9]).screen(ref, begins, lens, 1, threads=4), "vs oracle (a sample of the second table)")
+    if devices == (0, 0):
+        # -c 3, and a group with a 4-byte-counter sample: no cohort table for it, same results
+        wide = make_db(tmp, "wide", ref, 777, k=k, p=3, cs=4, m=7, bins=4, both=True, noise=3_000)[0]
+        mixed = prefixes[:3] + [wide]
+        got3, st3 = engine.screen_sharded(mixed, k, ref, begins, lens, 3, devices=devices, mode=engine.SHARD_COHORT)
+        assert st3.shard_mode_used == engine.SHARD_COHORT
+        for i, p in enumerate(mixed):
+            assert_same(got3[i], engine.KmcDb.open(p).screen(ref, begins, lens, 3), f"mixed counter widths, sample {i}")

@@ -46,6 +46,13 @@ def worker(rank, world, port, tmpdir, n_samples, mode, q):
         mine = shard.samples_of_rank(n_samples, world, rank)
         recs = [oracle.OracleDb(prefixes[s]).screen(ref, wb, wl, 1) for s in mine]
         local = np.concatenate(recs) if recs else np.zeros(0, dtype=oracle.RESULT_DTYPE)
+    elif mode == "cohort":
+        # cohort tables x window ranges: a rank's units are (group of up to eight samples, window range); on the GPU one cohort
+        # table answers for the whole group, here the oracle does, sample by sample
+        recs = []
+        for first, n, lo, hi in shard.cohort_segments_of_rank(wl, K, n_samples, world, rank):
+            recs += [oracle.OracleDb(prefixes[s]).screen(ref, wb[lo:hi], wl[lo:hi], 1) for s in range(first, first + n)]
+        local = np.concatenate(recs) if recs else np.zeros(0, dtype=oracle.RESULT_DTYPE)
     else:
         lo, hi = shard.window_range_of_rank(wl, K, world, rank)
         local = oracle.OracleDb(prefixes[0]).screen(ref, wb[lo:hi], wl[lo:hi], 1)
@@ -57,7 +64,8 @@ def worker(rank, world, port, tmpdir, n_samples, mode, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_samples,mode", [(2, 4, "samples"), (2, 1, "windows"), (3, 1, "windows"), (2, 3, "samples")])
+@pytest.mark.parametrize("world,n_samples,mode", [(2, 4, "samples"), (2, 1, "windows"), (3, 1, "windows"), (2, 3, "samples"),
+                                                  (2, 3, "cohort"), (3, 10, "cohort")])
 def test_sharded_run_equals_single_process(tmp_path, world, n_samples, mode):
     from oracle import binding as oracle
     import queue as _queue
@@ -93,6 +101,13 @@ def test_sharded_run_equals_single_process(tmp_path, world, n_samples, mode):
             want = [oracle.OracleDb(prefixes[s]).screen(ref, wb, wl, 1) for s in shard.samples_of_rank(n_samples, world, r)]
             want = np.concatenate(want) if want else np.zeros(0, dtype=oracle.RESULT_DTYPE)
             assert np.array_equal(got, want)
+    elif mode == "cohort":
+        segs = [shard.cohort_segments_of_rank(wl, K, n_samples, world, r) for r in range(world)]
+        got = shard.assemble_cohort_shards([p.view(oracle.RESULT_DTYPE) for p in parts], segs, n_samples, len(wb))
+        for s in range(n_samples):
+            assert np.array_equal(got[s], oracle.OracleDb(prefixes[s]).screen(ref, wb, wl, 1)), s
+        if n_samples > 8:
+            assert {f for sg in segs for f, *_ in sg} == {0, 8}          # two tables
     else:
         got = shard.merge_window_shards([p.view(oracle.RESULT_DTYPE) for p in parts])
         want = oracle.OracleDb(prefixes[0]).screen(ref, wb, wl, 1)

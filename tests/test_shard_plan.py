@@ -59,3 +59,42 @@ def test_sample_and_window_modes_keep_their_shapes():
     assert used == engine.SHARD_WINDOWS and [(lo, hi) for _, _, lo, hi in plan] == [(0, 250), (250, 500), (500, 750), (750, 1000)]
     # nothing to screen: no segments
     assert engine.shard_plan(wl, K, 0, 4)[0] == [] and engine.shard_plan(np.zeros(0, np.int32), K, 3, 4)[0] == []
+
+
+def cohort_coverage(plan, S, W):
+    """a cohort segment covers the group of up to 8 consecutive samples that starts at seg_sample"""
+    seen = np.zeros((S, W), dtype=np.int32)
+    for dev, s, lo, hi in plan:
+        assert s % engine.COHORT_MAX == 0 and 0 <= s < S and 0 <= lo < hi <= W, (dev, s, lo, hi)
+        seen[s:min(S, s + engine.COHORT_MAX), lo:hi] += 1
+    return seen
+
+
+@settings(max_examples=120, deadline=None)
+@given(st.integers(1, 12), st.integers(1, 40), st.lists(st.integers(0, 400), min_size=1, max_size=60))
+def test_cohort_mode_covers_every_pair_once(G, S, lens):
+    wl = np.array(lens, dtype=np.int32)
+    plan, used = engine.shard_plan(wl, K, S, G, engine.SHARD_COHORT)
+    assert used == engine.SHARD_COHORT                          # (never chosen by AUTO: the other test pins that)
+    assert np.all(cohort_coverage(plan, S, len(wl)) == 1)
+    assert all(0 <= dev < G for dev, *_ in plan)
+
+
+def test_cohort_mode_shapes_of_the_baseline_configs():
+    """BASELINE configs[3]: 8 samples on 8 devices = ONE table, every device an eighth of the windows; configs[4]: 32 samples =
+    four tables, two devices each. Loads within 2 %, a device builds at most two tables (one when G is a multiple of the groups)."""
+    rng = np.random.default_rng(9)
+    wl = rng.integers(31, 60_000, 12_003).astype(np.int32)
+    kmers = np.maximum(0, wl.astype(np.int64) - K + 1)
+    for S, G, tables_per_dev in ((8, 8, 1), (32, 8, 1), (16, 8, 1), (12, 8, 2), (8, 3, 1), (9, 2, 2), (40, 8, 2)):
+        plan, used = engine.shard_plan(wl, K, S, G, engine.SHARD_COHORT)
+        assert used == engine.SHARD_COHORT and np.all(cohort_coverage(plan, S, len(wl)) == 1)
+        groups = -(-S // engine.COHORT_MAX)
+        load = np.zeros(G)
+        for d, s, lo, hi in plan:
+            load[d] += kmers[lo:hi].sum()
+        assert load.max() <= 1.02 * load.mean(), (S, G, load)
+        assert abs(load.sum() - groups * kmers.sum()) < 1           # a group's look-ups are one pass whatever its size
+        assert max(len({s for d, s, *_ in plan if d == g}) for g in range(G)) <= tables_per_dev, (S, G)
+    plan, _ = engine.shard_plan(np.full(1000, 10_000, dtype=np.int32), K, 8, 8, engine.SHARD_COHORT)
+    assert sorted(plan) == [(g, 0, 125 * g, 125 * (g + 1)) for g in range(8)]
