@@ -143,9 +143,10 @@ def test_multi_sample_equals_cohort_of_single_sample_runs(oracle, tmp_path):
 
 
 def test_cohort_table_option_gives_the_same_file(tmp_path):
-    """`--cohort-table`: the samples in ONE table (kcfx_cohort_open), one look-up per reference k-mer for all of them -- the
-    multi-sample KCF must be the file the per-sample tables give, byte for byte (##CMD / ##date aside). Golden databases of
-    one k and strandedness; a mixed pair is refused with the library's message."""
+    """`--cohort-table` (= `--shard cohort`): the samples in ONE table per group of eight (kcfx_cohort_open), one look-up per
+    reference k-mer for the group, tables x window ranges over the listed devices -- the multi-sample KCF must be the file the
+    per-sample tables give, byte for byte (##CMD / ##date aside), on one worker and on three. A pair that cannot share a table
+    (mixed strandedness) is screened sample by sample inside the same call: same file again."""
     fa = str(tmp_path / "ref.fa")
     shutil.copy(os.path.join(G, "ref.fa"), fa)
     ref = open(os.path.join(G, "ref.fa"), "rb").read()
@@ -158,15 +159,18 @@ def test_cohort_table_option_gives_the_same_file(tmp_path):
         synth.write_kmc(pfx, km, ct, prm)
         prefixes.append(pfx)
     outs = []
-    for extra in ([], ["--cohort-table"]):
+    def body(path):
+        return [l for l in open(path).read().split("\n") if not l.startswith("##CMD") and not l.startswith("##date")]
+    for extra in ([], ["--cohort-table"], ["--shard", "cohort", "--devices", "0,0,0"]):
         out = str(tmp_path / f"o{len(outs)}.kcf")
         log = run_cli(["-r", fa, "-k", ",".join(prefixes), "-o", out, "-s", "A,B,C", "-f", "window", "-w", "3000"] + extra)
-        assert ("one cohort table" in log) == bool(extra)
-        outs.append([l for l in open(out).read().split("\n") if not l.startswith("##CMD") and not l.startswith("##date")])
-    assert outs[0] == outs[1] and len(outs[0]) > 20
-    log = run_cli(["-r", fa, "-k", prefixes[0] + "," + os.path.join(G, "db_fwd_k31_p7_cs1_m7"), "-o", str(tmp_path / "x.kcf"), "-s", "A,B",
-                   "-f", "window", "-w", "3000", "--cohort-table"], expect_rc=1)
-    assert "strandedness" in log
+        assert ("cohort-table x window-sharded" in log) == bool(extra)
+        outs.append(body(out))
+    assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 20
+    mixed = ["-r", fa, "-k", prefixes[0] + "," + os.path.join(G, "db_fwd_k31_p7_cs1_m7"), "-s", "A,B", "-f", "window", "-w", "3000"]
+    run_cli(mixed + ["-o", str(tmp_path / "x0.kcf")])
+    run_cli(mixed + ["-o", str(tmp_path / "x1.kcf"), "--cohort-table"])
+    assert body(str(tmp_path / "x0.kcf")) == body(str(tmp_path / "x1.kcf"))
 
 
 def test_samples_sharded_over_devices_give_the_same_file(tmp_path):
