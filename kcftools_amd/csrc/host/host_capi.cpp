@@ -20,6 +20,30 @@ extern "C" {
 const char* kcfh_fmt_2f(double x) { return ret(java_fmt_2f(x)); }
 const char* kcfh_double_to_string(double x) { return ret(java_double_to_string(x)); }
 const char* kcfh_float_to_string(float x) { return ret(java_float_to_string(x)); }
+const char* kcfh_jdk17_fmt_2f(double x) { return ret(jdk17_fmt_2f(x)); }
+const char* kcfh_jdk17_double_to_string(double x) { return ret(jdk17_double_to_string(x)); }
+const char* kcfh_jdk17_float_to_string(float x) { return ret(jdk17_float_to_string(x)); }
+// bulk form for the enumeration tests: how many of xs[0 .. n) the two digit generators format differently as %.2f; the first
+// such value in *first_bad
+long kcfh_fmt_2f_disagreements(const double* xs, long n, double* first_bad) {
+    long bad = 0;
+    for (long i = 0; i < n; ++i)
+        if (java_fmt_2f(xs[i]) != jdk17_fmt_2f(xs[i])) {
+            if (bad == 0 && first_bad) *first_bad = xs[i];
+            ++bad;
+        }
+    return bad;
+}
+// ... and as Double.toString (1) / how often the JDK 17 digits are NOT the shortest (2: a longer string, or another last digit)
+long kcfh_double_to_string_disagreements(const double* xs, long n, double* first_bad) {
+    long bad = 0;
+    for (long i = 0; i < n; ++i)
+        if (java_double_to_string(xs[i]) != jdk17_double_to_string(xs[i])) {
+            if (bad == 0 && first_bad) *first_bad = xs[i];
+            ++bad;
+        }
+    return bad;
+}
 
 // "" on success else the error text; *out = .faidx text
 const char* kcfh_faidx(const char* fasta, const char** out) {

@@ -32,7 +32,71 @@ def host():
     L.kcfh_faidx.argtypes = [C.c_char_p, C.POINTER(C.c_char_p)]
     L.kcfh_get_sequence.argtypes = [C.c_char_p, C.c_char_p, C.c_long, C.c_long, C.POINTER(C.c_char_p)]
     L.kcfh_gtf_windows.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p)]
+    for f in ("kcfh_jdk17_fmt_2f", "kcfh_jdk17_double_to_string", "kcfh_jdk17_float_to_string"):
+        getattr(L, f).restype = C.c_char_p
+    L.kcfh_jdk17_fmt_2f.argtypes = [C.c_double]
+    L.kcfh_jdk17_double_to_string.argtypes = [C.c_double]
+    L.kcfh_jdk17_float_to_string.argtypes = [C.c_float]
+    for f in ("kcfh_fmt_2f_disagreements", "kcfh_double_to_string_disagreements"):
+        getattr(L, f).restype = C.c_long
+        getattr(L, f).argtypes = [C.c_void_p, C.c_long, C.c_void_p]
     return L
+
+
+def test_jdk17_digits_and_shortest_digits_print_the_same_kcf(host):
+    """kcftools targets Java 17 (pom.xml:16), whose digit generator (FloatingDecimal, restated in java_fd17.cpp) is not always the
+    shortest one (JDK-4511638; fixed in JDK 19), while the product prints from the shortest digits. The restatement first against
+    what is documented of JDK <= 18: Double.toString(2e23) = "1.9999999999999998E23" (JDK 19 release note on the change),
+    2^-44 = "5.6843418860808015E-14" (the bug report's example), Float.toString(123456789f) = "1.23456792E8". Then the bound: on
+    every value a KCF file can hold AT a two-decimal tie (KD = count sum / observed k-mers, window sizes up to 50 kb: p / q with
+    1000 p / q an odd multiple of 5), on its neighbours, on millions of scores and depths from random window integers, on the
+    float means of MV= -- the two digit generators must print the same text."""
+    assert host.kcfh_jdk17_double_to_string(2e23).decode() == "1.9999999999999998E23" and host.kcfh_double_to_string(2e23).decode() == "2.0E23"
+    assert host.kcfh_jdk17_double_to_string(2.0 ** -44).decode() == "5.6843418860808015E-14"
+    assert host.kcfh_jdk17_float_to_string(123456789.0).decode() == "1.23456792E8"
+    for x, want in {0.3: "0.3", 1.0: "1.0", 0.001: "0.001", 1e7: "1.0E7", 1234567.0: "1234567.0", 0.1 + 0.2: "0.30000000000000004", 100.0: "100.0",
+                    4.9e-324: "4.9E-324", 1.7976931348623157e308: "1.7976931348623157E308", 9007199254740993.0: "9.007199254740992E15"}.items():
+        assert host.kcfh_jdk17_double_to_string(x).decode() == want, x
+    for x, want in {2.125: "2.13", 1.005: "1.01", 0.125: "0.13", 0.005: "0.01", 0.0005: "0.00", 99.995: "100.00", -0.001: "-0.00", 0.0: "0.00",
+                    6314.0: "6314.00", 1234567.891: "1234567.89", 1e23: "99999999999999990000000.00"}.items():
+        assert host.kcfh_jdk17_fmt_2f(x).decode() == want, x
+    first = C.c_double(0)
+
+    def same_2f(x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        bad = host.kcfh_fmt_2f_disagreements(x.ctypes.data, len(x), C.byref(first))
+        assert bad == 0, (bad, first.value, host.kcfh_fmt_2f(first.value), host.kcfh_jdk17_fmt_2f(first.value))
+        return len(x)
+    n = 0
+    # exact ties of KD: q a multiple of 8 whose 5-part leaves 1000 / gcd(q, 1000) in {5, 25, 125}; p = t q / 1000 for t = odd multiples
+    for q in range(8, 50_001, 8):
+        step = 1000 // np.gcd(q, 1000)
+        if step not in (5, 25, 125):
+            continue
+        t = np.arange(step, 120_000, 2 * step, dtype=np.int64)            # odd multiples: t % 10 == 5
+        p = t * q // 1000
+        assert np.all(p * 1000 == t * q)
+        for dp in (-1, 0, 1):                                               # the tie and its neighbours
+            n += same_2f((p + dp).astype(np.float64) / q)
+    rng = np.random.default_rng(17)
+    # scores and depths of random windows (Data.java:87, :104-106 in double, as kcfx_score evaluates them)
+    for _ in range(8):
+        total = rng.integers(1, 50_000, 400_000)
+        obs = rng.integers(1, total + 1)
+        eff = total + 30 * rng.integers(1, 4, len(total))
+        inner = rng.integers(0, eff + 1)
+        tail = rng.integers(0, total - obs + 1)
+        sc = ((0.4 * (obs / total)) + (0.3 * (1.0 - inner / eff)) + (0.3 * (1.0 - tail / eff))) * 100.0
+        kd = np.floor(obs * rng.uniform(1, 400, len(obs))) / obs
+        n += same_2f(sc) + same_2f(kd) + same_2f(np.round(sc, 3)) + same_2f(np.float32(sc).astype(np.float64))
+    assert n > 10_000_000
+    # MV= : Float.toString of a float mean of small integers; the ##PARAM weights: Double.toString
+    for S in range(1, 33):
+        for tot in range(0, 3000, 7 if S > 8 else 1):
+            x = float(np.float32(tot) / np.float32(S))
+            assert host.kcfh_float_to_string(x) == host.kcfh_jdk17_float_to_string(x), (tot, S)
+    w = np.round(rng.random(200_000), rng.integers(1, 6))                   # weights as typed on a command line
+    assert host.kcfh_double_to_string_disagreements(w.ctypes.data, len(w), C.byref(first)) == 0, first.value
 
 
 def test_java_number_formats(host):
