@@ -276,11 +276,11 @@ bool cells_eligible(const kcfx_db* db, int32_t counter_size) {
 // KCFX_TABLE_LBITS overrides.
 // Memory against speed (profiles/r03_density.csv, bench workload, 150 M k-mers): 0.07 / 0.14 / 0.28 / 0.56 k-mers per cell =
 // 17.4 / 9.1 / 5.4 / 4.3 GB = 1.00 / 1.00 / 1.21 / 1.57 x the screening time per k-mer (round 4, same box: 0.0844 / 0.0841 /
-// 0.1000 ms per pass). 0.14 per cell is the knee: a handle that is expected to serve fewer than QUERIES_FOR_SPARSE look-ups
-// (kcfx_db_opts: the command-line driver's one pass per sample) is built there -- half the memory of the sparse table at its
-// speed. (Round 3 built such handles at ~0.3 per cell to save the clearing of 4 GB more; under the command-line driver the
-// three sizes are indistinguishable end to end -- profiles/r04_notes.md: 0.44 - 0.55 s each over six rounds -- and the screening
-// pass is 16 % slower at 0.28.)
+// 0.1000 ms per pass on one box, 0.0770 / 0.0840 on another: the sparse table is never the slower one). Round 3 built the handles
+// of one-pass jobs (kcfx_db_opts.expected_queries below QUERIES_FOR_SPARSE: the command-line driver) at ~0.3 per cell to save the
+// clearing of 12 GB more. Under the command-line driver the three sizes are indistinguishable end to end (profiles/r04_notes.md:
+// 0.37 - 0.55 s each over six rounds) while the screening pass is 16 - 30 % slower at 0.28: since round 4 every handle gets
+// the same ~0.075 per cell, and expected_queries only decides the crowding counters (pop_alloc).
 constexpr double QUERIES_FOR_SPARSE = 1e10;
 int32_t cells_lbits(int64_t n_keys, int32_t k, bool both, int64_t expected_queries, int32_t line_footprint = LINE_BYTES) {
     const int32_t cap = cells_lbits_cap(k);
@@ -289,7 +289,8 @@ int32_t cells_lbits(int64_t n_keys, int32_t k, bool both, int64_t expected_queri
     if (s && atoi(s) >= lmin && atoi(s) <= cap) return atoi(s);
     const size_t free_b = free_device_bytes();
     const double room = std::min(48.0 * (double)(1ull << 30), 0.5 * (double)free_b);
-    const double density = (expected_queries > 0 && (double)expected_queries < QUERIES_FOR_SPARSE) ? 0.15 : 0.075;
+    (void)expected_queries;                               // (one density for every handle since round 4, see above)
+    const double density = 0.075;
     int32_t L = lmin;
     while (L < cap && 16.0 * (double)(1ull << L) * density < (double)n_keys) ++L;
     while (L > lmin && (double)(1ull << L) * line_footprint > room && 16.0 * (double)(1ull << (L - 1)) >= (double)n_keys) --L;
@@ -573,12 +574,16 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     uint64_t* d_lut = nullptr;
     uint64_t* d_keys = nullptr;
     uint32_t* d_counts = nullptr;
+    uint64_t* d_pw = nullptr;          // the cells of the resident records, kept by the first pass for the later ones (RecProbes)
+    uint8_t* d_ps = nullptr;
     hipEvent_t done[2] = {nullptr, nullptr};
     int32_t rc = KCFX_OK;
     auto cleanup = [&]() {
         // the temporaries are used on db->stream only: wait for that stream, not for the device (the other worker's
         // screening kernel, the next database's uploads)
         (void)hipStreamSynchronize(db->stream);
+        if (d_pw) (void)dev_free_idle(d_pw);
+        if (d_ps) (void)dev_free_idle(d_ps);
         for (int i = 0; i < 2; ++i) {
             if (h_buf[i]) (void)host_free(h_buf[i]);
             if (d_rec[i]) (void)dev_free_idle(d_rec[i]);
@@ -616,6 +621,14 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     LOAD_HIP(dev_alloc(&d_lut, (size_t)std::max<int64_t>(h.lut_entries, 1) * 8));
     LOAD_HIP(dev_alloc(&d_keys, (size_t)n_keys_buf * 8));
     LOAD_HIP(dev_alloc(&d_counts, (size_t)n_keys_buf * 4));
+    // cell tables, records resident: 9 more bytes per record buy four of the five passes their ~600 instructions per k-mer
+    // (KCFX_LOAD_NO_PROBES=1: every pass derives the cells itself, as a streamed-twice load has to -- A/B and test hook)
+    const bool keep_probes = cells && resident && getenv("KCFX_LOAD_NO_PROBES") == nullptr &&
+                             (double)h.total * 21.0 + (double)(2 * chunk_bytes) + (double)(64 << 20) < 0.5 * (double)free_b;
+    if (keep_probes) {
+        LOAD_HIP(dev_alloc(&d_pw, (size_t)n_keys_buf * 8));
+        LOAD_HIP(dev_alloc(&d_ps, (size_t)n_keys_buf));
+    }
     if (h.lut_entries) LOAD_HIP(hipMemcpyAsync(d_lut, h.lut_bytes, (size_t)h.lut_entries * 8, hipMemcpyHostToDevice, db->stream));
     tr.mark("buffers + LUT upload");
 
@@ -625,10 +638,15 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     auto apply = [&](int phase, const uint64_t* keys, const uint32_t* counts, int64_t n) -> hipError_t {
         if (cells) {
             const int32_t kk = db->info.kmer_length;
-            if (phase == 0) return launch_cells_count(db->d_pop, db->pop_bits, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream);
-            if (phase == 1 || phase == 2) return launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, phase == 1 ? 1 : 0, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream);
-            if (phase == 3) return launch_cells_settle(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stats, db->stream);
-            return launch_cells_stash(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stash, db->stash_mask, db->stream);
+            // (the kept cells of these records: the batch's offset in the resident arrays is its offset in d_keys)
+            uint64_t* pw = d_pw ? d_pw + (keys - d_keys) : nullptr;
+            uint8_t* ps = d_ps ? d_ps + (keys - d_keys) : nullptr;
+            if (phase == 0)
+                return pw ? launch_cells_resolve(db->d_pop, db->pop_bits, kk, db->lbits, db->info.both_strands, keys, counts, n, pw, ps, db->stream)
+                          : launch_cells_count(db->d_pop, db->pop_bits, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream);
+            if (phase == 1 || phase == 2) return launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, phase == 1 ? 1 : 0, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream, 0, pw, ps);
+            if (phase == 3) return launch_cells_settle(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stats, db->stream, 0, pw, ps);
+            return launch_cells_stash(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stash, db->stash_mask, db->stream, 0, pw, ps);
         }
         if (phase == 0) return launch_table_count(db->d_lines, db->view(), h.k, keys, n, db->stream);
         return launch_table_insert(db->d_lines, db->view(), h.k, keys, counts, n, db->stream);
@@ -1309,9 +1327,13 @@ int32_t kcfx_cohort_open(const char* const* kmc_prefixes, int32_t n_samples, int
         kcfx_cohort* c = nullptr;
         uint64_t* d_keys = nullptr;
         uint32_t* d_counts = nullptr;
+        uint64_t* d_pw = nullptr;                          // the records' cells, kept by the first build pass (RecProbes)
+        uint8_t* d_ps = nullptr;
         ~Hold() {
             if (d_keys) (void)dev_free(d_keys);
             if (d_counts) (void)dev_free(d_counts);
+            if (d_pw) (void)dev_free(d_pw);
+            if (d_ps) (void)dev_free(d_ps);
             kcfx_cohort_close(c);
         }
     } hold;
@@ -1359,16 +1381,29 @@ int32_t kcfx_cohort_open(const char* const* kmc_prefixes, int32_t n_samples, int
     if (int32_t rc = table_alloc(db, N, 2, true, false)) return rc;
     if (db->fmt != FORMAT_CELLS) return fail(KCFX_ERR_ARG, "cohort tables need a cell table (KCFX_TABLE_FORMAT / KCFX_GENERIC_KERNEL / too many k-mers)");
     const int32_t k = hs[0].k, both = db->info.both_strands;
+    // the cells of every record once, for the four later passes and the S counter passes (9 bytes per record, if they fit)
+    if (getenv("KCFX_LOAD_NO_PROBES") == nullptr && (double)nn * 9.0 < 0.25 * (double)free_device_bytes()) {
+        if (dev_alloc(&hold.d_pw, nn * 8) != hipSuccess || dev_alloc(&hold.d_ps, nn) != hipSuccess) {
+            (void)hipGetLastError();
+            if (hold.d_pw) (void)dev_free(hold.d_pw);
+            hold.d_pw = nullptr;
+            hold.d_ps = nullptr;
+        }
+    }
     auto pass = [&](int phase) -> hipError_t {
         for (int64_t first = 0; first < N; first += (1ll << 30)) {
             const int64_t n = std::min<int64_t>(1ll << 30, N - first);
             const uint64_t* kk = hold.d_keys + first;
             const uint32_t* cc = hold.d_counts + first;
+            uint64_t* pw = hold.d_pw ? hold.d_pw + first : nullptr;
+            uint8_t* ps = hold.d_ps ? hold.d_ps + first : nullptr;
             hipError_t e2 = hipSuccess;
-            if (phase == 0) e2 = launch_cells_count(db->d_pop, db->pop_bits, k, db->lbits, both, kk, cc, n, db->stream, 1);
-            else if (phase == 1 || phase == 2) e2 = launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, phase == 1 ? 1 : 0, k, db->lbits, both, kk, cc, n, db->stream, 1);
-            else if (phase == 3) e2 = launch_cells_settle(db->d_lines, k, db->lbits, both, kk, cc, n, db->d_stats, db->stream, 1);
-            else e2 = launch_cells_stash(db->d_lines, k, db->lbits, both, kk, cc, n, db->d_stash, db->stash_mask, db->stream, 1);
+            if (phase == 0)
+                e2 = pw ? launch_cells_resolve(db->d_pop, db->pop_bits, k, db->lbits, both, kk, cc, n, pw, ps, db->stream)
+                        : launch_cells_count(db->d_pop, db->pop_bits, k, db->lbits, both, kk, cc, n, db->stream, 1);
+            else if (phase == 1 || phase == 2) e2 = launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, phase == 1 ? 1 : 0, k, db->lbits, both, kk, cc, n, db->stream, 1, pw, ps);
+            else if (phase == 3) e2 = launch_cells_settle(db->d_lines, k, db->lbits, both, kk, cc, n, db->d_stats, db->stream, 1, pw, ps);
+            else e2 = launch_cells_stash(db->d_lines, k, db->lbits, both, kk, cc, n, db->d_stash, db->stash_mask, db->stream, 1, pw, ps);
             if (e2 != hipSuccess) return e2;
         }
         return hipSuccess;
@@ -1387,7 +1422,7 @@ int32_t kcfx_cohort_open(const char* const* kmc_prefixes, int32_t n_samples, int
     off = 0;
     for (int32_t s = 0; s < n_samples; ++s) {
         if ((e = launch_cohort_fill(db->view(), k, both, hold.d_keys + off, hold.d_counts + off, hs[(size_t)s].total, s, co->d_counts,
-                                    co->d_scounts, db->stream)) != hipSuccess)
+                                    co->d_scounts, db->stream, hold.d_pw ? hold.d_pw + off : nullptr, hold.d_ps ? hold.d_ps + off : nullptr)) != hipSuccess)
             return hip_fail(e, "kcfx_cohort_open: counter pass");
         off += hs[(size_t)s].total;
     }

@@ -286,10 +286,23 @@ constexpr uint32_t CELL_R_ALT = 0x8000u;
 // rest of G32, so bit 14 of r says which of the two this is (CELL_R_FLIP: the stored word is the reverse complement of
 // N). Such a table needs lbits >= 18 and has one filter bit less. `both` = the database is canonical (both strands).
 constexpr uint32_t CELL_R_FLIP = 0x4000u;
+// THIRD LINES (round 4). A k-mer that finds its second-line cell taken as well gets one more line before the stash -- and this
+// one is chosen by more than the minimizer: by the three bases of the flank next to it, on the side where the k-mer has more of
+// them (cell_third_line). The losers of a run still move together (at most two groups: the k-mers with the minimizer in their
+// second half share the bases before it, the others the bases after it), but DIFFERENT loci that contain the same 16-mer part
+// ways here -- which the second line, a function of the minimizer alone, cannot do for them: beyond ~0.5 G distinct k-mers the
+// 2^31 canonical 16-mers are shared by several loci each, and a third locus of a minimizer used to live in the stash, k-mer by
+// k-mer (profiles/r03_config5: 19 - 33 % of a 2.1 G-k-mer database). Such an entry carries ALT and one more mark: the top spare
+// bit of r (bit 14, forward-only tables: 13), taken from the filter bits -- tables with fewer than three spare bits have no third
+// lines and send on to the stash as before.
+KCFX_HD bool cell_has_third(int32_t lbits, bool both) { return lbits - cell_lbits_min(both) >= 3; }
+KCFX_HD uint32_t cell_r_third(bool both) { return both ? 0x4000u : 0x2000u; }
 KCFX_HD uint32_t cell_rmask(int32_t lbits, bool both) {          // the bits of r that identify
-    return (0xFFFFFFFFu >> lbits) | CELL_R_ALT | (both ? 0u : CELL_R_FLIP);
+    return (0xFFFFFFFFu >> lbits) | CELL_R_ALT | (both ? 0u : CELL_R_FLIP) | (cell_has_third(lbits, both) ? cell_r_third(both) : 0u);
 }
-KCFX_HD uint32_t cell_spare_bits(int32_t lbits, bool both) { return (uint32_t)(lbits - cell_lbits_min(both)); }
+KCFX_HD uint32_t cell_spare_bits(int32_t lbits, bool both) {     // filter bits of a flagged cell
+    return (uint32_t)(lbits - cell_lbits_min(both)) - (cell_has_third(lbits, both) ? 1u : 0u);
+}
 // bit position inside r of the filter bit of a k-mer with flank w (meaningful only when cell_spare_bits() > 0)
 KCFX_HD uint32_t cell_filter_pos(uint32_t w, int32_t lbits, bool both) {
     const uint32_t h = w * 0x9E3779B1u;                         // single-base neighbours must spread: multiplicative hash
@@ -380,6 +393,25 @@ KCFX_HD CellProbe cell_second_line(const CellProbe& p, int32_t lbits) {
     q.sh = p.sh;
     q.w = p.w;
     q.r = (g2 & idm) | CELL_R_ALT | (p.r & CELL_R_FLIP & ~idm);    // (a canonical table of 2^17 lines has a G32 bit where FLIP would be)
+    return q;
+}
+
+// the third-line probe of a first-choice probe (call only when cell_has_third): line and r from a bijection of G32' that the
+// flank's bases next to the minimizer select -- side (1 bit: before / after the minimizer, whichever side the k-mer has more
+// bases on) and up to three bases there. (sh, w) are compared with the entry, so (line, r, sh, w) still identify the k-mer.
+KCFX_HD CellProbe cell_third_line(const CellProbe& p, int32_t lbits, bool both, int W) {
+    const uint32_t idm = 0xFFFFFFFFu >> lbits;
+    // the flank: its first sh bits are the sh / 2 bases in front of the minimizer, the rest the bases behind it (cell_flank)
+    const bool before = (int)p.sh >= W;                           // offset >= W / 2: more bases in front (sh >= 4 there: W >= 4)
+    const uint32_t near6 = before ? (p.w >> (32u - p.sh)) & 63u : (p.w >> (26u - p.sh)) & 63u;
+    const uint32_t e = (near6 << 1) | (before ? 1u : 0u);
+    const uint32_t g2 = cell_g32b((p.line << (32 - lbits)) | (p.r & idm));
+    const uint32_t g3 = cell_g32b(g2 ^ ((e + 1u) * 0x9E3779B1u));
+    CellProbe q;
+    q.line = g3 >> (32 - lbits);
+    q.sh = p.sh;
+    q.w = p.w;
+    q.r = (g3 & idm) | CELL_R_ALT | cell_r_third(both) | (p.r & CELL_R_FLIP & ~idm);
     return q;
 }
 

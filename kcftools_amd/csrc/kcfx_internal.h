@@ -72,7 +72,8 @@ constexpr int MODE_KEYHASH = 0, MODE_MINIMIZER = 1;
 //   sequencing-error neighbours, which share its minimizer and offset). A loser takes, in this order: (a retired build-time
 //   option, KCFX_ALT_FREE_MAX_W: for k < 31 a free cell W .. 15 of the same line;) the same cell of its SECOND LINE (top lbits of G32' = a second bijection of the
 //   minimizer, r from G32' with bit 15 set: cell_second_line) -- the losers of a minimizer meet again there, one request for
-//   all of them; the stash: open addressing over 16-byte entries {u64 key, u32 count, u32 pad}, slot = hash32(key) & mask,
+//   all of them; (round 4, tables with >= 3 spare r bits) the same cell of its THIRD LINE -- chosen by the minimizer AND the three
+//   flank bases next to it (cell_third_line: different loci that share a 16-mer part ways there; r carries one more mark); the stash: open addressing over 16-byte entries {u64 key, u32 count, u32 pad}, slot = hash32(key) & mask,
 //   probed by the lanes individually. Both steps only into EMPTY cells, and each is announced in the cell before it
 //   (flag + filter bit), so a query follows exactly the path the build took.
 // ----------------------------------------------------------------------------------------------------
@@ -288,19 +289,24 @@ size_t cells_pop_bytes(int32_t pop_bits);          // pop_bits = 32 (one counter
 // (presence != 0: every non-zero counter is stored as 1 -- the key table of a cohort, kcfx_cohort_open)
 hipError_t launch_cells_count(uint32_t* pop32, int32_t pop_bits, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
                               hipStream_t st, int32_t presence = 0);
+// (pw / ps: the cells of the records as launch_cells_resolve kept them -- 8 + 1 bytes per record, see RecProbes in kcfx_kernels.hip --
+// or null: the pass derives them itself with cells_visit. launch_cells_resolve = launch_cells_count + keeping them.)
+hipError_t launch_cells_resolve(uint32_t* pop32, int32_t pop_bits, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
+                                uint64_t* pw, uint8_t* ps, hipStream_t st);
 hipError_t launch_cells_insert(uint8_t* lines, const uint32_t* pop32, int32_t pop_bits, int32_t cls, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys,
-                               const uint32_t* counts, int64_t n, hipStream_t st, int32_t presence = 0);
+                               const uint32_t* counts, int64_t n, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr);
 hipError_t launch_cells_settle(uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                               unsigned long long* stats, hipStream_t st, int32_t presence = 0);
+                               unsigned long long* stats, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr);
 hipError_t launch_cells_stash(const uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                              uint4* stash, uint32_t stash_mask, hipStream_t st, int32_t presence = 0);
+                              uint4* stash, uint32_t stash_mask, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr);
 // cohort tables: one sample's counters into the finished key table; S samples screened in one pass (bits / count_sums laid out
 // per sample as launch_screen_multi's: sample s at bits + s * n_tiles * TILE_BITS_U64, count_sums + s * n_tiles)
 // phase 0: every record votes for its k-mer in `votes` (2^n slots of 16 bytes, all bytes 0xFF); phase 1: the bid rank of every
 // record (samples holding its k-mer, then its counter) into the upper half of its counts word
 hipError_t launch_cohort_votes(const uint64_t* keys, uint32_t* counts, int64_t n, uint4* votes, uint32_t mask, int32_t phase, hipStream_t st);
 hipError_t launch_cohort_fill(TableView tv, int32_t k, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                              int32_t sample, uint16_t* cell_counts, uint16_t* stash_counts, hipStream_t st);
+                              int32_t sample, uint16_t* cell_counts, uint16_t* stash_counts, hipStream_t st,
+                              const uint64_t* pw = nullptr, const uint8_t* ps = nullptr);
 hipError_t launch_screen_cohort(const uint8_t* text, RefPlan plan, const TileDesc* tiles, int32_t n_tiles, CohortView cv, int32_t k,
                                 int32_t both_strands, int32_t min_count, uint64_t* bits, int64_t* count_sums, hipStream_t st,
                                 hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);

@@ -245,12 +245,66 @@ __global__ void cells_count_kernel(uint32_t* pop32, int32_t pop_bits, int32_t k,
     }
 }
 
+// ---- the cells of a record, worked out ONCE ----------------------------------------------------------------------------
+// cells_visit costs ~600 instructions per k-mer (26 canonical 6-mer hashes, 16 order keys, the probe of every tied offset) and
+// the build walks the records five times: on the bench database that was 5 x 14 ms of a 105 ms kcfx_db_open, all of it
+// instruction issue. When the decoded records stay resident between the passes (they do unless the database is larger than
+// half the device), the first pass keeps what it derived -- G32 and the flank in one 64-bit word, cell index and two flags in a
+// byte: 9 bytes per record -- and the later passes read that instead. A k-mer with MORE than one cell (tied or palindromic
+// minimizers: a few in 10^5) is flagged and walked by cells_visit as before.
+struct RecProbes {
+    const uint64_t* pw;     // G32 | flank << 32        (null: nothing was kept -- every pass derives the cells itself)
+    const uint8_t* ps;      // cell index | REC_MULTI | REC_FLIP
+};
+constexpr uint8_t REC_MULTI = 0x10, REC_FLIP = 0x20;
+template <class F>
+__device__ __forceinline__ int record_cells(const RecProbes& rp, int64_t i, uint64_t key, int32_t k, int32_t lbits, bool both, F&& f) {
+    if (rp.pw) {
+        const uint32_t s = rp.ps[i];
+        if (!(s & REC_MULTI)) {
+            const uint64_t w = rp.pw[i];
+            const uint32_t g = (uint32_t)w;
+            CellProbe p;
+            p.line = g >> (32 - lbits);
+            p.r = (g & (0xFFFFFFFFu >> lbits)) | ((s & REC_FLIP) ? CELL_R_FLIP : 0u);
+            p.w = (uint32_t)(w >> 32);
+            p.sh = 2u * (s & 15u);
+            f(p, 0);
+            return 1;
+        }
+    }
+    return cells_visit(key, k, lbits, both, f);
+}
+
+// Pass 0 when the records stay resident: cells_count_kernel + the probes kept
+__global__ void cells_resolve_kernel(uint32_t* pop32, int32_t pop_bits, int32_t k, int32_t lbits, int32_t both, const uint64_t* __restrict__ keys,
+                                     const uint32_t* __restrict__ counts, int64_t n, uint64_t* __restrict__ pw, uint8_t* __restrict__ ps) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        if (counts[i] == 0) {                                   // never stored (every later pass skips it on its counter)
+            pw[i] = 0ull;
+            ps[i] = 0;
+            continue;
+        }
+        CellProbe first{0, 0, 0, 0};
+        const int nc = cells_visit(keys[i], k, lbits, both != 0, [&](const CellProbe& p, int a) {
+            if (a == 0) first = p;
+        });
+        const uint64_t sub = cell_sub_bucket(first, lbits, pop_bits);
+        atomicAdd(&pop32[sub >> 2], 1u << (8 * (uint32_t)(sub & 3)));
+        const uint32_t g = (first.line << (32 - lbits)) | (first.r & (0xFFFFFFFFu >> lbits));
+        pw[i] = (uint64_t)g | ((uint64_t)first.w << 32);
+        ps[i] = (uint8_t)((first.sh >> 1) | (nc > 1 ? REC_MULTI : 0) | ((first.r & CELL_R_FLIP & ~(0xFFFFFFFFu >> lbits)) ? REC_FLIP : 0));
+    }
+}
+
 // Pass 1 (cls = 1) and pass 2 (cls = 0, after ALL of pass 1): every stored k-mer of the class bids for its first-choice
 // cell(s). Crowded k-mers bid with a 64-bit atomic max -- the count is the most significant field, so the most abundant
 // one gets the cell whatever the arrival order. The others do the same among themselves (a CAS loop), but never replace a
 // crowded occupant.
 __global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__ pop32, int32_t pop_bits, int32_t cls, int32_t k, int32_t lbits, int32_t both,
-                                    const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, int64_t n, int32_t presence) {
+                                    const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, int64_t n, int32_t presence, RecProbes rp) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
@@ -258,7 +312,7 @@ __global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__
         if (c == 0) continue;                       // can never be observed (count >= -c >= 1 is needed): not stored
         if (c > CELL_COUNT_MAX) continue;           // a 3- / 4-byte counter that does not fit a cell: lives in the stash (settle)
         bool crowded = false;
-        cells_visit(keys[i], k, lbits, both != 0, [&](const CellProbe& p, int a) {
+        record_cells(rp, i, keys[i], k, lbits, both != 0, [&](const CellProbe& p, int a) {
             if (a == 0) {
                 const uint64_t sub = cell_sub_bucket(p, lbits, pop_bits);
                 crowded = ((pop32[sub >> 2] >> (8 * (uint32_t)(sub & 3))) & 0xFFu) >= CELL_CROWD;
@@ -281,8 +335,8 @@ __global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__
 }
 
 // where a k-mer stands after the build passes so far: in its first-choice cell (0), in a free cell of the same line (1: k < 31,
-// cell_alt_free), in the same cell of its second line (2), or nowhere (STAND_NONE: the stash)
-constexpr int STAND_FIRST = 0, STAND_FREE = 1, STAND_SECOND_LINE = 2, STAND_NONE = 3;
+// cell_alt_free), in the same cell of its second line (2) or of its third line (4: cell_third_line), or nowhere (STAND_NONE: the stash)
+constexpr int STAND_FIRST = 0, STAND_FREE = 1, STAND_SECOND_LINE = 2, STAND_NONE = 3, STAND_THIRD_LINE = 4;
 __device__ __forceinline__ int cell_standing(const uint8_t* lines, const CellProbe& p, uint32_t c, int32_t lbits, bool both, int W,
                                              int32_t presence = 0) {
     const uint64_t kc = cell_keycount_mask(lbits, both);              // (flags and filter bits are not part of the k-mer)
@@ -297,6 +351,11 @@ __device__ __forceinline__ int cell_standing(const uint8_t* lines, const CellPro
     const CellProbe q = cell_second_line(p, lbits);
     const uint64_t there = __atomic_load_n(reinterpret_cast<const uint64_t*>(lines + (size_t)q.line * LINE_BYTES + 4 * q.sh), __ATOMIC_RELAXED);
     if (cell_same(there, cell_word(q.w, q.r, c), kc, presence)) return STAND_SECOND_LINE;
+    if (cell_has_third(lbits, both)) {
+        const CellProbe t = cell_third_line(p, lbits, both, W);
+        const uint64_t third = __atomic_load_n(reinterpret_cast<const uint64_t*>(lines + (size_t)t.line * LINE_BYTES + 4 * t.sh), __ATOMIC_RELAXED);
+        if (cell_same(third, cell_word(t.w, t.r, c), kc, presence)) return STAND_THIRD_LINE;
+    }
     return STAND_NONE;
 }
 
@@ -306,7 +365,7 @@ __device__ __forceinline__ int cell_standing(const uint8_t* lines, const CellPro
 // too). stats[0] = k-mers for the stash, [1] = k-mers stored (count != 0), [2] = k-mers with more than one first-choice cell,
 // [3] = k-mers placed outside their first-choice cell
 __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, int32_t both_i, const uint64_t* __restrict__ keys,
-                                    const uint32_t* __restrict__ counts, int64_t n, unsigned long long* stats, int32_t presence) {
+                                    const uint32_t* __restrict__ counts, int64_t n, unsigned long long* stats, int32_t presence, RecProbes rp) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     uint32_t n_lost = 0, n_stored = 0, n_multi = 0, n_second = 0;      // per lane; one atomic per wave at the end
@@ -316,7 +375,7 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, in
         if (c == 0) continue;
         bool lost = false;
         const bool wide = c > CELL_COUNT_MAX;
-        const int nc = cells_visit(keys[i], k, lbits, both, [&](const CellProbe& p, int) {
+        const int nc = record_cells(rp, i, keys[i], k, lbits, both, [&](const CellProbe& p, int) {
             uint8_t* line = lines + (size_t)p.line * LINE_BYTES;
             unsigned long long mark = CELL_FLAG_STASH;
             if (cell_spare_bits(lbits, both) > 0) mark |= 1ull << (32 + cell_filter_pos(p.w, lbits, both));
@@ -326,6 +385,10 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, in
                 const CellProbe q = cell_second_line(p, lbits);
                 atomicOr(reinterpret_cast<unsigned long long*>(line + 4 * p.sh), mark);
                 atomicOr(reinterpret_cast<unsigned long long*>(lines + (size_t)q.line * LINE_BYTES + 4 * q.sh), mark);
+                if (cell_has_third(lbits, both)) {
+                    const CellProbe t = cell_third_line(p, lbits, both, cell_nw(k));
+                    atomicOr(reinterpret_cast<unsigned long long*>(lines + (size_t)t.line * LINE_BYTES + 4 * t.sh), mark);
+                }
                 lost = true;
                 return;
             }
@@ -357,7 +420,17 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, in
                 ++n_second;
                 return;
             }
-            atomicOr(there, mark);                                           // ... and so does the second-line cell: the stash
+            atomicOr(there, mark);                                           // ... and so does the second-line cell
+            if (cell_has_third(lbits, both)) {
+                // the same cell of its third line: where the losers of DIFFERENT loci with this minimizer part ways
+                const CellProbe t = cell_third_line(p, lbits, both, cell_nw(k));
+                unsigned long long* third = reinterpret_cast<unsigned long long*>(lines + (size_t)t.line * LINE_BYTES + 4 * t.sh);
+                if (take(third, cell_word(t.w, t.r, c), cell_keycount_mask(lbits, both))) {
+                    ++n_second;
+                    return;
+                }
+                atomicOr(third, mark);                                       // ... and the third-line cell: the stash
+            }
             lost = true;
         });
         n_lost += lost ? 1u : 0u;
@@ -376,7 +449,7 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, in
 
 // Pass 3 (after pass 2 has completed): a k-mer that stands in neither cell of one of its candidates goes to the stash.
 __global__ void cells_stash_kernel(const uint8_t* __restrict__ lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* __restrict__ keys,
-                                   const uint32_t* __restrict__ counts, int64_t n, uint4* stash, uint32_t mask, int32_t presence) {
+                                   const uint32_t* __restrict__ counts, int64_t n, uint4* stash, uint32_t mask, int32_t presence, RecProbes rp) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
@@ -385,7 +458,7 @@ __global__ void cells_stash_kernel(const uint8_t* __restrict__ lines, int32_t k,
         const uint64_t key = keys[i];
         bool lost = c > CELL_COUNT_MAX;                 // (counters wider than a cell's 16 bits)
         if (!lost)
-            cells_visit(key, k, lbits, both != 0, [&](const CellProbe& p, int) { lost |= cell_standing(lines, p, c, lbits, both != 0, cell_nw(k), presence) == STAND_NONE; });
+            record_cells(rp, i, key, k, lbits, both != 0, [&](const CellProbe& p, int) { lost |= cell_standing(lines, p, c, lbits, both != 0, cell_nw(k), presence) == STAND_NONE; });
         if (!lost) continue;
         uint32_t slot = stash_slot(key, mask);
         for (;;) {
@@ -452,10 +525,22 @@ __global__ __launch_bounds__(256) void lookup_cells_kernel(TableView tv, int32_t
             if (!found && sent_on(first)) {
                 const CellProbe q = cell_second_line(c0, tv.lbits);
                 const uint64_t there = *reinterpret_cast<const uint64_t*>(tv.lines + (size_t)q.line * LINE_BYTES + 4 * q.sh);
-                if (((there ^ cell_word(q.w, q.r, 0)) & KEY_BITS) == 0 && (there >> 48) != 0)
+                if (((there ^ cell_word(q.w, q.r, 0)) & KEY_BITS) == 0 && (there >> 48) != 0) {
                     result = (int32_t)(there >> 48);
-                else if (sent_on(there))
-                    result = (int32_t)stash_find(tv, key);
+                } else if (sent_on(there)) {
+                    bool on = true;
+                    if (cell_has_third(tv.lbits, both)) {
+                        const CellProbe t = cell_third_line(c0, tv.lbits, both, cell_nw(k));
+                        const uint64_t third = *reinterpret_cast<const uint64_t*>(tv.lines + (size_t)t.line * LINE_BYTES + 4 * t.sh);
+                        if (((third ^ cell_word(t.w, t.r, 0)) & KEY_BITS) == 0 && (third >> 48) != 0) {
+                            result = (int32_t)(third >> 48);
+                            on = false;
+                        } else {
+                            on = sent_on(third);
+                        }
+                    }
+                    if (on) result = (int32_t)stash_find(tv, key);
+                }
             }
         }
         out[i] = result;
@@ -528,7 +613,7 @@ __global__ void cohort_prio_kernel(const uint64_t* __restrict__ keys, uint32_t* 
 // columns, so there is no race.
 __global__ void cohort_fill_kernel(TableView tv, int32_t k, int32_t both_i, const uint64_t* __restrict__ keys,
                                    const uint32_t* __restrict__ counts, int64_t n, int32_t sample, uint16_t* cell_counts,
-                                   uint16_t* stash_counts) {
+                                   uint16_t* stash_counts, RecProbes rp) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const bool both = both_i != 0;
@@ -537,14 +622,15 @@ __global__ void cohort_fill_kernel(TableView tv, int32_t k, int32_t both_i, cons
         if (c == 0) continue;
         const uint64_t key = keys[i];
         bool stashed = false;
-        cells_visit(key, k, tv.lbits, both, [&](const CellProbe& p, int) {
+        record_cells(rp, i, key, k, tv.lbits, both, [&](const CellProbe& p, int) {
             const int st = cell_standing(tv.lines, p, 1u, tv.lbits, both, cell_nw(k), 1);
             if (st == STAND_NONE) {
                 stashed = true;
                 return;
             }
             const uint32_t sh = st == STAND_FREE ? cell_alt_of(p.sh, p.w, p.r, cell_nw(k), tv.lbits, both).sh : p.sh;
-            const uint32_t ln = st == STAND_SECOND_LINE ? cell_second_line(p, tv.lbits).line : p.line;
+            const uint32_t ln = st == STAND_SECOND_LINE ? cell_second_line(p, tv.lbits).line
+                                : st == STAND_THIRD_LINE ? cell_third_line(p, tv.lbits, both, cell_nw(k)).line : p.line;
             const size_t cell = (size_t)ln * 16 + (sh >> 1);
             cell_counts[cell * COHORT_STRIDE + sample] = (uint16_t)c;
         });
@@ -1474,7 +1560,21 @@ __device__ __forceinline__ int k31c_deferred_round(const TableView& tv, const Ld
             found(id, e.y >> 16, (uint32_t)cell, false);
         } else {
             const uint32_t nspare = cell_spare_bits(tv.lbits, BOTH);
-            const bool on = (e.x & CELL_FLAG_STASH) && (nspare == 0 || ((e.y >> cell_filter_pos(q2.w, tv.lbits, BOTH)) & 1u));
+            // (w is the same in every line of the k-mer: so is its filter bit)
+            const uint32_t fpos = nspare == 0 ? 0u : cell_filter_pos(q2.w, tv.lbits, BOTH);
+            bool on = (e.x & CELL_FLAG_STASH) && (nspare == 0 || ((e.y >> fpos) & 1u));
+            if (on && cell_has_third(tv.lbits, BOTH)) {
+                // its third line: the losers of this minimizer's other loci are not here
+                const CellProbe q3 = cell_third_line(p, tv.lbits, BOTH, cell_nw(K));
+                const size_t cell3 = (size_t)q3.line * 16 + (q3.sh >> 1);
+                const uint2 e3 = reinterpret_cast<const uint2*>(tv.lines)[cell3];
+                if (((e3.x ^ q3.w) <= CELL_FLAG_MASK) && (((e3.y ^ q3.r) & rmask) == 0) && (e3.y >> 16) != 0u) {
+                    found(id, e3.y >> 16, (uint32_t)cell3, false);
+                    on = false;
+                } else {
+                    on = (e3.x & CELL_FLAG_STASH) && (nspare == 0 || ((e3.y >> fpos) & 1u));
+                }
+            }
             if (on) {
                 const uint32_t slot = stash_find_slot(tv, key);
                 if (slot != ~0u) found(id, tv.stash[slot].z, slot, true);
@@ -2195,27 +2295,35 @@ hipError_t launch_cells_count(uint32_t* pop32, int32_t pop_bits, int32_t k, int3
     return hipGetLastError();
 }
 
-hipError_t launch_cells_insert(uint8_t* lines, const uint32_t* pop32, int32_t pop_bits, int32_t cls, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys,
-                               const uint32_t* counts, int64_t n, hipStream_t st, int32_t presence) {
+hipError_t launch_cells_resolve(uint32_t* pop32, int32_t pop_bits, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
+                                uint64_t* pw, uint8_t* ps, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(cells_insert_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, pop32, pop_bits, cls, k, lbits, both, keys, counts, n, presence);
+    hipLaunchKernelGGL(cells_resolve_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, pop32, pop_bits, k, lbits, both, keys, counts, n, pw, ps);
+    return hipGetLastError();
+}
+
+hipError_t launch_cells_insert(uint8_t* lines, const uint32_t* pop32, int32_t pop_bits, int32_t cls, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys,
+                               const uint32_t* counts, int64_t n, hipStream_t st, int32_t presence, const uint64_t* pw, const uint8_t* ps) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(cells_insert_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, pop32, pop_bits, cls, k, lbits, both, keys, counts, n, presence,
+                       RecProbes{pw, ps});
     return hipGetLastError();
 }
 
 size_t cells_pop_bytes(int32_t pop_bits) { return (size_t)1 << pop_bits; }
 
 hipError_t launch_cells_settle(uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                               unsigned long long* stats, hipStream_t st, int32_t presence) {
+                               unsigned long long* stats, hipStream_t st, int32_t presence, const uint64_t* pw, const uint8_t* ps) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(cells_settle_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, k, lbits, both, keys, counts, n, stats, presence);
+    hipLaunchKernelGGL(cells_settle_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, k, lbits, both, keys, counts, n, stats, presence, RecProbes{pw, ps});
     return hipGetLastError();
 }
 
 hipError_t launch_cells_stash(const uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                              uint4* stash, uint32_t stash_mask, hipStream_t st, int32_t presence) {
+                              uint4* stash, uint32_t stash_mask, hipStream_t st, int32_t presence, const uint64_t* pw, const uint8_t* ps) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(cells_stash_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, k, lbits, both, keys, counts, n, stash,
-                       stash_mask, presence);
+                       stash_mask, presence, RecProbes{pw, ps});
     return hipGetLastError();
 }
 
@@ -2339,10 +2447,10 @@ hipError_t launch_cohort_votes(const uint64_t* keys, uint32_t* counts, int64_t n
 }
 
 hipError_t launch_cohort_fill(TableView tv, int32_t k, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                              int32_t sample, uint16_t* cell_counts, uint16_t* stash_counts, hipStream_t st) {
+                              int32_t sample, uint16_t* cell_counts, uint16_t* stash_counts, hipStream_t st, const uint64_t* pw, const uint8_t* ps) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(cohort_fill_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, tv, k, both, keys, counts, n, sample,
-                       cell_counts, stash_counts);
+                       cell_counts, stash_counts, RecProbes{pw, ps});
     return hipGetLastError();
 }
 

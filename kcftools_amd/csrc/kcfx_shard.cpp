@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -268,55 +269,72 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
             for (int32_t w = sg.w_lo; w < sg.w_hi; ++w) q += std::max<int64_t>(0, (int64_t)win_len[w] - kmer_length + 1);
             return std::max<int64_t>(1, q);
         };
-        // consecutive segments of the same sample (none in the modes above, but harmless) would reuse the handle; the loader opens
-        // one database per segment, in order, at most one ahead of the one being screened
-        std::mutex mu;
+        // The loaders open one database (or cohort table) per segment, in segment order, at most LOAD_AHEAD segments ahead of the one
+        // being screened. ONE loader by default: a load is a file streamed from the page cache through pinned buffers (~40 ms for
+        // 1.2 GB: ~30 GB/s whatever the number of reader threads) followed by the build passes on the GPU (~22 ms), and two loads
+        // in flight take exactly twice as long each -- measured, profiles/r04_notes.md: the host-side copy is the shared resource,
+        // not the GPU. KCFX_SHARD_LOADERS=1 .. 4 keeps the experiment repeatable. Cohort tables are opened one at a time
+        // (their vote table alone can take tens of GiB).
+        std::mutex mu, cohort_mu;
         std::condition_variable cv;
-        struct Loaded {                                  // what the loader hands over for a segment
+        struct Loaded {                                  // what a loader hands over for a segment
             kcfx_db* db = nullptr;                       // a sample's table, or
             kcfx_cohort* co = nullptr;                   // a group's cohort table, or
             bool one_by_one = false;                     // neither: the cohort table could not be built -- screen the group's samples singly
             std::string why;
         };
-        std::deque<Loaded> ready;
-        bool stop = false, loader_done = false;
+        std::map<size_t, Loaded> ready;                  // by segment index
+        const size_t n_segs = wk.segs.size();
+        size_t next_load = 0, next_screen = 0;           // the next segment a loader claims / the screening thread waits for
+        constexpr size_t LOAD_AHEAD = 2;
+        bool stop = false;
         int in_use = 0;                                  // databases the screening thread holds (0 or 1)
+        int loaders_alive = 0;
         int32_t load_rc = KCFX_OK;
         std::string load_error;
-        std::thread loader([&]() {
+        auto loader_body = [&]() {
             try {
-            for (size_t i = 0; i < wk.segs.size(); ++i) {
+            for (;;) {
+                size_t i;
                 {
                     std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return stop || ready.size() < 1; });
-                    if (stop) break;
+                    cv.wait(lk, [&] { return stop || load_rc != KCFX_OK || next_load >= n_segs || next_load - next_screen < LOAD_AHEAD; });
+                    if (stop || load_rc != KCFX_OK || next_load >= n_segs) break;
+                    i = next_load++;
                 }
                 const double t1 = now_s();
                 kcfx_db* db = nullptr;
                 Loaded ld;
                 // one pass of this segment's window range per database (GetVariants.java:129-159): the table is sized for that.
-                // First without the line-table fallback: a cell table that does not fit NEXT TO the database being screened
+                // First without the line-table fallback: a cell table that does not fit NEXT TO the databases already resident
                 // (two wheat-scale tables do not always fit) is worth waiting for -- the line table screens at ~0.55x the
-                // speed and its odd size defeats the block pool. Only a database that does not fit an otherwise empty
-                // device falls back.
+                // speed and its odd size defeats the block pool. When this segment is the next to be screened and nothing is
+                // being screened, it is opened again with the fallback allowed.
                 kcfx_db_opts opts;
                 opts.expected_queries = seg_queries(wk.segs[i]);
                 opts.no_fallback = 1;
                 opts.reserved = 0;
                 const char* prefix = kmc_prefixes[wk.segs[i].sample];
+                auto my_turn = [&](std::unique_lock<std::mutex>& lk) {
+                    cv.wait(lk, [&] { return stop || (in_use == 0 && next_screen == i); });
+                    return !stop;
+                };
                 int32_t rc;
                 if (wk.segs[i].n > 1) {
                     // a cohort table for the group (key table + 16 bytes of counters per cell: ~3 x a single table of the union).
-                    // If the device cannot hold it beside the one being screened: once more when that one is gone. If it cannot
+                    // If the device cannot hold it beside what is resident: once more when it is this segment's turn. If it cannot
                     // be built at all (3- / 4-byte counters, mixed strandedness, k outside 19 .. 31, too large): the group's
                     // samples are screened one by one, which is what the other modes do.
                     opts.no_fallback = 0;
-                    rc = kcfx_cohort_open(kmc_prefixes + wk.segs[i].sample, wk.segs[i].n, wk.device, &opts, &ld.co);
+                    {
+                        std::lock_guard<std::mutex> one(cohort_mu);
+                        rc = kcfx_cohort_open(kmc_prefixes + wk.segs[i].sample, wk.segs[i].n, wk.device, &opts, &ld.co);
+                    }
                     if (rc == KCFX_ERR_DEVICE) {
                         std::unique_lock<std::mutex> lk(mu);
-                        cv.wait(lk, [&] { return stop || (in_use == 0 && ready.empty()); });
-                        if (!stop) {
+                        if (my_turn(lk)) {
                             lk.unlock();
+                            std::lock_guard<std::mutex> one(cohort_mu);
                             rc = kcfx_cohort_open(kmc_prefixes + wk.segs[i].sample, wk.segs[i].n, wk.device, &opts, &ld.co);
                         }
                     }
@@ -329,8 +347,7 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
                     rc = kcfx_db_open_opts(prefix, wk.device, &opts, &db);
                     if (rc == KCFX_ERR_DEVICE) {
                         std::unique_lock<std::mutex> lk(mu);
-                        cv.wait(lk, [&] { return stop || (in_use == 0 && ready.empty()); });
-                        if (!stop) {
+                        if (my_turn(lk)) {
                             lk.unlock();
                             opts.no_fallback = 0;
                             rc = kcfx_db_open_opts(prefix, wk.device, &opts, &db);
@@ -341,43 +358,66 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
                 std::lock_guard<std::mutex> lk(mu);
                 wk.t_open += now_s() - t1;
                 if (rc) {
-                    load_rc = rc;
-                    load_error = kcfx_last_error();
+                    if (load_rc == KCFX_OK) {
+                        load_rc = rc;
+                        load_error = kcfx_last_error();
+                    }
+                    cv.notify_all();
                     break;
                 }
-                ready.push_back(ld);
+                ready[i] = ld;
                 cv.notify_all();
             }
             } catch (...) {
                 const int32_t rc = kcfx::exception_to_status("kcfx_screen_sharded (loader)");
                 std::lock_guard<std::mutex> lk(mu);
-                load_rc = rc;
-                try { load_error = kcfx_last_error(); } catch (...) {}
+                if (load_rc == KCFX_OK) {
+                    load_rc = rc;
+                    try { load_error = kcfx_last_error(); } catch (...) {}
+                }
             }
             std::lock_guard<std::mutex> lk(mu);
-            loader_done = true;
+            --loaders_alive;
             cv.notify_all();
-        });
-        // on every way out of this scope (normal, error, exception): stop the loader, join it, close what it had ready
+        };
+        int n_loaders = 1;
+        if (const char* e = getenv("KCFX_SHARD_LOADERS")) n_loaders = std::max(1, std::min(4, atoi(e)));
+        n_loaders = (int)std::min<size_t>((size_t)n_loaders, std::max<size_t>(n_segs, 1));
+        std::vector<std::thread> loaders;
+        // on every way out of this scope (normal, error, exception): stop the loaders, join them, close what they had ready
         struct Joiner {
-            std::thread& t;
+            std::vector<std::thread>& ts;
             std::mutex& mu;
             std::condition_variable& cv;
             bool& stop;
-            std::deque<Loaded>& ready;
+            std::map<size_t, Loaded>& ready;
             ~Joiner() {
                 {
                     std::lock_guard<std::mutex> lk(mu);
                     stop = true;
                     cv.notify_all();
                 }
-                if (t.joinable()) t.join();
-                for (Loaded& ld : ready) {
-                    kcfx_db_close(ld.db);
-                    kcfx_cohort_close(ld.co);
+                for (auto& t : ts)
+                    if (t.joinable()) t.join();
+                for (auto& kv : ready) {
+                    kcfx_db_close(kv.second.db);
+                    kcfx_cohort_close(kv.second.co);
                 }
             }
-        } joiner{loader, mu, cv, stop, ready};
+        } joiner{loaders, mu, cv, stop, ready};
+        loaders.reserve((size_t)n_loaders);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            loaders_alive = n_loaders;
+        }
+        for (int t = 0; t < n_loaders; ++t) {
+            try {
+                loaders.emplace_back(loader_body);
+            } catch (...) {                              // (a thread that could not be started: the others carry on)
+                std::lock_guard<std::mutex> lk(mu);
+                --loaders_alive;
+            }
+        }
         for (size_t i = 0; i < wk.segs.size() && wk.rc == KCFX_OK; ++i) {
             const Segment& sg = wk.segs[i];
             if (int32_t rc = ref_for(sg.w_lo, sg.w_hi)) {      // (beside the loader's first open)
@@ -388,16 +428,17 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
             {
                 const double t1 = now_s();
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return !ready.empty() || loader_done; });
+                cv.wait(lk, [&] { return ready.count(i) != 0 || load_rc != KCFX_OK || loaders_alive == 0; });
                 wk.t_wait += now_s() - t1;
-                if (ready.empty()) {                    // the loader failed
+                if (ready.count(i) == 0) {              // a loader failed (or none could be started)
                     wk.rc = load_rc ? load_rc : KCFX_ERR_DEVICE;
-                    wk.error = load_error;
+                    wk.error = load_rc ? load_error : "could not start a loader thread";
                     break;
                 }
-                ld = ready.front();
-                ready.pop_front();
+                ld = ready[i];
+                ready.erase(i);
                 in_use = 1;
+                next_screen = i + 1;
                 cv.notify_all();
             }
             const double t1 = now_s();

@@ -249,6 +249,21 @@ void harness_cell_second_line(uint32_t line, uint32_t sh, uint32_t w, uint32_t r
     out[2] = q.w;
     out[3] = q.r;
 }
+// out[0..3] = (line, sh, w, r) of the third-line probe; returns 0 when the table has no third lines
+int harness_cell_third_line(uint32_t line, uint32_t sh, uint32_t w, uint32_t r, int k, int lbits, int both, uint32_t* out) {
+    if (!cell_has_third(lbits, both != 0)) return 0;
+    CellProbe p;
+    p.line = line;
+    p.sh = sh;
+    p.w = w;
+    p.r = r;
+    const CellProbe q = cell_third_line(p, lbits, both != 0, cell_nw(k));
+    out[0] = q.line;
+    out[1] = q.sh;
+    out[2] = q.w;
+    out[3] = q.r;
+    return 1;
+}
 uint32_t harness_cell_rmask(int lbits, int both) { return cell_rmask(lbits, both != 0); }
 int harness_alt_free_max_w(void) { return CELL_ALT_FREE_MAX_W; }
 uint64_t harness_revcomp_word(uint64_t x, int len) { return revcomp_word(x, len); }

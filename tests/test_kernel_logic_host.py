@@ -55,6 +55,8 @@ def harness():
     L.harness_cell_second_line.restype = None
     L.harness_cell_rmask.argtypes = [C.c_int, C.c_int]
     L.harness_cell_rmask.restype = C.c_uint32
+    L.harness_cell_third_line.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.harness_cell_third_line.restype = C.c_int
     L.harness_plan_strips.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.harness_anchor_reference.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
     return L
@@ -275,6 +277,7 @@ def test_cell_table_build_side_covers_query_side(harness, oracle):
         else:                                          # a forward-only database may hold a k-mer AND its reverse complement
             canon = np.unique(np.concatenate([lst[:m], synth.revcomp(lst[:m], k)]))
         seen, seen_alt, seen_2nd = {}, {}, {}
+        thirds, seconds = set(), set()
         W = k - 15
         # (free-cell second choices are a build-time option, retired by default: CELL_ALT_FREE_MAX_W = 0)
         free_scheme = k - 15 <= harness.harness_alt_free_max_w() and lbits - (17 if both else 18) >= 4
@@ -306,6 +309,19 @@ def test_cell_table_build_side_covers_query_side(harness, oracle):
                 assert both or (r2 & 0x4000) == (r & 0x4000)             # forward-only: the strand mark travels with the entry
                 second = (l2, sh2, w2, r2)
                 assert seen_2nd.setdefault(second, int(c)) == int(c), (k, lbits, hex(int(c)), hex(seen_2nd[second]))
+                # third-line entries (tables with >= 3 spare r bits): line and r from a bijection of the minimizer that the flank's
+                # bases next to it select; marked ALT and the top spare bit, so never a first-choice or second-line entry; injective
+                has3 = harness.harness_cell_third_line(line, sh, w, r, k, lbits, both, q4.ctypes.data)
+                assert bool(has3) == (lbits - (17 if both else 18) >= 3)
+                if has3:
+                    l3, sh3, w3, r3 = (int(x) for x in q4)
+                    third_mark = 0x4000 if both else 0x2000
+                    assert (sh3, w3) == (sh, w) and r3 & 0x8000 and r3 & third_mark and r3 & ~rmask == 0 and l3 < (1 << lbits)
+                    assert r2 & third_mark == 0 and r & third_mark == 0
+                    third = (l3, sh3, w3, r3)
+                    assert seen_2nd.setdefault(third, int(c)) == int(c), (k, lbits, hex(int(c)))
+                    thirds.add(l3)
+                    seconds.add(l2)
 
 
 def _planner_text(rng):
