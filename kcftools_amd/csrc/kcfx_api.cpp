@@ -125,6 +125,7 @@ struct kcfx_db {
     int32_t alloc_rc = KCFX_OK;          // written by alloc_thread, read after the join
     std::string alloc_error;
     bool alloc_oom = false;
+    bool table_arrived = false;          // table_ready() has succeeded: a later device error is not about the table's size
     int32_t fmt = FORMAT_LINES;          // FORMAT_CELLS: d_lines holds 1 << lbits cell lines, d_stash the overflow k-mers
     int32_t lbits = 0;
     uint4* d_stash = nullptr;
@@ -272,7 +273,7 @@ bool cells_eligible(const kcfx_db* db, int32_t counter_size) {
 
 // 2^lbits lines of 16 cells. The sparser the table the fewer k-mers find their cell taken and go to the stash (bench
 // workload, 150 M k-mers: 9.7 % at 2^26 lines, 6.2 % at 2^27), and every stash lookup is a random 16-byte fetch of its own:
-// aim at ~0.075 k-mers per cell while that stays under 48 GiB and 50 % of the free memory, else halve down to ~1 per cell.
+// aim at ~0.075 k-mers per cell while that stays under 50 % of the free memory, else halve down to ~1 per cell.
 // KCFX_TABLE_LBITS overrides.
 // Memory against speed (profiles/r03_density.csv, bench workload, 150 M k-mers): 0.07 / 0.14 / 0.28 / 0.56 k-mers per cell =
 // 17.4 / 9.1 / 5.4 / 4.3 GB = 1.00 / 1.00 / 1.21 / 1.57 x the screening time per k-mer (round 4, same box: 0.0844 / 0.0841 /
@@ -288,12 +289,18 @@ int32_t cells_lbits(int64_t n_keys, int32_t k, bool both, int64_t expected_queri
     const char* s = getenv("KCFX_TABLE_LBITS");
     if (s && atoi(s) >= lmin && atoi(s) <= cap) return atoi(s);
     const size_t free_b = free_device_bytes();
-    const double room = std::min(48.0 * (double)(1ull << 30), 0.5 * (double)free_b);
+    // A table above 48 GiB is halved while that leaves it at <= ~0.5 k-mers per cell (the 2.1 G-k-mer test database: 2^28 lines), and
+    // beyond that only when it does not fit half of the free memory: a database of billions of GENOMIC k-mers needs the lines --
+    // at ~1 per cell a quarter of it lives in the stash, at ~0.5 a twelfth (profiles/r04_notes.md) -- and a second database that
+    // does not fit beside it is waited for by the sharded loader (kcfx_shard.cpp).
+    const double soft_cap = 48.0 * (double)(1ull << 30), hard_cap = 0.5 * (double)free_b;
     (void)expected_queries;                               // (one density for every handle since round 4, see above)
     const double density = 0.075;
     int32_t L = lmin;
     while (L < cap && 16.0 * (double)(1ull << L) * density < (double)n_keys) ++L;
-    while (L > lmin && (double)(1ull << L) * line_footprint > room && 16.0 * (double)(1ull << (L - 1)) >= (double)n_keys) --L;
+    auto bytes = [&](int32_t l) { return (double)(1ull << l) * line_footprint; };
+    while (L > lmin && bytes(L) > soft_cap && 16.0 * (double)(1ull << (L - 1)) * 0.5 >= (double)n_keys) --L;
+    while (L > lmin && bytes(L) > hard_cap && 16.0 * (double)(1ull << (L - 1)) >= (double)n_keys) --L;
     return L;
 }
 
@@ -301,6 +308,7 @@ int32_t cells_lbits(int64_t n_keys, int32_t k, bool both, int64_t expected_queri
 int32_t table_ready(kcfx_db* db) {
     if (db->alloc_thread.joinable()) db->alloc_thread.join();
     if (db->alloc_rc != KCFX_OK) return fail(db->alloc_rc, db->alloc_error);
+    db->table_arrived = true;
     return KCFX_OK;
 }
 
@@ -338,6 +346,7 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys, bool deferred = false) {
     if (db->lbits_cap > 0) L0 = std::min(L0, db->lbits_cap);
     db->alloc_rc = KCFX_OK;
     db->alloc_oom = false;
+    db->table_arrived = false;
     if (deferred && L0 >= cell_lbits_min(both) && (double)n_keys <= 16.0 * (double)(1ull << L0)) {
         // the policy's size, allocated and cleared beside the file streaming; if it does not fit, kcfx_db_open starts over
         // with denser tables, synchronously
@@ -875,8 +884,10 @@ int32_t kcfx_db_open_opts(const char* kmc_prefix, int32_t device, const kcfx_db_
     // (the allocation thread may still be running when the streaming failed first -- an I/O error, or the decoded arrays lost the
     // race for the memory to the table: join it before its outcome is read)
     if (rc && db->alloc_thread.joinable()) db->alloc_thread.join();
+    // (a denser table helps when the table itself did not fit, or when the streaming's buffers lost the race for the memory to
+    // it -- not when a later step failed: a stash that does not fit only grows with a denser table)
     if (rc == KCFX_ERR_DEVICE && db->fmt == FORMAT_CELLS && db->lbits - 1 >= cell_lbits_min(db->info.both_strands != 0) &&
-        (db->alloc_oom || db->alloc_rc == KCFX_OK)) {
+        (db->alloc_oom || (db->alloc_rc == KCFX_OK && !db->table_arrived))) {
         // the policy's table did not fit next to what else lives on the device: denser cell tables, allocated synchronously
         const int32_t cap = db->lbits - 1;
         table_release(db);

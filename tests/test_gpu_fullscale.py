@@ -455,9 +455,10 @@ def test_wheat_scale_genomic_database(oracle, monkeypatch):
     """A database at wheat scale made of GENOMIC k-mers (runs that share minimizers, as a real `kmc` count of a 14.5 Gb genome is),
     not of random ones: one non-tiled synthetic genome as large as this box's memory and scratch space allow (9.1 Gb = 8 G distinct
     31-mers where the cgroup grants ~300 GB; the size that ran is printed), its mutated sample counted into ONE KMC database (64 GB
-    .kmc_suf), opened (a) as the size policy opens it -- capped at 48 GiB of table, i.e. ~0.9 k-mers per cell -- and (b) at twice the
-    lines, and the genome's own 50 kb tiling screened against both. Both tables must give identical records on every window,
-    >= 10 000 sampled windows must equal the oracle's, and the log line carries what the review asked for: stash share, second- and
+    .kmc_suf), opened (a) as the size policy opens it -- ~0.5 k-mers per cell, 128 GiB of lines for 8 G k-mers -- and (b) at half the
+    lines (~1 per cell, which a quarter of the k-mers pays for with a place in the stash: allowed to fail on the stash's size), and
+    the genome's own 50 kb tiling screened against both. Both tables must give identical records on every window, >= 10 000
+    sampled windows must equal the oracle's, and the log line carries what the review asked for: stash share, second- and
     third-line share, open time, k-mers/s of the pass. (KCFX_WHEAT=<bases> overrides the size; the inputs live in /dev/shm when
     the scratch disk is too small and are removed afterwards.)"""
     import shutil
@@ -531,12 +532,13 @@ def test_wheat_scale_genomic_database(oracle, monkeypatch):
         assert n > 0.97 * len(text)
         hit = res_policy["obs"].sum() / n
         assert 0.5 < hit < 0.85                                  # the sample is the genome at 1 % divergence with 10 % deleted
-        res_wide, b = None, None
-        free = torch.cuda.mem_get_info()[0]
-        if 2 * a["lines"] * 128 * 1.25 < free:
-            res_wide, b = open_and_screen(int(np.log2(a["lines"])) + 1)
+        res_dense, b, b_err = None, None, None
+        try:
+            res_dense, b = open_and_screen(int(np.log2(a["lines"])) - 1)
             for f in FIELDS:
-                assert np.array_equal(res_wide[f], res_policy[f]), f
+                assert np.array_equal(res_dense[f], res_policy[f]), f
+        except engine.KcfxError as exc:                          # (a stash of two billion k-mers may not fit: said, not hidden)
+            b_err = str(exc)
         # >= 10 000 sampled windows against the oracle (the C restatement bisects the 64 GB file itself)
         rng = np.random.default_rng(11)
         idx = np.unique(np.concatenate([rng.choice(len(starts), min(10_000, len(starts)), replace=False), [0, len(starts) - 1]]))
@@ -553,15 +555,13 @@ def test_wheat_scale_genomic_database(oracle, monkeypatch):
                     f"{gk / x['kernel_ms'] * 1e3:.0f} G k-mers/s")
         line = (f"wheat-scale genomic database ({why}): {len(text) / 1e9:.2f} Gb non-tiled genome, {n_db / 1e9:.2f} G distinct 31-mers of its sample "
                 f"({os.path.getsize(prefix + '.kmc_suf') / 1e9:.0f} GB .kmc_suf in {base}, generated in {t_gen:.0f} s), {len(starts)} windows of 50 kb, hit rate "
-                f"{hit:.3f}; size policy: {show(a)}" + (f"; twice the lines: {show(b)}, every window identical" if b else "") +
+                f"{hit:.3f}; size policy: {show(a)}" + (f"; half the lines: {show(b)}, every window identical" if b else f"; half the lines: {b_err}") +
                 f"; oracle on {len(idx)} sampled windows {t_oracle:.0f} s; test wall {time.time() - t_all:.0f} s")
         print(line)
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "wheat_genomic.log"), "a") as fh:
             fh.write(line + "\n")
         # what the third lines are for: a genomic database at ~1 k-mer per cell used to leave a quarter to a third of itself in the stash
-        assert a["stash"] < 0.25
-        if b:
-            assert b["stash"] < 0.10
+        assert a["stash"] < 0.12 and a["per_cell"] < 0.6
     finally:
         shutil.rmtree(d, ignore_errors=True)

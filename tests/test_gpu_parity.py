@@ -341,28 +341,31 @@ def test_stash_budget_and_line_table_fallback(oracle, tmp_path, monkeypatch, cap
 
 
 def test_db_open_opts_size_the_table_for_the_expected_look_ups(oracle, tmp_path, monkeypatch):
-    """kcfx_db_open_opts: a handle that will serve one pass (the command-line driver, kcfx_screen_sharded's loader) gets a
-    table ~4x denser than the default sized for many passes -- same results; the allocation thread that runs beside the file
-    streaming and the synchronous path (KCFX_SYNC_ALLOC) build the same table; no_fallback turns the silent line-table
-    rebuild into KCFX_ERR_DEVICE."""
+    """kcfx_db_open_opts: since round 4 every handle gets the same table size whatever expected_queries says (a handle that will
+    serve one pass -- the command-line driver, kcfx_screen_sharded's loader -- only keeps the cheaper crowding counters of the
+    build); a denser table (KCFX_TABLE_LBITS) gives the same results; the allocation thread that runs beside the file streaming
+    and the synchronous path (KCFX_SYNC_ALLOC) build the same table; no_fallback turns the silent line-table rebuild into
+    KCFX_ERR_DEVICE."""
     k = 31
     ref = synth.random_reference(600_000, 21)
     prefix, kmers, counts, prm = make_db(tmp_path, "opts", ref, 22, k=31, p=7, cs=2, m=9, bins=32, noise=1_500_000)
     s, e = engine.windows(len(ref), 10_000, 0, k)
     want = oracle.OracleDb(prefix).screen(ref, s, e - s, 1, threads=8)
     sparse = engine.KmcDb.open(prefix)
-    dense = engine.KmcDb.open(prefix, expected_queries=int((e - s - k + 1).sum()))
+    one_pass = engine.KmcDb.open(prefix, expected_queries=int((e - s - k + 1).sum()))
     many = engine.KmcDb.open(prefix, expected_queries=10**12)
-    assert sparse.info.table_format == dense.info.table_format == 1
-    assert many.info.table_lines == sparse.info.table_lines
-    assert dense.info.table_lines * 2 <= sparse.info.table_lines
-    assert 16 * dense.info.table_lines >= dense.info.total_kmers
-    for db, name in ((sparse, "sparse"), (dense, "dense"), (many, "many")):
+    assert sparse.info.table_format == one_pass.info.table_format == 1
+    assert many.info.table_lines == sparse.info.table_lines == one_pass.info.table_lines
+    monkeypatch.setenv("KCFX_TABLE_LBITS", str(int(np.log2(sparse.info.table_lines)) - 2))
+    dense = engine.KmcDb.open(prefix, expected_queries=1000)
+    monkeypatch.delenv("KCFX_TABLE_LBITS")
+    assert dense.info.table_lines * 4 == sparse.info.table_lines and 16 * dense.info.table_lines >= dense.info.total_kmers
+    for db, name in ((sparse, "sparse"), (one_pass, "one pass"), (dense, "dense"), (many, "many")):
         assert_same(db.screen(ref, s, e - s, 1), want, name)
     monkeypatch.setenv("KCFX_SYNC_ALLOC", "1")
     sync = engine.KmcDb.open(prefix, expected_queries=1000)
     assert (sync.info.table_lines, sync.info.stash_kmers, sync.info.second_choice_kmers) == \
-        (dense.info.table_lines, dense.info.stash_kmers, dense.info.second_choice_kmers)
+        (one_pass.info.table_lines, one_pass.info.stash_kmers, one_pass.info.second_choice_kmers)
     assert_same(sync.screen(ref, s, e - s, 1), want, "sync alloc")
     monkeypatch.delenv("KCFX_SYNC_ALLOC")
     monkeypatch.setenv("KCFX_TABLE_LBITS", "17")
