@@ -120,6 +120,7 @@ struct kcfx_db {
     // kcfx_db_open allocates and clears the cell table (up to 48 GiB: hipMalloc alone can take a second when the driver scrubs
     // the block first) on a thread of its own while the .kmc_suf is read, decoded and counted: nothing touches the lines
     // before the first bidding pass, which waits for it (table_ready)
+    int32_t ext = 0;                     // FORMAT_CELLS: an extended table (TableView::ext)
     int32_t line_footprint = LINE_BYTES;   // bytes per table line the handle will hold in all (a cohort's key table: + 256 B of counters)
     std::thread alloc_thread;
     int32_t alloc_rc = KCFX_OK;          // written by alloc_thread, read after the join
@@ -134,7 +135,7 @@ struct kcfx_db {
     uint32_t* d_pop = nullptr;               // FORMAT_CELLS build scratch: k-mers per minimizer (freed after the build)
     int32_t pop_bits = 32;                   // 2^pop_bits byte counters: 32 = one per minimizer, lbits + 2 when 4 GiB cannot be had
     hipStream_t stream = nullptr;
-    TableView view() const { return TableView{d_lines, n_lines, wide, mode, mm_len, fmt, lbits, stash_mask, d_stash, generic, info.both_strands}; }
+    TableView view() const { return TableView{d_lines, n_lines, wide, mode, mm_len, fmt, lbits, stash_mask, d_stash, generic, info.both_strands, ext}; }
 };
 
 struct kcfx_ref {
@@ -340,6 +341,10 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys, bool deferred = false) {
     db->info.table_mode = MODE_MINIMIZER;
     db->info.minimizer_length = db->mm_len;
     db->info.table_format = FORMAT_CELLS;
+    // Extended tables (kcfx_device.h: cell_first_ext) from ~0.5 G k-mers on: that is where the runs of a genome start to outnumber
+    // the open-syncmer 16-mers their minimizers concentrate on (profiles/r04_notes.md). KCFX_TABLE_EXT=0 / 1 overrides (tests, A/B).
+    db->ext = n_keys >= 500000000ll ? 1 : 0;
+    if (const char* xe = getenv("KCFX_TABLE_EXT")) db->ext = atoi(xe) != 0;
     hipError_t e = hipErrorOutOfMemory;
     const bool both = db->info.both_strands != 0;
     int32_t L0 = cells_lbits(n_keys, db->info.kmer_length, both, db->expected_queries, db->line_footprint);
@@ -651,11 +656,11 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
             uint64_t* pw = d_pw ? d_pw + (keys - d_keys) : nullptr;
             uint8_t* ps = d_ps ? d_ps + (keys - d_keys) : nullptr;
             if (phase == 0)
-                return pw ? launch_cells_resolve(db->d_pop, db->pop_bits, kk, db->lbits, db->info.both_strands, keys, counts, n, pw, ps, db->stream)
-                          : launch_cells_count(db->d_pop, db->pop_bits, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream);
-            if (phase == 1 || phase == 2) return launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, phase == 1 ? 1 : 0, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream, 0, pw, ps);
-            if (phase == 3) return launch_cells_settle(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stats, db->stream, 0, pw, ps);
-            return launch_cells_stash(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stash, db->stash_mask, db->stream, 0, pw, ps);
+                return pw ? launch_cells_resolve(db->d_pop, db->pop_bits, kk, db->lbits, db->info.both_strands, keys, counts, n, pw, ps, db->stream, db->ext)
+                          : launch_cells_count(db->d_pop, db->pop_bits, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream, 0, db->ext);
+            if (phase == 1 || phase == 2) return launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, phase == 1 ? 1 : 0, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream, 0, pw, ps, db->ext);
+            if (phase == 3) return launch_cells_settle(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stats, db->stream, 0, pw, ps, db->ext);
+            return launch_cells_stash(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stash, db->stash_mask, db->stream, 0, pw, ps, db->ext);
         }
         if (phase == 0) return launch_table_count(db->d_lines, db->view(), h.k, keys, n, db->stream);
         return launch_table_insert(db->d_lines, db->view(), h.k, keys, counts, n, db->stream);
@@ -967,13 +972,13 @@ int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, 
         int32_t rc = table_alloc(db, n, counter_size, allow_cells);
         if (rc || n == 0) return rc;
         if (db->fmt == FORMAT_CELLS) {
-            if ((e = launch_cells_count(db->d_pop, db->pop_bits, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream)) != hipSuccess ||
-                (e = launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, 1, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream)) != hipSuccess ||
-                (e = launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, 0, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream)) != hipSuccess ||
-                (e = launch_cells_settle(db->d_lines, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->d_stats, db->stream)) != hipSuccess)
+            if ((e = launch_cells_count(db->d_pop, db->pop_bits, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream, 0, db->ext)) != hipSuccess ||
+                (e = launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, 1, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream, 0, nullptr, nullptr, db->ext)) != hipSuccess ||
+                (e = launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, 0, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream, 0, nullptr, nullptr, db->ext)) != hipSuccess ||
+                (e = launch_cells_settle(db->d_lines, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->d_stats, db->stream, 0, nullptr, nullptr, db->ext)) != hipSuccess)
                 return hip_fail(e, "kcfx_db_build insert");
             if ((rc = cells_stash_alloc(db))) return rc;
-            if ((e = launch_cells_stash(db->d_lines, db->info.kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->d_stash, db->stash_mask, db->stream)) != hipSuccess ||
+            if ((e = launch_cells_stash(db->d_lines, db->info.kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->d_stash, db->stash_mask, db->stream, 0, nullptr, nullptr, db->ext)) != hipSuccess ||
                 (e = hipStreamSynchronize(db->stream)) != hipSuccess)
                 return hip_fail(e, "kcfx_db_build stash");
         } else {
@@ -1410,11 +1415,11 @@ int32_t kcfx_cohort_open(const char* const* kmc_prefixes, int32_t n_samples, int
             uint8_t* ps = hold.d_ps ? hold.d_ps + first : nullptr;
             hipError_t e2 = hipSuccess;
             if (phase == 0)
-                e2 = pw ? launch_cells_resolve(db->d_pop, db->pop_bits, k, db->lbits, both, kk, cc, n, pw, ps, db->stream)
-                        : launch_cells_count(db->d_pop, db->pop_bits, k, db->lbits, both, kk, cc, n, db->stream, 1);
-            else if (phase == 1 || phase == 2) e2 = launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, phase == 1 ? 1 : 0, k, db->lbits, both, kk, cc, n, db->stream, 1, pw, ps);
-            else if (phase == 3) e2 = launch_cells_settle(db->d_lines, k, db->lbits, both, kk, cc, n, db->d_stats, db->stream, 1, pw, ps);
-            else e2 = launch_cells_stash(db->d_lines, k, db->lbits, both, kk, cc, n, db->d_stash, db->stash_mask, db->stream, 1, pw, ps);
+                e2 = pw ? launch_cells_resolve(db->d_pop, db->pop_bits, k, db->lbits, both, kk, cc, n, pw, ps, db->stream, db->ext)
+                        : launch_cells_count(db->d_pop, db->pop_bits, k, db->lbits, both, kk, cc, n, db->stream, 1, db->ext);
+            else if (phase == 1 || phase == 2) e2 = launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, phase == 1 ? 1 : 0, k, db->lbits, both, kk, cc, n, db->stream, 1, pw, ps, db->ext);
+            else if (phase == 3) e2 = launch_cells_settle(db->d_lines, k, db->lbits, both, kk, cc, n, db->d_stats, db->stream, 1, pw, ps, db->ext);
+            else e2 = launch_cells_stash(db->d_lines, k, db->lbits, both, kk, cc, n, db->d_stash, db->stash_mask, db->stream, 1, pw, ps, db->ext);
             if (e2 != hipSuccess) return e2;
         }
         return hipSuccess;

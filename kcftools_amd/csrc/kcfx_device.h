@@ -415,6 +415,29 @@ KCFX_HD CellProbe cell_third_line(const CellProbe& p, int32_t lbits, bool both, 
     return q;
 }
 
+// EXTENDED TABLES (TableView::ext; round 4, databases of >= ~0.5 G k-mers). The order puts open syncmers first, so the
+// minimizers of a genome concentrate on ~1 / 11 of the 2^31 canonical 16-mers: a count of a 9 Gb genome has ~780 M runs over ~195 M
+// preferred 16-mers, FOUR loci per minimizer -- and the first-choice line, a function of the minimizer alone, holds one of them:
+// two thirds of such a database sat outside its first-choice cells (profiles/r04_notes.md). In an extended table the line and r
+// of the FIRST choice (and with them of the second and third, which are derived from it) come from a bijection of G32 that the
+// flank selects: the three bases in front of the minimizer for a k-mer that has them (offset >= 3: thirteen of the sixteen
+// offsets), else the three behind it. A run costs ~1.3 line requests instead of 1, its loci no longer meet. (sh, w) are part of
+// what a cell compares, so (line, r, sh, w) still identify the k-mer exactly.
+KCFX_HD uint32_t cell_ext_select(uint32_t w, uint32_t sh) {
+    const bool before = sh >= 6u;
+    const uint32_t near6 = before ? (w >> (32u - sh)) & 63u : (w >> (26u - sh)) & 63u;
+    return (((near6 << 1) | (before ? 1u : 0u)) + 1u) * 0x9E3779B1u;
+}
+KCFX_HD uint32_t cell_g32_ext(uint32_t g, uint32_t w, uint32_t sh) { return cell_g32b(g ^ cell_ext_select(w, sh)); }
+KCFX_HD CellProbe cell_first_ext(const CellProbe& p, int32_t lbits) {
+    const uint32_t idm = 0xFFFFFFFFu >> lbits;
+    const uint32_t gx = cell_g32_ext((p.line << (32 - lbits)) | (p.r & idm), p.w, p.sh);
+    CellProbe q = p;
+    q.line = gx >> (32 - lbits);
+    q.r = (gx & idm) | (p.r & ~idm);
+    return q;
+}
+
 // Query side, one lane: F / R = the k-mer as the text reads it and its reverse complement, mn = the tagged minimum over
 // the k-mer's 16 M-mers, lane = this lane's position label base (order27_tagged was fed (lane + offset) & 15).
 // (lane2 = 2 * position, what order27_label2 was fed -- mod 32 is enough)
@@ -453,8 +476,9 @@ KCFX_HD CellProbe cell_probe_of(uint64_t F, uint64_t R, uint32_t mn, uint32_t la
 constexpr int CELL_MAX_CANDS = 32;
 // f(const CellProbe&, int index) for every such cell, in a fixed order; returns how many. (A visitor, not an array: the
 // kernels that walk a k-mer's cells keep nothing in private memory.)
+// (ext: the table is an extended one -- cell_first_ext is applied to every probe)
 template <class F>
-KCFX_HD int cells_visit(uint64_t C, int32_t k, int32_t lbits, bool both, F&& f) {
+KCFX_HD int cells_visit(uint64_t C, int32_t k, int32_t lbits, bool both, bool ext, F&& f) {
     const int M = cell_mlen(k), W = cell_nw(k);
     const uint64_t Rc = revcomp_word(C, k);
     // the k-mer's k - 5 canonical 6-mer hashes, once (the 6-mer at base t of C is the reverse complement of the one at base
@@ -497,15 +521,15 @@ KCFX_HD int cells_visit(uint64_t C, int32_t k, int32_t lbits, bool both, F&& f) 
             p.sh = sh;
             p.line = g >> (32 - lbits);
             p.r = (g & (0xFFFFFFFFu >> lbits)) | ((!both && strand == 1) ? CELL_R_FLIP : 0u);
-            f(p, n);
+            f(ext ? cell_first_ext(p, lbits) : p, n);
             ++n;
         }
     }
     return n;
 }
 // the same into an array of CELL_MAX_CANDS (host-side checks)
-KCFX_HD int cells_of_key(uint64_t C, int32_t k, int32_t lbits, CellProbe* out, bool both) {
-    return cells_visit(C, k, lbits, both, [&](const CellProbe& p, int i) { out[i] = p; });
+KCFX_HD int cells_of_key(uint64_t C, int32_t k, int32_t lbits, CellProbe* out, bool both, bool ext = false) {
+    return cells_visit(C, k, lbits, both, ext, [&](const CellProbe& p, int i) { out[i] = p; });
 }
 
 KCFX_HD uint32_t stash_slot(uint64_t key, uint32_t mask) { return hash32(key) & mask; }

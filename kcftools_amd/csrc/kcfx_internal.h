@@ -100,6 +100,7 @@ struct TableView {
     const uint4* stash;
     int32_t generic;     // screen with the general kernel whatever k / M (test and A/B hook, fixed when the handle is made)
     int32_t both;        // the database is canonical (both strands); 0: k-mers are looked up as the text reads them
+    int32_t ext;         // FORMAT_CELLS: an extended table -- the first-choice line depends on the flank too (cell_first_ext, kcfx_device.h)
 };
 
 // ----------------------------------------------------------------------------------------------------
@@ -288,17 +289,17 @@ size_t cells_pop_bytes(int32_t pop_bits);          // pop_bits = 32 (one counter
 // (both = the database is canonical; see CELL_R_FLIP in kcfx_device.h for what a forward-only one changes)
 // (presence != 0: every non-zero counter is stored as 1 -- the key table of a cohort, kcfx_cohort_open)
 hipError_t launch_cells_count(uint32_t* pop32, int32_t pop_bits, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                              hipStream_t st, int32_t presence = 0);
+                              hipStream_t st, int32_t presence = 0, int32_t ext = 0);
 // (pw / ps: the cells of the records as launch_cells_resolve kept them -- 8 + 1 bytes per record, see RecProbes in kcfx_kernels.hip --
 // or null: the pass derives them itself with cells_visit. launch_cells_resolve = launch_cells_count + keeping them.)
 hipError_t launch_cells_resolve(uint32_t* pop32, int32_t pop_bits, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                                uint64_t* pw, uint8_t* ps, hipStream_t st);
+                                uint64_t* pw, uint8_t* ps, hipStream_t st, int32_t ext = 0);
 hipError_t launch_cells_insert(uint8_t* lines, const uint32_t* pop32, int32_t pop_bits, int32_t cls, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys,
-                               const uint32_t* counts, int64_t n, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr);
+                               const uint32_t* counts, int64_t n, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr, int32_t ext = 0);
 hipError_t launch_cells_settle(uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                               unsigned long long* stats, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr);
+                               unsigned long long* stats, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr, int32_t ext = 0);
 hipError_t launch_cells_stash(const uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                              uint4* stash, uint32_t stash_mask, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr);
+                              uint4* stash, uint32_t stash_mask, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr, int32_t ext = 0);
 // cohort tables: one sample's counters into the finished key table; S samples screened in one pass (bits / count_sums laid out
 // per sample as launch_screen_multi's: sample s at bits + s * n_tiles * TILE_BITS_U64, count_sums + s * n_tiles)
 // phase 0: every record votes for its k-mer in `votes` (2^n slots of 16 bytes, all bytes 0xFF); phase 1: the bid rank of every

@@ -232,12 +232,12 @@ __device__ __forceinline__ uint64_t cell_sub_bucket(const CellProbe& p, int32_t 
 // Pass 0: k-mers per sub-bucket, one byte each (a byte that overflows spills into its neighbour: the classes are a
 // heuristic, see above)
 __global__ void cells_count_kernel(uint32_t* pop32, int32_t pop_bits, int32_t k, int32_t lbits, int32_t both, const uint64_t* __restrict__ keys,
-                                   const uint32_t* __restrict__ counts, int64_t n, int32_t presence) {
+                                   const uint32_t* __restrict__ counts, int64_t n, int32_t presence, int32_t ext) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         if (counts[i] == 0) continue;                           // (presence mode: the same test)
-        cells_visit(keys[i], k, lbits, both != 0, [&](const CellProbe& p, int a) {
+        cells_visit(keys[i], k, lbits, both != 0, ext != 0, [&](const CellProbe& p, int a) {
             if (a != 0) return;                                 // the first of its cells names the k-mer's sub-bucket
             const uint64_t sub = cell_sub_bucket(p, lbits, pop_bits);
             atomicAdd(&pop32[sub >> 2], 1u << (8 * (uint32_t)(sub & 3)));
@@ -255,6 +255,7 @@ __global__ void cells_count_kernel(uint32_t* pop32, int32_t pop_bits, int32_t k,
 struct RecProbes {
     const uint64_t* pw;     // G32 | flank << 32        (null: nothing was kept -- every pass derives the cells itself)
     const uint8_t* ps;      // cell index | REC_MULTI | REC_FLIP
+    int32_t ext;            // the table is an extended one (what is kept is the extended G32: cell_first_ext)
 };
 constexpr uint8_t REC_MULTI = 0x10, REC_FLIP = 0x20;
 template <class F>
@@ -273,12 +274,12 @@ __device__ __forceinline__ int record_cells(const RecProbes& rp, int64_t i, uint
             return 1;
         }
     }
-    return cells_visit(key, k, lbits, both, f);
+    return cells_visit(key, k, lbits, both, rp.ext != 0, f);
 }
 
 // Pass 0 when the records stay resident: cells_count_kernel + the probes kept
 __global__ void cells_resolve_kernel(uint32_t* pop32, int32_t pop_bits, int32_t k, int32_t lbits, int32_t both, const uint64_t* __restrict__ keys,
-                                     const uint32_t* __restrict__ counts, int64_t n, uint64_t* __restrict__ pw, uint8_t* __restrict__ ps) {
+                                     const uint32_t* __restrict__ counts, int64_t n, uint64_t* __restrict__ pw, uint8_t* __restrict__ ps, int32_t ext) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
@@ -288,7 +289,7 @@ __global__ void cells_resolve_kernel(uint32_t* pop32, int32_t pop_bits, int32_t 
             continue;
         }
         CellProbe first{0, 0, 0, 0};
-        const int nc = cells_visit(keys[i], k, lbits, both != 0, [&](const CellProbe& p, int a) {
+        const int nc = cells_visit(keys[i], k, lbits, both != 0, ext != 0, [&](const CellProbe& p, int a) {
             if (a == 0) first = p;
         });
         const uint64_t sub = cell_sub_bucket(first, lbits, pop_bits);
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(256) void lookup_cells_kernel(TableView tv, int32_t
         const bool both = both_i != 0;
         if ((!both || key <= revcomp_word(key, k)) && (key & ~(~0ull << (64 - 2 * k))) == 0) {
             CellProbe c0{0, 0, 0, 0};                            // any one of its cells decides: the first
-            cells_visit(key, k, tv.lbits, both, [&](const CellProbe& p, int a) {
+            cells_visit(key, k, tv.lbits, both, tv.ext != 0, [&](const CellProbe& p, int a) {
                 if (a == 0) c0 = p;
             });
             const uint8_t* line = tv.lines + (size_t)c0.line * LINE_BYTES;
@@ -1512,11 +1513,12 @@ struct PlannedWords {
 
 // cell_probe_of when the anchor byte has said where the minimizer sits (sh2 = 2 * its offset in N, fm = the flip mask)
 template <bool BOTH>
-__device__ __forceinline__ CellProbe cell_probe_planned(uint64_t N, uint32_t sh2, uint32_t fm, int32_t lbits) {
+__device__ __forceinline__ CellProbe cell_probe_planned(uint64_t N, uint32_t sh2, uint32_t fm, int32_t lbits, int32_t ext) {
     CellProbe p;
     uint32_t cm;
     p.w = cell_flank(N, sh2, 16, &cm);
-    const uint32_t g = cell_g32(cm);
+    uint32_t g = cell_g32(cm);
+    if (ext) g = cell_g32_ext(g, p.w, sh2);                 // (wave-uniform: an extended table, cell_first_ext)
     p.sh = sh2;
     p.line = g >> (32 - lbits);
     p.r = (g & (0xFFFFFFFFu >> lbits)) | (BOTH ? 0u : (fm & CELL_R_FLIP));
@@ -1526,7 +1528,7 @@ __device__ __forceinline__ CellProbe cell_probe_planned(uint64_t N, uint32_t sh2
 // A queued k-mer, derived again from the packed tile (the queue holds where it sits and its anchor bits): its probe and the
 // word the database stores it under
 template <int K, bool BOTH, class Lds>
-__device__ __forceinline__ CellProbe k31_probe_at(const Lds& sh, int q, uint32_t anc, int32_t lbits, uint64_t& key) {
+__device__ __forceinline__ CellProbe k31_probe_at(const Lds& sh, int q, uint32_t anc, int32_t lbits, int32_t ext, uint64_t& key) {
     constexpr uint32_t lo_mask = ~0u << (64 - 2 * K);
     const int b0 = 2 * q - 1;
     const uint2* p = sh.fcx + 1 + (b0 >> 5);
@@ -1536,7 +1538,7 @@ __device__ __forceinline__ CellProbe k31_probe_at(const Lds& sh, int q, uint32_t
     const uint64_t rc = u64_of(brev32(alignbit32(x.y, y.y, s)), brev32(alignbit32(y.y, z.y, s) & lo_mask)) << (64 - 2 * K);
     key = (BOTH && rc < fwd) ? rc : fwd;                    // canonical (Kmer.java:72-79), or as the text reads it (:57-65)
     const uint32_t fm = 0u - (anc & 1u);
-    return cell_probe_planned<BOTH>(fm ? rc : fwd, anc & 30u, fm, lbits);
+    return cell_probe_planned<BOTH>(fm ? rc : fwd, anc & 30u, fm, lbits, ext);
 }
 
 // The first min(qn, 64) queued k-mers -- their first-choice cell said "someone who belongs here lives elsewhere", with their filter
@@ -1551,7 +1553,7 @@ __device__ __forceinline__ int k31c_deferred_round(const TableView& tv, const Ld
     if (lane < rest) ids[lane] = i2;                        // the entries behind the batch move to the front
     if (lane < nb) {
         uint64_t key;
-        const CellProbe p = k31_probe_at<K, BOTH>(sh, pos0 + (int)(id & 0xFFFFu), id >> QUEUE_ANCHOR_SHIFT, tv.lbits, key);
+        const CellProbe p = k31_probe_at<K, BOTH>(sh, pos0 + (int)(id & 0xFFFFu), id >> QUEUE_ANCHOR_SHIFT, tv.lbits, tv.ext, key);
         const CellProbe q2 = cell_second_line(p, tv.lbits);
         const size_t cell = (size_t)q2.line * 16 + (q2.sh >> 1);
         const uint2 e = reinterpret_cast<const uint2*>(tv.lines)[cell];      // (plain: with the non-temporal hint this one is slower)
@@ -1632,7 +1634,7 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
         uint64_t N, V;
         uint32_t sh2, fm;
         words.next(w, N, sh2, fm, V);
-        cells_issue<cell_nw(K), BOTH>(tv, V, cell_probe_planned<BOTH>(N, sh2, fm, tv.lbits), sh2 | (fm & 1u), cw);
+        cells_issue<cell_nw(K), BOTH>(tv, V, cell_probe_planned<BOTH>(N, sh2, fm, tv.lbits, tv.ext), sh2 | (fm & 1u), cw);
     };
     // stage B of word w: cells matched, ballots out, stash candidates queued
     auto retire = [&](int w, const CellWord& cw) {
@@ -1783,7 +1785,7 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 
             uint64_t N;
             uint32_t sh2, fm;
             words.next(w, N, sh2, fm, V);
-            p = cell_probe_planned<BOTH>(N, sh2, fm, tv.lbits);
+            p = cell_probe_planned<BOTH>(N, sh2, fm, tv.lbits, tv.ext);
             anc = sh2 | (fm & 1u);
         }
         const bool valid = __builtin_amdgcn_inverse_ballot_w64(V);
@@ -2289,41 +2291,41 @@ hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide,
 }
 
 hipError_t launch_cells_count(uint32_t* pop32, int32_t pop_bits, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                              hipStream_t st, int32_t presence) {
+                              hipStream_t st, int32_t presence, int32_t ext) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(cells_count_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, pop32, pop_bits, k, lbits, both, keys, counts, n, presence);
+    hipLaunchKernelGGL(cells_count_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, pop32, pop_bits, k, lbits, both, keys, counts, n, presence, ext);
     return hipGetLastError();
 }
 
 hipError_t launch_cells_resolve(uint32_t* pop32, int32_t pop_bits, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                                uint64_t* pw, uint8_t* ps, hipStream_t st) {
+                                uint64_t* pw, uint8_t* ps, hipStream_t st, int32_t ext) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(cells_resolve_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, pop32, pop_bits, k, lbits, both, keys, counts, n, pw, ps);
+    hipLaunchKernelGGL(cells_resolve_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, pop32, pop_bits, k, lbits, both, keys, counts, n, pw, ps, ext);
     return hipGetLastError();
 }
 
 hipError_t launch_cells_insert(uint8_t* lines, const uint32_t* pop32, int32_t pop_bits, int32_t cls, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys,
-                               const uint32_t* counts, int64_t n, hipStream_t st, int32_t presence, const uint64_t* pw, const uint8_t* ps) {
+                               const uint32_t* counts, int64_t n, hipStream_t st, int32_t presence, const uint64_t* pw, const uint8_t* ps, int32_t ext) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(cells_insert_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, pop32, pop_bits, cls, k, lbits, both, keys, counts, n, presence,
-                       RecProbes{pw, ps});
+                       RecProbes{pw, ps, ext});
     return hipGetLastError();
 }
 
 size_t cells_pop_bytes(int32_t pop_bits) { return (size_t)1 << pop_bits; }
 
 hipError_t launch_cells_settle(uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                               unsigned long long* stats, hipStream_t st, int32_t presence, const uint64_t* pw, const uint8_t* ps) {
+                               unsigned long long* stats, hipStream_t st, int32_t presence, const uint64_t* pw, const uint8_t* ps, int32_t ext) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(cells_settle_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, k, lbits, both, keys, counts, n, stats, presence, RecProbes{pw, ps});
+    hipLaunchKernelGGL(cells_settle_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, k, lbits, both, keys, counts, n, stats, presence, RecProbes{pw, ps, ext});
     return hipGetLastError();
 }
 
 hipError_t launch_cells_stash(const uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                              uint4* stash, uint32_t stash_mask, hipStream_t st, int32_t presence, const uint64_t* pw, const uint8_t* ps) {
+                              uint4* stash, uint32_t stash_mask, hipStream_t st, int32_t presence, const uint64_t* pw, const uint8_t* ps, int32_t ext) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(cells_stash_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, k, lbits, both, keys, counts, n, stash,
-                       stash_mask, presence, RecProbes{pw, ps});
+                       stash_mask, presence, RecProbes{pw, ps, ext});
     return hipGetLastError();
 }
 
@@ -2450,7 +2452,7 @@ hipError_t launch_cohort_fill(TableView tv, int32_t k, int32_t both, const uint6
                               int32_t sample, uint16_t* cell_counts, uint16_t* stash_counts, hipStream_t st, const uint64_t* pw, const uint8_t* ps) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(cohort_fill_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, tv, k, both, keys, counts, n, sample,
-                       cell_counts, stash_counts, RecProbes{pw, ps});
+                       cell_counts, stash_counts, RecProbes{pw, ps, tv.ext});
     return hipGetLastError();
 }
 

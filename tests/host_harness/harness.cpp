@@ -16,6 +16,8 @@ void set_error(const std::string&) {}
 int32_t hip_fail(hipError_t, const char*) { return 4; }
 }
 
+static int g_ext = 0;      // harness_set_ext: the cell functions below act on an EXTENDED table (cell_first_ext)
+
 static constexpr int MAX_CHUNKS = (31 + TILE_K + 31 + 31) / 32 + 1;
 
 struct Packed {
@@ -200,9 +202,10 @@ int harness_cells(const uint8_t* text, int64_t text_off, int n_kmers, int k, int
         for (int t = 1; t < W; ++t) mn = std::min(mn, h[j + t]);
         uint64_t F, R;
         extract_pair(P.fw(), P.cw(), P.off + j, k, F, R);
-        const CellProbe q = cell_probe_of(F, R, mn, 2u * ((uint32_t)j & 63u), lbits, M, both != 0, W);
+        CellProbe q = cell_probe_of(F, R, mn, 2u * ((uint32_t)j & 63u), lbits, M, both != 0, W);
+        if (g_ext) q = cell_first_ext(q, lbits);            // (what cell_probe_planned does for an extended table)
         CellProbe c[CELL_MAX_CANDS];
-        const int n = cells_of_key((both && R < F) ? R : F, k, lbits, c, both != 0);
+        const int n = cells_of_key((both && R < F) ? R : F, k, lbits, c, both != 0, g_ext != 0);
         bool ok = false;
         for (int i = 0; i < n; ++i) ok |= c[i].line == q.line && c[i].sh == q.sh && c[i].w == q.w && c[i].r == q.r;
         if (!ok) ++bad;
@@ -217,7 +220,7 @@ int harness_cells(const uint8_t* text, int64_t text_off, int n_kmers, int k, int
 // injectivity spot check: the cells of two different canonical k-mers never coincide in (line, sh, w, r)
 int harness_cells_of_key(uint64_t C, int k, int lbits, int both, uint32_t* out) {
     CellProbe c[CELL_MAX_CANDS];
-    const int n = cells_of_key(C, k, lbits, c, both != 0);
+    const int n = cells_of_key(C, k, lbits, c, both != 0, g_ext != 0);
     for (int i = 0; i < n; ++i) {
         out[4 * i] = c[i].line;
         out[4 * i + 1] = c[i].sh;
@@ -265,6 +268,7 @@ int harness_cell_third_line(uint32_t line, uint32_t sh, uint32_t w, uint32_t r, 
     return 1;
 }
 uint32_t harness_cell_rmask(int lbits, int both) { return cell_rmask(lbits, both != 0); }
+void harness_set_ext(int on) { g_ext = on; }
 int harness_alt_free_max_w(void) { return CELL_ALT_FREE_MAX_W; }
 uint64_t harness_revcomp_word(uint64_t x, int len) { return revcomp_word(x, len); }
 int harness_tile_k(void) { return TILE_K; }

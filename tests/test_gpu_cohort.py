@@ -88,15 +88,19 @@ def test_cohort_tables_for_the_other_kmer_lengths(oracle, tmp_path, monkeypatch,
                 assert np.array_equal(got[i][f], want[f]), (k, both, lbits, i, f)
 
 
-def test_cohort_with_a_crowded_table_and_a_loaded_stash(oracle, tmp_path, monkeypatch):
-    """2^17 lines for ~2 M records: second choices and the stash (with its own counters) carry real weight."""
+@pytest.mark.parametrize("lbits,ext", [(17, 0), (17, 1), (20, 1)])
+def test_cohort_with_a_crowded_table_and_a_loaded_stash(oracle, tmp_path, monkeypatch, lbits, ext):
+    """2^17 lines for ~2 M records: second choices and the stash (with its own counters) carry real weight; 2^20: third lines too
+    (their cells carry counters like any other). ext = 1: an extended key table (what >= 0.5 G records get, cell_first_ext)."""
     ref = synth.random_reference(500_000, 41)
     prefixes = [make_sample(tmp_path, f"d{i}", ref, 200 + i, cs=2, noise=60_000) for i in range(4)]
     s, e = engine.windows(len(ref), 10_000, 0, K)
-    monkeypatch.setenv("KCFX_TABLE_LBITS", "17")
+    monkeypatch.setenv("KCFX_TABLE_LBITS", str(lbits))
+    monkeypatch.setenv("KCFX_TABLE_EXT", str(ext))
     co = engine.Cohort(prefixes)
     monkeypatch.delenv("KCFX_TABLE_LBITS")
-    assert co.info.table_lines == 1 << 17 and co.info.stash_records > 0.05 * co.info.total_records
+    monkeypatch.delenv("KCFX_TABLE_EXT")
+    assert co.info.table_lines == 1 << lbits and (lbits > 17 or co.info.stash_records > 0.05 * co.info.total_records)
     r = engine.Reference(ref, s, e - s, K)
     check(co.screen(r, 1), prefixes, ref, s, e - s, 1, oracle, "crowded")
     check(co.screen(r, 3), prefixes, ref, s, e - s, 3, oracle, "crowded -c 3")

@@ -562,6 +562,6 @@ def test_wheat_scale_genomic_database(oracle, monkeypatch):
         with open(os.path.join(ROOT, "gpurun_out", "wheat_genomic.log"), "a") as fh:
             fh.write(line + "\n")
         # what the third lines are for: a genomic database at ~1 k-mer per cell used to leave a quarter to a third of itself in the stash
-        assert a["stash"] < 0.12 and a["per_cell"] < 0.6
+        assert a["stash"] < 0.10 and a["per_cell"] < 0.6
     finally:
         shutil.rmtree(d, ignore_errors=True)

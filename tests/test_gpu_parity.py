@@ -114,6 +114,40 @@ def test_screen_parity_small(oracle, tmp_path, k, p, cs, m, bins, both):
     assert int(got["kmer_count_sum"].sum()) == int(whole["kmer_count_sum"][0])
 
 
+@pytest.mark.parametrize("k,p,cs,m,bins,both", [CONFIGS[0], CONFIGS[2], CONFIGS[3], CONFIGS[11], CONFIGS[13], CONFIGS[14]])
+@pytest.mark.parametrize("lbits", [0, 17, 21])
+def test_extended_table_parity(oracle, tmp_path, monkeypatch, k, p, cs, m, bins, both, lbits):
+    """EXTENDED cell tables (KCFX_TABLE_EXT=1 forces what databases of >= 0.5 G k-mers get: the first-choice line of a k-mer
+    depends on the three flank bases next to its minimizer as well, cell_first_ext): KMC.getCount of present and absent k-mers and
+    every window of several geometries against the oracle, planned and text-only reference, dense tables (lbits 17 / 21: second
+    and third lines and the stash carry weight; 17 has no third lines) and the policy's size."""
+    monkeypatch.setenv("KCFX_TABLE_EXT", "1")
+    if lbits:
+        monkeypatch.setenv("KCFX_TABLE_LBITS", str(lbits + (0 if both else 1)))
+    ref = synth.random_reference(150_000, 77 + k, n_run_every=11_000, max_n_run=300, lower_frac=0.1, iupac_rate=3e-4)
+    prefix, kmers, counts, prm = make_db(tmp_path, "dbx", ref, 31, k, p, cs, m, bins, both, noise=30_000 if lbits else 3_000,
+                                         sub_rate=1e-2, indel_rate=1e-3, big_del_per_mb=30, big_del_len=3000)
+    db = engine.KmcDb.open(prefix)
+    assert db.info.table_format == 1
+    odb = oracle.OracleDb(prefix)
+    assert np.array_equal(db.lookup(kmers), counts.astype(np.uint32).astype(np.int32))
+    rng = np.random.default_rng(2)
+    mask = np.uint64((0xFFFFFFFFFFFFFFFF << (64 - 2 * k)) & 0xFFFFFFFFFFFFFFFF)
+    q = rng.integers(0, np.iinfo(np.uint64).max, size=3000, dtype=np.uint64, endpoint=True) & mask
+    if both:
+        q = np.minimum(q, synth.revcomp(q, k))
+    assert np.array_equal(db.lookup(q), np.array([odb.get_count(int(x)) for x in q], dtype=np.int32))
+    for window, step in ((10_000, 0), (900, 0), (50_000, 0)):
+        s, e = engine.windows(len(ref), window, step, k)
+        want = odb.screen(ref, s, e - s, 1, threads=4)
+        assert_same(db.screen(ref, s, e - s, 1), want, f"ext w={window}")
+        monkeypatch.setenv("KCFX_REF_PLAN", "0")
+        assert_same(db.screen(ref, s, e - s, 1), want, f"ext, text-only reference, w={window}")
+        monkeypatch.delenv("KCFX_REF_PLAN")
+    s, e = engine.windows(len(ref), 10_000, 0, k)
+    assert_same(db.screen(ref, s, e - s, 3), odb.screen(ref, s, e - s, 3, threads=4), "ext -c 3")
+
+
 def test_screen_irregular_windows(oracle, tmp_path):
     """gene-model-like windows: 31 bp .. 60 kbp, overlapping, unsorted, at every alignment"""
     k = 31
@@ -395,7 +429,8 @@ def test_read_error_like_database(oracle, tmp_path, monkeypatch, lbits):
     db = engine.KmcDb.open(prefix)
     assert db.info.table_format == 1 and db.info.table_lines == 1 << lbits
     # the error neighbours of a genomic k-mer want its cell: one of them fits the second line, the rest live in the stash
-    assert db.info.stash_kmers > 0.1 * db.info.total_kmers                        # (1.4 M k-mers; 2.1 M cells at lbits 17)
+    # (1.4 M k-mers; 2.1 M cells at lbits 17. Tables with third lines -- three spare r bits: lbits >= 20 -- keep fewer in the stash)
+    assert db.info.stash_kmers > (0.1 if lbits < 20 else 0.03) * db.info.total_kmers
     assert db.info.stash_kmers + db.info.second_choice_kmers > 0.2 * db.info.total_kmers
     odb = oracle.OracleDb(prefix)
     s, e = engine.windows(len(ref), 5_000, 0, 31)

@@ -234,12 +234,16 @@ def test_scalar_gap_loop_equals_lane_parallel_form(harness):
                 assert (out[0], out[1]) == (out[2], out[3]), (hex(V), hex(H), cg, cany)
 
 
-def test_cell_table_build_side_covers_query_side(harness, oracle):
+@pytest.mark.parametrize("ext", [0, 1])
+def test_cell_table_build_side_covers_query_side(harness, oracle, ext):
     """FORMAT_CELLS (kcfx_internal.h): the cell screen_k31c derives for a reference k-mer -- line from the tagged sliding
     minimum, cell index from the minimizer's offset on the strand where it is canonical, quotiented key (w, r) -- must be one
     of the cells the build stores the canonical k-mer in, for every k-mer, alignment and strand, including repeated
     16-mers (ties), reverse-palindromic 16-mers and low-complexity text. And distinct k-mers never share a full
     (line, cell, w, r): that is what makes the 48-bit compare exact."""
+    # ext = 1: the same for an EXTENDED table (databases of >= 0.5 G k-mers: the first-choice line depends on the flank bases next to
+    # the minimizer too, cell_first_ext) -- build and query must still meet, the entries must still be injective
+    harness.harness_set_ext(ext)
     rng = np.random.default_rng(33)
     acgt = np.frombuffer(b"ACGTacgt", dtype=np.uint8)
     pal = b"ACGTACGTACGTACGT"            # its own reverse complement (and so are its even-length prefixes)
@@ -322,6 +326,12 @@ def test_cell_table_build_side_covers_query_side(harness, oracle):
                     assert seen_2nd.setdefault(third, int(c)) == int(c), (k, lbits, hex(int(c)))
                     thirds.add(l3)
                     seconds.add(l2)
+
+
+@pytest.fixture(autouse=True)
+def _plain_tables_by_default(harness):
+    yield
+    harness.harness_set_ext(0)
 
 
 def _planner_text(rng):

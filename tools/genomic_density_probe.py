@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--len", type=float, default=2.4e9)
     ap.add_argument("--lbits", default="27,28,29")
     ap.add_argument("--base", default="/dev/shm")
+    ap.add_argument("--ext", default="0,1", help="plain / extended tables (KCFX_TABLE_EXT)")
     args = ap.parse_args()
     import torch
     d = tempfile.mkdtemp(prefix="kcfx_gd_", dir=args.base)
@@ -46,13 +47,14 @@ def main():
         stream = torch.cuda.current_stream()
         outbuf = torch.zeros(len(starts) * 10, dtype=torch.int32, device="cuda:0")
         base = None
-        for lb in [int(x) for x in args.lbits.split(",")]:
+        for lb, ext in [(int(x), int(y)) for x in args.lbits.split(",") for y in args.ext.split(",")]:
             os.environ["KCFX_TABLE_LBITS"] = str(lb)
+            os.environ["KCFX_TABLE_EXT"] = str(ext)
             t1 = time.time()
             try:
                 db = engine.KmcDb.open(prefix, no_fallback=True)
             except engine.KcfxError as exc:
-                print(f"2^{lb}: {exc}", flush=True)
+                print(f"2^{lb} ext {ext}: {exc}", flush=True)
                 continue
             t_open = time.time() - t1
             i = db.info
@@ -68,7 +70,7 @@ def main():
             ms, cnt = ref.prof_read(reset=True)
             ref.prof_enable(False)
             n = int(res["total_kmers"].sum())
-            print(f"2^{lb} lines: {i.stored_kmers / (16.0 * i.table_lines):.2f} per cell, {i.table_bytes / 2**30:.1f} GiB incl. stash, opened in {t_open:.1f} s, "
+            print(f"2^{lb} lines{' EXT' if ext else '    '}: {i.stored_kmers / (16.0 * i.table_lines):.2f} per cell, {i.table_bytes / 2**30:.1f} GiB incl. stash, opened in {t_open:.1f} s, "
                   f"stash {100.0 * i.stash_kmers / i.stored_kmers:.1f} %, second / third lines {100.0 * i.second_choice_kmers / i.stored_kmers:.1f} %, "
                   f"pass {ms / cnt:.2f} ms = {n / (ms / cnt) / 1e6:.0f} G k-mers/s, hit rate {res['obs'].sum() / n:.3f}, identical to the first: {same}", flush=True)
             db.close()
