@@ -291,10 +291,10 @@ int32_t cells_lbits(int64_t n_keys, int32_t k, bool both, int64_t expected_queri
     if (s && atoi(s) >= lmin && atoi(s) <= cap) return atoi(s);
     const size_t free_b = free_device_bytes();
     // A table above 48 GiB is halved while that leaves it at <= ~0.5 k-mers per cell (the 2.1 G-k-mer test database: 2^28 lines), and
-    // beyond that only when it does not fit half of the free memory: a database of billions of GENOMIC k-mers needs the lines --
+    // beyond that only when it does not fit 60 % of the free memory: a database of billions of GENOMIC k-mers needs the lines --
     // at ~1 per cell a quarter of it lives in the stash, at ~0.5 a twelfth (profiles/r04_notes.md) -- and a second database that
     // does not fit beside it is waited for by the sharded loader (kcfx_shard.cpp).
-    const double soft_cap = 48.0 * (double)(1ull << 30), hard_cap = 0.5 * (double)free_b;
+    const double soft_cap = 48.0 * (double)(1ull << 30), hard_cap = 0.6 * (double)free_b;
     (void)expected_queries;                               // (one density for every handle since round 4, see above)
     const double density = 0.075;
     int32_t L = lmin;

@@ -17,6 +17,11 @@ src = f"gpurun_out/{tag}"
 os.makedirs("profiles", exist_ok=True)
 # the dominant kernel of the bench workload, as the bench line names it (screen_k31c_kernel on a cell table)
 KERNEL = json.load(open(f"{src}/bench.json"))["roofline"]["kernel"]
+# (round 4: a bench process runs three kernels of interest -- the screening kernel on the planned reference, the same template on a
+# text-only reference (K1 - K3 in one launch) and ref_plan_kernel; rocprofv3 prints template arguments, which tell them apart)
+PLANNED = KERNEL + "<31, true, true>" if KERNEL in ("screen_k31c_kernel", "screen_cohort_kernel") else KERNEL
+TEXT_ONLY = KERNEL + "<31, true, false>"
+PLAN = "ref_plan_kernel<31>"
 
 
 def counters(pattern, kernel):
@@ -31,20 +36,38 @@ def counters(pattern, kernel):
 out = {"tag": tag}
 bench = json.load(open(f"{src}/bench.json"))
 out["kernel"] = KERNEL
-out["bench"] = {k: bench[k] for k in ("value", "ms_per_step", "roofline", "cpu_baseline", "parity", "config")}
+out["bench"] = {k: bench.get(k) for k in ("value", "ms_per_step", "step", "amortised", "one_pass", "cold_start", "text_only_reference", "roofline",
+                                          "cpu_baseline", "parity", "config")}
 for f in glob.glob(f"{src}/stats/*kernel_stats.csv"):
     shutil.copy(f, f"profiles/{tag}_kernel_stats.csv")
     for r in csv.DictReader(open(f)):
-        if KERNEL in r["Name"]:
+        if PLANNED in r["Name"]:
             out["rocprof_kernel"] = r["Name"].split("(")[0]
             out["rocprof_kernel_avg_ms"] = float(r["AverageNs"]) / 1e6
             out["rocprof_kernel_calls"] = int(r["Calls"])
-fetch, n1 = counters(f"{src}/pmc_fetch/*counter_collection.csv", KERNEL)
-write, _ = counters(f"{src}/pmc_write/*counter_collection.csv", KERNEL)
-tcc, _ = counters(f"{src}/pmc_tcc/*counter_collection.csv", KERNEL)
-sq, _ = counters(f"{src}/pmc_sq/*counter_collection.csv", KERNEL)
-sq2, _ = counters(f"{src}/pmc_sq2/*counter_collection.csv", KERNEL)
+        elif TEXT_ONLY in r["Name"]:
+            out["rocprof_text_only_kernel_avg_ms"] = float(r["AverageNs"]) / 1e6
+            out["rocprof_text_only_kernel_calls"] = int(r["Calls"])
+        elif PLAN in r["Name"]:
+            out["rocprof_ref_plan_avg_ms"] = float(r["AverageNs"]) / 1e6
+            out["rocprof_ref_plan_calls"] = int(r["Calls"])
+fetch, n1 = counters(f"{src}/pmc_fetch/*counter_collection.csv", PLANNED)
+write, _ = counters(f"{src}/pmc_write/*counter_collection.csv", PLANNED)
+tcc, _ = counters(f"{src}/pmc_tcc/*counter_collection.csv", PLANNED)
+sq, _ = counters(f"{src}/pmc_sq/*counter_collection.csv", PLANNED)
+sq2, _ = counters(f"{src}/pmc_sq2/*counter_collection.csv", PLANNED)
 sq.update(sq2)
+# the other two kernels: requests, VALU instructions, bytes
+others = {}
+for name, pat in (("text_only", TEXT_ONLY), ("ref_plan", PLAN)):
+    f2, _ = counters(f"{src}/pmc_fetch/*counter_collection.csv", pat)
+    w2, _ = counters(f"{src}/pmc_write/*counter_collection.csv", pat)
+    t2, _ = counters(f"{src}/pmc_tcc/*counter_collection.csv", pat)
+    q2, _ = counters(f"{src}/pmc_sq/*counter_collection.csv", pat)
+    if f2 or t2 or q2:
+        others[name] = {"hbm_read_bytes_per_launch": 2.0 * f2["FETCH_SIZE"] * 1024 if f2.get("FETCH_SIZE") is not None else None,
+                        "hbm_write_bytes_per_launch": w2["WRITE_SIZE"] * 1024 if w2.get("WRITE_SIZE") is not None else None, **t2, **q2}
+out["other_kernels"] = others
 cal, _ = counters(f"{src}/pmc_cal/*counter_collection.csv", "gather_coop<8, 1>")
 out["counters"] = {"FETCH_SIZE_KB": fetch.get("FETCH_SIZE"), "WRITE_SIZE_KB": write.get("WRITE_SIZE"), **tcc, **sq}
 if cal.get("FETCH_SIZE"):
@@ -62,7 +85,7 @@ if fetch.get("FETCH_SIZE") is not None:
         json.dump({"tag": tag, "kernel": KERNEL, "hbm_bytes_per_launch": rd + wr,
                    "rocprof_kernel_avg_ms": out.get("rocprof_kernel_avg_ms"),
                    "hbm_read_requests_per_launch": tcc.get("TCC_EA0_RDREQ_sum"),
-                   "ref_len": 30427671, "db_kmers": 150000000, "window": 10000,
+                   "ref_len": 30427671, "db_kmers": 150000000, "window": 10000, "table_lines": bench["roofline"].get("table", {}).get("lines"),
                    "note": "2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes), separate --pmc passes, averaged over launches"},
                   open("profiles/traffic.json", "w"), indent=1)
     kms = bench["roofline"]["kernel_avg_ms"]

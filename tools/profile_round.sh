@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile: run ON THE GPU BOX (gpurun -- 'bash tools/profile_round.sh r01'). Writes gpurun_out/<tag>_*;
 # copy the summaries into profiles/ with tools/pmc_summary.py afterwards.
-TAG=${1:-r01}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
