@@ -1,4 +1,4 @@
-"""The bench line the driver parses: the committed profile of the last GPU run (profiles/r02_bench.json, written by
+"""The bench line the driver parses: the committed profile of the last GPU run (profiles/r04_bench.json, written by
 tools/profile_round.sh from `python bench.py`) must carry every field of the contract with consistent values. Runs on CPU."""
 import json
 import os
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -36,9 +36,19 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r["kernel"] == "screen_k31c_kernel" and (r["traffic"] is None or "not measured in this run" in r["traffic_source"])
     assert d["parity"]["bit_exact"] is True
     # the rocprofv3 summary committed next to it agrees with the HIP-event figure within 10 %
-    s = json.load(open(os.path.join(ROOT, "profiles", "r02_summary.json")))
+    s = json.load(open(os.path.join(ROOT, "profiles", "r04_summary.json")))
     assert abs(s["rocprof_kernel_avg_ms"] - r["kernel_avg_ms"]) < 0.1 * r["kernel_avg_ms"]
     assert r["traffic"] is None or r["traffic"] > alg      # HBM traffic by PMC is above the algorithmic bytes
+    # round 4: the step is ONE PASS (K1 - K3: plan + screen + reduce); the plan kernel, the amortised form of the step and the
+    # one-launch form on a text-only reference are measured beside it and the one-pass fractions follow from them
+    assert d["step"].startswith("one pass") and d["amortised"]["value"] > d["value"] and d["warmup"] >= d["warmup_requested"] + d["steps"]
+    assert abs(s["rocprof_ref_plan_avg_ms"] - r["ref_plan_ms"]) < 0.1 * r["ref_plan_ms"] and r["ref_plan_ms"] <= 0.030
+    assert abs(r["frac_one_pass"] - alg / ((r["kernel_avg_ms"] + r["ref_plan_ms"]) * 1e-3) / 1e9 / r["peak"]) < 1e-9
+    assert abs(r["frac_text_only"] - alg / (r["text_only_kernel_ms"] * 1e-3) / 1e9 / r["peak"]) < 1e-9
+    assert d["text_only_reference"]["identical_to_planned"] is True and d["cold_start"]["steps"] == d["steps"]
+    assert r["table"]["policy"] == "product" and r["table"]["lines"] == json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["table_lines"]
+    # the CPU leg says how many cores it really had
+    assert c["host_cores"] <= c["host_cores_logical"] and str(c["host_cores"]) in c["by_threads"]
 
 
 def test_gpus_n_run_plainly_starts_the_ranks_as_a_child(tmp_path, monkeypatch):
