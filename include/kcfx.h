@@ -90,7 +90,10 @@ typedef struct {
     int64_t stash_kmers;     /* format 1: k-mers that found their cell and their second line's cell taken and live in the stash */
     int64_t stash_bytes;     /* format 1: HBM bytes of the stash (included in table_bytes) */
     int64_t multi_cell_kmers;/* format 1: k-mers stored in more than one cell (tied or palindromic minimizers) */
-    int64_t second_choice_kmers; /* format 1: k-mers placed outside their first-choice cell (a free cell of the line, or the second line) */
+    int64_t second_choice_kmers; /* format 1: k-mers placed outside their first-choice cell (second or third line) */
+    int32_t extended;        /* format 1: 1 = the first-choice line of a k-mer depends on the flank bases next to its minimizer too
+                                (databases of >= 0.5 G k-mers whose plain table left > 15 % of them outside their cell) */
+    int32_t _reserved;
 } kcfx_db_info_t;
 
 /* ---- database ------------------------------------------------------------------------------------ */
@@ -103,10 +106,10 @@ int32_t kcfx_db_open(const char* kmc_prefix, int32_t device, kcfx_db** out);
 
 /* kcfx_db_open with options (NULL = the defaults of kcfx_db_open).
  *   expected_queries  k-mer look-ups this handle is expected to serve over its lifetime = reference k-mers x passes (the
- *                     reference runs ONE pass per database: GetVariants.java:129-159); 0 = unknown. The table is sized for
- *                     it: a handle that serves few look-ups gets a dense table (~0.3 k-mers per cell: 5 GB for 150 M k-mers,
- *                     +21 % screening time) instead of the sparse one (~0.07 per cell: 17 GB) that pays off only over
- *                     ~10^10 look-ups -- allocating and clearing 16 GiB can cost a second (profiles/r03_density.csv).
+ *                     reference runs ONE pass per database: GetVariants.java:129-159); 0 = unknown. Since round 4 the table
+ *                     has the same size either way (~0.07 k-mers per cell: 17 GB for 150 M k-mers; end to end the sizes are
+ *                     indistinguishable and the sparse one screens 16 - 30 % faster, profiles/r04_notes.md); a handle that
+ *                     serves fewer than 10^10 look-ups only builds with the cheaper crowding counters (no 4 GiB scratch).
  *   no_fallback       1: a cell table that does not fit the device fails with KCFX_ERR_DEVICE instead of being rebuilt as
  *                     a 12-slot line table (callers that can free memory and retry, like kcfx_screen_sharded's loader). */
 typedef struct {

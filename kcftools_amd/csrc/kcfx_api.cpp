@@ -121,6 +121,7 @@ struct kcfx_db {
     // the block first) on a thread of its own while the .kmc_suf is read, decoded and counted: nothing touches the lines
     // before the first bidding pass, which waits for it (table_ready)
     int32_t ext = 0;                     // FORMAT_CELLS: an extended table (TableView::ext)
+    bool ext_auto = false;               // ... decided by the build itself: plain first, rebuilt extended if too many k-mers lost their cell
     int32_t line_footprint = LINE_BYTES;   // bytes per table line the handle will hold in all (a cohort's key table: + 256 B of counters)
     std::thread alloc_thread;
     int32_t alloc_rc = KCFX_OK;          // written by alloc_thread, read after the join
@@ -341,10 +342,18 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys, bool deferred = false) {
     db->info.table_mode = MODE_MINIMIZER;
     db->info.minimizer_length = db->mm_len;
     db->info.table_format = FORMAT_CELLS;
-    // Extended tables (kcfx_device.h: cell_first_ext) from ~0.5 G k-mers on: that is where the runs of a genome start to outnumber
-    // the open-syncmer 16-mers their minimizers concentrate on (profiles/r04_notes.md). KCFX_TABLE_EXT=0 / 1 overrides (tests, A/B).
-    db->ext = n_keys >= 500000000ll ? 1 : 0;
-    if (const char* xe = getenv("KCFX_TABLE_EXT")) db->ext = atoi(xe) != 0;
+    // Extended tables (kcfx_device.h: cell_first_ext) are for databases whose runs outnumber the open-syncmer 16-mers their
+    // minimizers concentrate on. Whether that is so shows in the build: kcfx_db_open builds a database of >= 0.5 G k-mers as a
+    // plain table up to the settle pass, and starts over as an extended one if more than EXT_MOVED_SHARE of the k-mers did not get
+    // their first-choice cell (load_suffix_file). The query side pays ~1.3 line requests per run in an extended table, so a
+    // database that does not need it must not get it: the bench cohort (1.2 G records, mostly k-mers private to one sample) screens
+    // in 0.21 ms plain and 0.28 ms extended. KCFX_TABLE_EXT=0 / 1 decides by hand (tests, A/B). Cohort tables stay plain.
+    db->ext = 0;
+    db->ext_auto = n_keys >= 500000000ll && db->line_footprint == LINE_BYTES;
+    if (const char* xe = getenv("KCFX_TABLE_EXT")) {
+        db->ext = atoi(xe) != 0;
+        db->ext_auto = false;
+    }
     hipError_t e = hipErrorOutOfMemory;
     const bool both = db->info.both_strands != 0;
     int32_t L0 = cells_lbits(n_keys, db->info.kmer_length, both, db->expected_queries, db->line_footprint);
@@ -417,6 +426,7 @@ int32_t cells_stash_alloc(kcfx_db* db) {
     db->info.stored_kmers = (int64_t)h[1];
     db->info.multi_cell_kmers = (int64_t)h[2];
     db->info.second_choice_kmers = (int64_t)h[3];
+    db->info.extended = db->ext;
     const size_t free_b = free_device_bytes();
     double budget = 0.5 * (double)free_b;
     if (const char* s = getenv("KCFX_STASH_BUDGET")) budget = std::max(0.0, atof(s));
@@ -718,6 +728,23 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
             tr.mark("wait for the table");
             for (int phase = 1; phase <= 3; ++phase)
                 if ((rc = later_pass(phase))) return rc;
+            if (db->ext_auto && !db->ext) {
+                // how many k-mers sit outside their first-choice cell? (d_stats: [0] for the stash, [1] stored, [3] second / third lines)
+                unsigned long long st4[4] = {0, 0, 0, 0};
+                LOAD_HIP(hipMemcpyAsync(st4, db->d_stats, sizeof st4, hipMemcpyDeviceToHost, db->stream));
+                LOAD_HIP(hipStreamSynchronize(db->stream));
+                constexpr double EXT_MOVED_SHARE = 0.15;
+                if ((double)(st4[0] + st4[3]) > EXT_MOVED_SHARE * (double)std::max<unsigned long long>(st4[1], 1)) {
+                    db->ext = 1;                            // start over: lines, counters and statistics cleared, the four passes again
+                    LOAD_HIP(hipMemsetAsync(db->d_lines, 0, (size_t)LINE_BYTES << db->lbits, db->stream));
+                    LOAD_HIP(hipMemsetAsync(db->d_pop, 0, cells_pop_bytes(db->pop_bits), db->stream));
+                    LOAD_HIP(hipMemsetAsync(db->d_stats, 0, 4 * sizeof(unsigned long long), db->stream));
+                    tr.mark("plain table: too many k-mers outside their cell");
+                    for (int phase = 0; phase <= 3; ++phase)
+                        if ((rc = later_pass(phase))) return rc;
+                    tr.mark("rebuilt as an extended table");
+                }
+            }
             if ((rc = cells_stash_alloc(db))) {
                 cleanup();
                 return rc;

@@ -520,7 +520,7 @@ def test_wheat_scale_genomic_database(oracle, monkeypatch):
             torch.cuda.synchronize()
             ms, cnt = ref.prof_read(reset=True)
             ref.prof_enable(False)
-            d_ = dict(lines=int(info.table_lines), per_cell=info.stored_kmers / (16.0 * info.table_lines), gib=info.table_bytes / 2 ** 30,
+            d_ = dict(lines=int(info.table_lines), extended=int(info.extended), per_cell=info.stored_kmers / (16.0 * info.table_lines), gib=info.table_bytes / 2 ** 30,
                       stash=info.stash_kmers / max(1, info.stored_kmers), moved=info.second_choice_kmers / max(1, info.stored_kmers),
                       open_s=t_open, kernel_ms=ms / max(1, cnt))
             db.close()
@@ -551,7 +551,7 @@ def test_wheat_scale_genomic_database(oracle, monkeypatch):
         gk = n / 1e9
 
         def show(x):
-            return (f"2^{int(np.log2(x['lines']))} lines = {x['per_cell']:.2f} per cell, {x['gib']:.0f} GiB incl. stash, opened in {x['open_s']:.1f} s, "
+            return (f"2^{int(np.log2(x['lines']))} lines ({'extended' if x['extended'] else 'plain'}) = {x['per_cell']:.2f} per cell, {x['gib']:.0f} GiB incl. stash, opened in {x['open_s']:.1f} s, "
                     f"{100 * x['stash']:.1f} % in the stash, {100 * x['moved']:.1f} % in second / third lines, pass {x['kernel_ms']:.1f} ms = "
                     f"{gk / x['kernel_ms'] * 1e3:.0f} G k-mers/s")
         line = (f"wheat-scale genomic database ({why}): {len(text) / 1e9:.2f} Gb non-tiled genome, {n_db / 1e9:.2f} G distinct 31-mers of its sample "
@@ -565,6 +565,7 @@ def test_wheat_scale_genomic_database(oracle, monkeypatch):
         # what the third lines are for: a genomic database at ~1 k-mer per cell used to leave a quarter to a third of itself in the stash
         # (which size the policy picks depends on what else this process holds on the device: 2^30 lines for 8 G k-mers when 60 % of
         # the free memory can take them, else 2^29)
+        assert a["extended"] == 1                                # (the build found > 15 % of the k-mers outside their first-choice cell and started over)
         assert a["stash"] < (0.10 if a["per_cell"] < 0.6 else 0.22)
     finally:
         shutil.rmtree(d, ignore_errors=True)

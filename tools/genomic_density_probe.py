@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--len", type=float, default=2.4e9)
     ap.add_argument("--lbits", default="27,28,29")
     ap.add_argument("--base", default="/dev/shm")
-    ap.add_argument("--ext", default="0,1", help="plain / extended tables (KCFX_TABLE_EXT)")
+    ap.add_argument("--ext", default="0,1,auto", help="plain / extended tables (KCFX_TABLE_EXT), auto = the library decides")
     args = ap.parse_args()
     import torch
     d = tempfile.mkdtemp(prefix="kcfx_gd_", dir=args.base)
@@ -47,9 +47,12 @@ def main():
         stream = torch.cuda.current_stream()
         outbuf = torch.zeros(len(starts) * 10, dtype=torch.int32, device="cuda:0")
         base = None
-        for lb, ext in [(int(x), int(y)) for x in args.lbits.split(",") for y in args.ext.split(",")]:
+        for lb, ext in [(int(x), y) for x in args.lbits.split(",") for y in args.ext.split(",")]:
             os.environ["KCFX_TABLE_LBITS"] = str(lb)
-            os.environ["KCFX_TABLE_EXT"] = str(ext)
+            if ext == "auto":
+                os.environ.pop("KCFX_TABLE_EXT", None)
+            else:
+                os.environ["KCFX_TABLE_EXT"] = ext
             t1 = time.time()
             try:
                 db = engine.KmcDb.open(prefix, no_fallback=True)
@@ -70,7 +73,7 @@ def main():
             ms, cnt = ref.prof_read(reset=True)
             ref.prof_enable(False)
             n = int(res["total_kmers"].sum())
-            print(f"2^{lb} lines{' EXT' if ext else '    '}: {i.stored_kmers / (16.0 * i.table_lines):.2f} per cell, {i.table_bytes / 2**30:.1f} GiB incl. stash, opened in {t_open:.1f} s, "
+            print(f"2^{lb} lines ({ext}: {'extended' if i.extended else 'plain'}): {i.stored_kmers / (16.0 * i.table_lines):.2f} per cell, {i.table_bytes / 2**30:.1f} GiB incl. stash, opened in {t_open:.1f} s, "
                   f"stash {100.0 * i.stash_kmers / i.stored_kmers:.1f} %, second / third lines {100.0 * i.second_choice_kmers / i.stored_kmers:.1f} %, "
                   f"pass {ms / cnt:.2f} ms = {n / (ms / cnt) / 1e6:.0f} G k-mers/s, hit rate {res['obs'].sum() / n:.3f}, identical to the first: {same}", flush=True)
             db.close()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Profile of the cohort-table step (bench.py --samples 8 --cohort), ON THE GPU BOX: bench line, rocprofv3 --kernel-trace --stats,
 # and the --pmc passes (HBM traffic, requests, instruction mix). Summarised by tools/pmc_summary.py <tag> --cohort.
-TAG=${1:-r03_cohort}
+TAG=${1:-r04_cohort}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/$TAG
 mkdir -p $OUT

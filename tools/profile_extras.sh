@@ -2,7 +2,7 @@
 # Other inputs under rocprofv3 --kernel-trace --stats, ON THE GPU BOX (tools/realistic_db_probe.py checks every window against
 # the oracle): k = 25 (KMC's default; uniform-noise database), a read-error-like database (k = 31), a repeat-structured genome.
 #   bash tools/profile_extras.sh <tag>   ->  gpurun_out/<tag>_{k25,readerror_db,repeats}/ + .log
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 run() {  # name, args...
   local name=$1; shift
