@@ -156,6 +156,20 @@ int32_t kcfx_release_cached(int32_t device);
  * from those instead of from the ASCII (KCFX_REF_PLAN=0 in the environment: text only, the kernels derive it per launch). */
 int32_t kcfx_ref_create(int32_t device, int32_t kmer_length, const uint8_t* text, int64_t text_len,
                         const int64_t* win_begin, const int32_t* win_len, int32_t n_windows, kcfx_ref** out);
+/* kcfx_ref_create with options (NULL = the defaults of kcfx_ref_create).
+ *   expected_screens  how many databases will be screened against this reference: 0 = unknown / several -- the reference is
+ *                     PLANNED once (2-bit codes + one anchor byte per k-mer beside the text) and every pass starts from the plan;
+ *                     1 = exactly one (the reference program's own usage: one getVariations run per sample,
+ *                     run_kcftools.sh:124-140) -- the reference stays text only and the one screening launch plans its tiles
+ *                     itself: K1 - K3 in one kernel, faster than plan + screen as two launches and 1.25 bytes per base lighter.
+ *                     (KCFX_REF_PLAN=0 / 1 in the environment forces text-only / planned whatever this says.) */
+typedef struct {
+    int32_t expected_screens;
+    int32_t reserved;
+} kcfx_ref_opts;
+int32_t kcfx_ref_create_opts(int32_t device, int32_t kmer_length, const uint8_t* text, int64_t text_len,
+                             const int64_t* win_begin, const int32_t* win_len, int32_t n_windows, const kcfx_ref_opts* opts,
+                             kcfx_ref** out);
 int32_t kcfx_ref_n_windows(const kcfx_ref* ref);
 int64_t kcfx_ref_n_kmer_slots(const kcfx_ref* ref);   /* sum over windows of max(0, len - k + 1) */
 void kcfx_ref_destroy(kcfx_ref* ref);

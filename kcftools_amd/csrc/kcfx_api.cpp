@@ -1077,7 +1077,14 @@ int32_t kcfx_release_cached(int32_t device) try {
 } KCFX_CATCH("kcfx_release_cached")
 
 int32_t kcfx_ref_create(int32_t device, int32_t kmer_length, const uint8_t* text, int64_t text_len,
-                        const int64_t* win_begin, const int32_t* win_len, int32_t n_windows, kcfx_ref** out) try {
+                        const int64_t* win_begin, const int32_t* win_len, int32_t n_windows, kcfx_ref** out) {
+    return kcfx_ref_create_opts(device, kmer_length, text, text_len, win_begin, win_len, n_windows, nullptr, out);
+}
+
+int32_t kcfx_ref_create_opts(int32_t device, int32_t kmer_length, const uint8_t* text, int64_t text_len,
+                             const int64_t* win_begin, const int32_t* win_len, int32_t n_windows, const kcfx_ref_opts* opts,
+                             kcfx_ref** out) try {
+    if (opts && opts->expected_screens < 0) return fail(KCFX_ERR_ARG, "kcfx_ref_opts: negative expected_screens");
     if (!out || text_len < 0 || n_windows < 0 || (text_len > 0 && !text) || (n_windows > 0 && (!win_begin || !win_len)))
         return fail(KCFX_ERR_ARG, "null argument");
     *out = nullptr;
@@ -1085,9 +1092,14 @@ int32_t kcfx_ref_create(int32_t device, int32_t kmer_length, const uint8_t* text
     const int32_t k = kmer_length;
     // KCFX_REF_PLAN=0 in the environment keeps the reference as text only (A/B and test hook, read here, never per launch):
     // cell-table launches then plan every tile themselves and take tiles of at most TEXT_TILE_K k-mers (k31_plan_tile)
+    // A reference that ONE database will be screened against (kcfx_ref_opts.expected_screens == 1: one sample per device in the
+    // sharded call, the one-shot kcfx_screen) is kept as text only too: the one launch that plans its tiles itself is faster than
+    // plan + screen as two (0.095 against 0.027 + 0.078 ms on the bench workload) and needs no plan buffers.
     const char* plan_env = getenv("KCFX_REF_PLAN");
     const bool cell_k = k >= CELL_K_MIN && k <= CELL_K_MAX;
-    const bool planned = cell_k && text_len > 0 && !(plan_env && plan_env[0] == '0');
+    bool planned = cell_k && text_len > 0 && !(opts && opts->expected_screens == 1);
+    if (plan_env) planned = planned && plan_env[0] != '0';
+    if (plan_env && plan_env[0] == '1') planned = cell_k && text_len > 0;
     const int64_t tile_k = (cell_k && !planned) ? TEXT_TILE_K : TILE_K;
     // tile plan: every window is cut into near-equal tiles of <= tile_k k-mer start positions (multiples of 64)
     std::vector<TileDesc> tiles;
@@ -1152,7 +1164,7 @@ int32_t kcfx_ref_create(int32_t device, int32_t kmer_length, const uint8_t* text
     if ((e = hipStreamSynchronize(r->stream)) != hipSuccess) return hip_fail(e, "kcfx_ref_create");
     *out = hold.release();
     return KCFX_OK;
-} KCFX_CATCH("kcfx_ref_create")
+} KCFX_CATCH("kcfx_ref_create_opts")
 
 // The sample-independent half of a pass (SURVEY's K1: 2-bit pack, validity, minimizer choice) over the resident text again, on
 // the caller's stream: what a job that screens ONE sample per reference pays per pass. Idempotent (same text, same plan).
@@ -1332,7 +1344,10 @@ int32_t kcfx_screen(kcfx_db* db, const uint8_t* text, int64_t text_len, const in
                     const int32_t* win_len, int32_t n_windows, int32_t min_kmer_count, kcfx_result* out) try {
     if (!db) return fail(KCFX_ERR_ARG, "null argument");
     kcfx_ref* ref = nullptr;
-    if (int32_t rc = kcfx_ref_create(db->device, db->info.kmer_length, text, text_len, win_begin, win_len, n_windows, &ref))
+    kcfx_ref_opts one;
+    one.expected_screens = 1;                               // (one database against this text: planned inside the launch)
+    one.reserved = 0;
+    if (int32_t rc = kcfx_ref_create_opts(db->device, db->info.kmer_length, text, text_len, win_begin, win_len, n_windows, &one, &ref))
         return rc;
     const int32_t rc = kcfx_screen_ref(db, ref, min_kmer_count, out);
     kcfx_ref_destroy(ref);

@@ -257,7 +257,16 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
             std::vector<int64_t> wb((size_t)nw);
             for (int32_t i = 0; i < nw; ++i) wb[(size_t)i] = win_begin[lo + i] - t_lo;
             const double t = now_s();
-            const int32_t rc = kcfx_ref_create(wk.device, kmer_length, text + t_lo, t_hi - t_lo, wb.data(), win_len + lo, nw, &ref_hold.p);
+            // (how many of this worker's segments screen exactly this window range: one -> a text-only reference, planned inside
+            // its single launch; several -> planned once for all of them)
+            kcfx_ref_opts ro;
+            ro.expected_screens = 0;
+            ro.reserved = 0;
+            int32_t uses = 0;
+            for (const Segment& sg2 : wk.segs)
+                if (sg2.w_lo == lo && sg2.w_hi == hi) uses += (sg2.n > 1 ? 2 : 1);      // (a cohort table that cannot be built screens its samples one by one)
+            if (uses == 1) ro.expected_screens = 1;
+            const int32_t rc = kcfx_ref_create_opts(wk.device, kmer_length, text + t_lo, t_hi - t_lo, wb.data(), win_len + lo, nw, &ro, &ref_hold.p);
             wk.t_ref += now_s() - t;
             ref_hold.lo = lo;
             ref_hold.hi = hi;

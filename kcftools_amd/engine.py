@@ -25,7 +25,7 @@ assert RESULT_DTYPE.itemsize == 40
 ABI_SYMBOLS = (
     "kcfx_db_open", "kcfx_db_open_opts", "kcfx_db_build", "kcfx_db_info", "kcfx_db_header", "kcfx_db_lookup", "kcfx_db_close",
     "kcfx_release_cached",
-    "kcfx_ref_create", "kcfx_ref_n_windows", "kcfx_ref_n_kmer_slots", "kcfx_ref_destroy",
+    "kcfx_ref_create", "kcfx_ref_create_opts", "kcfx_ref_n_windows", "kcfx_ref_n_kmer_slots", "kcfx_ref_destroy",
     "kcfx_screen_ref", "kcfx_screen_ref_async", "kcfx_screen_ref_multi", "kcfx_screen_ref_multi_async", "kcfx_screen",
     "kcfx_ref_reserve_multi",
     "kcfx_cohort_open", "kcfx_cohort_info", "kcfx_cohort_close", "kcfx_cohort_screen_ref", "kcfx_cohort_screen_ref_async",
@@ -56,6 +56,10 @@ class ShardStats(C.Structure):
 
 SHARD_AUTO, SHARD_SAMPLES, SHARD_WINDOWS, SHARD_GRID, SHARD_COHORT = 0, 1, 2, 3, 4
 COHORT_MAX = 8
+
+
+class RefOpts(C.Structure):
+    _fields_ = [("expected_screens", C.c_int32), ("reserved", C.c_int32)]
 
 
 class DbOpts(C.Structure):
@@ -128,6 +132,7 @@ def lib() -> C.CDLL:
         L.kcfx_db_close.restype = None
         L.kcfx_release_cached.argtypes = [i32]
         L.kcfx_ref_create.argtypes = [i32, i32, vp, i64, vp, vp, i32, C.POINTER(vp)]
+        L.kcfx_ref_create_opts.argtypes = [i32, i32, vp, i64, vp, vp, i32, C.POINTER(RefOpts), C.POINTER(vp)]
         L.kcfx_ref_n_windows.argtypes = [vp]
         L.kcfx_ref_n_kmer_slots.argtypes = [vp]
         L.kcfx_ref_n_kmer_slots.restype = i64
@@ -312,14 +317,17 @@ class Cohort:
 class Reference:
     """Reference text + window list resident in HBM (GetVariants.java:117-121 windows, :188-197 window text)."""
 
-    def __init__(self, text: bytes, win_begin, win_len, k: int, device: int = 0):
+    def __init__(self, text: bytes, win_begin, win_len, k: int, device: int = 0, expected_screens: int = 0):
+        """expected_screens = 1: ONE database will be screened against this reference -- it stays text only and the screening
+        launch plans its tiles itself (kcfx_ref_opts); 0: planned once for any number of passes."""
         wb = np.ascontiguousarray(win_begin, dtype=np.int64)
         wl = np.ascontiguousarray(win_len, dtype=np.int32)
         assert len(wb) == len(wl)
         buf = np.frombuffer(text, dtype=np.uint8)
         self._h = C.c_void_p()
-        _check(lib().kcfx_ref_create(device, k, buf.ctypes.data if len(buf) else None, len(buf), wb.ctypes.data,
-                                     wl.ctypes.data, len(wb), C.byref(self._h)))
+        opts = RefOpts(int(expected_screens), 0)
+        _check(lib().kcfx_ref_create_opts(device, k, buf.ctypes.data if len(buf) else None, len(buf), wb.ctypes.data,
+                                          wl.ctypes.data, len(wb), C.byref(opts), C.byref(self._h)))
         self.n_windows = len(wb)
         self.n_kmer_slots = lib().kcfx_ref_n_kmer_slots(self._h)
         self.device = device

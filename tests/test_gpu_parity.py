@@ -715,6 +715,18 @@ def test_planned_reference_and_text_only_reference_agree(oracle, tmp_path, monke
         a, b = planned.screen(db, mc), text_only.screen(db, mc)
         assert_same(a, b, f"planned vs text-only, -c {mc}")
     assert_same(planned.screen(db, 1), want, "planned vs oracle")
+    # kcfx_ref_create_opts: a caller that will screen exactly ONE database says so and the reference stays text only (the plan
+    # would be written and read once); any other count plans as kcfx_ref_create does. The environment variable overrides both.
+    assert planned.planned and not text_only.planned
+    single = engine.Reference(ref, begins, lens, k, expected_screens=1)
+    many = engine.Reference(ref, begins, lens, k, expected_screens=8)
+    assert not single.planned and many.planned
+    assert_same(single.screen(db, 1), want, "expected_screens=1 vs oracle")
+    assert_same(many.screen(db, 1), want, "expected_screens=8 vs oracle")
+    assert_same(db.screen(ref, begins, lens, 1), want, "one-shot kcfx_screen (text only) vs oracle")
+    monkeypatch.setenv("KCFX_REF_PLAN", "1")
+    assert engine.Reference(ref, begins, lens, k, expected_screens=1).planned
+    monkeypatch.delenv("KCFX_REF_PLAN")
 
 
 def test_planned_reference_at_the_text_lengths_where_its_arrays_end(oracle, tmp_path):
