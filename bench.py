@@ -694,6 +694,12 @@ def main():
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    # a number measured on results that differ from the oracle's (or on two forms of the kernel that disagree) is not a
+    # measurement: the line above says so ("parity", "identical_to_planned"), and so does the exit code
+    wrong = (parity is not None and not parity["bit_exact"]) or (text_only is not None and not text_only["identical_to_planned"])
+    if wrong:
+        log("bench.py: PARITY FAILURE -- the line above is not a valid measurement")
+        sys.exit(3)
 
 
 if __name__ == "__main__":

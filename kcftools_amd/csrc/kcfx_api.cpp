@@ -563,12 +563,15 @@ void ref_free(kcfx_ref* r) {
 
 // KCFX_LOAD_TRACE=1: phase timings of kcfx_db_open on stderr
 struct LoadTrace {
+    const char* tag = "load";
     bool on = getenv("KCFX_LOAD_TRACE") != nullptr;
     double t = now_s();
+    LoadTrace() = default;
+    LoadTrace(const char* tag_, const char* env) : tag(tag_), on(getenv(env) != nullptr) {}
     void mark(const char* what) {
         if (!on) return;
         const double n = now_s();
-        fprintf(stderr, "[kcfx load] %-28s %8.1f ms\n", what, (n - t) * 1e3);
+        fprintf(stderr, "[kcfx %s] %-28s %8.1f ms\n", tag, what, (n - t) * 1e3);
         t = n;
     }
 };
@@ -1101,6 +1104,7 @@ int32_t kcfx_ref_create_opts(int32_t device, int32_t kmer_length, const uint8_t*
     if (plan_env) planned = planned && plan_env[0] != '0';
     if (plan_env && plan_env[0] == '1') planned = cell_k && text_len > 0;
     const int64_t tile_k = (cell_k && !planned) ? TEXT_TILE_K : TILE_K;
+    LoadTrace trace("ref", "KCFX_REF_TRACE");               // KCFX_REF_TRACE=1: phase timings on stderr
     // tile plan: every window is cut into near-equal tiles of <= tile_k k-mer start positions (multiples of 64)
     std::vector<TileDesc> tiles;
     std::vector<int32_t> win_tile0((size_t)n_windows + 1, 0);
@@ -1125,6 +1129,7 @@ int32_t kcfx_ref_create_opts(int32_t device, int32_t kmer_length, const uint8_t*
         if (tiles.size() > 0x7FFFFFF0u) return fail(KCFX_ERR_ARG, "too many tiles");
     }
     win_tile0[(size_t)n_windows] = (int32_t)tiles.size();
+    trace.mark("tile list (host)");
 
     if (int32_t rc = check_device(device)) return rc;
     DeviceGuard g(device);
@@ -1155,6 +1160,7 @@ int32_t kcfx_ref_create_opts(int32_t device, int32_t kmer_length, const uint8_t*
         (!tiles.empty() && (e = hipMemcpyAsync(r->d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, r->stream)) != hipSuccess) ||
         (e = hipMemcpyAsync(r->d_win_tile0, win_tile0.data(), win_tile0.size() * 4, hipMemcpyHostToDevice, r->stream)) != hipSuccess)
         return hip_fail(e, "kcfx_ref_create");
+    trace.mark("allocations + copies queued");
     if (planned) {                                          // on the same stream, behind the text upload
         r->d_anchors = r->d_text + text_alloc;
         r->d_codes = reinterpret_cast<uint32_t*>(r->d_text + text_alloc + ab);
@@ -1162,6 +1168,7 @@ int32_t kcfx_ref_create_opts(int32_t device, int32_t kmer_length, const uint8_t*
             return hip_fail(e, "kcfx_ref_create (reference plan)");
     }
     if ((e = hipStreamSynchronize(r->stream)) != hipSuccess) return hip_fail(e, "kcfx_ref_create");
+    trace.mark(planned ? "uploads + plan done" : "uploads done");
     *out = hold.release();
     return KCFX_OK;
 } KCFX_CATCH("kcfx_ref_create_opts")

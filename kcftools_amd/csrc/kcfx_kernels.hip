@@ -1251,28 +1251,6 @@ __device__ __forceinline__ u32x4n nt_load4(const void* p) {
     typedef const __attribute__((address_space(1))) u32x4n* gp;
     return __builtin_nontemporal_load((gp)(uint64_t)p);
 }
-// The cell load of the word loop, issued and waited for BY HAND. The compiler counts outstanding loads per path; the word loop has
-// conditional loads inside (the deferred rounds), so at the loop header its count is "unknown" and the first use in the body got
-// s_waitcnt vmcnt(0): once per CELLS_PIPE words the whole pipeline drained (round 4 listing). An asm load is invisible to that pass;
-// cells_wait<N> is the wait -- "at most N loads issued after this one are still out" -- and carries the loaded registers through
-// itself so that no use can be scheduled above it. Loads retire in issue order, so loads the compiler tracks by itself (the deferred
-// rounds') only ever make either kind of wait longer, never too short.
-__device__ __forceinline__ u32x2 nt_load2_untracked(const void* p) {
-    u32x2 v;
-    asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(v) : "v"(p));
-    return v;
-}
-template <int N>
-__device__ __forceinline__ void cells_wait(u32x2& cell) {
-    static_assert(N >= 0 && N <= 7, "s_waitcnt vmcnt");
-    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(cell) : "n"(N));
-}
-__device__ __forceinline__ void cells_wait_n(u32x2& cell, int n) {      // n wave-uniform: the tail of a wave's words
-    if (n >= 3) cells_wait<3>(cell);
-    else if (n == 2) cells_wait<2>(cell);
-    else if (n == 1) cells_wait<1>(cell);
-    else cells_wait<0>(cell);
-}
 
 struct CellWord {
     uint64_t V;            // valid lanes
@@ -1281,16 +1259,13 @@ struct CellWord {
     uint32_t r_alt;        // (k <= 30 only) what the r field of its free-cell entry must be (cell_alt_of)
     u32x2 cell, alt;       // what its first-choice cell and (k <= 30 only) its free cell hold
 };
-constexpr uint32_t QUEUE_ANCHOR_SHIFT = 16;
-#ifndef KCFX_HAND_WAITS
-#define KCFX_HAND_WAITS 1
-#endif                 // queue id = (word of the wave << 6) | lane | anc << 16
+constexpr uint32_t QUEUE_ANCHOR_SHIFT = 16;                 // queue id = (word of the wave << 6) | lane | anc << 16
 
 // stage A: the load of every lane's cell (k <= 30: and of its free cell in the same line), issued and not waited for. The same
 // load instructions for every word, every lane active (an invalid lane reads line 0): the compiler can then count what is
 // in flight -- s_waitcnt vmcnt(n) where word w is consumed while word w + 1's loads stay out -- instead of falling back to
 // vmcnt(0) as it must around a conditional load.
-template <int W, bool BOTH, bool UNTRACKED = false>
+template <int W, bool BOTH>
 __device__ __forceinline__ void cells_issue(const TableView& tv, uint64_t V, const CellProbe& p, uint32_t anc, CellWord& cw) {
     const bool valid = __builtin_amdgcn_inverse_ballot_w64(V);
     cw.V = V;
@@ -1308,7 +1283,7 @@ __device__ __forceinline__ void cells_issue(const TableView& tv, uint64_t V, con
     // compiler cannot count in vmcnt and waits for with vmcnt(0) -- the end of the software pipeline)
     // (k = 31 only: with a second load of the same line behind it -- the free cell of k < 31 -- the hint costs that load its hit:
     // k = 25, 0.131 ms with it, 0.121 ms without)
-    if constexpr (W > CELL_ALT_FREE_MAX_W) cw.cell = UNTRACKED ? nt_load2_untracked(a0) : nt_load2(a0);
+    if constexpr (W > CELL_ALT_FREE_MAX_W) cw.cell = nt_load2(a0);
     else cw.cell = *reinterpret_cast<const u32x2*>(a0);
     if constexpr (W <= CELL_ALT_FREE_MAX_W) {
         // (on a table without the free-cell scheme this reads some cell of the line and cells_match ignores it)
@@ -1618,7 +1593,6 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
     const uint8_t* __restrict__ text, RefPlan plan, const TileDesc* __restrict__ tiles, TableView tv, int32_t min_count,
     uint64_t* __restrict__ bits, int64_t* __restrict__ count_sums) {
     constexpr int WAVES = CELLS_WAVES;                      // (this kernel's own workgroup shape: kcfx_internal.h)
-    constexpr bool HAND_WAITS = KCFX_HAND_WAITS != 0 && cell_nw(K) > CELL_ALT_FREE_MAX_W;     // (cells_wait: see nt_load2_untracked)
     using Lds = K31Plan;
     __shared__ Lds sh;
     // (a text-only reference is planned tile by tile: the planner's exchange rows are dead before the queues are first written)
@@ -1661,14 +1635,10 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
         uint64_t N, V;
         uint32_t sh2, fm;
         words.next(w, N, sh2, fm, V);
-        cells_issue<cell_nw(K), BOTH, HAND_WAITS>(tv, V, cell_probe_planned<BOTH>(N, sh2, fm, tv.lbits, tv.ext), sh2 | (fm & 1u), cw);
+        cells_issue<cell_nw(K), BOTH>(tv, V, cell_probe_planned<BOTH>(N, sh2, fm, tv.lbits, tv.ext), sh2 | (fm & 1u), cw);
     };
     // stage B of word w: cells matched, ballots out, stash candidates queued
-    auto retire = [&](int w, CellWord& cw, int later) {     // later = cell loads issued after this word's (wave-uniform; < 0: the steady state's D - 1)
-        if constexpr (HAND_WAITS) {
-            if (later < 0) cells_wait<(CELLS_PIPE - 1 < 7 ? CELLS_PIPE - 1 : 7)>(cw.cell);
-            else cells_wait_n(cw.cell, later);
-        }
+    auto retire = [&](int w, const CellWord& cw) {
         uint32_t cnt = 0, pend = 0;
         cells_match<BOTH, cell_nw(K)>(cw, tv.lbits, cnt, pend);
         // cnt is 0 unless the k-mer was found and min_count >= 1 (checked by the API), so this is "found && count >= -c"
@@ -1704,13 +1674,13 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             issue(base + i + D - 1, cw[(i + D - 1) % D]);
-            retire(base + i, cw[i], -1);
+            retire(base + i, cw[i]);
         }
     }
 #pragma unroll
     for (int i = 0; i < 2 * D - 2; ++i) {
         if (base + i + D - 1 < w_end) issue(base + i + D - 1, cw[(i + D - 1) % D]);
-        if (base + i < w_end) retire(base + i, cw[i % D], min(D - 1, w_end - 1 - (base + i)));
+        if (base + i < w_end) retire(base + i, cw[i % D]);
     }
     while (qn > 0) qn = k31c_deferred_round<K, BOTH>(tv, sh, q.id, lane, qn, pos0, found);
     if (lane < w_end - w_begin) {                           // the wave's words of the window's bitmap

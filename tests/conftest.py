@@ -29,3 +29,34 @@ def _native_pieces_built():
     if os.environ.get("KCFX_LIB") is None and not all(os.path.exists(p) for p in need):
         import __graft_entry__ as g
         g.build()
+
+
+@pytest.fixture(autouse=True)
+def _one_shot_screens_take_both_reference_forms(request, monkeypatch):
+    """kcfx_screen keeps its one-shot reference as text (the screening launch plans its tiles itself); a resident reference
+    is planned once by ref_plan_kernel. Two kernels for the same answer: in the GPU suites every KmcDb.screen(...) call also
+    screens a planned Reference of the same text and windows and must get the identical records -- so every parity case
+    written against the one-shot call covers both forms."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import numpy as np
+    from kcftools_amd import engine
+    one_shot = engine.KmcDb.screen
+
+    def screen(self, text, win_begin, win_len, min_count=1):
+        got = one_shot(self, text, win_begin, win_len, min_count)
+        if len(text) > 2_000_000_000:                       # (the wheat-scale cases: their memory is budgeted for one reference)
+            return got
+        ref = engine.Reference(text, win_begin, win_len, self.info.kmer_length, device=self.info.device, expected_screens=0)
+        try:
+            if 19 <= self.info.kmer_length <= 31 and len(text) > 0 and "KCFX_REF_PLAN" not in os.environ:
+                assert ref.planned
+            planned = ref.screen(self, min_count)
+        finally:
+            ref.close()
+        assert np.array_equal(got, planned), "one-shot (text-only) and planned reference disagree"
+        return got
+
+    monkeypatch.setattr(engine.KmcDb, "screen", screen)
+    yield

@@ -8,6 +8,6 @@ for i in $(seq 1 $N); do
     env $L $AB_ENV python3 bench.py --cpu-baseline-seconds 0 --no-end-to-end $AB_ARGS 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('$l $AB_ENV', 'kernel_ms', round(d['roofline']['kernel_avg_ms'],5), 'step_ms', round(d['ms_per_step'],5), 'Gkmers/s', round(d['value']/1e9,1), 'frac', round(d['roofline']['frac'],4), 'box', (d.get('box') or {}).get('G_lines_per_s'))"
+print('$l $AB_ENV', 'kernel_ms', round(d['roofline']['kernel_avg_ms'],5), 'step_ms', round(d['ms_per_step'],5), 'Gkmers/s', round(d['value']/1e9,1), 'frac', round(d['roofline']['frac'],4), 'box', (d.get('box') or {}).get('G_lines_per_s'), 'text_only==planned', (d.get('text_only_reference') or {}).get('identical_to_planned'))"
   done
 done
