@@ -39,9 +39,11 @@ void log_line(const char* level, const std::string& msg) {
 }
 void info(const std::string& m) { log_line("INFO", m); }
 void warning(const std::string& m) { log_line("WARNING", m); }
+std::thread* g_background = nullptr;       // the GPU runtime coming up (main): joined before the process exits on an error
 [[noreturn]] void error(const std::string& m) {
     log_line("ERROR", m);
-    std::exit(1);
+    if (g_background && g_background->joinable()) g_background->join();
+    std::exit(1);                           // Logger.java:29-31
 }
 
 struct Options {
@@ -87,6 +89,15 @@ int main(int argc, char** argv) {
         usage();
         return 2;
     }
+    // KCFX_CLI_TRACE=1: wall time of every phase of the run on stderr
+    const bool trace_on = std::getenv("KCFX_CLI_TRACE") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!trace_on) return;
+        const auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[kcftools-amd] %-34s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     Options o;
     std::string cmdline = "kcftools-amd";
     for (int i = 1; i < argc; ++i) cmdline += std::string(" ") + argv[i];
@@ -160,6 +171,18 @@ int main(int argc, char** argv) {
     o.sample = sample_list[0];
     for (size_t i = 1; i < sample_list.size(); ++i) o.sample += "\t" + sample_list[i];    // #CHROM line columns
 
+    // The GPU runtime takes ~0.1 s to come up (kcfx_ctx_create is the process's first HIP call): it does so on its own thread while
+    // this one reads the .kmc_pre header, the FASTA index and the windows' text
+    std::vector<int32_t> devices(o.devices.begin(), o.devices.end());
+    kcfx_ctx* ctx = nullptr;
+    int32_t ctx_rc = 0;
+    std::string ctx_err;
+    std::thread ctx_thread([&] {
+        ctx_rc = kcfx_ctx_create(devices.data(), (int32_t)devices.size(), &ctx);
+        if (ctx_rc) ctx_err = kcfx_last_error();             // (the message is thread-local)
+    });
+    g_background = &ctx_thread;                              // (error() exits the process: not with this thread inside HIP)
+
     // new KMC(prefix, loadMemory) (:95): the header now (k for the windows and the KCF header, :96,:103); the records are
     // loaded onto the GPUs by kcfx_screen_sharded, each database while the previous one is being screened
     kcfx_db_info_t dbi;
@@ -167,9 +190,11 @@ int main(int argc, char** argv) {
     const int k = dbi.kmer_length;
     info("KMC database: k=" + std::to_string(k) + ", " + std::to_string(dbi.total_kmers) + " k-mers");
 
+    mark("options + .kmc_pre header");
     FastaIndex index;
     std::string err;
     if (!index.open(o.ref, err)) error(err);
+    mark("FASTA index");
     Gtf gtf;
     const bool targeted = o.feature != "window";
     if (targeted && !gtf.parse(o.gtf, err)) error(err);
@@ -239,6 +264,7 @@ int main(int argc, char** argv) {
         per_contig.emplace_back(first, wins.size());
     }
     info("Number of windows: " + std::to_string(wins.size()));
+    mark("windows + their text");
 
     // the hot path: one call instead of the thread pool (:129-159)
     const int32_t n = (int32_t)wins.size();
@@ -260,15 +286,17 @@ int main(int argc, char** argv) {
     // counters, mixed strandedness, no room) is screened sample by sample inside the same call.
     if (o.cohort_table && S >= 2) o.shard = KCFX_SHARD_COHORT;
     {
-        std::vector<int32_t> devices(o.devices.begin(), o.devices.end());
         std::vector<const char*> prefixes;
         for (const auto& p : kmc_list) prefixes.push_back(p.c_str());
-        kcfx_ctx* ctx = nullptr;
-        if (kcfx_ctx_create(devices.data(), (int32_t)devices.size(), &ctx)) error(kcfx_last_error());
+        ctx_thread.join();
+        g_background = nullptr;
+        if (ctx_rc) error(ctx_err);
+        mark("kcfx_ctx_create (rest of)");
         kcfx_shard_stats st;
         const int32_t rc = kcfx_screen_sharded(ctx, prefixes.data(), (int32_t)S, k, reinterpret_cast<const uint8_t*>(text.data()),
                                                (int64_t)text.size(), wb.data(), wl.data(), n, o.min_count, o.shard, all.data(), &st);
         const std::string msg = rc ? kcfx_last_error() : "";
+        mark("kcfx_screen_sharded");
         kcfx_ctx_destroy(ctx);
         if (rc) error(msg);
         char line[256];
@@ -306,5 +334,6 @@ int main(int argc, char** argv) {
         }
     }
     out.close();
+    mark("scores + KCF written");
     return 0;
 }
