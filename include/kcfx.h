@@ -93,7 +93,7 @@ typedef struct {
     int64_t second_choice_kmers; /* format 1: k-mers placed outside their first-choice cell (second or third line) */
     int32_t extended;        /* format 1: 1 = the first-choice line of a k-mer depends on the flank bases next to its minimizer too
                                 (databases of >= 0.5 G k-mers whose plain table left > 15 % of them outside their cell) */
-    int32_t _reserved;
+    int32_t regions;         /* format 1: table_lines = regions x 2^n (1, 3, 5 or 7: table sizes between the powers of two for large databases) */
 } kcfx_db_info_t;
 
 /* ---- database ------------------------------------------------------------------------------------ */

@@ -130,13 +130,14 @@ struct kcfx_db {
     bool table_arrived = false;          // table_ready() has succeeded: a later device error is not about the table's size
     int32_t fmt = FORMAT_LINES;          // FORMAT_CELLS: d_lines holds 1 << lbits cell lines, d_stash the overflow k-mers
     int32_t lbits = 0;
+    int32_t regions = 1;                 // FORMAT_CELLS: n_lines = regions << lbits (cell_line_index, kcfx_device.h)
     uint4* d_stash = nullptr;
     uint32_t stash_mask = 0;
     unsigned long long* d_stats = nullptr;   // FORMAT_CELLS build counters (cells_settle_kernel)
     uint32_t* d_pop = nullptr;               // FORMAT_CELLS build scratch: k-mers per minimizer (freed after the build)
     int32_t pop_bits = 32;                   // 2^pop_bits byte counters: 32 = one per minimizer, lbits + 2 when 4 GiB cannot be had
     hipStream_t stream = nullptr;
-    TableView view() const { return TableView{d_lines, n_lines, wide, mode, mm_len, fmt, lbits, stash_mask, d_stash, generic, info.both_strands, ext}; }
+    TableView view() const { return TableView{d_lines, n_lines, wide, mode, mm_len, fmt, lbits, stash_mask, d_stash, generic, info.both_strands, ext, regions}; }
 };
 
 struct kcfx_ref {
@@ -323,7 +324,7 @@ int32_t pop_alloc(kcfx_db* db) {
     // policy: allocating 4 GiB in a fresh process costs ~30 ms of its 0.5 s, the look-ups it saves a fraction of a millisecond.
     // (KCFX_CROWD_PER_LINE=1: the fallback by choice -- test hook, read when the handle is made)
     const bool few = db->expected_queries > 0 && (double)db->expected_queries < QUERIES_FOR_SPARSE;
-    if (!few && getenv("KCFX_CROWD_PER_LINE") == nullptr && free_device_bytes() > ((size_t)LINE_BYTES << db->lbits) + ((size_t)6 << 30))
+    if (!few && getenv("KCFX_CROWD_PER_LINE") == nullptr && free_device_bytes() > ((size_t)LINE_BYTES * db->n_lines) + ((size_t)6 << 30))
         e = dev_alloc(&db->d_pop, cells_pop_bytes(db->pop_bits));
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -358,25 +359,50 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys, bool deferred = false) {
     const bool both = db->info.both_strands != 0;
     int32_t L0 = cells_lbits(n_keys, db->info.kmer_length, both, db->expected_queries, db->line_footprint);
     if (db->lbits_cap > 0) L0 = std::min(L0, db->lbits_cap);
+    // Regions (kcfx_device.h: cell_line_index). Where the caps of cells_lbits left the table above 0.3 k-mers per cell, the space
+    // between this power of two and the next is used in quarters: 1.25 / 1.5 / 1.75 x 2^L0 lines = 5 / 3 / 7 regions of 2^(L0 - 2) /
+    // 2^(L0 - 1) / 2^(L0 - 2) lines -- a table under 48 GiB up to 48 GiB (a 2.1 G-k-mer database: 0.33 per cell instead of 0.49), a
+    // larger one up to 80 % of the free memory (8 G genomic k-mers: 192 GiB, 0.31 per cell instead of 0.47; the stash, the
+    // crowding counters and the streaming buffers of such a build take ~25 GiB beside it). Cohort tables, retries after an allocation that did not fit and KCFX_TABLE_LBITS keep one region;
+    // KCFX_TABLE_REGIONS=R (1, 3, 5, 7; with KCFX_TABLE_LBITS=L: R << L lines) decides by hand (tests, A/B).
+    db->regions = 1;
+    int32_t R = 1, Lr = L0;
+    if (db->line_footprint == LINE_BYTES && db->lbits_cap == 0) {
+        const int32_t lmin = cell_lbits_min(both);
+        if (const char* rs = getenv("KCFX_TABLE_REGIONS")) {
+            const int v = atoi(rs);
+            if ((v == 3 || v == 5 || v == 7) && ((uint64_t)v << L0) < (1ull << 32)) R = v;
+        } else if (getenv("KCFX_TABLE_LBITS") == nullptr && L0 - 2 >= lmin && (double)n_keys > 0.30 * 16.0 * (double)(1ull << L0)) {
+            const double one = (double)(1ull << L0) * LINE_BYTES, gib48 = 48.0 * (double)(1ull << 30);
+            const double limit = one < gib48 ? gib48 : 0.80 * (double)free_device_bytes();   // (a table under 48 GiB grows up to them)
+            for (int q = 7; q >= 5; --q)
+                if (one * q / 4.0 <= limit) {
+                    R = q == 6 ? 3 : q;
+                    Lr = q == 6 ? L0 - 1 : L0 - 2;
+                    break;
+                }
+        }
+    }
     db->alloc_rc = KCFX_OK;
     db->alloc_oom = false;
     db->table_arrived = false;
-    if (deferred && L0 >= cell_lbits_min(both) && (double)n_keys <= 16.0 * (double)(1ull << L0)) {
+    if (deferred && Lr >= cell_lbits_min(both) && (double)n_keys <= 16.0 * (double)((uint64_t)R << Lr)) {
         // the policy's size, allocated and cleared beside the file streaming; if it does not fit, kcfx_db_open starts over
         // with denser tables, synchronously
-        db->lbits = L0;
-        db->n_lines = 1u << L0;
+        db->lbits = Lr;
+        db->regions = R;
+        db->n_lines = (uint32_t)R << Lr;
         KCFX_HIP(dev_alloc(&db->d_stats, 4 * sizeof(unsigned long long)));
         KCFX_HIP(hipMemsetAsync(db->d_stats, 0, 4 * sizeof(unsigned long long), db->stream));
         if (int32_t rc = pop_alloc(db)) return rc;
-        db->info.table_bytes = (int64_t)LINE_BYTES << db->lbits;
+        db->info.table_bytes = (int64_t)LINE_BYTES * (int64_t)db->n_lines;
         db->info.table_lines = db->n_lines;
         db->info.slots_per_line = 16;
         db->alloc_thread = std::thread([db]() {
             try {
                 hipError_t e2 = hipSetDevice(db->device);
-                if (e2 == hipSuccess) e2 = dev_alloc(&db->d_lines, (size_t)LINE_BYTES << db->lbits);
-                if (e2 == hipSuccess) e2 = hipMemsetAsync(db->d_lines, 0, (size_t)LINE_BYTES << db->lbits, db->stream);
+                if (e2 == hipSuccess) e2 = dev_alloc(&db->d_lines, (size_t)LINE_BYTES * db->n_lines);
+                if (e2 == hipSuccess) e2 = hipMemsetAsync(db->d_lines, 0, (size_t)LINE_BYTES * db->n_lines, db->stream);
                 if (e2 != hipSuccess) {
                     db->alloc_oom = (e2 == hipErrorOutOfMemory);
                     db->alloc_rc = KCFX_ERR_DEVICE;
@@ -390,7 +416,17 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys, bool deferred = false) {
         });
         return KCFX_OK;
     }
-    for (int32_t L = L0; L >= cell_lbits_min(both); --L) {
+    if (R > 1 && (double)n_keys <= 16.0 * (double)((uint64_t)R << Lr)) {       // the regions first; if they do not fit: powers of two
+        e = dev_alloc(&db->d_lines, ((size_t)LINE_BYTES * R) << Lr);
+        if (e == hipSuccess) {
+            db->lbits = Lr;
+            db->regions = R;
+        } else {
+            (void)hipGetLastError();
+            db->d_lines = nullptr;
+        }
+    }
+    for (int32_t L = L0; e != hipSuccess && L >= cell_lbits_min(both); --L) {
         if ((double)n_keys > 16.0 * (double)(1ull << L))            // fewer cells than k-mers: not a cell table any more
             return fail(KCFX_ERR_DEVICE, "no cell table of 2^" + std::to_string(L) + " or more lines fits the device memory (or KCFX_TABLE_LBITS)");
         e = dev_alloc(&db->d_lines, (size_t)LINE_BYTES << L);
@@ -403,12 +439,12 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys, bool deferred = false) {
         break;
     }
     if (e != hipSuccess) return hip_fail(e, "hipMalloc of the k-mer table");
-    db->n_lines = 1u << db->lbits;
-    KCFX_HIP(hipMemsetAsync(db->d_lines, 0, (size_t)LINE_BYTES << db->lbits, db->stream));
+    db->n_lines = (uint32_t)db->regions << db->lbits;
+    KCFX_HIP(hipMemsetAsync(db->d_lines, 0, (size_t)LINE_BYTES * db->n_lines, db->stream));
     KCFX_HIP(dev_alloc(&db->d_stats, 4 * sizeof(unsigned long long)));
     KCFX_HIP(hipMemsetAsync(db->d_stats, 0, 4 * sizeof(unsigned long long), db->stream));
     if (int32_t rc = pop_alloc(db)) return rc;
-    db->info.table_bytes = (int64_t)LINE_BYTES << db->lbits;
+    db->info.table_bytes = (int64_t)LINE_BYTES * (int64_t)db->n_lines;
     db->info.table_lines = db->n_lines;
     db->info.slots_per_line = 16;
     return KCFX_OK;
@@ -427,6 +463,7 @@ int32_t cells_stash_alloc(kcfx_db* db) {
     db->info.multi_cell_kmers = (int64_t)h[2];
     db->info.second_choice_kmers = (int64_t)h[3];
     db->info.extended = db->ext;
+    db->info.regions = db->regions;
     const size_t free_b = free_device_bytes();
     double budget = 0.5 * (double)free_b;
     if (const char* s = getenv("KCFX_STASH_BUDGET")) budget = std::max(0.0, atof(s));
@@ -458,6 +495,7 @@ void table_release(kcfx_db* db) {
     db->d_pop = nullptr;
     db->fmt = FORMAT_LINES;
     db->lbits = 0;
+    db->regions = 1;
     db->stash_mask = 0;
     db->n_lines = 0;
     db->info.table_format = FORMAT_LINES;
@@ -635,7 +673,7 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     // keep every decoded record resident between the phases?
     size_t free_b = free_device_bytes();
     // (the table may still be on its way -- table_ready -- and must not be counted as free room: conservative when it has arrived)
-    if (db->alloc_thread.joinable()) free_b -= std::min<size_t>(free_b, (size_t)LINE_BYTES << db->lbits);
+    if (db->alloc_thread.joinable()) free_b -= std::min<size_t>(free_b, (size_t)LINE_BYTES * db->n_lines);
     const bool resident = two_phase && getenv("KCFX_LOAD_STREAM_TWICE") == nullptr &&
                           (double)h.total * 12.0 + (double)(2 * chunk_bytes) + (double)(64 << 20) < 0.5 * (double)free_b;
     const int64_t n_chunk_max = std::min<int64_t>(CH, std::max<int64_t>(h.total, 1));
@@ -671,9 +709,9 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
             if (phase == 0)
                 return pw ? launch_cells_resolve(db->d_pop, db->pop_bits, kk, db->lbits, db->info.both_strands, keys, counts, n, pw, ps, db->stream, db->ext)
                           : launch_cells_count(db->d_pop, db->pop_bits, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream, 0, db->ext);
-            if (phase == 1 || phase == 2) return launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, phase == 1 ? 1 : 0, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream, 0, pw, ps, db->ext);
-            if (phase == 3) return launch_cells_settle(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stats, db->stream, 0, pw, ps, db->ext);
-            return launch_cells_stash(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stash, db->stash_mask, db->stream, 0, pw, ps, db->ext);
+            if (phase == 1 || phase == 2) return launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, phase == 1 ? 1 : 0, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream, 0, pw, ps, db->ext, db->regions);
+            if (phase == 3) return launch_cells_settle(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stats, db->stream, 0, pw, ps, db->ext, db->regions);
+            return launch_cells_stash(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stash, db->stash_mask, db->stream, 0, pw, ps, db->ext, db->regions);
         }
         if (phase == 0) return launch_table_count(db->d_lines, db->view(), h.k, keys, n, db->stream);
         return launch_table_insert(db->d_lines, db->view(), h.k, keys, counts, n, db->stream);
@@ -739,7 +777,7 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
                 constexpr double EXT_MOVED_SHARE = 0.15;
                 if ((double)(st4[0] + st4[3]) > EXT_MOVED_SHARE * (double)std::max<unsigned long long>(st4[1], 1)) {
                     db->ext = 1;                            // start over: lines, counters and statistics cleared, the four passes again
-                    LOAD_HIP(hipMemsetAsync(db->d_lines, 0, (size_t)LINE_BYTES << db->lbits, db->stream));
+                    LOAD_HIP(hipMemsetAsync(db->d_lines, 0, (size_t)LINE_BYTES * db->n_lines, db->stream));
                     LOAD_HIP(hipMemsetAsync(db->d_pop, 0, cells_pop_bytes(db->pop_bits), db->stream));
                     LOAD_HIP(hipMemsetAsync(db->d_stats, 0, 4 * sizeof(unsigned long long), db->stream));
                     tr.mark("plain table: too many k-mers outside their cell");
@@ -921,10 +959,11 @@ int32_t kcfx_db_open_opts(const char* kmc_prefix, int32_t device, const kcfx_db_
     if (rc && db->alloc_thread.joinable()) db->alloc_thread.join();
     // (a denser table helps when the table itself did not fit, or when the streaming's buffers lost the race for the memory to
     // it -- not when a later step failed: a stash that does not fit only grows with a denser table)
-    if (rc == KCFX_ERR_DEVICE && db->fmt == FORMAT_CELLS && db->lbits - 1 >= cell_lbits_min(db->info.both_strands != 0) &&
+    if (rc == KCFX_ERR_DEVICE && db->fmt == FORMAT_CELLS && (db->regions > 1 || db->lbits - 1 >= cell_lbits_min(db->info.both_strands != 0)) &&
         (db->alloc_oom || (db->alloc_rc == KCFX_OK && !db->table_arrived))) {
         // the policy's table did not fit next to what else lives on the device: denser cell tables, allocated synchronously
-        const int32_t cap = db->lbits - 1;
+        // (a table of R regions that did not fit: the power of two below it -- (3 << L) -> 2^(L + 1), (5 | 7) << L -> 2^(L + 2) -- as one region)
+        const int32_t cap = db->regions > 1 ? db->lbits + (db->regions == 3 ? 1 : 2) : db->lbits - 1;
         table_release(db);
         db->lbits_cap = cap;
         rc = table_alloc(db, h.total, h.counter_size, true, false);
@@ -1003,12 +1042,12 @@ int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, 
         if (rc || n == 0) return rc;
         if (db->fmt == FORMAT_CELLS) {
             if ((e = launch_cells_count(db->d_pop, db->pop_bits, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream, 0, db->ext)) != hipSuccess ||
-                (e = launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, 1, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream, 0, nullptr, nullptr, db->ext)) != hipSuccess ||
-                (e = launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, 0, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream, 0, nullptr, nullptr, db->ext)) != hipSuccess ||
-                (e = launch_cells_settle(db->d_lines, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->d_stats, db->stream, 0, nullptr, nullptr, db->ext)) != hipSuccess)
+                (e = launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, 1, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream, 0, nullptr, nullptr, db->ext, db->regions)) != hipSuccess ||
+                (e = launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, 0, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream, 0, nullptr, nullptr, db->ext, db->regions)) != hipSuccess ||
+                (e = launch_cells_settle(db->d_lines, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->d_stats, db->stream, 0, nullptr, nullptr, db->ext, db->regions)) != hipSuccess)
                 return hip_fail(e, "kcfx_db_build insert");
             if ((rc = cells_stash_alloc(db))) return rc;
-            if ((e = launch_cells_stash(db->d_lines, db->info.kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->d_stash, db->stash_mask, db->stream, 0, nullptr, nullptr, db->ext)) != hipSuccess ||
+            if ((e = launch_cells_stash(db->d_lines, db->info.kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->d_stash, db->stash_mask, db->stream, 0, nullptr, nullptr, db->ext, db->regions)) != hipSuccess ||
                 (e = hipStreamSynchronize(db->stream)) != hipSuccess)
                 return hip_fail(e, "kcfx_db_build stash");
         } else {
@@ -1466,9 +1505,9 @@ int32_t kcfx_cohort_open(const char* const* kmc_prefixes, int32_t n_samples, int
             if (phase == 0)
                 e2 = pw ? launch_cells_resolve(db->d_pop, db->pop_bits, k, db->lbits, both, kk, cc, n, pw, ps, db->stream, db->ext)
                         : launch_cells_count(db->d_pop, db->pop_bits, k, db->lbits, both, kk, cc, n, db->stream, 1, db->ext);
-            else if (phase == 1 || phase == 2) e2 = launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, phase == 1 ? 1 : 0, k, db->lbits, both, kk, cc, n, db->stream, 1, pw, ps, db->ext);
-            else if (phase == 3) e2 = launch_cells_settle(db->d_lines, k, db->lbits, both, kk, cc, n, db->d_stats, db->stream, 1, pw, ps, db->ext);
-            else e2 = launch_cells_stash(db->d_lines, k, db->lbits, both, kk, cc, n, db->d_stash, db->stash_mask, db->stream, 1, pw, ps, db->ext);
+            else if (phase == 1 || phase == 2) e2 = launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, phase == 1 ? 1 : 0, k, db->lbits, both, kk, cc, n, db->stream, 1, pw, ps, db->ext, db->regions);
+            else if (phase == 3) e2 = launch_cells_settle(db->d_lines, k, db->lbits, both, kk, cc, n, db->d_stats, db->stream, 1, pw, ps, db->ext, db->regions);
+            else e2 = launch_cells_stash(db->d_lines, k, db->lbits, both, kk, cc, n, db->d_stash, db->stash_mask, db->stream, 1, pw, ps, db->ext, db->regions);
             if (e2 != hipSuccess) return e2;
         }
         return hipSuccess;

@@ -438,6 +438,23 @@ KCFX_HD CellProbe cell_first_ext(const CellProbe& p, int32_t lbits) {
     return q;
 }
 
+// TABLES OF R x 2^lbits LINES (TableView::regions = R; round 4). A table of 2^lbits lines doubles or halves; between 48 GiB and what
+// a device holds that is the difference between 0.47 and 0.94 k-mers per cell (an 8 G-k-mer genomic database: 4 % or 18 % of it in
+// the stash, 176 or 102 G k-mers/s). With R > 1 the table is R regions of 2^lbits lines: everything that identifies a k-mer --
+// line = top lbits of G32, r = the rest, second and third lines, filter bits -- is as in a table of 2^lbits lines, and only the
+// ADDRESS of a line gets a region in front of it, chosen by a hash of the same 32 bits (so the k-mers of a run, and the losers of
+// a minimizer in their second line, still share their line). R = 3 on lbits - 1 is 1.5 x 2^lbits lines, R = 5 / 7 on lbits - 2
+// are 1.25 / 1.75 x. Costs the query one multiply-high behind a wave-uniform branch.
+KCFX_HD uint32_t cell_region_of(uint32_t g, uint32_t regions) {
+    const uint32_t h = (g ^ (g >> 15)) * 0x2C1B3C6Du;
+    return (uint32_t)(((uint64_t)(h ^ (h >> 12)) * regions) >> 32);
+}
+KCFX_HD uint32_t cell_line_index(uint32_t line, uint32_t r, int32_t lbits, int32_t regions) {
+    if (regions <= 1) return line;
+    const uint32_t g = (line << (32 - lbits)) | (r & (0xFFFFFFFFu >> lbits));
+    return (cell_region_of(g, (uint32_t)regions) << lbits) | line;
+}
+
 // Query side, one lane: F / R = the k-mer as the text reads it and its reverse complement, mn = the tagged minimum over
 // the k-mer's 16 M-mers, lane = this lane's position label base (order27_tagged was fed (lane + offset) & 15).
 // (lane2 = 2 * position, what order27_label2 was fed -- mod 32 is enough)

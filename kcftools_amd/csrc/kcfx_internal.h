@@ -68,8 +68,9 @@ constexpr int MODE_KEYHASH = 0, MODE_MINIMIZER = 1;
 //   the k-mer. Which 16-mer of a k-mer is its minimizer: the smallest under an order that puts open syncmers first
 //   (cell_order27: 0.097 minimizer runs per k-mer instead of 0.118). When several k-mers want one cell, a k-mer whose minimizer
 //   is shared by >= 3 k-mers of the database (the genome's runs -- what a reference window asks for) beats an isolated one, then
-//   the larger counter wins (64-bit atomic max: deterministic, and in a real database the genomic k-mer beats its
-//   sequencing-error neighbours, which share its minimizer and offset). A loser takes, in this order: (a retired build-time
+//   a counter >= 2 one of 1, then the k-mer of the higher-ranked RUN (a hash of the minimizer: where two runs share a line one of
+//   them keeps every contested cell -- cell_bid, kcfx_kernels.hip), then the larger counter (64-bit atomic max: deterministic, and
+//   in a real database the genomic k-mer beats its sequencing-error neighbours, which share its minimizer and offset). A loser takes, in this order: (a retired build-time
 //   option, KCFX_ALT_FREE_MAX_W: for k < 31 a free cell W .. 15 of the same line;) the same cell of its SECOND LINE (top lbits of G32' = a second bijection of the
 //   minimizer, r from G32' with bit 15 set: cell_second_line) -- the losers of a minimizer meet again there, one request for
 //   all of them; (round 4, tables with >= 3 spare r bits) the same cell of its THIRD LINE -- chosen by the minimizer AND the three
@@ -95,12 +96,13 @@ struct TableView {
     int32_t mode;        // MODE_KEYHASH / MODE_MINIMIZER
     int32_t mm_len;      // M (minimizer length, <= min(k, 32)); unused in MODE_KEYHASH
     int32_t fmt;         // FORMAT_LINES (above) / FORMAT_CELLS
-    int32_t lbits;       // FORMAT_CELLS: n_lines == 1 << lbits
+    int32_t lbits;       // FORMAT_CELLS: n_lines == regions << lbits
     uint32_t stash_mask; // FORMAT_CELLS: stash slots - 1 (a power of two)
     const uint4* stash;
     int32_t generic;     // screen with the general kernel whatever k / M (test and A/B hook, fixed when the handle is made)
     int32_t both;        // the database is canonical (both strands); 0: k-mers are looked up as the text reads them
     int32_t ext;         // FORMAT_CELLS: an extended table -- the first-choice line depends on the flank too (cell_first_ext, kcfx_device.h)
+    int32_t regions;     // FORMAT_CELLS: 1, or R regions of 2^lbits lines each (cell_line_index, kcfx_device.h)
 };
 
 // ----------------------------------------------------------------------------------------------------
@@ -295,11 +297,11 @@ hipError_t launch_cells_count(uint32_t* pop32, int32_t pop_bits, int32_t k, int3
 hipError_t launch_cells_resolve(uint32_t* pop32, int32_t pop_bits, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
                                 uint64_t* pw, uint8_t* ps, hipStream_t st, int32_t ext = 0);
 hipError_t launch_cells_insert(uint8_t* lines, const uint32_t* pop32, int32_t pop_bits, int32_t cls, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys,
-                               const uint32_t* counts, int64_t n, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr, int32_t ext = 0);
+                               const uint32_t* counts, int64_t n, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr, int32_t ext = 0, int32_t regions = 1);
 hipError_t launch_cells_settle(uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                               unsigned long long* stats, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr, int32_t ext = 0);
+                               unsigned long long* stats, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr, int32_t ext = 0, int32_t regions = 1);
 hipError_t launch_cells_stash(const uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                              uint4* stash, uint32_t stash_mask, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr, int32_t ext = 0);
+                              uint4* stash, uint32_t stash_mask, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr, int32_t ext = 0, int32_t regions = 1);
 // cohort tables: one sample's counters into the finished key table; S samples screened in one pass (bits / count_sums laid out
 // per sample as launch_screen_multi's: sample s at bits + s * n_tiles * TILE_BITS_U64, count_sums + s * n_tiles)
 // phase 0: every record votes for its k-mer in `votes` (2^n slots of 16 bytes, all bytes 0xFF); phase 1: the bid rank of every

@@ -195,11 +195,11 @@ __global__ __launch_bounds__(256) void lookup_kernel(TableView tv, int32_t k, co
 // Who gets a contested cell. A reference window asks for the k-mers of a genome, which come in runs that share their
 // minimizer; an isolated k-mer (a sequencing error, a contaminant) is asked for rarely. So: first the k-mer whose minimizer
 // is shared by more k-mers of the database (class "crowded": >= CELL_CROWD of them in its sub-bucket = line + 2 more bits of
-// the minimizer's mix), then the larger counter. Exactness never depends on this -- it only decides who lives in a cell and
-// who in the stash; on the bench database it halves the stash look-ups of a screening pass.
+// the minimizer's mix), then "seen more than once", then -- round 4 -- the RUN the k-mer belongs to (cell_bid: one run takes every
+// cell two runs contest), then the larger counter. Exactness never depends on this -- it only decides who lives in a cell and
+// who elsewhere; on the bench database the classes halve the stash look-ups of a screening pass.
 constexpr uint32_t CELL_CROWD = 3;
 constexpr uint32_t CELL_COUNT_MAX = 0xFFFFu;                // what the 16-bit count field of a cell holds
-constexpr uint32_t CELL_FLAG_CROWDED = 2u;                  // bit 1 of w: the occupant is of the crowded class
 // The key table of a COHORT (one table for S samples: every sample's records go through the same passes, the counters live
 // beside the cells; presence != 0): the count field of a cell only says "present" (non-zero) and ranks the bids -- a record
 // bids with its own counter, capped at what the field holds, so that the k-mers of the genome (seen depth times in every
@@ -256,7 +256,12 @@ struct RecProbes {
     const uint64_t* pw;     // G32 | flank << 32        (null: nothing was kept -- every pass derives the cells itself)
     const uint8_t* ps;      // cell index | REC_MULTI | REC_FLIP
     int32_t ext;            // the table is an extended one (what is kept is the extended G32: cell_first_ext)
+    int32_t regions;        // the table has R regions of 2^lbits lines (cell_line_index): where a probe's line IS
 };
+// byte address of a probe's cell in the table
+__device__ __forceinline__ size_t cell_byte_at(const CellProbe& p, int32_t lbits, int32_t regions) {
+    return (size_t)cell_line_index(p.line, p.r, lbits, regions) * LINE_BYTES + 4 * p.sh;
+}
 constexpr uint8_t REC_MULTI = 0x10, REC_FLIP = 0x20;
 template <class F>
 __device__ __forceinline__ int record_cells(const RecProbes& rp, int64_t i, uint64_t key, int32_t k, int32_t lbits, bool both, F&& f) {
@@ -300,10 +305,25 @@ __global__ void cells_resolve_kernel(uint32_t* pop32, int32_t pop_bits, int32_t 
     }
 }
 
-// Pass 1 (cls = 1) and pass 2 (cls = 0, after ALL of pass 1): every stored k-mer of the class bids for its first-choice
-// cell(s). Crowded k-mers bid with a 64-bit atomic max -- the count is the most significant field, so the most abundant
-// one gets the cell whatever the arrival order. The others do the same among themselves (a CAS loop), but never replace a
-// crowded occupant.
+// Pass 1 (cls = 1: claim) and pass 2 (cls = 0: write, after ALL of pass 1). Claim: every stored k-mer bids for its first-choice
+// cell(s) with a 64-bit atomic max of its RANK -- not of its cell word: [crowded : 1][counter >= 2 : 1][run : 14][counter : 16]
+// [hash of (w, r) : 32]. "run" is a hash of the minimizer (of G32: line and the identifying bits of r), the same for every k-mer of
+// a minimizer run: where two runs share a line the SAME run wins every cell both want, so a screening pass over the winner's locus
+// finds all of its k-mers at home and only the loser's locus pays the request for a second line (with the counter as the rank both
+// runs lost about half of the contested cells and both loci paid: round 4, profiles/r04_notes.md). "Seen more than once" stays
+// above the run -- the k-mers of the genome keep their cells against a run of sequencing errors whatever the hashes say; a finer
+// counter class would split a run wherever the coverage steps -- and the counter itself below it: among k-mers of ONE minimizer (the alleles of a site, an error and its original:
+// same cell) the most abundant one still wins. Write: a k-mer that finds its own rank in the cell stores its cell word there. Two
+// k-mers with the same rank (a 32-bit hash collision among the bidders of one cell) both store; the pass after this one
+// (cells_settle_kernel) looks at the cell WORDS and treats whoever is not standing in its cell as a loser, so exactness never
+// depends on the bidding.
+__device__ __forceinline__ unsigned long long cell_bid(const CellProbe& p, uint32_t c, bool crowded, int32_t lbits) {
+    const uint32_t g = (p.line << (32 - lbits)) | (p.r & (0xFFFFFFFFu >> lbits));
+    const uint32_t run = (g * 0x9E3779B1u) >> 18;
+    const uint32_t top = ((crowded ? 1u : 0u) << 15) | ((c >= 2u ? 1u : 0u) << 14) | run;
+    const uint32_t idh = ((p.w & ~CELL_FLAG_MASK) * 0x85EBCA6Bu) ^ ((p.r & 0xFFFFu) * 0xC2B2AE35u) ^ (p.sh * 0x27D4EB2Fu);
+    return ((unsigned long long)top << 48) | ((unsigned long long)(c & 0xFFFFu) << 32) | idh;
+}
 __global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__ pop32, int32_t pop_bits, int32_t cls, int32_t k, int32_t lbits, int32_t both,
                                     const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, int64_t n, int32_t presence, RecProbes rp) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -318,19 +338,10 @@ __global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__
                 const uint64_t sub = cell_sub_bucket(p, lbits, pop_bits);
                 crowded = ((pop32[sub >> 2] >> (8 * (uint32_t)(sub & 3))) & 0xFFu) >= CELL_CROWD;
             }
-            if ((int32_t)crowded != cls) return;
-            unsigned long long* cell = reinterpret_cast<unsigned long long*>(lines + (size_t)p.line * LINE_BYTES + 4 * p.sh);
-            if (crowded) {
-                atomicMax(cell, (unsigned long long)cell_word(p.w | CELL_FLAG_CROWDED, p.r, c));
-            } else {
-                const unsigned long long mine = cell_word(p.w, p.r, c);
-                unsigned long long old = __atomic_load_n(cell, __ATOMIC_RELAXED);
-                while (!(old & CELL_FLAG_CROWDED) && old < mine) {
-                    const unsigned long long prev = atomicCAS(cell, old, mine);
-                    if (prev == old) break;
-                    old = prev;
-                }
-            }
+            unsigned long long* cell = reinterpret_cast<unsigned long long*>(lines + cell_byte_at(p, lbits, rp.regions));
+            const unsigned long long bid = cell_bid(p, c, crowded, lbits);
+            if (cls) atomicMax(cell, bid);
+            else if (__atomic_load_n(cell, __ATOMIC_RELAXED) == bid) __atomic_store_n(cell, (unsigned long long)cell_word(p.w, p.r, c), __ATOMIC_RELAXED);
         });
     }
 }
@@ -339,9 +350,9 @@ __global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__
 // cell_alt_free), in the same cell of its second line (2) or of its third line (4: cell_third_line), or nowhere (STAND_NONE: the stash)
 constexpr int STAND_FIRST = 0, STAND_FREE = 1, STAND_SECOND_LINE = 2, STAND_NONE = 3, STAND_THIRD_LINE = 4;
 __device__ __forceinline__ int cell_standing(const uint8_t* lines, const CellProbe& p, uint32_t c, int32_t lbits, bool both, int W,
-                                             int32_t presence = 0) {
+                                             int32_t presence = 0, int32_t regions = 1) {
     const uint64_t kc = cell_keycount_mask(lbits, both);              // (flags and filter bits are not part of the k-mer)
-    const uint8_t* line = lines + (size_t)p.line * LINE_BYTES;
+    const uint8_t* line = lines + (size_t)cell_line_index(p.line, p.r, lbits, regions) * LINE_BYTES;
     const uint64_t first = __atomic_load_n(reinterpret_cast<const uint64_t*>(line + 4 * p.sh), __ATOMIC_RELAXED);
     if (cell_same(first, cell_word(p.w, p.r, c), kc, presence)) return STAND_FIRST;
     if (cell_alt_free(W, lbits, both)) {
@@ -350,11 +361,11 @@ __device__ __forceinline__ int cell_standing(const uint8_t* lines, const CellPro
         if (cell_same(second, cell_word(p.w, a.r, c), 0xFFFF0000FFFFFFFCull | ((uint64_t)a.rmask << 32), presence)) return STAND_FREE;
     }
     const CellProbe q = cell_second_line(p, lbits);
-    const uint64_t there = __atomic_load_n(reinterpret_cast<const uint64_t*>(lines + (size_t)q.line * LINE_BYTES + 4 * q.sh), __ATOMIC_RELAXED);
+    const uint64_t there = __atomic_load_n(reinterpret_cast<const uint64_t*>(lines + cell_byte_at(q, lbits, regions)), __ATOMIC_RELAXED);
     if (cell_same(there, cell_word(q.w, q.r, c), kc, presence)) return STAND_SECOND_LINE;
     if (cell_has_third(lbits, both)) {
         const CellProbe t = cell_third_line(p, lbits, both, W);
-        const uint64_t third = __atomic_load_n(reinterpret_cast<const uint64_t*>(lines + (size_t)t.line * LINE_BYTES + 4 * t.sh), __ATOMIC_RELAXED);
+        const uint64_t third = __atomic_load_n(reinterpret_cast<const uint64_t*>(lines + cell_byte_at(t, lbits, regions)), __ATOMIC_RELAXED);
         if (cell_same(third, cell_word(t.w, t.r, c), kc, presence)) return STAND_THIRD_LINE;
     }
     return STAND_NONE;
@@ -377,7 +388,7 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, in
         bool lost = false;
         const bool wide = c > CELL_COUNT_MAX;
         const int nc = record_cells(rp, i, keys[i], k, lbits, both, [&](const CellProbe& p, int) {
-            uint8_t* line = lines + (size_t)p.line * LINE_BYTES;
+            uint8_t* line = lines + (size_t)cell_line_index(p.line, p.r, lbits, rp.regions) * LINE_BYTES;
             unsigned long long mark = CELL_FLAG_STASH;
             if (cell_spare_bits(lbits, both) > 0) mark |= 1ull << (32 + cell_filter_pos(p.w, lbits, both));
             if (wide) {
@@ -385,15 +396,15 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, in
                 // there, or nobody), with its filter bit
                 const CellProbe q = cell_second_line(p, lbits);
                 atomicOr(reinterpret_cast<unsigned long long*>(line + 4 * p.sh), mark);
-                atomicOr(reinterpret_cast<unsigned long long*>(lines + (size_t)q.line * LINE_BYTES + 4 * q.sh), mark);
+                atomicOr(reinterpret_cast<unsigned long long*>(lines + cell_byte_at(q, lbits, rp.regions)), mark);
                 if (cell_has_third(lbits, both)) {
                     const CellProbe t = cell_third_line(p, lbits, both, cell_nw(k));
-                    atomicOr(reinterpret_cast<unsigned long long*>(lines + (size_t)t.line * LINE_BYTES + 4 * t.sh), mark);
+                    atomicOr(reinterpret_cast<unsigned long long*>(lines + cell_byte_at(t, lbits, rp.regions)), mark);
                 }
                 lost = true;
                 return;
             }
-            if (cell_standing(lines, p, c, lbits, both, cell_nw(k), presence) != STAND_NONE) return;   // (already placed: the same word twice in the input)
+            if (cell_standing(lines, p, c, lbits, both, cell_nw(k), presence, rp.regions) != STAND_NONE) return;   // (already placed: the same word twice in the input)
             // an empty cell (count field 0: nobody's first choice landed there, no other loser took it) is taken with a CAS that
             // keeps the flag and filter bits it may carry
             auto take = [&](unsigned long long* cell, unsigned long long mine, unsigned long long kcm) -> bool {
@@ -415,7 +426,7 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, in
             }
             // the same cell of its second line: the first-choice cell says "look on" (flag + filter bit)
             const CellProbe q = cell_second_line(p, lbits);
-            unsigned long long* there = reinterpret_cast<unsigned long long*>(lines + (size_t)q.line * LINE_BYTES + 4 * q.sh);
+            unsigned long long* there = reinterpret_cast<unsigned long long*>(lines + cell_byte_at(q, lbits, rp.regions));
             atomicOr(reinterpret_cast<unsigned long long*>(line + 4 * p.sh), mark);
             if (take(there, cell_word(q.w, q.r, c), cell_keycount_mask(lbits, both))) {
                 ++n_second;
@@ -425,7 +436,7 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, in
             if (cell_has_third(lbits, both)) {
                 // the same cell of its third line: where the losers of DIFFERENT loci with this minimizer part ways
                 const CellProbe t = cell_third_line(p, lbits, both, cell_nw(k));
-                unsigned long long* third = reinterpret_cast<unsigned long long*>(lines + (size_t)t.line * LINE_BYTES + 4 * t.sh);
+                unsigned long long* third = reinterpret_cast<unsigned long long*>(lines + cell_byte_at(t, lbits, rp.regions));
                 if (take(third, cell_word(t.w, t.r, c), cell_keycount_mask(lbits, both))) {
                     ++n_second;
                     return;
@@ -459,7 +470,7 @@ __global__ void cells_stash_kernel(const uint8_t* __restrict__ lines, int32_t k,
         const uint64_t key = keys[i];
         bool lost = c > CELL_COUNT_MAX;                 // (counters wider than a cell's 16 bits)
         if (!lost)
-            record_cells(rp, i, key, k, lbits, both != 0, [&](const CellProbe& p, int) { lost |= cell_standing(lines, p, c, lbits, both != 0, cell_nw(k), presence) == STAND_NONE; });
+            record_cells(rp, i, key, k, lbits, both != 0, [&](const CellProbe& p, int) { lost |= cell_standing(lines, p, c, lbits, both != 0, cell_nw(k), presence, rp.regions) == STAND_NONE; });
         if (!lost) continue;
         uint32_t slot = stash_slot(key, mask);
         for (;;) {
@@ -502,7 +513,7 @@ __global__ __launch_bounds__(256) void lookup_cells_kernel(TableView tv, int32_t
             cells_visit(key, k, tv.lbits, both, tv.ext != 0, [&](const CellProbe& p, int a) {
                 if (a == 0) c0 = p;
             });
-            const uint8_t* line = tv.lines + (size_t)c0.line * LINE_BYTES;
+            const uint8_t* line = tv.lines + (size_t)cell_line_index(c0.line, c0.r, tv.lbits, tv.regions) * LINE_BYTES;
             const uint64_t first = *reinterpret_cast<const uint64_t*>(line + 4 * c0.sh);
             const uint64_t KEY_BITS = cell_keycount_mask(tv.lbits, both) & 0x0000FFFFFFFFFFFFull;     // w without the flags, r without the filter
             // "someone who belongs in this cell lives elsewhere" and, when the table has filter bits, "with my filter bit"
@@ -525,14 +536,14 @@ __global__ __launch_bounds__(256) void lookup_cells_kernel(TableView tv, int32_t
             }
             if (!found && sent_on(first)) {
                 const CellProbe q = cell_second_line(c0, tv.lbits);
-                const uint64_t there = *reinterpret_cast<const uint64_t*>(tv.lines + (size_t)q.line * LINE_BYTES + 4 * q.sh);
+                const uint64_t there = *reinterpret_cast<const uint64_t*>(tv.lines + cell_byte_at(q, tv.lbits, tv.regions));
                 if (((there ^ cell_word(q.w, q.r, 0)) & KEY_BITS) == 0 && (there >> 48) != 0) {
                     result = (int32_t)(there >> 48);
                 } else if (sent_on(there)) {
                     bool on = true;
                     if (cell_has_third(tv.lbits, both)) {
                         const CellProbe t = cell_third_line(c0, tv.lbits, both, cell_nw(k));
-                        const uint64_t third = *reinterpret_cast<const uint64_t*>(tv.lines + (size_t)t.line * LINE_BYTES + 4 * t.sh);
+                        const uint64_t third = *reinterpret_cast<const uint64_t*>(tv.lines + cell_byte_at(t, tv.lbits, tv.regions));
                         if (((third ^ cell_word(t.w, t.r, 0)) & KEY_BITS) == 0 && (third >> 48) != 0) {
                             result = (int32_t)(third >> 48);
                             on = false;
@@ -624,15 +635,15 @@ __global__ void cohort_fill_kernel(TableView tv, int32_t k, int32_t both_i, cons
         const uint64_t key = keys[i];
         bool stashed = false;
         record_cells(rp, i, key, k, tv.lbits, both, [&](const CellProbe& p, int) {
-            const int st = cell_standing(tv.lines, p, 1u, tv.lbits, both, cell_nw(k), 1);
+            const int st = cell_standing(tv.lines, p, 1u, tv.lbits, both, cell_nw(k), 1, tv.regions);
             if (st == STAND_NONE) {
                 stashed = true;
                 return;
             }
             const uint32_t sh = st == STAND_FREE ? cell_alt_of(p.sh, p.w, p.r, cell_nw(k), tv.lbits, both).sh : p.sh;
-            const uint32_t ln = st == STAND_SECOND_LINE ? cell_second_line(p, tv.lbits).line
-                                : st == STAND_THIRD_LINE ? cell_third_line(p, tv.lbits, both, cell_nw(k)).line : p.line;
-            const size_t cell = (size_t)ln * 16 + (sh >> 1);
+            const CellProbe at = st == STAND_SECOND_LINE ? cell_second_line(p, tv.lbits)
+                                 : st == STAND_THIRD_LINE ? cell_third_line(p, tv.lbits, both, cell_nw(k)) : p;
+            const size_t cell = (size_t)cell_line_index(at.line, at.r, tv.lbits, tv.regions) * 16 + (sh >> 1);
             cell_counts[cell * COHORT_STRIDE + sample] = (uint16_t)c;
         });
         if (stashed) {
@@ -1556,7 +1567,7 @@ __device__ __forceinline__ int k31c_deferred_round(const TableView& tv, const Ld
         uint64_t key;
         const CellProbe p = k31_probe_at<K, BOTH>(sh, pos0 + (int)(id & 0xFFFFu), id >> QUEUE_ANCHOR_SHIFT, tv.lbits, tv.ext, key);
         const CellProbe q2 = cell_second_line(p, tv.lbits);
-        const size_t cell = (size_t)q2.line * 16 + (q2.sh >> 1);
+        const size_t cell = (size_t)cell_line_index(q2.line, q2.r, tv.lbits, tv.regions) * 16 + (q2.sh >> 1);
         const uint2 e = reinterpret_cast<const uint2*>(tv.lines)[cell];      // (plain: with the non-temporal hint this one is slower)
         const uint32_t rmask = cell_rmask(tv.lbits, BOTH);
         if (((e.x ^ q2.w) <= CELL_FLAG_MASK) && (((e.y ^ q2.r) & rmask) == 0) && (e.y >> 16) != 0u) {
@@ -1569,7 +1580,7 @@ __device__ __forceinline__ int k31c_deferred_round(const TableView& tv, const Ld
             if (on && cell_has_third(tv.lbits, BOTH)) {
                 // its third line: the losers of this minimizer's other loci are not here
                 const CellProbe q3 = cell_third_line(p, tv.lbits, BOTH, cell_nw(K));
-                const size_t cell3 = (size_t)q3.line * 16 + (q3.sh >> 1);
+                const size_t cell3 = (size_t)cell_line_index(q3.line, q3.r, tv.lbits, tv.regions) * 16 + (q3.sh >> 1);
                 const uint2 e3 = reinterpret_cast<const uint2*>(tv.lines)[cell3];
                 if (((e3.x ^ q3.w) <= CELL_FLAG_MASK) && (((e3.y ^ q3.r) & rmask) == 0) && (e3.y >> 16) != 0u) {
                     found(id, e3.y >> 16, (uint32_t)cell3, false);
@@ -1635,7 +1646,9 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
         uint64_t N, V;
         uint32_t sh2, fm;
         words.next(w, N, sh2, fm, V);
-        cells_issue<cell_nw(K), BOTH>(tv, V, cell_probe_planned<BOTH>(N, sh2, fm, tv.lbits, tv.ext), sh2 | (fm & 1u), cw);
+        CellProbe p = cell_probe_planned<BOTH>(N, sh2, fm, tv.lbits, tv.ext);
+        if (tv.regions > 1) p.line = cell_line_index(p.line, p.r, tv.lbits, tv.regions);    // (wave-uniform; from here on the line is only an address)
+        cells_issue<cell_nw(K), BOTH>(tv, V, p, sh2 | (fm & 1u), cw);
     };
     // stage B of word w: cells matched, ballots out, stash candidates queued
     auto retire = [&](int w, const CellWord& cw) {
@@ -2306,27 +2319,27 @@ hipError_t launch_cells_resolve(uint32_t* pop32, int32_t pop_bits, int32_t k, in
 }
 
 hipError_t launch_cells_insert(uint8_t* lines, const uint32_t* pop32, int32_t pop_bits, int32_t cls, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys,
-                               const uint32_t* counts, int64_t n, hipStream_t st, int32_t presence, const uint64_t* pw, const uint8_t* ps, int32_t ext) {
+                               const uint32_t* counts, int64_t n, hipStream_t st, int32_t presence, const uint64_t* pw, const uint8_t* ps, int32_t ext, int32_t regions) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(cells_insert_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, pop32, pop_bits, cls, k, lbits, both, keys, counts, n, presence,
-                       RecProbes{pw, ps, ext});
+                       RecProbes{pw, ps, ext, regions});
     return hipGetLastError();
 }
 
 size_t cells_pop_bytes(int32_t pop_bits) { return (size_t)1 << pop_bits; }
 
 hipError_t launch_cells_settle(uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                               unsigned long long* stats, hipStream_t st, int32_t presence, const uint64_t* pw, const uint8_t* ps, int32_t ext) {
+                               unsigned long long* stats, hipStream_t st, int32_t presence, const uint64_t* pw, const uint8_t* ps, int32_t ext, int32_t regions) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(cells_settle_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, k, lbits, both, keys, counts, n, stats, presence, RecProbes{pw, ps, ext});
+    hipLaunchKernelGGL(cells_settle_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, k, lbits, both, keys, counts, n, stats, presence, RecProbes{pw, ps, ext, regions});
     return hipGetLastError();
 }
 
 hipError_t launch_cells_stash(const uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                              uint4* stash, uint32_t stash_mask, hipStream_t st, int32_t presence, const uint64_t* pw, const uint8_t* ps, int32_t ext) {
+                              uint4* stash, uint32_t stash_mask, hipStream_t st, int32_t presence, const uint64_t* pw, const uint8_t* ps, int32_t ext, int32_t regions) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(cells_stash_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, k, lbits, both, keys, counts, n, stash,
-                       stash_mask, presence, RecProbes{pw, ps, ext});
+                       stash_mask, presence, RecProbes{pw, ps, ext, regions});
     return hipGetLastError();
 }
 
@@ -2453,7 +2466,7 @@ hipError_t launch_cohort_fill(TableView tv, int32_t k, int32_t both, const uint6
                               int32_t sample, uint16_t* cell_counts, uint16_t* stash_counts, hipStream_t st, const uint64_t* pw, const uint8_t* ps) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(cohort_fill_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, tv, k, both, keys, counts, n, sample,
-                       cell_counts, stash_counts, RecProbes{pw, ps, tv.ext});
+                       cell_counts, stash_counts, RecProbes{pw, ps, tv.ext, tv.regions});
     return hipGetLastError();
 }
 

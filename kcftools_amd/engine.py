@@ -45,7 +45,7 @@ class DbInfo(C.Structure):
                 ("heavy_lines", C.c_int64), ("overflow_lines", C.c_int64),
                 ("table_format", C.c_int32), ("lut_suspect", C.c_int32), ("stored_kmers", C.c_int64),
                 ("stash_kmers", C.c_int64), ("stash_bytes", C.c_int64), ("multi_cell_kmers", C.c_int64),
-                ("second_choice_kmers", C.c_int64), ("extended", C.c_int32), ("_reserved", C.c_int32)]
+                ("second_choice_kmers", C.c_int64), ("extended", C.c_int32), ("regions", C.c_int32)]
 
 
 class ShardStats(C.Structure):

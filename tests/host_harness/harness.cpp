@@ -268,6 +268,10 @@ int harness_cell_third_line(uint32_t line, uint32_t sh, uint32_t w, uint32_t r, 
     return 1;
 }
 uint32_t harness_cell_rmask(int lbits, int both) { return cell_rmask(lbits, both != 0); }
+// the physical line of n probes (line, r) in a table of `regions` x 2^lbits lines (cell_line_index)
+void harness_cell_line_index(const uint32_t* line, const uint32_t* r, int64_t n, int lbits, int regions, uint32_t* out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = cell_line_index(line[i], r[i], lbits, regions);
+}
 void harness_set_ext(int on) { g_ext = on; }
 int harness_alt_free_max_w(void) { return CELL_ALT_FREE_MAX_W; }
 uint64_t harness_revcomp_word(uint64_t x, int len) { return revcomp_word(x, len); }

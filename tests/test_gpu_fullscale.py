@@ -424,7 +424,7 @@ def test_config5_shape_wheat_scale(oracle, genome, cohort, monkeypatch):
     line = (f"config-5 ({why}): {L / 1e9:.1f} Gb reference, {len(starts)} windows x {N_SAMPLES} samples = {N_SAMPLES * n / 1e9:.0f} G k-mer probes; "
             f"kcfx_screen_sharded (2 workers on one GPU, load overlapped): {t_sharded:.1f} s wall, loads {st.seconds_db_open_sum:.1f} s of "
             f"which {st.seconds_exposed_load:.1f} s exposed, screening {st.seconds_screen_sum:.2f} s; large database {bi.total_kmers / 1e9:.2f} G "
-            f"k-mers generated in {t_gen:.0f} s, opened in {t_big_open:.1f} s (2^{int(np.log2(bi.table_lines))} lines = "
+            f"k-mers generated in {t_gen:.0f} s, opened in {t_big_open:.1f} s ({bi.regions} x 2^{int(np.log2(bi.table_lines // bi.regions))} lines = "
             f"{bi.total_kmers / (16.0 * bi.table_lines):.2f} per cell, {bi.table_bytes / 2**30:.0f} GiB incl. stash, "
             f"{100.0 * bi.stash_kmers / bi.total_kmers:.0f} % in the stash; as a line table {t_lines_open:.1f} s); DENSE 2^{dense_bits} lines = "
             f"{di.total_kmers / (16.0 * di.table_lines):.2f} per cell: opened in {t_dense_open:.1f} s, {di.table_bytes / 2**30:.0f} GiB, "
@@ -520,7 +520,7 @@ def test_wheat_scale_genomic_database(oracle, monkeypatch):
             torch.cuda.synchronize()
             ms, cnt = ref.prof_read(reset=True)
             ref.prof_enable(False)
-            d_ = dict(lines=int(info.table_lines), extended=int(info.extended), per_cell=info.stored_kmers / (16.0 * info.table_lines), gib=info.table_bytes / 2 ** 30,
+            d_ = dict(lines=int(info.table_lines), regions=int(info.regions), extended=int(info.extended), per_cell=info.stored_kmers / (16.0 * info.table_lines), gib=info.table_bytes / 2 ** 30,
                       stash=info.stash_kmers / max(1, info.stored_kmers), moved=info.second_choice_kmers / max(1, info.stored_kmers),
                       open_s=t_open, kernel_ms=ms / max(1, cnt))
             db.close()
@@ -551,7 +551,8 @@ def test_wheat_scale_genomic_database(oracle, monkeypatch):
         gk = n / 1e9
 
         def show(x):
-            return (f"2^{int(np.log2(x['lines']))} lines ({'extended' if x['extended'] else 'plain'}) = {x['per_cell']:.2f} per cell, {x['gib']:.0f} GiB incl. stash, opened in {x['open_s']:.1f} s, "
+            shape = f"2^{int(np.log2(x['lines']))}" if x["regions"] == 1 else f"{x['regions']} x 2^{int(np.log2(x['lines'] // x['regions']))}"
+            return (f"{shape} lines ({'extended' if x['extended'] else 'plain'}) = {x['per_cell']:.2f} per cell, {x['gib']:.0f} GiB incl. stash, opened in {x['open_s']:.1f} s, "
                     f"{100 * x['stash']:.1f} % in the stash, {100 * x['moved']:.1f} % in second / third lines, pass {x['kernel_ms']:.1f} ms = "
                     f"{gk / x['kernel_ms'] * 1e3:.0f} G k-mers/s")
         line = (f"wheat-scale genomic database ({why}): {len(text) / 1e9:.2f} Gb non-tiled genome, {n_db / 1e9:.2f} G distinct 31-mers of its sample "

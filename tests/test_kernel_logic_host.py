@@ -57,6 +57,8 @@ def harness():
     L.harness_cell_rmask.restype = C.c_uint32
     L.harness_cell_third_line.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.harness_cell_third_line.restype = C.c_int
+    L.harness_cell_line_index.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
+    L.harness_cell_line_index.restype = None
     L.harness_plan_strips.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.harness_anchor_reference.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
     return L
@@ -326,6 +328,40 @@ def test_cell_table_build_side_covers_query_side(harness, oracle, ext):
                     assert seen_2nd.setdefault(third, int(c)) == int(c), (k, lbits, hex(int(c)))
                     thirds.add(l3)
                     seconds.add(l2)
+
+
+@pytest.mark.parametrize("lbits", [17, 22, 29])
+def test_region_tables_address_lines_not_identities(harness, lbits):
+    """cell_line_index: a table of R regions of 2^lbits lines. The physical line keeps the logical line in its low lbits (what a
+    cell compares -- w, r, the second and third lines -- is untouched), the region in front of it is a function of (line, the
+    identifying bits of r) alone -- spare, mark and filter bits of r do not move a k-mer -- stays below R, and takes every value about
+    equally often, also among the probes of ONE logical line (otherwise a line's tenants would all land in the same region)."""
+    rng = np.random.default_rng(lbits)
+    n = 200_000
+    idm = 0xFFFFFFFF >> lbits
+    line = rng.integers(0, 1 << lbits, n, dtype=np.uint32)
+    line[: n // 4] = line[0]                                            # many probes of one logical line
+    r = rng.integers(0, 1 << 16, n, dtype=np.uint32) if lbits >= 17 else None
+    g_low = rng.integers(0, idm + 1, n, dtype=np.uint32)
+    r = (r & ~np.uint32(idm & 0xFFFF)) | (g_low & np.uint32(0xFFFF))       # identifying bits + random mark / filter bits above them
+    out = np.zeros(n, dtype=np.uint32)
+    harness.harness_cell_line_index(line.ctypes.data, r.ctypes.data, n, lbits, 1, out.ctypes.data)
+    assert np.array_equal(out, line)
+    for R in (3, 5, 7):
+        harness.harness_cell_line_index(line.ctypes.data, r.ctypes.data, n, lbits, R, out.ctypes.data)
+        assert np.array_equal(out & np.uint32((1 << lbits) - 1), line)
+        region = out >> np.uint32(lbits)
+        assert region.max() < R
+        # the bits of r above the identifying ones do not matter
+        out2 = np.zeros(n, dtype=np.uint32)
+        r2 = (r & np.uint32(idm & 0xFFFF)) | np.uint32(0x8000 & ~idm)
+        harness.harness_cell_line_index(line.ctypes.data, r2.ctypes.data, n, lbits, R, out2.ctypes.data)
+        assert np.array_equal(out, out2)
+        for sel in (slice(n // 4, None), slice(0, n // 4)):
+            if lbits == 29 and sel.start == 0:
+                continue                                                # (3 identifying bits: eight tenants per line, nothing to count)
+            cnt = np.bincount(region[sel], minlength=R)
+            assert cnt.min() > 0.8 * cnt.sum() / R and cnt.max() < 1.2 * cnt.sum() / R, (R, cnt)
 
 
 @pytest.fixture(autouse=True)
