@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--lbits", default="27,28,29")
     ap.add_argument("--base", default="/dev/shm")
     ap.add_argument("--ext", default="0,1,auto", help="plain / extended tables (KCFX_TABLE_EXT), auto = the library decides")
+    ap.add_argument("--regions", default="1", help="regions of 2^lbits lines each (KCFX_TABLE_REGIONS); with --lbits 0 the size policy decides everything")
     args = ap.parse_args()
     import torch
     d = tempfile.mkdtemp(prefix="kcfx_gd_", dir=args.base)
@@ -47,8 +48,13 @@ def main():
         stream = torch.cuda.current_stream()
         outbuf = torch.zeros(len(starts) * 10, dtype=torch.int32, device="cuda:0")
         base = None
-        for lb, ext in [(int(x), y) for x in args.lbits.split(",") for y in args.ext.split(",")]:
-            os.environ["KCFX_TABLE_LBITS"] = str(lb)
+        for lb, ext, reg in [(int(x), y, int(z)) for x in args.lbits.split(",") for y in args.ext.split(",") for z in args.regions.split(",")]:
+            if lb:
+                os.environ["KCFX_TABLE_LBITS"] = str(lb)
+                os.environ["KCFX_TABLE_REGIONS"] = str(reg)
+            else:
+                os.environ.pop("KCFX_TABLE_LBITS", None)
+                os.environ.pop("KCFX_TABLE_REGIONS", None)
             if ext == "auto":
                 os.environ.pop("KCFX_TABLE_EXT", None)
             else:
@@ -73,7 +79,7 @@ def main():
             ms, cnt = ref.prof_read(reset=True)
             ref.prof_enable(False)
             n = int(res["total_kmers"].sum())
-            print(f"2^{lb} lines ({ext}: {'extended' if i.extended else 'plain'}): {i.stored_kmers / (16.0 * i.table_lines):.2f} per cell, {i.table_bytes / 2**30:.1f} GiB incl. stash, opened in {t_open:.1f} s, "
+            print(f"{i.regions} x 2^{int(np.log2(i.table_lines // i.regions))} lines ({ext}: {'extended' if i.extended else 'plain'}): {i.stored_kmers / (16.0 * i.table_lines):.2f} per cell, {i.table_bytes / 2**30:.1f} GiB incl. stash, opened in {t_open:.1f} s, "
                   f"stash {100.0 * i.stash_kmers / i.stored_kmers:.1f} %, second / third lines {100.0 * i.second_choice_kmers / i.stored_kmers:.1f} %, "
                   f"pass {ms / cnt:.2f} ms = {n / (ms / cnt) / 1e6:.0f} G k-mers/s, hit rate {res['obs'].sum() / n:.3f}, identical to the first: {same}", flush=True)
             db.close()
