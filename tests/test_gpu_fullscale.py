@@ -568,5 +568,7 @@ def test_wheat_scale_genomic_database(oracle, monkeypatch):
         # the free memory can take them, else 2^29)
         assert a["extended"] == 1                                # (the build found > 15 % of the k-mers outside their first-choice cell and started over)
         assert a["stash"] < (0.10 if a["per_cell"] < 0.6 else 0.22)
+        if a["per_cell"] < 0.4:                                  # (3 x 2^29 lines: 211 G k-mers/s on the round's boxes; the bound leaves room for a slow one)
+            assert gk / a["kernel_ms"] * 1e3 > 170
     finally:
         shutil.rmtree(d, ignore_errors=True)
