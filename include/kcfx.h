@@ -204,6 +204,15 @@ int32_t kcfx_screen_ref_multi_async(kcfx_db* const* dbs, int32_t n_db, kcfx_ref*
 /* Reserve the multi-sample scratch of `ref` for batches of up to `n_samples` line-table databases (clamped to 8). */
 int32_t kcfx_ref_reserve_multi(kcfx_ref* ref, int32_t n_samples);
 
+/* The table kcfx_db_open would build for a database of `total_kmers` k-mers of length `kmer_length` (canonical: both_strands != 0)
+ * on a device with `free_bytes` of free memory -- host arithmetic only, no GPU: what a caller budgets memory with before it opens
+ * anything (new KMC(prefix, loadMemory) holds the whole database too: KMC.java:56-78). *lines = regions x 2^n lines of 128 bytes
+ * (16 cells each) for k = 19 .. 31; the stash (the k-mers that found their cells taken: 0.03 - 4 % of the database, 16 - 64 bytes
+ * each) comes on top. *lines = 0 (and KCFX_OK): k outside 19 .. 31 or more k-mers than cells -- such a database gets the 12-slot
+ * line table, whose size depends on its minimizer statistics. lines / regions may be NULL. */
+int32_t kcfx_table_plan(int64_t total_kmers, int32_t kmer_length, int32_t both_strands, int64_t free_bytes,
+                        int64_t* lines, int32_t* regions);
+
 /* One-shot convenience: kcfx_ref_create + kcfx_screen_ref + kcfx_ref_destroy. */
 int32_t kcfx_screen(kcfx_db* db, const uint8_t* text, int64_t text_len, const int64_t* win_begin,
                     const int32_t* win_len, int32_t n_windows, int32_t min_kmer_count, kcfx_result* out);

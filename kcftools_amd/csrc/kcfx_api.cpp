@@ -286,12 +286,11 @@ bool cells_eligible(const kcfx_db* db, int32_t counter_size) {
 // 0.37 - 0.55 s each over six rounds) while the screening pass is 16 - 30 % slower at 0.28: since round 4 every handle gets
 // the same ~0.075 per cell, and expected_queries only decides the crowding counters (pop_alloc).
 constexpr double QUERIES_FOR_SPARSE = 1e10;
-int32_t cells_lbits(int64_t n_keys, int32_t k, bool both, int64_t expected_queries, int32_t line_footprint = LINE_BYTES) {
+int32_t cells_lbits(int64_t n_keys, int32_t k, bool both, int64_t expected_queries, int32_t line_footprint, size_t free_b) {
     const int32_t cap = cells_lbits_cap(k);
     const int32_t lmin = cell_lbits_min(both);
     const char* s = getenv("KCFX_TABLE_LBITS");
     if (s && atoi(s) >= lmin && atoi(s) <= cap) return atoi(s);
-    const size_t free_b = free_device_bytes();
     // A table above 48 GiB is halved while that leaves it at <= ~0.5 k-mers per cell (the 2.1 G-k-mer test database: 2^28 lines), and
     // beyond that only when it does not fit 60 % of the free memory: a database of billions of GENOMIC k-mers needs the lines --
     // at ~1 per cell a quarter of it lives in the stash, at ~0.5 a twelfth (profiles/r04_notes.md) -- and a second database that
@@ -305,6 +304,39 @@ int32_t cells_lbits(int64_t n_keys, int32_t k, bool both, int64_t expected_queri
     while (L > lmin && bytes(L) > soft_cap && 16.0 * (double)(1ull << (L - 1)) * 0.5 >= (double)n_keys) --L;
     while (L > lmin && bytes(L) > hard_cap && 16.0 * (double)(1ull << (L - 1)) >= (double)n_keys) --L;
     return L;
+}
+
+// Regions (kcfx_device.h: cell_line_index). Where the caps of cells_lbits left the table above 0.3 k-mers per cell it grows in
+// quarters of its power of two -- 1.25 / 1.5 / 1.75 / 2 / 2.5 / 3 / 3.5 x 2^L0 lines = 5 / 3 / 7 / 1 / 5 / 3 / 7 regions of 2^(L0 - 2) ..
+// 2^(L0 + 1) lines -- to the first size at or under 0.3 per cell, or the largest one its limit allows: a table under 48 GiB up
+// to 48 GiB (a 2.1 G-k-mer database: 3 x 2^27 lines, 0.33 per cell instead of 0.49), a larger one up to 80 % of the free memory (8 G
+// genomic k-mers: 3 x 2^29 lines = 192 GiB, 0.31 per cell instead of 0.47; the stash, the crowding counters and the streaming
+// buffers of such a build take ~25 GiB beside it). Past ~0.2 per cell a genomic database gains nothing more
+// (profiles/r04_notes.md). Cohort tables, retries after an allocation that did not fit and KCFX_TABLE_LBITS keep one region;
+// KCFX_TABLE_REGIONS=R (1, 3, 5, 7; with KCFX_TABLE_LBITS=L: R << L lines) decides by hand (tests, A/B).
+void cells_regions(int64_t n_keys, int32_t k, bool both, int32_t L0, size_t free_b, int32_t* regions, int32_t* lbits) {
+    *regions = 1;
+    *lbits = L0;
+    const int32_t lmin = cell_lbits_min(both), cap = cells_lbits_cap(k);
+    if (const char* rs = getenv("KCFX_TABLE_REGIONS")) {
+        const int v = atoi(rs);
+        if ((v == 3 || v == 5 || v == 7) && ((uint64_t)v << L0) < (1ull << 32)) *regions = v;
+        return;
+    }
+    auto density = [&](double lines) { return (double)n_keys / (16.0 * lines); };
+    if (getenv("KCFX_TABLE_LBITS") != nullptr || density((double)(1ull << L0)) <= 0.30) return;
+    const double one = (double)(1ull << L0) * LINE_BYTES, gib48 = 48.0 * (double)(1ull << 30), most = 0.80 * (double)free_b;
+    const double limit = one < gib48 ? std::min(gib48, most) : most;        // (a table under 48 GiB grows up to them)
+    static const struct { int32_t r, dl; } steps[] = {{5, -2}, {3, -1}, {7, -2}, {1, 1}, {5, -1}, {3, 0}, {7, -1}};   // ascending sizes
+    for (const auto& st : steps) {
+        const int32_t L = L0 + st.dl;
+        if (L < lmin || L > cap || ((uint64_t)st.r << L) >= (1ull << 32)) continue;
+        const double lines = (double)((uint64_t)st.r << L);
+        if (lines * LINE_BYTES > limit) break;
+        *regions = st.r;
+        *lbits = L;
+        if (density(lines) <= 0.30) break;
+    }
 }
 
 // the deferred half of cells_alloc: join the allocation thread, report what it found
@@ -357,32 +389,12 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys, bool deferred = false) {
     }
     hipError_t e = hipErrorOutOfMemory;
     const bool both = db->info.both_strands != 0;
-    int32_t L0 = cells_lbits(n_keys, db->info.kmer_length, both, db->expected_queries, db->line_footprint);
+    const size_t free_b = free_device_bytes();
+    int32_t L0 = cells_lbits(n_keys, db->info.kmer_length, both, db->expected_queries, db->line_footprint, free_b);
     if (db->lbits_cap > 0) L0 = std::min(L0, db->lbits_cap);
-    // Regions (kcfx_device.h: cell_line_index). Where the caps of cells_lbits left the table above 0.3 k-mers per cell, the space
-    // between this power of two and the next is used in quarters: 1.25 / 1.5 / 1.75 x 2^L0 lines = 5 / 3 / 7 regions of 2^(L0 - 2) /
-    // 2^(L0 - 1) / 2^(L0 - 2) lines -- a table under 48 GiB up to 48 GiB (a 2.1 G-k-mer database: 0.33 per cell instead of 0.49), a
-    // larger one up to 80 % of the free memory (8 G genomic k-mers: 192 GiB, 0.31 per cell instead of 0.47; the stash, the
-    // crowding counters and the streaming buffers of such a build take ~25 GiB beside it). Cohort tables, retries after an allocation that did not fit and KCFX_TABLE_LBITS keep one region;
-    // KCFX_TABLE_REGIONS=R (1, 3, 5, 7; with KCFX_TABLE_LBITS=L: R << L lines) decides by hand (tests, A/B).
     db->regions = 1;
     int32_t R = 1, Lr = L0;
-    if (db->line_footprint == LINE_BYTES && db->lbits_cap == 0) {
-        const int32_t lmin = cell_lbits_min(both);
-        if (const char* rs = getenv("KCFX_TABLE_REGIONS")) {
-            const int v = atoi(rs);
-            if ((v == 3 || v == 5 || v == 7) && ((uint64_t)v << L0) < (1ull << 32)) R = v;
-        } else if (getenv("KCFX_TABLE_LBITS") == nullptr && L0 - 2 >= lmin && (double)n_keys > 0.30 * 16.0 * (double)(1ull << L0)) {
-            const double one = (double)(1ull << L0) * LINE_BYTES, gib48 = 48.0 * (double)(1ull << 30);
-            const double limit = one < gib48 ? gib48 : 0.80 * (double)free_device_bytes();   // (a table under 48 GiB grows up to them)
-            for (int q = 7; q >= 5; --q)
-                if (one * q / 4.0 <= limit) {
-                    R = q == 6 ? 3 : q;
-                    Lr = q == 6 ? L0 - 1 : L0 - 2;
-                    break;
-                }
-        }
-    }
+    if (db->line_footprint == LINE_BYTES && db->lbits_cap == 0) cells_regions(n_keys, db->info.kmer_length, both, L0, free_b, &R, &Lr);
     db->alloc_rc = KCFX_OK;
     db->alloc_oom = false;
     db->table_arrived = false;
@@ -426,7 +438,9 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys, bool deferred = false) {
             db->d_lines = nullptr;
         }
     }
-    for (int32_t L = L0; e != hipSuccess && L >= cell_lbits_min(both); --L) {
+    // (the power of two at or below the policy's size, then denser ones)
+    const int32_t Lf = std::min(cells_lbits_cap(db->info.kmer_length), R == 1 ? Lr : Lr + (R == 3 ? 1 : 2));
+    for (int32_t L = Lf; e != hipSuccess && L >= cell_lbits_min(both); --L) {
         if ((double)n_keys > 16.0 * (double)(1ull << L))            // fewer cells than k-mers: not a cell table any more
             return fail(KCFX_ERR_DEVICE, "no cell table of 2^" + std::to_string(L) + " or more lines fits the device memory (or KCFX_TABLE_LBITS)");
         e = dev_alloc(&db->d_lines, (size_t)LINE_BYTES << L);
@@ -963,7 +977,7 @@ int32_t kcfx_db_open_opts(const char* kmc_prefix, int32_t device, const kcfx_db_
         (db->alloc_oom || (db->alloc_rc == KCFX_OK && !db->table_arrived))) {
         // the policy's table did not fit next to what else lives on the device: denser cell tables, allocated synchronously
         // (a table of R regions that did not fit: the power of two below it -- (3 << L) -> 2^(L + 1), (5 | 7) << L -> 2^(L + 2) -- as one region)
-        const int32_t cap = db->regions > 1 ? db->lbits + (db->regions == 3 ? 1 : 2) : db->lbits - 1;
+        const int32_t cap = db->regions > 1 ? std::min(cells_lbits_cap(db->info.kmer_length), db->lbits + (db->regions == 3 ? 1 : 2)) : db->lbits - 1;
         table_release(db);
         db->lbits_cap = cap;
         rc = table_alloc(db, h.total, h.counter_size, true, false);
@@ -988,6 +1002,28 @@ int32_t kcfx_db_open_opts(const char* kmc_prefix, int32_t device, const kcfx_db_
     *out = hold.release();
     return KCFX_OK;
 } KCFX_CATCH("kcfx_db_open")
+
+int32_t kcfx_table_plan(int64_t total_kmers, int32_t kmer_length, int32_t both_strands, int64_t free_bytes,
+                        int64_t* lines, int32_t* regions) try {
+    if (total_kmers < 0 || free_bytes < 0) return fail(KCFX_ERR_ARG, "kcfx_table_plan: negative argument");
+    if (kmer_length < 1 || kmer_length > 32) return fail(KCFX_ERR_FORMAT, "unsupported k-mer length (1..32)");
+    int64_t n_lines = 0;
+    int32_t R = 1;
+    const bool both = both_strands != 0;
+    if (kmer_length >= CELL_K_MIN && kmer_length <= CELL_K_MAX && total_kmers <= (int64_t)16 << cells_lbits_cap(kmer_length)) {
+        const int32_t L0 = cells_lbits(total_kmers, kmer_length, both, 0, LINE_BYTES, (size_t)free_bytes);
+        int32_t Lr = L0;
+        cells_regions(total_kmers, kmer_length, both, L0, (size_t)free_bytes, &R, &Lr);
+        n_lines = (int64_t)R << Lr;
+        if ((double)total_kmers > 16.0 * (double)n_lines) {      // (the device cannot hold a cell per k-mer)
+            n_lines = 0;
+            R = 1;
+        }
+    }
+    if (lines) *lines = n_lines;
+    if (regions) *regions = R;
+    return KCFX_OK;
+} KCFX_CATCH("kcfx_table_plan")
 
 int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, int32_t kmer_length,
                       int32_t counter_size, int32_t both_strands, int32_t device, kcfx_db** out) try {

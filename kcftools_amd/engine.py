@@ -31,7 +31,7 @@ ABI_SYMBOLS = (
     "kcfx_cohort_open", "kcfx_cohort_info", "kcfx_cohort_close", "kcfx_cohort_screen_ref", "kcfx_cohort_screen_ref_async",
     "kcfx_ctx_create", "kcfx_ctx_n_devices", "kcfx_ctx_destroy", "kcfx_screen_sharded", "kcfx_shard_plan",
     "kcfx_score", "kcfx_windows",
-    "kcfx_prof_enable", "kcfx_prof_read", "kcfx_ref_plan_async", "kcfx_ref_is_planned", "kcfx_prof_read_plan", "kcfx_last_error", "kcfx_device_count", "kcfx_version",
+    "kcfx_table_plan", "kcfx_prof_enable", "kcfx_prof_read", "kcfx_ref_plan_async", "kcfx_ref_is_planned", "kcfx_prof_read_plan", "kcfx_last_error", "kcfx_device_count", "kcfx_version",
 )
 
 
@@ -127,6 +127,7 @@ def lib() -> C.CDLL:
         L.kcfx_ctx_destroy.restype = None
         L.kcfx_screen_sharded.argtypes = [vp, vp, i32, i32, vp, i64, vp, vp, i32, i32, i32, vp, C.POINTER(ShardStats)]
         L.kcfx_shard_plan.argtypes = [i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, i64, C.POINTER(i64), C.POINTER(i32)]
+        L.kcfx_table_plan.argtypes = [i64, i32, i32, i64, C.POINTER(i64), C.POINTER(i32)]
         L.kcfx_db_lookup.argtypes = [vp, vp, i64, vp]
         L.kcfx_db_close.argtypes = [vp]
         L.kcfx_db_close.restype = None
@@ -169,6 +170,13 @@ def _check(rc: int) -> None:
 def release_cached(device: int = -1) -> None:
     """Give the device buffers that closed databases / destroyed references left behind back to the driver."""
     _check(lib().kcfx_release_cached(device))
+
+
+def table_plan(total_kmers: int, k: int, both_strands: bool = True, free_bytes: int = 256 << 30) -> tuple[int, int]:
+    """kcfx_table_plan (host only): (lines, regions) of the cell table kcfx_db_open would build; lines = 0: a line table."""
+    n, r = C.c_int64(0), C.c_int32(0)
+    _check(lib().kcfx_table_plan(int(total_kmers), int(k), int(bool(both_strands)), int(free_bytes), C.byref(n), C.byref(r)))
+    return n.value, r.value
 
 
 def device_count() -> int:
