@@ -14,6 +14,7 @@ s, e = engine.windows(len(text), 10_000, 0, K)
 ref = engine.Reference(text, s.astype(np.int64), (e - s).astype(np.int32), K)
 out = torch.zeros(len(s) * 10, dtype=torch.int32, device="cuda:0")
 st = torch.cuda.current_stream()
+os.environ["KCFX_VERBOSE"] = "1"                  # (kcfx_db_open then says where the table is: stderr)
 dbs = [engine.KmcDb.open(prefix) for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5)]
 def t(db, n=300):
     for _ in range(20):
