@@ -280,8 +280,9 @@ def test_config5_shape_wheat_scale(oracle, genome, cohort, monkeypatch):
     """BASELINE.json configs[4] as it is stated: a wheat-scale 14.5 Gb reference, 50 kb tiling windows (290 k of them), THIRTY-TWO
     samples, k = 31 -- through kcfx_screen_sharded (what the command-line driver runs; two workers on the one GPU, the next
     database loaded while the current one is screened). The reference is the 119 Mb genome repeated with 0.5 % point mutations;
-    the samples are the cohort's eight databases (~100-150 M k-mers each) in rotation plus ONE LARGE database of 2.1 G k-mers
-    (17 GB .kmc_suf; a 2^28-line cell table at 0.5 k-mers per cell). Falls back to a 3.2 Gb reference only when the box lacks
+    the samples are THIRTY-ONE distinct samples of that genome (~100 M k-mers each; the cohort's eight in rotation only where the
+    scratch space does not take 23 more -- the log line says which) plus ONE LARGE database of 2.1 G k-mers (17 GB .kmc_suf; a cell
+    table of 3 x 2^27 lines at 0.33 k-mers per cell). Falls back to a 3.2 Gb reference only when the box lacks
     the host memory or scratch disk (KCFX_HUGE=<bases> overrides) and says which size ran. Also: the large database
     * as resident handles through kcfx_screen_ref_multi (ten > 8 forces a second batch),
     * rebuilt by re-streaming its file, and as a 12-slot line table (>= 2^29 lines, which the multi-sample kernel refuses),
@@ -320,8 +321,22 @@ def test_config5_shape_wheat_scale(oracle, genome, cohort, monkeypatch):
     starts, lens = starts[lens >= K], lens[lens >= K]
     tbytes = text.tobytes()
     del text
-    # 32 samples: the eight cohort databases in rotation, the large one last
-    prefixes = [cohort[i % 8] for i in range(N_SAMPLES - 1)] + [big]
+    # 32 samples: the eight cohort databases, 23 more samples of the same genome (their own mutations; ~100 M k-mers, 0.85 GB each)
+    # where the scratch space takes them -- else the eight in rotation, and the log line says so -- and the large one last
+    prefixes = list(cohort)
+    extra_need = (N_SAMPLES - 1 - 8) * int(1.0e9) + (4 << 30)
+    distinct = shutil.disk_usage(genome["dir"]).free > extra_need and not os.environ.get("KCFX_ROTATE_SAMPLES")
+    t0 = time.time()
+    for i in range(8, N_SAMPLES - 1):
+        if distinct:
+            pfx = os.path.join(genome["dir"], f"x{i}")
+            subprocess.run([SYNTH, "--out", pfx, "--contig-lens", ",".join(map(str, LENS)), "--seed", "3", "--sample-seed", str(100 + i),
+                            "--noise", "1000000"], check=True, capture_output=True, text=True)
+            prefixes.append(pfx)
+        else:
+            prefixes.append(cohort[i % 8])
+    t_gen_samples = time.time() - t0
+    prefixes.append(big)
     BIG = N_SAMPLES - 1
     # ---- every GPU entry point the CLI uses: sharded over "two devices" (the one GPU twice), next database loaded during
     #      the current screening ---------------------------------------------------------------------------------------
@@ -331,10 +346,13 @@ def test_config5_shape_wheat_scale(oracle, genome, cohort, monkeypatch):
     assert got.shape == (N_SAMPLES, len(starts)) and st.shard_mode_used == engine.SHARD_SAMPLES
     n = int(got[0]["total_kmers"].sum())
     assert n > 0.95 * L
-    for i in range(8, N_SAMPLES - 1):                                                   # the same database again: the same records
-        for f in FIELDS:
-            assert np.array_equal(got[i][f], got[i % 8][f]), (i, f)
-    assert len({int(got[s]["obs"].sum()) for s in (0, 1, 2, 3, 4, 5, 6, 7, BIG)}) == 9   # nine different samples
+    if distinct:
+        assert len({int(got[s]["obs"].sum()) for s in range(N_SAMPLES)}) == N_SAMPLES    # thirty-two different samples
+    else:
+        for i in range(8, N_SAMPLES - 1):                                               # the same database again: the same records
+            for f in FIELDS:
+                assert np.array_equal(got[i][f], got[i % 8][f]), (i, f)
+        assert len({int(got[s]["obs"].sum()) for s in (0, 1, 2, 3, 4, 5, 6, 7, BIG)}) == 9   # nine different samples
     assert int(got[BIG]["obs"].sum()) > int(got[0]["obs"].sum()) * 0.5
     # partition identity at full size: every k-mer of the reference lies in exactly one tiling window (SURVEY a-1)
     assert n == int(got[BIG]["total_kmers"].sum()) and np.all(got[0]["total_kmers"] <= lens - K + 1)
@@ -413,7 +431,7 @@ def test_config5_shape_wheat_scale(oracle, genome, cohort, monkeypatch):
     # ---- 10 000 sampled windows (0.5 G k-mers) of four samples against the oracle, the large / dense one among them ----------
     t0 = time.time()
     n_checked = 0
-    for s, pfx, n_check in ((0, cohort[0], 3000), (3, cohort[3], 3000), (29, cohort[5], 3000), (BIG, big, 1000)):
+    for s, pfx, n_check in ((0, prefixes[0], 3000), (3, prefixes[3], 3000), (29, prefixes[29], 3000), (BIG, big, 1000)):
         idx = np.unique(np.concatenate([rng.choice(len(starts), min(n_check, len(starts)), replace=False), [0, len(starts) - 1]]))
         want = oracle.OracleDb(pfx).screen(tbytes, starts[idx], lens[idx], 1, threads=HOST_THREADS)
         for f in FIELDS:
@@ -421,7 +439,7 @@ def test_config5_shape_wheat_scale(oracle, genome, cohort, monkeypatch):
         n_checked += len(idx)
     t_oracle = time.time() - t0
     gk = n / 1e9
-    line = (f"config-5 ({why}): {L / 1e9:.1f} Gb reference, {len(starts)} windows x {N_SAMPLES} samples = {N_SAMPLES * n / 1e9:.0f} G k-mer probes; "
+    line = (f"config-5 ({why}): {L / 1e9:.1f} Gb reference, {len(starts)} windows x {N_SAMPLES} samples ({'all distinct: 23 generated in %.0f s' % t_gen_samples if distinct else 'eight databases in rotation + the large one'}) = {N_SAMPLES * n / 1e9:.0f} G k-mer probes; "
             f"kcfx_screen_sharded (2 workers on one GPU, load overlapped): {t_sharded:.1f} s wall, loads {st.seconds_db_open_sum:.1f} s of "
             f"which {st.seconds_exposed_load:.1f} s exposed, screening {st.seconds_screen_sum:.2f} s; large database {bi.total_kmers / 1e9:.2f} G "
             f"k-mers generated in {t_gen:.0f} s, opened in {t_big_open:.1f} s ({bi.regions} x 2^{int(np.log2(bi.table_lines // bi.regions))} lines = "
