@@ -613,12 +613,6 @@ void ref_free(kcfx_ref* r) {
     delete r;
 }
 
-// whose turn it is to stream a .kmc_suf onto device d (load_suffix_file)
-std::mutex& stream_turn(int32_t device) {
-    static std::mutex mu[64];
-    return mu[(uint32_t)device & 63u];
-}
-
 // KCFX_LOAD_TRACE=1: phase timings of kcfx_db_open on stderr
 struct LoadTrace {
     const char* tag = "load";
@@ -737,11 +731,6 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
         return launch_table_insert(db->d_lines, db->view(), h.k, keys, counts, n, db->stream);
     };
     auto stream_file = [&](int phase, bool keep) -> int32_t {
-        // One file at a time per device: two loads that stream together each take twice as long (the path page cache -> pinned
-        // buffer -> device is the shared resource: ~30 GB/s whatever the number of threads on it), and neither can start its build
-        // passes before its file is through. Taking turns, one load streams while the other parses its .kmc_pre, allocates, or runs
-        // its build passes on the GPU (kcfx_screen_sharded opens databases from two loader threads per device).
-        std::lock_guard<std::mutex> one_file(stream_turn(db->device));
         int64_t first = 0;
         int turn = 0;
         bool used[2] = {false, false};
@@ -880,9 +869,6 @@ int32_t decode_file_to_device(const std::string& path, const KmcHeader& h, uint6
     if (h.lut_entries) DEC_HIP(hipMemcpyAsync(d_lut, h.lut_bytes, (size_t)h.lut_entries * 8, hipMemcpyHostToDevice, st));
     int turn = 0;
     bool used[2] = {false, false};
-    int cur_dev = 0;
-    (void)hipGetDevice(&cur_dev);
-    std::unique_lock<std::mutex> one_file(stream_turn(cur_dev));    // (one file at a time per device: load_suffix_file)
     for (int64_t first = 0; first < h.total;) {
         const int64_t n = std::min(CH, h.total - first);
         const int64_t bytes = n * h.record_size;

@@ -282,9 +282,8 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
         // being screened. ONE loader by default: a load is a file streamed from the page cache through pinned buffers (~40 ms for
         // 1.2 GB: ~30 GB/s whatever the number of reader threads) followed by the build passes on the GPU (~22 ms), and two loads
         // in flight take exactly twice as long each -- measured, profiles/r04_notes.md: the host-side copy is the shared resource,
-        // not the GPU. Since the files take turns on that path (stream_turn, kcfx_api.cpp) a second loader does overlap one load's
-        // build passes with the next one's streaming: configs[3] on one GPU 0.68 s instead of 0.75 s for the sharded call -- not
-        // worth a third table in flight by default. KCFX_SHARD_LOADERS=1 .. 4 keeps the experiment repeatable. Cohort tables are opened one at a time
+        // not the GPU (making the files take turns on that path changes nothing either: profiles/r04_notes.md). KCFX_SHARD_LOADERS=
+        // 1 .. 4 keeps the experiment repeatable. Cohort tables are opened one at a time
         // (their vote table alone can take tens of GiB).
         std::mutex mu, cohort_mu;
         std::condition_variable cv;
