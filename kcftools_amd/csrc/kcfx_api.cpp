@@ -712,7 +712,7 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     tr.mark("buffers + LUT upload");
 
     // One pass of the build over a batch of decoded records. Line tables: 0 = count per home line (minimizer tables only),
-    // 1 = insert. Cell tables: 0 = count per minimizer sub-bucket, 1 / 2 = bids of the crowded / the other k-mers, 3 = settle
+    // 1 = insert. Cell tables: 0 = count per minimizer sub-bucket, 1 / 2 = claim the first-choice cells / write the winners' cell words, 3 = settle
     // the losers, 4 = fill the stash.
     auto apply = [&](int phase, const uint64_t* keys, const uint32_t* counts, int64_t n) -> hipError_t {
         if (cells) {

@@ -285,7 +285,8 @@ hipError_t launch_table_insert(uint8_t* lines, TableView tv, int32_t k, const ui
                                const uint32_t* counts, int64_t n, hipStream_t st);
 hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide, unsigned long long* stats, hipStream_t st);
 // FORMAT_CELLS build, five passes over the k-mers, each after ALL of the one before: count per minimizer sub-bucket
-// (cells_pop_bytes of zeroed scratch), bids of the crowded class (cls 1), bids of the others (cls 0), settle the losers into
+// (cells_pop_bytes of zeroed scratch), the bids for the first-choice cells (cls 1: every k-mer claims with its rank), the winners'
+// cell words (cls 0: written where a k-mer finds its own rank), settle the losers into
 // second-choice cells or flag them for the stash (stats[0] = how many), fill the stash
 size_t cells_pop_bytes(int32_t pop_bits);          // pop_bits = 32 (one counter per minimizer) or lbits + 2
 // (both = the database is canonical; see CELL_R_FLIP in kcfx_device.h for what a forward-only one changes)
