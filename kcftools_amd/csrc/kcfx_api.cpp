@@ -122,7 +122,7 @@ struct kcfx_db {
     // before the first bidding pass, which waits for it (table_ready)
     int32_t ext = 0;                     // FORMAT_CELLS: an extended table (TableView::ext)
     bool ext_auto = false;               // ... decided by the build itself: plain first, rebuilt extended if too many k-mers lost their cell
-    int32_t line_footprint = LINE_BYTES;   // bytes per table line the handle will hold in all (a cohort's key table: + 256 B of counters)
+    int32_t line_footprint = LINE_BYTES;   // bytes per table line the handle will hold in all (a cohort's key table: + 128 B of counters)
     std::thread alloc_thread;
     int32_t alloc_rc = KCFX_OK;          // written by alloc_thread, read after the join
     std::string alloc_error;
@@ -180,7 +180,7 @@ struct kcfx_cohort {
     int32_t device = 0;
     int32_t n_samples = 0;
     kcfx_db* keys = nullptr;           // the key table: an ordinary FORMAT_CELLS handle whose count fields are all 1
-    uint16_t* d_counts = nullptr;      // [16 * lines][COHORT_STRIDE]
+    uint8_t* d_counts = nullptr;       // [16 * lines][COHORT_STRIDE], 8 bits each
     uint16_t* d_scounts = nullptr;     // [stash slots][COHORT_STRIDE]
     kcfx_cohort_info_t info{};
 };
@@ -1489,7 +1489,7 @@ int32_t kcfx_cohort_open(const char* const* kmc_prefixes, int32_t n_samples, int
     db->info.counter_size = 2;
     db->info.device = device;
     db->expected_queries = opts ? opts->expected_queries : 0;
-    db->line_footprint = LINE_BYTES + 16 * COHORT_STRIDE * 2;       // cells + 16 bytes of counters per cell: the size policy budgets both
+    db->line_footprint = LINE_BYTES + 16 * COHORT_STRIDE;           // cells + 8 bytes of counters per cell: the size policy budgets both
     hipError_t e = db_stream(device, &db->stream);
     if (e != hipSuccess) return hip_fail(e, "hipStreamCreate");
     const size_t nn = (size_t)std::max<int64_t>(N, 1);
@@ -1555,8 +1555,8 @@ int32_t kcfx_cohort_open(const char* const* kmc_prefixes, int32_t n_samples, int
     if (int32_t rc = cells_stash_alloc(db)) return rc;       // (sized for the records that lost: a k-mer of several samples counts once per sample)
     if ((e = pass(4)) != hipSuccess) return hip_fail(e, "kcfx_cohort_open: stash pass");
     if (int32_t rc = table_finish(db)) return rc;
-    // the counters: COHORT_STRIDE u16 per cell and per stash slot
-    const size_t cell_bytes = ((size_t)db->n_lines * 16) * COHORT_STRIDE * 2, stash_bytes = ((size_t)db->stash_mask + 1) * COHORT_STRIDE * 2;
+    // the counters: COHORT_STRIDE u8 per cell, COHORT_STRIDE u16 per stash slot
+    const size_t cell_bytes = ((size_t)db->n_lines * 16) * COHORT_STRIDE, stash_bytes = ((size_t)db->stash_mask + 1) * COHORT_STRIDE * 2;
     if ((e = dev_alloc(&co->d_counts, cell_bytes)) != hipSuccess || (e = dev_alloc(&co->d_scounts, stash_bytes)) != hipSuccess ||
         (e = hipMemsetAsync(co->d_counts, 0, cell_bytes, db->stream)) != hipSuccess ||
         (e = hipMemsetAsync(co->d_scounts, 0, stash_bytes, db->stream)) != hipSuccess)
@@ -1621,7 +1621,7 @@ int32_t kcfx_cohort_screen_ref_async(kcfx_cohort* cohort, kcfx_ref* ref, int32_t
         ev1 = ref->events[ref->events_used].second;
         ref->events_used++;
     }
-    CohortView cv{cohort->keys->view(), reinterpret_cast<const uint4*>(cohort->d_counts), reinterpret_cast<const uint4*>(cohort->d_scounts),
+    CohortView cv{cohort->keys->view(), reinterpret_cast<const uint2*>(cohort->d_counts), reinterpret_cast<const uint4*>(cohort->d_scounts),
                   cohort->n_samples};
     KCFX_HIP(launch_screen_cohort(ref->d_text, ref->plan(), ref->d_tiles, ref->n_tiles, cv, ref->k, cohort->info.both_strands, min_kmer_count,
                                   ref->d_mbits, ref->d_mcsum, st, ev0, ev1));

@@ -107,13 +107,17 @@ struct TableView {
 
 // ----------------------------------------------------------------------------------------------------
 // Cohort table (kcfx_cohort_open): ONE FORMAT_CELLS key table for S <= COHORT_STRIDE samples -- every stored k-mer's count
-// field is 1 -- and the counters beside it: counts[cell][COHORT_STRIDE] u16 (cell = 16 * line + cell index: 16 bytes per
-// cell, 256 bytes per line), stash_counts[slot][COHORT_STRIDE] u16. Counters are at most 2 bytes wide (counter_size <= 2).
+// field is 1 -- and the counters beside it: counts[cell][COHORT_STRIDE] u8 (cell = 16 * line + cell index: 8 bytes per
+// cell, 128 bytes per line -- the ~10 cells of a minimizer run are ONE more line request; as u16 they were 1.75),
+// stash_counts[slot][COHORT_STRIDE] u16. Counters are at most 2 bytes wide (counter_size <= 2); a k-mer that some sample counted
+// more than COHORT_CELL_MAX times lives in the stash with all its counters (cohort_prio_kernel).
 // ----------------------------------------------------------------------------------------------------
 constexpr int COHORT_STRIDE = 8;
+constexpr uint32_t COHORT_CELL_MAX = 255u;        // what a cell's 8-bit counter of one sample holds (0 = the sample does not have the k-mer)
+constexpr uint32_t COHORT_RANK_WIDE = 0xFFFFu;    // the bid rank of a record whose k-mer has a wider counter in some sample: never bids, lives in the stash
 struct CohortView {
     TableView tv;
-    const uint4* counts;
+    const uint2* counts;
     const uint4* stash_counts;
     int32_t n_samples;
 };
@@ -309,7 +313,7 @@ hipError_t launch_cells_stash(const uint8_t* lines, int32_t k, int32_t lbits, in
 // record (samples holding its k-mer, then its counter) into the upper half of its counts word
 hipError_t launch_cohort_votes(const uint64_t* keys, uint32_t* counts, int64_t n, uint4* votes, uint32_t mask, int32_t phase, hipStream_t st);
 hipError_t launch_cohort_fill(TableView tv, int32_t k, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                              int32_t sample, uint16_t* cell_counts, uint16_t* stash_counts, hipStream_t st,
+                              int32_t sample, uint8_t* cell_counts, uint16_t* stash_counts, hipStream_t st,
                               const uint64_t* pw = nullptr, const uint8_t* ps = nullptr);
 hipError_t launch_screen_cohort(const uint8_t* text, RefPlan plan, const TileDesc* tiles, int32_t n_tiles, CohortView cv, int32_t k,
                                 int32_t both_strands, int32_t min_count, uint64_t* bits, int64_t* count_sums, hipStream_t st,

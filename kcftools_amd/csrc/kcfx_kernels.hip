@@ -212,6 +212,9 @@ constexpr uint32_t CELL_COUNT_MAX = 0xFFFFu;                // what the 16-bit c
 // and the stash. (With the counter alone as the rank half of the reference's k-mers lived in the stash: 32 M HBM requests per
 // pass of the bench cohort instead of 12 M.)
 __device__ __forceinline__ uint32_t cell_build_count(uint32_t c, int32_t presence) { return presence ? (c >> 16) : c; }
+// the k-mer of this record cannot have a cell: its counter does not fit (c = cell_build_count: a single sample's counter, or a cohort
+// record's rank, where cohort_prio_kernel marks "some sample's counter is wider than the cohort's 8-bit cell counters")
+__device__ __forceinline__ bool cell_is_wide(uint32_t c, int32_t presence) { return presence ? c == COHORT_RANK_WIDE : c > CELL_COUNT_MAX; }
 // cell word `have` (identity bits kc, flags and filter bits excluded) is the k-mer whose word is `mine`
 __device__ __forceinline__ bool cell_same(uint64_t have, uint64_t mine, uint64_t kc, int32_t presence) {
     if (!presence) return (have & kc) == mine;
@@ -336,7 +339,7 @@ __global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__
     for (; i < n; i += stride) {
         const uint32_t c = cell_build_count(counts[i], presence);
         if (c == 0) continue;                       // can never be observed (count >= -c >= 1 is needed): not stored
-        if (c > CELL_COUNT_MAX) continue;           // a 3- / 4-byte counter that does not fit a cell: lives in the stash (settle)
+        if (cell_is_wide(c, presence)) continue;    // a counter that does not fit a cell (3- / 4-byte; a cohort's: > 8 bits): lives in the stash (settle)
         bool crowded = false;
         record_cells(rp, i, keys[i], k, lbits, both != 0, [&](const CellProbe& p, int a) {
             if (a == 0) {
@@ -391,7 +394,7 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, in
         const uint32_t c = cell_build_count(counts[i], presence);
         if (c == 0) continue;
         bool lost = false;
-        const bool wide = c > CELL_COUNT_MAX;
+        const bool wide = cell_is_wide(c, presence);
         const int nc = record_cells(rp, i, keys[i], k, lbits, both, [&](const CellProbe& p, int) {
             uint8_t* line = lines + (size_t)cell_line_index(p.line, p.r, lbits, rp.regions) * LINE_BYTES;
             unsigned long long mark = CELL_FLAG_STASH;
@@ -473,7 +476,7 @@ __global__ void cells_stash_kernel(const uint8_t* __restrict__ lines, int32_t k,
         const uint32_t c = cell_build_count(counts[i], presence);
         if (c == 0) continue;
         const uint64_t key = keys[i];
-        bool lost = c > CELL_COUNT_MAX;                 // (counters wider than a cell's 16 bits)
+        bool lost = cell_is_wide(c, presence);          // (counters wider than a cell's 16 bits; a cohort's: than its 8)
         if (!lost)
             record_cells(rp, i, key, k, lbits, both != 0, [&](const CellProbe& p, int) { lost |= cell_standing(lines, p, c, lbits, both != 0, cell_nw(k), presence, rp.regions) == STAND_NONE; });
         if (!lost) continue;
@@ -581,9 +584,12 @@ __device__ __forceinline__ uint32_t stash_find_slot(const TableView& tv, uint64_
     }
 }
 
-// Votes: an open-addressing table {u64 key, u32 samples that hold it, u32 pad} over the records of all samples (the stash's
-// entry layout and probing), then every record's bid rank = min(samples, 15) << 12 | min(counter, 4095) into the upper half of
-// its counts word (counters of a cohort are at most 16 bits wide).
+// Votes: an open-addressing table {u64 key, u32 samples that hold it, u32 ~(largest counter any of them has)} over the records of
+// all samples (the stash's entry layout and probing), then every record's bid rank = min(samples, 15) << 12 | min(counter, 4095)
+// into the upper half of its counts word (counters of a cohort are at most 16 bits wide). A k-mer that SOME sample counted
+// COHORT_CELL_MAX + 1 times or more does not fit the table's 8-bit counters: every one of its records gets the rank COHORT_RANK_WIDE
+// (no real rank: that would take 15 samples) -- it never bids, flags the cells it would have and lives in the stash, whose
+// counters are 16 bits wide (as a k-mer with a 3- / 4-byte counter does in a single sample's table).
 __global__ void cohort_vote_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, int64_t n, uint4* votes, uint32_t mask) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -596,6 +602,7 @@ __global__ void cohort_vote_kernel(const uint64_t* __restrict__ keys, const uint
             const unsigned long long prev = atomicCAS(kp, (unsigned long long)EMPTY_KEY, (unsigned long long)key);
             if (prev == EMPTY_KEY || prev == key) {
                 atomicAdd(reinterpret_cast<uint32_t*>(kp) + 2, 1u);
+                atomicMin(reinterpret_cast<uint32_t*>(kp) + 3, ~(counts[i] & 0xFFFFu));     // (the entry's last word: ~ the largest counter)
                 break;
             }
             slot = (slot + 1) & mask;
@@ -609,19 +616,21 @@ __global__ void cohort_prio_kernel(const uint64_t* __restrict__ keys, uint32_t* 
         const uint32_t c = counts[i] & 0xFFFFu;
         if (c == 0) continue;
         const uint64_t key = keys[i];
-        uint32_t slot = stash_slot(key, mask), v = 1;
+        uint32_t slot = stash_slot(key, mask), v = 1, widest = c;
         for (;;) {
             const uint4 e = votes[slot];
             const uint64_t ek = u64_of(e.x, e.y);
             if (ek == key) {
                 // entries were zero-filled apart from the key (0xFF..): the vote word started at 0xFFFFFFFF and wrapped
                 v = e.z + 1u;
+                widest = ~e.w;
                 break;
             }
             if (ek == EMPTY_KEY) break;
             slot = (slot + 1) & mask;
         }
-        counts[i] = c | ((min(v, 15u) << 12 | min(c, 4095u)) << 16);
+        const uint32_t rank = widest > COHORT_CELL_MAX ? COHORT_RANK_WIDE : (min(v, 15u) << 12 | min(c, 4095u));
+        counts[i] = c | (rank << 16);
     }
 }
 
@@ -629,7 +638,7 @@ __global__ void cohort_prio_kernel(const uint64_t* __restrict__ keys, uint32_t* 
 // tied minimizers has several), or in the stash. Records of one sample are distinct k-mers and samples write different
 // columns, so there is no race.
 __global__ void cohort_fill_kernel(TableView tv, int32_t k, int32_t both_i, const uint64_t* __restrict__ keys,
-                                   const uint32_t* __restrict__ counts, int64_t n, int32_t sample, uint16_t* cell_counts,
+                                   const uint32_t* __restrict__ counts, int64_t n, int32_t sample, uint8_t* cell_counts,
                                    uint16_t* stash_counts, RecProbes rp) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -649,7 +658,7 @@ __global__ void cohort_fill_kernel(TableView tv, int32_t k, int32_t both_i, cons
             const CellProbe at = st == STAND_SECOND_LINE ? cell_second_line(p, tv.lbits)
                                  : st == STAND_THIRD_LINE ? cell_third_line(p, tv.lbits, both, cell_nw(k)) : p;
             const size_t cell = (size_t)cell_line_index(at.line, at.r, tv.lbits, tv.regions) * 16 + (sh >> 1);
-            cell_counts[cell * COHORT_STRIDE + sample] = (uint16_t)c;
+            cell_counts[cell * COHORT_STRIDE + sample] = (uint8_t)c;      // (<= COHORT_CELL_MAX: a k-mer with a wider counter anywhere has no cell)
         });
         if (stashed) {
             const uint32_t slot = stash_find_slot(tv, key);
@@ -1741,14 +1750,11 @@ struct CohortKeys {                       // stage 1 -> 2
     uint64_t l32;                         // 32 * line + 2 * first-choice cell: byte offset of the cell / 4, and of its counters / 8
     u32x2 cell, alt;
 };
-typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
 struct CohortCounts {                     // stage 2 -> 3
     uint64_t V, M;                        // valid lanes; lanes whose k-mer stands in a cell
-    u32x4_ c;                             // the 8 u16 counters of this lane's cell (meaningless outside M)
+    u32x2 c;                              // the 8 u8 counters of this lane's cell (meaningless outside M)
 };
 typedef const __attribute__((address_space(1))) u32x2* gcell_ptr_t;
-typedef u32x4_ u32x4;
-typedef const __attribute__((address_space(1))) u32x4* gcount_ptr_t;
 
 template <int K, bool BOTH, bool PLANNED>
 __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) void screen_cohort_kernel(
@@ -1790,8 +1796,9 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 
     if (w_begin < w_end) words.start(sh, off, td.n_kmers, lane, w_begin);
     const uint8_t* const count_base = reinterpret_cast<const uint8_t*>(cv.counts);
 
-    // u16 counter s of the eight a lane has loaded
-    auto counter = [&](const u32x4& c, int s) -> uint32_t {
+    // counter s of the eight a lane has loaded: 8 bits each in a cell, 16 bits each in a stash entry
+    auto counter = [&](const u32x2& c, int s) -> uint32_t { return ((s >> 2) == 0 ? c.x : c.y) >> (8 * (s & 3)) & 0xFFu; };
+    auto counter16 = [&](const uint4& c, int s) -> uint32_t {
         const uint32_t d = (s >> 1) == 0 ? c.x : (s >> 1) == 1 ? c.y : (s >> 1) == 2 ? c.z : c.w;
         return (s & 1) ? (d >> 16) : (d & 0xFFFFu);
     };
@@ -1831,15 +1838,18 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 
     // the queued k-mers (their cell sent them on, with their filter bit): looked up 64 at a time in their second line, then in
     // the stash (k31c_deferred_round); a lane that finds its k-mer fetches the counters of that cell / stash slot
     auto found = [&](uint32_t id, uint32_t, uint32_t where, bool in_stash) {
-        const uint4 c4 = in_stash ? cv.stash_counts[where] : cv.counts[where];
-        u32x4 c;
-        c.x = c4.x;
-        c.y = c4.y;
-        c.z = c4.z;
-        c.w = c4.w;
+        uint4 c16 = make_uint4(0u, 0u, 0u, 0u);
+        u32x2 c8;
+        c8.x = c8.y = 0u;
+        if (in_stash) c16 = cv.stash_counts[where];
+        else {
+            const uint2 t = cv.counts[where];
+            c8.x = t.x;
+            c8.y = t.y;
+        }
 #pragma unroll
         for (int s = 0; s < COHORT_STRIDE; ++s) {
-            const uint32_t cs = counter(c, s);
+            const uint32_t cs = in_stash ? counter16(c16, s) : counter(c8, s);
             if (s < S && (int32_t)cs >= min_count) {               // GetVariants.java:224-227
                 atomicOr(&q.hit[s][(id >> 6) & 0x3FFu], 1ull << (id & 63));
                 sum[s] += cs;
@@ -1869,8 +1879,8 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 
             const bool first = ((kw.cell.x ^ kw.w) <= CELL_FLAG_MASK) && (((kw.cell.y ^ kw.r) & cell_rmask(tv.lbits, BOTH)) == 0);
             l32 ^= (uint64_t)(first ? 0u : kw.dsh);
         }
-        if constexpr (W > CELL_ALT_FREE_MAX_W) cw.c = nt_load4(count_base + (l32 << 3));           // 16 bytes per cell, cell = l32 / 2
-        else cw.c = *(gcount_ptr_t)(count_base + (l32 << 3));
+        if constexpr (W > CELL_ALT_FREE_MAX_W) cw.c = nt_load2(count_base + (l32 << 2));           // 8 bytes per cell, cell = l32 / 2
+        else cw.c = *(gcell_ptr_t)(count_base + (l32 << 2));
         const uint64_t PM = wave_ballot(pend != 0u) & wave_ballot(cnt == 0u) & kw.V;
         if (PM) {
             const bool pending = __builtin_amdgcn_inverse_ballot_w64(PM);
@@ -2468,7 +2478,7 @@ hipError_t launch_cohort_votes(const uint64_t* keys, uint32_t* counts, int64_t n
 }
 
 hipError_t launch_cohort_fill(TableView tv, int32_t k, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                              int32_t sample, uint16_t* cell_counts, uint16_t* stash_counts, hipStream_t st, const uint64_t* pw, const uint8_t* ps) {
+                              int32_t sample, uint8_t* cell_counts, uint16_t* stash_counts, hipStream_t st, const uint64_t* pw, const uint8_t* ps) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(cohort_fill_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, tv, k, both, keys, counts, n, sample,
                        cell_counts, stash_counts, RecProbes{pw, ps, tv.ext, tv.regions});

@@ -88,6 +88,43 @@ def test_cohort_tables_for_the_other_kmer_lengths(oracle, tmp_path, monkeypatch,
                 assert np.array_equal(got[i][f], want[f]), (k, both, lbits, i, f)
 
 
+def test_cohort_counters_wider_than_a_cell_holds(oracle, tmp_path):
+    """A cohort cell has 8 bits per sample (one more line request per minimizer run instead of 1.75 for u16). A k-mer that SOME
+    sample counted more than 255 times lives in the stash with 16-bit counters for all samples -- also for the samples that hold it
+    with a small counter or not at all. Counters of exactly 255 and 256, 65 535, whole runs of wide k-mers (a repeat: every k-mer of
+    a window wide in one sample), -c thresholds above 255, KD sums: every (window, sample) against the oracle."""
+    ref = synth.random_reference(300_000, 77, n_run_every=60_000, max_n_run=200)
+    s, e = engine.windows(len(ref), 10_000, 0, K)
+    lens = e - s
+    prm = synth.KmcParams(k=K, p=3, counter_size=2, sig_len=7, n_bins=8, both_strands=True, max_count=65535)
+    prefixes = []
+    rng = np.random.default_rng(9)
+    for i in range(4):
+        kmers, counts = synth.build_sample_db(synth.mutate_sample(ref, 300 + i, sub_rate=0.004), prm, 400 + i, noise_kmers=3000)
+        counts = counts.astype(np.int64)
+        if i == 0:                                           # scattered wide counters, the boundary values among them
+            idx = rng.choice(len(kmers), 4000, replace=False)
+            counts[idx] = rng.choice([255, 256, 257, 300, 1000, 65535, 254], size=len(idx))
+        elif i == 1:                                         # a repeat: every k-mer of the first 25 kb of the reference is wide here
+            sel = np.isin(kmers, synth.kmers_of_text(ref[:25_000], K, True))
+            counts[sel] = 500 + (np.arange(int(sel.sum())) % 7) * 100
+        elif i == 2:
+            counts[:] = np.minimum(counts * 60, 65535)       # a deep sample: many counters near and above 255
+        prefix = str(tmp_path / f"w{i}")
+        synth.write_kmc(prefix, kmers, counts.astype(np.uint32), prm)
+        prefixes.append(prefix)
+    co = engine.Cohort(prefixes)
+    assert co.info.stash_records > 3000                      # the wide k-mers went there
+    r = engine.Reference(ref, s, lens, K)
+    for c in (1, 255, 256, 300, 1001):
+        check(co.screen(r, c), prefixes, ref, s, lens, c, oracle, f"wide counters, -c {c}")
+    # the same through a text-only reference and irregular windows
+    r1 = engine.Reference(ref, s, lens, K, expected_screens=1)
+    got_text, got_plan = co.screen(r1, 2), co.screen(r, 2)
+    for f in FIELDS:
+        assert np.array_equal(got_text[f], got_plan[f]), f
+
+
 @pytest.mark.parametrize("lbits,ext", [(17, 0), (17, 1), (20, 1)])
 def test_cohort_with_a_crowded_table_and_a_loaded_stash(oracle, tmp_path, monkeypatch, lbits, ext):
     """2^17 lines for ~2 M records: second choices and the stash (with its own counters) carry real weight; 2^20: third lines too
