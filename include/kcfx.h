@@ -235,7 +235,8 @@ int32_t kcfx_windows(int32_t seq_len, int32_t window, int32_t step, int32_t kmer
  * per sample: algorithmic bytes per sample-k-mer = (1 + 8) / S + counter_size. Needs k = 19 .. 31 (the k-mer lengths a cell
  * table exists for; one k across the samples), counters of at most 2 bytes and
  * one strandedness across the samples (KCFX_ERR_ARG otherwise: screen such samples through kcfx_screen_ref_multi).
- * Memory: 8 + 2 * KCFX_COHORT_MAX bytes per cell of the union of the samples' k-mers. */
+ * Memory: 8 + KCFX_COHORT_MAX bytes per cell of the union of the samples' k-mers (a cell holds 8 bits per sample; a k-mer that some
+ * sample counted more than 255 times lives in the overflow stash with 16-bit counters -- the results are exact either way). */
 #define KCFX_COHORT_MAX 8
 typedef struct kcfx_cohort kcfx_cohort;
 typedef struct {
@@ -278,8 +279,8 @@ void kcfx_ctx_destroy(kcfx_ctx* ctx);
                                   group-major sequence of (group, window) units is cut into equal contiguous parts like the grid's.
                                   8 samples on 8 devices: every device builds the same table and screens an eighth of the windows;
                                   32 samples: four tables, two devices each. A group whose table cannot be built (3- / 4-byte
-                                  counters, mixed strandedness, k outside 19 .. 31, no room: key table + 16 B of counters per cell,
-                                  ~0.85 GiB per million k-mers of the union at the one-pass density) is screened sample by sample.
+                                  counters, mixed strandedness, k outside 19 .. 31, no room: key table + 8 B of counters per cell,
+                                  ~0.55 GiB per million k-mers of the union at the one-pass density) is screened sample by sample.
                                   kcfx_shard_plan reports a group as seg_sample = its first sample; it spans
                                   min(KCFX_COHORT_MAX, n_samples - seg_sample) samples */
 
