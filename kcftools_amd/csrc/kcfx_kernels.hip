@@ -1739,7 +1739,8 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
 struct CohortQueue {
     uint32_t id[K31_QUEUE];                                           // (word of the wave << 6) | lane
     unsigned long long vw[CELLS_WORDS_PER_WAVE];                      // validity ballots of the wave's words
-    unsigned long long hit[COHORT_STRIDE][CELLS_WORDS_PER_WAVE];      // hit ballots per sample (OR-ed: the stash adds its own)
+    unsigned long long hit[COHORT_STRIDE][CELLS_WORDS_PER_WAVE];      // hit bits of the QUEUED k-mers per sample (OR-ed in by the lanes that find theirs)
+    unsigned long long own[COHORT_STRIDE][CELLS_WORDS_PER_WAVE];      // hit ballots of the words themselves per sample (written once, plain stores)
 };
 struct CohortKeys {                       // stage 1 -> 2
     uint64_t V;
@@ -1779,7 +1780,7 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 
     if constexpr (PLANNED) off = k31_load_plan_tile<CELLS_BLOCK>(sh, plan, td, K, tid);
     else off = k31_plan_tile<K>(sh, s_scratch.rows, text, td, tid);
     CohortQueue& q = s_scratch.queue[wave];
-    // the hit words are OR-ed into (the stash may add a k-mer's bits before or after its word's own ballots arrive); wave-private
+    // the queued k-mers' hit bits are OR-ed into zeroed words (a word's own ballots live beside them: CohortQueue::own); wave-private
     for (int i = lane; i < COHORT_STRIDE * CELLS_WORDS_PER_WAVE; i += 64) (&q.hit[0][0])[i] = 0ull;
     wave_lds_fence();
 
@@ -1892,18 +1893,24 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 
         while (qn >= 64) stash_round();
     };
     // stage 3: S hit ballots and count sums of the word
+    // (the S ballots of a word go to LDS in ONE store: sample s's ballot is put into lane s of a register pair -- v_writelane, two per
+    // sample -- where an atomicOr by "one lane" per sample cost the election of that lane, a branch and an LDS atomic each: 74 M VALU
+    // instructions per launch of the bench cohort, the kernel's bound, of which a quarter went there)
     auto consume = [&](int w, const CohortCounts& cw) {
         if (lane == 0) q.vw[w - w_begin] = cw.V;
-#pragma unroll
-        for (int s = 0; s < COHORT_STRIDE; ++s) {
+        uint32_t h_lo = 0u, h_hi = 0u;
+        static_for<0, COHORT_STRIDE>([&](auto ic) {
+            constexpr int s = ic;
             if (s < S) {
                 const uint32_t cs = counter(cw.c, s);
                 const uint64_t H = wave_ballot((int32_t)cs >= min_count) & cw.M;   // GetVariants.java:224
                 const bool hit = __builtin_amdgcn_inverse_ballot_w64(H);
-                if (lane == 0 && H) atomicOr(&q.hit[s][w - w_begin], (unsigned long long)H);
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(h_lo) : "s"((uint32_t)H), "n"(s));
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(h_hi) : "s"((uint32_t)(H >> 32)), "n"(s));
                 sum[s] += hit ? cs : 0u;                                           // GetVariants.java:226
             }
-        }
+        });
+        if (lane < S) q.own[lane][w - w_begin] = u64_of(h_lo, h_hi);
     };
     CohortKeys ka, kb;
     CohortCounts ca, cb;
@@ -1945,7 +1952,7 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 
         uint64_t* my_bits = bits + (size_t)s * bits_stride + (size_t)blockIdx.x * TILE_BITS_U64;
         if (lane < w_end - w_begin) {
             my_bits[w_begin + lane] = q.vw[lane];
-            my_bits[TILE_WORDS + w_begin + lane] = q.hit[s][lane];
+            my_bits[TILE_WORDS + w_begin + lane] = q.hit[s][lane] | q.own[s][lane];
         }
     }
 #pragma unroll
