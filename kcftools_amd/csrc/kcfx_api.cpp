@@ -1626,7 +1626,7 @@ int32_t kcfx_cohort_screen_ref_async(kcfx_cohort* cohort, kcfx_ref* ref, int32_t
     KCFX_HIP(launch_screen_cohort(ref->d_text, ref->plan(), ref->d_tiles, ref->n_tiles, cv, ref->k, cohort->info.both_strands, min_kmer_count,
                                   ref->d_mbits, ref->d_mcsum, st, ev0, ev1));
     KCFX_HIP(launch_reduce_windows(ref->d_tiles, ref->n_tiles, cohort->n_samples, ref->d_mbits, ref->d_mcsum, ref->d_win_tile0,
-                                   ref->n_windows, ref->k, reinterpret_cast<kcfx_result*>(out_device), st));
+                                   ref->n_windows, ref->k, reinterpret_cast<kcfx_result*>(out_device), st, 1));
     return KCFX_OK;
 } KCFX_CATCH("kcfx_cohort_screen_ref_async")
 

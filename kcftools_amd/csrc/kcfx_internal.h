@@ -333,7 +333,7 @@ hipError_t launch_screen_tiles(const uint8_t* text, RefPlan plan, const TileDesc
 // hit bitmaps + count sums of n_samples consecutive samples -> kcfx_result per (sample, window)
 hipError_t launch_reduce_windows(const TileDesc* tiles, int32_t n_tiles, int32_t n_samples, const uint64_t* bits,
                                  const int64_t* count_sums, const int32_t* win_tile0, int32_t n_windows, int32_t k,
-                                 kcfx_result* out, hipStream_t st);
+                                 kcfx_result* out, hipStream_t st, int32_t shared_valid = 0);
 // S <= SCREEN_MULTI_MAX tables in one pass over the reference (k = 31, M = 16 minimizer tables with one strandedness);
 // sample s writes bits + s * n_tiles * TILE_BITS_U64 and count_sums + s * n_tiles
 constexpr int SCREEN_MULTI_MAX = 8;

@@ -1948,10 +1948,10 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 
     while (qn > 0) stash_round();
     wave_lds_fence();
     const int64_t bits_stride = (int64_t)n_tiles * TILE_BITS_U64;
-    for (int s = 0; s < S; ++s) {                           // per sample: the wave's words of the tile's bitmap (validity replicated)
+    for (int s = 0; s < S; ++s) {                           // per sample: the wave's words of the tile's hit bitmap
         uint64_t* my_bits = bits + (size_t)s * bits_stride + (size_t)blockIdx.x * TILE_BITS_U64;
         if (lane < w_end - w_begin) {
-            my_bits[w_begin + lane] = q.vw[lane];
+            if (s == 0) my_bits[w_begin + lane] = q.vw[lane];          // (once: reduce_windows_kernel reads them for every sample, shared_valid)
             my_bits[TILE_WORDS + w_begin + lane] = q.hit[s][lane] | q.own[s][lane];
         }
     }
@@ -2219,10 +2219,13 @@ __global__ __launch_bounds__(REDUCE_BLOCK) void reduce_windows_kernel(const Tile
                                                                       const uint64_t* __restrict__ bits,
                                                                       const int64_t* __restrict__ count_sums,
                                                                       const int32_t* __restrict__ win_tile0, int32_t n_windows,
-                                                                      int32_t k, kcfx_result* __restrict__ out) {
+                                                                      int32_t k, kcfx_result* __restrict__ out, int32_t shared_valid) {
     constexpr int PW = TILE_WORDS / SUM_LANES;             // words per piece
     constexpr int GROUP = 64 / SUM_LANES;                  // tiles per wave step
     // blockIdx.y = sample of a multi-sample pass: its bitmaps, count sums and results follow the previous sample's
+    // (shared_valid: the validity words of a tile are the same for every sample and were written once, into sample 0's block --
+    // a cohort pass, whose kernel derives them once)
+    const uint64_t* const vbits = bits + (shared_valid ? 0 : (size_t)blockIdx.y * n_tiles * TILE_BITS_U64);
     bits += (size_t)blockIdx.y * n_tiles * TILE_BITS_U64;
     count_sums += (size_t)blockIdx.y * n_tiles;
     out += (size_t)blockIdx.y * n_windows;
@@ -2239,12 +2242,13 @@ __global__ __launch_bounds__(REDUCE_BLOCK) void reduce_windows_kernel(const Tile
             // everything the piece needs is requested at once (words beyond the tile's last are never looked at): the kernel's
             // time is its chain of dependent loads -- 9.4 us with one round trip per word, tile descriptor and count sum
             const uint64_t* b = bits + (size_t)t * TILE_BITS_U64 + sub * PW;
+            const uint64_t* bv = vbits + (size_t)t * TILE_BITS_U64 + sub * PW;
             const int32_t nk = tiles[t].n_kmers;
             const int64_t cs = count_sums[t];
             uint64_t Vl[PW], Hl[PW];
 #pragma unroll
             for (int i = 0; i < PW; ++i) {
-                Vl[i] = b[i];
+                Vl[i] = bv[i];
                 Hl[i] = b[TILE_WORDS + i];
             }
 #pragma unroll
@@ -2381,11 +2385,11 @@ hipError_t launch_lookup(TableView tv, int32_t k, const uint64_t* keys, int64_t 
 
 hipError_t launch_reduce_windows(const TileDesc* tiles, int32_t n_tiles, int32_t n_samples, const uint64_t* bits,
                                  const int64_t* count_sums, const int32_t* win_tile0, int32_t n_windows, int32_t k,
-                                 kcfx_result* out, hipStream_t st) {
+                                 kcfx_result* out, hipStream_t st, int32_t shared_valid) {
     if (n_windows <= 0 || n_samples <= 0) return hipSuccess;
     const int wpb = REDUCE_BLOCK / 64;
     hipLaunchKernelGGL(reduce_windows_kernel, dim3((n_windows + wpb - 1) / wpb, n_samples), dim3(REDUCE_BLOCK), 0, st, tiles,
-                       n_tiles, bits, count_sums, win_tile0, n_windows, k, out);
+                       n_tiles, bits, count_sums, win_tile0, n_windows, k, out, shared_valid);
     return hipGetLastError();
 }
 
