@@ -84,6 +84,15 @@ def test_error_codes_without_gpu(tmp_path):
     # (k - p) % 4 != 0 cannot be searched by the reference (HelperFunctions.java:232-243)
     with pytest.raises(engine.KcfxError):
         engine.KmcDb.build(np.zeros(1, dtype=np.uint64), np.ones(1, dtype=np.uint32), 33)
+    # argument errors of the round-4 entry points are found before any device is asked for
+    with pytest.raises(engine.KcfxError) as ei:
+        engine.Reference(b"ACGT" * 20, [0], [80], 31, expected_screens=-1)
+    assert ei.value.code == 1 and "expected_screens" in str(ei.value)            # KCFX_ERR_ARG
+    with pytest.raises(engine.KcfxError) as ei:
+        engine.Reference(b"ACGT" * 20, [70], [80], 31, expected_screens=1)            # a window past the text (FastaIndex.java:131-134)
+    assert "outside the text" in str(ei.value)
+    with pytest.raises(engine.KcfxError):
+        engine.table_plan(10, 0, True, 1 << 30)
 
 
 def test_score_matches_oracle(oracle):
