@@ -117,6 +117,47 @@ JNIEXPORT jlong JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_refCreate(JNIEnv* e
     return reinterpret_cast<jlong>(ref);
 }
 
+// long refCreateFor(int device, int k, ByteBuffer text, long[] winBegin, int[] winLen, int expectedScreens)
+// expectedScreens = 1: ONE database will be screened against this reference (a getVariations run as the plugin stands) -- it is
+// kept as text and the screening launch plans its tiles itself (kcfx_ref_create_opts); 0: unknown, planned once for any number
+JNIEXPORT jlong JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_refCreateFor(JNIEnv* env, jclass, jint device, jint k, jobject text,
+                                                                          jlongArray winBegin, jintArray winLen, jint expectedScreens) {
+    const auto* t = static_cast<const uint8_t*>(env->GetDirectBufferAddress(text));
+    if (!t) {
+        jclass cls = env->FindClass("java/lang/IllegalArgumentException");
+        if (cls) env->ThrowNew(cls, "text must be a direct buffer");
+        return 0;
+    }
+    const jlong tlen = env->GetDirectBufferCapacity(text);
+    const jsize n = env->GetArrayLength(winLen);
+    jlong* wb = env->GetLongArrayElements(winBegin, nullptr);
+    jint* wl = env->GetIntArrayElements(winLen, nullptr);
+    kcfx_ref* ref = nullptr;
+    kcfx_ref_opts opts;
+    opts.expected_screens = expectedScreens;
+    opts.reserved = 0;
+    const int32_t rc = kcfx_ref_create_opts(device, k, t, tlen, reinterpret_cast<const int64_t*>(wb),
+                                            reinterpret_cast<const int32_t*>(wl), n, &opts, &ref);
+    env->ReleaseLongArrayElements(winBegin, wb, JNI_ABORT);
+    env->ReleaseIntArrayElements(winLen, wl, JNI_ABORT);
+    if (rc) { throw_kcfx(env, rc); return 0; }
+    return reinterpret_cast<jlong>(ref);
+}
+
+// long[] tablePlan(long totalKmers, int k, boolean bothStrands, long freeBytes)  ->  {lines of 128 bytes, regions}; host only
+JNIEXPORT jlongArray JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_tablePlan(JNIEnv* env, jclass, jlong totalKmers, jint k,
+                                                                            jboolean bothStrands, jlong freeBytes) {
+    int64_t lines = 0;
+    int32_t regions = 1;
+    const int32_t rc = kcfx_table_plan(totalKmers, k, bothStrands ? 1 : 0, freeBytes, &lines, &regions);
+    if (rc) { throw_kcfx(env, rc); return nullptr; }
+    jlongArray out = env->NewLongArray(2);
+    if (!out) return nullptr;
+    const jlong v[2] = {(jlong)lines, (jlong)regions};
+    env->SetLongArrayRegion(out, 0, 2, v);
+    return out;
+}
+
 JNIEXPORT void JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_refDestroy(JNIEnv*, jclass, jlong ref) {
     kcfx_ref_destroy(reinterpret_cast<kcfx_ref*>(ref));
 }
