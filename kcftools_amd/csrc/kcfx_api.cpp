@@ -1246,6 +1246,9 @@ int32_t kcfx_ref_create_opts(int32_t device, int32_t kmer_length, const uint8_t*
     }
     if ((e = hipStreamSynchronize(r->stream)) != hipSuccess) return hip_fail(e, "kcfx_ref_create");
     trace.mark(planned ? "uploads + plan done" : "uploads done");
+    if (getenv("KCFX_VERBOSE"))
+        fprintf(stderr, "kcfx: reference: text at %p (%zu bytes with the plan), tiles at %p, bitmaps at %p, sums at %p, results at %p\n", (void*)r->d_text,
+                text_alloc + ab + cb, (void*)r->d_tiles, (void*)r->d_bits, (void*)r->d_csum, (void*)r->d_res);
     *out = hold.release();
     return KCFX_OK;
 } KCFX_CATCH("kcfx_ref_create_opts")

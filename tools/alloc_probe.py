@@ -11,10 +11,10 @@ prefix, meta = bench.make_dataset(synth_bin, os.environ.get("KCFX_BENCH_DIR", "/
 text = np.fromfile(prefix + ".ref.txt", dtype=np.uint8).tobytes()
 K = 31
 s, e = engine.windows(len(text), 10_000, 0, K)
+os.environ["KCFX_VERBOSE"] = "1"                  # (kcfx_db_open / kcfx_ref_create then say where their buffers are: stderr)
 ref = engine.Reference(text, s.astype(np.int64), (e - s).astype(np.int32), K)
 out = torch.zeros(len(s) * 10, dtype=torch.int32, device="cuda:0")
 st = torch.cuda.current_stream()
-os.environ["KCFX_VERBOSE"] = "1"                  # (kcfx_db_open then says where the table is: stderr)
 dbs = [engine.KmcDb.open(prefix) for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5)]
 def t(db, n=300):
     for _ in range(20):
@@ -28,3 +28,12 @@ def t(db, n=300):
     return ms / c
 for rep in range(2):
     print("round", rep, " ".join(f"{t(db):.5f}" for db in dbs), flush=True)
+# the same handles against a second reference (other addresses for text, plan and bitmaps): is a handle's speed its own?
+keep = [ref]
+for j, pad_mb in enumerate((300, 5000, 40000)):
+    pad = torch.zeros(pad_mb * 1_000_000, dtype=torch.uint8, device="cuda:0")      # (moves the next allocations somewhere else)
+    keep.append(pad)
+    ref = engine.Reference(text, s.astype(np.int64), (e - s).astype(np.int32), K)
+    keep.append(ref)
+    for rep in range(2):
+        print(f"ref {j + 2}, round", rep, " ".join(f"{t(db):.5f}" for db in dbs), flush=True)
