@@ -673,6 +673,14 @@ def test_fuzz_window_geometry_against_oracle(oracle, tmp_path, seed, kernel, mon
         elif seed % 3 == 2:                 # a few filter bits
             monkeypatch.setenv("KCFX_TABLE_LBITS", str(18 + seed % 4))
             noise = 300_000
+        # the table shapes large databases get, forced on small ones: extended (the first-choice line depends on the flank) and / or
+        # several regions of 2^lbits lines (the address of a line gets a region in front of it)
+        if seed % 5 in (1, 3):
+            monkeypatch.setenv("KCFX_TABLE_EXT", "1")
+        if seed % 4 == 1 or seed % 7 == 3:
+            monkeypatch.setenv("KCFX_TABLE_REGIONS", str((3, 5, 7)[seed % 3]))
+            if "KCFX_TABLE_LBITS" not in os.environ:
+                monkeypatch.setenv("KCFX_TABLE_LBITS", str(19 + seed % 3))
     p_of_k = {31: int(rng.choice([3, 7])), 30: 2, 29: 5, 28: 4, 27: 3, 26: 6, 25: 5, 24: 4, 23: 3, 22: 2, 21: 5, 20: 4, 19: 3}
     prefix, *_ = make_db(tmp_path, "fz", ref, 300 + seed, k=k, p=p_of_k[k], cs=cs, m=7, bins=4, both=both, noise=noise)
     db = engine.KmcDb.open(prefix)
@@ -688,7 +696,8 @@ def test_fuzz_window_geometry_against_oracle(oracle, tmp_path, seed, kernel, mon
     minc = int(rng.choice([1, 1, 2, 5]))
     got = db.screen(ref, begins, lens, minc)
     want = odb.screen(ref, begins, lens, minc, threads=4)
-    assert_same(got, want, f"fuzz seed {seed} (k={k}, cs={cs}, both={both}, -c {minc}, table 2^{int(np.log2(max(1, db.info.table_lines)))})")
+    assert_same(got, want, f"fuzz seed {seed} (k={k}, cs={cs}, both={both}, -c {minc}, table of {db.info.table_lines} lines, "
+                           f"regions {db.info.regions}, extended {db.info.extended})")
     assert_scores(oracle, got, want)
 
 
