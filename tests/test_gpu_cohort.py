@@ -15,11 +15,17 @@ FIELDS = engine.INT_FIELDS
 K = 31
 
 
-def make_sample(tmp_path, name, ref, seed, cs=2, both=True, noise=3000, k=K, **mut):
+def make_sample(tmp_path, name, ref, seed, cs=2, both=True, noise=3000, k=K, boost=False, **mut):
     sample = synth.mutate_sample(ref, seed, **mut)
     p = max(q for q in range(2, 8) if (k - q) % 4 == 0)
     prm = synth.KmcParams(k=k, p=p, counter_size=cs, sig_len=7, n_bins=8, both_strands=both, max_count=(1 << (8 * cs)) - 1)
     kmers, counts = synth.build_sample_db(sample, prm, seed + 1, noise_kmers=noise)
+    if boost:                                   # counters around and beyond the 255 a cohort cell holds per sample (capped at the database's own)
+        rng = np.random.default_rng(seed)
+        sel = rng.random(len(counts)) < 0.15
+        counts = counts.astype(np.int64)
+        counts[sel] = np.minimum(counts[sel] * rng.integers(8, 60, int(sel.sum())), prm.max_count)
+        counts = counts.astype(np.uint32)
     prefix = str(tmp_path / name)
     synth.write_kmc(prefix, kmers, counts, prm)
     return prefix
@@ -205,7 +211,8 @@ def test_cohort_fuzz_against_the_single_sample_path(oracle, tmp_path, monkeypatc
     both = bool(seed % 4)
     k = (31, 25, 29, 31, 27, 23, 31, 30, 21, 19)[seed % 10]
     prefixes = [make_sample(tmp_path, f"z{i}", ref, 9000 + 31 * seed + i, cs=int(rng.integers(1, 3)), both=both, k=k,
-                            noise=int(rng.choice([500, 20_000, 150_000])), sub_rate=float(rng.choice([0.001, 0.01, 0.03])))
+                            noise=int(rng.choice([500, 20_000, 150_000])), sub_rate=float(rng.choice([0.001, 0.01, 0.03])),
+                            boost=(seed + i) % 3 == 1)
                 for i in range(S)]
     if S > 2 and seed % 3 == 0:
         prefixes[-1] = prefixes[0]                          # the same database twice: two identical columns
