@@ -1,11 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- k-mers screened/s of the getVariations hot path on N MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path over one batch: every window of the reference screened against one
-sample's KMC database, inputs resident in HBM -- the reference as TEXT, the database as its table. A step is therefore K1 to K3 of
-SURVEY.md section 8(d): kcfx_ref_plan_async (2-bit pack, validity, minimizer choice: ref_plan_kernel) + kcfx_screen_ref_async
-(screen_k31c + reduce_windows). `--step amortised` leaves the plan out of the step (a job that screens MANY samples against one
-reference plans it once); the line carries both figures either way (`value` / `amortised`, `roofline.frac_one_pass` / `roofline.frac`).
+A "step" is one pass of the hot path over one batch: every window of the reference screened against one sample's KMC
+database, inputs resident in HBM -- the reference as TEXT, the database as its table: K1 to K3 of SURVEY.md section 8(d). The
+default form of the step is the one the product runs for one sample per reference (kcftools-amd getVariations, kcfx_screen_sharded,
+kcfx_ref_opts.expected_screens = 1): ONE launch of screen_k31c_kernel<k, both, false>, which plans its tiles itself (2-bit pack,
+validity, minimizer choice), + reduce_windows. `--step two-launch` is the same work as ref_plan_kernel + screening kernel on a
+planned reference, `--step amortised` leaves the plan out of the step (a job that screens MANY samples against one reference plans
+it once); at N = 1 the line carries all three (`other_forms`, `roofline.frac_one_pass` / `frac_two_launch` / `frac_amortised`).
+The line's figures are those of the W requested warm-up steps + K timed steps (`--spin-ms` > 0 adds a clock-ramped repeat as
+`ramped`, beside them); `cache_state` says what one launch costs after a read-only sweep of the caches and right after kcfx_db_open.
 
 Workload at N=1 (BASELINE.json configs[1]): synthetic A. thaliana chr1-sized reference (30,427,671 bp, seeded),
 one synthetic KMC sample (k=31, counter_size 2, ~150 M k-mers = sample-genome k-mers + random noise k-mers),
@@ -193,6 +197,73 @@ def usable_cores() -> int:
     return n
 
 
+def cache_state_leg(engine, torch, prefix, ref, db, out_ptr, stream, min_count, expected, device, launches=40, opens=5):
+    """What ONE screening launch costs depending on what the launches before it left on the chip (kernel time by HIP events on the
+    launch itself, so the sweeps between launches are not in it):
+      hot_loop     the launch repeated back to back (what every other figure of the line is);
+      read_swept   a READ-ONLY pass over a 1 GiB buffer (torch sum) between launches: L2s and Infinity Cache hold other data, nothing dirty;
+      write_swept  a 1 GiB fill between launches: the caches are left DIRTY, and the launch also pays their write-back (round 4's
+                   probe; kept for comparison, it is not what a clean cold start costs);
+      first_pass   a fresh kcfx_db_open followed at once by its first screening launch (the build kernels have just written the
+                   table: what a one-pass job sees), `opens` open / close cycles."""
+    def timed(pre, n):
+        ref.prof_enable(True)
+        ref.prof_read(reset=True)
+        for _ in range(n):
+            if pre is not None:
+                pre()
+            ref.screen_async(db, out_ptr, stream, min_count)
+        torch.cuda.synchronize()
+        ms, c = ref.prof_read(reset=True)
+        ref.prof_enable(False)
+        return ms / max(1, c)
+    res = {}
+    for _ in range(5):
+        ref.screen_async(db, out_ptr, stream, min_count)
+    torch.cuda.synchronize()
+    res["hot_loop_ms"] = timed(None, launches)
+    sweep = torch.ones(1 << 28, dtype=torch.int32, device=f"cuda:{device}")        # 1 GiB
+    sink = []
+    res["read_swept_ms"] = timed(lambda: sink.append(sweep.sum()), launches)
+    res["write_swept_ms"] = timed(lambda: sweep.fill_(1), launches)
+    del sweep, sink
+    # a fresh handle's first launches: right after kcfx_db_open (its build kernels have just written the table: L2s and Infinity
+    # Cache full of dirty lines of it), the launch after that one, and -- each on a handle of its own -- the first launch after a
+    # read-only sweep / after 50 ms of idle time between the open and the launch
+    def first_of(pre, n_launch=1):
+        d2 = engine.KmcDb.open(prefix, device=device, expected_queries=expected)
+        if pre is not None:
+            pre()
+        out_ms = []
+        for _ in range(n_launch):
+            ref.prof_enable(True)
+            ref.prof_read(reset=True)
+            ref.screen_async(d2, out_ptr, stream, min_count)
+            torch.cuda.synchronize()
+            ms, c = ref.prof_read(reset=True)
+            ref.prof_enable(False)
+            out_ms.append(ms / max(1, c))
+        d2.close()
+        return out_ms
+    sweep = torch.ones(1 << 28, dtype=torch.int32, device=f"cuda:{device}")
+    firsts, seconds, after_sweep, after_idle = [], [], [], []
+    for _ in range(opens):
+        a, b = first_of(None, 2)
+        firsts.append(a)
+        seconds.append(b)
+        after_sweep.append(first_of(lambda: (sweep.sum(), torch.cuda.synchronize()))[0])
+        after_idle.append(first_of(lambda: time.sleep(0.05))[0])
+    del sweep
+    med = lambda v: sorted(v)[len(v) // 2]
+    res["first_pass_ms"] = [round(x, 5) for x in firsts]
+    res["first_pass_median_ms"] = med(firsts)
+    res["second_pass_median_ms"] = med(seconds)
+    res["first_pass_after_read_sweep_median_ms"] = med(after_sweep)
+    res["first_pass_after_50ms_idle_median_ms"] = med(after_idle)
+    res["launches_per_state"] = launches
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,13 +281,19 @@ def main():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=5.0,
                     help="wall seconds per thread count of the CPU baseline leg (T = 1, 16, 64, all; 0 = skip)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the FASTA -> KCF command-line run")
+    ap.add_argument("--no-cache-state", action="store_true", help="skip the hot / swept / first-pass launches of the cache_state leg")
     ap.add_argument("--min-count", type=int, default=1)
-    ap.add_argument("--spin-ms", type=float, default=60.0,
-                    help="clock ramp before the timed steps: untimed repetitions of the step for this long, COUNTED in the reported "
-                         "\"warmup\"; the same K steps measured before the ramp are reported beside as \"cold_start\" (0 = no ramp)")
-    ap.add_argument("--step", choices=("one-pass", "amortised"), default="one-pass",
-                    help="one-pass: plan + screen + reduce (K1 - K3, what one sample per reference costs); amortised: the plan stays "
-                         "out of the step (many samples per reference)")
+    ap.add_argument("--spin-ms", type=float, default=0.0,
+                    help="0 (default): the line's figures are those of the W requested warm-up steps + K timed steps, nothing else. "
+                         "> 0: after them, a clock ramp -- untimed repetitions of the step for this long -- and the K steps once more: "
+                         "reported beside as \"ramped\" (its warm-up count stated there), never as the headline")
+    ap.add_argument("--step", choices=("one-pass", "two-launch", "amortised"), default="one-pass",
+                    help="one-pass (default): K1 - K3 of ONE sample against a reference the way the product runs it -- the reference "
+                         "resident as TEXT (kcfx_ref_opts.expected_screens = 1: what the command-line driver and kcfx_screen_sharded "
+                         "create), the screening launch plans its tiles itself: screen_k31c_kernel<K, both, false> + reduce_windows. "
+                         "two-launch: the same work as ref_plan_kernel + screening kernel + reduce on a planned reference. amortised: "
+                         "the plan stays out of the step (many samples per reference). With --samples > 1 the reference is planned "
+                         "and one-pass means two-launch")
     ap.add_argument("--table", choices=("product", "sparse"), default="product",
                     help="product: the table density the command-line driver selects for one pass (expected_queries = the step's "
                          "k-mers); sparse: kcfx_db_open's default for an unknown / large number of look-ups")
@@ -304,8 +381,14 @@ def main():
         lo, hi = shard.window_range_of_rank(win_len, K, world, rank)
         win_begin, win_len = win_begin[lo:hi], win_len[lo:hi]
 
+    # the form of the step (see --step). One sample: the product's one-launch form on a text-only reference unless asked otherwise.
+    single = (max(1, args.samples) == 1 and not args.cohort) or (cohort_sharded and S == 1)
+    form = args.step
+    if form == "one-pass" and not single:
+        form = "two-launch"
     t0 = time.time()
-    ref = engine.Reference(text, win_begin, win_len, K, device=local_rank)      # upload + tile plan + (k = 19 .. 31) the reference plan
+    # upload + tile list (+ for a planned reference, k = 19 .. 31: codes and anchor bytes by ref_plan_kernel)
+    ref = engine.Reference(text, win_begin, win_len, K, device=local_rank, expected_screens=1 if form == "one-pass" else 0)
     ref_s = time.time() - t0
     n_win = len(win_begin)
     # The table a handle gets depends on the look-ups it is opened for (kcfx_db_open_opts.expected_queries): the command-line
@@ -313,14 +396,15 @@ def main():
     expected = int(ref.n_kmer_slots) if args.table == "product" else 0
     t0 = time.time()
     cohort = None
-    if args.cohort and (S > 1 or cohort_sharded):
+    if args.cohort and S > 1:                      # (a group of ONE sample -- e.g. 9 samples on 2 ranks -- takes the single-database path, as kcfx_screen_sharded does)
         cohort = engine.Cohort(prefixes, device=local_rank, expected_queries=expected)
         dbs = [engine.KmcDb.open(prefixes[0], device=local_rank, expected_queries=expected)]   # (the first sample on its own: the parity leg's single-sample twin)
     else:
         dbs = [engine.KmcDb.open(pfx, device=local_rank, expected_queries=expected) for pfx in prefixes]
     db = dbs[0]
     load_s = (time.time() - t0) / S
-    one_pass = args.step == "one-pass" and ref.planned
+    if form != "one-pass" and not ref.planned:          # (k outside 19 .. 31, KCFX_REF_PLAN=0: there is no plan to make)
+        form = "amortised"
 
     # every rank gathers the same number of records (a window-sharded rank's range is padded to the longest)
     n_rec = S * n_win
@@ -333,43 +417,50 @@ def main():
     gathered = [torch.zeros_like(out, device=cdev) for _ in range(world)] if (world > 1 and rank == 0) else None
     stream = torch.cuda.current_stream()
 
-    def screen():
+    def screen(r, o):
         if cohort is not None:
-            cohort.screen_async(ref, out.data_ptr(), stream.cuda_stream, args.min_count)
+            cohort.screen_async(r, o.data_ptr(), stream.cuda_stream, args.min_count)
         elif S == 1:
-            ref.screen_async(db, out.data_ptr(), stream.cuda_stream, args.min_count)
+            r.screen_async(db, o.data_ptr(), stream.cuda_stream, args.min_count)
         else:
-            ref.screen_multi_async(dbs, out.data_ptr(), stream.cuda_stream, args.min_count)
+            r.screen_multi_async(dbs, o.data_ptr(), stream.cuda_stream, args.min_count)
 
-    def step():
-        if one_pass:
-            ref.plan_async(stream.cuda_stream)       # K1 + the minimizer choice: ref_plan_kernel over the resident text
-        screen()                                     # K2 + K3: screen_k31c / screen_cohort + reduce_windows
+    def make_step(r, o, frm):
+        """one step of form `frm` on reference r: one-pass = the one launch that plans its tiles itself (K1 - K3) + reduce;
+        two-launch = ref_plan_kernel, then screening kernel + reduce; amortised = screening kernel + reduce"""
+        def run():
+            if frm == "two-launch":
+                r.plan_async(stream.cuda_stream)     # K1 + the minimizer choice: ref_plan_kernel over the resident text
+            screen(r, o)                             # (K1 +) K2 + K3: screen_k31c / screen_cohort + reduce_windows
+        return run
+
+    step = make_step(ref, out, form)
 
     def final_gather():
         if world > 1:
             dist.gather(out.to(cdev), gathered, dst=0)      # RCCL over xGMI: 40 B per (window, sample), once per job
 
-    def timed(n_steps, with_gather):
+    def timed(run, r, n_steps, with_gather):
         """the contract's timed region: barrier + synchronize on both sides of exactly n_steps steps; kernel times by HIP events"""
-        ref.prof_enable(True)
-        ref.prof_read(reset=True)
-        ref.prof_read_plan(reset=True)
+        r.prof_enable(True)
+        r.prof_read(reset=True)
+        if r.planned:
+            r.prof_read_plan(reset=True)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t_a = time.perf_counter()
         for _ in range(n_steps):
-            step()
+            run()
         if with_gather:
             final_gather()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         t_e = time.perf_counter() - t_a
-        k_ms, k_n = ref.prof_read(reset=True)
-        p_ms, p_n = ref.prof_read_plan(reset=True)
-        ref.prof_enable(False)
+        k_ms, k_n = r.prof_read(reset=True)
+        p_ms, p_n = r.prof_read_plan(reset=True) if r.planned else (0.0, 0)
+        r.prof_enable(False)
         return t_e, k_ms, k_n, p_ms, p_n
 
     for _ in range(args.warmup):
@@ -380,62 +471,56 @@ def main():
     res = res_all[0]                               # the sample checked against the oracle below
     kmers_per_step = int(res_all["total_kmers"].sum())
 
-    # Without a clock ramp: the W warm-up steps above, then K steps. The driver's run is 5 + 20 steps = 3 ms of GPU work in all,
-    # which an idle GPU spends climbing out of its low-power clocks; reported as "cold_start" beside the figures below.
-    cold = None
-    spin_steps = 0
+    # ---- timed region: the W requested warm-up steps above, then exactly K steps ----------------------------------
+    elapsed, kernel_ms, launches, plan_ms_sum, plan_launches = timed(step, ref, args.steps, True)
+
+    # the other forms of the step, beside it (same process, no gather), each on its own reference handle and output buffer
+    others = {}
+    forms_same = None
+    if world == 1 and S == 1 and cohort is None and K >= 19:
+        ref_o = engine.Reference(text, win_begin, win_len, K, device=local_rank, expected_screens=0 if form == "one-pass" else 1)
+        out_o = torch.zeros_like(out)
+        for frm in ("one-pass", "two-launch", "amortised"):
+            if frm == form:
+                continue
+            r, o = (ref_o, out_o) if (frm == "one-pass") != (form == "one-pass") else (ref, out)
+            if (frm == "one-pass") == r.planned:           # (KCFX_REF_PLAN in the environment overrides the handle's form: skip)
+                continue
+            run = make_step(r, o, frm)
+            for _ in range(max(3, args.warmup)):
+                run()
+            o_el, o_kms, o_kn, o_pms, o_pn = timed(run, r, args.steps, False)
+            others[frm] = {"ms_per_step": o_el / args.steps * 1e3, "kernel_avg_ms": o_kms / max(1, o_kn),
+                           "ref_plan_ms": (o_pms / o_pn) if o_pn else None, "value": kmers_per_step * args.steps / o_el}
+        if any(((f == "one-pass") != (form == "one-pass")) for f in others):     # (the other handle ran)
+            forms_same = bool(torch.equal(out_o, out))
+        if forms_same is False:
+            log("bench.py: the text-only reference gives other results than the planned one")
+
+    # Optional clock ramp (--spin-ms > 0): the step repeated untimed for that long, then the K steps once more -- reported
+    # beside the line's own figures, never instead of them.
+    ramped = None
     if args.spin_ms > 0:
-        c_el, c_kms, c_kn, c_pms, c_pn = timed(args.steps, False)
-        cold = {"ms_per_step": c_el / args.steps * 1e3, "kernel_avg_ms": c_kms / max(1, c_kn),
-                "ref_plan_ms": (c_pms / c_pn) if c_pn else None, "warmup": args.warmup, "steps": args.steps,
-                "value": kmers_per_step * args.steps / c_el}
-        # Clock ramp: the same step, untimed, for --spin-ms; its repetitions are COUNTED in the reported "warmup".
+        spin_steps = 0
         t_spin = time.perf_counter()
         while (time.perf_counter() - t_spin) * 1e3 < args.spin_ms:
             for _ in range(50):
                 step()
             torch.cuda.synchronize()
             spin_steps += 50
+        r_el, r_kms, r_kn, r_pms, r_pn = timed(step, ref, args.steps, False)
+        ramped = {"ms_per_step": r_el / args.steps * 1e3, "kernel_avg_ms": r_kms / max(1, r_kn),
+                  "ref_plan_ms": (r_pms / r_pn) if r_pn else None, "value": kmers_per_step * args.steps / r_el,
+                  "untimed_steps_before": args.warmup + args.steps * (1 + len(others)) + spin_steps, "spin_ms": args.spin_ms}
 
-    # ---- timed region -----------------------------------------------------------------------------------------
-    elapsed, kernel_ms, launches, plan_ms_sum, plan_launches = timed(args.steps, True)
-
-    # the other form of the step, beside it (same clocks, no gather): amortised when the step is one pass and vice versa
-    other = None
-    text_only = None
-    if world == 1 and S == 1 and cohort is None and ref.planned:
-        one_pass = not one_pass
-        o_el, o_kms, o_kn, o_pms, o_pn = timed(args.steps, False)
-        one_pass = not one_pass
-        other = {"ms_per_step": o_el / args.steps * 1e3, "kernel_avg_ms": o_kms / max(1, o_kn),
-                 "ref_plan_ms": (o_pms / o_pn) if o_pn else None, "value": kmers_per_step * args.steps / o_el}
-        # ... and K1 - K3 in ONE launch: the same reference kept as text only (KCFX_REF_PLAN=0 is read by kcfx_ref_create), every
-        # tile planned inside the screening kernel
+    # what ONE launch costs by what the launches before it left on the chip (hot loop / caches swept / first launch after an open)
+    cache_state = None
+    if world == 1 and S == 1 and cohort is None and not args.no_cache_state:
         try:
-            os.environ["KCFX_REF_PLAN"] = "0"
-            ref_t = engine.Reference(text, win_begin, win_len, K, device=local_rank)
-        finally:
-            os.environ.pop("KCFX_REF_PLAN", None)
-        out_t = torch.zeros_like(out)
-        for _ in range(max(3, args.warmup)):
-            ref_t.screen_async(db, out_t.data_ptr(), stream.cuda_stream, args.min_count)
-        ref_t.prof_enable(True)
-        ref_t.prof_read(reset=True)
-        torch.cuda.synchronize()
-        t_a = time.perf_counter()
-        for _ in range(args.steps):
-            ref_t.screen_async(db, out_t.data_ptr(), stream.cuda_stream, args.min_count)
-        torch.cuda.synchronize()
-        t_el = time.perf_counter() - t_a
-        t_kms, t_kn = ref_t.prof_read(reset=True)
-        ref_t.prof_enable(False)
-        same = bool(torch.equal(out_t, out))
-        text_only = {"kernel_avg_ms": t_kms / max(1, t_kn), "ms_per_step": t_el / args.steps * 1e3,
-                     "value": kmers_per_step * args.steps / t_el, "identical_to_planned": same}
-        if not same:
-            log("bench.py: the text-only reference gives other results than the planned one")
-        ref_t.close()
-        del out_t
+            cache_state = cache_state_leg(engine, torch, prefix, ref, db, out.data_ptr(), stream.cuda_stream, args.min_count, expected,
+                                          local_rank)
+        except Exception as exc:                     # the bench line must not die on the extra leg
+            cache_state = {"error": str(exc)[:300]}
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     tot = torch.tensor([kmers_per_step], dtype=torch.int64, device=cdev)
@@ -458,15 +543,27 @@ def main():
     # cohort table the key is compared once for all of them too: (1 + 8) / S + counter_size
     b_alg = ((1.0 + 8.0) / S + COUNTER_SIZE) if cohort is not None else (1.0 / S + 8 + COUNTER_SIZE)
     achieved_gbs = (kmers_per_step * b_alg / launches_per_step) / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
-    # K1 - K3: the plan kernel + the screening kernel of the same timed region (or of the other form of the step, run beside it)
-    plan_avg_ms = (plan_ms_sum / plan_launches) if plan_launches else ((other or {}).get("ref_plan_ms"))
-    one_pass_gbs = ((kmers_per_step * b_alg / launches_per_step) / ((kern_avg_ms + plan_avg_ms) * 1e-3) / 1e9
-                    if (plan_avg_ms and kern_avg_ms > 0) else None)
-    text_only_gbs = ((kmers_per_step * b_alg) / (text_only["kernel_avg_ms"] * 1e-3) / 1e9
-                     if (text_only and text_only["kernel_avg_ms"] > 0) else None)
+    # every form of the step that was measured: its screening kernel's average, its plan kernel's (two-launch), and the same
+    # algorithmic bytes over what the form launches for K1 - K3
+    plan_avg_ms = (plan_ms_sum / plan_launches) if plan_launches else None
+    forms = {form: {"ms_per_step": ms_per_step, "kernel_avg_ms": kern_avg_ms, "ref_plan_ms": plan_avg_ms, "value": value}}
+    forms.update(others)
+    if plan_avg_ms is None:
+        plan_avg_ms = (forms.get("two-launch") or {}).get("ref_plan_ms")
+    step_bytes = kmers_per_step * b_alg / launches_per_step
+
+    def frac_of(frm):
+        f = forms.get(frm)
+        if not f or not f["kernel_avg_ms"]:
+            return None
+        ms = f["kernel_avg_ms"] + ((f["ref_plan_ms"] or 0.0) if frm == "two-launch" else 0.0)
+        return step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
 
     kernel_name = ("screen_k31c_kernel" if db.info.table_format == 1 else "screen_k31_kernel") if (S == 1 or db.info.table_format == 1) \
         else "screen_k31_multi_kernel"
+    # (the instantiation, as rocprofv3 --kernel-trace names it: <k, both strands, planned reference>)
+    kernel_inst = (f"screen_k31c_kernel<{K}, {'true' if db.info.both_strands else 'false'}, {'false' if form == 'one-pass' else 'true'}>"
+                   if kernel_name == "screen_k31c_kernel" else kernel_name)
     if cohort is not None:
         kernel_name = "screen_cohort_kernel"
     if os.environ.get("KCFX_GENERIC_KERNEL"):           # A/B hook: the general kernel on a line table
@@ -484,7 +581,7 @@ def main():
             tj = json.load(open(tpath))
             if (S == 1 and world == 1 and tj.get("kernel") == kernel_name and tj.get("ref_len") == args.ref_len
                     and tj.get("db_kmers") == args.db_kmers and tj.get("window") == args.window
-                    and tj.get("table_lines") in (None, int(db.info.table_lines))):
+                    and tj.get("table_lines") in (None, int(db.info.table_lines)) and tj.get("step_form", "two-launch") == form):
                 traffic = tj.get("hbm_bytes_per_launch")
                 requests = tj.get("hbm_read_requests_per_launch")
                 rocprof_ms = tj.get("rocprof_kernel_avg_ms")    # the committed rocprofv3 --stats average of the same kernel
@@ -629,15 +726,17 @@ def main():
         "unit": "k-mers/s",
         "n_gpus": world,
         "steps": args.steps,
-        # (every untimed step before the timed region: the W requested + the clock ramp's; "cold_start" = W warm-up steps, no ramp)
-        "warmup": args.warmup + spin_steps + (args.steps if cold is not None else 0),
-        "warmup_requested": args.warmup,
+        "warmup": args.warmup,
         "ms_per_step": ms_per_step,
-        "step": ("one pass: ref_plan_kernel + screening kernel + reduce_windows (K1 - K3, reference resident as text + plan buffers)"
-                 if one_pass else "amortised: screening kernel + reduce_windows (the reference's plan made once, outside the step)"),
-        ("amortised" if one_pass else "one_pass"): other,
-        "cold_start": cold,
-        "text_only_reference": text_only,
+        "step": {"one-pass": "one pass of one sample as the product runs it: the reference resident as text, ONE launch that plans its "
+                             "tiles itself (K1 - K3: screen_k31c_kernel<k, both, false>) + reduce_windows",
+                 "two-launch": "one pass as two launches on a planned reference: ref_plan_kernel + screening kernel + reduce_windows (K1 - K3)",
+                 "amortised": "screening kernel + reduce_windows (the reference's plan made once, outside the step: many samples per reference)"}[form],
+        "step_form": form,
+        "other_forms": others or None,
+        "forms_identical": forms_same,
+        "ramped": ramped,
+        "cache_state": cache_state,
         "higher_is_better": True,
         "scaling": "strong" if window_sharded else "weak",
         "vs_baseline": None,
@@ -666,14 +765,13 @@ def main():
         "windows_per_s": (n_win_total * max(1, args.samples) if window_sharded else n_win * S * world) * args.steps / elapsed,
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": kernel_name, "kernel_avg_ms": kern_avg_ms,
+                     "kernel": kernel_name, "kernel_instance": kernel_inst, "kernel_avg_ms": kern_avg_ms,
                      "launches_timed": int(launches), "algorithmic_bytes_per_kmer": b_alg if S > 1 else B_ALG,
                      "rocprof_kernel_avg_ms": rocprof_ms,
-                     # K1 - K3 for ONE sample: the same bytes over plan + screen (two launches) and over the one launch of a
-                     # text-only reference
-                     "ref_plan_ms": plan_avg_ms, "frac_one_pass": (one_pass_gbs / HBM_PEAK_GBS) if one_pass_gbs else None,
-                     "text_only_kernel_ms": text_only["kernel_avg_ms"] if text_only else None,
-                     "frac_text_only": (text_only_gbs / HBM_PEAK_GBS) if text_only_gbs else None,
+                     # the same bytes over each form of the step that was measured: the one launch on a text-only reference (K1 - K3),
+                     # plan + screen on a planned one (K1 - K3 in two launches), the screening kernel alone (plan amortised)
+                     "ref_plan_ms": plan_avg_ms, "frac_one_pass": frac_of("one-pass"), "frac_two_launch": frac_of("two-launch"),
+                     "frac_amortised": frac_of("amortised"),
                      "table": {"policy": args.table, "expected_queries": expected, "lines": int(db.info.table_lines),
                                "bytes": int(db.info.table_bytes), "kmers_per_cell": float(db.info.stored_kmers) / max(1, 16 * int(db.info.table_lines)),
                                "stash_kmers": int(db.info.stash_kmers)}},
@@ -689,14 +787,14 @@ def main():
         # anchor byte per k-mer, what every screening launch against this reference then starts from; outside the timed region
         # like the database's table, inside end_to_end)
         "setup_seconds": {"generate": gen_s, "db_open": load_s, "db_open_inner": float(db.info.load_seconds),
-                          "ref_create": ref_s, "clock_ramp_steps": spin_steps},
+                          "ref_create": ref_s},
     }
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
     # a number measured on results that differ from the oracle's (or on two forms of the kernel that disagree) is not a
     # measurement: the line above says so ("parity", "identical_to_planned"), and so does the exit code
-    wrong = (parity is not None and not parity["bit_exact"]) or (text_only is not None and not text_only["identical_to_planned"])
+    wrong = (parity is not None and not parity["bit_exact"]) or (forms_same is False)
     if wrong:
         log("bench.py: PARITY FAILURE -- the line above is not a valid measurement")
         sys.exit(3)

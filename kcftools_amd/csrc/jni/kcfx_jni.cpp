@@ -20,7 +20,9 @@ extern "C" {
 
 // long dbOpen(String kmcPrefix, int device)                              <-> new KMC(prefix, inMemory), KMC.java:56
 JNIEXPORT jlong JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_dbOpen(JNIEnv* env, jclass, jstring prefix, jint device) {
+    if (!prefix) { throw_kcfx(env, KCFX_ERR_ARG); return 0; }
     const char* p = env->GetStringUTFChars(prefix, nullptr);
+    if (!p) return 0;                                       // (OutOfMemoryError is pending)
     kcfx_db* db = nullptr;
     const int32_t rc = kcfx_db_open(p, device, &db);
     env->ReleaseStringUTFChars(prefix, p);
@@ -87,7 +89,12 @@ JNIEXPORT void JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_screen(JNIEnv* env, 
         return;
     }
     jlong* wb = env->GetLongArrayElements(winBegin, nullptr);
+    if (!wb) return;                                        // (OutOfMemoryError is pending)
     jint* wl = env->GetIntArrayElements(winLen, nullptr);
+    if (!wl) {
+        env->ReleaseLongArrayElements(winBegin, wb, JNI_ABORT);
+        return;
+    }
     const int32_t rc = kcfx_screen(reinterpret_cast<kcfx_db*>(db), t, tlen, reinterpret_cast<const int64_t*>(wb),
                                    reinterpret_cast<const int32_t*>(wl), n, minKmerCount, out);
     env->ReleaseLongArrayElements(winBegin, wb, JNI_ABORT);
@@ -95,26 +102,42 @@ JNIEXPORT void JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_screen(JNIEnv* env, 
     if (rc) throw_kcfx(env, rc);
 }
 
-// long refCreate(int device, int k, ByteBuffer text, long[] winBegin, int[] winLen)   -- reference resident for several samples
-JNIEXPORT jlong JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_refCreate(JNIEnv* env, jclass, jint device, jint k, jobject text,
-                                                                       jlongArray winBegin, jintArray winLen) {
-    const auto* t = static_cast<const uint8_t*>(env->GetDirectBufferAddress(text));
-    if (!t) {
+
+// shared body of refCreate / refCreateFor: both window arrays must have the same length (the tile planner of
+// kcfx_ref_create_opts reads winBegin[i] for every i < winLen.length) and may fail to pin
+static jlong ref_create_checked(JNIEnv* env, jint device, jint k, jobject text, jlongArray winBegin, jintArray winLen,
+                                const kcfx_ref_opts* opts) {
+    auto illegal = [&](const char* msg) -> jlong {
         jclass cls = env->FindClass("java/lang/IllegalArgumentException");
-        if (cls) env->ThrowNew(cls, "text must be a direct buffer");
+        if (cls) env->ThrowNew(cls, msg);
         return 0;
-    }
+    };
+    if (!text || !winBegin || !winLen) return illegal("text, winBegin and winLen must not be null");
+    const auto* t = static_cast<const uint8_t*>(env->GetDirectBufferAddress(text));
+    if (!t) return illegal("text must be a direct buffer");
     const jlong tlen = env->GetDirectBufferCapacity(text);
     const jsize n = env->GetArrayLength(winLen);
+    if (env->GetArrayLength(winBegin) != n) return illegal("winBegin and winLen differ in length");
     jlong* wb = env->GetLongArrayElements(winBegin, nullptr);
+    if (!wb) return 0;                                      // (OutOfMemoryError is pending)
     jint* wl = env->GetIntArrayElements(winLen, nullptr);
+    if (!wl) {
+        env->ReleaseLongArrayElements(winBegin, wb, JNI_ABORT);
+        return 0;
+    }
     kcfx_ref* ref = nullptr;
-    const int32_t rc = kcfx_ref_create(device, k, t, tlen, reinterpret_cast<const int64_t*>(wb),
-                                       reinterpret_cast<const int32_t*>(wl), n, &ref);
+    const int32_t rc = kcfx_ref_create_opts(device, k, t, tlen, reinterpret_cast<const int64_t*>(wb),
+                                            reinterpret_cast<const int32_t*>(wl), n, opts, &ref);
     env->ReleaseLongArrayElements(winBegin, wb, JNI_ABORT);
     env->ReleaseIntArrayElements(winLen, wl, JNI_ABORT);
     if (rc) { throw_kcfx(env, rc); return 0; }
     return reinterpret_cast<jlong>(ref);
+}
+
+// long refCreate(int device, int k, ByteBuffer text, long[] winBegin, int[] winLen)
+JNIEXPORT jlong JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_refCreate(JNIEnv* env, jclass, jint device, jint k, jobject text,
+                                                                       jlongArray winBegin, jintArray winLen) {
+    return ref_create_checked(env, device, k, text, winBegin, winLen, nullptr);
 }
 
 // long refCreateFor(int device, int k, ByteBuffer text, long[] winBegin, int[] winLen, int expectedScreens)
@@ -122,26 +145,10 @@ JNIEXPORT jlong JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_refCreate(JNIEnv* e
 // kept as text and the screening launch plans its tiles itself (kcfx_ref_create_opts); 0: unknown, planned once for any number
 JNIEXPORT jlong JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_refCreateFor(JNIEnv* env, jclass, jint device, jint k, jobject text,
                                                                           jlongArray winBegin, jintArray winLen, jint expectedScreens) {
-    const auto* t = static_cast<const uint8_t*>(env->GetDirectBufferAddress(text));
-    if (!t) {
-        jclass cls = env->FindClass("java/lang/IllegalArgumentException");
-        if (cls) env->ThrowNew(cls, "text must be a direct buffer");
-        return 0;
-    }
-    const jlong tlen = env->GetDirectBufferCapacity(text);
-    const jsize n = env->GetArrayLength(winLen);
-    jlong* wb = env->GetLongArrayElements(winBegin, nullptr);
-    jint* wl = env->GetIntArrayElements(winLen, nullptr);
-    kcfx_ref* ref = nullptr;
     kcfx_ref_opts opts;
     opts.expected_screens = expectedScreens;
     opts.reserved = 0;
-    const int32_t rc = kcfx_ref_create_opts(device, k, t, tlen, reinterpret_cast<const int64_t*>(wb),
-                                            reinterpret_cast<const int32_t*>(wl), n, &opts, &ref);
-    env->ReleaseLongArrayElements(winBegin, wb, JNI_ABORT);
-    env->ReleaseIntArrayElements(winLen, wl, JNI_ABORT);
-    if (rc) { throw_kcfx(env, rc); return 0; }
-    return reinterpret_cast<jlong>(ref);
+    return ref_create_checked(env, device, k, text, winBegin, winLen, &opts);
 }
 
 // long[] tablePlan(long totalKmers, int k, boolean bothStrands, long freeBytes)  ->  {lines of 128 bytes, regions}; host only
@@ -225,7 +232,9 @@ JNIEXPORT void JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_cohortScreenRef(JNIE
 
 // int[] dbHeader(String kmcPrefix): the dbInfo fields from the header alone, no GPU (KMC.java:107-168; GetVariants.java:96,103)
 JNIEXPORT jintArray JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_dbHeader(JNIEnv* env, jclass, jstring prefix) {
+    if (!prefix) { throw_kcfx(env, KCFX_ERR_ARG); return nullptr; }
     const char* p = env->GetStringUTFChars(prefix, nullptr);
+    if (!p) return nullptr;
     kcfx_db_info_t info;
     const int32_t rc = kcfx_db_header(p, &info);
     env->ReleaseStringUTFChars(prefix, p);
@@ -272,7 +281,7 @@ JNIEXPORT void JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_screenSharded(JNIEnv
     const char** names = new const char*[s > 0 ? s : 1];
     for (jsize i = 0; i < s; ++i) names[i] = env->GetStringUTFChars(static_cast<jstring>(env->GetObjectArrayElement(prefixes, i)), nullptr);
     jlong* wb = env->GetLongArrayElements(winBegin, nullptr);
-    jint* wl = env->GetIntArrayElements(winLen, nullptr);
+    jint* wl = env->GetIntArrayElements(winLen, nullptr);       // (a null from either: kcfx_screen_sharded returns KCFX_ERR_ARG)
     rc = kcfx_screen_sharded(ctx, names, s, k, t, env->GetDirectBufferCapacity(text), reinterpret_cast<const int64_t*>(wb),
                              reinterpret_cast<const int32_t*>(wl), n, minKmerCount, shardMode, out, nullptr);
     env->ReleaseLongArrayElements(winBegin, wb, JNI_ABORT);

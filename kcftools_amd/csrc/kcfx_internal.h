@@ -150,11 +150,12 @@ constexpr int TILE_K = KCFX_TILE_K;   // k-mer start positions per tile (multipl
 constexpr int TILE_WORDS = TILE_K / 64;
 // per tile: TILE_WORDS valid-ballots then TILE_WORDS hit-ballots (screen kernel -> reduce_windows)
 constexpr int TILE_BITS_U64 = 2 * TILE_WORDS;
-// A reference that is kept as text only (KCFX_REF_PLAN=0) is planned tile by tile inside the screening launch (k31_plan_tile):
-// every thread of the workgroup plans a strip of 16 positions, the last two strips only lend to their neighbours -- which
-// covers tiles of at most this many k-mers (up to 15 bases of alignment in front). Not a multiple of 64: a 10 kb window is
-// 5 x 1 994 k-mers, and only a tile's LAST word has to be ragged.
-constexpr int TEXT_TILE_K = 16 * (CELLS_BLOCK - 2) - 15;
+// A reference that is kept as text only (kcfx_ref_opts.expected_screens = 1, KCFX_REF_PLAN=0) is planned tile by tile inside the
+// screening launch. screen_k31c_kernel: ONE wave per tile, a strip of 32 positions per lane, lane 63's strip only lends to its
+// neighbour (k31_plan_tile_wave); screen_cohort_kernel: every thread of the workgroup a strip of 16, the last two strips only
+// lend (k31_plan_tile). Either way that covers tiles of at most this many k-mers (up to 15 bases of alignment in front). Not a
+// multiple of 64: a 10 kb window is 5 x 1 994 k-mers, and only a tile's LAST word has to be ragged.
+constexpr int TEXT_TILE_K = (16 * (CELLS_BLOCK - 2) < 32 * 63 ? 16 * (CELLS_BLOCK - 2) : 32 * 63) - 15;
 
 // The sample-independent half of a cell-table look-up, worked out once per reference (launch_ref_plan, k = 19 .. 31):
 // 2-bit codes of the text (16 bases per dword, first base in the top bits) and one anchor byte per k-mer start position

@@ -1253,11 +1253,23 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 constexpr int CELLS_WAVES = CELLS_BLOCK / 64;
 constexpr int CELLS_WORDS_PER_WAVE = (TILE_WORDS + CELLS_WAVES - 1) / CELLS_WAVES;
 static_assert(CELLS_WAVES >= 1 && CELLS_WAVES <= WAVES && CELLS_WORDS_PER_WAVE <= 64, "cell-table kernel: workgroup shape");
-struct K31CQueue {
+template <int WPW = CELLS_WORDS_PER_WAVE>
+struct K31CQueueT {
     uint32_t id[K31_QUEUE];                                 // (word of the wave << 6) | lane
-    unsigned long long hit[CELLS_WORDS_PER_WAVE];           // hit ballots of the wave's words
-    unsigned long long vw[CELLS_WORDS_PER_WAVE];            // their validity ballots (written out with the hits)
+    unsigned long long hit[WPW];                            // hit ballots of the wave's words
+    unsigned long long vw[WPW];                             // their validity ballots (written out with the hits)
 };
+typedef K31CQueueT<> K31CQueue;
+// A text-only reference (K1 - K3 in one launch) is screened by ONE wave per tile: the wave plans the tile -- a strip of 32
+// positions per lane, neighbours through wave-private LDS rows, fences instead of barriers: ref_plan_kernel's form of the
+// planner, 28 VALU per position where two waves of 16-position strips spend 33 -- and then walks all of its words. No barrier
+// anywhere in the launch; a wave's fixed costs are paid once per 32 words. Lane 63's strip only lends to lane 62:
+// 63 x 32 positions, up to 15 of them alignment in front of the tile.
+constexpr int TEXT_BLOCK = 64;
+#ifndef KCFX_TEXT_WAVES_MIN
+#define KCFX_TEXT_WAVES_MIN 7
+#endif
+static_assert(TEXT_TILE_K + 15 <= 32 * 63 && TEXT_TILE_K + 15 + 30 <= 32 * 64 && TEXT_TILE_K <= TILE_K, "text-only tiles");
 
 // The probe of a word is split in two so that the cell loads of word w + 1 are in flight while word w is matched: with
 // ~65 VALU instructions per word the kernel is no longer issue-bound, and a wave that waits for its own loads before it
@@ -1336,7 +1348,9 @@ __device__ __forceinline__ void cells_match(const CellWord& cw, int32_t lbits, u
     {
         const uint32_t x = cw.cell.x, y = cw.cell.y;
         // (cw.r has no bits outside rmask and bit 15 clear; xor + and fuse into one v_bitop3)
-        const bool first = ((x ^ cw.w) <= CELL_FLAG_MASK) && (((y ^ cw.r) & rmask) == 0);
+        // (an invalid lane has loaded cell 0 of line 0 and compared it with whatever its bases encode: never a match -- the
+        // validity mask is AND-ed to the compares' on the scalar unit)
+        const bool first = __builtin_amdgcn_inverse_ballot_w64(cw.V) && ((x ^ cw.w) <= CELL_FLAG_MASK) && (((y ^ cw.r) & rmask) == 0);
         if constexpr (W <= CELL_ALT_FREE_MAX_W) {
             const bool free_scheme = cell_alt_free(W, lbits, BOTH);                              // (wave-uniform)
             const uint32_t rmask_alt = rmask | (0xFu << (32 - lbits));
@@ -1365,27 +1379,39 @@ __device__ __forceinline__ void cells_match(const CellWord& cw, int32_t lbits, u
 // A screening launch then copies a tile's codes and anchors into LDS and starts at the flank: no ASCII, no hashes, no scans,
 // no cross-lane traffic in the word loop -- ~30 VALU instructions per word instead of 53 before the cell loads are issued,
 // and a minimizer ORDER of any cost (kcfx_device.h: cell_order27) is free for the launches that follow.
+// In LDS the tile's codes stand TWICE (round 5): as the text reads them (fw) and as the reverse complement of the whole tile
+// (rw: word j = brev(comp_swap(word NW - 1 - j))), so that the reverse complement of the k-mer at packed position q is the
+// window of rw at T - q - K (T = 16 NW bases) and both strands are read the same way: three dwords, two v_alignbit. The anchor
+// byte says which strand a lane needs, so a lane reads ONE of them (v_bfi of the two LDS addresses) where round 4 read a pair
+// of streams and built both k-mers -- 9 VALU per word instead of 14, half the LDS bytes.
 struct K31Plan {
-    static_assert(2 * (MAX_CHUNKS + 2) > ((2 * (31 + TILE_K - 1) + 31) >> 5) + 4, "code arrays too short for unclamped reads");
-    __attribute__((aligned(8))) uint2 fcx[2 * (MAX_CHUNKS + 2) + 1];   // as K31Pack::fcx ([0] is the lead word)
+    static constexpr int NW = 2 * (MAX_CHUNKS + 2);         // code words: 16 NW bases from the tile's aligned start
+    static constexpr int T = 16 * NW;
+    static_assert(NW > ((2 * (31 + TILE_K - 1) + 31) >> 5) + 4, "code arrays too short for unclamped reads");
+    static_assert(31 + TILE_K - 1 + CELL_K_MAX + 1 <= T, "every k-mer's reverse complement starts at a position >= 1 of rw");
+    __attribute__((aligned(16))) uint32_t fw[1 + NW + 3];   // [0] is the lead word (position 0 reads bit -1); fw[1 + c] = code word c
+    __attribute__((aligned(16))) uint32_t rw[NW + 4];       // the reverse complement of the tile, mirrored (+ the word read past it)
     __attribute__((aligned(16))) uint4 an[(32 + TILE_K + 15) / 16 + 1]; // anchor bytes of the tile from its 32-aligned start
     int64_t sum[WAVES];
+    __device__ __forceinline__ void put_code(int c, uint32_t code) {       // code word c of the tile, both ways
+        fw[1 + c] = code;
+        rw[NW - 1 - c] = brev32(comp_swap(code));
+    }
 };
 
-// phase 1 of a planned launch: codes (+ their complement-swapped twin) and anchor bytes of the tile into LDS; returns `off`
+// phase 1 of a planned launch: codes (both ways) and anchor bytes of the tile into LDS; returns `off`
 template <int NT>
 __device__ __forceinline__ int k31_load_plan_tile(K31Plan& sh, const RefPlan& plan, const TileDesc& td, int k, int tid) {
     const int64_t a0 = td.text_off & ~(int64_t)31;
     const int off = (int)(td.text_off - a0);
     const int nbases = off + td.n_kmers + k - 1;
     const int nchunks = (nbases + 31) >> 5;
-    uint2* const s_fc = sh.fcx + 1;
-    if (tid == 0) sh.fcx[0] = make_uint2(0u, 0u);
+    if (tid == 0) sh.fw[0] = 0u;
     const uint2* const codes = reinterpret_cast<const uint2*>(plan.codes) + (a0 >> 5);       // 32 bases = 8 bytes
     for (int c = tid; c < nchunks + 2; c += NT) {
         const uint2 x = codes[c];
-        s_fc[2 * c] = make_uint2(x.x, comp_swap(x.x));
-        s_fc[2 * c + 1] = make_uint2(x.y, comp_swap(x.y));
+        sh.put_code(2 * c, x.x);
+        sh.put_code(2 * c + 1, x.y);
     }
     const uint4* const an = reinterpret_cast<const uint4*>(plan.anchors + a0);
     const int n16 = (off + td.n_kmers + 15) >> 4;
@@ -1470,8 +1496,11 @@ struct PlanWaveIo {
         }
         sync();                                   // (the rows may be reused by the caller)
     }
-    // every base this WAVE looked at is A/C/G/T: the valid-start masks are all ones (wave-uniform, so a branch costs nothing)
-    __device__ __forceinline__ bool all_clean(bool mine) const { return wave_ballot(!mine) == 0ull; }
+    // every base this WAVE looked at is A/C/G/T: the valid-start masks are all ones (wave-uniform, so a branch costs nothing).
+    // (The last VN strips read rows behind the last one written -- their results are not used and neither is their vote.)
+    __device__ __forceinline__ bool all_clean(bool mine) const {
+        return wave_ballot(!mine && lane < (BLOCKWIDE ? CELLS_BLOCK : 64) - P::VN) == 0ull;
+    }
 };
 
 // phase 1 of a launch on a text-only reference (KCFX_REF_PLAN=0, or kcfx_screen with a one-shot text): the tile is planned
@@ -1492,10 +1521,35 @@ __device__ __forceinline__ int k31_plan_tile(K31Plan& sh, PlanRowsBlock& rows, c
     const int need = off + td.n_kmers + 30;
     PlanWaveIo<K, 16, true> io{rows, tid, 16 * tid < need ? text + a0 + 16 * (int64_t)tid : nullptr};
     const typename P::Result res = P::run(io);
-    if (tid == 0) sh.fcx[0] = make_uint2(0u, 0u);
-    sh.fcx[1 + tid] = make_uint2(res.codes[0], comp_swap(res.codes[0]));
+    if (tid == 0) sh.fw[0] = 0u;
+    sh.put_code(tid, res.codes[0]);
     if (tid < CELLS_BLOCK - 2) sh.an[tid] = make_uint4(res.anchors[0], res.anchors[1], res.anchors[2], res.anchors[3]);
     __syncthreads();
+    return off;
+}
+
+// The same for the ONE wave that screens a text-only tile on its own (screen_k31c_kernel, PLANNED = false): a strip of 32 positions
+// per lane from the tile's 16-aligned start, wave-private rows, fences. `rows` may overlap `sh` and the queues: every lane has
+// its results in registers before the first of them is written (one wave: its LDS instructions execute in order).
+template <int K>
+__device__ __forceinline__ int k31_plan_tile_wave(K31Plan& sh, PlanRows& rows, const uint8_t* __restrict__ text, const TileDesc& td, int lane) {
+    using P = StripPlanner<K, 32>;
+    const int64_t a0 = td.text_off & ~(int64_t)15;
+    const int off = (int)(td.text_off - a0);
+    // bases the tile's k-mers, their 16-mers' keys and those keys' 6-mers reach: nothing behind them is read (the text is
+    // readable 128 bytes past its end, a tile ends at most there minus K - 1)
+    const int need = off + td.n_kmers + 30;
+    PlanWaveIo<K, 32, false> io{rows, lane, 32 * lane < need ? text + a0 + 32 * (int64_t)lane : nullptr};
+    const typename P::Result res = P::run(io);
+    wave_lds_fence();
+    if (lane == 0) sh.fw[0] = 0u;
+    sh.put_code(2 * lane, res.codes[0]);
+    sh.put_code(2 * lane + 1, res.codes[1]);
+    if (lane < 63) {
+        sh.an[2 * lane] = make_uint4(res.anchors[0], res.anchors[1], res.anchors[2], res.anchors[3]);
+        sh.an[2 * lane + 1] = make_uint4(res.anchors[4], res.anchors[5], res.anchors[6], res.anchors[7]);
+    }
+    wave_lds_fence();
     return off;
 }
 
@@ -1503,36 +1557,42 @@ __device__ __forceinline__ int k31_plan_tile(K31Plan& sh, PlanRowsBlock& rows, c
 // minimizer's offset there, the flip mask, validity. Nothing is carried between words but two LDS addresses.
 template <int K>
 struct PlannedWords {
-    const uint2* p_fc;          // entry holding bit 2q - 1 of this lane's position q in the current word
+    // byte offsets from the start of the tile's LDS block (K31Plan) of the dword holding bit 2q - 1 of this lane's position q in
+    // the current word, as the text reads it / of bit 2q' - 1 in the mirrored reverse complement (q' = T - q - K); the shifts
+    // that go with them do not change from word to word (a word is 128 bits on)
+    uint32_t a_f, a_r;
+    uint32_t s_f, s_r;
     const int8_t* p_an;         // this lane's anchor byte
-    uint32_t sh_fc;
+    const uint8_t* base;
     int n_kmers;
     __device__ __forceinline__ void start(const K31Plan& sh, int off, int n_kmers_, int lane, int w_begin) {
         n_kmers = n_kmers_;
+        base = reinterpret_cast<const uint8_t*>(&sh);
         const int q = off + w_begin * 64 + lane;
         const int b0 = 2 * q - 1;
-        p_fc = sh.fcx + 1 + (b0 >> 5);
-        sh_fc = 31u - (uint32_t)(b0 & 31);
+        a_f = (uint32_t)offsetof(K31Plan, fw) + 4u * (uint32_t)(1 + (b0 >> 5));
+        s_f = 31u - (uint32_t)(b0 & 31);
+        const int b1 = 2 * (K31Plan::T - q - K) - 1;
+        a_r = (uint32_t)offsetof(K31Plan, rw) + 4u * (uint32_t)(b1 >> 5);
+        s_r = 31u - (uint32_t)(b1 & 31);
         p_an = reinterpret_cast<const int8_t*>(sh.an) + q;
     }
     __device__ __forceinline__ void next(int w, uint64_t& N, uint32_t& sh2, uint32_t& fm, uint64_t& V) {
         constexpr uint32_t lo_mask = ~0u << (64 - 2 * K);
-        const uint2 x0 = p_fc[0], x1 = p_fc[1], x2 = p_fc[2];
         const int32_t a = (int32_t)p_an[0];                  // sign-extended: valid <=> negative
-        const uint32_t f_hi = alignbit32(x0.x, x1.x, sh_fc);
-        const uint32_t c_hi = alignbit32(x0.y, x1.y, sh_fc);
-        const uint32_t f_lo = alignbit32(x1.x, x2.x, sh_fc) & lo_mask;
-        const uint32_t c_lo = alignbit32(x1.y, x2.y, sh_fc) & lo_mask;
-        // extract_kmer (kcfx_device.h): the k-mer as the text reads it (Kmer.java:232-252) and its reverse complement (:300-338)
-        const uint64_t rc = u64_of(brev32(c_hi), brev32(c_lo)) << (64 - 2 * K);
         asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(fm) : "v"(a));  // all ones: N is the reverse complement
-        const uint32_t n_lo = (f_lo & ~fm) | ((uint32_t)rc & fm);            // v_bfi_b32
-        const uint32_t n_hi = (f_hi & ~fm) | ((uint32_t)(rc >> 32) & fm);
-        N = u64_of(n_lo, n_hi);
+        // the k-mer as the text reads it (Kmer.java:232-252) or its reverse complement (:300-338): whichever has the minimizer
+        // in canonical form -- one stream per lane
+        const uint32_t at = (a_f & ~fm) | (a_r & fm);        // v_bfi_b32
+        const uint32_t sx = (s_f & ~fm) | (s_r & fm);
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(base + at);
+        const uint32_t y0 = p[0], y1 = p[1], y2 = p[2];
+        N = u64_of(alignbit32(y1, y2, sx) & lo_mask, alignbit32(y0, y1, sx));
         sh2 = (uint32_t)a & 30u;
         const int rem = n_kmers - w * 64;
         V = (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull)) & wave_ballot(a < 0);
-        p_fc += 4;
+        a_f += 16u;
+        a_r -= 16u;
         p_an += 64;
     }
 };
@@ -1556,12 +1616,12 @@ __device__ __forceinline__ CellProbe cell_probe_planned(uint64_t N, uint32_t sh2
 template <int K, bool BOTH, class Lds>
 __device__ __forceinline__ CellProbe k31_probe_at(const Lds& sh, int q, uint32_t anc, int32_t lbits, int32_t ext, uint64_t& key) {
     constexpr uint32_t lo_mask = ~0u << (64 - 2 * K);
-    const int b0 = 2 * q - 1;
-    const uint2* p = sh.fcx + 1 + (b0 >> 5);
-    const uint32_t s = 31u - (uint32_t)(b0 & 31);
-    const uint2 x = p[0], y = p[1], z = p[2];
-    const uint64_t fwd = u64_of(alignbit32(y.x, z.x, s) & lo_mask, alignbit32(x.x, y.x, s));
-    const uint64_t rc = u64_of(brev32(alignbit32(x.y, y.y, s)), brev32(alignbit32(y.y, z.y, s) & lo_mask)) << (64 - 2 * K);
+    const int b0 = 2 * q - 1, b1 = 2 * (Lds::T - q - K) - 1;
+    const uint32_t* pf = sh.fw + 1 + (b0 >> 5);
+    const uint32_t* pr = sh.rw + (b1 >> 5);
+    const uint32_t sf = 31u - (uint32_t)(b0 & 31), sr = 31u - (uint32_t)(b1 & 31);
+    const uint64_t fwd = u64_of(alignbit32(pf[1], pf[2], sf) & lo_mask, alignbit32(pf[0], pf[1], sf));
+    const uint64_t rc = u64_of(alignbit32(pr[1], pr[2], sr) & lo_mask, alignbit32(pr[0], pr[1], sr));
     key = (BOTH && rc < fwd) ? rc : fwd;                    // canonical (Kmer.java:72-79), or as the text reads it (:57-65)
     const uint32_t fm = 0u - (anc & 1u);
     return cell_probe_planned<BOTH>(fm ? rc : fwd, anc & 30u, fm, lbits, ext);
@@ -1614,30 +1674,42 @@ __device__ __forceinline__ int k31c_deferred_round(const TableView& tv, const Ld
 }
 
 template <int K, bool BOTH, bool PLANNED>
-__global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void screen_k31c_kernel(
+__global__ __launch_bounds__(PLANNED ? CELLS_BLOCK : TEXT_BLOCK) __attribute__((amdgpu_waves_per_eu(PLANNED ? 8 : KCFX_TEXT_WAVES_MIN, 8))) void screen_k31c_kernel(
     const uint8_t* __restrict__ text, RefPlan plan, const TileDesc* __restrict__ tiles, TableView tv, int32_t min_count,
     uint64_t* __restrict__ bits, int64_t* __restrict__ count_sums) {
-    constexpr int WAVES = CELLS_WAVES;                      // (this kernel's own workgroup shape: kcfx_internal.h)
+    // (this kernel's own workgroup shapes. Planned reference: kcfx_internal.h; text-only: one wave per tile, see TEXT_BLOCK)
+    constexpr int WAVES = PLANNED ? CELLS_WAVES : TEXT_BLOCK / 64;
+    constexpr int WPW = (TILE_WORDS + WAVES - 1) / WAVES;   // words a wave can have
     using Lds = K31Plan;
-    __shared__ Lds sh;
-    // (a text-only reference is planned tile by tile: the planner's exchange rows are dead before the queues are first written)
+    using Queue = K31CQueueT<WPW>;
+    // (a text-only reference is planned tile by tile: the planner's exchange rows are dead before the codes, the anchors and the
+    // queue are first written, and lie under all three)
+    struct Work {
+        Queue queue[WAVES];                                 // (first: its words are written once per word of the loop, with short offsets)
+        Lds sh;
+    };
     union Scratch {
-        K31CQueue queue[WAVES];
-        typename std::conditional<PLANNED, uint32_t, PlanRowsBlock>::type rows;
+        Work w;
+        typename std::conditional<PLANNED, uint32_t, PlanRows>::type rows;
     };
     __shared__ __attribute__((aligned(16))) Scratch s_scratch;
+    Lds& sh = s_scratch.w.sh;
     const TileDesc td = tiles[blockIdx.x];
     const int tid = threadIdx.x;
     int off;
     if constexpr (PLANNED) off = k31_load_plan_tile<CELLS_BLOCK>(sh, plan, td, K, tid);
-    else off = k31_plan_tile<K>(sh, s_scratch.rows, text, td, tid);
+    else off = k31_plan_tile_wave<K>(sh, s_scratch.rows, text, td, tid);
+#ifdef KCFX_EXP_PRIO
+    // (experiment: the waves that issue table loads go first, the planning waves of the same SIMD fill the issue slots they leave)
+    if constexpr (!PLANNED) __builtin_amdgcn_s_setprio(KCFX_EXP_PRIO);
+#endif
 
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, wave = PLANNED ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
     const int n_words = (td.n_kmers + 63) >> 6;
     const int wpw = (n_words + WAVES - 1) / WAVES;
     const int w_begin = min(wave * wpw, n_words);
     const int w_end = min(w_begin + wpw, n_words);
-    K31CQueue& q = s_scratch.queue[wave];
+    Queue& q = s_scratch.w.queue[wave];
     int qn = 0;                                             // queued k-mers (wave-uniform)
     const int pos0 = off + w_begin * 64;                    // packed position of the wave's first k-mer
 
@@ -1668,15 +1740,18 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
     auto retire = [&](int w, const CellWord& cw) {
         uint32_t cnt = 0, pend = 0;
         cells_match<BOTH, cell_nw(K)>(cw, tv.lbits, cnt, pend);
-        // cnt is 0 unless the k-mer was found and min_count >= 1 (checked by the API), so this is "found && count >= -c"
-        const uint64_t H = wave_ballot((int32_t)cnt >= min_count) & cw.V;   // GetVariants.java:224 (valid positions only)
-        const bool hit = __builtin_amdgcn_inverse_ballot_w64(H);
+        // cnt is 0 unless the k-mer was found at a valid position, and min_count >= 1 (checked by the API), so this is "found && count >= -c"
+        const uint64_t H = wave_ballot((int32_t)cnt >= min_count);          // GetVariants.java:224 (valid positions only: cells_match)
         if (lane == 0) {
             q.vw[w - w_begin] = cw.V;                                       // validity word of the window's bitmap
             q.hit[w - w_begin] = H;                                         // hits so far; queued k-mers may add theirs
         }
-        sum_acc += hit ? cnt : 0u;                                          // GetVariants.java:226
-        const uint64_t PM = wave_ballot(pend != 0u) & wave_ballot(cnt == 0u) & cw.V;
+        // GetVariants.java:226 (-c 1, the default: every found counter is a hit; wave-uniform)
+        if (min_count == 1) sum_acc += cnt;
+        else sum_acc += __builtin_amdgcn_inverse_ballot_w64(H) ? cnt : 0u;
+        // looked up further: flagged cell + filter bit, and not a hit here (a k-mer found below -c is not stored anywhere else
+        // either: its look-up would end as the miss it already is -- harmless, and one compare less than "cnt == 0")
+        const uint64_t PM = wave_ballot(pend != 0u) & ~H & cw.V;
         if (PM) {
             const bool pending = __builtin_amdgcn_inverse_ballot_w64(PM);
             const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(PM >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)PM, 0u));
@@ -1719,13 +1794,17 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
     // is taken only when some lane has one)
     int64_t count_sum = (int64_t)wave_sum_u32_dpp(sum_acc);
     if (wave_ballot(big_acc != 0) != 0) count_sum += wave_sum_i64(big_acc);
-    if (lane == 0) sh.sum[wave] = count_sum;
-    __syncthreads();
-    if (tid == 0) {
-        int64_t t = 0;
+    if constexpr (WAVES == 1) {
+        if (lane == 0) count_sums[blockIdx.x] = count_sum;
+    } else {
+        if (lane == 0) sh.sum[wave] = count_sum;
+        __syncthreads();
+        if (tid == 0) {
+            int64_t t = 0;
 #pragma unroll
-        for (int i = 0; i < WAVES; ++i) t += sh.sum[i];
-        count_sums[blockIdx.x] = t;
+            for (int i = 0; i < WAVES; ++i) t += sh.sum[i];
+            count_sums[blockIdx.x] = t;
+        }
     }
 }
 
@@ -2440,7 +2519,7 @@ hipError_t launch_screen_tiles(const uint8_t* text, RefPlan plan, const TileDesc
     const bool generic_only = tv.generic != 0;                                      // A/B and test hook, fixed at kcfx_db_open
     if (tv.fmt == FORMAT_CELLS) {
 #define KCFX_LAUNCHC1(KK, BS, PL) \
-    hipExtLaunchKernelGGL((screen_k31c_kernel<KK, BS, PL>), g, bc, 0, st, ev_start, ev_stop, 0, text, plan, tiles, tv, min_count, bits, count_sums)
+    hipExtLaunchKernelGGL((screen_k31c_kernel<KK, BS, PL>), g, (PL) ? bc : dim3(TEXT_BLOCK), 0, st, ev_start, ev_stop, 0, text, plan, tiles, tv, min_count, bits, count_sums)
 #define KCFX_LAUNCHC(KK)                                                                  \
     do {                                                                                  \
         if (plan.codes) { if (both_strands) KCFX_LAUNCHC1(KK, true, true); else KCFX_LAUNCHC1(KK, false, true); }   \

@@ -278,8 +278,9 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
             for (int32_t w = sg.w_lo; w < sg.w_hi; ++w) q += std::max<int64_t>(0, (int64_t)win_len[w] - kmer_length + 1);
             return std::max<int64_t>(1, q);
         };
-        // The loaders open one database (or cohort table) per segment, in segment order, at most LOAD_AHEAD segments ahead of the one
-        // being screened. ONE loader by default: a load is a file streamed from the page cache through pinned buffers (~40 ms for
+        // The loaders open one database (or cohort table) per segment, in segment order, while at most MAX_RESIDENT tables exist on
+        // the device: the one being screened + the ones ready + the ones being built (counted when a loader CLAIMS a segment, so
+        // that the table sizing of kcfx_db_open -- 60 % / 80 % of the free memory -- never meets a third table). ONE loader by default: a load is a file streamed from the page cache through pinned buffers (~40 ms for
         // 1.2 GB: ~30 GB/s whatever the number of reader threads) followed by the build passes on the GPU (~22 ms), and two loads
         // in flight take exactly twice as long each -- measured, profiles/r04_notes.md: the host-side copy is the shared resource,
         // not the GPU (making the files take turns on that path changes nothing either: profiles/r04_notes.md). KCFX_SHARD_LOADERS=
@@ -296,9 +297,11 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
         std::map<size_t, Loaded> ready;                  // by segment index
         const size_t n_segs = wk.segs.size();
         size_t next_load = 0, next_screen = 0;           // the next segment a loader claims / the screening thread waits for
-        constexpr size_t LOAD_AHEAD = 2;
+        constexpr int MAX_RESIDENT = 2;
         bool stop = false;
         int in_use = 0;                                  // databases the screening thread holds (0 or 1)
+        int loading = 0;                                 // segments claimed by a loader and not yet handed over
+        auto resident = [&] { return in_use + (int)ready.size() + loading; };
         int loaders_alive = 0;
         int32_t load_rc = KCFX_OK;
         std::string load_error;
@@ -308,9 +311,10 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
                 size_t i;
                 {
                     std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return stop || load_rc != KCFX_OK || next_load >= n_segs || next_load - next_screen < LOAD_AHEAD; });
+                    cv.wait(lk, [&] { return stop || load_rc != KCFX_OK || next_load >= n_segs || resident() < MAX_RESIDENT; });
                     if (stop || load_rc != KCFX_OK || next_load >= n_segs) break;
                     i = next_load++;
+                    ++loading;
                 }
                 const double t1 = now_s();
                 kcfx_db* db = nullptr;
@@ -367,6 +371,7 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
                 }
                 std::lock_guard<std::mutex> lk(mu);
                 wk.t_open += now_s() - t1;
+                --loading;
                 if (rc) {
                     if (load_rc == KCFX_OK) {
                         load_rc = rc;

@@ -64,6 +64,8 @@ static std::vector<uint32_t> make_norm(int m) {
 
 struct Opts {
     int64_t ref_len = 1000000;
+    int64_t ref_offset = 0;                // --ref-offset O (a multiple of 100 000): the reference is bases [O, O + ref_len) of the seed's genome
+    bool ref_only = false;                 // --ref-only: write PREFIX.ref.txt (and .fa) and stop: no sample, no database
     uint64_t seed = 1, sample_seed = 2;
     int64_t noise = 0;
     int64_t error_events = 0;              // --error-events: read-error model, see below
@@ -82,6 +84,8 @@ int main(int argc, char** argv) {
         std::string a = argv[i];
         auto val = [&]() -> const char* { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
         if (a == "--ref-len") o.ref_len = atoll(val());
+        else if (a == "--ref-offset") o.ref_offset = atoll(val());
+        else if (a == "--ref-only") o.ref_only = true;
         else if (a == "--seed") o.seed = strtoull(val(), nullptr, 10);
         else if (a == "--sample-seed") o.sample_seed = strtoull(val(), nullptr, 10);
         else if (a == "--noise") o.noise = atoll(val());
@@ -111,8 +115,12 @@ int main(int argc, char** argv) {
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     if (o.error_events > 0 && o.k > 31) { fprintf(stderr, "--error-events needs k <= 31\n"); return 2; }
+    if (o.ref_offset < 0 || o.ref_offset % 100000 != 0 || (o.ref_offset > 0 && o.repeats > 0)) {
+        fprintf(stderr, "--ref-offset must be a non-negative multiple of 100000 (and excludes --repeats)\n");
+        return 2;
+    }
     if (o.out.empty() || o.k < 9 || o.k > 32 || (o.k - o.p) % 4 != 0 || o.cs < 1 || o.cs > 4 || o.sig_len > o.k) {
-        fprintf(stderr, "usage: kcfx_synth --out PREFIX [--ref-len N --seed S --sample-seed S --noise N --error-events N --repeats F --k 31 --p 7 --cs 2 --bins 512 --threads T --fasta]\n");
+        fprintf(stderr, "usage: kcfx_synth --out PREFIX [--ref-len N --ref-offset O --ref-only --seed S --sample-seed S --noise N --error-events N --repeats F --k 31 --p 7 --cs 2 --bins 512 --threads T --fasta]\n");
         return 2;
     }
     if (o.threads <= 0) o.threads = (int)std::max(1u, std::thread::hardware_concurrency());
@@ -129,10 +137,11 @@ int main(int argc, char** argv) {
         for (int64_t l : o.contig_lens) { contig_start.push_back(acc); acc += l; }
     }
     std::vector<uint8_t> ref((size_t)L);
+    const int64_t O = o.ref_offset;        // every position-keyed choice below is keyed by the position in the seed's whole genome
     const uint64_t s1 = mix64(o.seed * 0x1000193ull + 11);
     parallel_for(L, T, [&](int64_t lo, int64_t hi, int) {
         for (int64_t i = lo; i < hi; ++i) {
-            const uint64_t h = mix64(s1 + (uint64_t)i);
+            const uint64_t h = mix64(s1 + (uint64_t)(O + i));
             uint8_t c = "ACGT"[h & 3];
             if ((h >> 8) % 10000 == 0) c = "RYKMSWBDHVN"[(h >> 40) % 11];     // rare IUPAC codes
             ref[(size_t)i] = c;
@@ -241,16 +250,17 @@ int main(int argc, char** argv) {
             rep_bases[3] += len;
         }
     }
-    for (int64_t blk = 0; blk * 5000 < L; ++blk) {                             // soft-masked blocks (~10 %)
+    // (blocks of the whole genome; the one in front of the window may reach into it)
+    for (int64_t blk = std::max<int64_t>(0, O / 5000 - 1); blk * 5000 < O + L; ++blk) {            // soft-masked blocks (~10 %)
         const uint64_t h = mix64(s1 ^ (0xABCDull + (uint64_t)blk * 7919));
         if (h % 10 != 0) continue;
-        const int64_t s = blk * 5000 + (int64_t)((h >> 8) % 2500), e = std::min(L, s + 2000 + (int64_t)((h >> 24) % 3000));
-        for (int64_t i = s; i < e; ++i) ref[(size_t)i] |= 0x20;
+        const int64_t s = blk * 5000 + (int64_t)((h >> 8) % 2500) - O, e = std::min(L, s + 2000 + (int64_t)((h >> 24) % 3000));
+        for (int64_t i = std::max<int64_t>(s, 0); i < e; ++i) ref[(size_t)i] |= 0x20;
     }
-    for (int64_t blk = 0; blk * 100000 < L; ++blk) {                           // one N-run per ~100 kb
+    for (int64_t blk = std::max<int64_t>(0, O / 100000 - 1); blk * 100000 < O + L; ++blk) {        // one N-run per ~100 kb
         const uint64_t h = mix64(s1 ^ (0x5151ull + (uint64_t)blk * 104729));
-        const int64_t s = blk * 100000 + (int64_t)((h >> 4) % 100000), e = std::min(L, s + 1 + (int64_t)((h >> 32) % 2000));
-        for (int64_t i = s; i < e && i < L; ++i) ref[(size_t)i] = 'N';
+        const int64_t s = blk * 100000 + (int64_t)((h >> 4) % 100000) - O, e = std::min(L, s + 1 + (int64_t)((h >> 32) % 2000));
+        for (int64_t i = std::max<int64_t>(s, 0); i < e && i < L; ++i) ref[(size_t)i] = 'N';
     }
     {
         FILE* f = fopen((o.out + ".ref.txt").c_str(), "wb");
@@ -273,6 +283,11 @@ int main(int argc, char** argv) {
         }
     }
     const double t_ref = now_s();
+    if (o.ref_only) {
+        printf("{\"ref_len\": %lld, \"ref_offset\": %lld, \"seed\": %llu, \"seconds\": %.3f}\n", (long long)L, (long long)O,
+               (unsigned long long)o.seed, t_ref - t0);
+        return 0;
+    }
 
     // ---- sample genome: substitutions, 1-10 bp indels, 20 kb deletions (5 per Mb) ----------------------
     std::vector<uint8_t> smp;

@@ -276,11 +276,28 @@ def _mem_available_bytes():
     return 0
 
 
-def test_config5_shape_wheat_scale(oracle, genome, cohort, monkeypatch):
+_SIZE_DECISIONS = {}
+
+
+def _size_case(name, size, decide):
+    """The two size-adaptive tests run as `[full]` and `[fallback]`: exactly one of the two runs, the other SKIPS with the reason,
+    so that `N passed, M skipped` (and -rs) says which size a box ran. `decide()` -> (bases, why) is evaluated once per test."""
+    if name not in _SIZE_DECISIONS:
+        _SIZE_DECISIONS[name] = decide()
+    L, why = _SIZE_DECISIONS[name]
+    ran = "fallback" if why.startswith("FALLBACK") else "full"
+    if size != ran:
+        pytest.skip(f"the [{ran}] case runs on this box: {L / 1e9:.1f} Gb ({why})")
+    return L, why
+
+
+@pytest.mark.parametrize("size", ["full", "fallback"])
+def test_config5_shape_wheat_scale(oracle, genome, cohort, monkeypatch, size):
     """BASELINE.json configs[4] as it is stated: a wheat-scale 14.5 Gb reference, 50 kb tiling windows (290 k of them), THIRTY-TWO
     samples, k = 31 -- through kcfx_screen_sharded (what the command-line driver runs; two workers on the one GPU, the next
-    database loaded while the current one is screened). The reference is the 119 Mb genome repeated with 0.5 % point mutations;
-    the samples are THIRTY-ONE distinct samples of that genome (~100 M k-mers each; the cohort's eight in rotation only where the
+    database loaded while the current one is screened). The reference is ONE 14.5 Gb genome (kcfx_synth --ref-only: the fixture's
+    119 Mb genome is its first 119 Mb); the samples are THIRTY-ONE distinct samples of 119 Mb stretches of it (eight of the first
+    stretch -- the cohort fixture -- and 23 of stretches spread over the rest, --ref-offset; ~100 M k-mers each; the cohort's eight in rotation only where the
     scratch space does not take 23 more -- the log line says which) plus ONE LARGE database of 2.1 G k-mers (17 GB .kmc_suf; a cell
     table of 3 x 2^27 lines at 0.33 k-mers per cell). Falls back to a 3.2 Gb reference only when the box lacks
     the host memory or scratch disk (KCFX_HUGE=<bases> overrides) and says which size ran. Also: the large database
@@ -291,13 +308,16 @@ def test_config5_shape_wheat_scale(oracle, genome, cohort, monkeypatch):
     10 000 sampled windows (0.5 G k-mers) of four samples, the large (and dense) one among them, against the oracle."""
     import shutil
     big_kmers = int(float(os.environ.get("KCFX_BIG_DB", "2.0e9")))
-    L = int(float(os.environ.get("KCFX_HUGE", "14.5e9")))
-    why = "KCFX_HUGE" if os.environ.get("KCFX_HUGE") else "BASELINE configs[4] size"
-    if not os.environ.get("KCFX_HUGE"):
-        need_ram, have_ram = 6 * L, _mem_available_bytes()
-        if have_ram and have_ram < need_ram:
-            L, why = int(3.2e9), f"FALLBACK: {have_ram / 1e9:.0f} GB of host memory available, 14.5 Gb needs {need_ram / 1e9:.0f} GB"
-    need = big_kmers * 9 + L * 2
+    def decide():
+        L = int(float(os.environ.get("KCFX_HUGE", "14.5e9")))
+        why = "KCFX_HUGE" if os.environ.get("KCFX_HUGE") else "BASELINE configs[4] size"
+        if not os.environ.get("KCFX_HUGE"):
+            need_ram, have_ram = 6 * L, _mem_available_bytes()
+            if have_ram and have_ram < need_ram:
+                L, why = int(3.2e9), f"FALLBACK: {have_ram / 1e9:.0f} GB of host memory available, 14.5 Gb needs {need_ram / 1e9:.0f} GB"
+        return L, why
+    L, why = _size_case("config5", size, decide)
+    need = big_kmers * 9 + L * 3
     if shutil.disk_usage(genome["dir"]).free < need:
         pytest.skip(f"needs {need / 1e9:.0f} GB of scratch disk for the large database")
     N_SAMPLES = 32
@@ -310,31 +330,39 @@ def test_config5_shape_wheat_scale(oracle, genome, cohort, monkeypatch):
                     "--noise", str(big_kmers)], check=True, capture_output=True, text=True)
     t_gen = time.time() - t0
     # ---- the reference ------------------------------------------------------------------------------------------------
-    base = np.frombuffer(genome["text"], dtype=np.uint8)
-    text = np.tile(base, (L + len(base) - 1) // len(base))[:L].copy()
-    pos = rng.integers(0, L, size=L // 200)
-    text[pos] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=len(pos))]
-    del pos
+    # ONE genome of L bases, not the small one tiled (round 5): kcfx_synth's reference is a function of (seed, position), so the
+    # fixture's 119 Mb genome (seed 3) is the first 119 Mb of the seed's 14.5 Gb genome, and a sample of any other stretch of it is
+    # `--ref-offset`. N-runs, soft-masked blocks and IUPAC codes as everywhere.
+    big_ref = os.path.join(genome["dir"], "huge")
+    subprocess.run([SYNTH, "--out", big_ref, "--ref-len", str(L), "--seed", "3", "--ref-only"], check=True, capture_output=True, text=True)
+    tbytes = np.fromfile(big_ref + ".ref.txt", dtype=np.uint8).tobytes()
+    os.remove(big_ref + ".ref.txt")
+    assert tbytes[:len(genome["text"])] == genome["text"]
     W = 50_000
     starts = np.arange(0, L - K + 1, W - K + 1, dtype=np.int64)
     lens = np.minimum(W, L - starts).astype(np.int32)
     starts, lens = starts[lens >= K], lens[lens >= K]
-    tbytes = text.tobytes()
-    del text
     # 32 samples: the eight cohort databases, 23 more samples of the same genome (their own mutations; ~100 M k-mers, 0.85 GB each)
     # where the scratch space takes them -- else the eight in rotation, and the log line says so -- and the large one last
     prefixes = list(cohort)
     extra_need = (N_SAMPLES - 1 - 8) * int(1.0e9) + (4 << 30)
     distinct = shutil.disk_usage(genome["dir"]).free > extra_need and not os.environ.get("KCFX_ROTATE_SAMPLES")
     t0 = time.time()
+    small = sum(LENS)
+    region = {s_: 0 for s_ in range(8)}                                  # where in the reference a sample's genome lies
     for i in range(8, N_SAMPLES - 1):
         if distinct:
+            # its own stretch of the genome: 23 stretches spread over what lies behind the fixture's
+            off = (small + (i - 8) * max(0, L - 2 * small) // 22) // 100000 * 100000
             pfx = os.path.join(genome["dir"], f"x{i}")
-            subprocess.run([SYNTH, "--out", pfx, "--contig-lens", ",".join(map(str, LENS)), "--seed", "3", "--sample-seed", str(100 + i),
-                            "--noise", "1000000"], check=True, capture_output=True, text=True)
+            subprocess.run([SYNTH, "--out", pfx, "--ref-len", str(min(small, L - off)), "--ref-offset", str(off), "--seed", "3",
+                            "--sample-seed", str(100 + i), "--noise", "1000000"], check=True, capture_output=True, text=True)
+            os.remove(pfx + ".ref.txt")
             prefixes.append(pfx)
+            region[i] = off
         else:
             prefixes.append(cohort[i % 8])
+            region[i] = 0
     t_gen_samples = time.time() - t0
     prefixes.append(big)
     BIG = N_SAMPLES - 1
@@ -432,14 +460,17 @@ def test_config5_shape_wheat_scale(oracle, genome, cohort, monkeypatch):
     t0 = time.time()
     n_checked = 0
     for s, pfx, n_check in ((0, prefixes[0], 3000), (3, prefixes[3], 3000), (29, prefixes[29], 3000), (BIG, big, 1000)):
-        idx = np.unique(np.concatenate([rng.choice(len(starts), min(n_check, len(starts)), replace=False), [0, len(starts) - 1]]))
+        # (sampled over the whole reference + 400 windows of the stretch the sample was drawn from: elsewhere it has nothing to find)
+        w0 = int(region.get(s, 0) // (W - K + 1))
+        own = np.arange(w0, min(len(starts), w0 + 400))
+        idx = np.unique(np.concatenate([rng.choice(len(starts), min(n_check - 400, len(starts)), replace=False), own, [0, len(starts) - 1]]))
         want = oracle.OracleDb(pfx).screen(tbytes, starts[idx], lens[idx], 1, threads=HOST_THREADS)
         for f in FIELDS:
             assert np.array_equal(want[f], got[s][f][idx]), (s, f)
         n_checked += len(idx)
     t_oracle = time.time() - t0
     gk = n / 1e9
-    line = (f"config-5 ({why}): {L / 1e9:.1f} Gb reference, {len(starts)} windows x {N_SAMPLES} samples ({'all distinct: 23 generated in %.0f s' % t_gen_samples if distinct else 'eight databases in rotation + the large one'}) = {N_SAMPLES * n / 1e9:.0f} G k-mer probes; "
+    line = (f"config-5 ({why}): {L / 1e9:.1f} Gb reference (ONE genome, not tiled), {len(starts)} windows x {N_SAMPLES} samples ({'all distinct: 23 generated in %.0f s' % t_gen_samples if distinct else 'eight databases in rotation + the large one'}) = {N_SAMPLES * n / 1e9:.0f} G k-mer probes; "
             f"kcfx_screen_sharded (2 workers on one GPU, load overlapped): {t_sharded:.1f} s wall, loads {st.seconds_db_open_sum:.1f} s of "
             f"which {st.seconds_exposed_load:.1f} s exposed, screening {st.seconds_screen_sum:.2f} s; large database {bi.total_kmers / 1e9:.2f} G "
             f"k-mers generated in {t_gen:.0f} s, opened in {t_big_open:.1f} s ({bi.regions} x 2^{int(np.log2(bi.table_lines // bi.regions))} lines = "
@@ -469,7 +500,8 @@ def _cgroup_memory_limit():
     return 0
 
 
-def test_wheat_scale_genomic_database(oracle, monkeypatch):
+@pytest.mark.parametrize("size", ["full", "fallback"])
+def test_wheat_scale_genomic_database(oracle, monkeypatch, size):
     """A database at wheat scale made of GENOMIC k-mers (runs that share minimizers, as a real `kmc` count of a 14.5 Gb genome is),
     not of random ones: one non-tiled synthetic genome as large as this box's memory and scratch space allow (9.1 Gb = 8 G distinct
     31-mers where the cgroup grants ~300 GB; the size that ran is printed), its mutated sample counted into ONE KMC database (64 GB
@@ -485,11 +517,14 @@ def test_wheat_scale_genomic_database(oracle, monkeypatch):
     t_all = time.time()
     mem = _cgroup_memory_limit() or _mem_available_bytes()
     mem = min(mem, _mem_available_bytes() or mem)
-    L = int(float(os.environ.get("KCFX_WHEAT", "9.1e9")))
-    why = "KCFX_WHEAT" if os.environ.get("KCFX_WHEAT") else "8 G genomic k-mers"
-    if not os.environ.get("KCFX_WHEAT") and mem and 30.0 * L > 0.85 * mem:        # the generator peaks at ~25 bytes per base, the files add 9 in /dev/shm
-        L = int(0.85 * mem / 30.0)
-        why = f"FALLBACK: {mem / 1e9:.0f} GB of memory granted"
+    def decide():
+        L = int(float(os.environ.get("KCFX_WHEAT", "9.1e9")))
+        why = "KCFX_WHEAT" if os.environ.get("KCFX_WHEAT") else "8 G genomic k-mers"
+        if not os.environ.get("KCFX_WHEAT") and mem and 30.0 * L > 0.85 * mem:    # the generator peaks at ~25 bytes per base, the files add 9 in /dev/shm
+            L = int(0.85 * mem / 30.0)
+            why = f"FALLBACK: {mem / 1e9:.0f} GB of memory granted"
+        return L, why
+    L, why = _size_case("wheat", size, decide)
     if L < 1.0e9:
         pytest.skip(f"needs ~30 bytes of host memory per base; {mem / 1e9:.0f} GB granted")
     need_disk = int(9.2 * L)
