@@ -270,11 +270,14 @@ def main():
     ap.add_argument("--steps", type=int, default=500, help="default sized for a timed region of ~0.1 s")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--ref-len", type=int, default=0, help="0 = 30,427,671 (configs[1]) on one GPU, 119,667,750 (configs[3]) on several")
-    ap.add_argument("--shard", choices=("samples", "windows", "cohort"), default="samples",
+    ap.add_argument("--shard", choices=("samples", "windows", "cohort", "table"), default="samples",
                     help="N > 1: one sample per GPU against the whole window list (weak scaling, configs[3]) or one sample "
                          "replicated and the windows split (strong scaling, the S < G case); cohort = --samples S (the JOB's samples) "
                          "in cohort tables of eight, tables x window ranges over the GPUs (kcfx_shard_plan, KCFX_SHARD_COHORT: "
-                         "8 samples on 8 GPUs = every GPU the same table and an eighth of the windows; 32 = four tables, two GPUs each)")
+                         "8 samples on 8 GPUs = every GPU the same table and an eighth of the windows; 32 = four tables, two GPUs each); "
+                         "table = ONE sample whose TABLE is cut into one slice per GPU by minimizer (kcfx_db_open_slice: the database a single "
+                         "GPU could only hold densely), every GPU screens the whole window list against its slice and the tiles' hit bitmaps "
+                         "meet on rank 0 in EVERY step -- the one data-path exchange of the engine")
     ap.add_argument("--db-kmers", type=int, default=150_000_000)
     ap.add_argument("--window", type=int, default=10_000)
     ap.add_argument("--workdir", default=os.environ.get("KCFX_BENCH_DIR", "/tmp/kcfx_bench"))
@@ -323,6 +326,8 @@ def main():
     if cohort_sharded:
         args.cohort = True
     window_sharded = world > 1 and args.shard in ("windows", "cohort")      # (the samples are the same on every rank, the windows are cut)
+    table_sharded = world > 1 and args.shard == "table"                      # (ONE sample, the same on every rank; its table is cut)
+    same_data = window_sharded or table_sharded
     synth_bin = ensure_built()
     import torch
     import torch.distributed as dist
@@ -347,14 +352,14 @@ def main():
     prefixes = []
     for i in range(S):
         # window-sharded: every rank holds the SAME sample (replicated database); sample-sharded: its own
-        seed = 2 + (0 if window_sharded else rank * S) + i
-        if window_sharded and rank != 0:
+        seed = 2 + (0 if same_data else rank * S) + i
+        if same_data and rank != 0:
             if world > 1 and not os.path.exists(os.path.join(args.workdir, f"r{args.ref_len}_d{args.db_kmers}_s{seed}.meta.json")):
                 time.sleep(1.0)
             while not os.path.exists(os.path.join(args.workdir, f"r{args.ref_len}_d{args.db_kmers}_s{seed}.meta.json")):
                 time.sleep(0.5)                # rank 0 writes it
         pfx, meta = make_dataset(synth_bin, args.workdir, args.ref_len, args.db_kmers, seed,
-                                 ncpu if window_sharded else max(1, ncpu // world))
+                                 ncpu if same_data else max(1, ncpu // world))
         prefixes.append(pfx)
     prefix = prefixes[0]
     text = np.fromfile(prefix + ".ref.txt", dtype=np.uint8).tobytes()
@@ -399,6 +404,8 @@ def main():
     if args.cohort and S > 1:                      # (a group of ONE sample -- e.g. 9 samples on 2 ranks -- takes the single-database path, as kcfx_screen_sharded does)
         cohort = engine.Cohort(prefixes, device=local_rank, expected_queries=expected)
         dbs = [engine.KmcDb.open(prefixes[0], device=local_rank, expected_queries=expected)]   # (the first sample on its own: the parity leg's single-sample twin)
+    elif table_sharded:
+        dbs = [engine.KmcDb.open(prefixes[0], device=local_rank, expected_queries=expected, n_slices=world, slice=rank)]
     else:
         dbs = [engine.KmcDb.open(pfx, device=local_rank, expected_queries=expected) for pfx in prefixes]
     db = dbs[0]
@@ -417,7 +424,25 @@ def main():
     gathered = [torch.zeros_like(out, device=cdev) for _ in range(world)] if (world > 1 and rank == 0) else None
     stream = torch.cuda.current_stream()
 
+    if table_sharded:
+        from kcftools_amd import shard
+        nb, ns = ref.partial_bytes()
+        part_bits = torch.zeros(nb // 8, dtype=torch.int64, device=f"cuda:{local_rank}")
+        part_sums = torch.zeros(ns // 8, dtype=torch.int64, device=f"cuda:{local_rank}")
+
     def screen(r, o):
+        if table_sharded:
+            # this rank's slice against the whole window list; the tiles' bitmaps and count sums to rank 0 (RCCL over xGMI: 520 B
+            # per tile and rank), OR-ed / added there, reduced once
+            r.screen_partial_async(db, stream.cuda_stream, args.min_count)
+            r.export_partial_async(part_bits.data_ptr(), part_sums.data_ptr(), stream.cuda_stream)
+            gb, gs = shard.gather_table_partials(part_bits.to(cdev), part_sums.to(cdev), dst=0)
+            if rank == 0:
+                for b, c in zip(gb[1:], gs[1:]):
+                    b, c = b.to(f"cuda:{local_rank}"), c.to(f"cuda:{local_rank}")
+                    r.merge_partial_async(b.data_ptr(), c.data_ptr(), stream.cuda_stream)
+                r.finish_async(o.data_ptr(), stream.cuda_stream)
+            return
         if cohort is not None:
             cohort.screen_async(r, o.data_ptr(), stream.cuda_stream, args.min_count)
         elif S == 1:
@@ -437,7 +462,7 @@ def main():
     step = make_step(ref, out, form)
 
     def final_gather():
-        if world > 1:
+        if world > 1 and not table_sharded:                 # (table slices: rank 0 already holds the job's records)
             dist.gather(out.to(cdev), gathered, dst=0)      # RCCL over xGMI: 40 B per (window, sample), once per job
 
     def timed(run, r, n_steps, with_gather):
@@ -593,6 +618,16 @@ def main():
     # ---- CPU baseline: the oracle (C restatement of the reference path, probing the on-disk KMC layout) -----------
     cpu = None
     parity = None
+    if table_sharded:
+        # the merged records of the slices against ONE table of the whole database on this rank (it fits here; the point of the
+        # mode is the database that does not)
+        whole = engine.KmcDb.open(prefix, device=local_rank, expected_queries=expected)
+        ref_w = engine.Reference(text, win_begin, win_len, K, device=local_rank, expected_screens=1)
+        want = ref_w.screen(whole, args.min_count)
+        parity = {"windows_checked": int(n_win), "against": "the unsharded table on rank 0 (kcfx_screen_ref)",
+                  "bit_exact": bool(all(np.array_equal(res[f], want[f]) for f in engine.INT_FIELDS))}
+        ref_w.close()
+        whole.close()
     if world == 1 and args.cpu_baseline_seconds > 0:
         from oracle import binding as oracle
         odb = oracle.OracleDb(prefix)
@@ -738,22 +773,26 @@ def main():
         "ramped": ramped,
         "cache_state": cache_state,
         "higher_is_better": True,
-        "scaling": "strong" if window_sharded else "weak",
+        "scaling": "strong" if (window_sharded or table_sharded) else "weak",
         "vs_baseline": None,
         "dtype": "u64",
         "data": "synthetic",
         "config": {"workload": (f"getVariations: synthetic {'chr1' if args.ref_len < 100_000_000 else 'whole-genome'}-sized reference "
                                 f"{args.ref_len} bp (BASELINE configs[{1 if args.ref_len < 100_000_000 else 3}] shape), "
-                                + ((f"ONE KMC sample replicated on {world} GPUs" if S == 1 else
+                                + (f"ONE KMC sample, its table in {world} slices on {world} GPUs" if table_sharded else
+                                   (f"ONE KMC sample replicated on {world} GPUs" if S == 1 else
                                     f"{S} KMC samples ({'one cohort table' if cohort is not None else 'one table each'}) replicated on {world} GPUs")
                                    if window_sharded else
                                    f"{S} KMC sample{'s' if S > 1 else ''} per GPU ({S * world} in all)")
                                 + f" (k=31, counter_size {COUNTER_SIZE}, {meta['db_kmers']} k-mers each), {args.window // 1000} kb tiling "
                                 f"windows ({n_win_total} windows), -c {args.min_count}"),
                    "windows": n_win_total, "samples_per_gpu": S, "kmers_per_step_per_gpu": kmers_per_step, "db_kmers": meta["db_kmers"],
-                   "parallelism": ((f"window-sharded x{world} (contiguous ranges of equal k-mer count, database replicated)" if window_sharded
+                   "parallelism": ((f"table-sharded x{world}: the sample's table in {world} slices by minimizer, every GPU screens every window against "
+                                    f"its slice, the tiles' hit bitmaps gathered to rank 0 and OR-ed in every step" if table_sharded else
+                                    f"window-sharded x{world} (contiguous ranges of equal k-mer count, database replicated)" if window_sharded
                                     else f"sample-sharded x{world} (reference replicated)")
-                                   + ", no data-path collective, one final RCCL gather of 40 B records"
+                                   + (", one RCCL gather of 520 B per tile and rank per step" if table_sharded else
+                                      ", no data-path collective, one final RCCL gather of 40 B records")
                                    + (" -- REHEARSAL: all ranks on one GPU over gloo, not a measurement" if rehearsal else ""))
                    if world > 1 else "single GPU",
                    "table_bytes": int(cohort.info.table_bytes if cohort is not None else db.info.table_bytes),
@@ -762,7 +801,7 @@ def main():
                                                                    "stash_records": int(cohort.info.stash_records),
                                                                    "open_seconds": float(cohort.info.load_seconds)}),
                    "hit_rate": float(res["obs"].sum() / max(1, res["total_kmers"].sum()))},
-        "windows_per_s": (n_win_total * max(1, args.samples) if window_sharded else n_win * S * world) * args.steps / elapsed,
+        "windows_per_s": (n_win_total * max(1, args.samples) if (window_sharded or table_sharded) else n_win * S * world) * args.steps / elapsed,
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": kernel_name, "kernel_instance": kernel_inst, "kernel_avg_ms": kern_avg_ms,

@@ -94,6 +94,8 @@ typedef struct {
     int32_t extended;        /* format 1: 1 = the first-choice line of a k-mer depends on the flank bases next to its minimizer too
                                 (databases of >= 0.5 G k-mers whose plain table left > 15 % of them outside their cell) */
     int32_t regions;         /* format 1: table_lines = regions x 2^n (1, 3, 5 or 7: table sizes between the powers of two for large databases) */
+    int32_t table_slices;    /* 1, or the n of kcfx_db_open_slice: the handle holds one slice of the database's table */
+    int32_t table_slice;     /* ... this one (stored_kmers, stash_kmers, table_* are the slice's) */
 } kcfx_db_info_t;
 
 /* ---- database ------------------------------------------------------------------------------------ */
@@ -118,6 +120,23 @@ typedef struct {
     int32_t reserved;
 } kcfx_db_opts;
 int32_t kcfx_db_open_opts(const char* kmc_prefix, int32_t device, const kcfx_db_opts* opts, kcfx_db** out);
+
+/* ONE SLICE of the database's table (round 5; KMC.java:173-189 maps a .kmc_suf of any size -- an HBM-resident table has to fit):
+ * the k-mers are partitioned over n_slices handles BY MINIMIZER (a hash of the 32 bits that name a k-mer's first-choice line and
+ * cell, so a k-mer's second / third lines and stash entry live in the slice of its first-choice cell and the k-mers of a minimizer
+ * run stay together); this handle builds the cells of slice `slice` in a table of 1 / n_slices of the size -- n_slices devices hold
+ * a database n_slices times as large at the density one device gives a small one. Every handle still streams the whole file.
+ * k = 19 .. 31 (cell tables) only, never rebuilt as a line table. Screening: kcfx_screen_ref_partial_async on every slice (each
+ * against a reference of the same text and windows on its device: the lanes whose minimizer another slice holds stay idle), the
+ * tiles' hit bitmaps and count sums merged (kcfx_ref_merge_from inside a process, kcfx_ref_export_partial_async / an RCCL gather /
+ * kcfx_ref_merge_partial_async between processes) and ONE kcfx_ref_finish_async -- or all of it in one call:
+ * kcfx_screen_sharded(KCFX_SHARD_TABLE). kcfx_screen_ref* on a slice handle fail with KCFX_ERR_ARG; kcfx_db_lookup returns a
+ * k-mer's counter on the slice(s) that hold it and 0 elsewhere. n_slices = 1 is kcfx_db_open_opts. */
+#define KCFX_SLICES_MAX 64
+int32_t kcfx_db_open_slice(const char* kmc_prefix, int32_t device, const kcfx_db_opts* opts, int32_t n_slices, int32_t slice, kcfx_db** out);
+/* which slice holds the cells of a minimizer: g32 = the 32 bits (line : r) of a first-choice cell in a table of 2^lbits lines per
+ * region; host arithmetic (the kernels' cell_slice_of), -1 on bad arguments */
+int32_t kcfx_table_slice_of(uint32_t g32, int32_t lbits, int32_t n_slices);
 
 /* Build the same table from host arrays of distinct k-mer words and counts (no files). `counter_size` in
  * 0..4 selects the stored counter width exactly like the KMC header field. */
@@ -284,6 +303,13 @@ void kcfx_ctx_destroy(kcfx_ctx* ctx);
                                   kcfx_shard_plan reports a group as seg_sample = its first sample; it spans
                                   min(KCFX_COHORT_MAX, n_samples - seg_sample) samples */
 
+#define KCFX_SHARD_TABLE 5     /* the TABLE of every sample partitioned over the devices (never chosen by AUTO; k = 19 .. 31): device g
+                                  opens slice g of G of the sample's database (kcfx_db_open_slice: 1 / G of the lines, every device
+                                  streams the file), screens the WHOLE window list against it, the tiles' hit bitmaps are OR-ed on
+                                  the first device and reduced there; sample after sample. For a database that one device holds
+                                  only at a density that costs it half its speed (a wheat-scale count: BASELINE configs[4]).
+                                  kcfx_shard_plan reports one segment per (device, sample), all windows each */
+
 typedef struct {
     int32_t shard_mode_used, n_devices;
     double seconds_total;         /* wall time of the call */
@@ -297,7 +323,8 @@ typedef struct {
 /* The partitioning kcfx_screen_sharded would use, without touching a GPU: segment i = device seg_device[i] (index into the
  * context's device list) screens sample seg_sample[i] against windows [seg_w_lo[i], seg_w_hi[i]); segments of one device are in
  * execution order. Up to `cap` segments are written, *n_segments = how many there are; *mode_used = what KCFX_SHARD_AUTO chose.
- * Every (sample, window) pair lies in exactly one segment. Output arrays may be NULL. */
+ * Every (sample, window) pair lies in exactly one segment (KCFX_SHARD_TABLE: in one segment PER DEVICE -- every device screens
+ * every pair against its slice of the sample's table). Output arrays may be NULL. */
 int32_t kcfx_shard_plan(int32_t shard_mode, int32_t n_devices, int32_t n_samples, const int32_t* win_len, int32_t n_windows,
                         int32_t kmer_length, int32_t* seg_device, int32_t* seg_sample, int32_t* seg_w_lo, int32_t* seg_w_hi,
                         int64_t cap, int64_t* n_segments, int32_t* mode_used);
@@ -311,6 +338,25 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
                             const uint8_t* text, int64_t text_len, const int64_t* win_begin, const int32_t* win_len,
                             int32_t n_windows, int32_t min_kmer_count, int32_t shard_mode, kcfx_result* out,
                             kcfx_shard_stats* stats);
+
+/* ---- the pieces of a pass over a partitioned table (kcfx_db_open_slice) -------------------------------------------------- */
+
+/* The screening kernel alone on the caller's stream: the tiles' bitmaps (validity, and the hits this slice found) and count sums
+ * stay in the reference's scratch (one screen in flight per reference, as for kcfx_screen_ref_async). Also takes a whole table. */
+int32_t kcfx_screen_ref_partial_async(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count, void* hip_stream);
+int32_t kcfx_screen_ref_partial(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count);     /* synchronous, on the reference's own stream */
+/* bytes of a reference's partial results: 512 per tile of bitmaps + 8 per tile of count sums (returns their sum) */
+int64_t kcfx_ref_partial_bytes(const kcfx_ref* ref, int64_t* bitmap_bytes, int64_t* sum_bytes);
+/* the partial results copied into caller-owned DEVICE buffers (tensors handed to an RCCL gather), on the caller's stream */
+int32_t kcfx_ref_export_partial_async(kcfx_ref* ref, void* bitmaps_device, void* sums_device, void* hip_stream);
+/* another slice's partial results -- device buffers on the reference's device, same text and windows -- into this reference's:
+ * hit words OR-ed, count sums added (every k-mer is looked up on exactly one slice) */
+int32_t kcfx_ref_merge_partial_async(kcfx_ref* ref, const void* bitmaps_device, const void* sums_device, void* hip_stream);
+/* the same from another reference handle of this process, on this device or another (peer copy); synchronous */
+int32_t kcfx_ref_merge_from(kcfx_ref* dst, kcfx_ref* src);
+/* reduce_windows over what the reference's scratch holds now: 40 bytes per window to out_device / to host memory */
+int32_t kcfx_ref_finish_async(kcfx_ref* ref, void* out_device, void* hip_stream);
+int32_t kcfx_ref_finish(kcfx_ref* ref, kcfx_result* out);
 
 /* ---- measurement ------------------------------------------------------------------------------------ */
 

@@ -50,7 +50,7 @@ struct Options {
     std::string ref, kmc, out, sample, feature, gtf;
     int threads = 2, window = 0, min_count = 1, step = 0;
     std::vector<int> devices{0};          // --device N | --devices a,b,...: the job is sharded over them (kcfx_screen_sharded)
-    int shard = KCFX_SHARD_AUTO;          // --shard auto|samples|windows|grid
+    int shard = KCFX_SHARD_AUTO;          // --shard auto|samples|windows|grid|cohort|table
     bool cohort_table = false;            // --cohort-table (= --shard cohort): the samples in cohort tables of up to 8, tables x window
                                           // ranges over the devices (KCFX_SHARD_COHORT)
     bool memory = false;
@@ -59,7 +59,7 @@ struct Options {
 
 void usage() {
     std::puts("Usage: kcftools-amd getVariations -r <ref.fa> -k <kmc prefix> -o <out.kcf> -s <sample> -f window|gene|transcript\n"
-              "       [-w window] [-p step] [-g gtf] [-c min-k-count] [--wi 0.3] [--wt 0.3] [--wr 0.4] [-t threads] [-m] [--device 0 | --devices 0,1,...] [--shard auto|samples|windows|grid|cohort] [--cohort-table]");
+              "       [-w window] [-p step] [-g gtf] [-c min-k-count] [--wi 0.3] [--wt 0.3] [--wr 0.4] [-t threads] [-m] [--device 0 | --devices 0,1,...] [--shard auto|samples|windows|grid|cohort|table] [--cohort-table]");
 }
 
 std::vector<std::string> split_commas(const std::string& v) {
@@ -133,7 +133,8 @@ int main(int argc, char** argv) {
             else if (v == "windows") o.shard = KCFX_SHARD_WINDOWS;
             else if (v == "grid") o.shard = KCFX_SHARD_GRID;
             else if (v == "cohort") o.shard = KCFX_SHARD_COHORT;
-            else error("Invalid --shard value: " + v + " (auto, samples, windows, grid or cohort)");
+            else if (v == "table") o.shard = KCFX_SHARD_TABLE;          // every sample's table in slices over the devices (a database too large for one)
+            else error("Invalid --shard value: " + v + " (auto, samples, windows, grid, cohort or table)");
         }
         else if (a == "--cohort-table") o.cohort_table = true;
         else if (a == "-h" || a == "--help") { usage(); return 0; }
@@ -302,7 +303,7 @@ int main(int argc, char** argv) {
         char line[256];
         std::snprintf(line, sizeof line, "Screened %zu sample(s) on %d device(s), %s-sharded: %.3f s (reference %.3f s, database loading %.3f s of which %.3f s not hidden behind screening, screening %.3f s)",
                       S, st.n_devices, st.shard_mode_used == KCFX_SHARD_SAMPLES ? "sample" : st.shard_mode_used == KCFX_SHARD_GRID ? "sample x window" :
-                      st.shard_mode_used == KCFX_SHARD_COHORT ? "cohort-table x window" : "window", st.seconds_total, st.seconds_ref,
+                      st.shard_mode_used == KCFX_SHARD_COHORT ? "cohort-table x window" : st.shard_mode_used == KCFX_SHARD_TABLE ? "table" : "window", st.seconds_total, st.seconds_ref,
                       st.seconds_db_open_sum, st.seconds_exposed_load, st.seconds_screen_sum);
         info(line);
     }

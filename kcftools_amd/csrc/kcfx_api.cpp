@@ -8,6 +8,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cmath>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -137,7 +138,9 @@ struct kcfx_db {
     uint32_t* d_pop = nullptr;               // FORMAT_CELLS build scratch: k-mers per minimizer (freed after the build)
     int32_t pop_bits = 32;                   // 2^pop_bits byte counters: 32 = one per minimizer, lbits + 2 when 4 GiB cannot be had
     hipStream_t stream = nullptr;
-    TableView view() const { return TableView{d_lines, n_lines, wide, mode, mm_len, fmt, lbits, stash_mask, d_stash, generic, info.both_strands, ext, regions}; }
+    int32_t n_slices = 1, slice = 0;         // kcfx_db_open_slice: the table holds slice `slice` of `n_slices` of the database (cell_slice_of)
+    int32_t slicing() const { return n_slices > 1 ? (n_slices << 8 | slice) : 0; }
+    TableView view() const { return TableView{d_lines, n_lines, wide, mode, mm_len, fmt, lbits, stash_mask, d_stash, generic, info.both_strands, ext, regions, n_slices, slice}; }
 };
 
 struct kcfx_ref {
@@ -271,7 +274,7 @@ bool cells_eligible(const kcfx_db* db, int32_t counter_size) {
         getenv("KCFX_MM_LEN") != nullptr)
         return false;
     // the minimizer is k - 15 bases: a line number cannot carry more than its 2 (k - 15) bits
-    return db->info.total_kmers <= (int64_t)16 << cells_lbits_cap(k);
+    return db->info.total_kmers / std::max(1, db->n_slices) <= (int64_t)16 << cells_lbits_cap(k);   // (a slice holds 1 / n of the k-mers)
 }
 
 // 2^lbits lines of 16 cells. The sparser the table the fewer k-mers find their cell taken and go to the stash (bench
@@ -655,12 +658,14 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     uint32_t* d_counts = nullptr;
     uint64_t* d_pw = nullptr;          // the cells of the resident records, kept by the first pass for the later ones (RecProbes)
     uint8_t* d_ps = nullptr;
+    uint8_t* d_raw = nullptr;          // the .kmc_suf records as the file holds them, resident between the passes (see below)
     hipEvent_t done[2] = {nullptr, nullptr};
     int32_t rc = KCFX_OK;
     auto cleanup = [&]() {
         // the temporaries are used on db->stream only: wait for that stream, not for the device (the other worker's
         // screening kernel, the next database's uploads)
         (void)hipStreamSynchronize(db->stream);
+        if (d_raw) (void)dev_free_idle(d_raw);
         if (d_pw) (void)dev_free_idle(d_pw);
         if (d_ps) (void)dev_free_idle(d_ps);
         for (int i = 0; i < 2; ++i) {
@@ -688,8 +693,18 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     size_t free_b = free_device_bytes();
     // (the table may still be on its way -- table_ready -- and must not be counted as free room: conservative when it has arrived)
     if (db->alloc_thread.joinable()) free_b -= std::min<size_t>(free_b, (size_t)LINE_BYTES * db->n_lines);
-    const bool resident = two_phase && getenv("KCFX_LOAD_STREAM_TWICE") == nullptr &&
+    const char* raw_env = getenv("KCFX_LOAD_RAW");          // 1: the raw tier whatever fits (test hook); 0: never
+    const bool resident = two_phase && getenv("KCFX_LOAD_STREAM_TWICE") == nullptr && !(raw_env && raw_env[0] == '1') &&
                           (double)h.total * 12.0 + (double)(2 * chunk_bytes) + (double)(64 << 20) < 0.5 * (double)free_b;
+    // Round 5, between "everything decoded stays" and "the file is streamed once per pass": the RECORDS stay, as the file holds them
+    // (record_size bytes each: 8 for k = 31, p = 7, 2-byte counters -- two thirds of the decoded 12, a third of the 21 with the kept
+    // cells), and every pass decodes its chunk again from HBM (decode_records_kernel: ~3 % of a pass). A wheat-scale database
+    // (8 G k-mers, 65 GB of records beside 192 GiB of lines) then streams its file ONCE for the build passes and once more for the
+    // stash pass -- the records make room for the stash first -- where round 4 streamed it nine times (26 s for a 43 ms pass).
+    // Only tried when the decoded form does not fit; an allocation that fails falls back to streaming per pass.
+    bool raw_tier = two_phase && cells && !resident && !(raw_env && raw_env[0] == '0') && getenv("KCFX_LOAD_STREAM_TWICE") == nullptr &&
+                    ((raw_env && raw_env[0] == '1') ||
+                     (double)h.total * h.record_size + (double)h.total / 16.0 + (double)(4 * chunk_bytes) + (double)(1ull << 30) < (double)free_b);
     const int64_t n_chunk_max = std::min<int64_t>(CH, std::max<int64_t>(h.total, 1));
     const int64_t n_keys_buf = resident ? std::max<int64_t>(h.total, 1) : n_chunk_max;
     for (int i = 0; i < 2; ++i) {
@@ -708,8 +723,15 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
         LOAD_HIP(dev_alloc(&d_pw, (size_t)n_keys_buf * 8));
         LOAD_HIP(dev_alloc(&d_ps, (size_t)n_keys_buf));
     }
+    if (raw_tier) {
+        if (dev_alloc(&d_raw, (size_t)h.total * h.record_size + 64) != hipSuccess) {
+            (void)hipGetLastError();
+            d_raw = nullptr;
+            raw_tier = false;
+        }
+    }
     if (h.lut_entries) LOAD_HIP(hipMemcpyAsync(d_lut, h.lut_bytes, (size_t)h.lut_entries * 8, hipMemcpyHostToDevice, db->stream));
-    tr.mark("buffers + LUT upload");
+    tr.mark(raw_tier ? "buffers + LUT upload (records will stay resident)" : "buffers + LUT upload");
 
     // One pass of the build over a batch of decoded records. Line tables: 0 = count per home line (minimizer tables only),
     // 1 = insert. Cell tables: 0 = count per minimizer sub-bucket, 1 / 2 = claim the first-choice cells / write the winners' cell words, 3 = settle
@@ -723,9 +745,9 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
             if (phase == 0)
                 return pw ? launch_cells_resolve(db->d_pop, db->pop_bits, kk, db->lbits, db->info.both_strands, keys, counts, n, pw, ps, db->stream, db->ext)
                           : launch_cells_count(db->d_pop, db->pop_bits, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream, 0, db->ext);
-            if (phase == 1 || phase == 2) return launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, phase == 1 ? 1 : 0, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream, 0, pw, ps, db->ext, db->regions);
-            if (phase == 3) return launch_cells_settle(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stats, db->stream, 0, pw, ps, db->ext, db->regions);
-            return launch_cells_stash(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stash, db->stash_mask, db->stream, 0, pw, ps, db->ext, db->regions);
+            if (phase == 1 || phase == 2) return launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, phase == 1 ? 1 : 0, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream, 0, pw, ps, db->ext, db->regions, db->slicing());
+            if (phase == 3) return launch_cells_settle(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stats, db->stream, 0, pw, ps, db->ext, db->regions, db->slicing());
+            return launch_cells_stash(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stash, db->stash_mask, db->stream, 0, pw, ps, db->ext, db->regions, db->slicing());
         }
         if (phase == 0) return launch_table_count(db->d_lines, db->view(), h.k, keys, n, db->stream);
         return launch_table_insert(db->d_lines, db->view(), h.k, keys, counts, n, db->stream);
@@ -743,12 +765,14 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
                 return fail(KCFX_ERR_IO, "short read on " + path);
             }
             // d_rec[turn] was last read by the decode two chunks ago, which precedes this copy in stream order
-            LOAD_HIP(hipMemcpyAsync(d_rec[turn], h_buf[turn], (size_t)bytes, hipMemcpyHostToDevice, db->stream));
+            // (the raw tier: the chunk lands in its place among the resident records)
+            uint8_t* const rec_at = d_raw ? d_raw + (size_t)first * h.record_size : d_rec[turn];
+            LOAD_HIP(hipMemcpyAsync(rec_at, h_buf[turn], (size_t)bytes, hipMemcpyHostToDevice, db->stream));
             LOAD_HIP(hipEventRecord(done[turn], db->stream));
             used[turn] = true;
             uint64_t* keys = d_keys + (keep ? first : 0);
             uint32_t* counts = d_counts + (keep ? first : 0);
-            LOAD_HIP(launch_decode_records(d_rec[turn], first, n, h.record_size, h.suffix_bytes, h.counter_size, h.p, d_lut,
+            LOAD_HIP(launch_decode_records(rec_at, first, n, h.record_size, h.suffix_bytes, h.counter_size, h.p, d_lut,
                                            h.lut_entries, keys, counts, db->stream));
             LOAD_HIP(apply(phase, keys, counts, n));
             first += n;
@@ -766,8 +790,44 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
             }
             return KCFX_OK;
         }
+        if (d_raw) {                                        // the records are resident: decode chunk by chunk from HBM
+            for (int64_t first = 0; first < h.total; first += CH) {
+                const int64_t n = std::min(CH, h.total - first);
+                LOAD_HIP(launch_decode_records(d_raw + (size_t)first * h.record_size, first, n, h.record_size, h.suffix_bytes, h.counter_size, h.p, d_lut,
+                                               h.lut_entries, d_keys, d_counts, db->stream));
+                LOAD_HIP(apply(phase, d_keys, d_counts, n));
+            }
+            return KCFX_OK;
+        }
         LOAD_HIP(hipStreamSynchronize(db->stream));
         return stream_file(phase, false);
+    };
+    // Does this database want an EXTENDED table? Round 4 found out by building a plain one (four passes) and starting over when more
+    // than EXT_MOVED_SHARE of the k-mers sat outside their first-choice cells. The crowding counters of pass 0 say as much before
+    // any bid: a minimizer with c k-mers is c / L runs of ~L consecutive offsets (L = 0.65 W: the run length of the order) that
+    // fall on the W cells of a line independently, so W (1 - (1 - L / W)^(c / L)) of its k-mers find a cell of their own and the rest
+    // are displaced (8 G genomic k-mers, four loci per preferred 16-mer: c ~ 41 -> 61 %, measured 65 %; the bench database: ~0).
+    // Only with one counter per minimizer (pop_bits == 32); the check after the build stays as the safety net.
+    auto ext_by_crowding = [&](double* share) -> int32_t {
+        unsigned long long* d_hist = nullptr;
+        unsigned long long hist[256];
+        LOAD_HIP(dev_alloc(&d_hist, sizeof hist));
+        hipError_t e2 = hipMemsetAsync(d_hist, 0, sizeof hist, db->stream);
+        if (e2 == hipSuccess) e2 = launch_pop_histogram(db->d_pop, db->pop_bits, d_hist, db->stream);
+        if (e2 == hipSuccess) e2 = hipMemcpyAsync(hist, d_hist, sizeof hist, hipMemcpyDeviceToHost, db->stream);
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(db->stream);
+        (void)dev_free_idle(d_hist);
+        LOAD_HIP(e2);
+        const double W = (double)(db->info.kmer_length - 15), L = 0.65 * W;
+        double all = 0, moved = 0;
+        for (int c = 1; c < 256; ++c) {
+            const double n = (double)hist[c];
+            const double home = std::min((double)c, W * (1.0 - std::pow(1.0 - L / W, (double)c / L)));
+            all += n * c;
+            moved += n * ((double)c - home);
+        }
+        *share = all > 0 ? moved / all : 0.0;
+        return KCFX_OK;
     };
 
     if (!two_phase) {
@@ -781,6 +841,18 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
                 return rc;
             }
             tr.mark("wait for the table");
+            constexpr double EXT_MOVED_SHARE = 0.15;
+            if (db->ext_auto && !db->ext && db->pop_bits == 32 && getenv("KCFX_EXT_LATE") == nullptr) {
+                double share = 0;
+                if ((rc = ext_by_crowding(&share))) return rc;
+                if (tr.on) fprintf(stderr, "[kcfx load] crowding counters: %.1f %% of the k-mers would sit outside their first-choice cells in a plain table\n", 100.0 * share);
+                if (share > EXT_MOVED_SHARE) {
+                    db->ext = 1;                            // the counters again, per extended minimizer; nothing else has been built yet
+                    LOAD_HIP(hipMemsetAsync(db->d_pop, 0, cells_pop_bytes(db->pop_bits), db->stream));
+                    if ((rc = later_pass(0))) return rc;
+                    tr.mark("extended table chosen by the crowding counters");
+                }
+            }
             for (int phase = 1; phase <= 3; ++phase)
                 if ((rc = later_pass(phase))) return rc;
             if (db->ext_auto && !db->ext) {
@@ -788,7 +860,7 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
                 unsigned long long st4[4] = {0, 0, 0, 0};
                 LOAD_HIP(hipMemcpyAsync(st4, db->d_stats, sizeof st4, hipMemcpyDeviceToHost, db->stream));
                 LOAD_HIP(hipStreamSynchronize(db->stream));
-                constexpr double EXT_MOVED_SHARE = 0.15;
+                if (tr.on) fprintf(stderr, "[kcfx load] plain table: %.1f %% of the k-mers outside their first-choice cells\n", 100.0 * (double)(st4[0] + st4[3]) / (double)std::max<unsigned long long>(st4[1], 1));
                 if ((double)(st4[0] + st4[3]) > EXT_MOVED_SHARE * (double)std::max<unsigned long long>(st4[1], 1)) {
                     db->ext = 1;                            // start over: lines, counters and statistics cleared, the four passes again
                     LOAD_HIP(hipMemsetAsync(db->d_lines, 0, (size_t)LINE_BYTES * db->n_lines, db->stream));
@@ -799,6 +871,11 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
                         if ((rc = later_pass(phase))) return rc;
                     tr.mark("rebuilt as an extended table");
                 }
+            }
+            if (d_raw) {                                    // the resident records make room for the stash; its pass streams the file once more
+                LOAD_HIP(hipStreamSynchronize(db->stream));
+                (void)dev_free_idle(d_raw);
+                d_raw = nullptr;
             }
             if ((rc = cells_stash_alloc(db))) {
                 cleanup();
@@ -941,9 +1018,19 @@ int32_t kcfx_device_count(int32_t* n) {
 
 int32_t kcfx_db_open(const char* kmc_prefix, int32_t device, kcfx_db** out) { return kcfx_db_open_opts(kmc_prefix, device, nullptr, out); }
 
-int32_t kcfx_db_open_opts(const char* kmc_prefix, int32_t device, const kcfx_db_opts* opts, kcfx_db** out) try {
+int32_t kcfx_db_open_opts(const char* kmc_prefix, int32_t device, const kcfx_db_opts* opts, kcfx_db** out) {
+    return kcfx_db_open_slice(kmc_prefix, device, opts, 1, 0, out);
+}
+
+int32_t kcfx_table_slice_of(uint32_t g32, int32_t lbits, int32_t n_slices) {
+    if (n_slices < 1 || n_slices > KCFX_SLICES_MAX || lbits < CELL_LBITS_MIN || lbits > CELL_LBITS_MAX) return -1;
+    return (int32_t)cell_slice_of(g32 >> (32 - lbits), g32, lbits, (uint32_t)n_slices);
+}
+
+int32_t kcfx_db_open_slice(const char* kmc_prefix, int32_t device, const kcfx_db_opts* opts, int32_t n_slices, int32_t slice, kcfx_db** out) try {
     if (!kmc_prefix || !out) return fail(KCFX_ERR_ARG, "null argument");
     if (opts && opts->expected_queries < 0) return fail(KCFX_ERR_ARG, "kcfx_db_opts: negative expected_queries");
+    if (n_slices < 1 || n_slices > KCFX_SLICES_MAX || slice < 0 || slice >= n_slices) return fail(KCFX_ERR_ARG, "kcfx_db_open_slice: slice out of range (1 .. 64 slices)");
     *out = nullptr;
     const double t0 = now_s();
     KmcHeader h;
@@ -962,10 +1049,22 @@ int32_t kcfx_db_open_opts(const char* kmc_prefix, int32_t device, const kcfx_db_
     info_from_header(h, db->info);
     db->info.device = device;
     db->expected_queries = opts ? opts->expected_queries : 0;
+    db->n_slices = n_slices;
+    db->slice = slice;
+    db->info.table_slices = n_slices;
+    db->info.table_slice = slice;
     hipError_t e = db_stream(device, &db->stream);
     if (e != hipSuccess) return hip_fail(e, "hipStreamCreate");
     tr.mark("device + stream");
-    int32_t rc = table_alloc(db, h.total, h.counter_size, true, getenv("KCFX_SYNC_ALLOC") == nullptr);
+    // a slice holds 1 / n of the k-mers (a hash of the minimizer decides: + 2 % and a few thousand for the unevenness) -- the table is
+    // sized for that many, every pass still walks the whole file
+    const int64_t n_mine = n_slices > 1 ? std::min<int64_t>(h.total, h.total / n_slices + h.total / (50 * n_slices) + 4096) : h.total;
+    if (n_slices > 1) {
+        const int32_t kk = db->info.kmer_length;
+        if (kk < CELL_K_MIN || kk > CELL_K_MAX || getenv("KCFX_TABLE_FORMAT") || getenv("KCFX_GENERIC_KERNEL") || getenv("KCFX_MM_LEN") || table_mode() != MODE_MINIMIZER)
+            return fail(KCFX_ERR_ARG, "table slices need a cell table (k = 19 .. 31, the default table format)");
+    }
+    int32_t rc = table_alloc(db, n_mine, h.counter_size, true, getenv("KCFX_SYNC_ALLOC") == nullptr);
     tr.mark("table alloc (deferred)");
     if (!rc) rc = load_suffix_file(db, std::string(kmc_prefix) + ".kmc_suf", h);
     // (the allocation thread may still be running when the streaming failed first -- an I/O error, or the decoded arrays lost the
@@ -980,11 +1079,11 @@ int32_t kcfx_db_open_opts(const char* kmc_prefix, int32_t device, const kcfx_db_
         const int32_t cap = db->regions > 1 ? std::min(cells_lbits_cap(db->info.kmer_length), db->lbits + (db->regions == 3 ? 1 : 2)) : db->lbits - 1;
         table_release(db);
         db->lbits_cap = cap;
-        rc = table_alloc(db, h.total, h.counter_size, true, false);
+        rc = table_alloc(db, n_mine, h.counter_size, true, false);
         if (!rc) rc = load_suffix_file(db, std::string(kmc_prefix) + ".kmc_suf", h);
         tr.mark("denser cell table after an out-of-memory");
     }
-    if (rc == KCFX_ERR_DEVICE && db->fmt == FORMAT_CELLS && !(opts && opts->no_fallback)) {
+    if (rc == KCFX_ERR_DEVICE && db->fmt == FORMAT_CELLS && !(opts && opts->no_fallback) && n_slices == 1) {     // (a slice is a cell table or nothing)
         // the cell table or its stash did not fit (a database of many billions of k-mers next to another resident one):
         // the 12-slot line table stores a k-mer in 11-30 bytes instead of 100+, at ~0.55x the screening speed
         const std::string why = g_error;
@@ -1003,7 +1102,7 @@ int32_t kcfx_db_open_opts(const char* kmc_prefix, int32_t device, const kcfx_db_
     db->info.load_seconds = now_s() - t0;
     *out = hold.release();
     return KCFX_OK;
-} KCFX_CATCH("kcfx_db_open")
+} KCFX_CATCH("kcfx_db_open_slice")
 
 int32_t kcfx_table_plan(int64_t total_kmers, int32_t kmer_length, int32_t both_strands, int64_t free_bytes,
                         int64_t* lines, int32_t* regions) try {
@@ -1282,11 +1381,15 @@ int32_t kcfx_ref_n_windows(const kcfx_ref* ref) { return ref ? ref->n_windows : 
 int64_t kcfx_ref_n_kmer_slots(const kcfx_ref* ref) { return ref ? ref->n_slots : 0; }
 void kcfx_ref_destroy(kcfx_ref* ref) { ref_free(ref); }
 
-int32_t kcfx_screen_ref_async(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count, void* out_device, void* hip_stream) try {
-    if (!db || !ref || !out_device) return fail(KCFX_ERR_ARG, "null argument");
+// the screening launch of one database against a resident reference (+ reduce_windows unless `partial`: the table is one slice of
+// its database and the tiles' bitmaps are merged with the other slices' first)
+static int32_t screen_ref_launch(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count, void* out_device, void* hip_stream, bool partial) {
+    if (!db || !ref || (!out_device && !partial)) return fail(KCFX_ERR_ARG, "null argument");
     if (db->device != ref->device) return fail(KCFX_ERR_ARG, "database and reference live on different devices");
     if (db->info.kmer_length != ref->k) return fail(KCFX_ERR_ARG, "reference was planned for a different k-mer length");
     if (min_kmer_count < 1) return fail(KCFX_ERR_ARG, "Minimum kmer count should be at least 1");   // GetVariants.java:383-385
+    if (db->n_slices > 1 && !partial)
+        return fail(KCFX_ERR_ARG, "the handle holds one slice of its database (kcfx_db_open_slice): use kcfx_screen_ref_partial_async + kcfx_ref_merge_* + kcfx_ref_finish_async");
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
     DeviceGuard g(db->device);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1303,10 +1406,112 @@ int32_t kcfx_screen_ref_async(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count
     }
     KCFX_HIP(launch_screen_tiles(ref->d_text, ref->plan(), ref->d_tiles, ref->n_tiles, db->view(), ref->k, db->info.both_strands,
                                  min_kmer_count, ref->d_bits, ref->d_csum, st, ev0, ev1));
+    if (partial) return KCFX_OK;                           // (kcfx_screen_ref_partial_async: the bitmaps stay where they are)
     KCFX_HIP(launch_reduce_windows(ref->d_tiles, ref->n_tiles, 1, ref->d_bits, ref->d_csum, ref->d_win_tile0, ref->n_windows,
                                    ref->k, reinterpret_cast<kcfx_result*>(out_device), st));
     return KCFX_OK;
+}
+
+int32_t kcfx_screen_ref_async(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count, void* out_device, void* hip_stream) try {
+    return screen_ref_launch(db, ref, min_kmer_count, out_device, hip_stream, false);
 } KCFX_CATCH("kcfx_screen_ref_async")
+
+// ---- a table partitioned over devices (kcfx_db_open_slice): screen against one slice, merge, reduce once ---------------------
+// The screening kernel alone: the tiles' bitmaps (validity + the hits THIS slice found) and count sums stay in the reference's
+// scratch. Works for a whole table too (one slice of one).
+int32_t kcfx_screen_ref_partial_async(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count, void* hip_stream) try {
+    if (!db || !ref) return fail(KCFX_ERR_ARG, "null argument");
+    if (db->fmt != FORMAT_CELLS) return fail(KCFX_ERR_ARG, "a partial screen needs a cell table (k = 19 .. 31)");
+    return screen_ref_launch(db, ref, min_kmer_count, nullptr, hip_stream, true);
+} KCFX_CATCH("kcfx_screen_ref_partial_async")
+
+int64_t kcfx_ref_partial_bytes(const kcfx_ref* ref, int64_t* bitmap_bytes, int64_t* sum_bytes) {
+    if (!ref) return 0;
+    const int64_t b = (int64_t)std::max(ref->n_tiles, 1) * TILE_BITS_U64 * 8, c = (int64_t)std::max(ref->n_tiles, 1) * 8;
+    if (bitmap_bytes) *bitmap_bytes = b;
+    if (sum_bytes) *sum_bytes = c;
+    return b + c;
+}
+
+// the reference's partial results copied into caller-owned DEVICE buffers (e.g. tensors handed to an RCCL gather)
+int32_t kcfx_ref_export_partial_async(kcfx_ref* ref, void* bitmaps_device, void* sums_device, void* hip_stream) try {
+    if (!ref || !bitmaps_device || !sums_device) return fail(KCFX_ERR_ARG, "null argument");
+    int64_t b = 0, c = 0;
+    kcfx_ref_partial_bytes(ref, &b, &c);
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    DeviceGuard g(ref->device);
+    KCFX_HIP(hipMemcpyAsync(bitmaps_device, ref->d_bits, (size_t)b, hipMemcpyDeviceToDevice, st));
+    KCFX_HIP(hipMemcpyAsync(sums_device, ref->d_csum, (size_t)c, hipMemcpyDeviceToDevice, st));
+    return KCFX_OK;
+} KCFX_CATCH("kcfx_ref_export_partial_async")
+
+// another slice's partial results (device buffers on the reference's device, same tile list) into this reference's: hits OR-ed,
+// count sums added; the validity words are the same on every slice
+int32_t kcfx_ref_merge_partial_async(kcfx_ref* ref, const void* bitmaps_device, const void* sums_device, void* hip_stream) try {
+    if (!ref || !bitmaps_device || !sums_device) return fail(KCFX_ERR_ARG, "null argument");
+    DeviceGuard g(ref->device);
+    KCFX_HIP(launch_merge_partial(ref->d_bits, ref->d_csum, reinterpret_cast<const uint64_t*>(bitmaps_device),
+                                  reinterpret_cast<const int64_t*>(sums_device), ref->n_tiles, reinterpret_cast<hipStream_t>(hip_stream)));
+    return KCFX_OK;
+} KCFX_CATCH("kcfx_ref_merge_partial_async")
+
+// the same from another reference handle of the same text and windows, on this device or on another one of the process (peer copy
+// into a scratch buffer first); synchronous: returns when dst holds the merged results
+int32_t kcfx_ref_merge_from(kcfx_ref* dst, kcfx_ref* src) try {
+    if (!dst || !src) return fail(KCFX_ERR_ARG, "null argument");
+    if (dst->n_tiles != src->n_tiles || dst->n_windows != src->n_windows || dst->k != src->k)
+        return fail(KCFX_ERR_ARG, "kcfx_ref_merge_from: the two references do not describe the same windows");
+    if (dst == src || dst->n_tiles == 0) return KCFX_OK;
+    int64_t b = 0, c = 0;
+    kcfx_ref_partial_bytes(dst, &b, &c);
+    {
+        DeviceGuard gs(src->device);
+        KCFX_HIP(hipStreamSynchronize(src->stream));        // (the caller has waited for src's screening launch; its own stream is idle)
+    }
+    DeviceGuard g(dst->device);
+    if (dst->device == src->device) {
+        KCFX_HIP(launch_merge_partial(dst->d_bits, dst->d_csum, src->d_bits, src->d_csum, dst->n_tiles, dst->stream));
+        KCFX_HIP(hipStreamSynchronize(dst->stream));
+        return KCFX_OK;
+    }
+    uint8_t* tmp = nullptr;
+    KCFX_HIP(dev_alloc(&tmp, (size_t)(b + c)));
+    hipError_t e = hipMemcpyPeerAsync(tmp, dst->device, src->d_bits, src->device, (size_t)b, dst->stream);
+    if (e == hipSuccess) e = hipMemcpyPeerAsync(tmp + b, dst->device, src->d_csum, src->device, (size_t)c, dst->stream);
+    if (e == hipSuccess) e = launch_merge_partial(dst->d_bits, dst->d_csum, reinterpret_cast<const uint64_t*>(tmp), reinterpret_cast<const int64_t*>(tmp + b), dst->n_tiles, dst->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(dst->stream);
+    (void)dev_free_idle(tmp);
+    if (e != hipSuccess) return hip_fail(e, "kcfx_ref_merge_from");
+    return KCFX_OK;
+} KCFX_CATCH("kcfx_ref_merge_from")
+
+// reduce_windows over what the reference's scratch holds now (one slice's results or the merged ones): 40 bytes per window to out_device
+int32_t kcfx_ref_finish_async(kcfx_ref* ref, void* out_device, void* hip_stream) try {
+    if (!ref || !out_device) return fail(KCFX_ERR_ARG, "null argument");
+    DeviceGuard g(ref->device);
+    KCFX_HIP(launch_reduce_windows(ref->d_tiles, ref->n_tiles, 1, ref->d_bits, ref->d_csum, ref->d_win_tile0, ref->n_windows,
+                                   ref->k, reinterpret_cast<kcfx_result*>(out_device), reinterpret_cast<hipStream_t>(hip_stream)));
+    return KCFX_OK;
+} KCFX_CATCH("kcfx_ref_finish_async")
+
+// synchronous forms on the handles' own streams (what kcfx_screen_sharded's workers call)
+int32_t kcfx_screen_ref_partial(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count) try {
+    if (!ref) return fail(KCFX_ERR_ARG, "null argument");
+    if (int32_t rc = kcfx_screen_ref_partial_async(db, ref, min_kmer_count, ref->stream)) return rc;
+    DeviceGuard g(ref->device);
+    KCFX_HIP(hipStreamSynchronize(ref->stream));
+    return KCFX_OK;
+} KCFX_CATCH("kcfx_screen_ref_partial")
+
+int32_t kcfx_ref_finish(kcfx_ref* ref, kcfx_result* out) try {
+    if (!ref || (!out && ref->n_windows > 0)) return fail(KCFX_ERR_ARG, "null argument");
+    if (ref->n_windows == 0) return KCFX_OK;
+    if (int32_t rc = kcfx_ref_finish_async(ref, ref->d_res, ref->stream)) return rc;
+    DeviceGuard g(ref->device);
+    KCFX_HIP(hipMemcpyAsync(out, ref->d_res, (size_t)ref->n_windows * sizeof(kcfx_result), hipMemcpyDeviceToHost, ref->stream));
+    KCFX_HIP(hipStreamSynchronize(ref->stream));
+    return KCFX_OK;
+} KCFX_CATCH("kcfx_ref_finish")
 
 // SURVEY f-4: S resident databases, one pass over the reference. Databases the multi-sample kernel cannot take
 // (k != 31, key-hash tables) go through the single-sample path into their slice of the output.

@@ -89,6 +89,20 @@ __host__ __device__ inline uint64_t cell_word(uint32_t w, uint32_t r, uint32_t c
     return (uint64_t)w | ((uint64_t)(r & 0xFFFFu) << 32) | ((uint64_t)(count & 0xFFFFu) << 48);
 }
 
+// TABLE SLICES (TableView::slices = S; round 5): a database whose table does not fit one device at a density worth having is
+// partitioned over the S devices of a node BY MINIMIZER -- device s holds the cells of the k-mers whose (line, r) hash to s, in a
+// table of 1 / S of the lines (kcfx_db_open_slice); every device screens the whole reference with the lanes whose minimizer is not
+// its own switched off, and the per-tile hit bitmaps and count sums are OR-ed / added before ONE reduce_windows (kcfx_shard.cpp,
+// KCFX_SHARD_TABLE). A function of the same 32 bits that name the line and r of the FIRST choice, so a k-mer's second and third
+// lines, its filter bits and its stash entry live where its first-choice cell does, and the k-mers of a minimizer run stay
+// together (an extended table cuts a run in two at most, as it does for its lines). A k-mer with several first-choice cells (tied
+// minimizers) is stored per cell, each copy where a query that derives THAT cell will look.
+__host__ __device__ inline uint32_t cell_slice_of(uint32_t line, uint32_t r, int32_t lbits, uint32_t n_slices) {
+    const uint32_t g = (line << (32 - lbits)) | (r & (0xFFFFFFFFu >> lbits));
+    const uint32_t h = (g ^ (g >> 13)) * 0x7FEB352Du;
+    return (uint32_t)(((uint64_t)(h ^ (h >> 15)) * n_slices) >> 32);
+}
+
 struct TableView {
     const uint8_t* lines;
     uint32_t n_lines;
@@ -103,6 +117,8 @@ struct TableView {
     int32_t both;        // the database is canonical (both strands); 0: k-mers are looked up as the text reads them
     int32_t ext;         // FORMAT_CELLS: an extended table -- the first-choice line depends on the flank too (cell_first_ext, kcfx_device.h)
     int32_t regions;     // FORMAT_CELLS: 1, or R regions of 2^lbits lines each (cell_line_index, kcfx_device.h)
+    int32_t slices;      // FORMAT_CELLS: 1, or the table holds slice `slice` of `slices` of the database (cell_slice_of, kcfx_device.h)
+    int32_t slice;
 };
 
 // ----------------------------------------------------------------------------------------------------
@@ -293,7 +309,9 @@ hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide,
 // (cells_pop_bytes of zeroed scratch), the bids for the first-choice cells (cls 1: every k-mer claims with its rank), the winners'
 // cell words (cls 0: written where a k-mer finds its own rank), settle the losers into
 // second-choice cells or flag them for the stash (stats[0] = how many), fill the stash
-size_t cells_pop_bytes(int32_t pop_bits);          // pop_bits = 32 (one counter per minimizer) or lbits + 2
+size_t cells_pop_bytes(int32_t pop_bits);
+// minimizers per crowding count 0 .. 255 (hist256: 256 zeroed counters on the device), see kcfx_db_open's early choice of an extended table
+hipError_t launch_pop_histogram(const uint32_t* pop32, int32_t pop_bits, unsigned long long* hist256, hipStream_t st);          // pop_bits = 32 (one counter per minimizer) or lbits + 2
 // (both = the database is canonical; see CELL_R_FLIP in kcfx_device.h for what a forward-only one changes)
 // (presence != 0: every non-zero counter is stored as 1 -- the key table of a cohort, kcfx_cohort_open)
 hipError_t launch_cells_count(uint32_t* pop32, int32_t pop_bits, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
@@ -303,11 +321,12 @@ hipError_t launch_cells_count(uint32_t* pop32, int32_t pop_bits, int32_t k, int3
 hipError_t launch_cells_resolve(uint32_t* pop32, int32_t pop_bits, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
                                 uint64_t* pw, uint8_t* ps, hipStream_t st, int32_t ext = 0);
 hipError_t launch_cells_insert(uint8_t* lines, const uint32_t* pop32, int32_t pop_bits, int32_t cls, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys,
-                               const uint32_t* counts, int64_t n, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr, int32_t ext = 0, int32_t regions = 1);
+                               const uint32_t* counts, int64_t n, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr, int32_t ext = 0, int32_t regions = 1, int32_t slicing = 0);
 hipError_t launch_cells_settle(uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                               unsigned long long* stats, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr, int32_t ext = 0, int32_t regions = 1);
+                               unsigned long long* stats, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr, int32_t ext = 0, int32_t regions = 1, int32_t slicing = 0);
 hipError_t launch_cells_stash(const uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                              uint4* stash, uint32_t stash_mask, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr, int32_t ext = 0, int32_t regions = 1);
+                              uint4* stash, uint32_t stash_mask, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr, int32_t ext = 0, int32_t regions = 1, int32_t slicing = 0);
+// (slicing: 0, or slices << 8 | slice -- the table is one slice of the database, kcfx_db_open_slice: the passes act on this slice's cells only)
 // cohort tables: one sample's counters into the finished key table; S samples screened in one pass (bits / count_sums laid out
 // per sample as launch_screen_multi's: sample s at bits + s * n_tiles * TILE_BITS_U64, count_sums + s * n_tiles)
 // phase 0: every record votes for its k-mer in `votes` (2^n slots of 16 bytes, all bytes 0xFF); phase 1: the bid rank of every
@@ -332,6 +351,8 @@ hipError_t launch_screen_tiles(const uint8_t* text, RefPlan plan, const TileDesc
                                int32_t both_strands, int32_t min_count, uint64_t* bits, int64_t* count_sums,
                                hipStream_t st, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // hit bitmaps + count sums of n_samples consecutive samples -> kcfx_result per (sample, window)
+// table slices: another slice's tile bitmaps (hit halves OR-ed) and count sums (added) into these
+hipError_t launch_merge_partial(uint64_t* bits, int64_t* sums, const uint64_t* obits, const int64_t* osums, int32_t n_tiles, hipStream_t st);
 hipError_t launch_reduce_windows(const TileDesc* tiles, int32_t n_tiles, int32_t n_samples, const uint64_t* bits,
                                  const int64_t* count_sums, const int32_t* win_tile0, int32_t n_windows, int32_t k,
                                  kcfx_result* out, hipStream_t st, int32_t shared_valid = 0);

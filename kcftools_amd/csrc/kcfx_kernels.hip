@@ -260,6 +260,11 @@ struct RecProbes {
     const uint8_t* ps;      // cell index | REC_MULTI | REC_FLIP
     int32_t ext;            // the table is an extended one (what is kept is the extended G32: cell_first_ext)
     int32_t regions;        // the table has R regions of 2^lbits lines (cell_line_index): where a probe's line IS
+    int32_t slicing;        // 0, or (slices << 8 | slice): the table holds one slice of the database (cell_slice_of) -- a pass acts
+                            // on the cells of a record that are this slice's and leaves the others to the devices that hold theirs
+    __device__ __forceinline__ bool mine(const CellProbe& p, int32_t lbits) const {
+        return slicing == 0 || cell_slice_of(p.line, p.r, lbits, (uint32_t)slicing >> 8) == ((uint32_t)slicing & 0xFFu);
+    }
 };
 // byte address of a probe's cell in the table
 __device__ __forceinline__ size_t cell_byte_at(const CellProbe& p, int32_t lbits, int32_t regions) {
@@ -346,6 +351,7 @@ __global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__
                 const uint64_t sub = cell_sub_bucket(p, lbits, pop_bits);
                 crowded = ((pop32[sub >> 2] >> (8 * (uint32_t)(sub & 3))) & 0xFFu) >= CELL_CROWD;
             }
+            if (!rp.mine(p, lbits)) return;             // (a table slice: the crowding counters are of the whole database, the cells of this slice)
             unsigned long long* cell = reinterpret_cast<unsigned long long*>(lines + cell_byte_at(p, lbits, rp.regions));
             const unsigned long long bid = cell_bid(p, c, crowded, lbits, presence);
             if (cls) atomicMax(cell, bid);
@@ -395,7 +401,10 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, in
         if (c == 0) continue;
         bool lost = false;
         const bool wide = cell_is_wide(c, presence);
-        const int nc = record_cells(rp, i, keys[i], k, lbits, both, [&](const CellProbe& p, int) {
+        int nc = 0;                                     // its cells in this table (all of them unless the table is a slice)
+        record_cells(rp, i, keys[i], k, lbits, both, [&](const CellProbe& p, int) {
+            if (!rp.mine(p, lbits)) return;
+            ++nc;
             uint8_t* line = lines + (size_t)cell_line_index(p.line, p.r, lbits, rp.regions) * LINE_BYTES;
             unsigned long long mark = CELL_FLAG_STASH;
             if (cell_spare_bits(lbits, both) > 0) mark |= 1ull << (32 + cell_filter_pos(p.w, lbits, both));
@@ -453,6 +462,7 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, in
             }
             lost = true;
         });
+        if (nc == 0) continue;                          // (a table slice: none of its cells is here)
         n_lost += lost ? 1u : 0u;
         ++n_stored;
         n_multi += nc > 1 ? 1u : 0u;
@@ -476,9 +486,14 @@ __global__ void cells_stash_kernel(const uint8_t* __restrict__ lines, int32_t k,
         const uint32_t c = cell_build_count(counts[i], presence);
         if (c == 0) continue;
         const uint64_t key = keys[i];
-        bool lost = cell_is_wide(c, presence);          // (counters wider than a cell's 16 bits; a cohort's: than its 8)
-        if (!lost)
-            record_cells(rp, i, key, k, lbits, both != 0, [&](const CellProbe& p, int) { lost |= cell_standing(lines, p, c, lbits, both != 0, cell_nw(k), presence, rp.regions) == STAND_NONE; });
+        const bool wide = cell_is_wide(c, presence);    // (counters wider than a cell's 16 bits; a cohort's: than its 8)
+        bool lost = false;
+        if (!wide || rp.slicing != 0)
+            record_cells(rp, i, key, k, lbits, both != 0, [&](const CellProbe& p, int) {
+                if (!rp.mine(p, lbits)) return;
+                lost |= wide || cell_standing(lines, p, c, lbits, both != 0, cell_nw(k), presence, rp.regions) == STAND_NONE;
+            });
+        else lost = true;
         if (!lost) continue;
         uint32_t slot = stash_slot(key, mask);
         for (;;) {
@@ -1290,7 +1305,8 @@ __device__ __forceinline__ u32x4n nt_load4(const void* p) {
 }
 
 struct CellWord {
-    uint64_t V;            // valid lanes
+    uint64_t V;            // valid lanes (a table slice: whose minimizer this slice holds)
+    uint64_t Vfull;        // valid lanes whatever the slice: the validity word of the bitmap
     uint32_t w, r;         // what this lane's cell must hold (CellProbe)
     uint32_t anc;          // 2 * cell index | (N is the reverse complement): what a queued k-mer needs to derive its probe again
     uint32_t r_alt;        // (k <= 30 only) what the r field of its free-cell entry must be (cell_alt_of)
@@ -1699,10 +1715,10 @@ __global__ __launch_bounds__(PLANNED ? CELLS_BLOCK : TEXT_BLOCK) __attribute__((
     int off;
     if constexpr (PLANNED) off = k31_load_plan_tile<CELLS_BLOCK>(sh, plan, td, K, tid);
     else off = k31_plan_tile_wave<K>(sh, s_scratch.rows, text, td, tid);
-#ifdef KCFX_EXP_PRIO
-    // (experiment: the waves that issue table loads go first, the planning waves of the same SIMD fill the issue slots they leave)
-    if constexpr (!PLANNED) __builtin_amdgcn_s_setprio(KCFX_EXP_PRIO);
-#endif
+    // From here on this wave issues table loads: it goes first, and the waves of the SIMD that are still planning their tiles
+    // (pure arithmetic, nothing in flight) fill the issue slots it leaves while it waits. Same-box A/B on the bench workload:
+    // 0.0880 - 0.0883 ms per launch against 0.0902 - 0.0913 without (profiles/r05_notes.md)
+    if constexpr (!PLANNED) __builtin_amdgcn_s_setprio(3);
 
     const int lane = tid & 63, wave = PLANNED ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
     const int n_words = (td.n_kmers + 63) >> 6;
@@ -1733,6 +1749,10 @@ __global__ __launch_bounds__(PLANNED ? CELLS_BLOCK : TEXT_BLOCK) __attribute__((
         uint32_t sh2, fm;
         words.next(w, N, sh2, fm, V);
         CellProbe p = cell_probe_planned<BOTH>(N, sh2, fm, tv.lbits, tv.ext);
+        cw.Vfull = V;
+        // (wave-uniform: the table is one slice of the database -- the k-mers whose minimizer another device holds are that
+        // device's to look up: no load, no hit, no queue entry here; the tiles' bitmaps are OR-ed afterwards)
+        if (tv.slices > 1) V &= wave_ballot(cell_slice_of(p.line, p.r, tv.lbits, (uint32_t)tv.slices) == (uint32_t)tv.slice);
         if (tv.regions > 1) p.line = cell_line_index(p.line, p.r, tv.lbits, tv.regions);    // (wave-uniform; from here on the line is only an address)
         cells_issue<cell_nw(K), BOTH>(tv, V, p, sh2 | (fm & 1u), cw);
     };
@@ -1743,7 +1763,7 @@ __global__ __launch_bounds__(PLANNED ? CELLS_BLOCK : TEXT_BLOCK) __attribute__((
         // cnt is 0 unless the k-mer was found at a valid position, and min_count >= 1 (checked by the API), so this is "found && count >= -c"
         const uint64_t H = wave_ballot((int32_t)cnt >= min_count);          // GetVariants.java:224 (valid positions only: cells_match)
         if (lane == 0) {
-            q.vw[w - w_begin] = cw.V;                                       // validity word of the window's bitmap
+            q.vw[w - w_begin] = cw.Vfull;                                   // validity word of the window's bitmap
             q.hit[w - w_begin] = H;                                         // hits so far; queued k-mers may add theirs
         }
         // GetVariants.java:226 (-c 1, the default: every found counter is a hit; wave-uniform)
@@ -2424,27 +2444,54 @@ hipError_t launch_cells_resolve(uint32_t* pop32, int32_t pop_bits, int32_t k, in
 }
 
 hipError_t launch_cells_insert(uint8_t* lines, const uint32_t* pop32, int32_t pop_bits, int32_t cls, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys,
-                               const uint32_t* counts, int64_t n, hipStream_t st, int32_t presence, const uint64_t* pw, const uint8_t* ps, int32_t ext, int32_t regions) {
+                               const uint32_t* counts, int64_t n, hipStream_t st, int32_t presence, const uint64_t* pw, const uint8_t* ps, int32_t ext, int32_t regions, int32_t slicing) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(cells_insert_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, pop32, pop_bits, cls, k, lbits, both, keys, counts, n, presence,
-                       RecProbes{pw, ps, ext, regions});
+                       RecProbes{pw, ps, ext, regions, slicing});
     return hipGetLastError();
 }
 
 size_t cells_pop_bytes(int32_t pop_bits) { return (size_t)1 << pop_bits; }
 
+// how many minimizers have c k-mers, c = 0 .. 255: the histogram of the build's crowding counters (one byte per minimizer), from
+// which kcfx_db_open estimates BEFORE the bids how many k-mers a plain table would leave outside their first-choice cells
+__global__ void pop_histogram_kernel(const uint32_t* __restrict__ pop32, int64_t n_words, unsigned long long* __restrict__ hist) {
+    __shared__ uint32_t h[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) h[i] = 0u;
+    __syncthreads();
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n_words; i += stride) {
+        const uint32_t w = pop32[i];
+        if (w == 0u) continue;                                  // (most minimizers of a 2^32 space are nobody's)
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t c = (w >> (8 * b)) & 0xFFu;
+            if (c) atomicAdd(&h[c], 1u);
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 256; j += blockDim.x)
+        if (h[j]) atomicAdd(&hist[j], (unsigned long long)h[j]);
+}
+hipError_t launch_pop_histogram(const uint32_t* pop32, int32_t pop_bits, unsigned long long* hist256, hipStream_t st) {
+    const int64_t n_words = (int64_t)(cells_pop_bytes(pop_bits) / 4);
+    hipLaunchKernelGGL(pop_histogram_kernel, dim3(4096), dim3(256), 0, st, pop32, n_words, hist256);
+    return hipGetLastError();
+}
+
+
 hipError_t launch_cells_settle(uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                               unsigned long long* stats, hipStream_t st, int32_t presence, const uint64_t* pw, const uint8_t* ps, int32_t ext, int32_t regions) {
+                               unsigned long long* stats, hipStream_t st, int32_t presence, const uint64_t* pw, const uint8_t* ps, int32_t ext, int32_t regions, int32_t slicing) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(cells_settle_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, k, lbits, both, keys, counts, n, stats, presence, RecProbes{pw, ps, ext, regions});
+    hipLaunchKernelGGL(cells_settle_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, k, lbits, both, keys, counts, n, stats, presence, RecProbes{pw, ps, ext, regions, slicing});
     return hipGetLastError();
 }
 
 hipError_t launch_cells_stash(const uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                              uint4* stash, uint32_t stash_mask, hipStream_t st, int32_t presence, const uint64_t* pw, const uint8_t* ps, int32_t ext, int32_t regions) {
+                              uint4* stash, uint32_t stash_mask, hipStream_t st, int32_t presence, const uint64_t* pw, const uint8_t* ps, int32_t ext, int32_t regions, int32_t slicing) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(cells_stash_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, k, lbits, both, keys, counts, n, stash,
-                       stash_mask, presence, RecProbes{pw, ps, ext, regions});
+                       stash_mask, presence, RecProbes{pw, ps, ext, regions, slicing});
     return hipGetLastError();
 }
 
@@ -2469,6 +2516,24 @@ hipError_t launch_reduce_windows(const TileDesc* tiles, int32_t n_tiles, int32_t
     const int wpb = REDUCE_BLOCK / 64;
     hipLaunchKernelGGL(reduce_windows_kernel, dim3((n_windows + wpb - 1) / wpb, n_samples), dim3(REDUCE_BLOCK), 0, st, tiles,
                        n_tiles, bits, count_sums, win_tile0, n_windows, k, out, shared_valid);
+    return hipGetLastError();
+}
+
+// Another table slice's results for the same tiles into these: the hit words OR-ed (a k-mer is looked up on exactly one slice),
+// the count sums added; the validity words are the same on both sides. One thread per 64-bit word of the hit half.
+__global__ void merge_partial_kernel(uint64_t* __restrict__ bits, int64_t* __restrict__ sums, const uint64_t* __restrict__ obits,
+                                     const int64_t* __restrict__ osums, int64_t n_tiles) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n_tiles * TILE_WORDS) return;
+    const int64_t tile = i / TILE_WORDS, w = i % TILE_WORDS;
+    const int64_t at = tile * TILE_BITS_U64 + TILE_WORDS + w;
+    bits[at] |= obits[at];
+    if (w == 0) sums[tile] += osums[tile];
+}
+hipError_t launch_merge_partial(uint64_t* bits, int64_t* sums, const uint64_t* obits, const int64_t* osums, int32_t n_tiles, hipStream_t st) {
+    if (n_tiles <= 0) return hipSuccess;
+    const int64_t n = (int64_t)n_tiles * TILE_WORDS;
+    hipLaunchKernelGGL(merge_partial_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bits, sums, obits, osums, (int64_t)n_tiles);
     return hipGetLastError();
 }
 
@@ -2571,7 +2636,7 @@ hipError_t launch_cohort_fill(TableView tv, int32_t k, int32_t both, const uint6
                               int32_t sample, uint8_t* cell_counts, uint16_t* stash_counts, hipStream_t st, const uint64_t* pw, const uint8_t* ps) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(cohort_fill_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, tv, k, both, keys, counts, n, sample,
-                       cell_counts, stash_counts, RecProbes{pw, ps, tv.ext, tv.regions});
+                       cell_counts, stash_counts, RecProbes{pw, ps, tv.ext, tv.regions, 0});
     return hipGetLastError();
 }
 

@@ -14,6 +14,11 @@
 //                        (kcfx_cohort_open: one look-up per reference k-mer for the eight); the group-major sequence of
 //                        (group, window) units is cut like the grid's. 8 samples on 8 devices: every device the same table and
 //                        an eighth of the windows; 32 samples: four tables, two devices each.
+//   table partitioned   : (KCFX_SHARD_TABLE, on request) every sample's TABLE is cut into G slices by minimizer (kcfx_db_open_slice);
+//                        device g holds slice g, screens the whole window list against it with the lanes of foreign minimizers
+//                        idle, the tiles' hit bitmaps are OR-ed on the first device (kcfx_ref_merge_from: a peer copy + one
+//                        small kernel -- the one exchange step on this path) and reduced there. For a database that a single
+//                        device can only hold densely (screen_table_sharded below).
 // Inside a worker the next sample's database is opened (file read, upload, table build) by a loader thread while the
 // current one is screened: at most two databases are resident per device, and a sample costs max(load, screen), not the sum.
 // Built on the public entry points only (kcfx_db_open / kcfx_ref_create / kcfx_screen_ref); HIP is never touched here.
@@ -24,6 +29,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -80,7 +86,11 @@ struct Worker {
 std::vector<std::vector<Segment>> plan_segments(int32_t mode, int32_t G, int32_t n_samples, const int32_t* win_len, int32_t n_windows,
                                                 int32_t kmer_length) {
     std::vector<std::vector<Segment>> plan((size_t)G);
-    if (mode == KCFX_SHARD_SAMPLES) {
+    if (mode == KCFX_SHARD_TABLE) {
+        // every device screens every sample's whole window list against ITS slice of that sample's table
+        for (int32_t g = 0; g < G; ++g)
+            for (int32_t s = 0; s < n_samples; ++s) plan[(size_t)g].push_back(Segment{s, 0, n_windows});
+    } else if (mode == KCFX_SHARD_SAMPLES) {
         for (int32_t g = 0; g < G; ++g)
             for (int32_t s = g; s < n_samples; s += G) plan[(size_t)g].push_back(Segment{s, 0, n_windows});
     } else if (mode == KCFX_SHARD_WINDOWS) {
@@ -143,6 +153,114 @@ std::vector<std::vector<Segment>> plan_segments(int32_t mode, int32_t G, int32_t
     return plan;
 }
 
+// KCFX_SHARD_TABLE: sample after sample, the sample's table in G slices on the G devices. Each device keeps ONE reference of the
+// whole window list for the call (planned once when several samples follow, text-only for one); per sample a thread per device
+// opens its slice, screens, closes; then the slices' bitmaps meet on the first device and are reduced there.
+int32_t screen_table_sharded(const std::vector<int32_t>& devices, const char* const* kmc_prefixes, int32_t n_samples, int32_t kmer_length,
+                             const uint8_t* text, int64_t text_len, const int64_t* win_begin, const int32_t* win_len, int32_t n_windows,
+                             int32_t min_kmer_count, kcfx_result* out, kcfx_shard_stats* stats) {
+    const int32_t G = (int32_t)devices.size();
+    if (G > KCFX_SLICES_MAX) return fail(KCFX_ERR_ARG, "KCFX_SHARD_TABLE: at most " + std::to_string(KCFX_SLICES_MAX) + " devices");
+    struct Dev {
+        kcfx_ref* ref = nullptr;
+        int32_t rc = KCFX_OK;
+        std::string error;
+        double t_ref = 0, t_open = 0, t_screen = 0;
+    };
+    std::vector<Dev> dev((size_t)G);
+    struct Cleanup {
+        std::vector<Dev>& d;
+        ~Cleanup() { for (auto& x : d) kcfx_ref_destroy(x.ref); }
+    } cleanup{dev};
+    auto in_parallel = [&](const std::function<void(int32_t)>& body) {
+        auto guarded = [&](int32_t g) {
+            try {
+                body(g);
+            } catch (...) {
+                dev[(size_t)g].rc = kcfx::exception_to_status("kcfx_screen_sharded (table slices)");
+                try { dev[(size_t)g].error = kcfx_last_error(); } catch (...) {}
+            }
+        };
+        if (G == 1) {
+            guarded(0);
+            return;
+        }
+        std::vector<std::thread> th;
+        th.reserve((size_t)G);
+        try {
+            for (int32_t g = 0; g < G; ++g) th.emplace_back(guarded, g);
+        } catch (...) {
+            dev[th.size()].rc = KCFX_ERR_HOST;
+            dev[th.size()].error = "could not start a worker thread";
+        }
+        for (auto& x : th) x.join();
+    };
+    auto first_error = [&]() -> int32_t {
+        for (int32_t g = 0; g < G; ++g)
+            if (dev[(size_t)g].rc != KCFX_OK) return fail(dev[(size_t)g].rc, "device " + std::to_string(devices[(size_t)g]) + " (slice " + std::to_string(g) + "): " + dev[(size_t)g].error);
+        return KCFX_OK;
+    };
+    int64_t queries = 0;
+    for (int32_t w = 0; w < n_windows; ++w) queries += std::max<int64_t>(0, (int64_t)win_len[w] - kmer_length + 1);
+    in_parallel([&](int32_t g) {
+        Dev& d = dev[(size_t)g];
+        const double t = now_s();
+        kcfx_ref_opts ro;
+        ro.expected_screens = n_samples == 1 ? 1 : 0;
+        ro.reserved = 0;
+        d.rc = kcfx_ref_create_opts(devices[(size_t)g], kmer_length, text, text_len, win_begin, win_len, n_windows, &ro, &d.ref);
+        if (d.rc) d.error = kcfx_last_error();
+        d.t_ref = now_s() - t;
+    });
+    if (int32_t rc = first_error()) return rc;
+    double t_merge = 0;
+    for (int32_t s = 0; s < n_samples; ++s) {
+        in_parallel([&](int32_t g) {
+            Dev& d = dev[(size_t)g];
+            kcfx_db_opts opts;
+            opts.expected_queries = std::max<int64_t>(1, queries);
+            opts.no_fallback = 1;
+            opts.reserved = 0;
+            kcfx_db* db = nullptr;
+            double t = now_s();
+            d.rc = kcfx_db_open_slice(kmc_prefixes[s], devices[(size_t)g], &opts, G, g, &db);
+            d.t_open += now_s() - t;
+            if (!d.rc) {
+                kcfx_db_info_t info;
+                kcfx_db_info(db, &info);
+                t = now_s();
+                if (info.kmer_length != kmer_length) {
+                    d.rc = KCFX_ERR_ARG;
+                    d.error = "Kmer size mismatch between the KMC databases";              // KCFHeader.equals (Cohort.java:71-119)
+                } else {
+                    d.rc = kcfx_screen_ref_partial(db, d.ref, min_kmer_count);
+                    if (d.rc) d.error = kcfx_last_error();
+                }
+                d.t_screen += now_s() - t;
+            } else {
+                d.error = kcfx_last_error();
+            }
+            kcfx_db_close(db);
+        });
+        if (int32_t rc = first_error()) return rc;
+        const double t = now_s();
+        for (int32_t g = 1; g < G; ++g)
+            if (int32_t rc = kcfx_ref_merge_from(dev[0].ref, dev[(size_t)g].ref)) return rc;
+        if (int32_t rc = kcfx_ref_finish(dev[0].ref, out + (size_t)s * n_windows)) return rc;
+        t_merge += now_s() - t;
+    }
+    if (stats) {
+        for (const Dev& d : dev) {
+            stats->seconds_ref = std::max(stats->seconds_ref, d.t_ref);
+            stats->seconds_db_open_sum += d.t_open;
+            stats->seconds_screen_sum += d.t_screen;
+            stats->seconds_exposed_load = std::max(stats->seconds_exposed_load, d.t_open);   // (nothing hides a slice's load here)
+        }
+        stats->seconds_screen_sum += t_merge;
+    }
+    return KCFX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -168,7 +286,7 @@ int32_t kcfx_shard_plan(int32_t shard_mode, int32_t n_devices, int32_t n_samples
                         int64_t cap, int64_t* n_segments, int32_t* mode_used) try {
     if (n_devices < 1 || n_samples < 0 || n_windows < 0 || kmer_length < 1 || !n_segments || (n_windows > 0 && !win_len))
         return fail(KCFX_ERR_ARG, "kcfx_shard_plan: bad argument");
-    if (shard_mode < KCFX_SHARD_AUTO || shard_mode > KCFX_SHARD_COHORT) return fail(KCFX_ERR_ARG, "unknown shard mode");
+    if (shard_mode < KCFX_SHARD_AUTO || shard_mode > KCFX_SHARD_TABLE) return fail(KCFX_ERR_ARG, "unknown shard mode");
     int32_t mode = shard_mode;
     if (mode == KCFX_SHARD_AUTO)
         mode = (n_samples >= n_devices || n_windows == 0) ? KCFX_SHARD_SAMPLES : (n_samples == 1 ? KCFX_SHARD_WINDOWS : KCFX_SHARD_GRID);
@@ -202,7 +320,7 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
         ((int64_t)n_samples * n_windows > 0 && !out))
         return fail(KCFX_ERR_ARG, "null argument");
     if (min_kmer_count < 1) return fail(KCFX_ERR_ARG, "Minimum kmer count should be at least 1");   // GetVariants.java:383-385
-    if (shard_mode < KCFX_SHARD_AUTO || shard_mode > KCFX_SHARD_COHORT) return fail(KCFX_ERR_ARG, "unknown shard mode");
+    if (shard_mode < KCFX_SHARD_AUTO || shard_mode > KCFX_SHARD_TABLE) return fail(KCFX_ERR_ARG, "unknown shard mode");
     for (int32_t s = 0; s < n_samples; ++s)
         if (!kmc_prefixes[s]) return fail(KCFX_ERR_ARG, "null database prefix");
     for (int32_t w = 0; w < n_windows; ++w)
@@ -219,6 +337,12 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
         stats->n_devices = G;
     }
     if (n_samples == 0 || n_windows == 0) return KCFX_OK;
+    if (mode == KCFX_SHARD_TABLE) {
+        const int32_t rc = screen_table_sharded(ctx->devices, kmc_prefixes, n_samples, kmer_length, text, text_len, win_begin, win_len, n_windows,
+                                                min_kmer_count, out, stats);
+        if (stats) stats->seconds_total = now_s() - t0;
+        return rc;
+    }
 
     std::vector<Worker> workers((size_t)G);
     {

@@ -30,6 +30,8 @@ ABI_SYMBOLS = (
     "kcfx_ref_reserve_multi",
     "kcfx_cohort_open", "kcfx_cohort_info", "kcfx_cohort_close", "kcfx_cohort_screen_ref", "kcfx_cohort_screen_ref_async",
     "kcfx_ctx_create", "kcfx_ctx_n_devices", "kcfx_ctx_destroy", "kcfx_screen_sharded", "kcfx_shard_plan",
+    "kcfx_db_open_slice", "kcfx_table_slice_of", "kcfx_screen_ref_partial_async", "kcfx_screen_ref_partial", "kcfx_ref_partial_bytes",
+    "kcfx_ref_export_partial_async", "kcfx_ref_merge_partial_async", "kcfx_ref_merge_from", "kcfx_ref_finish_async", "kcfx_ref_finish",
     "kcfx_score", "kcfx_windows",
     "kcfx_table_plan", "kcfx_prof_enable", "kcfx_prof_read", "kcfx_ref_plan_async", "kcfx_ref_is_planned", "kcfx_prof_read_plan", "kcfx_last_error", "kcfx_device_count", "kcfx_version",
 )
@@ -45,7 +47,8 @@ class DbInfo(C.Structure):
                 ("heavy_lines", C.c_int64), ("overflow_lines", C.c_int64),
                 ("table_format", C.c_int32), ("lut_suspect", C.c_int32), ("stored_kmers", C.c_int64),
                 ("stash_kmers", C.c_int64), ("stash_bytes", C.c_int64), ("multi_cell_kmers", C.c_int64),
-                ("second_choice_kmers", C.c_int64), ("extended", C.c_int32), ("regions", C.c_int32)]
+                ("second_choice_kmers", C.c_int64), ("extended", C.c_int32), ("regions", C.c_int32),
+                ("table_slices", C.c_int32), ("table_slice", C.c_int32)]
 
 
 class ShardStats(C.Structure):
@@ -54,7 +57,8 @@ class ShardStats(C.Structure):
                 ("seconds_exposed_load", C.c_double)]
 
 
-SHARD_AUTO, SHARD_SAMPLES, SHARD_WINDOWS, SHARD_GRID, SHARD_COHORT = 0, 1, 2, 3, 4
+SHARD_AUTO, SHARD_SAMPLES, SHARD_WINDOWS, SHARD_GRID, SHARD_COHORT, SHARD_TABLE = 0, 1, 2, 3, 4, 5
+SLICES_MAX = 64
 COHORT_MAX = 8
 
 
@@ -118,6 +122,17 @@ def lib() -> C.CDLL:
         L.kcfx_device_count.argtypes = [C.POINTER(i32)]
         L.kcfx_db_open.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
         L.kcfx_db_open_opts.argtypes = [C.c_char_p, i32, C.POINTER(DbOpts), C.POINTER(vp)]
+        L.kcfx_db_open_slice.argtypes = [C.c_char_p, i32, C.POINTER(DbOpts), i32, i32, C.POINTER(vp)]
+        L.kcfx_table_slice_of.argtypes = [C.c_uint32, i32, i32]
+        L.kcfx_screen_ref_partial_async.argtypes = [vp, vp, i32, vp]
+        L.kcfx_screen_ref_partial.argtypes = [vp, vp, i32]
+        L.kcfx_ref_partial_bytes.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+        L.kcfx_ref_partial_bytes.restype = i64
+        L.kcfx_ref_export_partial_async.argtypes = [vp, vp, vp, vp]
+        L.kcfx_ref_merge_partial_async.argtypes = [vp, vp, vp, vp]
+        L.kcfx_ref_merge_from.argtypes = [vp, vp]
+        L.kcfx_ref_finish_async.argtypes = [vp, vp, vp]
+        L.kcfx_ref_finish.argtypes = [vp, vp]
         L.kcfx_db_build.argtypes = [vp, vp, i64, i32, i32, i32, i32, C.POINTER(vp)]
         L.kcfx_db_info.argtypes = [vp, C.POINTER(DbInfo)]
         L.kcfx_db_header.argtypes = [C.c_char_p, C.POINTER(DbInfo)]
@@ -179,6 +194,12 @@ def table_plan(total_kmers: int, k: int, both_strands: bool = True, free_bytes: 
     return n.value, r.value
 
 
+def table_slice_of(g32: int, lbits: int, n_slices: int) -> int:
+    """kcfx_table_slice_of (host only): which of n_slices devices holds the cells of the minimizer whose first-choice line and r
+    are the 32 bits g32 in a table of 2^lbits lines per region; -1 on bad arguments."""
+    return int(lib().kcfx_table_slice_of(C.c_uint32(g32 & 0xFFFFFFFF), int(lbits), int(n_slices)))
+
+
 def device_count() -> int:
     n = C.c_int32(0)
     _check(lib().kcfx_device_count(C.byref(n)))
@@ -234,10 +255,16 @@ class KmcDb:
         _check(lib().kcfx_db_info(self._h, C.byref(self.info)))
 
     @classmethod
-    def open(cls, kmc_prefix: str, device: int = 0, expected_queries: int = 0, no_fallback: bool = False) -> "KmcDb":
-        """expected_queries = reference k-mers x passes this handle will serve (0 = unknown: the sparse, fastest table)."""
+    def open(cls, kmc_prefix: str, device: int = 0, expected_queries: int = 0, no_fallback: bool = False,
+             n_slices: int = 1, slice: int = 0) -> "KmcDb":
+        """expected_queries = reference k-mers x passes this handle will serve (0 = unknown: the sparse, fastest table).
+        n_slices > 1: the handle holds slice `slice` of the database's table (kcfx_db_open_slice): screened with
+        Reference.screen_partial, merged with Reference.merge_from / merge_partial_async, reduced by Reference.finish."""
         h = C.c_void_p()
-        if expected_queries or no_fallback:
+        if n_slices != 1:
+            opts = DbOpts(int(expected_queries), int(no_fallback), 0)
+            _check(lib().kcfx_db_open_slice(os.fsencode(kmc_prefix), device, C.byref(opts), int(n_slices), int(slice), C.byref(h)))
+        elif expected_queries or no_fallback:
             opts = DbOpts(int(expected_queries), int(no_fallback), 0)
             _check(lib().kcfx_db_open_opts(os.fsencode(kmc_prefix), device, C.byref(opts), C.byref(h)))
         else:
@@ -360,6 +387,38 @@ class Reference:
         handles = (C.c_void_p * max(len(dbs), 1))(*[C.cast(d._h, C.c_void_p).value for d in dbs])
         _check(lib().kcfx_screen_ref_multi_async(handles, len(dbs), self._h, min_count, C.c_void_p(out_device_ptr),
                                                  C.c_void_p(stream)))
+
+    # ---- a table partitioned over devices (KmcDb.open(..., n_slices, slice)) ----
+    def screen_partial(self, db: "KmcDb", min_count: int = 1) -> None:
+        """The screening kernel against one slice (or a whole table): the tiles' bitmaps and count sums stay in this reference."""
+        _check(lib().kcfx_screen_ref_partial(db._h, self._h, min_count))
+
+    def screen_partial_async(self, db: "KmcDb", stream: int = 0, min_count: int = 1) -> None:
+        _check(lib().kcfx_screen_ref_partial_async(db._h, self._h, min_count, C.c_void_p(stream)))
+
+    def merge_from(self, other: "Reference") -> None:
+        """another slice's results (a reference of the same text and windows, any device of this process) into this one's"""
+        _check(lib().kcfx_ref_merge_from(self._h, other._h))
+
+    def partial_bytes(self) -> tuple[int, int]:
+        b, c = C.c_int64(0), C.c_int64(0)
+        lib().kcfx_ref_partial_bytes(self._h, C.byref(b), C.byref(c))
+        return b.value, c.value
+
+    def export_partial_async(self, bitmaps_device_ptr: int, sums_device_ptr: int, stream: int = 0) -> None:
+        _check(lib().kcfx_ref_export_partial_async(self._h, C.c_void_p(bitmaps_device_ptr), C.c_void_p(sums_device_ptr), C.c_void_p(stream)))
+
+    def merge_partial_async(self, bitmaps_device_ptr: int, sums_device_ptr: int, stream: int = 0) -> None:
+        _check(lib().kcfx_ref_merge_partial_async(self._h, C.c_void_p(bitmaps_device_ptr), C.c_void_p(sums_device_ptr), C.c_void_p(stream)))
+
+    def finish(self) -> np.ndarray:
+        """reduce_windows over what this reference holds now (one slice's results, or the merged ones)"""
+        out = np.zeros(self.n_windows, dtype=RESULT_DTYPE)
+        _check(lib().kcfx_ref_finish(self._h, out.ctypes.data))
+        return out
+
+    def finish_async(self, out_device_ptr: int, stream: int = 0) -> None:
+        _check(lib().kcfx_ref_finish_async(self._h, C.c_void_p(out_device_ptr), C.c_void_p(stream)))
 
     def reserve_multi(self, n_samples: int) -> None:
         """Allocate the multi-sample scratch now (needed before capturing screen_multi_async into a HIP graph)."""

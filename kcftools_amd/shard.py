@@ -14,7 +14,12 @@ runs samples in separate processes) -- so there is NO data-path collective. Two 
                        8 samples on 8 ranks: every rank the same table and an eighth of the windows; 32 samples: four tables,
                        two ranks each. The plan is kcfx_shard_plan's (KCFX_SHARD_COHORT), host arithmetic inside libkcfx.
 
-The only exchange is the final gather of the 40-byte per-(window, sample) records to rank 0.
+  * table slices    : (on request, round 5) a database too large for one device at a density worth having: its TABLE is cut
+                       into one slice per rank by minimizer (kcfx_db_open_slice), every rank screens the whole window list
+                       against its slice, and the tiles' hit bitmaps (512 B per tile) + count sums meet on rank 0 -- the one
+                       data-path exchange of this engine: a gather of the partial results, OR / add, then ONE reduce_windows.
+
+Otherwise the only exchange is the final gather of the 40-byte per-(window, sample) records to rank 0.
 """
 from __future__ import annotations
 
@@ -97,3 +102,30 @@ def assemble_cohort_shards(parts: list[np.ndarray], segments: list[list[tuple[in
             at += m
         assert at == len(part)
     return out
+
+
+# ---- table slices: the partial results of a pass (kcfx_ref_export_partial_async) ------------------------------------------------
+TILE_WORDS = 32               # per tile: 32 validity words, then 32 hit words (kcfx_internal.h: TILE_BITS_U64 = 64)
+
+
+def gather_table_partials(bits, sums, dst: int = 0, group=None):
+    """Every rank's tile bitmaps (int64 tensor [n_tiles * 64]) and count sums (int64 [n_tiles]) to `dst`: lists of per-rank
+    tensors there, (None, None) elsewhere. Every rank screens the same tiles, so the sizes agree."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    gb = [torch.zeros_like(bits) for _ in range(world)] if rank == dst else None
+    gs = [torch.zeros_like(sums) for _ in range(world)] if rank == dst else None
+    dist.gather(bits, gb, dst=dst, group=group)
+    dist.gather(sums, gs, dst=dst, group=group)
+    return gb, gs
+
+
+def merge_table_partials(bits, sums, other_bits, other_sums):
+    """What kcfx_ref_merge_partial_async does on the device, in torch (the CPU tests' model and a fallback-free reference for the
+    GPU test): the hit words of `other` OR-ed into `bits`, its count sums added; validity words untouched. In place."""
+    b = bits.view(-1, 2 * TILE_WORDS)
+    b[:, TILE_WORDS:] |= other_bits.view(-1, 2 * TILE_WORDS)[:, TILE_WORDS:]
+    sums += other_sums
+    return bits, sums

@@ -37,17 +37,19 @@ def test_screening_kernels_do_not_spill_and_fit_their_occupancy(kernels):
     hot = {n: m for n, m in kernels.items() if re.search(r"screen_k31c_kernel|screen_k31_kernel|screen_k31_multi|screen_tiles_kernel|reduce_windows", n)}
     # k = 19 .. 31 x canonical / forward-only x planned / text-only reference, the line-table kernels, the general kernel, the reduction
     assert sum("screen_k31c_kernel" in n for n in hot) == 52 and len(hot) >= 62
+    text_only = lambda name: "screen_k31c_kernel" in name and name.endswith("Lb0EEEvPKhNS_7RefPlanEPKNS_8TileDescENS_9TableViewEiPmPl")
     for name, m in hot.items():
         assert m["private_segment_fixed_size"] == 0, (name, m)           # no scratch
-        # 8 waves per SIMD; the multi-sample line-table kernel is planned for 6 (amdgpu_waves_per_eu(6, 8): <= 80 VGPRs)
-        assert m["vgpr_count"] <= (80 if "screen_k31_multi" in name else 64), (name, m)
+        # 8 waves per SIMD (<= 64 VGPRs); the multi-sample line-table kernel is planned for 6 (amdgpu_waves_per_eu(6, 8): <= 80);
+        # the text-only form of the cell-table kernel (round 5: ONE wave per tile that plans 32-position strips, kcfx_plan.h, and
+        # then walks the tile's 32 words) for 7: <= 72 -- at 64 it spills, at 80 it loses a wave and 3 % (profiles/r05_notes.md)
+        assert m["vgpr_count"] <= (80 if "screen_k31_multi" in name else 72 if text_only(name) else 64), (name, m)
     for name, m in hot.items():
         if "screen_k31c_kernel" in name:
-            # 64 VGPRs = 8 waves per SIMD: four words of cell loads in flight per wave (52 - 59 registers). The text-only form
-            # (KCFX_REF_PLAN=0: every tile planned inside the launch, kcfx_plan.h) carries the planner's exchange rows in LDS on
-            # top (a union with the queues): 12 KB per workgroup of two waves = 13 workgroups per CU, 6.5 waves per SIMD
-            text_only = name.endswith("Lb0EEEvPKhNS_7RefPlanEPKNS_8TileDescENS_9TableViewEiPmPl")
-            assert m["vgpr_count"] <= 64 and m["group_segment_fixed_size"] <= (12288 if text_only else 8192), (name, m)
+            # planned reference: two waves per workgroup, 4.8 KB of LDS (codes both ways, anchors, queues) -- 16 workgroups per CU.
+            # text-only: one wave per workgroup, the planner's exchange rows UNDER the codes, anchors and queue: 4.3 KB -- 28
+            # workgroups (7 waves per SIMD) take 120 KB of a CU's 160
+            assert m["group_segment_fixed_size"] <= (4608 if text_only(name) else 5120), (name, m)
         elif "screen_" in name:
             assert m["group_segment_fixed_size"] <= 20480, (name, m)     # 160 KB LDS per CU / 8 workgroups
 

@@ -803,3 +803,35 @@ def test_planned_reference_at_the_text_lengths_where_its_arrays_end(oracle, tmp_
         got = db.screen(text, begins, lens, 1)
         want = odb.screen(text, begins, lens, 1, threads=2)
         assert_same(got, want, f"text of {L} bases")
+
+
+def test_every_load_tier_builds_the_same_table(oracle, tmp_path, monkeypatch):
+    """kcfx_db_open keeps between its build passes what fits: the decoded records and their cells (21 B per k-mer), the decoded
+    records (12 B), the records as the file holds them (record_size B, decoded again per pass: round 5, what a wheat-scale
+    database gets), or nothing (the file streamed once per pass). Which tier ran must not show: the same table statistics,
+    KMC.getCount and windows from all four, for a plain table and for a forced extended one, 2- and 4-byte counters (odd record
+    sizes: 7 and 10 bytes per record here)."""
+    k = 31
+    ref = synth.random_reference(400_000, 77, n_run_every=50_000, max_n_run=600)
+    s, e = engine.windows(len(ref), 10_000, 0, k)
+    for name, cs, p in (("a", 2, 3), ("b", 4, 7)):
+        prefix, kmers, counts, _ = make_db(tmp_path, name, ref, 300 + cs, k=k, p=p, cs=cs, m=7, bins=5, noise=30_000)
+        want = oracle.OracleDb(prefix).screen(ref, s, e - s, 1, threads=4)
+        pick = np.random.default_rng(1).choice(len(kmers), 5_000, replace=False)
+        for ext in ("0", "1"):
+            monkeypatch.setenv("KCFX_TABLE_EXT", ext)
+            stats = {}
+            for tier, env in (("probes", {}), ("decoded", {"KCFX_LOAD_NO_PROBES": "1"}), ("raw", {"KCFX_LOAD_RAW": "1"}),
+                              ("streamed", {"KCFX_LOAD_STREAM_TWICE": "1"})):
+                for kk, v in env.items():
+                    monkeypatch.setenv(kk, v)
+                db = engine.KmcDb.open(prefix)
+                for kk in env:
+                    monkeypatch.delenv(kk)
+                i = db.info
+                stats[tier] = (int(i.table_lines), int(i.stored_kmers), int(i.multi_cell_kmers), int(i.extended))     # (which loser finds an empty second-line cell first is a race: not compared)
+                assert_same(db.screen(ref, s, e - s, 1), want, f"{name} ext={ext} tier={tier}")
+                assert np.array_equal(db.lookup(kmers[pick]), counts[pick].astype(np.int32)), (name, ext, tier)
+                db.close()
+            assert len(set(stats.values())) == 1, stats
+        monkeypatch.delenv("KCFX_TABLE_EXT")

@@ -171,3 +171,95 @@ def test_cohort_tables_across_devices(oracle, tmp_path_factory, devices):
         assert st3.shard_mode_used == engine.SHARD_COHORT
         for i, p in enumerate(mixed):
             assert_same(got3[i], engine.KmcDb.open(p).screen(ref, begins, lens, 3), f"mixed counter widths, sample {i}")
+
+
+@pytest.mark.parametrize("devices", [(0,), (0, 0), (0, 0, 0), (0,) * 5])
+def test_table_partitioned_over_devices(oracle, job, devices):
+    """KCFX_SHARD_TABLE: every sample's table in len(devices) slices by minimizer (here: on one GPU), every slice screened against
+    the whole window list, the tiles' bitmaps merged and reduced once == the unsharded call == the oracle. Canonical and
+    forward-only databases, 1- / 2- / 4-byte counters (wide counters live in the slices' stashes), gene-like windows."""
+    k, ref, prefixes, begins, lens, want = job
+    got, st = engine.screen_sharded(prefixes, k, ref, begins, lens, 1, devices=devices, mode=engine.SHARD_TABLE)
+    assert st.shard_mode_used == engine.SHARD_TABLE and st.n_devices == len(devices)
+    for i in range(len(prefixes)):
+        assert_same(got[i], want[i], f"sample {i}, table slices on {devices}")
+    assert_same(got[3], oracle.OracleDb(prefixes[3]).screen(ref, begins, lens, 1, threads=4), "forward-only sample vs oracle")
+    got2, _ = engine.screen_sharded(prefixes[:2], k, ref, begins, lens, 3, devices=devices, mode=engine.SHARD_TABLE)
+    for i in range(2):
+        assert_same(got2[i], engine.KmcDb.open(prefixes[i]).screen(ref, begins, lens, 3), "-c 3")
+
+
+def test_table_slices_piece_by_piece(oracle, job, tmp_path):
+    """The entry points behind KCFX_SHARD_TABLE one by one: kcfx_db_open_slice (the slices hold every stored k-mer exactly once, up
+    to the few with several first-choice cells; a look-up finds a k-mer on the slice that holds it), kcfx_screen_ref_partial on a
+    planned and on a text-only reference, merge through another reference handle and through exported device buffers (what an RCCL
+    gather carries; the torch model of the merge beside the kernel), kcfx_ref_finish. Whole-table entry points refuse a slice."""
+    import torch
+    from kcftools_amd import shard
+    k, ref, prefixes, begins, lens, want = job
+    for pi in (0, 2, 3):                                       # 2-byte canonical, 4-byte counters, forward-only
+        prefix = prefixes[pi]
+        whole = engine.KmcDb.open(prefix)
+        n = 3
+        slices = [engine.KmcDb.open(prefix, n_slices=n, slice=i) for i in range(n)]
+        infos = [d.info for d in slices]
+        assert all(i.table_slices == n and i.table_slice == j and i.table_format == 1 for j, i in enumerate(infos))
+        stored = sum(int(i.stored_kmers) for i in infos)
+        assert whole.info.stored_kmers <= stored <= whole.info.stored_kmers + 2 * whole.info.multi_cell_kmers + 4
+        assert max(int(i.stored_kmers) for i in infos) < 0.45 * whole.info.stored_kmers      # thirds, roughly
+        assert all(i.table_lines < whole.info.table_lines or whole.info.table_lines <= (1 << 18) for i in infos)
+        # KMC.getCount through the slices: a present k-mer is found on (at least) one, an absent one nowhere
+        if pi == 0:
+            lp, kmers, counts, _ = make_db(tmp_path, "lookup", ref, 900, k=k, p=3, cs=2, m=7, bins=4, both=True, noise=4_000)   # (sample 0 again: its k-mers)
+            absent = np.random.default_rng(4).integers(0, 1 << 62, 5_000, dtype=np.uint64) << np.uint64(2)
+            absent = np.minimum(absent, synth.revcomp(absent, k))
+            keys = np.concatenate([kmers[np.random.default_rng(3).choice(len(kmers), min(20_000, len(kmers)), replace=False)], absent])
+            full = whole.lookup(keys)
+            per = np.stack([d.lookup(keys) for d in slices])
+            assert np.array_equal(per.max(0), full)                                # found where it is held, with its counter
+            assert np.all((per != 0).sum(0) >= (full != 0)) and np.all((per != 0).sum(0)[full == 0] == 0)
+            assert ((per != 0).sum(0) > 1).mean() < 1e-3                           # several slices only for tied minimizers
+        for planned in (True, False):
+            refs = [engine.Reference(ref, begins, lens, k, expected_screens=0 if planned else 1) for _ in range(n)]
+            assert refs[0].planned == planned
+            for r, d in zip(refs, slices):
+                r.screen_partial(d, 1)
+            # one slice alone is a subset of the hits
+            alone = refs[1].finish()
+            assert np.all(alone["obs"] <= want[pi]["obs"]) and np.array_equal(alone["total_kmers"], want[pi]["total_kmers"])
+            # (a) through exported device buffers, merged by the kernel and by the torch model
+            nb, ns = refs[0].partial_bytes()
+            bufs = []
+            for r in refs:
+                b = torch.zeros(nb // 8, dtype=torch.int64, device="cuda:0")
+                c = torch.zeros(ns // 8, dtype=torch.int64, device="cuda:0")
+                r.export_partial_async(b.data_ptr(), c.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                bufs.append((b, c))
+            torch.cuda.synchronize()
+            mb, mc = bufs[0][0].clone(), bufs[0][1].clone()
+            for b, c in bufs[1:]:
+                shard.merge_table_partials(mb, mc, b, c)
+            # (b) in place, through the other handles
+            refs[0].merge_from(refs[1])
+            refs[0].merge_from(refs[2])
+            assert_same(refs[0].finish(), want[pi], f"slices merged handle to handle (sample {pi}, planned={planned})")
+            eb = torch.zeros_like(mb)
+            ec = torch.zeros_like(mc)
+            refs[0].export_partial_async(eb.data_ptr(), ec.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert torch.equal(eb, mb) and torch.equal(ec, mc)               # kernel merge == torch model
+            # (c) the exported buffers of slices 0 and 2 into slice 1's reference (any order)
+            refs[1].merge_partial_async(bufs[2][0].data_ptr(), bufs[2][1].data_ptr(), torch.cuda.current_stream().cuda_stream)
+            refs[1].merge_partial_async(bufs[0][0].data_ptr(), bufs[0][1].data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert_same(refs[1].finish(), want[pi], "slices merged from exported buffers")
+        # a slice is not a database: the whole-table entry points say so
+        with pytest.raises(engine.KcfxError) as ei:
+            refs[0].screen(slices[0], 1)
+        assert ei.value.code == 1 and "slice" in str(ei.value)
+        with pytest.raises(engine.KcfxError):
+            slices[0].screen(ref, begins, lens, 1)
+    with pytest.raises(engine.KcfxError):
+        engine.KmcDb.open(prefixes[0], n_slices=3, slice=3)
+    with pytest.raises(engine.KcfxError):
+        engine.KmcDb.open(prefixes[0], n_slices=65, slice=0)

@@ -127,3 +127,77 @@ def test_window_ranges_partition_and_balance():
             assert max(per) <= 1.05 * (sum(per) / world) + int(work.max())
     assert shard.samples_of_rank(8, 8, 3) == [3] and shard.samples_of_rank(32, 8, 7) == [7, 15, 23, 31]
     assert shard.samples_of_rank(3, 8, 5) == []
+
+
+# ---- table slices: the one data-path exchange (shard.gather_table_partials + merge_table_partials) -------------------------------
+def _table_partials(world, n_tiles=53, seed=19):
+    """What `world` slices of a table would hold after a pass over n_tiles tiles: the same validity words everywhere, every hit bit
+    on exactly one slice (a k-mer's minimizer belongs to one), count sums that add up. Returns (valid, hits, per-rank hit words,
+    per-rank sums)."""
+    rng = np.random.default_rng(seed)
+    W = shard.TILE_WORDS
+    valid = rng.integers(0, 1 << 63, (n_tiles, W), dtype=np.int64) | rng.integers(0, 1 << 63, (n_tiles, W), dtype=np.int64)
+    hits = valid & rng.integers(0, 1 << 63, (n_tiles, W), dtype=np.int64)
+    owner = rng.integers(0, world, (n_tiles, W, 63))                          # which slice holds the minimizer of each position
+    bit = (np.int64(1) << np.arange(63, dtype=np.int64))
+    per_hits = [((hits[:, :, None] & bit) * (owner == r)).sum(-1).astype(np.int64) for r in range(world)]
+    per_sums = [rng.integers(0, 1 << 40, n_tiles, dtype=np.int64) for _ in range(world)]
+    return valid, hits, per_hits, per_sums
+
+
+def table_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    valid, hits, per_hits, per_sums = _table_partials(world)
+    bits = torch.from_numpy(np.concatenate([valid, per_hits[rank]], axis=1).reshape(-1).copy())     # per tile: 32 validity, 32 hit words
+    sums = torch.from_numpy(per_sums[rank].copy())
+    gb, gs = shard.gather_table_partials(bits, sums, dst=0)
+    if rank == 0:
+        mb, mc = gb[0].clone(), gs[0].clone()
+        for b, c in zip(gb[1:], gs[1:]):
+            shard.merge_table_partials(mb, mc, b, c)
+        q.put((mb.numpy().copy(), mc.numpy().copy()))
+    else:
+        assert gb is None and gs is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_table_slices_meet_on_rank_zero(world):
+    """bench.py --shard table / a job with one process per GPU: every rank screens the whole window list against ITS slice of the
+    table, the tiles' bitmaps and count sums are gathered to rank 0 (RCCL on GPUs, gloo here) and merged -- hits OR-ed, sums added,
+    validity words as they were -- before the one reduce_windows. (On the GPU the merge is kcfx_ref_merge_partial_async;
+    tests/test_gpu_sharded.py checks that kernel against this torch model.)"""
+    import queue as _queue
+    import time
+    ctx = mp.get_context("spawn")
+    got = None
+    for attempt in range(2):
+        q = ctx.Queue()
+        port = free_port()
+        procs = [ctx.Process(target=table_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        deadline = time.time() + 240
+        while got is None and time.time() < deadline:
+            try:
+                got = q.get(timeout=2)
+            except _queue.Empty:
+                if any(p.exitcode not in (None, 0) for p in procs):
+                    break
+        for p in procs:
+            p.join(timeout=90 if got is not None else 1)
+            if p.is_alive():
+                p.kill()
+                p.join()
+        if got is not None:
+            assert all(p.exitcode == 0 for p in procs)
+            break
+    assert got is not None, "multi-rank run did not produce a result"
+    valid, hits, per_hits, per_sums = _table_partials(world)
+    bits, sums = got
+    bits = bits.reshape(-1, 2 * shard.TILE_WORDS)
+    assert np.array_equal(bits[:, :shard.TILE_WORDS], valid) and np.array_equal(bits[:, shard.TILE_WORDS:], hits)
+    assert np.array_equal(sums, np.sum(per_sums, axis=0))

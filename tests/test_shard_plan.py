@@ -98,3 +98,28 @@ def test_cohort_mode_shapes_of_the_baseline_configs():
         assert max(len({s for d, s, *_ in plan if d == g}) for g in range(G)) <= tables_per_dev, (S, G)
     plan, _ = engine.shard_plan(np.full(1000, 10_000, dtype=np.int32), K, 8, 8, engine.SHARD_COHORT)
     assert sorted(plan) == [(g, 0, 125 * g, 125 * (g + 1)) for g in range(8)]
+
+
+def test_table_mode_gives_every_device_every_sample_and_the_slices_partition_the_minimizers():
+    """KCFX_SHARD_TABLE: the TABLE is cut, not the work list -- every device screens every (sample, window) pair against its slice
+    of that sample's table, and every minimizer (the 32 bits that name a first-choice line and r) belongs to exactly one slice."""
+    wl = np.array([10_000, 50, 31, 0, 7_000] * 40, dtype=np.int32)
+    for S, G in ((1, 4), (3, 2), (2, 8)):
+        plan, used = engine.shard_plan(wl, K, S, G, engine.SHARD_TABLE)
+        assert used == engine.SHARD_TABLE and len(plan) == S * G
+        assert np.all(coverage(plan, S, len(wl)) == G)                      # once per device
+        assert sorted(plan) == sorted((g, s, 0, len(wl)) for g in range(G) for s in range(S))
+    assert engine.shard_plan(wl, K, 5, 5)[1] != engine.SHARD_TABLE         # never chosen by AUTO
+    rng = np.random.default_rng(11)
+    g32 = rng.integers(0, 1 << 32, 200_000, dtype=np.uint64)
+    for n in (1, 2, 3, 4, 7, 8, 64):
+        sl = np.array([engine.table_slice_of(int(g), 27, n) for g in g32[:20_000]])
+        assert sl.min() >= 0 and sl.max() < n and len(np.unique(sl)) == n
+        cnt = np.bincount(sl, minlength=n)
+        assert cnt.max() <= 1.25 * cnt.mean() + 40, cnt                     # even within sampling noise
+    # a function of the 32 bits alone, whatever the table's size says about which of them are the line (same bits, same slice)
+    assert all(engine.table_slice_of(int(g), 24, 4) == engine.table_slice_of(int(g), 29, 4) for g in g32[:2000])
+    # the k-mers of one line do not sit on one slice (the line number alone does not decide)
+    line = 0x5A5A5 << 12
+    assert len({engine.table_slice_of(line | r, 20, 4) for r in range(4096)}) == 4
+    assert engine.table_slice_of(1, 27, 0) == -1 and engine.table_slice_of(1, 27, 65) == -1 and engine.table_slice_of(1, 5, 4) == -1
