@@ -264,6 +264,77 @@ def cache_state_leg(engine, torch, prefix, ref, db, out_ptr, stream, min_count, 
     return res
 
 
+def realistic_leg(engine, torch, synth_bin, workdir, ref_len, window, min_count, device, threads, launches=100):
+    """Inputs that look like data, beside the uniform-noise database of the headline (every one on the chr1-sized reference, every
+    window of every one against the oracle):
+      read_error_db  a database as `kmc -ci1` writes it from reads (README.md:171-177): the sample genome's k-mers + ~5 x as many
+                     count-1 k-mers in runs around substitution errors, which share minimizers and cells with their originals;
+      k25            KMC's default k (W = 10 of a line's 16 cells: shorter minimizer runs, more lines per k-mer);
+      repeats        reference and sample with genome structure (TE families, satellite arrays, segmental duplications,
+                     microsatellites: kcfx_synth --repeats 0.3): crowded minimizers.
+    Per input: the screening kernel's average (HIP events on the launch) of the one-pass form (text-only reference, K1 - K3 in one
+    launch) and of the amortised form (planned reference), as fractions of the HBM roofline at 1 + 8 + counter_size bytes per k-mer."""
+    from oracle import binding as oracle
+    out = {}
+    cases = (("read_error_db", 31, 7, ["--error-events", "4500000", "--noise", "0"]),
+             ("k25", 25, 5, ["--noise", str(max(0, 150_000_000 - int(0.885 * ref_len)))]),
+             ("repeats", 31, 7, ["--repeats", "0.3", "--noise", str(max(0, 150_000_000 - int(0.885 * ref_len)))]))
+    for name, k, p, extra in cases:
+        try:
+            prefix = os.path.join(workdir, f"real_{name}_r{ref_len}")
+            if not os.path.exists(prefix + ".meta.json"):
+                cmd = [synth_bin, "--out", prefix, "--ref-len", str(ref_len), "--seed", "1", "--sample-seed", "2", "--k", str(k), "--p", str(p),
+                       "--cs", str(COUNTER_SIZE), "--bins", "512", "--threads", str(threads)] + extra
+                meta = json.loads(subprocess.run(cmd, check=True, capture_output=True, text=True).stdout.strip().splitlines()[-1])
+                json.dump(meta, open(prefix + ".meta.json", "w"))
+            meta = json.load(open(prefix + ".meta.json"))
+            text = np.fromfile(prefix + ".ref.txt", dtype=np.uint8).tobytes()
+            starts, ends = engine.windows(len(text), window, 0, k)
+            wb, wl = starts.astype(np.int64), (ends - starts).astype(np.int32)
+            stream = torch.cuda.current_stream().cuda_stream
+            res = {}
+            rec = None
+            for form, screens in (("one_pass", 1), ("amortised", 0)):
+                ref = engine.Reference(text, wb, wl, k, device=device, expected_screens=screens)
+                db = engine.KmcDb.open(prefix, device=device, expected_queries=int(ref.n_kmer_slots))
+                o = torch.zeros(len(wb) * 10, dtype=torch.int32, device=f"cuda:{device}")
+                for _ in range(5):
+                    ref.screen_async(db, o.data_ptr(), stream, min_count)
+                torch.cuda.synchronize()
+                ref.prof_enable(True)
+                ref.prof_read(reset=True)
+                for _ in range(launches):
+                    ref.screen_async(db, o.data_ptr(), stream, min_count)
+                torch.cuda.synchronize()
+                ms, n = ref.prof_read(reset=True)
+                r = o.cpu().numpy().view(engine.RESULT_DTYPE)[:len(wb)].copy()
+                nk = int(r["total_kmers"].sum())
+                res[form] = {"kernel_avg_ms": ms / max(1, n), "frac": nk * B_ALG / (ms / max(1, n) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                if rec is None:
+                    rec = r
+                    info = db.info
+                    res["table"] = {"lines": int(info.table_lines), "kmers_per_cell": float(info.stored_kmers) / max(1, 16 * int(info.table_lines)),
+                                    "stash_share": float(info.stash_kmers) / max(1, int(info.stored_kmers)),
+                                    "outside_first_choice_share": float(info.second_choice_kmers + info.stash_kmers) / max(1, int(info.stored_kmers)),
+                                    "extended": int(info.extended)}
+                else:
+                    res["forms_identical"] = bool(all(np.array_equal(r[f], rec[f]) for f in engine.INT_FIELDS))
+                ref.close()
+                db.close()
+                del o
+            want = oracle.OracleDb(prefix).screen(text, wb, wl, min_count, threads=threads)
+            res["parity"] = {"windows_checked": int(len(wb)), "bit_exact": bool(all(np.array_equal(rec[f], want[f]) for f in engine.INT_FIELDS))}
+            res["kmers_per_pass"] = int(rec["total_kmers"].sum())
+            res["hit_rate"] = float(rec["obs"].sum() / max(1, rec["total_kmers"].sum()))
+            res["db_kmers"] = int(meta["db_kmers"])
+            res["k"] = k
+            out[name] = res
+        except Exception as exc:                     # the bench line must not die on an extra leg
+            out[name] = {"error": str(exc)[:300]}
+    engine.release_cached()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -284,12 +355,15 @@ def main():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=5.0,
                     help="wall seconds per thread count of the CPU baseline leg (T = 1, 16, 64, all; 0 = skip)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the FASTA -> KCF command-line run")
+    ap.add_argument("--no-realistic", action="store_true",
+                    help="skip the inputs that look like data (read-error database, k = 25, repeat-structured genome: ~1 min of generation, "
+                         "opens and oracle checks)")
     ap.add_argument("--no-cache-state", action="store_true", help="skip the hot / swept / first-pass launches of the cache_state leg")
     ap.add_argument("--min-count", type=int, default=1)
-    ap.add_argument("--spin-ms", type=float, default=0.0,
-                    help="0 (default): the line's figures are those of the W requested warm-up steps + K timed steps, nothing else. "
-                         "> 0: after them, a clock ramp -- untimed repetitions of the step for this long -- and the K steps once more: "
-                         "reported beside as \"ramped\" (its warm-up count stated there), never as the headline")
+    ap.add_argument("--spin-ms", type=float, default=60.0,
+                    help="the line's own figures (value, ms_per_step, roofline) are ALWAYS those of the W requested warm-up steps + K timed "
+                         "steps. After them, when this is > 0: a clock ramp -- untimed repetitions of the step for this long -- and the K steps "
+                         "once more, reported beside as \"ramped\" (its warm-up count stated there), never as the headline; 0 = skip")
     ap.add_argument("--step", choices=("one-pass", "two-launch", "amortised"), default="one-pass",
                     help="one-pass (default): K1 - K3 of ONE sample against a reference the way the product runs it -- the reference "
                          "resident as TEXT (kcfx_ref_opts.expected_screens = 1: what the command-line driver and kcfx_screen_sharded "
@@ -750,6 +824,15 @@ def main():
         except Exception as exc:
             box = {"error": str(exc)[:200]}
 
+    # ---- inputs that look like data (after the handles of the headline are gone: each case opens a 17 GB table of its own) ----
+    realistic = None
+    if world == 1 and S == 1 and cohort is None and not args.no_realistic:
+        for d_ in dbs:
+            d_.close()
+        ref.close()
+        engine.release_cached()
+        realistic = realistic_leg(engine, torch, synth_bin, args.workdir, args.ref_len, args.window, args.min_count, local_rank, ncpu)
+
     jvm = jvm_probe()
     java_leg = None
     if world == 1 and S == 1:
@@ -772,6 +855,7 @@ def main():
         "forms_identical": forms_same,
         "ramped": ramped,
         "cache_state": cache_state,
+        "realistic": realistic,
         "higher_is_better": True,
         "scaling": "strong" if (window_sharded or table_sharded) else "weak",
         "vs_baseline": None,

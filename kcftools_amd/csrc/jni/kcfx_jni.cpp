@@ -230,6 +230,43 @@ JNIEXPORT void JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_cohortScreenRef(JNIE
     if (int32_t rc = kcfx_cohort_screen_ref(co, r, minKmerCount, out)) throw_kcfx(env, rc);
 }
 
+// ---- a table partitioned over devices (kcfx_db_open_slice; include/kcfx.h) -------------------------------------------------------
+// long dbOpenSlice(String kmcPrefix, int device, long expectedQueries, int nSlices, int slice)
+JNIEXPORT jlong JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_dbOpenSlice(JNIEnv* env, jclass, jstring prefix, jint device, jlong expectedQueries,
+                                                                         jint nSlices, jint slice) {
+    if (!prefix) { throw_kcfx(env, KCFX_ERR_ARG); return 0; }
+    const char* p = env->GetStringUTFChars(prefix, nullptr);
+    if (!p) return 0;
+    kcfx_db* db = nullptr;
+    kcfx_db_opts opts;
+    opts.expected_queries = expectedQueries;
+    opts.no_fallback = 1;
+    opts.reserved = 0;
+    const int32_t rc = kcfx_db_open_slice(p, device, &opts, nSlices, slice, &db);
+    env->ReleaseStringUTFChars(prefix, p);
+    if (rc) { throw_kcfx(env, rc); return 0; }
+    return reinterpret_cast<jlong>(db);
+}
+// void screenRefPartial(long db, long ref, int minKmerCount): this slice's hits into the reference's tile bitmaps (synchronous)
+JNIEXPORT void JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_screenRefPartial(JNIEnv* env, jclass, jlong db, jlong ref, jint minKmerCount) {
+    if (int32_t rc = kcfx_screen_ref_partial(reinterpret_cast<kcfx_db*>(db), reinterpret_cast<kcfx_ref*>(ref), minKmerCount)) throw_kcfx(env, rc);
+}
+// void refMergeFrom(long dst, long src): another slice's bitmaps (a reference of the same text and windows, any device) into dst's
+JNIEXPORT void JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_refMergeFrom(JNIEnv* env, jclass, jlong dst, jlong src) {
+    if (int32_t rc = kcfx_ref_merge_from(reinterpret_cast<kcfx_ref*>(dst), reinterpret_cast<kcfx_ref*>(src))) throw_kcfx(env, rc);
+}
+// void refFinish(long ref, ByteBuffer results): the window records of what ref's bitmaps hold now; results = nWindows * 40 bytes
+JNIEXPORT void JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_refFinish(JNIEnv* env, jclass, jlong ref, jobject results) {
+    kcfx_ref* r = reinterpret_cast<kcfx_ref*>(ref);
+    auto* out = results ? static_cast<kcfx_result*>(env->GetDirectBufferAddress(results)) : nullptr;
+    if (!r || !out || env->GetDirectBufferCapacity(results) < (jlong)kcfx_ref_n_windows(r) * (jlong)sizeof(kcfx_result)) {
+        jclass cls = env->FindClass("java/lang/IllegalArgumentException");
+        if (cls) env->ThrowNew(cls, "results must be a direct buffer of nWindows * 40 bytes");
+        return;
+    }
+    if (int32_t rc = kcfx_ref_finish(r, out)) throw_kcfx(env, rc);
+}
+
 // int[] dbHeader(String kmcPrefix): the dbInfo fields from the header alone, no GPU (KMC.java:107-168; GetVariants.java:96,103)
 JNIEXPORT jintArray JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_dbHeader(JNIEnv* env, jclass, jstring prefix) {
     if (!prefix) { throw_kcfx(env, KCFX_ERR_ARG); return nullptr; }

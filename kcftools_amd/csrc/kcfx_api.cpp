@@ -128,6 +128,7 @@ struct kcfx_db {
     int32_t alloc_rc = KCFX_OK;          // written by alloc_thread, read after the join
     std::string alloc_error;
     bool alloc_oom = false;
+    std::atomic<bool> alloc_landed{false};   // alloc_thread: the table's memory has been taken (hipMemGetInfo no longer counts it as free)
     bool table_arrived = false;          // table_ready() has succeeded: a later device error is not about the table's size
     int32_t fmt = FORMAT_LINES;          // FORMAT_CELLS: d_lines holds 1 << lbits cell lines, d_stash the overflow k-mers
     int32_t lbits = 0;
@@ -138,6 +139,7 @@ struct kcfx_db {
     uint32_t* d_pop = nullptr;               // FORMAT_CELLS build scratch: k-mers per minimizer (freed after the build)
     int32_t pop_bits = 32;                   // 2^pop_bits byte counters: 32 = one per minimizer, lbits + 2 when 4 GiB cannot be had
     hipStream_t stream = nullptr;
+    uint32_t* touch_sink = nullptr;          // (see the end of kcfx_db_open_slice)
     int32_t n_slices = 1, slice = 0;         // kcfx_db_open_slice: the table holds slice `slice` of `n_slices` of the database (cell_slice_of)
     int32_t slicing() const { return n_slices > 1 ? (n_slices << 8 | slice) : 0; }
     TableView view() const { return TableView{d_lines, n_lines, wide, mode, mm_len, fmt, lbits, stash_mask, d_stash, generic, info.both_strands, ext, regions, n_slices, slice}; }
@@ -400,6 +402,7 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys, bool deferred = false) {
     if (db->line_footprint == LINE_BYTES && db->lbits_cap == 0) cells_regions(n_keys, db->info.kmer_length, both, L0, free_b, &R, &Lr);
     db->alloc_rc = KCFX_OK;
     db->alloc_oom = false;
+    db->alloc_landed = false;
     db->table_arrived = false;
     if (deferred && Lr >= cell_lbits_min(both) && (double)n_keys <= 16.0 * (double)((uint64_t)R << Lr)) {
         // the policy's size, allocated and cleared beside the file streaming; if it does not fit, kcfx_db_open starts over
@@ -417,6 +420,7 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys, bool deferred = false) {
             try {
                 hipError_t e2 = hipSetDevice(db->device);
                 if (e2 == hipSuccess) e2 = dev_alloc(&db->d_lines, (size_t)LINE_BYTES * db->n_lines);
+                if (e2 == hipSuccess) db->alloc_landed = true;
                 if (e2 == hipSuccess) e2 = hipMemsetAsync(db->d_lines, 0, (size_t)LINE_BYTES * db->n_lines, db->stream);
                 if (e2 != hipSuccess) {
                     db->alloc_oom = (e2 == hipErrorOutOfMemory);
@@ -589,6 +593,7 @@ void db_free(kcfx_db* db) {
     if (db->d_stash) (void)dev_free(db->d_stash);
     if (db->d_stats) (void)dev_free(db->d_stats);
     if (db->d_pop) (void)dev_free(db->d_pop);
+    if (db->touch_sink) (void)dev_free(db->touch_sink);
     delete db;
 }
 
@@ -659,6 +664,7 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     uint64_t* d_pw = nullptr;          // the cells of the resident records, kept by the first pass for the later ones (RecProbes)
     uint8_t* d_ps = nullptr;
     uint8_t* d_raw = nullptr;          // the .kmc_suf records as the file holds them, resident between the passes (see below)
+    uint32_t* d_pop2 = nullptr;        // the crowding counters of the OTHER form of the table (extended), counted in the same first pass
     hipEvent_t done[2] = {nullptr, nullptr};
     int32_t rc = KCFX_OK;
     auto cleanup = [&]() {
@@ -666,6 +672,7 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
         // screening kernel, the next database's uploads)
         (void)hipStreamSynchronize(db->stream);
         if (d_raw) (void)dev_free_idle(d_raw);
+        if (d_pop2) (void)dev_free_idle(d_pop2);
         if (d_pw) (void)dev_free_idle(d_pw);
         if (d_ps) (void)dev_free_idle(d_ps);
         for (int i = 0; i < 2; ++i) {
@@ -692,19 +699,20 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     // keep every decoded record resident between the phases?
     size_t free_b = free_device_bytes();
     // (the table may still be on its way -- table_ready -- and must not be counted as free room: conservative when it has arrived)
-    if (db->alloc_thread.joinable()) free_b -= std::min<size_t>(free_b, (size_t)LINE_BYTES * db->n_lines);
+    // (the table may still be on its way -- table_ready -- and must not be counted as free room; once its allocation has landed
+    // hipMemGetInfo no longer counts it and subtracting it again -- round 4 did -- left a wheat-scale open no tier that fit)
+    if (db->alloc_thread.joinable() && !db->alloc_landed) free_b -= std::min<size_t>(free_b, (size_t)LINE_BYTES * db->n_lines);
     const char* raw_env = getenv("KCFX_LOAD_RAW");          // 1: the raw tier whatever fits (test hook); 0: never
     const bool resident = two_phase && getenv("KCFX_LOAD_STREAM_TWICE") == nullptr && !(raw_env && raw_env[0] == '1') &&
                           (double)h.total * 12.0 + (double)(2 * chunk_bytes) + (double)(64 << 20) < 0.5 * (double)free_b;
     // Round 5, between "everything decoded stays" and "the file is streamed once per pass": the RECORDS stay, as the file holds them
     // (record_size bytes each: 8 for k = 31, p = 7, 2-byte counters -- two thirds of the decoded 12, a third of the 21 with the kept
-    // cells), and every pass decodes its chunk again from HBM (decode_records_kernel: ~3 % of a pass). A wheat-scale database
-    // (8 G k-mers, 65 GB of records beside 192 GiB of lines) then streams its file ONCE for the build passes and once more for the
-    // stash pass -- the records make room for the stash first -- where round 4 streamed it nine times (26 s for a 43 ms pass).
-    // Only tried when the decoded form does not fit; an allocation that fails falls back to streaming per pass.
-    bool raw_tier = two_phase && cells && !resident && !(raw_env && raw_env[0] == '0') && getenv("KCFX_LOAD_STREAM_TWICE") == nullptr &&
-                    ((raw_env && raw_env[0] == '1') ||
-                     (double)h.total * h.record_size + (double)h.total / 16.0 + (double)(4 * chunk_bytes) + (double)(1ull << 30) < (double)free_b);
+    // cells), and every pass decodes its chunk again from HBM; they make room for the stash before its pass, which streams the file
+    // once more. Built for the wheat-scale open (8 G k-mers, 65 GB of records beside 192 GiB of lines: two streams of the file instead
+    // of six), measured, and NOT the default: on this platform allocating the 65 GB costs 4 - 5 s (the driver hands memory out
+    // cleared) and a build pass from HBM takes 1.95 s where a streamed one takes 2.5 s -- 20.0 s against 18.7 s for the open
+    // (profiles/r05_notes.md). KCFX_LOAD_RAW=1 selects it (tests/test_gpu_parity.py runs all four tiers against each other).
+    bool raw_tier = two_phase && cells && !resident && raw_env && raw_env[0] == '1' && getenv("KCFX_LOAD_STREAM_TWICE") == nullptr;
     const int64_t n_chunk_max = std::min<int64_t>(CH, std::max<int64_t>(h.total, 1));
     const int64_t n_keys_buf = resident ? std::max<int64_t>(h.total, 1) : n_chunk_max;
     for (int i = 0; i < 2; ++i) {
@@ -730,6 +738,17 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
             raw_tier = false;
         }
     }
+    // (a database that may want an extended table -- ext_auto -- counts its k-mers per minimizer BOTH ways in the first pass, the
+    // second way under the file's copies: the choice then costs no pass of its own)
+    const bool early_ext = cells && db->ext_auto && !db->ext && db->pop_bits == 32 && getenv("KCFX_EXT_LATE") == nullptr;
+    if (early_ext && !resident) {
+        if (dev_alloc(&d_pop2, cells_pop_bytes(db->pop_bits)) != hipSuccess) {
+            (void)hipGetLastError();
+            d_pop2 = nullptr;
+        } else {
+            LOAD_HIP(hipMemsetAsync(d_pop2, 0, cells_pop_bytes(db->pop_bits), db->stream));
+        }
+    }
     if (h.lut_entries) LOAD_HIP(hipMemcpyAsync(d_lut, h.lut_bytes, (size_t)h.lut_entries * 8, hipMemcpyHostToDevice, db->stream));
     tr.mark(raw_tier ? "buffers + LUT upload (records will stay resident)" : "buffers + LUT upload");
 
@@ -742,9 +761,14 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
             // (the kept cells of these records: the batch's offset in the resident arrays is its offset in d_keys)
             uint64_t* pw = d_pw ? d_pw + (keys - d_keys) : nullptr;
             uint8_t* ps = d_ps ? d_ps + (keys - d_keys) : nullptr;
-            if (phase == 0)
+            if (phase == 0) {
+                if (d_pop2 && !db->ext) {                   // ... and per minimizer of the extended form (see early_ext)
+                    const hipError_t e0 = launch_cells_count(d_pop2, db->pop_bits, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream, 0, 1);
+                    if (e0 != hipSuccess) return e0;
+                }
                 return pw ? launch_cells_resolve(db->d_pop, db->pop_bits, kk, db->lbits, db->info.both_strands, keys, counts, n, pw, ps, db->stream, db->ext)
                           : launch_cells_count(db->d_pop, db->pop_bits, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream, 0, db->ext);
+            }
             if (phase == 1 || phase == 2) return launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, phase == 1 ? 1 : 0, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream, 0, pw, ps, db->ext, db->regions, db->slicing());
             if (phase == 3) return launch_cells_settle(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stats, db->stream, 0, pw, ps, db->ext, db->regions, db->slicing());
             return launch_cells_stash(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stash, db->stash_mask, db->stream, 0, pw, ps, db->ext, db->regions, db->slicing());
@@ -807,6 +831,7 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     // any bid: a minimizer with c k-mers is c / L runs of ~L consecutive offsets (L = 0.65 W: the run length of the order) that
     // fall on the W cells of a line independently, so W (1 - (1 - L / W)^(c / L)) of its k-mers find a cell of their own and the rest
     // are displaced (8 G genomic k-mers, four loci per preferred 16-mer: c ~ 41 -> 61 %, measured 65 %; the bench database: ~0).
+    // An estimate that decides between two forms, not a count: the check after the build still catches what it misses.
     // Only with one counter per minimizer (pop_bits == 32); the check after the build stays as the safety net.
     auto ext_by_crowding = [&](double* share) -> int32_t {
         unsigned long long* d_hist = nullptr;
@@ -826,7 +851,13 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
             all += n * c;
             moved += n * ((double)c - home);
         }
-        *share = all > 0 ? moved / all : 0.0;
+        // ... and a k-mer that keeps its place among the k-mers of its own minimizer still meets those of OTHER minimizers that
+        // hash to its line and cell: d = k-mers per cell of them on average, and of two runs that contest a line one keeps every
+        // cell (cell_bid) -- half of the contested k-mers move (the 2.1 G-k-mer database of random k-mers at 0.33 per cell: 11 %
+        // by its own minimizers, 49 % outside their cells in the plain table that round 4 built first)
+        const double d = all / (16.0 * (double)db->n_lines);
+        const double own = all > 0 ? moved / all : 0.0;
+        *share = own + (1.0 - own) * 0.5 * (1.0 - std::exp(-d));
         return KCFX_OK;
     };
 
@@ -842,15 +873,25 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
             }
             tr.mark("wait for the table");
             constexpr double EXT_MOVED_SHARE = 0.15;
-            if (db->ext_auto && !db->ext && db->pop_bits == 32 && getenv("KCFX_EXT_LATE") == nullptr) {
+            if (early_ext) {
                 double share = 0;
                 if ((rc = ext_by_crowding(&share))) return rc;
                 if (tr.on) fprintf(stderr, "[kcfx load] crowding counters: %.1f %% of the k-mers would sit outside their first-choice cells in a plain table\n", 100.0 * share);
                 if (share > EXT_MOVED_SHARE) {
-                    db->ext = 1;                            // the counters again, per extended minimizer; nothing else has been built yet
-                    LOAD_HIP(hipMemsetAsync(db->d_pop, 0, cells_pop_bytes(db->pop_bits), db->stream));
-                    if ((rc = later_pass(0))) return rc;
+                    db->ext = 1;                            // nothing but the counters has been built yet
+                    if (d_pop2) {                           // ... and the extended form's were counted beside them
+                        LOAD_HIP(hipStreamSynchronize(db->stream));
+                        std::swap(db->d_pop, d_pop2);
+                    } else {                                // (records resident, or no room for a second set: once more, per extended minimizer)
+                        LOAD_HIP(hipMemsetAsync(db->d_pop, 0, cells_pop_bytes(db->pop_bits), db->stream));
+                        if ((rc = later_pass(0))) return rc;
+                    }
                     tr.mark("extended table chosen by the crowding counters");
+                }
+                if (d_pop2) {
+                    LOAD_HIP(hipStreamSynchronize(db->stream));
+                    (void)dev_free_idle(d_pop2);
+                    d_pop2 = nullptr;
                 }
             }
             for (int phase = 1; phase <= 3; ++phase)
@@ -1003,7 +1044,7 @@ struct RefHold {
 extern "C" {
 
 const char* kcfx_last_error(void) { return g_error.c_str(); }
-const char* kcfx_version(void) { return "kcfx 0.4.0 (gfx950)"; }
+const char* kcfx_version(void) { return "kcfx 0.5.0 (gfx950)"; }
 
 int32_t kcfx_device_count(int32_t* n) {
     if (!n) return fail(KCFX_ERR_ARG, "null argument");
@@ -1095,6 +1136,23 @@ int32_t kcfx_db_open_slice(const char* kmc_prefix, int32_t device, const kcfx_db
         tr.mark("rebuilt as a line table");
     }
     if (!rc) rc = table_finish(db);
+    if (!rc && db->fmt == FORMAT_CELLS) {
+        // Experiment (round 5, profiles/r05_notes.md section 8; OFF unless KCFX_OPEN_TOUCH=<KB> is set): one read per <KB> of the
+        // finished table as the last thing an open does. The first screening launch on a fresh handle takes twice the time of the
+        // second (0.19 against 0.09 ms on the bench workload) with the same HBM requests, cache misses and UTCL1 misses; if that were
+        // address translations lost when the build's temporaries are freed, this would cure it. It does not (2 MB, 64 KB, 4 KB strides).
+        const char* t = getenv("KCFX_OPEN_TOUCH");
+        const size_t stride = (t && atoi(t) > 0) ? (size_t)atoi(t) * 1024 : 0;
+        if (stride) {
+            uint32_t* sink = nullptr;
+            hipError_t e2 = dev_alloc(&sink, 256);
+            if (e2 == hipSuccess) e2 = launch_touch(db->d_lines, (size_t)LINE_BYTES * db->n_lines, stride, sink, db->stream);
+            if (e2 == hipSuccess && db->d_stash) e2 = launch_touch(db->d_stash, ((size_t)db->stash_mask + 1) * 16, stride, sink, db->stream);
+            if (e2 == hipSuccess) e2 = hipStreamSynchronize(db->stream);
+            (void)hipGetLastError();
+            db->touch_sink = sink;                         // (freed with the handle: a free here would undo what the touch did)
+        }
+    }
     tr.mark("finalize");
     if (!rc && getenv("KCFX_VERBOSE"))
         fprintf(stderr, "kcfx: %s: table at %p, %u lines (%d region(s) of 2^%d), stash at %p\n", kmc_prefix, (void*)db->d_lines, db->n_lines, db->regions, db->lbits, (void*)db->d_stash);

@@ -97,10 +97,12 @@ __host__ __device__ inline uint64_t cell_word(uint32_t w, uint32_t r, uint32_t c
 // lines, its filter bits and its stash entry live where its first-choice cell does, and the k-mers of a minimizer run stay
 // together (an extended table cuts a run in two at most, as it does for its lines). A k-mer with several first-choice cells (tied
 // minimizers) is stored per cell, each copy where a query that derives THAT cell will look.
-__host__ __device__ inline uint32_t cell_slice_of(uint32_t line, uint32_t r, int32_t lbits, uint32_t n_slices) {
-    const uint32_t g = (line << (32 - lbits)) | (r & (0xFFFFFFFFu >> lbits));
+__host__ __device__ inline uint32_t cell_slice_of_g(uint32_t g, uint32_t n_slices) {        // g = the 32 bits (line : r) themselves
     const uint32_t h = (g ^ (g >> 13)) * 0x7FEB352Du;
     return (uint32_t)(((uint64_t)(h ^ (h >> 15)) * n_slices) >> 32);
+}
+__host__ __device__ inline uint32_t cell_slice_of(uint32_t line, uint32_t r, int32_t lbits, uint32_t n_slices) {
+    return cell_slice_of_g((line << (32 - lbits)) | (r & (0xFFFFFFFFu >> lbits)), n_slices);
 }
 
 struct TableView {
@@ -351,6 +353,7 @@ hipError_t launch_screen_tiles(const uint8_t* text, RefPlan plan, const TileDesc
                                int32_t both_strands, int32_t min_count, uint64_t* bits, int64_t* count_sums,
                                hipStream_t st, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // hit bitmaps + count sums of n_samples consecutive samples -> kcfx_result per (sample, window)
+hipError_t launch_touch(const void* p, size_t bytes, size_t stride, uint32_t* sink, hipStream_t st);   // (experiment: KCFX_OPEN_TOUCH)
 // table slices: another slice's tile bitmaps (hit halves OR-ed) and count sums (added) into these
 hipError_t launch_merge_partial(uint64_t* bits, int64_t* sums, const uint64_t* obits, const int64_t* osums, int32_t n_tiles, hipStream_t st);
 hipError_t launch_reduce_windows(const TileDesc* tiles, int32_t n_tiles, int32_t n_samples, const uint64_t* bits,

@@ -1350,7 +1350,7 @@ __device__ __forceinline__ void cells_issue(const TableView& tv, uint64_t V, con
 // is flagged "someone who belongs here lives elsewhere" and this flank's filter bit is set (if cnt == 0 the k-mer is queued
 // and looked up in its second line, then in the stash)
 template <bool BOTH, int W>
-__device__ __forceinline__ void cells_match(const CellWord& cw, int32_t lbits, uint32_t& cnt, uint32_t& pend) {
+__device__ __forceinline__ void cells_match(const CellWord& cw, int32_t lbits, uint32_t& cnt, uint32_t& pend, uint64_t* matched = nullptr) {
     const uint32_t rmask = cell_rmask(lbits, BOTH);             // (wave-uniform: scalar registers)
     // (cell_filter_pos with its two wave-uniform terms pinned to scalar registers: one v_add instead of a sub + add pair)
     uint32_t rb = (uint32_t)(32 - lbits);
@@ -1366,7 +1366,10 @@ __device__ __forceinline__ void cells_match(const CellWord& cw, int32_t lbits, u
         // (cw.r has no bits outside rmask and bit 15 clear; xor + and fuse into one v_bitop3)
         // (an invalid lane has loaded cell 0 of line 0 and compared it with whatever its bases encode: never a match -- the
         // validity mask is AND-ed to the compares' on the scalar unit)
-        const bool first = __builtin_amdgcn_inverse_ballot_w64(cw.V) && ((x ^ cw.w) <= CELL_FLAG_MASK) && (((y ^ cw.r) & rmask) == 0);
+        // (ballots AND-ed, not `&&`: both compares for every lane, no exec juggling for a short circuit)
+        const uint64_t FM = cw.V & wave_ballot((x ^ cw.w) <= CELL_FLAG_MASK) & wave_ballot(((y ^ cw.r) & rmask) == 0);
+        const bool first = __builtin_amdgcn_inverse_ballot_w64(FM);
+        if (matched) *matched = FM;                         // (k <= 30 with the retired free-cell scheme: first-choice matches only)
         if constexpr (W <= CELL_ALT_FREE_MAX_W) {
             const bool free_scheme = cell_alt_free(W, lbits, BOTH);                              // (wave-uniform)
             const uint32_t rmask_alt = rmask | (0xFu << (32 - lbits));
@@ -1576,20 +1579,20 @@ struct PlannedWords {
     // byte offsets from the start of the tile's LDS block (K31Plan) of the dword holding bit 2q - 1 of this lane's position q in
     // the current word, as the text reads it / of bit 2q' - 1 in the mirrored reverse complement (q' = T - q - K); the shifts
     // that go with them do not change from word to word (a word is 128 bits on)
-    uint32_t a_f, a_r;
+    uint32_t a_f, a_r;          // (LDS addresses, whole: the three reads of a word then need no address arithmetic)
     uint32_t s_f, s_r;
     const int8_t* p_an;         // this lane's anchor byte
-    const uint8_t* base;
     int n_kmers;
+    typedef const __attribute__((address_space(3))) uint32_t* lds_u32;
+    static __device__ __forceinline__ uint32_t lds_address(const uint32_t* p) { return (uint32_t)(uintptr_t)(lds_u32)p; }
     __device__ __forceinline__ void start(const K31Plan& sh, int off, int n_kmers_, int lane, int w_begin) {
         n_kmers = n_kmers_;
-        base = reinterpret_cast<const uint8_t*>(&sh);
         const int q = off + w_begin * 64 + lane;
         const int b0 = 2 * q - 1;
-        a_f = (uint32_t)offsetof(K31Plan, fw) + 4u * (uint32_t)(1 + (b0 >> 5));
+        a_f = lds_address(sh.fw + 1 + (b0 >> 5));
         s_f = 31u - (uint32_t)(b0 & 31);
         const int b1 = 2 * (K31Plan::T - q - K) - 1;
-        a_r = (uint32_t)offsetof(K31Plan, rw) + 4u * (uint32_t)(b1 >> 5);
+        a_r = lds_address(sh.rw + (b1 >> 5));
         s_r = 31u - (uint32_t)(b1 & 31);
         p_an = reinterpret_cast<const int8_t*>(sh.an) + q;
     }
@@ -1601,7 +1604,7 @@ struct PlannedWords {
         // in canonical form -- one stream per lane
         const uint32_t at = (a_f & ~fm) | (a_r & fm);        // v_bfi_b32
         const uint32_t sx = (s_f & ~fm) | (s_r & fm);
-        const uint32_t* p = reinterpret_cast<const uint32_t*>(base + at);
+        const lds_u32 p = (lds_u32)(uintptr_t)at;
         const uint32_t y0 = p[0], y1 = p[1], y2 = p[2];
         N = u64_of(alignbit32(y1, y2, sx) & lo_mask, alignbit32(y0, y1, sx));
         sh2 = (uint32_t)a & 30u;
@@ -1615,12 +1618,13 @@ struct PlannedWords {
 
 // cell_probe_of when the anchor byte has said where the minimizer sits (sh2 = 2 * its offset in N, fm = the flip mask)
 template <bool BOTH>
-__device__ __forceinline__ CellProbe cell_probe_planned(uint64_t N, uint32_t sh2, uint32_t fm, int32_t lbits, int32_t ext) {
+__device__ __forceinline__ CellProbe cell_probe_planned(uint64_t N, uint32_t sh2, uint32_t fm, int32_t lbits, int32_t ext, uint32_t* g_out = nullptr) {
     CellProbe p;
     uint32_t cm;
     p.w = cell_flank(N, sh2, 16, &cm);
     uint32_t g = cell_g32(cm);
     if (ext) g = cell_g32_ext(g, p.w, sh2);                 // (wave-uniform: an extended table, cell_first_ext)
+    if (g_out) *g_out = g;                                  // (line : r in one word: what regions and slices hash)
     p.sh = sh2;
     p.line = g >> (32 - lbits);
     p.r = (g & (0xFFFFFFFFu >> lbits)) | (BOTH ? 0u : (fm & CELL_R_FLIP));
@@ -1748,27 +1752,35 @@ __global__ __launch_bounds__(PLANNED ? CELLS_BLOCK : TEXT_BLOCK) __attribute__((
         uint64_t N, V;
         uint32_t sh2, fm;
         words.next(w, N, sh2, fm, V);
-        CellProbe p = cell_probe_planned<BOTH>(N, sh2, fm, tv.lbits, tv.ext);
+        uint32_t g;
+        CellProbe p = cell_probe_planned<BOTH>(N, sh2, fm, tv.lbits, tv.ext, &g);
         cw.Vfull = V;
         // (wave-uniform: the table is one slice of the database -- the k-mers whose minimizer another device holds are that
         // device's to look up: no load, no hit, no queue entry here; the tiles' bitmaps are OR-ed afterwards)
-        if (tv.slices > 1) V &= wave_ballot(cell_slice_of(p.line, p.r, tv.lbits, (uint32_t)tv.slices) == (uint32_t)tv.slice);
-        if (tv.regions > 1) p.line = cell_line_index(p.line, p.r, tv.lbits, tv.regions);    // (wave-uniform; from here on the line is only an address)
+        if (tv.slices > 1) V &= wave_ballot(cell_slice_of_g(g, (uint32_t)tv.slices) == (uint32_t)tv.slice);
+        if (tv.regions > 1) p.line |= cell_region_of(g, (uint32_t)tv.regions) << tv.lbits;  // (wave-uniform: cell_line_index; from here on the line is only an address)
         cells_issue<cell_nw(K), BOTH>(tv, V, p, sh2 | (fm & 1u), cw);
     };
     // stage B of word w: cells matched, ballots out, stash candidates queued
     auto retire = [&](int w, const CellWord& cw) {
         uint32_t cnt = 0, pend = 0;
-        cells_match<BOTH, cell_nw(K)>(cw, tv.lbits, cnt, pend);
+        uint64_t M = 0;
+        cells_match<BOTH, cell_nw(K)>(cw, tv.lbits, cnt, pend, &M);
         // cnt is 0 unless the k-mer was found at a valid position, and min_count >= 1 (checked by the API), so this is "found && count >= -c"
         const uint64_t H = wave_ballot((int32_t)cnt >= min_count);          // GetVariants.java:224 (valid positions only: cells_match)
         if (lane == 0) {
             q.vw[w - w_begin] = cw.Vfull;                                   // validity word of the window's bitmap
             q.hit[w - w_begin] = H;                                         // hits so far; queued k-mers may add theirs
         }
-        // GetVariants.java:226 (-c 1, the default: every found counter is a hit; wave-uniform)
-        if (min_count == 1) sum_acc += cnt;
-        else sum_acc += __builtin_amdgcn_inverse_ballot_w64(H) ? cnt : 0u;
+        // GetVariants.java:226: the counters of the hits. Every found counter is added; the lanes that found theirs below -c (none
+        // at the default -c 1; decided on the scalar unit from the two masks) take it back
+        sum_acc += cnt;
+        if constexpr (cell_nw(K) > CELL_ALT_FREE_MAX_W) {
+            const uint64_t low = M & ~H;
+            if (low) sum_acc -= __builtin_amdgcn_inverse_ballot_w64(low) ? cnt : 0u;
+        } else {
+            sum_acc -= __builtin_amdgcn_inverse_ballot_w64(H) ? 0u : cnt;
+        }
         // looked up further: flagged cell + filter bit, and not a hit here (a k-mer found below -c is not stored anywhere else
         // either: its look-up would end as the miss it already is -- harmless, and one compare less than "cnt == 0")
         const uint64_t PM = wave_ballot(pend != 0u) & ~H & cw.V;
@@ -2534,6 +2546,22 @@ hipError_t launch_merge_partial(uint64_t* bits, int64_t* sums, const uint64_t* o
     if (n_tiles <= 0) return hipSuccess;
     const int64_t n = (int64_t)n_tiles * TILE_WORDS;
     hipLaunchKernelGGL(merge_partial_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bits, sums, obits, osums, (int64_t)n_tiles);
+    return hipGetLastError();
+}
+
+// one dword per `stride` bytes of a buffer, read and dropped (experiment: does a first pass over a fresh table pay for its address
+// translations? -- KCFX_OPEN_TOUCH, tools/first_pass_probe.py)
+__global__ void touch_kernel(const uint32_t* __restrict__ p, int64_t n_steps, int64_t stride_dwords, uint32_t* sink) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    uint32_t acc = 0;
+    for (; i < n_steps; i += (int64_t)gridDim.x * blockDim.x) acc += p[i * stride_dwords];
+    if (acc == 0x5EED1234u) *sink = acc;                    // (never true for table data that matters; keeps the loads)
+}
+hipError_t launch_touch(const void* p, size_t bytes, size_t stride, uint32_t* sink, hipStream_t st) {
+    const int64_t n = (int64_t)(bytes / stride);
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(touch_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, st,
+                       reinterpret_cast<const uint32_t*>(p), n, (int64_t)(stride / 4), sink);
     return hipGetLastError();
 }
 

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""What does the FIRST screening launch on a fresh handle pay for? bench.py's cache_state leg says: ~0.19 ms against ~0.09 for the
+launch after it, whatever the caches hold (a 1 GiB read-only sweep before it changes nothing, 50 ms of idle time neither). This
+script makes the pair visible to rocprofv3: per cycle a fresh kcfx_db_open, then TWO launches of the one-pass form back to back, then
+close -- under `rocprofv3 --kernel-trace --pmc ...` the per-dispatch counter rows of the screening kernel alternate first / second.
+
+    python tools/first_pass_probe.py [cycles]          (prints its own event timings; tools/first_pass_pmc.sh wraps it)
+
+Variants (FIRST_PASS_MODE): plain | touch -- before the first launch, one 4-byte read per 2 MB of the table (a tiny kernel: torch
+gather) -- | same -- the SAME handle screened again after 20 other launches against another handle | other -- the first launch after the open goes to an
+OLD handle, then the fresh one (is it the handle or the moment?)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import torch  # noqa: E402
+from kcftools_amd import engine  # noqa: E402
+
+cycles = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+mode = os.environ.get("FIRST_PASS_MODE", "plain")
+synth_bin = bench.ensure_built()
+prefix, meta = bench.make_dataset(synth_bin, os.environ.get("KCFX_BENCH_DIR", "/tmp/kcfx_bench"), 30_427_671, 150_000_000, 2, os.cpu_count() or 8)
+text = np.fromfile(prefix + ".ref.txt", dtype=np.uint8).tobytes()
+K = 31
+s, e = engine.windows(len(text), 10_000, 0, K)
+ref = engine.Reference(text, s.astype(np.int64), (e - s).astype(np.int32), K, expected_screens=1)
+out = torch.zeros(len(s) * 10, dtype=torch.int32, device="cuda:0")
+st = torch.cuda.current_stream().cuda_stream
+expected = int(ref.n_kmer_slots)
+
+
+def launch(db, n=1):
+    res = []
+    for _ in range(n):
+        ref.prof_enable(True)
+        ref.prof_read(reset=True)
+        ref.screen_async(db, out.data_ptr(), st, 1)
+        torch.cuda.synchronize()
+        ms, c = ref.prof_read(reset=True)
+        ref.prof_enable(False)
+        res.append(ms / max(1, c))
+    return res
+
+
+warm = engine.KmcDb.open(prefix, expected_queries=expected)
+launch(warm, 5)
+for c in range(cycles):
+    if mode in ("allocfree", "bigfree"):
+        # no open at all: device allocations made and given back to the driver (a small reference handle: a few hipMalloc / hipFree
+        # of KB-sized buffers; "bigfree": a 1 GiB block through the library's pool and kcfx_release_cached), then the OLD handle
+        if mode == "allocfree":
+            r2 = engine.Reference(text[:100_000], [0], [100_000], K)
+            r2.close()
+        else:
+            r3 = engine.Reference(text + text[:1_000_000], s[:10].astype(np.int64), (e - s)[:10].astype(np.int32), K)
+            r3.close()
+            engine.release_cached()
+        a, b = launch(warm, 2)
+        print(f"cycle {c}: old handle after {mode}: first {a:.5f} ms, second {b:.5f} ms", flush=True)
+        continue
+    db = engine.KmcDb.open(prefix, expected_queries=expected)
+    if mode == "touch":
+        # (the engine hands out no table pointer: the stand-in is a pass of ANOTHER handle's launches, which leaves this handle's
+        # table untouched -- the touch variant proper lives in kcfx_db_open behind KCFX_OPEN_TOUCH=1, read when the handle is made)
+        pass
+    if mode == "other":
+        # is it the fresh HANDLE or the moment? the first launch after the open goes to the OLD handle (a table nobody has written
+        # for a long time), the fresh one is screened after it
+        o1 = launch(warm, 1)[0]
+        a, b = launch(db, 2)
+        print(f"cycle {c}: old handle right after the open {o1:.5f} ms, then the fresh handle: first {a:.5f} ms, second {b:.5f} ms", flush=True)
+        db.close()
+        continue
+    a, b = launch(db, 2)
+    line = f"cycle {c}: first {a:.5f} ms, second {b:.5f} ms"
+    if mode == "same":
+        launch(warm, 20)
+        c2, d2 = launch(db, 2)
+        line += f"; after 20 launches against another handle: {c2:.5f}, {d2:.5f}"
+    print(line, flush=True)
+    db.close()

@@ -17,12 +17,15 @@ src = f"gpurun_out/{tag}"
 os.makedirs("profiles", exist_ok=True)
 # the dominant kernel of the bench workload, as the bench line names it (screen_k31c_kernel on a cell table)
 KERNEL = json.load(open(f"{src}/bench.json"))["roofline"]["kernel"]
-# (round 4: a bench process runs three kernels of interest -- the screening kernel on the planned reference, the same template on a
-# text-only reference (K1 - K3 in one launch) and ref_plan_kernel; rocprofv3 prints template arguments, which tell them apart)
+# A bench process runs three kernels of interest -- the screening kernel on a text-only reference (round 5: the step's own,
+# K1 - K3 in one launch), the same template on a planned reference, and ref_plan_kernel; rocprofv3 prints template arguments, which
+# tell them apart. HEAD = the instantiation the bench line's roofline is about (roofline.kernel_instance).
+_BENCH = json.load(open(f"{src}/bench.json"))
+HEAD = _BENCH["roofline"].get("kernel_instance") or (KERNEL + "<31, true, true>")
 PLANNED = KERNEL + "<31, true, true>" if KERNEL in ("screen_k31c_kernel", "screen_cohort_kernel") else KERNEL
 TEXT_ONLY = KERNEL + "<31, true, false>"
 PLAN = "ref_plan_kernel<31>"
-
+OTHER = PLANNED if HEAD == TEXT_ONLY else TEXT_ONLY
 
 def counters(pattern, kernel):
     agg = collections.defaultdict(list)
@@ -36,30 +39,31 @@ def counters(pattern, kernel):
 out = {"tag": tag}
 bench = json.load(open(f"{src}/bench.json"))
 out["kernel"] = KERNEL
-out["bench"] = {k: bench.get(k) for k in ("value", "ms_per_step", "step", "amortised", "one_pass", "cold_start", "text_only_reference", "roofline",
-                                          "cpu_baseline", "parity", "config")}
+out["bench"] = {k: bench.get(k) for k in ("value", "ms_per_step", "step", "step_form", "other_forms", "forms_identical", "ramped", "cache_state",
+                                          "realistic", "roofline", "cpu_baseline", "parity", "config")}
 for f in glob.glob(f"{src}/stats/*kernel_stats.csv"):
     shutil.copy(f, f"profiles/{tag}_kernel_stats.csv")
     for r in csv.DictReader(open(f)):
-        if PLANNED in r["Name"]:
+        if HEAD in r["Name"]:
             out["rocprof_kernel"] = r["Name"].split("(")[0]
             out["rocprof_kernel_avg_ms"] = float(r["AverageNs"]) / 1e6
             out["rocprof_kernel_calls"] = int(r["Calls"])
-        elif TEXT_ONLY in r["Name"]:
-            out["rocprof_text_only_kernel_avg_ms"] = float(r["AverageNs"]) / 1e6
-            out["rocprof_text_only_kernel_calls"] = int(r["Calls"])
+        elif OTHER in r["Name"]:
+            out["rocprof_other_form_kernel"] = r["Name"].split("(")[0]
+            out["rocprof_other_form_kernel_avg_ms"] = float(r["AverageNs"]) / 1e6
+            out["rocprof_other_form_kernel_calls"] = int(r["Calls"])
         elif PLAN in r["Name"]:
             out["rocprof_ref_plan_avg_ms"] = float(r["AverageNs"]) / 1e6
             out["rocprof_ref_plan_calls"] = int(r["Calls"])
-fetch, n1 = counters(f"{src}/pmc_fetch/*counter_collection.csv", PLANNED)
-write, _ = counters(f"{src}/pmc_write/*counter_collection.csv", PLANNED)
-tcc, _ = counters(f"{src}/pmc_tcc/*counter_collection.csv", PLANNED)
-sq, _ = counters(f"{src}/pmc_sq/*counter_collection.csv", PLANNED)
-sq2, _ = counters(f"{src}/pmc_sq2/*counter_collection.csv", PLANNED)
+fetch, n1 = counters(f"{src}/pmc_fetch/*counter_collection.csv", HEAD)
+write, _ = counters(f"{src}/pmc_write/*counter_collection.csv", HEAD)
+tcc, _ = counters(f"{src}/pmc_tcc/*counter_collection.csv", HEAD)
+sq, _ = counters(f"{src}/pmc_sq/*counter_collection.csv", HEAD)
+sq2, _ = counters(f"{src}/pmc_sq2/*counter_collection.csv", HEAD)
 sq.update(sq2)
 # the other two kernels: requests, VALU instructions, bytes
 others = {}
-for name, pat in (("text_only", TEXT_ONLY), ("ref_plan", PLAN)):
+for name, pat in (("planned_reference" if OTHER == PLANNED else "text_only", OTHER), ("ref_plan", PLAN)):
     f2, _ = counters(f"{src}/pmc_fetch/*counter_collection.csv", pat)
     w2, _ = counters(f"{src}/pmc_write/*counter_collection.csv", pat)
     t2, _ = counters(f"{src}/pmc_tcc/*counter_collection.csv", pat)
@@ -82,7 +86,7 @@ if fetch.get("FETCH_SIZE") is not None:
     out["hbm_write_bytes_per_launch"] = wr
     cfg = bench["config"]
     if not COHORT:
-        json.dump({"tag": tag, "kernel": KERNEL, "hbm_bytes_per_launch": rd + wr,
+        json.dump({"tag": tag, "kernel": KERNEL, "kernel_instance": HEAD, "step_form": bench.get("step_form", "two-launch"), "hbm_bytes_per_launch": rd + wr,
                    "rocprof_kernel_avg_ms": out.get("rocprof_kernel_avg_ms"),
                    "hbm_read_requests_per_launch": tcc.get("TCC_EA0_RDREQ_sum"),
                    "ref_len": 30427671, "db_kmers": 150000000, "window": 10000, "table_lines": bench["roofline"].get("table", {}).get("lines"),
