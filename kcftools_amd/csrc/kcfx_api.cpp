@@ -139,7 +139,6 @@ struct kcfx_db {
     uint32_t* d_pop = nullptr;               // FORMAT_CELLS build scratch: k-mers per minimizer (freed after the build)
     int32_t pop_bits = 32;                   // 2^pop_bits byte counters: 32 = one per minimizer, lbits + 2 when 4 GiB cannot be had
     hipStream_t stream = nullptr;
-    uint32_t* touch_sink = nullptr;          // (see the end of kcfx_db_open_slice)
     int32_t n_slices = 1, slice = 0;         // kcfx_db_open_slice: the table holds slice `slice` of `n_slices` of the database (cell_slice_of)
     int32_t slicing() const { return n_slices > 1 ? (n_slices << 8 | slice) : 0; }
     TableView view() const { return TableView{d_lines, n_lines, wide, mode, mm_len, fmt, lbits, stash_mask, d_stash, generic, info.both_strands, ext, regions, n_slices, slice}; }
@@ -593,7 +592,6 @@ void db_free(kcfx_db* db) {
     if (db->d_stash) (void)dev_free(db->d_stash);
     if (db->d_stats) (void)dev_free(db->d_stats);
     if (db->d_pop) (void)dev_free(db->d_pop);
-    if (db->touch_sink) (void)dev_free(db->touch_sink);
     delete db;
 }
 
@@ -1136,23 +1134,6 @@ int32_t kcfx_db_open_slice(const char* kmc_prefix, int32_t device, const kcfx_db
         tr.mark("rebuilt as a line table");
     }
     if (!rc) rc = table_finish(db);
-    if (!rc && db->fmt == FORMAT_CELLS) {
-        // Experiment (round 5, profiles/r05_notes.md section 8; OFF unless KCFX_OPEN_TOUCH=<KB> is set): one read per <KB> of the
-        // finished table as the last thing an open does. The first screening launch on a fresh handle takes twice the time of the
-        // second (0.19 against 0.09 ms on the bench workload) with the same HBM requests, cache misses and UTCL1 misses; if that were
-        // address translations lost when the build's temporaries are freed, this would cure it. It does not (2 MB, 64 KB, 4 KB strides).
-        const char* t = getenv("KCFX_OPEN_TOUCH");
-        const size_t stride = (t && atoi(t) > 0) ? (size_t)atoi(t) * 1024 : 0;
-        if (stride) {
-            uint32_t* sink = nullptr;
-            hipError_t e2 = dev_alloc(&sink, 256);
-            if (e2 == hipSuccess) e2 = launch_touch(db->d_lines, (size_t)LINE_BYTES * db->n_lines, stride, sink, db->stream);
-            if (e2 == hipSuccess && db->d_stash) e2 = launch_touch(db->d_stash, ((size_t)db->stash_mask + 1) * 16, stride, sink, db->stream);
-            if (e2 == hipSuccess) e2 = hipStreamSynchronize(db->stream);
-            (void)hipGetLastError();
-            db->touch_sink = sink;                         // (freed with the handle: a free here would undo what the touch did)
-        }
-    }
     tr.mark("finalize");
     if (!rc && getenv("KCFX_VERBOSE"))
         fprintf(stderr, "kcfx: %s: table at %p, %u lines (%d region(s) of 2^%d), stash at %p\n", kmc_prefix, (void*)db->d_lines, db->n_lines, db->regions, db->lbits, (void*)db->d_stash);

@@ -353,7 +353,6 @@ hipError_t launch_screen_tiles(const uint8_t* text, RefPlan plan, const TileDesc
                                int32_t both_strands, int32_t min_count, uint64_t* bits, int64_t* count_sums,
                                hipStream_t st, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // hit bitmaps + count sums of n_samples consecutive samples -> kcfx_result per (sample, window)
-hipError_t launch_touch(const void* p, size_t bytes, size_t stride, uint32_t* sink, hipStream_t st);   // (experiment: KCFX_OPEN_TOUCH)
 // table slices: another slice's tile bitmaps (hit halves OR-ed) and count sums (added) into these
 hipError_t launch_merge_partial(uint64_t* bits, int64_t* sums, const uint64_t* obits, const int64_t* osums, int32_t n_tiles, hipStream_t st);
 hipError_t launch_reduce_windows(const TileDesc* tiles, int32_t n_tiles, int32_t n_samples, const uint64_t* bits,

@@ -1336,6 +1336,8 @@ __device__ __forceinline__ void cells_issue(const TableView& tv, uint64_t V, con
     // compiler cannot count in vmcnt and waits for with vmcnt(0) -- the end of the software pipeline)
     // (k = 31 only: with a second load of the same line behind it -- the free cell of k < 31 -- the hint costs that load its hit:
     // k = 25, 0.131 ms with it, 0.121 ms without)
+    // (round 5 tried the ordinary policy for the lanes next to a word border -- where a minimizer run straddles two words and its
+    // line is wanted twice -- so that the second word would find it in the L2: 0.0835 against 0.0801 ms, profiles/r05_notes.md)
     if constexpr (W > CELL_ALT_FREE_MAX_W) cw.cell = nt_load2(a0);
     else cw.cell = *reinterpret_cast<const u32x2*>(a0);
     if constexpr (W <= CELL_ALT_FREE_MAX_W) {
@@ -2546,22 +2548,6 @@ hipError_t launch_merge_partial(uint64_t* bits, int64_t* sums, const uint64_t* o
     if (n_tiles <= 0) return hipSuccess;
     const int64_t n = (int64_t)n_tiles * TILE_WORDS;
     hipLaunchKernelGGL(merge_partial_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bits, sums, obits, osums, (int64_t)n_tiles);
-    return hipGetLastError();
-}
-
-// one dword per `stride` bytes of a buffer, read and dropped (experiment: does a first pass over a fresh table pay for its address
-// translations? -- KCFX_OPEN_TOUCH, tools/first_pass_probe.py)
-__global__ void touch_kernel(const uint32_t* __restrict__ p, int64_t n_steps, int64_t stride_dwords, uint32_t* sink) {
-    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    uint32_t acc = 0;
-    for (; i < n_steps; i += (int64_t)gridDim.x * blockDim.x) acc += p[i * stride_dwords];
-    if (acc == 0x5EED1234u) *sink = acc;                    // (never true for table data that matters; keeps the loads)
-}
-hipError_t launch_touch(const void* p, size_t bytes, size_t stride, uint32_t* sink, hipStream_t st) {
-    const int64_t n = (int64_t)(bytes / stride);
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(touch_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, st,
-                       reinterpret_cast<const uint32_t*>(p), n, (int64_t)(stride / 4), sink);
     return hipGetLastError();
 }
 

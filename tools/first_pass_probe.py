@@ -6,9 +6,9 @@ close -- under `rocprofv3 --kernel-trace --pmc ...` the per-dispatch counter row
 
     python tools/first_pass_probe.py [cycles]          (prints its own event timings; tools/first_pass_pmc.sh wraps it)
 
-Variants (FIRST_PASS_MODE): plain | touch -- before the first launch, one 4-byte read per 2 MB of the table (a tiny kernel: torch
-gather) -- | same -- the SAME handle screened again after 20 other launches against another handle | other -- the first launch after the open goes to an
-OLD handle, then the fresh one (is it the handle or the moment?)."""
+Variants (FIRST_PASS_MODE): plain | same -- the SAME handle screened again after 20 other launches against another handle | other -- the first launch after the open goes to an
+OLD handle, then the fresh one (is it the handle or the moment?) | idle -- no open, only time without GPU work | allocfree / bigfree --
+no open, device memory taken and given back to the driver (small buffers / a 60 MB block through kcfx_release_cached), then the OLD handle."""
 import os
 import sys
 
@@ -49,6 +49,17 @@ def launch(db, n=1):
 warm = engine.KmcDb.open(prefix, expected_queries=expected)
 launch(warm, 5)
 for c in range(cycles):
+    if mode == "idle":
+        # nothing but time: the old handle after 1 / 5 / 50 ms without any GPU work
+        import time
+        line = []
+        for ms in (0.2, 1, 5, 50):
+            launch(warm, 3)
+            time.sleep(ms * 1e-3)
+            a, b = launch(warm, 2)
+            line.append(f"{ms} ms idle: {a:.5f} / {b:.5f}")
+        print(f"cycle {c}: old handle, first / second launch after " + "; ".join(line), flush=True)
+        continue
     if mode in ("allocfree", "bigfree"):
         # no open at all: device allocations made and given back to the driver (a small reference handle: a few hipMalloc / hipFree
         # of KB-sized buffers; "bigfree": a 1 GiB block through the library's pool and kcfx_release_cached), then the OLD handle
@@ -63,10 +74,6 @@ for c in range(cycles):
         print(f"cycle {c}: old handle after {mode}: first {a:.5f} ms, second {b:.5f} ms", flush=True)
         continue
     db = engine.KmcDb.open(prefix, expected_queries=expected)
-    if mode == "touch":
-        # (the engine hands out no table pointer: the stand-in is a pass of ANOTHER handle's launches, which leaves this handle's
-        # table untouched -- the touch variant proper lives in kcfx_db_open behind KCFX_OPEN_TOUCH=1, read when the handle is made)
-        pass
     if mode == "other":
         # is it the fresh HANDLE or the moment? the first launch after the open goes to the OLD handle (a table nobody has written
         # for a long time), the fresh one is screened after it
