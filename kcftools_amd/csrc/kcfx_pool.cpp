@@ -9,6 +9,7 @@
 // request (kcfx_release_cached), disabled by KCFX_NO_POOL. Memory policies that look at the free device memory count the
 // kept blocks as free (free_device_bytes).
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <unordered_map>
@@ -20,8 +21,20 @@ namespace kcfx {
 
 namespace {
 
-constexpr size_t POOL_MIN_BYTES = (size_t)8 << 20;      // smaller requests go straight to hipMalloc
-constexpr size_t POOL_MAX_BLOCKS = 16;                  // kept blocks per device
+size_t pool_min_bytes() {                               // smaller requests go straight to hipMalloc (KCFX_POOL_MIN_KB: experiments)
+    static const size_t n = [] {
+        const char* e = getenv("KCFX_POOL_MIN_KB");
+        return e && atoi(e) > 0 ? (size_t)atoi(e) << 10 : (size_t)8 << 20;
+    }();
+    return n;
+}
+size_t pool_max_blocks() {                              // kept blocks per device (KCFX_POOL_BLOCKS: experiments)
+    static const size_t n = [] {
+        const char* e = getenv("KCFX_POOL_BLOCKS");
+        return e && atoi(e) > 0 ? (size_t)atoi(e) : (size_t)16;
+    }();
+    return n;
+}
 constexpr double POOL_MAX_FRACTION = 0.4;               // of the device's memory
 
 struct Block {
@@ -54,6 +67,7 @@ struct OnDevice {
 // replaces -- synchronises the whole device anyway)
 void really_free(const Block& b) {
     OnDevice g(b.dev);
+    if (getenv("KCFX_POOL_TRACE")) fprintf(stderr, "[kcfx pool] hipFree of %zu bytes\n", b.bytes);
     (void)hipFree(b.p);
 }
 
@@ -99,7 +113,7 @@ hipError_t dev_alloc(void** p, size_t bytes) {
     *p = nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    const bool big = pool_on() && bytes >= POOL_MIN_BYTES;
+    const bool big = pool_on() && bytes >= pool_min_bytes();
     if (big) {
         std::lock_guard<std::mutex> lk(g_mu);
         long best = -1;                                   // smallest kept block that fits without wasting a quarter
@@ -116,6 +130,7 @@ hipError_t dev_alloc(void** p, size_t bytes) {
             return hipSuccess;
         }
     }
+    if (getenv("KCFX_POOL_TRACE")) fprintf(stderr, "[kcfx pool] hipMalloc of %zu bytes\n", bytes);
     hipError_t e = hipMalloc(p, bytes);
     if (e == hipErrorOutOfMemory && pooled_device_bytes(dev) > 0) {
         (void)hipGetLastError();
@@ -146,7 +161,10 @@ static hipError_t dev_free_impl(void* p, bool idle) {
             g_live.erase(it);
         }
     }
-    if (!b.p) return hipFree(p);                         // a small block
+    if (!b.p) {                                          // a small block
+        if (getenv("KCFX_POOL_TRACE")) fprintf(stderr, "[kcfx pool] hipFree of a small block\n");
+        return hipFree(p);
+    }
     if (!idle) {
         OnDevice g(b.dev);
         (void)hipDeviceSynchronize();                    // as hipFree would have: nothing queued may still touch the block
@@ -164,7 +182,7 @@ static hipError_t dev_free_impl(void* p, bool idle) {
         for (;;) {
             size_t n = 0;
             for (const Block& s : g_spare) n += s.dev == b.dev ? 1 : 0;
-            if (n <= POOL_MAX_BLOCKS && (double)pooled_locked(b.dev) <= POOL_MAX_FRACTION * (double)total_b) break;
+            if (n <= pool_max_blocks() && (double)pooled_locked(b.dev) <= POOL_MAX_FRACTION * (double)total_b) break;
             bool dropped = false;
             for (size_t i = 0; i < g_spare.size(); ++i)
                 if (g_spare[i].dev == b.dev) {
@@ -225,6 +243,7 @@ hipError_t host_free(void* p) {
             }
         }
     }
+    if (getenv("KCFX_POOL_TRACE")) fprintf(stderr, "[kcfx pool] hipHostFree\n");
     return hipHostFree(p);
 }
 

@@ -183,11 +183,14 @@ def test_samples_sharded_over_devices_give_the_same_file(tmp_path):
            "db_canon_k31_p3_cs2_m9"]
     k = ",".join(os.path.join(G, d) for d in dbs)
     outs = []
-    for i, dev in enumerate((["--device", "0"], ["--devices", "0,0,0"], ["--devices", "0,0"])):
+    # (... and `--shard table`: every sample's TABLE cut into one slice per listed device by minimizer, every device screens every
+    # window against its slice, the hit bitmaps merged -- the same file again)
+    for i, dev in enumerate((["--device", "0"], ["--devices", "0,0,0"], ["--devices", "0,0"], ["--devices", "0,0,0", "--shard", "table"],
+                             ["--device", "0", "--shard", "table"])):
         out = str(tmp_path / f"m{i}.kcf")
         run_cli(["-r", fa, "-k", k, "-o", out, "-s", "A,B,C,D,E", "-f", "window", "-w", "3000"] + dev)
         outs.append([l for l in open(out) if not l.startswith("##CMD") and not l.startswith("##date") and not l.startswith("##fileDate")])
-    assert outs[0] == outs[1] == outs[2] and sum(1 for l in outs[0] if not l.startswith("#")) > 10
+    assert all(o == outs[0] for o in outs[1:]) and sum(1 for l in outs[0] if not l.startswith("#")) > 10
 
 
 def test_pin_helper_accepts_the_driver_output_for_every_golden_case(tmp_path):

@@ -60,6 +60,24 @@ for c in range(cycles):
             line.append(f"{ms} ms idle: {a:.5f} / {b:.5f}")
         print(f"cycle {c}: old handle, first / second launch after " + "; ".join(line), flush=True)
         continue
+    if mode == "events":
+        # which kind of event in front of a launch on the OLD handle makes it slow? (no open, no library allocation)
+        line = []
+        host = torch.empty(64 << 20, dtype=torch.uint8)
+        pinned = torch.empty(64 << 20, dtype=torch.uint8).pin_memory()
+        devbuf = torch.empty(64 << 20, dtype=torch.uint8, device="cuda:0")
+        big = torch.empty(1 << 30, dtype=torch.uint8, device="cuda:0")
+        for name, ev in (("nothing", lambda: None), ("H2D 64 MB pageable", lambda: devbuf.copy_(host)), ("H2D 64 MB pinned", lambda: devbuf.copy_(pinned)),
+                         ("D2H 64 MB", lambda: host.copy_(devbuf)), ("D2D 1 GiB", lambda: big.copy_(big.roll(1) if False else big)),
+                         ("torch malloc+free 2 GiB (empty_cache)", lambda: (torch.empty(2 << 30, dtype=torch.uint8, device="cuda:0"), torch.cuda.empty_cache()))):
+            launch(warm, 3)
+            ev()
+            torch.cuda.synchronize()
+            a, b = launch(warm, 2)
+            line.append(f"{name}: {a:.5f} / {b:.5f}")
+        print(f"cycle {c}: old handle, first / second launch after " + "; ".join(line), flush=True)
+        del host, pinned, devbuf, big
+        continue
     if mode in ("allocfree", "bigfree"):
         # no open at all: device allocations made and given back to the driver (a small reference handle: a few hipMalloc / hipFree
         # of KB-sized buffers; "bigfree": a 1 GiB block through the library's pool and kcfx_release_cached), then the OLD handle
