@@ -1112,7 +1112,9 @@ int32_t kcfx_db_open_slice(const char* kmc_prefix, int32_t device, const kcfx_db
     // (a denser table helps when the table itself did not fit, or when the streaming's buffers lost the race for the memory to
     // it -- not when a later step failed: a stash that does not fit only grows with a denser table)
     if (rc == KCFX_ERR_DEVICE && db->fmt == FORMAT_CELLS && (db->regions > 1 || db->lbits - 1 >= cell_lbits_min(db->info.both_strands != 0)) &&
-        (db->alloc_oom || (db->alloc_rc == KCFX_OK && !db->table_arrived))) {
+        (db->alloc_oom || (db->alloc_rc == KCFX_OK && !db->table_arrived) || (db->regions > 1 && db->table_arrived))) {
+        // (... or a table of several regions -- grown up to 80 % of the free memory -- fitted and what comes after it did not: the
+        // stash, the crowding counters, the streaming buffers. The power of two below it leaves them a third or more of the table.)
         // the policy's table did not fit next to what else lives on the device: denser cell tables, allocated synchronously
         // (a table of R regions that did not fit: the power of two below it -- (3 << L) -> 2^(L + 1), (5 | 7) << L -> 2^(L + 2) -- as one region)
         const int32_t cap = db->regions > 1 ? std::min(cells_lbits_cap(db->info.kmer_length), db->lbits + (db->regions == 3 ? 1 : 2)) : db->lbits - 1;

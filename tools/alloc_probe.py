@@ -29,17 +29,8 @@ def t(db, n=300):
 for rep in range(2):
     print("round", rep, " ".join(f"{t(db):.5f}" for db in dbs), flush=True)
 # the same handles against a second reference (other addresses for text, plan and bitmaps): is a handle's speed its own?
-# ... and with the Infinity Cache swept between launches (a 1 GiB memset): is the fast speed the plan being served from there?
-flush = torch.zeros(1 << 30, dtype=torch.uint8, device="cuda:0")
-def t_cold(db, n=60):
-    ref.prof_enable(True); ref.prof_read(reset=True)
-    for _ in range(n):
-        flush.fill_(1)
-        ref.screen_async(db, out.data_ptr(), st.cuda_stream, 1)
-    torch.cuda.synchronize()
-    ms, c = ref.prof_read(reset=True); ref.prof_enable(False)
-    return ms / c
-print("swept round", " ".join(f"{t_cold(db):.5f}" for db in dbs), flush=True)
+# (the cache-state experiments -- read-only sweep, dirty sweep, first launch on a fresh handle -- live in tools/cache_state_probe.py and
+# tools/first_pass_probe.py since round 5: the 1 GiB fill_ that stood here left the caches dirty and measured its own write-back)
 keep = [ref]
 for j, pad_mb in enumerate((300, 5000, 40000)):
     pad = torch.zeros(pad_mb * 1_000_000, dtype=torch.uint8, device="cuda:0")      # (moves the next allocations somewhere else)
