@@ -271,16 +271,25 @@ def realistic_leg(engine, torch, synth_bin, workdir, ref_len, window, min_count,
                      count-1 k-mers in runs around substitution errors, which share minimizers and cells with their originals;
       k25            KMC's default k (W = 10 of a line's 16 cells: shorter minimizer runs, more lines per k-mer);
       repeats        reference and sample with genome structure (TE families, satellite arrays, segmental duplications,
-                     microsatellites: kcfx_synth --repeats 0.3): crowded minimizers.
+                     microsatellites: kcfx_synth --repeats 0.3): crowded minimizers;
+      dense_table    the headline's kind of database in a table of 0.28 k-mers per cell (KCFX_TABLE_LBITS=25) instead of 0.07: the
+                     density a database of billions of k-mers gets on one device.
     Per input: the screening kernel's average (HIP events on the launch) of the one-pass form (text-only reference, K1 - K3 in one
     launch) and of the amortised form (planned reference), as fractions of the HBM roofline at 1 + 8 + counter_size bytes per k-mer."""
     from oracle import binding as oracle
     out = {}
-    cases = (("read_error_db", 31, 7, ["--error-events", "4500000", "--noise", "0"]),
-             ("k25", 25, 5, ["--noise", str(max(0, 150_000_000 - int(0.885 * ref_len)))]),
-             ("repeats", 31, 7, ["--repeats", "0.3", "--noise", str(max(0, 150_000_000 - int(0.885 * ref_len)))]))
-    for name, k, p, extra in cases:
+    noise = str(max(0, 150_000_000 - int(0.885 * ref_len)))
+    # (dense_table: the HEADLINE database in a table of the density the size policy gives a database of billions of k-mers -- 0.28
+    # per cell, 2^25 lines instead of 2^27 -- where the headline's table has 0.07: what the 14 x memory of the sparse table buys)
+    cases = (("read_error_db", 31, 7, ["--error-events", "4500000", "--noise", "0"], None),
+             ("k25", 25, 5, ["--noise", noise], None),
+             ("repeats", 31, 7, ["--repeats", "0.3", "--noise", noise], None),
+             ("dense_table", 31, 7, ["--noise", noise], "25"))
+    for name, k, p, extra, lbits in cases:
         try:
+            prev_lbits = os.environ.get("KCFX_TABLE_LBITS")
+            if lbits and prev_lbits is None:
+                os.environ["KCFX_TABLE_LBITS"] = lbits      # (read when a handle is made; removed again below; a value the user set stays)
             prefix = os.path.join(workdir, f"real_{name}_r{ref_len}")
             if not os.path.exists(prefix + ".meta.json"):
                 cmd = [synth_bin, "--out", prefix, "--ref-len", str(ref_len), "--seed", "1", "--sample-seed", "2", "--k", str(k), "--p", str(p),
@@ -331,6 +340,9 @@ def realistic_leg(engine, torch, synth_bin, workdir, ref_len, window, min_count,
             out[name] = res
         except Exception as exc:                     # the bench line must not die on an extra leg
             out[name] = {"error": str(exc)[:300]}
+        finally:
+            if lbits and prev_lbits is None:
+                os.environ.pop("KCFX_TABLE_LBITS", None)
     engine.release_cached()
     return out
 

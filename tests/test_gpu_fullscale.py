@@ -216,6 +216,25 @@ def test_eight_samples_in_one_pass(oracle, genome, cohort):
         assert np.array_equal(np.sort(obs_col), np.sort(got[s]["obs"]))
 
 
+def test_table_slices_at_genome_scale(genome, cohort):
+    """KCFX_SHARD_TABLE at the size of BASELINE configs[3]: two samples of the 119 Mb genome (150 M and 100 M k-mers), each one's
+    TABLE cut into three slices by minimizer (three workers on the one GPU), every slice screened against all 11 953 windows, the hit
+    bitmaps merged: every record equal to the unsharded call's; and the gene-like short windows of the sharding fixture's kind."""
+    wb, wl = tiling(10_000)
+    prefixes = [genome["prefix"], cohort[3]]
+    t0 = time.time()
+    got, st = engine.screen_sharded(prefixes, K, genome["text"], wb, wl, 1, devices=(0, 0, 0), mode=engine.SHARD_TABLE)
+    t_tab = time.time() - t0
+    assert st.shard_mode_used == engine.SHARD_TABLE and got.shape == (2, len(wb))
+    want0 = genome["db"].screen(genome["text"], wb, wl, 1)
+    want1 = engine.KmcDb.open(cohort[3]).screen(genome["text"], wb, wl, 1)
+    for f in FIELDS:
+        assert np.array_equal(got[0][f], want0[f]) and np.array_equal(got[1][f], want1[f]), f
+    assert int(got[0]["total_kmers"].sum()) > 0.97 * len(genome["text"]) and 0.5 < got[0]["obs"].sum() / got[0]["total_kmers"].sum() < 0.9
+    print(f"table slices: 2 samples x 3 slices x {len(wb)} windows in {t_tab:.2f} s (loads {st.seconds_db_open_sum:.2f} s summed, "
+          f"screening + merge {st.seconds_screen_sum:.3f} s)")
+
+
 def test_repeat_structured_genome_at_chr1_scale(oracle, tmp_path_factory):
     """Inputs with genome structure (kcfx_synth --repeats 0.45: TE families at 80 - 95 % identity, tandem satellite arrays,
     segmental duplications, microsatellites -- in the reference AND the sample genome, which is derived from it) at the size of
