@@ -698,6 +698,12 @@ def test_fuzz_window_geometry_against_oracle(oracle, tmp_path, seed, kernel, mon
     want = odb.screen(ref, begins, lens, minc, threads=4)
     assert_same(got, want, f"fuzz seed {seed} (k={k}, cs={cs}, both={both}, -c {minc}, table of {db.info.table_lines} lines, "
                            f"regions {db.info.regions}, extended {db.info.extended})")
+    if cells and seed % 2 == 0:
+        # ... and the same database as 2 / 3 / 4 TABLE SLICES (kcfx_db_open_slice: whatever shape the table was forced into above, every
+        # slice gets it), each screened against every window, the bitmaps merged (KCFX_SHARD_TABLE)
+        n = 2 + (seed // 2) % 3
+        sl, _ = engine.screen_sharded([prefix], k, ref, begins, lens, minc, devices=(0,) * n, mode=engine.SHARD_TABLE)
+        assert_same(sl[0], want, f"fuzz seed {seed}: {n} table slices (k={k}, cs={cs}, both={both}, -c {minc}, kernel {kernel})")
     assert_scores(oracle, got, want)
 
 
