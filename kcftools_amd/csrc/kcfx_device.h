@@ -303,11 +303,28 @@ KCFX_HD uint32_t cell_rmask(int32_t lbits, bool both) {          // the bits of 
 KCFX_HD uint32_t cell_spare_bits(int32_t lbits, bool both) {     // filter bits of a flagged cell
     return (uint32_t)(lbits - cell_lbits_min(both)) - (cell_has_third(lbits, both) ? 1u : 0u);
 }
-// bit position inside r of the filter bit of a k-mer with flank w (meaningful only when cell_spare_bits() > 0)
-KCFX_HD uint32_t cell_filter_pos(uint32_t w, int32_t lbits, bool both) {
-    const uint32_t h = w * 0x9E3779B1u;                         // single-base neighbours must spread: multiplicative hash
+// Bit position inside r of the filter bit of a k-mer with flank w in a flagged cell that holds x (meaningful only when
+// cell_spare_bits() > 0). Round 5: the bit is chosen by HOW THE K-MER DIFFERS FROM THE CELL'S OCCUPANT -- the xor of the two flanks,
+// which cell_flank lays out relative to the minimizer, so that a base at a given distance from the minimizer is the same two bits
+// whatever cell (offset) the k-mer has -- not by its own flank alone. In a database counted from reads the k-mers that lose a
+// genomic k-mer's cell are its sequencing-error neighbours, and a reference k-mer that carries a variant is such a neighbour too:
+// with the flank as the key every cell of the ~10 that a minimizer run around the variant visits drew its own bit (~30 % set each:
+// the run was sent on to its second line with near certainty); with the difference as the key all of them ask for the SAME bit,
+// which the handful of error events around that minimizer have set or not -- the whole run is sent on or none of it. Build and
+// query agree because a flag is only ever keyed by an occupant that no longer changes (first-choice occupants are final before the
+// settle pass, second- / third-line ones once taken); a flag on a still-EMPTY cell sets every filter bit (cell_filter_all). A
+// difference in several bases, an unrelated occupant: some bit, the same on both sides. Costs the query nothing: the xor is the
+// one its compare needs anyway.
+KCFX_HD uint32_t cell_filter_key(uint32_t w, uint32_t x) { return (x & ~CELL_FLAG_MASK) ^ w; }
+KCFX_HD uint32_t cell_filter_pos(uint32_t w, uint32_t x, int32_t lbits, bool both) {
+    const uint32_t h = cell_filter_key(w, x) * 0x9E3779B1u;
     const uint32_t rb = (uint32_t)(32 - lbits);
     return rb + (uint32_t)(((uint64_t)h * cell_spare_bits(lbits, both)) >> 32);
+}
+// every filter bit of a cell (as a mask inside r): what flagging an EMPTY cell sets -- whoever takes the cell later is not the
+// occupant the flag could have been keyed by
+KCFX_HD uint32_t cell_filter_all(int32_t lbits, bool both) {
+    return ((1u << cell_spare_bits(lbits, both)) - 1u) << (32 - lbits);
 }
 // the bits of a 64-bit cell word that identify the k-mer and carry its counter (flags and filter bits excluded)
 KCFX_HD uint64_t cell_keycount_mask(int32_t lbits, bool both) {
@@ -323,13 +340,17 @@ KCFX_HD constexpr uint32_t cell_mmask(int M) { return 0xFFFFFFFFu << (32 - 2 * M
 // reverse complement of a left-aligned M-mer (comp_swap also complements the padding; the shift drops it)
 KCFX_HD uint32_t rc_mmer(uint32_t m, int M) { return brev32(comp_swap(m)) << (32 - 2 * M); }
 
-// the 15 bases of N around the M-mer at base offset sh / 2, left-aligned (low 2 bits zero); *m_out = that M-mer
+// the k - 16 bases of N around the M-mer at base offset sh / 2, laid out RELATIVE TO THE M-MER (round 5): the bases behind it
+// left-aligned from bit 31 down (the first one behind it in bits 31..30), the sh / 2 bases in front of it right-aligned above the
+// two flag bits (the last one in front of it in bits 3..2), zeros between and in bits 1..0. A base at a given distance from the
+// minimizer has the same two bits in every cell of a line -- what cell_filter_key relies on, and what makes "the three bases next
+// to the minimizer" (cell_third_line, cell_ext_select) a constant shift. *m_out = that M-mer
 KCFX_HD uint32_t cell_flank(uint64_t N, uint32_t sh, int M, uint32_t* m_out) {
     const uint64_t t = N << sh;
-    const uint32_t keep = 0xFFFFFFFFu >> sh;                  // bits that come from behind the M-mer
     *m_out = (uint32_t)(t >> 32) & cell_mmask(M);
     const uint32_t behind = M == 16 ? (uint32_t)t : (uint32_t)((t << (2 * M)) >> 32);
-    return (keep & (behind >> sh)) | (~keep & (uint32_t)(N >> 32));
+    const uint32_t front = (uint32_t)(N >> (62u - sh)) & ~3u;     // the top sh bits of N at bits sh + 1 .. 2
+    return behind | front;
 }
 
 struct CellProbe {
@@ -401,9 +422,9 @@ KCFX_HD CellProbe cell_second_line(const CellProbe& p, int32_t lbits) {
 // bases on) and up to three bases there. (sh, w) are compared with the entry, so (line, r, sh, w) still identify the k-mer.
 KCFX_HD CellProbe cell_third_line(const CellProbe& p, int32_t lbits, bool both, int W) {
     const uint32_t idm = 0xFFFFFFFFu >> lbits;
-    // the flank: its first sh bits are the sh / 2 bases in front of the minimizer, the rest the bases behind it (cell_flank)
+    // the flank: the bases in front of the minimizer end at bit 2, those behind it start at bit 31 (cell_flank)
     const bool before = (int)p.sh >= W;                           // offset >= W / 2: more bases in front (sh >= 4 there: W >= 4)
-    const uint32_t near6 = before ? (p.w >> (32u - p.sh)) & 63u : (p.w >> (26u - p.sh)) & 63u;
+    const uint32_t near6 = before ? (p.w >> 2) & 63u : p.w >> 26;
     const uint32_t e = (near6 << 1) | (before ? 1u : 0u);
     const uint32_t g2 = cell_g32b((p.line << (32 - lbits)) | (p.r & idm));
     const uint32_t g3 = cell_g32b(g2 ^ ((e + 1u) * 0x9E3779B1u));
@@ -425,7 +446,7 @@ KCFX_HD CellProbe cell_third_line(const CellProbe& p, int32_t lbits, bool both, 
 // what a cell compares, so (line, r, sh, w) still identify the k-mer exactly.
 KCFX_HD uint32_t cell_ext_select(uint32_t w, uint32_t sh) {
     const bool before = sh >= 6u;
-    const uint32_t near6 = before ? (w >> (32u - sh)) & 63u : (w >> (26u - sh)) & 63u;
+    const uint32_t near6 = before ? (w >> 2) & 63u : w >> 26;
     return (((near6 << 1) | (before ? 1u : 0u)) + 1u) * 0x9E3779B1u;
 }
 KCFX_HD uint32_t cell_g32_ext(uint32_t g, uint32_t w, uint32_t sh) { return cell_g32b(g ^ cell_ext_select(w, sh)); }

@@ -406,17 +406,26 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, in
             if (!rp.mine(p, lbits)) return;
             ++nc;
             uint8_t* line = lines + (size_t)cell_line_index(p.line, p.r, lbits, rp.regions) * LINE_BYTES;
-            unsigned long long mark = CELL_FLAG_STASH;
-            if (cell_spare_bits(lbits, both) > 0) mark |= 1ull << (32 + cell_filter_pos(p.w, lbits, both));
+            // "someone who belongs here lives elsewhere" + this k-mer's filter bit IN THAT CELL: keyed by how its flank differs from the
+            // occupant's (cell_filter_pos) -- the occupant as it stands now, which is final (see there); every bit for an empty cell
+            auto flag = [&](unsigned long long* cell, uint32_t w) {
+                unsigned long long mark = CELL_FLAG_STASH;
+                if (cell_spare_bits(lbits, both) > 0) {
+                    const unsigned long long now = __atomic_load_n(cell, __ATOMIC_RELAXED);
+                    mark |= (now >> 48) == 0 ? (unsigned long long)cell_filter_all(lbits, both) << 32
+                                             : 1ull << (32 + cell_filter_pos(w, (uint32_t)now, lbits, both));
+                }
+                atomicOr(cell, mark);
+            };
             if (wide) {
                 // never bid: every cell a query could derive for it -- first choice and second line -- is flagged (whoever lives
                 // there, or nobody), with its filter bit
                 const CellProbe q = cell_second_line(p, lbits);
-                atomicOr(reinterpret_cast<unsigned long long*>(line + 4 * p.sh), mark);
-                atomicOr(reinterpret_cast<unsigned long long*>(lines + cell_byte_at(q, lbits, rp.regions)), mark);
+                flag(reinterpret_cast<unsigned long long*>(line + 4 * p.sh), p.w);
+                flag(reinterpret_cast<unsigned long long*>(lines + cell_byte_at(q, lbits, rp.regions)), q.w);
                 if (cell_has_third(lbits, both)) {
                     const CellProbe t = cell_third_line(p, lbits, both, cell_nw(k));
-                    atomicOr(reinterpret_cast<unsigned long long*>(lines + cell_byte_at(t, lbits, rp.regions)), mark);
+                    flag(reinterpret_cast<unsigned long long*>(lines + cell_byte_at(t, lbits, rp.regions)), t.w);
                 }
                 lost = true;
                 return;
@@ -444,12 +453,12 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, in
             // the same cell of its second line: the first-choice cell says "look on" (flag + filter bit)
             const CellProbe q = cell_second_line(p, lbits);
             unsigned long long* there = reinterpret_cast<unsigned long long*>(lines + cell_byte_at(q, lbits, rp.regions));
-            atomicOr(reinterpret_cast<unsigned long long*>(line + 4 * p.sh), mark);
+            flag(reinterpret_cast<unsigned long long*>(line + 4 * p.sh), p.w);
             if (take(there, cell_word(q.w, q.r, c), cell_keycount_mask(lbits, both))) {
                 ++n_second;
                 return;
             }
-            atomicOr(there, mark);                                           // ... and so does the second-line cell
+            flag(there, q.w);                                                // ... and so does the second-line cell (occupied: take() failed)
             if (cell_has_third(lbits, both)) {
                 // the same cell of its third line: where the losers of DIFFERENT loci with this minimizer part ways
                 const CellProbe t = cell_third_line(p, lbits, both, cell_nw(k));
@@ -458,7 +467,7 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, in
                     ++n_second;
                     return;
                 }
-                atomicOr(third, mark);                                       // ... and the third-line cell: the stash
+                flag(third, t.w);                                            // ... and the third-line cell: the stash
             }
             lost = true;
         });
@@ -540,9 +549,9 @@ __global__ __launch_bounds__(256) void lookup_cells_kernel(TableView tv, int32_t
             const uint64_t first = *reinterpret_cast<const uint64_t*>(line + 4 * c0.sh);
             const uint64_t KEY_BITS = cell_keycount_mask(tv.lbits, both) & 0x0000FFFFFFFFFFFFull;     // w without the flags, r without the filter
             // "someone who belongs in this cell lives elsewhere" and, when the table has filter bits, "with my filter bit"
-            auto sent_on = [&](uint64_t cell) {
+            auto sent_on = [&](uint64_t cell) {            // (w is the same in every line of the k-mer; the occupant is the cell's own)
                 return (cell & CELL_FLAG_STASH) &&
-                       (cell_spare_bits(tv.lbits, both) == 0 || ((cell >> (32 + cell_filter_pos(c0.w, tv.lbits, both))) & 1));
+                       (cell_spare_bits(tv.lbits, both) == 0 || ((cell >> (32 + cell_filter_pos(c0.w, (uint32_t)cell, tv.lbits, both))) & 1));
             };
             bool found = false;
             if (((first ^ cell_word(c0.w, c0.r, 0)) & KEY_BITS) == 0 && (first >> 48) != 0) {
@@ -1369,7 +1378,9 @@ __device__ __forceinline__ void cells_match(const CellWord& cw, int32_t lbits, u
         // (an invalid lane has loaded cell 0 of line 0 and compared it with whatever its bases encode: never a match -- the
         // validity mask is AND-ed to the compares' on the scalar unit)
         // (ballots AND-ed, not `&&`: both compares for every lane, no exec juggling for a short circuit)
-        const uint64_t FM = cw.V & wave_ballot((x ^ cw.w) <= CELL_FLAG_MASK) & wave_ballot(((y ^ cw.r) & rmask) == 0);
+        // (d: how the cell's flank differs from this lane's, flags aside -- one v_bitop3; zero = the same flank; also the filter's key)
+        const uint32_t d = (x & ~CELL_FLAG_MASK) ^ cw.w;
+        const uint64_t FM = cw.V & wave_ballot(d == 0u) & wave_ballot(((y ^ cw.r) & rmask) == 0);
         const bool first = __builtin_amdgcn_inverse_ballot_w64(FM);
         if (matched) *matched = FM;                         // (k <= 30 with the retired free-cell scheme: first-choice matches only)
         if constexpr (W <= CELL_ALT_FREE_MAX_W) {
@@ -1384,7 +1395,8 @@ __device__ __forceinline__ void cells_match(const CellWord& cw, int32_t lbits, u
         // the stash only if the cell is flagged AND (when the table has filter bits) the bit of this flank is set.
         // "cnt == 0", not "no match": an EMPTY cell can be flagged (a k-mer whose counter does not fit 16 bits never takes
         // a cell) and would "match" the k-mer whose w and r are all zero
-        const uint32_t mine = (y >> (rb + __umulhi(cw.w * 0x9E3779B1u, nspare))) | unfiltered;
+        // (cell_filter_pos: the bit is chosen by how this flank differs from the occupant's -- d, cell_filter_key)
+        const uint32_t mine = (y >> (rb + __umulhi(d * 0x9E3779B1u, nspare))) | unfiltered;
         pend = x & mine & CELL_FLAG_STASH;
     }
 }
@@ -1666,29 +1678,34 @@ __device__ __forceinline__ int k31c_deferred_round(const TableView& tv, const Ld
         const size_t cell = (size_t)cell_line_index(q2.line, q2.r, tv.lbits, tv.regions) * 16 + (q2.sh >> 1);
         const uint2 e = reinterpret_cast<const uint2*>(tv.lines)[cell];      // (plain: with the non-temporal hint this one is slower)
         const uint32_t rmask = cell_rmask(tv.lbits, BOTH);
-        if (((e.x ^ q2.w) <= CELL_FLAG_MASK) && (((e.y ^ q2.r) & rmask) == 0) && (e.y >> 16) != 0u) {
-            found(id, e.y >> 16, (uint32_t)cell, false);
-        } else {
-            const uint32_t nspare = cell_spare_bits(tv.lbits, BOTH);
-            // (w is the same in every line of the k-mer: so is its filter bit)
-            const uint32_t fpos = nspare == 0 ? 0u : cell_filter_pos(q2.w, tv.lbits, BOTH);
-            bool on = (e.x & CELL_FLAG_STASH) && (nspare == 0 || ((e.y >> fpos) & 1u));
-            if (on && cell_has_third(tv.lbits, BOTH)) {
+        const uint32_t nspare = cell_spare_bits(tv.lbits, BOTH);
+        // a cell that does not hold the k-mer sends it on if it is flagged and (a table with filter bits) the k-mer's bit there is
+        // set: w is the same in every line of the k-mer, its bit in a cell depends on that cell's occupant (cell_filter_pos).
+        // (level after level, no nesting and no short circuits: the structurizer made a loop with spilled masks of the nested form)
+        auto holds = [&](const uint2& c, const CellProbe& q) {
+            return (((c.x ^ q.w) <= CELL_FLAG_MASK) & (((c.y ^ q.r) & rmask) == 0) & ((c.y >> 16) != 0u)) != 0;
+        };
+        auto sends_on = [&](const uint2& c, const CellProbe& q) {
+            const uint32_t bit = nspare == 0 ? 1u : (c.y >> cell_filter_pos(q.w, c.x, tv.lbits, BOTH)) & 1u;
+            return (c.x & CELL_FLAG_STASH & bit) != 0u;                 // (CELL_FLAG_STASH is bit 0)
+        };
+        const bool hit2 = holds(e, q2);
+        if (hit2) found(id, e.y >> 16, (uint32_t)cell, false);
+        bool on = !hit2 && sends_on(e, q2);
+        if (cell_has_third(tv.lbits, BOTH)) {                // (wave-uniform)
+            if (on) {
                 // its third line: the losers of this minimizer's other loci are not here
                 const CellProbe q3 = cell_third_line(p, tv.lbits, BOTH, cell_nw(K));
                 const size_t cell3 = (size_t)cell_line_index(q3.line, q3.r, tv.lbits, tv.regions) * 16 + (q3.sh >> 1);
                 const uint2 e3 = reinterpret_cast<const uint2*>(tv.lines)[cell3];
-                if (((e3.x ^ q3.w) <= CELL_FLAG_MASK) && (((e3.y ^ q3.r) & rmask) == 0) && (e3.y >> 16) != 0u) {
-                    found(id, e3.y >> 16, (uint32_t)cell3, false);
-                    on = false;
-                } else {
-                    on = (e3.x & CELL_FLAG_STASH) && (nspare == 0 || ((e3.y >> fpos) & 1u));
-                }
+                const bool hit3 = holds(e3, q3);
+                if (hit3) found(id, e3.y >> 16, (uint32_t)cell3, false);
+                on = !hit3 && sends_on(e3, q3);
             }
-            if (on) {
-                const uint32_t slot = stash_find_slot(tv, key);
-                if (slot != ~0u) found(id, tv.stash[slot].z, slot, true);
-            }
+        }
+        if (on) {
+            const uint32_t slot = stash_find_slot(tv, key);
+            if (slot != ~0u) found(id, tv.stash[slot].z, slot, true);
         }
     }
     wave_lds_fence();
