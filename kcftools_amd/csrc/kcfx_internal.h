@@ -53,13 +53,13 @@ constexpr int MODE_KEYHASH = 0, MODE_MINIMIZER = 1;
 // cooperative line fetch, no LDS staging, no 12-way 64-bit compare. A cell holds a quotiented key, exact by construction:
 //
 //   128-byte line = 16 x 8-byte cell;  cell = u32 w | u16 r | u16 count
-//     w     = the flank bits (the k - 16 <= 15 bases of N around the minimizer, left-aligned in 30 bits) | bit 0: some k-mer that maps
+//     w     = the flank bits (the k - 16 <= 15 bases of N around the minimizer, laid out relative to it: cell_flank) | bit 0: some k-mer that maps
 //             to this cell lives elsewhere (second line or stash) | bit 1: the occupant is of the "crowded" class (build time only)
 //     r     = low (32 - lbits) bits of G32 = a 32-bit mix of the canonical minimizer 16-mer; the line number is the top
 //             lbits of G32, and G32 <-> minimizer is a bijection (cell_g32)
 //             (at most 15 bits: lbits >= 17) | bit 15: this k-mer does NOT sit in its first-choice cell | the lbits - 17 bits in
-//             between: in a flagged cell, a one-hash Bloom filter of the flanks of the k-mers that were sent on
-//             (cell_filter_pos) -- a query that misses in a flagged cell looks further only if its bit is set
+//             between: in a flagged cell, a one-hash Bloom filter of the k-mers that were sent on, keyed by how their flank
+//             differs from the occupant's (cell_filter_pos) -- a query that misses in a flagged cell looks further only if its bit is set
 //     count = the stored counter; 0 = empty cell (a k-mer whose counter is 0 can never be observed -- GetVariants.java:224
 //             needs count >= -c >= 1 -- so it is not stored). A counter beyond 65535 (3- / 4-byte counters only) does not
 //             fit: that k-mer never takes a cell, it flags the cells it would have -- occupied or empty -- and lives in
