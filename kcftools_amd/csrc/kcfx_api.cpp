@@ -128,6 +128,7 @@ struct kcfx_db {
     int32_t alloc_rc = KCFX_OK;          // written by alloc_thread, read after the join
     std::string alloc_error;
     bool alloc_oom = false;
+    std::atomic<bool> alloc_go{false};       // the loader has taken its own buffers: the table's allocation may start (it holds the driver for seconds)
     std::atomic<bool> alloc_landed{false};   // alloc_thread: the table's memory has been taken (hipMemGetInfo no longer counts it as free)
     bool table_arrived = false;          // table_ready() has succeeded: a later device error is not about the table's size
     int32_t fmt = FORMAT_LINES;          // FORMAT_CELLS: d_lines holds 1 << lbits cell lines, d_stash the overflow k-mers
@@ -345,6 +346,7 @@ void cells_regions(int64_t n_keys, int32_t k, bool both, int32_t L0, size_t free
 
 // the deferred half of cells_alloc: join the allocation thread, report what it found
 int32_t table_ready(kcfx_db* db) {
+    db->alloc_go = true;
     if (db->alloc_thread.joinable()) db->alloc_thread.join();
     if (db->alloc_rc != KCFX_OK) return fail(db->alloc_rc, db->alloc_error);
     db->table_arrived = true;
@@ -402,6 +404,7 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys, bool deferred = false) {
     db->alloc_rc = KCFX_OK;
     db->alloc_oom = false;
     db->alloc_landed = false;
+    db->alloc_go = false;
     db->table_arrived = false;
     if (deferred && Lr >= cell_lbits_min(both) && (double)n_keys <= 16.0 * (double)((uint64_t)R << Lr)) {
         // the policy's size, allocated and cleared beside the file streaming; if it does not fit, kcfx_db_open starts over
@@ -417,6 +420,10 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys, bool deferred = false) {
         db->info.slots_per_line = 16;
         db->alloc_thread = std::thread([db]() {
             try {
+                // (the driver serves one allocation at a time and a table of 200 GB holds it for 5 - 6 s: the loader's own buffers --
+                // a few hundred MB, or the resident records -- go first, or its first pass over the file starts that much later;
+                // alloc_go comes from load_suffix_file, from whoever waits for the table, or after five seconds)
+                for (int waited = 0; !db->alloc_go && waited < 25000; ++waited) std::this_thread::sleep_for(std::chrono::microseconds(200));
                 hipError_t e2 = hipSetDevice(db->device);
                 if (e2 == hipSuccess) e2 = dev_alloc(&db->d_lines, (size_t)LINE_BYTES * db->n_lines);
                 if (e2 == hipSuccess) db->alloc_landed = true;
@@ -503,6 +510,7 @@ int32_t cells_stash_alloc(kcfx_db* db) {
 
 // back to "no table" (the handle keeps its stream and header fields): before a rebuild in the other format
 void table_release(kcfx_db* db) {
+    db->alloc_go = true;
     if (db->alloc_thread.joinable()) db->alloc_thread.join();
     (void)hipStreamSynchronize(db->stream);
     if (db->d_lines) (void)dev_free(db->d_lines);
@@ -585,6 +593,7 @@ int32_t table_finish(kcfx_db* db) {
 
 void db_free(kcfx_db* db) {
     if (!db) return;
+    db->alloc_go = true;
     if (db->alloc_thread.joinable()) db->alloc_thread.join();
     DeviceGuard g(db->device);
     if (db->stream) (void)hipStreamSynchronize(db->stream);   // shared per device (db_stream), never destroyed
@@ -663,13 +672,25 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     uint8_t* d_ps = nullptr;
     uint8_t* d_raw = nullptr;          // the .kmc_suf records as the file holds them, resident between the passes (see below)
     uint32_t* d_pop2 = nullptr;        // the crowding counters of the OTHER form of the table (extended), counted in the same first pass
-    hipEvent_t done[2] = {nullptr, nullptr};
+    LostList lost;                     // the k-mers the settle pass counts for the stash, written down (records not resident: see below)
+    hipEvent_t done[2] = {nullptr, nullptr};       // the copy of chunk buffer [i] to the device has finished (recorded on `copier`)
+    hipEvent_t decoded[2] = {nullptr, nullptr};    // the decode of d_rec[i] has finished (recorded on db->stream)
+    // The uploads run on a stream of their own (round 5): chunk n + 1 crosses PCIe while chunk n is decoded and applied -- on
+    // db->stream alone the copy waited for the table pass of the chunk before it, and a streamed pass over a 65 GB file took 2.5 s
+    // where the link and the page cache deliver it in 1.5 s (tools: 56 GB/s H2D, 60 GB/s pread, 45 GB/s both at once).
+    hipStream_t copier = nullptr;
     int32_t rc = KCFX_OK;
     auto cleanup = [&]() {
-        // the temporaries are used on db->stream only: wait for that stream, not for the device (the other worker's
+        // the temporaries are used on db->stream and the copier only: wait for those, not for the device (the other worker's
         // screening kernel, the next database's uploads)
+        if (copier) (void)hipStreamSynchronize(copier);
         (void)hipStreamSynchronize(db->stream);
+        if (copier) (void)hipStreamDestroy(copier);
+        copier = nullptr;
         if (d_raw) (void)dev_free_idle(d_raw);
+        if (lost.keys) (void)dev_free_idle(lost.keys);
+        if (lost.counts) (void)dev_free_idle(lost.counts);
+        if (lost.n) (void)dev_free_idle(lost.n);
         if (d_pop2) (void)dev_free_idle(d_pop2);
         if (d_pw) (void)dev_free_idle(d_pw);
         if (d_ps) (void)dev_free_idle(d_ps);
@@ -677,6 +698,7 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
             if (h_buf[i]) (void)host_free(h_buf[i]);
             if (d_rec[i]) (void)dev_free_idle(d_rec[i]);
             if (done[i]) (void)hipEventDestroy(done[i]);
+            if (decoded[i]) (void)hipEventDestroy(decoded[i]);
         }
         if (d_lut) (void)dev_free_idle(d_lut);
         if (d_keys) (void)dev_free_idle(d_keys);
@@ -717,7 +739,9 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
         LOAD_HIP(host_alloc(&h_buf[i], (size_t)std::min(chunk_bytes, std::max<int64_t>(h.total * h.record_size, 16))));
         LOAD_HIP(dev_alloc(&d_rec[i], (size_t)n_chunk_max * h.record_size + 16));
         LOAD_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+        LOAD_HIP(hipEventCreateWithFlags(&decoded[i], hipEventDisableTiming));
     }
+    if (getenv("KCFX_LOAD_ONE_STREAM") == nullptr) LOAD_HIP(hipStreamCreateWithFlags(&copier, hipStreamNonBlocking));   // (A/B and test hook)
     LOAD_HIP(dev_alloc(&d_lut, (size_t)std::max<int64_t>(h.lut_entries, 1) * 8));
     LOAD_HIP(dev_alloc(&d_keys, (size_t)n_keys_buf * 8));
     LOAD_HIP(dev_alloc(&d_counts, (size_t)n_keys_buf * 4));
@@ -748,6 +772,7 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
         }
     }
     if (h.lut_entries) LOAD_HIP(hipMemcpyAsync(d_lut, h.lut_bytes, (size_t)h.lut_entries * 8, hipMemcpyHostToDevice, db->stream));
+    db->alloc_go = true;                                    // (the table's allocation, if it is still to come: from here on)
     tr.mark(raw_tier ? "buffers + LUT upload (records will stay resident)" : "buffers + LUT upload");
 
     // One pass of the build over a batch of decoded records. Line tables: 0 = count per home line (minimizer tables only),
@@ -768,7 +793,7 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
                           : launch_cells_count(db->d_pop, db->pop_bits, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream, 0, db->ext);
             }
             if (phase == 1 || phase == 2) return launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, phase == 1 ? 1 : 0, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream, 0, pw, ps, db->ext, db->regions, db->slicing());
-            if (phase == 3) return launch_cells_settle(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stats, db->stream, 0, pw, ps, db->ext, db->regions, db->slicing());
+            if (phase == 3) return launch_cells_settle(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stats, db->stream, 0, pw, ps, db->ext, db->regions, db->slicing(), lost);
             return launch_cells_stash(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stash, db->stash_mask, db->stream, 0, pw, ps, db->ext, db->regions, db->slicing());
         }
         if (phase == 0) return launch_table_count(db->d_lines, db->view(), h.k, keys, n, db->stream);
@@ -778,28 +803,47 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
         int64_t first = 0;
         int turn = 0;
         bool used[2] = {false, false};
+        hipStream_t const up = copier ? copier : db->stream;
+        if (copier) {                                       // whatever db->stream still does with d_rec / the LUT upload comes first
+            LOAD_HIP(hipEventRecord(decoded[0], db->stream));
+            LOAD_HIP(hipStreamWaitEvent(copier, decoded[0], 0));
+        }
+        double t_wait = 0, t_read = 0, t_copy = 0, t_pass0 = tr.on ? now_s() : 0;     // (KCFX_LOAD_TRACE: where the host side of a pass spends its time)
         while (first < h.total) {
             const int64_t n = std::min(CH, h.total - first);
             const int64_t bytes = n * h.record_size;
+            const double t_a = tr.on ? now_s() : 0;
             if (used[turn]) LOAD_HIP(hipEventSynchronize(done[turn]));      // the copy out of h_buf[turn] has finished
+            const double t_b = tr.on ? now_s() : 0;
             if (!parallel_pread(fd, h_buf[turn], bytes, 4 + first * h.record_size)) {
                 cleanup();
                 return fail(KCFX_ERR_IO, "short read on " + path);
             }
-            // d_rec[turn] was last read by the decode two chunks ago, which precedes this copy in stream order
+            const double t_c = tr.on ? now_s() : 0;
+            if (tr.on) {
+                t_wait += t_b - t_a;
+                t_read += t_c - t_b;
+            }
+            // d_rec[turn] was last read by the decode two chunks ago: before this copy in stream order, or (the copier) waited for
             // (the raw tier: the chunk lands in its place among the resident records)
             uint8_t* const rec_at = d_raw ? d_raw + (size_t)first * h.record_size : d_rec[turn];
-            LOAD_HIP(hipMemcpyAsync(rec_at, h_buf[turn], (size_t)bytes, hipMemcpyHostToDevice, db->stream));
-            LOAD_HIP(hipEventRecord(done[turn], db->stream));
+            if (copier && used[turn]) LOAD_HIP(hipStreamWaitEvent(copier, decoded[turn], 0));
+            LOAD_HIP(hipMemcpyAsync(rec_at, h_buf[turn], (size_t)bytes, hipMemcpyHostToDevice, up));
+            LOAD_HIP(hipEventRecord(done[turn], up));
+            if (copier) LOAD_HIP(hipStreamWaitEvent(db->stream, done[turn], 0));
             used[turn] = true;
+            if (tr.on) t_copy += now_s() - t_c;
             uint64_t* keys = d_keys + (keep ? first : 0);
             uint32_t* counts = d_counts + (keep ? first : 0);
             LOAD_HIP(launch_decode_records(rec_at, first, n, h.record_size, h.suffix_bytes, h.counter_size, h.p, d_lut,
                                            h.lut_entries, keys, counts, db->stream));
+            if (copier) LOAD_HIP(hipEventRecord(decoded[turn], db->stream));
             LOAD_HIP(apply(phase, keys, counts, n));
             first += n;
             turn ^= 1;
         }
+        if (tr.on) fprintf(stderr, "[kcfx load]   pass %d over the file: host %.0f ms = %.0f waiting for the upload two chunks back + %.0f reading + %.0f enqueueing the upload + %.0f launching\n", phase,
+                           (now_s() - t_pass0) * 1e3, t_wait * 1e3, t_read * 1e3, t_copy * 1e3, (now_s() - t_pass0 - t_wait - t_read - t_copy) * 1e3);
         return KCFX_OK;
     };
     // a later pass: straight from HBM when the decoded records were kept (launches of at most 2^30 records), else the
@@ -823,6 +867,27 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
         }
         LOAD_HIP(hipStreamSynchronize(db->stream));
         return stream_file(phase, false);
+    };
+    // Records that are not resident between the passes (the file is streamed once per pass): the settle pass writes the k-mers it counts
+    // for the stash down, and the stash is filled from that list instead of from one more stream of the file (an 8 G-k-mer database:
+    // 1.4 s of 12.6). Room for a sixteenth of the database, within a twentieth of the free memory (the stash itself comes out of the
+    // same memory next); a list that overflows is ignored. KCFX_LOAD_NO_LOST_LIST=1: never (A/B and test hook).
+    auto lost_list_alloc = [&]() {
+        if (!cells || resident || lost.keys || getenv("KCFX_LOAD_NO_LOST_LIST")) return;
+        unsigned long long cap = (unsigned long long)std::max<int64_t>(h.total / 16, 1024);
+        if (const char* s = getenv("KCFX_LOAD_LOST_CAP")) cap = std::max(1ull, strtoull(s, nullptr, 10));          // (test hook: an overflowing list)
+        else cap = std::min<unsigned long long>(cap, (unsigned long long)(0.05 * (double)free_device_bytes() / 12.0));
+        if (cap == 0) return;
+        if (dev_alloc(&lost.keys, (size_t)cap * 8) != hipSuccess || dev_alloc(&lost.counts, (size_t)cap * 4) != hipSuccess ||
+            dev_alloc(&lost.n, sizeof(unsigned long long)) != hipSuccess || hipMemsetAsync(lost.n, 0, sizeof(unsigned long long), db->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            if (lost.keys) (void)dev_free_idle(lost.keys);
+            if (lost.counts) (void)dev_free_idle(lost.counts);
+            if (lost.n) (void)dev_free_idle(lost.n);
+            lost = LostList();
+            return;
+        }
+        lost.cap = cap;
     };
     // Does this database want an EXTENDED table? Round 4 found out by building a plain one (four passes) and starting over when more
     // than EXT_MOVED_SHARE of the k-mers sat outside their first-choice cells. The crowding counters of pass 0 say as much before
@@ -892,8 +957,10 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
                     d_pop2 = nullptr;
                 }
             }
-            for (int phase = 1; phase <= 3; ++phase)
+            for (int phase = 1; phase <= 3; ++phase) {
+                if (phase == 3) lost_list_alloc();
                 if ((rc = later_pass(phase))) return rc;
+            }
             if (db->ext_auto && !db->ext) {
                 // how many k-mers sit outside their first-choice cell? (d_stats: [0] for the stash, [1] stored, [3] second / third lines)
                 unsigned long long st4[4] = {0, 0, 0, 0};
@@ -906,6 +973,7 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
                     LOAD_HIP(hipMemsetAsync(db->d_pop, 0, cells_pop_bytes(db->pop_bits), db->stream));
                     LOAD_HIP(hipMemsetAsync(db->d_stats, 0, 4 * sizeof(unsigned long long), db->stream));
                     tr.mark("plain table: too many k-mers outside their cell");
+                    if (lost.n) LOAD_HIP(hipMemsetAsync(lost.n, 0, sizeof(unsigned long long), db->stream));
                     for (int phase = 0; phase <= 3; ++phase)
                         if ((rc = later_pass(phase))) return rc;
                     tr.mark("rebuilt as an extended table");
@@ -921,7 +989,17 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
                 return rc;
             }
             tr.mark("bids + settle + stash alloc");
-            if ((rc = later_pass(4))) return rc;
+            // the stash: from the list the settle pass wrote, when it holds every k-mer that pass counted; else one more pass over the records
+            unsigned long long n_listed = ~0ull;
+            if (lost.keys) {
+                LOAD_HIP(hipMemcpyAsync(&n_listed, lost.n, sizeof n_listed, hipMemcpyDeviceToHost, db->stream));
+                LOAD_HIP(hipStreamSynchronize(db->stream));
+            }
+            if (lost.keys && n_listed <= lost.cap && n_listed == (unsigned long long)db->info.stash_kmers) {
+                if (tr.on) fprintf(stderr, "[kcfx load] the stash is filled from the %llu k-mers the settle pass wrote down\n", n_listed);
+                LOAD_HIP(launch_cells_stash(db->d_lines, db->info.kmer_length, db->lbits, db->info.both_strands, lost.keys, lost.counts, (int64_t)n_listed,
+                                            db->d_stash, db->stash_mask, db->stream, 0, nullptr, nullptr, db->ext, db->regions, db->slicing()));
+            } else if ((rc = later_pass(4))) return rc;
         } else {
             LOAD_HIP(launch_table_mark_heavy(db->d_lines, db->n_lines, db->stream));
             if ((rc = later_pass(1))) return rc;
@@ -1108,6 +1186,7 @@ int32_t kcfx_db_open_slice(const char* kmc_prefix, int32_t device, const kcfx_db
     if (!rc) rc = load_suffix_file(db, std::string(kmc_prefix) + ".kmc_suf", h);
     // (the allocation thread may still be running when the streaming failed first -- an I/O error, or the decoded arrays lost the
     // race for the memory to the table: join it before its outcome is read)
+    if (rc) db->alloc_go = true;
     if (rc && db->alloc_thread.joinable()) db->alloc_thread.join();
     // (a denser table helps when the table itself did not fit, or when the streaming's buffers lost the race for the memory to
     // it -- not when a later step failed: a stash that does not fit only grows with a denser table)

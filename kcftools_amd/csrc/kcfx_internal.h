@@ -324,8 +324,17 @@ hipError_t launch_cells_resolve(uint32_t* pop32, int32_t pop_bits, int32_t k, in
                                 uint64_t* pw, uint8_t* ps, hipStream_t st, int32_t ext = 0);
 hipError_t launch_cells_insert(uint8_t* lines, const uint32_t* pop32, int32_t pop_bits, int32_t cls, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys,
                                const uint32_t* counts, int64_t n, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr, int32_t ext = 0, int32_t regions = 1, int32_t slicing = 0);
+// what the settle pass counts for the stash, written down (round 5): keys / counts of `cap` entries and the number appended so far
+// (it keeps counting beyond cap: n > cap = the list is incomplete and the stash is filled from the records instead). keys == null: no list.
+struct LostList {
+    uint64_t* keys = nullptr;
+    uint32_t* counts = nullptr;
+    unsigned long long* n = nullptr;
+    unsigned long long cap = 0;
+};
 hipError_t launch_cells_settle(uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                               unsigned long long* stats, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr, int32_t ext = 0, int32_t regions = 1, int32_t slicing = 0);
+                               unsigned long long* stats, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr, int32_t ext = 0, int32_t regions = 1, int32_t slicing = 0,
+                               LostList lost = LostList());
 hipError_t launch_cells_stash(const uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
                               uint4* stash, uint32_t stash_mask, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr, int32_t ext = 0, int32_t regions = 1, int32_t slicing = 0);
 // (slicing: 0, or slices << 8 | slice -- the table is one slice of the database, kcfx_db_open_slice: the passes act on this slice's cells only)

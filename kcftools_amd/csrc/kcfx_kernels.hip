@@ -390,8 +390,10 @@ __device__ __forceinline__ int cell_standing(const uint8_t* lines, const CellPro
 // bit, cell_filter_pos) -- each only if still empty -- or is counted for the stash (then the second-line cell is flagged
 // too). stats[0] = k-mers for the stash, [1] = k-mers stored (count != 0), [2] = k-mers with more than one first-choice cell,
 // [3] = k-mers placed outside their first-choice cell
+// (lost: when the load cannot keep its records between the passes, the k-mers this pass counts for the stash are also WRITTEN DOWN --
+// key and counter, appended by the wave -- so that filling the stash needs no further pass over the file: LostList, kcfx_internal.h)
 __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, int32_t both_i, const uint64_t* __restrict__ keys,
-                                    const uint32_t* __restrict__ counts, int64_t n, unsigned long long* stats, int32_t presence, RecProbes rp) {
+                                    const uint32_t* __restrict__ counts, int64_t n, unsigned long long* stats, int32_t presence, RecProbes rp, LostList ll) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     uint32_t n_lost = 0, n_stored = 0, n_multi = 0, n_second = 0;      // per lane; one atomic per wave at the end
@@ -472,6 +474,20 @@ __global__ void cells_settle_kernel(uint8_t* lines, int32_t k, int32_t lbits, in
             lost = true;
         });
         if (nc == 0) continue;                          // (a table slice: none of its cells is here)
+        if (lost && ll.keys) {
+            // one atomic per wave: the lanes that are here take consecutive entries; an entry beyond the capacity is counted and not
+            // written (the load then fills the stash from the file as before)
+            const uint64_t here = __builtin_amdgcn_ballot_w64(true);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(here >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)here, 0u));
+            unsigned long long base = 0;
+            if (rank == 0) base = atomicAdd(ll.n, (unsigned long long)__popcll(here));
+            const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+            const unsigned long long at = (((unsigned long long)bhi << 32) | blo) + rank;
+            if (at < ll.cap) {
+                ll.keys[at] = keys[i];
+                ll.counts[at] = counts[i];
+            }
+        }
         n_lost += lost ? 1u : 0u;
         ++n_stored;
         n_multi += nc > 1 ? 1u : 0u;
@@ -2512,9 +2528,9 @@ hipError_t launch_pop_histogram(const uint32_t* pop32, int32_t pop_bits, unsigne
 
 
 hipError_t launch_cells_settle(uint8_t* lines, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                               unsigned long long* stats, hipStream_t st, int32_t presence, const uint64_t* pw, const uint8_t* ps, int32_t ext, int32_t regions, int32_t slicing) {
+                               unsigned long long* stats, hipStream_t st, int32_t presence, const uint64_t* pw, const uint8_t* ps, int32_t ext, int32_t regions, int32_t slicing, LostList lost) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(cells_settle_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, k, lbits, both, keys, counts, n, stats, presence, RecProbes{pw, ps, ext, regions, slicing});
+    hipLaunchKernelGGL(cells_settle_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, k, lbits, both, keys, counts, n, stats, presence, RecProbes{pw, ps, ext, regions, slicing}, lost);
     return hipGetLastError();
 }
 

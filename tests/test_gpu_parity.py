@@ -827,14 +827,22 @@ def test_every_load_tier_builds_the_same_table(oracle, tmp_path, monkeypatch):
         for ext in ("0", "1"):
             monkeypatch.setenv("KCFX_TABLE_EXT", ext)
             stats = {}
+            # (round 5, the tiers that keep no decoded records: the uploads ride a stream of their own -- KCFX_LOAD_ONE_STREAM=1 is the
+            # old order -- and the settle pass writes the k-mers of the stash down so that the stash needs no pass of its own:
+            # with the list, without it, and with a list too short to hold them)
             for tier, env in (("probes", {}), ("decoded", {"KCFX_LOAD_NO_PROBES": "1"}), ("raw", {"KCFX_LOAD_RAW": "1"}),
-                              ("streamed", {"KCFX_LOAD_STREAM_TWICE": "1"})):
+                              ("raw, no list", {"KCFX_LOAD_RAW": "1", "KCFX_LOAD_NO_LOST_LIST": "1"}),
+                              ("streamed", {"KCFX_LOAD_STREAM_TWICE": "1"}),
+                              ("streamed, one stream", {"KCFX_LOAD_STREAM_TWICE": "1", "KCFX_LOAD_ONE_STREAM": "1"}),
+                              ("streamed, no list", {"KCFX_LOAD_STREAM_TWICE": "1", "KCFX_LOAD_NO_LOST_LIST": "1"}),
+                              ("streamed, short list", {"KCFX_LOAD_STREAM_TWICE": "1", "KCFX_LOAD_LOST_CAP": "3"})):
                 for kk, v in env.items():
                     monkeypatch.setenv(kk, v)
                 db = engine.KmcDb.open(prefix)
                 for kk in env:
                     monkeypatch.delenv(kk)
                 i = db.info
+                assert int(i.stash_kmers) > 3, (name, ext, tier, int(i.stash_kmers))          # (the stash paths above are exercised)
                 stats[tier] = (int(i.table_lines), int(i.stored_kmers), int(i.multi_cell_kmers), int(i.extended))     # (which loser finds an empty second-line cell first is a race: not compared)
                 assert_same(db.screen(ref, s, e - s, 1), want, f"{name} ext={ext} tier={tier}")
                 assert np.array_equal(db.lookup(kmers[pick]), counts[pick].astype(np.int32)), (name, ext, tier)
