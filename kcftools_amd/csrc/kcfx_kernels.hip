@@ -1479,6 +1479,9 @@ __device__ __forceinline__ int k31_load_plan_tile(K31Plan& sh, const RefPlan& pl
 // wave boundary too -- and a barrier stands where the wave-private form has a fence: the text-only screening kernels, whose
 // tile is ONE run of strips.)
 constexpr int PLAN_ROWS = 66;                               // 64 lanes + the rows lane 63 and 62 read past the end (garbage, unused)
+// (rows 64 bytes apart: every fourth lane's 16-byte piece falls on the same four banks, a four-way conflict on each b128 access of the
+// exchanges -- 5.9 M conflict cycles per launch of the one-wave-per-tile kernel. Rows of 80 bytes have none, and were slower: 0.0911
+// against 0.0884 ms -- the 5.3 KB of LDS per wave cost more occupancy than the conflicts cost time; profiles/r05_notes.md)
 typedef uint32_t PlanRows[PLAN_ROWS][16];
 typedef uint32_t PlanRowsBlock[CELLS_BLOCK + 2][16];
 template <int K, int L, bool BLOCKWIDE = false>
