@@ -261,14 +261,15 @@ KCFX_HD uint32_t order27_tagged(uint32_t key, uint32_t fwd_m, uint32_t rc_m, uin
     return key | (rc_m < fwd_m ? 1u : 0u) | label2;
 }
 KCFX_HD uint32_t order27_label2(uint32_t pos) { return (pos & 15u) << 1; }
-// canonical minimizer 16-mer -> G32: line = top lbits, r = the rest. A bijection on 32 bits (odd multiplies, right
-// xorshift), so (line, r) identify the minimizer exactly, and independent of the order key: the MINIMUM of 16 keys is skewed
-// towards 0 and keeps only ~24 bits of entropy, which would leave most lines of a table of 2^27 or more lines unused.
-KCFX_HD uint32_t cell_g32(uint32_t cm) {
-    uint32_t x = cm * 0xC2B2AE35u;
-    x ^= x >> 15;
-    return x * 0x27D4EB2Fu;
-}
+// canonical minimizer 16-mer -> G32: line = top lbits, r = the rest. A bijection on 32 bits, so (line, r) identify the minimizer
+// exactly, and independent of the order key: the MINIMUM of 16 keys is skewed towards 0 and keeps only ~24 bits of entropy, which
+// would leave most lines of a table of 2^27 or more lines unused. ONE odd multiply (round 5; rounds 2 - 4: multiply, xorshift,
+// multiply): the line is the TOP bits of the product, which every bit of the 16-mer reaches, and that is all a line number needs --
+// on the bench databases the tables come out marginally better placed (stash 51.1 K k-mers against 52.6 K; k = 25: 7.8 % outside
+// their first-choice cell against 8.0 %), and the word loop is three instructions shorter: 0.0855 against 0.0871 ms on the same box.
+// (r, the LOW bits, depends on the 16-mer's last bases only: it identifies, it does not need to spread. Everything that hashes G32
+// further -- second and third lines, extended tables, regions, slices -- has a mixer of its own.)
+KCFX_HD uint32_t cell_g32(uint32_t cm) { return cm * 0x9E3779B1u; }
 
 // Bit 15 of r: the entry does not sit in its first-choice cell. Such an entry can never be mistaken for the k-mer that has the
 // same (w, r) and this cell as its first choice. Two kinds, told apart by WHERE they sit (see CellAlt and cell_second_line):
