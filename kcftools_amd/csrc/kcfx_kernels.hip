@@ -1333,7 +1333,7 @@ struct CellWord {
     uint64_t V;            // valid lanes (a table slice: whose minimizer this slice holds)
     uint64_t Vfull;        // valid lanes whatever the slice: the validity word of the bitmap
     uint32_t w, r;         // what this lane's cell must hold (CellProbe)
-    uint32_t anc;          // 2 * cell index | (N is the reverse complement): what a queued k-mer needs to derive its probe again
+    uint32_t anc;          // low five bits: 2 * cell index | (N is the reverse complement) -- what a queued k-mer needs to derive its probe again
     uint32_t r_alt;        // (k <= 30 only) what the r field of its free-cell entry must be (cell_alt_of)
     u32x2 cell, alt;       // what its first-choice cell and (k <= 30 only) its free cell hold
 };
@@ -1354,7 +1354,9 @@ __device__ __forceinline__ void cells_issue(const TableView& tv, uint64_t V, con
     asm volatile("" : "+v"(line));                              // (select the 32-bit line number, not the 64-bit byte offset after the shift)
     // lines are 128-byte aligned (and so is the table): the cell's offset in the line (8 * cell = 4 * sh) is OR-ed into the low
     // dword of the line's byte offset: base + ((32 * line + sh) << 2) = v_lshlrev_b64, v_or, v_lshl_add_u64 (whose shift goes up to 4)
-    uint64_t l32 = ((uint64_t)line << 5) | (uint64_t)p.sh;
+    // (the two halves of 32 * line + sh separately -- v_lshl_or_b32, v_lshrrev_b32 -- not a 64-bit shift of a zero-extended line:
+    // one instruction less)
+    uint64_t l32 = u64_of((line << 5) | p.sh, line >> 27);
     asm volatile("" : "+v"(l32));                               // (or the compiler re-associates it into a shift by 7 and two 64-bit adds)
     const uint8_t* a0 = reinterpret_cast<const uint8_t*>(reinterpret_cast<const uint32_t*>(tv.lines) + l32);
     // (nt_load2 goes through a global-address-space pointer: through a generic one the load could become a flat_load, which the
@@ -1629,7 +1631,8 @@ struct PlannedWords {
         s_r = 31u - (uint32_t)(b1 & 31);
         p_an = reinterpret_cast<const int8_t*>(sh.an) + q;
     }
-    __device__ __forceinline__ void next(int w, uint64_t& N, uint32_t& sh2, uint32_t& fm, uint64_t& V) {
+    // (*anchor: the anchor byte as loaded, sign-extended -- its low five bits are what a queued k-mer keeps: CellWord::anc)
+    __device__ __forceinline__ void next(int w, uint64_t& N, uint32_t& sh2, uint32_t& fm, uint64_t& V, uint32_t* anchor = nullptr) {
         constexpr uint32_t lo_mask = ~0u << (64 - 2 * K);
         const int32_t a = (int32_t)p_an[0];                  // sign-extended: valid <=> negative
         asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(fm) : "v"(a));  // all ones: N is the reverse complement
@@ -1641,6 +1644,7 @@ struct PlannedWords {
         const uint32_t y0 = p[0], y1 = p[1], y2 = p[2];
         N = u64_of(alignbit32(y1, y2, sx) & lo_mask, alignbit32(y0, y1, sx));
         sh2 = (uint32_t)a & 30u;
+        if (anchor) *anchor = (uint32_t)a;
         const int rem = n_kmers - w * 64;
         V = (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull)) & wave_ballot(a < 0);
         a_f += 16u;
@@ -1788,8 +1792,8 @@ __global__ __launch_bounds__(PLANNED ? CELLS_BLOCK : TEXT_BLOCK) __attribute__((
     // stage A of word w: keys, minimizer, cell, fetches issued
     auto issue = [&](int w, CellWord& cw) {
         uint64_t N, V;
-        uint32_t sh2, fm;
-        words.next(w, N, sh2, fm, V);
+        uint32_t sh2, fm, a;
+        words.next(w, N, sh2, fm, V, &a);
         uint32_t g;
         CellProbe p = cell_probe_planned<BOTH>(N, sh2, fm, tv.lbits, tv.ext, &g);
         cw.Vfull = V;
@@ -1797,7 +1801,7 @@ __global__ __launch_bounds__(PLANNED ? CELLS_BLOCK : TEXT_BLOCK) __attribute__((
         // device's to look up: no load, no hit, no queue entry here; the tiles' bitmaps are OR-ed afterwards)
         if (tv.slices > 1) V &= wave_ballot(cell_slice_of_g(g, (uint32_t)tv.slices) == (uint32_t)tv.slice);
         if (tv.regions > 1) p.line |= cell_region_of(g, (uint32_t)tv.regions) << tv.lbits;  // (wave-uniform: cell_line_index; from here on the line is only an address)
-        cells_issue<cell_nw(K), BOTH>(tv, V, p, sh2 | (fm & 1u), cw);
+        cells_issue<cell_nw(K), BOTH>(tv, V, p, a, cw);          // (the anchor byte whole: masked when -- if -- the k-mer is queued)
     };
     // stage B of word w: cells matched, ballots out, stash candidates queued
     auto retire = [&](int w, const CellWord& cw) {
@@ -1825,7 +1829,7 @@ __global__ __launch_bounds__(PLANNED ? CELLS_BLOCK : TEXT_BLOCK) __attribute__((
         if (PM) {
             const bool pending = __builtin_amdgcn_inverse_ballot_w64(PM);
             const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(PM >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)PM, 0u));
-            if (pending) q.id[pos] = (uint32_t)(((w - w_begin) << 6) | lane) | (cw.anc << QUEUE_ANCHOR_SHIFT);
+            if (pending) q.id[pos] = (uint32_t)(((w - w_begin) << 6) | lane) | ((cw.anc & 31u) << QUEUE_ANCHOR_SHIFT);
             qn += __popcll(PM);
         }
         wave_lds_fence();
@@ -1971,7 +1975,7 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 
         kw.anc = anc;
         uint32_t line = valid ? p.line : 0u;
         asm volatile("" : "+v"(line));
-        uint64_t l32 = ((uint64_t)line << 5) | (uint64_t)p.sh;
+        uint64_t l32 = u64_of((line << 5) | p.sh, line >> 27);
         asm volatile("" : "+v"(l32));
         kw.l32 = l32;
         const uint8_t* a0 = reinterpret_cast<const uint8_t*>(reinterpret_cast<const uint32_t*>(tv.lines) + l32);
