@@ -903,6 +903,10 @@ def main():
                      "kernel": kernel_name, "kernel_instance": kernel_inst, "kernel_avg_ms": kern_avg_ms,
                      "launches_timed": int(launches), "algorithmic_bytes_per_kmer": b_alg if S > 1 else B_ALG,
                      "rocprof_kernel_avg_ms": rocprof_ms,
+                     # what the memory system really moves while the kernel runs (the committed PMC traffic per launch over this
+                     # run's launch duration), beside the algorithmic rate above: how close the ACCESS PATTERN is to the peak
+                     "traffic_GBps": (None if not traffic or not kern_avg_ms else traffic / (kern_avg_ms * 1e-3) / 1e9),
+                     "traffic_frac_of_peak": (None if not traffic or not kern_avg_ms else traffic / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS),
                      # the same bytes over each form of the step that was measured: the one launch on a text-only reference (K1 - K3),
                      # plan + screen on a planned one (K1 - K3 in two launches), the screening kernel alone (plan amortised)
                      "ref_plan_ms": plan_avg_ms, "frac_one_pass": frac_of("one-pass"), "frac_two_launch": frac_of("two-launch"),

@@ -39,6 +39,9 @@ def test_committed_bench_line_has_the_contract_fields():
     s = json.load(open(os.path.join(ROOT, "profiles", "r05_summary.json")))
     assert abs(s["rocprof_kernel_avg_ms"] - r["kernel_avg_ms"]) < 0.1 * r["kernel_avg_ms"]
     assert r["traffic"] is None or r["traffic"] > alg      # HBM traffic by PMC is above the algorithmic bytes
+    # ... and what the memory system really moves while the kernel runs stands beside the algorithmic rate
+    assert r["traffic"] is None or abs(r["traffic_GBps"] - r["traffic"] / (r["kernel_avg_ms"] * 1e-3) / 1e9) < 1e-6 * r["traffic_GBps"]
+    assert r["traffic"] is None or (r["frac"] < r["traffic_frac_of_peak"] < 1.0)
     # round 5: the step is the pass the product runs for one sample -- ONE launch on a text-only reference (K1 - K3) + reduce -- at the
     # REQUESTED warm-up; plan + screen as two launches and the amortised form are measured beside it and the fractions follow
     assert d["step_form"] == "one-pass" and d["step"].startswith("one pass") and d["warmup"] == 5
