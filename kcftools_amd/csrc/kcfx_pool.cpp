@@ -5,8 +5,8 @@
 // second or third hipMalloc of a 16 GiB table that follows the hipFree of the previous one takes 1.5 - 1.9 s (the driver
 // hands the pages back cleared), against a 0.1 s database load. So large blocks that are released are kept, per device, and
 // handed out again when a request of (about) the same size comes; everything the library clears or overwrites before use
-// anyway. Bounded (POOL_MAX_BLOCKS, POOL_MAX_FRACTION of the device), emptied when an allocation fails, released on
-// request (kcfx_release_cached), disabled by KCFX_NO_POOL. Memory policies that look at the free device memory count the
+// anyway. Bounded (pool_max_blocks, pool_max_fraction of the device), emptied when an allocation fails, released on
+// request (kcfx_release_cached), disabled by KCFX_NO_POOL, bounded lower by KCFX_POOL_FRACTION. Memory policies that look at the free device memory count the
 // kept blocks as free (free_device_bytes).
 #include <algorithm>
 #include <cstdio>
@@ -40,7 +40,14 @@ size_t pool_max_blocks() {                              // kept blocks per devic
 // for six seconds with the GPU idle and the uploads stuck in hipMemcpyAsync -- the driver clears released memory in the background
 // on the engines the uploads use. Kept, the second open of such a database takes 7 s instead of 12.8. What is kept is released
 // when any allocation fails, and counts as free memory in every policy: keeping more costs nothing.)
-constexpr double POOL_MAX_FRACTION = 0.9;
+double pool_max_fraction() {                            // (KCFX_POOL_FRACTION=<0..1>: a process that shares the device with another allocator)
+    static const double f = [] {
+        const char* e = getenv("KCFX_POOL_FRACTION");
+        const double v = e ? atof(e) : 0.9;
+        return v >= 0.0 && v <= 1.0 ? v : 0.9;
+    }();
+    return f;
+}
 
 struct Block {
     void* p;
@@ -187,7 +194,7 @@ static hipError_t dev_free_impl(void* p, bool idle) {
         for (;;) {
             size_t n = 0;
             for (const Block& s : g_spare) n += s.dev == b.dev ? 1 : 0;
-            if (n <= pool_max_blocks() && (double)pooled_locked(b.dev) <= POOL_MAX_FRACTION * (double)total_b) break;
+            if (n <= pool_max_blocks() && (double)pooled_locked(b.dev) <= pool_max_fraction() * (double)total_b) break;
             bool dropped = false;
             for (size_t i = 0; i < g_spare.size(); ++i)
                 if (g_spare[i].dev == b.dev) {
