@@ -281,7 +281,10 @@ def realistic_leg(engine, torch, synth_bin, workdir, ref_len, window, min_count,
     noise = str(max(0, 150_000_000 - int(0.885 * ref_len)))
     # (dense_table: the HEADLINE database in a table of the density the size policy gives a database of billions of k-mers -- 0.28
     # per cell, 2^25 lines instead of 2^27 -- where the headline's table has 0.07: what the 14 x memory of the sparse table buys)
+    # (read_error_db: genomic counters uniform in 1 .. 30, one in thirty a 1 that an error k-mer of the same cell beats on a coin toss;
+    # read_error_depth30: the same reads with the counters the error load implies -- ~30 x, no genomic k-mer seen once)
     cases = (("read_error_db", 31, 7, ["--error-events", "4500000", "--noise", "0"], None),
+             ("read_error_depth30", 31, 7, ["--error-events", "4500000", "--noise", "0", "--depth", "30"], None),
              ("k25", 25, 5, ["--noise", noise], None),
              ("repeats", 31, 7, ["--repeats", "0.3", "--noise", noise], None),
              ("dense_table", 31, 7, ["--noise", noise], "25"))

@@ -69,6 +69,7 @@ struct Opts {
     uint64_t seed = 1, sample_seed = 2;
     int64_t noise = 0;
     int64_t error_events = 0;              // --error-events: read-error model, see below
+    int depth = 0;                         // --depth D: counters of genomic k-mers spread over D / 2 .. 3 D / 2 - 1 (0: 1 .. 30, the older spread)
     int k = 31, p = 7, cs = 2, sig_len = 9, n_bins = 512, threads = 0;
     double sub_rate = 1e-2, indel_rate = 1e-3;
     double repeats = 0.0;                  // --repeats F: fraction of the reference overwritten with repeat structure (see below)
@@ -90,6 +91,7 @@ int main(int argc, char** argv) {
         else if (a == "--sample-seed") o.sample_seed = strtoull(val(), nullptr, 10);
         else if (a == "--noise") o.noise = atoll(val());
         else if (a == "--error-events") o.error_events = atoll(val());
+        else if (a == "--depth") o.depth = atoi(val());
         else if (a == "--repeats") o.repeats = atof(val());
         else if (a == "--k") o.k = atoi(val());
         else if (a == "--p") o.p = atoi(val());
@@ -120,7 +122,7 @@ int main(int argc, char** argv) {
         return 2;
     }
     if (o.out.empty() || o.k < 9 || o.k > 32 || (o.k - o.p) % 4 != 0 || o.cs < 1 || o.cs > 4 || o.sig_len > o.k) {
-        fprintf(stderr, "usage: kcfx_synth --out PREFIX [--ref-len N --ref-offset O --ref-only --seed S --sample-seed S --noise N --error-events N --repeats F --k 31 --p 7 --cs 2 --bins 512 --threads T --fasta]\n");
+        fprintf(stderr, "usage: kcfx_synth --out PREFIX [--ref-len N --ref-offset O --ref-only --seed S --sample-seed S --noise N --error-events N --depth D --repeats F --k 31 --p 7 --cs 2 --bins 512 --threads T --fasta]\n");
         return 2;
     }
     if (o.threads <= 0) o.threads = (int)std::max(1u, std::thread::hardware_concurrency());
@@ -458,8 +460,12 @@ int main(int argc, char** argv) {
                 const size_t d = uoff[b] + j;
                 uk[d] = w;
                 const uint64_t h = mix64(w ^ 0xC0FFEEull);
-                // depth-like spread for -c and KD; a k-mer that only read errors produced is seen as often as they occurred
-                uint64_t c = only_errors ? (uint64_t)occ[boff[b] + j] : (uint64_t)occ[boff[b] + j] * (1 + h % 30);
+                // depth-like spread for -c and KD; a k-mer that only read errors produced is seen as often as they occurred.
+                // (--depth D: D / 2 .. 3 D / 2 - 1 -- a count of reads that holds E error k-mers per genomic k-mer was sequenced to a
+                // depth of about E / (k x error rate), 4.5 M events on 27 M k-mers at 0.5 % errors: ~30 x, where a genomic k-mer
+                // seen ONCE does not occur; the older 1 .. 30 makes one in thirty of them indistinguishable from an error)
+                const uint64_t spread = o.depth >= 4 ? (uint64_t)(o.depth / 2) + h % (uint64_t)o.depth : 1 + h % 30;
+                uint64_t c = only_errors ? (uint64_t)occ[boff[b] + j] : (uint64_t)occ[boff[b] + j] * spread;
                 uc[d] = (uint32_t)std::min<uint64_t>(c, cmax);
                 uint32_t best = 1u << (2 * m);
                 for (int i = 0; i + m <= k; ++i) {

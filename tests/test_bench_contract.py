@@ -59,7 +59,7 @@ def test_committed_bench_line_has_the_contract_fields():
     assert cs["hot_loop_ms"] < 1.02 * cs["read_swept_ms"] < 1.2 * cs["hot_loop_ms"] and cs["read_swept_ms"] < cs["write_swept_ms"]
     assert len(cs["first_pass_ms"]) == 5 and cs["first_pass_median_ms"] > 1.5 * cs["second_pass_median_ms"]
     # inputs that look like data: every window of each against the oracle, both forms of the kernel
-    for name in ("read_error_db", "k25", "repeats"):
+    for name in ("read_error_db", "read_error_depth30", "k25", "repeats"):
         x = d["realistic"][name]
         assert x["parity"]["bit_exact"] is True and x["forms_identical"] is True and x["parity"]["windows_checked"] >= 3000, name
         assert 0.1 < x["one_pass"]["frac"] < 1.0 and 0.1 < x["amortised"]["frac"] < 1.0
