@@ -667,7 +667,10 @@ def test_wheat_scale_genomic_database(oracle, monkeypatch, size):
         # the free memory can take them, else 2^29)
         assert a["extended"] == 1                                # (the build found > 15 % of the k-mers outside their first-choice cell and started over)
         assert a["stash"] < (0.10 if a["per_cell"] < 0.6 else 0.22)
-        if a["per_cell"] < 0.4:                                  # (3 x 2^29 lines: 211 G k-mers/s on the round's boxes; the bound leaves room for a slow one)
-            assert gk / a["kernel_ms"] * 1e3 > 170
+        # (3 x 2^29 lines: a pass takes 42.6 - 43.0 ms = 209 - 211 G k-mers/s in six of the round's ten runs of this test and 51.6 - 53.0 ms
+        # = 169 - 174 G in the other four, on both handles of the process alike -- round 4's "two speeds of a table", 20 % at 206 GB: where
+        # the driver happened to place the table, not what the kernel does; the bound is under the slow mode)
+        if a["per_cell"] < 0.4:
+            assert gk / a["kernel_ms"] * 1e3 > 150
     finally:
         shutil.rmtree(d, ignore_errors=True)
