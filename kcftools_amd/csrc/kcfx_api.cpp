@@ -423,7 +423,8 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys, bool deferred = false) {
                 // (the driver serves one allocation at a time and a table of 200 GB holds it for 5 - 6 s: the loader's own buffers --
                 // a few hundred MB, or the resident records -- go first, or its first pass over the file starts that much later;
                 // alloc_go comes from load_suffix_file, from whoever waits for the table, or after five seconds)
-                for (int waited = 0; !db->alloc_go && waited < 25000; ++waited) std::this_thread::sleep_for(std::chrono::microseconds(200));
+                const bool early = getenv("KCFX_LOAD_TABLE_EARLY") != nullptr;     // (the table before everything else, as in rounds 1 - 4: profiles/r05_notes.md section 5)
+                for (int waited = 0; !early && !db->alloc_go && waited < 25000; ++waited) std::this_thread::sleep_for(std::chrono::microseconds(200));
                 hipError_t e2 = hipSetDevice(db->device);
                 if (e2 == hipSuccess) e2 = dev_alloc(&db->d_lines, (size_t)LINE_BYTES * db->n_lines);
                 if (e2 == hipSuccess) db->alloc_landed = true;
