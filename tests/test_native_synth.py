@@ -79,3 +79,30 @@ def test_native_synth_repeats_give_the_genome_structure(oracle, tmp_path):
     ref = np.frombuffer(open(str(tmp_path / "r1") + ".ref.txt", "rb").read(), dtype=np.uint8)
     win = np.lib.stride_tricks.sliding_window_view(ref[:400_000], 31)
     assert len(np.unique(win, axis=0)) < 0.97 * len(win)
+
+
+def test_native_synth_read_error_model_and_depth(oracle, tmp_path):
+    """--error-events: around E substitution errors of the sample, the k-mers that cover the wrong base, with the counter 1 (or how often
+    they occurred); --depth D: the genomic k-mers' counters spread over D / 2 .. 3 D / 2 - 1 instead of 1 .. 30 -- a count of reads that
+    holds five error k-mers per genomic one was sequenced to ~30 x, where a genomic k-mer seen once does not occur."""
+    if not os.path.exists(BIN):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "kcftools_amd", "csrc"), "../bin/kcfx_synth"], check=True, capture_output=True)
+    dumps = {}
+    for name, extra in (("uniform", []), ("depth", ["--depth", "30"])):
+        prefix = str(tmp_path / name)
+        out = subprocess.run([BIN, "--out", prefix, "--ref-len", "120000", "--noise", "0", "--error-events", "15000", "--threads", "4"] + extra,
+                             check=True, capture_output=True, text=True).stdout
+        meta = json.loads(out)
+        assert meta["error_kmers"] > 10 * 15000 and meta["sample_kmers"] < meta["db_kmers"] <= meta["sample_kmers"] + meta["error_kmers"]
+        km, ct = oracle.OracleDb(prefix).dump()
+        assert len(km) == meta["db_kmers"]
+        dumps[name] = dict(zip(km.tolist(), ct.tolist()))
+    u, d = dumps["uniform"], dumps["depth"]
+    assert u.keys() == d.keys()                                   # the same k-mers: only counters differ
+    genomic = [k for k in u if d[k] >= 15]                        # what --depth lifted is the genome (an error k-mer seen 15 times does not occur here)
+    assert 0.9 * 120000 * 0.85 < len(genomic) < 120000 and max(d.values()) < 3 * 45
+    # the error k-mers keep their occurrence counts in both; among the genomic ones the uniform spread has ~1 in 30 at counter 1
+    errors = [k for k in u if d[k] < 15]
+    assert all(u[k] == d[k] for k in errors) and len(errors) > 0.7 * len(u)
+    ones_genomic = sum(1 for k in genomic if u[k] == 1)
+    assert 0.015 * len(genomic) < ones_genomic < 0.06 * len(genomic)
