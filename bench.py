@@ -287,7 +287,10 @@ def realistic_leg(engine, torch, synth_bin, workdir, ref_len, window, min_count,
              ("read_error_depth30", 31, 7, ["--error-events", "4500000", "--noise", "0", "--depth", "30"], None),
              ("k25", 25, 5, ["--noise", noise], None),
              ("repeats", 31, 7, ["--repeats", "0.3", "--noise", noise], None),
-             ("dense_table", 31, 7, ["--noise", noise], "25"))
+             ("dense_table", 31, 7, ["--noise", noise], "25"),
+             # (... and what four times the memory buys: 2^29 lines, 64 GiB, 0.017 per cell -- a quarter of the k-mers that sit outside
+             # their first-choice cell at the policy's 2^27, and the second-line requests of the reference's k-mers among them)
+             ("sparse_table", 31, 7, ["--noise", noise], "29"))
     for name, k, p, extra, lbits in cases:
         try:
             prev_lbits = os.environ.get("KCFX_TABLE_LBITS")
