@@ -30,6 +30,7 @@ import argparse
 import json
 import math
 import os
+import re
 import subprocess
 import sys
 import time
@@ -267,35 +268,26 @@ def cache_state_leg(engine, torch, prefix, ref, db, out_ptr, stream, min_count, 
 def realistic_leg(engine, torch, synth_bin, workdir, ref_len, window, min_count, device, threads, launches=100):
     """Inputs that look like data, beside the uniform-noise database of the headline (every one on the chr1-sized reference, every
     window of every one against the oracle):
-      read_error_db  a database as `kmc -ci1` writes it from reads (README.md:171-177): the sample genome's k-mers + ~5 x as many
-                     count-1 k-mers in runs around substitution errors, which share minimizers and cells with their originals;
-      k25            KMC's default k (W = 10 of a line's 16 cells: shorter minimizer runs, more lines per k-mer);
-      repeats        reference and sample with genome structure (TE families, satellite arrays, segmental duplications,
-                     microsatellites: kcfx_synth --repeats 0.3): crowded minimizers;
-      dense_table    the headline's kind of database in a table of 0.28 k-mers per cell (KCFX_TABLE_LBITS=25) instead of 0.07: the
-                     density a database of billions of k-mers gets on one device.
-    Per input: the screening kernel's average (HIP events on the launch) of the one-pass form (text-only reference, K1 - K3 in one
-    launch) and of the amortised form (planned reference), as fractions of the HBM roofline at 1 + 8 + counter_size bytes per k-mer."""
+      read_error_db       a database as `kmc -ci1` writes it from reads (README.md:171-177): the sample genome's k-mers + ~5 x as many
+                          count-1 k-mers in runs around substitution errors, which share minimizers and cells with their originals
+                          (genomic counters uniform in 1 .. 30: one in thirty a 1 that an error k-mer of the same cell beats on a coin toss);
+      read_error_depth30  the same reads with the counters the error load implies (~30 x: no genomic k-mer seen once);
+      k25                 KMC's default k (W = 10 of a line's 16 cells: shorter minimizer runs, more lines per k-mer);
+      repeats             reference and sample with genome structure (TE families, satellite arrays, segmental duplications,
+                          microsatellites: kcfx_synth --repeats 0.3): crowded minimizers.
+    Per input the product's two configurations (round 6): `one_pass` = the one-sample job -- a text-only reference (K1 - K3 in one launch)
+    against the table kcfx_db_open_opts builds for ONE pass (expected_queries = the pass: ~0.3 k-mers per cell); `resident` = a handle
+    somebody keeps -- a planned reference against the table of expected_queries = 0 (~0.07 per cell). The screening kernel's average
+    (HIP events on the launch) as a fraction of the HBM roofline at 1 + 8 + counter_size bytes per k-mer."""
     from oracle import binding as oracle
     out = {}
     noise = str(max(0, 150_000_000 - int(0.885 * ref_len)))
-    # (dense_table: the HEADLINE database in a table of the density the size policy gives a database of billions of k-mers -- 0.28
-    # per cell, 2^25 lines instead of 2^27 -- where the headline's table has 0.07: what the 14 x memory of the sparse table buys)
-    # (read_error_db: genomic counters uniform in 1 .. 30, one in thirty a 1 that an error k-mer of the same cell beats on a coin toss;
-    # read_error_depth30: the same reads with the counters the error load implies -- ~30 x, no genomic k-mer seen once)
-    cases = (("read_error_db", 31, 7, ["--error-events", "4500000", "--noise", "0"], None),
-             ("read_error_depth30", 31, 7, ["--error-events", "4500000", "--noise", "0", "--depth", "30"], None),
-             ("k25", 25, 5, ["--noise", noise], None),
-             ("repeats", 31, 7, ["--repeats", "0.3", "--noise", noise], None),
-             ("dense_table", 31, 7, ["--noise", noise], "25"),
-             # (... and what four times the memory buys: 2^29 lines, 64 GiB, 0.017 per cell -- a quarter of the k-mers that sit outside
-             # their first-choice cell at the policy's 2^27, and the second-line requests of the reference's k-mers among them)
-             ("sparse_table", 31, 7, ["--noise", noise], "29"))
-    for name, k, p, extra, lbits in cases:
+    cases = (("read_error_db", 31, 7, ["--error-events", "4500000", "--noise", "0"]),
+             ("read_error_depth30", 31, 7, ["--error-events", "4500000", "--noise", "0", "--depth", "30"]),
+             ("k25", 25, 5, ["--noise", noise]),
+             ("repeats", 31, 7, ["--repeats", "0.3", "--noise", noise]))
+    for name, k, p, extra in cases:
         try:
-            prev_lbits = os.environ.get("KCFX_TABLE_LBITS")
-            if lbits and prev_lbits is None:
-                os.environ["KCFX_TABLE_LBITS"] = lbits      # (read when a handle is made; removed again below; a value the user set stays)
             prefix = os.path.join(workdir, f"real_{name}_r{ref_len}")
             if not os.path.exists(prefix + ".meta.json"):
                 cmd = [synth_bin, "--out", prefix, "--ref-len", str(ref_len), "--seed", "1", "--sample-seed", "2", "--k", str(k), "--p", str(p),
@@ -309,9 +301,11 @@ def realistic_leg(engine, torch, synth_bin, workdir, ref_len, window, min_count,
             stream = torch.cuda.current_stream().cuda_stream
             res = {}
             rec = None
-            for form, screens in (("one_pass", 1), ("amortised", 0)):
+            for form, screens in (("one_pass", 1), ("resident", 0)):
                 ref = engine.Reference(text, wb, wl, k, device=device, expected_screens=screens)
-                db = engine.KmcDb.open(prefix, device=device, expected_queries=int(ref.n_kmer_slots))
+                t_open = time.perf_counter()
+                db = engine.KmcDb.open(prefix, device=device, expected_queries=int(ref.n_kmer_slots) if form == "one_pass" else 0)
+                t_open = time.perf_counter() - t_open
                 o = torch.zeros(len(wb) * 10, dtype=torch.int32, device=f"cuda:{device}")
                 for _ in range(5):
                     ref.screen_async(db, o.data_ptr(), stream, min_count)
@@ -324,14 +318,15 @@ def realistic_leg(engine, torch, synth_bin, workdir, ref_len, window, min_count,
                 ms, n = ref.prof_read(reset=True)
                 r = o.cpu().numpy().view(engine.RESULT_DTYPE)[:len(wb)].copy()
                 nk = int(r["total_kmers"].sum())
-                res[form] = {"kernel_avg_ms": ms / max(1, n), "frac": nk * B_ALG / (ms / max(1, n) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                info = db.info
+                res[form] = {"kernel_avg_ms": ms / max(1, n), "frac": nk * B_ALG / (ms / max(1, n) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "db_open_seconds": t_open,
+                             "table": {"lines": int(info.table_lines), "kmers_per_cell": float(info.stored_kmers) / max(1, 16 * int(info.table_lines)),
+                                       "stash_share": float(info.stash_kmers) / max(1, int(info.stored_kmers)),
+                                       "outside_first_choice_share": float(info.second_choice_kmers + info.stash_kmers) / max(1, int(info.stored_kmers)),
+                                       "extended": int(info.extended)}}
                 if rec is None:
                     rec = r
-                    info = db.info
-                    res["table"] = {"lines": int(info.table_lines), "kmers_per_cell": float(info.stored_kmers) / max(1, 16 * int(info.table_lines)),
-                                    "stash_share": float(info.stash_kmers) / max(1, int(info.stored_kmers)),
-                                    "outside_first_choice_share": float(info.second_choice_kmers + info.stash_kmers) / max(1, int(info.stored_kmers)),
-                                    "extended": int(info.extended)}
                 else:
                     res["forms_identical"] = bool(all(np.array_equal(r[f], rec[f]) for f in engine.INT_FIELDS))
                 ref.close()
@@ -346,11 +341,42 @@ def realistic_leg(engine, torch, synth_bin, workdir, ref_len, window, min_count,
             out[name] = res
         except Exception as exc:                     # the bench line must not die on an extra leg
             out[name] = {"error": str(exc)[:300]}
-        finally:
-            if lbits and prev_lbits is None:
-                os.environ.pop("KCFX_TABLE_LBITS", None)
     engine.release_cached()
     return out
+
+
+_PHASE = re.compile(r"^\[(kcftools-amd|kcfx \w+)\]\s+(.*?)\s+([0-9.]+) ms\s*$")
+
+
+def end_to_end_runs(cli, fa, prefix, window, min_count, device, n_runs):
+    """`kcftools-amd getVariations` n_runs times, each in a fresh process with its phase trace on (KCFX_CLI_TRACE / KCFX_LOAD_TRACE):
+    per run the wall time and where it went -- the driver's own phases (options + .kmc_pre header, FASTA index, windows + text, the
+    rest of the GPU runtime's start, the sharded call, scores + KCF) and inside the sharded call the database load's (device + stream,
+    buffers, the pass over the file, bids + settle, ...)."""
+    env = dict(os.environ)
+    env["KCFX_CLI_TRACE"] = "1"
+    env["KCFX_LOAD_TRACE"] = "1"
+    runs = []
+    kcf = prefix + ".bench.kcf"
+    for _ in range(n_runs):
+        t0 = time.perf_counter()
+        pr = subprocess.run([cli, "getVariations", "-r", fa, "-k", prefix, "-o", kcf, "-s", "bench", "-f", "window",
+                             "-w", str(window), "-c", str(min_count), "--device", str(device)], capture_output=True, text=True, env=env)
+        wall = time.perf_counter() - t0
+        if pr.returncode != 0:
+            raise RuntimeError(pr.stdout[-500:] + pr.stderr[-500:])
+        phases = {}
+        for ln in pr.stderr.splitlines():
+            m = _PHASE.match(ln)
+            if m:
+                key = ("cli: " if m.group(1) == "kcftools-amd" else "load: ") + m.group(2).strip()
+                phases[key] = round(phases.get(key, 0.0) + float(m.group(3)), 1)
+        accounted = sum(v for k_, v in phases.items() if k_.startswith("cli: "))
+        phases["process start + exit (wall - the driver's phases)"] = round(wall * 1e3 - accounted, 1)
+        split = [ln for ln in pr.stdout.splitlines() if "Screened" in ln]
+        runs.append({"seconds_wall": round(wall, 4), "phases_ms": phases, "breakdown": split[-1].split(" - ")[-1] if split else ""})
+    rows = sum(1 for ln in open(kcf) if not ln.startswith("#"))
+    return runs, rows
 
 
 def main():
@@ -377,6 +403,7 @@ def main():
                     help="skip the inputs that look like data (read-error database, k = 25, repeat-structured genome: ~1 min of generation, "
                          "opens and oracle checks)")
     ap.add_argument("--no-cache-state", action="store_true", help="skip the hot / swept / first-pass launches of the cache_state leg")
+    ap.add_argument("--no-resident", action="store_true", help="skip the step's kernels against the table of a resident handle (expected_queries = 0)")
     ap.add_argument("--min-count", type=int, default=1)
     ap.add_argument("--spin-ms", type=float, default=60.0,
                     help="the line's own figures (value, ms_per_step, roofline) are ALWAYS those of the W requested warm-up steps + K timed "
@@ -390,8 +417,9 @@ def main():
                          "the plan stays out of the step (many samples per reference). With --samples > 1 the reference is planned "
                          "and one-pass means two-launch")
     ap.add_argument("--table", choices=("product", "sparse"), default="product",
-                    help="product: the table density the command-line driver selects for one pass (expected_queries = the step's "
-                         "k-mers); sparse: kcfx_db_open's default for an unknown / large number of look-ups")
+                    help="product: the table kcfx_db_open_opts builds for ONE pass (expected_queries = the step's k-mers: what the "
+                         "command-line driver and kcfx_screen_sharded pass; ~0.3 k-mers per cell since round 6); sparse: kcfx_db_open's "
+                         "table for an unknown / large number of look-ups (~0.07 per cell; measured beside the step either way: resident_table)")
     ap.add_argument("--samples", type=int, default=1,
                     help="samples per GPU; > 1 screens them in one pass over the reference (kcfx_screen_ref_multi, SURVEY f-4). "
                          "The default 1 is BASELINE.json's configuration")
@@ -614,6 +642,38 @@ def main():
         if forms_same is False:
             log("bench.py: the text-only reference gives other results than the planned one")
 
+    # The same two kernels against the table a RESIDENT handle gets (expected_queries = 0: ~0.07 k-mers per cell, 17 GB for this
+    # database -- kcfx_db_open's table, what an engine that keeps its handles and serves thousands of passes builds), beside the
+    # step's own table (sized for ONE pass since round 6: ~0.3 per cell, 4.4 GB -- what the one-sample job can afford to allocate)
+    resident = None
+    if world == 1 and S == 1 and cohort is None and K >= 19 and args.table == "product" and not args.no_resident:
+        try:
+            t_r = time.time()
+            db_res = engine.KmcDb.open(prefix, device=local_rank, expected_queries=0)
+            t_r = time.time() - t_r
+            resident = {"table": {"lines": int(db_res.info.table_lines), "bytes": int(db_res.info.table_bytes),
+                                  "kmers_per_cell": float(db_res.info.stored_kmers) / max(1, 16 * int(db_res.info.table_lines)),
+                                  "stash_kmers": int(db_res.info.stash_kmers)}, "db_open_seconds": t_r}
+            out_r = torch.zeros_like(out)
+            for frm, r in (("one-pass", ref if form == "one-pass" else ref_o), ("amortised", ref_o if form == "one-pass" else ref)):
+                if (frm == "one-pass") == r.planned:
+                    continue
+                def run_r(r=r):
+                    r.screen_async(db_res, out_r.data_ptr(), stream.cuda_stream, args.min_count)
+                for _ in range(max(3, args.warmup)):
+                    run_r()
+                r_el, r_kms, r_kn, _, _ = timed(run_r, r, args.steps, False)
+                resident[frm] = {"ms_per_step": r_el / args.steps * 1e3, "kernel_avg_ms": r_kms / max(1, r_kn),
+                                 "value": kmers_per_step * args.steps / r_el,
+                                 "frac": kmers_per_step * B_ALG / (r_kms / max(1, r_kn) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            resident["identical_to_the_step"] = bool(torch.equal(out_r, out))
+            if not resident["identical_to_the_step"]:
+                forms_same = False
+            del out_r
+            db_res.close()                           # (its 17 GB stay with the library's pool: nothing goes back to the driver here)
+        except Exception as exc:                     # the bench line must not die on the extra leg
+            resident = {"error": str(exc)[:300]}
+
     # Optional clock ramp (--spin-ms > 0): the step repeated untimed for that long, then the K steps once more -- reported
     # beside the line's own figures, never instead of them.
     ramped = None
@@ -767,36 +827,27 @@ def main():
             log("bench.py: GPU results differ from the oracle on the baseline sample")
 
     # ---- end to end: the command-line driver, FASTA read -> KCF written, same reference / sample / windows ----------------
+    # (four runs here -- the first writes the .fai and warms the page cache -- with this process's handles alive, and two more at the
+    # very end, right after this process has given ~20 GB back to the driver: `after_churn`, what a job sees on a node where another
+    # job has just finished. Every run with its phases.)
     e2e = None
+    cli = os.path.join(ROOT, "kcftools_amd", "bin", "kcftools-amd")
+    fa = prefix + ".fa"
     if world == 1 and S == 1 and not args.no_end_to_end:
         try:
             from kcftools_amd import synth
-            fa = prefix + ".fa"
             if not os.path.exists(fa):
                 synth.write_fasta(fa, [("chr1", text)])
-            cli = os.path.join(ROOT, "kcftools_amd", "bin", "kcftools-amd")
-            runs = []
-            for attempt in range(4):                 # the first run writes the .fai and warms the page cache
-                kcf = prefix + ".bench.kcf"
-                t0 = time.perf_counter()
-                pr = subprocess.run([cli, "getVariations", "-r", fa, "-k", prefix, "-o", kcf, "-s", "bench", "-f", "window",
-                                     "-w", str(args.window), "-c", str(args.min_count), "--device", str(local_rank)],
-                                    capture_output=True, text=True)
-                wall = time.perf_counter() - t0
-                if pr.returncode != 0:
-                    raise RuntimeError(pr.stdout[-500:] + pr.stderr[-500:])
-                split = [ln for ln in pr.stdout.splitlines() if "Screened" in ln]
-                runs.append((wall, split[-1].split(" - ")[-1] if split else ""))
-            rows = sum(1 for ln in open(kcf) if not ln.startswith("#"))
-            # one run in ten takes 1 - 2 s: the driver hands the next process VRAM that the previous one has just freed
-            # (16 GiB of table) only after clearing it -- hence the median of the three warm runs, and all four listed
-            wall, split = sorted(runs[1:])[1]
-            e2e = {"seconds_wall": wall, "seconds_wall_first_run": runs[0][0], "seconds_wall_all_runs": [round(r[0], 3) for r in runs],
-                   "kmers_per_s": kmers_per_step / wall,
+            runs, rows = end_to_end_runs(cli, fa, prefix, args.window, args.min_count, local_rank, 4)
+            warm = sorted(runs[1:], key=lambda r_: r_["seconds_wall"])
+            med = warm[len(warm) // 2]
+            e2e = {"seconds_wall": med["seconds_wall"], "seconds_wall_first_run": runs[0]["seconds_wall"],
+                   "seconds_wall_all_runs": [r_["seconds_wall"] for r_ in runs],
+                   "kmers_per_s": kmers_per_step / med["seconds_wall"],
                    "windows": rows, "what": "kcftools-amd getVariations: process start, FASTA index + sequence read, database load, "
                    "reference upload, screening, scores, KCF written (median of three runs after a first one that writes the "
-                   ".fai and warms the page cache)",
-                   "breakdown": split}
+                   ".fai and warms the page cache); runs[i].phases_ms: where each run's wall time went",
+                   "breakdown": med["breakdown"], "runs": runs}
         except Exception as exc:                     # the bench line must not die on the extra leg
             e2e = {"error": str(exc)[:300]}
 
@@ -850,6 +901,17 @@ def main():
         ref.close()
         engine.release_cached()
         realistic = realistic_leg(engine, torch, synth_bin, args.workdir, args.ref_len, args.window, args.min_count, local_rank, ncpu)
+    if e2e is not None and "error" not in e2e:
+        try:
+            for d_ in dbs:
+                d_.close()
+            ref.close()
+            engine.release_cached()                  # everything this process held goes back to the driver NOW (tables, pooled blocks)
+            runs2, _ = end_to_end_runs(cli, fa, prefix, args.window, args.min_count, local_rank, 2)
+            e2e["after_churn"] = {"seconds_wall_all_runs": [r_["seconds_wall"] for r_ in runs2], "runs": runs2,
+                                  "what": "the same command right after this process released its device memory to the driver"}
+        except Exception as exc:
+            e2e["after_churn"] = {"error": str(exc)[:300]}
 
     jvm = jvm_probe()
     java_leg = None
@@ -873,6 +935,7 @@ def main():
         "forms_identical": forms_same,
         "ramped": ramped,
         "cache_state": cache_state,
+        "resident_table": resident,
         "realistic": realistic,
         "higher_is_better": True,
         "scaling": "strong" if (window_sharded or table_sharded) else "weak",
@@ -917,6 +980,9 @@ def main():
                      # plan + screen on a planned one (K1 - K3 in two launches), the screening kernel alone (plan amortised)
                      "ref_plan_ms": plan_avg_ms, "frac_one_pass": frac_of("one-pass"), "frac_two_launch": frac_of("two-launch"),
                      "frac_amortised": frac_of("amortised"),
+                     # the same kernels against a resident handle's table (expected_queries = 0: the sparse one), see "resident_table"
+                     "frac_resident_one_pass": ((resident or {}).get("one-pass") or {}).get("frac"),
+                     "frac_resident_amortised": ((resident or {}).get("amortised") or {}).get("frac"),
                      "table": {"policy": args.table, "expected_queries": expected, "lines": int(db.info.table_lines),
                                "bytes": int(db.info.table_bytes), "kmers_per_cell": float(db.info.stored_kmers) / max(1, 16 * int(db.info.table_lines)),
                                "stash_kmers": int(db.info.stash_kmers)}},

@@ -108,10 +108,14 @@ int32_t kcfx_db_open(const char* kmc_prefix, int32_t device, kcfx_db** out);
 
 /* kcfx_db_open with options (NULL = the defaults of kcfx_db_open).
  *   expected_queries  k-mer look-ups this handle is expected to serve over its lifetime = reference k-mers x passes (the
- *                     reference runs ONE pass per database: GetVariants.java:129-159); 0 = unknown. Since round 4 the table
- *                     has the same size either way (~0.07 k-mers per cell: 17 GB for 150 M k-mers; end to end the sizes are
- *                     indistinguishable and the sparse one screens 16 - 30 % faster, profiles/r04_notes.md); a handle that
- *                     serves fewer than 10^10 look-ups only builds with the cheaper crowding counters (no 4 GiB scratch).
+ *                     reference runs ONE pass per database: GetVariants.java:129-159); 0 = unknown. Sizes the table: memory (and
+ *                     the time the driver takes to hand it out on a device other processes have used: 28 - 42 GB/s) against the
+ *                     speed of a pass. The size minimises  bytes / 35 GB/s + look-ups x seconds per look-up at that density  over
+ *                     the sizes from ~0.3 k-mers per cell (150 M k-mers: 2^25 lines, 4.4 GB, 0.092 ms per pass of a 30 Mb reference)
+ *                     to ~0.075 per cell (2^27 lines, 17 GB, 0.080 ms): a one-pass job gets the first, a handle that will serve
+ *                     more than ~4 x 10^11 look-ups -- or an unknown number: 0 -- the second (profiles/r06_notes.md section 1; rounds
+ *                     4 - 5 gave every handle the sparse table, and a one-pass job on a busy device paid 0.5 - 2.5 s for its 13 GB).
+ *                     A handle that serves fewer than 10^10 look-ups also builds with the cheaper crowding counters (no 4 GiB scratch).
  *   no_fallback       1: a cell table that does not fit the device fails with KCFX_ERR_DEVICE instead of being rebuilt as
  *                     a 12-slot line table (callers that can free memory and retry, like kcfx_screen_sharded's loader). */
 typedef struct {
@@ -158,11 +162,17 @@ void kcfx_db_close(kcfx_db* db);
 /* Large device buffers of closed databases and destroyed references (tables, stashes, reference text) are kept, per
  * device, for the next handle of the same size: a run over many samples opens one database after the other, and on this
  * platform hipMalloc of a table that follows the hipFree of the previous one costs up to 2 s (KMC.java:412-420 has no
- * counterpart: the JVM unmaps). At most 16 blocks and 40 % of the device; given back by themselves when an allocation of THIS
+ * counterpart: the JVM unmaps). At most 16 blocks and half of the device (kcfx_set_cache_fraction; kcfx_screen_sharded raises it to
+ * 0.9 for the length of its call: a table of 200 GB must survive until the next database takes it); given back by themselves when an allocation of THIS
  * library fails, by this call (device < 0: all devices), never kept with KCFX_NO_POOL=1 in the environment. A process that
  * shares the device with another allocator (PyTorch, ...) should call this after closing its handles, or set KCFX_NO_POOL:
  * the other allocator cannot see the kept blocks and may run out of memory while they sit here. */
 int32_t kcfx_release_cached(int32_t device);
+/* The share of a device's memory that released buffers may occupy before the oldest go back to the driver (0 .. 1; default 0.5,
+ * or KCFX_POOL_FRACTION in the environment). A process that opens one large database after the other (tables of 100 - 200 GB:
+ * the next open gets the previous table's memory instead of waiting for the driver to clear it, 7 s against 12.8 s) raises it;
+ * a process that shares the device lowers it or calls kcfx_release_cached. Returns the previous value; out-of-range: unchanged. */
+double kcfx_set_cache_fraction(double fraction);
 
 /* ---- reference text + windows ---------------------------------------------------------------------- */
 
@@ -231,6 +241,9 @@ int32_t kcfx_ref_reserve_multi(kcfx_ref* ref, int32_t n_samples);
  * line table, whose size depends on its minimizer statistics. lines / regions may be NULL. */
 int32_t kcfx_table_plan(int64_t total_kmers, int32_t kmer_length, int32_t both_strands, int64_t free_bytes,
                         int64_t* lines, int32_t* regions);
+/* ... for a handle opened with kcfx_db_opts.expected_queries = `expected_queries` (0 = unknown: kcfx_table_plan). */
+int32_t kcfx_table_plan_for(int64_t total_kmers, int32_t kmer_length, int32_t both_strands, int64_t free_bytes, int64_t expected_queries,
+                            int64_t* lines, int32_t* regions);
 
 /* One-shot convenience: kcfx_ref_create + kcfx_screen_ref + kcfx_ref_destroy. */
 int32_t kcfx_screen(kcfx_db* db, const uint8_t* text, int64_t text_len, const int64_t* win_begin,

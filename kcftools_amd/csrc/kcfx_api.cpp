@@ -139,6 +139,7 @@ struct kcfx_db {
     unsigned long long* d_stats = nullptr;   // FORMAT_CELLS build counters (cells_settle_kernel)
     uint32_t* d_pop = nullptr;               // FORMAT_CELLS build scratch: k-mers per minimizer (freed after the build)
     int32_t pop_bits = 32;                   // 2^pop_bits byte counters: 32 = one per minimizer, lbits + 2 when 4 GiB cannot be had
+    int32_t crowd_by_minimizer = 0;          // the counters (and the run of a bid) keyed by the minimizer alone, as before round 6 (hook KCFX_CROWD_BY_MINIMIZER; cell_crowd_key)
     hipStream_t stream = nullptr;
     int32_t n_slices = 1, slice = 0;         // kcfx_db_open_slice: the table holds slice `slice` of `n_slices` of the database (cell_slice_of)
     int32_t slicing() const { return n_slices > 1 ? (n_slices << 8 | slice) : 0; }
@@ -173,6 +174,8 @@ struct kcfx_ref {
     kcfx_result* d_mres = nullptr;     // synchronous multi entry point: n_db * n_windows records
     size_t mres_bytes = 0;
     hipStream_t stream = nullptr;
+    uint64_t win_hash = 0;             // fingerprint of the window list (begin, len): two references are mergeable when they agree (kcfx_ref_merge_from)
+    hipEvent_t partial_done = nullptr; // recorded behind every partial screen on the stream it was launched on: the merge waits for it
     // measurement
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -221,7 +224,7 @@ int32_t check_device(int32_t device) {
 // worth its HBM while HBM is plentiful (288 GB): the sparsest of 0.15 / 0.35 / 0.60 whose table stays under 48 / 128 GiB
 // and under 60 % of the free device memory (several samples may be resident at once). KCFX_TABLE_LOAD overrides.
 double table_load_factor(int64_t n_keys, int slots) {
-    const char* s = getenv("KCFX_TABLE_LOAD");
+    const char* s = hook("KCFX_TABLE_LOAD");
     if (s) {
         const double a = atof(s);
         if (a >= 0.05 && a <= 0.9) return a;
@@ -237,14 +240,14 @@ double table_load_factor(int64_t n_keys, int slots) {
 
 // KCFX_TABLE_MODE=keyhash selects per-k-mer hashing (A/B against the default minimizer bucketing)
 int32_t table_mode() {
-    const char* s = getenv("KCFX_TABLE_MODE");
+    const char* s = hook("KCFX_TABLE_MODE");
     return (s && (!strcmp(s, "keyhash") || !strcmp(s, "0"))) ? MODE_KEYHASH : MODE_MINIMIZER;
 }
 
 // Minimizer length M: long enough that distinct minimizers rarely share an M-mer by chance (4^M >> 16 x keys),
 // short enough to keep runs long (run length ~ (k - M + 2) / 2).
 int32_t minimizer_len(int32_t k, int64_t n_keys) {
-    const char* s = getenv("KCFX_MM_LEN");
+    const char* s = hook("KCFX_MM_LEN");
     int m;
     if (s && atoi(s) > 0) {
         m = atoi(s);
@@ -267,45 +270,85 @@ int32_t cells_lbits_cap(int32_t) { return std::min<int32_t>(CELL_LBITS_MAX, 2 * 
 // any counter size, minimizer bucketing. KCFX_TABLE_FORMAT=lines keeps the 12-slot line table (A/B and test
 // hook, read at open time).
 bool cells_eligible(const kcfx_db* db, int32_t counter_size) {
-    const char* s = getenv("KCFX_TABLE_FORMAT");
+    const char* s = hook("KCFX_TABLE_FORMAT");
     if (s && !strcmp(s, "lines")) return false;
     const int32_t k = db->info.kmer_length;
     // (3- and 4-byte counters too: a counter beyond 65535 does not fit a cell, that k-mer lives in the stash)
     // (forward-only databases too: bit 14 of r tells a k-mer from its reverse complement)
     if (k < CELL_K_MIN || k > CELL_K_MAX || table_mode() != MODE_MINIMIZER ||
-        getenv("KCFX_MM_LEN") != nullptr)
+        hook("KCFX_MM_LEN") != nullptr)
         return false;
     // the minimizer is k - 15 bases: a line number cannot carry more than its 2 (k - 15) bits
     return db->info.total_kmers / std::max(1, db->n_slices) <= (int64_t)16 << cells_lbits_cap(k);   // (a slice holds 1 / n of the k-mers)
 }
 
-// 2^lbits lines of 16 cells. The sparser the table the fewer k-mers find their cell taken and go to the stash (bench
-// workload, 150 M k-mers: 9.7 % at 2^26 lines, 6.2 % at 2^27), and every stash lookup is a random 16-byte fetch of its own:
-// aim at ~0.075 k-mers per cell while that stays under 50 % of the free memory, else halve down to ~1 per cell.
-// KCFX_TABLE_LBITS overrides.
-// Memory against speed (profiles/r03_density.csv, bench workload, 150 M k-mers): 0.07 / 0.14 / 0.28 / 0.56 k-mers per cell =
-// 17.4 / 9.1 / 5.4 / 4.3 GB = 1.00 / 1.00 / 1.21 / 1.57 x the screening time per k-mer (round 4, same box: 0.0844 / 0.0841 /
-// 0.1000 ms per pass on one box, 0.0770 / 0.0840 on another: the sparse table is never the slower one). Round 3 built the handles
-// of one-pass jobs (kcfx_db_opts.expected_queries below QUERIES_FOR_SPARSE: the command-line driver) at ~0.3 per cell to save the
-// clearing of 12 GB more. Under the command-line driver the three sizes are indistinguishable end to end (profiles/r04_notes.md:
-// 0.37 - 0.55 s each over six rounds) while the screening pass is 16 - 30 % slower at 0.28: since round 4 every handle gets
-// the same ~0.075 per cell, and expected_queries only decides the crowding counters (pop_alloc).
-constexpr double QUERIES_FOR_SPARSE = 1e10;
+// 2^lbits lines of 16 cells: memory (and the time the driver takes to hand it out) against the speed of a screening pass.
+// A denser table sends more k-mers to second / third lines and the stash, and every such look-up is a random request of its own
+// (profiles/r06_density.csv, bench workload, 150 M k-mers, screening kernel on a planned reference, same box):
+//     2^27 lines  0.070 per cell  17.2 GB   5.6 % outside their first-choice cell  0.03 % in the stash  0.0797 ms per pass
+//     2^26        0.140            8.6 GB   8.7 %                                   0.18 %               0.0833 ms
+//     2^25        0.280            4.4 GB  13.6 %                                   1.08 %               0.0921 ms
+//     2^24        0.559            3.2 GB  18.9 %                                   5.97 % (1 GiB stash) 0.1142 ms
+// What the memory costs is not the clearing (a few ms of hipMemset) but the ALLOCATION on a device that other processes have used:
+// the driver hands out memory that a finished process has just given back only after clearing it, at 28 - 42 GB/s, and while it
+// does so the uploads of the loading pass stand still (profiles/r06_notes.md section 1: the one-sample job end to end, 2^27 lines:
+// 0.47 - 0.53 s on an idle device, 2.8 - 3.1 s right after a process that had written 64 GiB; 2^25 lines: 0.45 - 0.55 s either way.
+// Rounds 4 and 5 gave every handle 2^27 lines "because the sizes are indistinguishable end to end" -- they are, on a device nobody
+// else has just used; the review's box was not one: 0.98 - 1.49 s in three runs of four).
+// So the size follows the look-ups the handle will serve (kcfx_db_opts.expected_queries = reference k-mers x passes):
+//     cost(L) = bytes(L) / ALLOC_BYTES_PER_S + expected_queries x seconds_per_query(k-mers per cell at L)
+// minimised over the sizes from "at most ~0.3 per cell" (the density the large databases get as well: cells_regions) to ~0.075 per
+// cell. One pass of a 30 Mb reference: 2^25 lines; the sparse table pays for its 13 GB after ~4 x 10^11 look-ups (a resident engine
+// that screens thousands of references, a cohort of hundreds of samples' worth of windows). expected_queries = 0 (unknown: a
+// handle somebody keeps) gets the sparse table, as kcfx_db_open always did. KCFX_TABLE_LBITS overrides.
+constexpr double QUERIES_FOR_SPARSE = 1e10;             // (pop_alloc: below this the build takes the cheaper crowding counters)
+constexpr double ALLOC_BYTES_PER_S = 35e9;              // what a used device hands out per second (profiles/r06_e2e_policy.log)
+constexpr double DENSITY_DENSE = 0.30, DENSITY_SPARSE = 0.075;
+// seconds per look-up at d k-mers per cell: the table above, linear in log2(d) between its rows (below 0.07 nothing more to gain)
+double seconds_per_query(double d) {
+    static const double dd[4] = {0.070, 0.140, 0.280, 0.559}, tt[4] = {0.0797e-3 / 30.0e6, 0.0833e-3 / 30.0e6, 0.0921e-3 / 30.0e6, 0.1142e-3 / 30.0e6};
+    if (d <= dd[0]) return tt[0];
+    for (int i = 1; i < 4; ++i)
+        if (d <= dd[i]) return tt[i - 1] + (tt[i] - tt[i - 1]) * std::log2(d / dd[i - 1]);
+    return tt[3] * (d / dd[3]);                         // (denser than anything the policy picks by itself)
+}
 int32_t cells_lbits(int64_t n_keys, int32_t k, bool both, int64_t expected_queries, int32_t line_footprint, size_t free_b) {
     const int32_t cap = cells_lbits_cap(k);
     const int32_t lmin = cell_lbits_min(both);
-    const char* s = getenv("KCFX_TABLE_LBITS");
+    const char* s = hook("KCFX_TABLE_LBITS");
     if (s && atoi(s) >= lmin && atoi(s) <= cap) return atoi(s);
     // A table above 48 GiB is halved while that leaves it at <= ~0.5 k-mers per cell (the 2.1 G-k-mer test database: 2^28 lines), and
     // beyond that only when it does not fit 60 % of the free memory: a database of billions of GENOMIC k-mers needs the lines --
     // at ~1 per cell a quarter of it lives in the stash, at ~0.5 a twelfth (profiles/r04_notes.md) -- and a second database that
     // does not fit beside it is waited for by the sharded loader (kcfx_shard.cpp).
     const double soft_cap = 48.0 * (double)(1ull << 30), hard_cap = 0.6 * (double)free_b;
-    (void)expected_queries;                               // (one density for every handle since round 4, see above)
-    const double density = 0.075;
-    int32_t L = lmin;
-    while (L < cap && 16.0 * (double)(1ull << L) * density < (double)n_keys) ++L;
+    auto per_cell = [&](int32_t l) { return (double)n_keys / (16.0 * (double)(1ull << l)); };
     auto bytes = [&](int32_t l) { return (double)(1ull << l) * line_footprint; };
+    int32_t L = lmin;
+    while (L < cap && per_cell(L) > DENSITY_SPARSE) ++L;
+    if (expected_queries > 0) {
+        // the cheapest size for that many look-ups, from the last power of two ABOVE ~0.3 per cell (cells_regions then grows it in
+        // quarters to the first size at or under 0.3: the dense end of the policy is the same for every database) upwards
+        int32_t Ld = lmin;
+        while (Ld < L && per_cell(Ld + 1) > DENSITY_DENSE) ++Ld;
+        int32_t best = Ld;
+        double best_cost = 0;
+        for (int32_t l = Ld; l <= L; ++l) {
+            // (what the handle gets at l: the region step of cells_regions when l is left above 0.3 per cell)
+            double lines = (double)(1ull << l);
+            if (per_cell(l) > DENSITY_DENSE && line_footprint == LINE_BYTES)
+                for (const double f : {1.25, 1.5, 1.75, 2.0}) {
+                    lines = f * (double)(1ull << l);
+                    if ((double)n_keys / (16.0 * lines) <= DENSITY_DENSE) break;
+                }
+            const double cost = lines * line_footprint / ALLOC_BYTES_PER_S + (double)expected_queries * seconds_per_query((double)n_keys / (16.0 * lines));
+            if (l == Ld || cost < best_cost) {
+                best = l;
+                best_cost = cost;
+            }
+        }
+        L = best;
+    }
     while (L > lmin && bytes(L) > soft_cap && 16.0 * (double)(1ull << (L - 1)) * 0.5 >= (double)n_keys) --L;
     while (L > lmin && bytes(L) > hard_cap && 16.0 * (double)(1ull << (L - 1)) >= (double)n_keys) --L;
     return L;
@@ -323,13 +366,13 @@ void cells_regions(int64_t n_keys, int32_t k, bool both, int32_t L0, size_t free
     *regions = 1;
     *lbits = L0;
     const int32_t lmin = cell_lbits_min(both), cap = cells_lbits_cap(k);
-    if (const char* rs = getenv("KCFX_TABLE_REGIONS")) {
+    if (const char* rs = hook("KCFX_TABLE_REGIONS")) {
         const int v = atoi(rs);
         if ((v == 3 || v == 5 || v == 7) && ((uint64_t)v << L0) < (1ull << 32)) *regions = v;
         return;
     }
     auto density = [&](double lines) { return (double)n_keys / (16.0 * lines); };
-    if (getenv("KCFX_TABLE_LBITS") != nullptr || density((double)(1ull << L0)) <= 0.30) return;
+    if (hook("KCFX_TABLE_LBITS") != nullptr || density((double)(1ull << L0)) <= 0.30) return;
     const double one = (double)(1ull << L0) * LINE_BYTES, gib48 = 48.0 * (double)(1ull << 30), most = 0.80 * (double)free_b;
     const double limit = one < gib48 ? std::min(gib48, most) : most;        // (a table under 48 GiB grows up to them)
     static const struct { int32_t r, dl; } steps[] = {{5, -2}, {3, -1}, {7, -2}, {1, 1}, {5, -1}, {3, 0}, {7, -1}};   // ascending sizes
@@ -359,15 +402,24 @@ int32_t pop_alloc(kcfx_db* db) {
     db->pop_bits = 32;
     hipError_t e = hipErrorOutOfMemory;
     // A handle that serves few look-ups (kcfx_db_opts.expected_queries: the command-line driver's one pass) takes the fallback by
-    // policy: allocating 4 GiB in a fresh process costs ~30 ms of its 0.5 s, the look-ups it saves a fraction of a millisecond.
+    // policy: allocating 4 GiB costs 30 ms of its 0.5 s in a fresh process on an idle device and 120 ms on a used one, the
+    // look-ups it saves a fraction of a millisecond.
     // (KCFX_CROWD_PER_LINE=1: the fallback by choice -- test hook, read when the handle is made)
     const bool few = db->expected_queries > 0 && (double)db->expected_queries < QUERIES_FOR_SPARSE;
-    if (!few && getenv("KCFX_CROWD_PER_LINE") == nullptr && free_device_bytes() > ((size_t)LINE_BYTES * db->n_lines) + ((size_t)6 << 30))
+    if (!few && hook("KCFX_CROWD_PER_LINE") == nullptr && free_device_bytes() > ((size_t)LINE_BYTES * db->n_lines) + ((size_t)6 << 30))
         e = dev_alloc(&db->d_pop, cells_pop_bytes(db->pop_bits));
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        db->pop_bits = std::min(32, db->lbits + 2);
-        KCFX_HIP(dev_alloc(&db->d_pop, cells_pop_bytes(db->pop_bits)));
+        // (round 6: 2^30 counters at least -- 1 GiB, 30 ms of allocation where 4 GiB cost 120 -- since the counters are keyed by the
+        // locus: at lbits + 2 bits a bucket of the bench database at 0.28 per cell holds 1.1 k-mers and every stranger looks crowded --
+        // 2.2 M queued look-ups per pass; 2^29 / 2^30 / 2^31 / 2^32 counters: 0.92 / 0.88 / 0.86 / 0.86 M, profiles/r06_notes.md section 2)
+        db->pop_bits = std::min(32, std::max(30, db->lbits + 2));
+        if (const char* pb = hook("KCFX_POP_BITS")) db->pop_bits = std::max(db->lbits + 2, std::min(32, atoi(pb)));      // (experiments: the resolution of the cheap counters)
+        if (dev_alloc(&db->d_pop, cells_pop_bytes(db->pop_bits)) != hipSuccess) {      // (a device that cannot spare even that: one counter per line + 2 bits)
+            (void)hipGetLastError();
+            db->pop_bits = std::min(32, db->lbits + 2);
+            KCFX_HIP(dev_alloc(&db->d_pop, cells_pop_bytes(db->pop_bits)));
+        }
     }
     KCFX_HIP(hipMemsetAsync(db->d_pop, 0, cells_pop_bytes(db->pop_bits), db->stream));
     return KCFX_OK;
@@ -387,9 +439,10 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys, bool deferred = false) {
     // their first-choice cell (load_suffix_file). The query side pays ~1.3 line requests per run in an extended table, so a
     // database that does not need it must not get it: the bench cohort (1.2 G records, mostly k-mers private to one sample) screens
     // in 0.21 ms plain and 0.28 ms extended. KCFX_TABLE_EXT=0 / 1 decides by hand (tests, A/B). Cohort tables stay plain.
+    db->crowd_by_minimizer = hook("KCFX_CROWD_BY_MINIMIZER") != nullptr;
     db->ext = 0;
     db->ext_auto = n_keys >= 500000000ll && db->line_footprint == LINE_BYTES;
-    if (const char* xe = getenv("KCFX_TABLE_EXT")) {
+    if (const char* xe = hook("KCFX_TABLE_EXT")) {
         db->ext = atoi(xe) != 0;
         db->ext_auto = false;
     }
@@ -423,7 +476,7 @@ int32_t cells_alloc(kcfx_db* db, int64_t n_keys, bool deferred = false) {
                 // (the driver serves one allocation at a time and a table of 200 GB holds it for 5 - 6 s: the loader's own buffers --
                 // a few hundred MB, or the resident records -- go first, or its first pass over the file starts that much later;
                 // alloc_go comes from load_suffix_file, from whoever waits for the table, or after five seconds)
-                const bool early = getenv("KCFX_LOAD_TABLE_EARLY") != nullptr;     // (the table before everything else, as in rounds 1 - 4: profiles/r05_notes.md section 5)
+                const bool early = hook("KCFX_LOAD_TABLE_EARLY") != nullptr;     // (the table before everything else, as in rounds 1 - 4: profiles/r05_notes.md section 5)
                 for (int waited = 0; !early && !db->alloc_go && waited < 25000; ++waited) std::this_thread::sleep_for(std::chrono::microseconds(200));
                 hipError_t e2 = hipSetDevice(db->device);
                 if (e2 == hipSuccess) e2 = dev_alloc(&db->d_lines, (size_t)LINE_BYTES * db->n_lines);
@@ -494,7 +547,7 @@ int32_t cells_stash_alloc(kcfx_db* db) {
     db->info.regions = db->regions;
     const size_t free_b = free_device_bytes();
     double budget = 0.5 * (double)free_b;
-    if (const char* s = getenv("KCFX_STASH_BUDGET")) budget = std::max(0.0, atof(s));
+    if (const char* s = hook("KCFX_STASH_BUDGET")) budget = std::max(0.0, atof(s));
     uint64_t slots = 1024;
     while (slots < 4 * h[0]) slots <<= 1;
     while (slots > 1024 && (double)slots * sizeof(uint4) > budget && (double)(slots >> 1) * 0.8 >= (double)h[0]) slots >>= 1;
@@ -534,7 +587,7 @@ void table_release(kcfx_db* db) {
 }
 
 int32_t table_alloc(kcfx_db* db, int64_t n_keys, int32_t counter_size, bool allow_cells = true, bool deferred = false) {
-    db->generic = getenv("KCFX_GENERIC_KERNEL") != nullptr;   // A/B and test hook: read when the handle is made, never per launch
+    db->generic = hook("KCFX_GENERIC_KERNEL") != nullptr;   // A/B and test hook: read when the handle is made, never per launch
     if (allow_cells && cells_eligible(db, counter_size) && !db->generic) return cells_alloc(db, n_keys, deferred);
     db->wide = counter_size > 2 ? 1 : 0;
     db->mode = table_mode();
@@ -616,6 +669,7 @@ void ref_free(kcfx_ref* r) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
     }
+    if (r->partial_done) (void)hipEventDestroy(r->partial_done);
     if (r->d_text) (void)dev_free(r->d_text);
     if (r->d_tiles) (void)dev_free(r->d_tiles);
     if (r->d_win_tile0) (void)dev_free(r->d_win_tile0);
@@ -662,7 +716,10 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
         return fail(KCFX_ERR_FORMAT, "missing KMCS marker in " + path);
     }
     LoadTrace tr;
-    const int64_t CH = 4ll << 20;    // records per chunk
+    // records per chunk (KCFX_LOAD_CHUNK_RECORDS: test hook -- a few thousand records per chunk make a small database take many chunks,
+    // both buffers reused, chunks at byte offsets that are no multiple of 4)
+    int64_t CH = 4ll << 20;
+    if (const char* ce = hook("KCFX_LOAD_CHUNK_RECORDS")) CH = std::max<int64_t>(64, std::min<int64_t>(CH, atoll(ce)));
     const int64_t chunk_bytes = CH * h.record_size;
     uint8_t* h_buf[2] = {nullptr, nullptr};
     uint8_t* d_rec[2] = {nullptr, nullptr};
@@ -671,7 +728,6 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     uint32_t* d_counts = nullptr;
     uint64_t* d_pw = nullptr;          // the cells of the resident records, kept by the first pass for the later ones (RecProbes)
     uint8_t* d_ps = nullptr;
-    uint8_t* d_raw = nullptr;          // the .kmc_suf records as the file holds them, resident between the passes (see below)
     uint32_t* d_pop2 = nullptr;        // the crowding counters of the OTHER form of the table (extended), counted in the same first pass
     LostList lost;                     // the k-mers the settle pass counts for the stash, written down (records not resident: see below)
     hipEvent_t done[2] = {nullptr, nullptr};       // the copy of chunk buffer [i] to the device has finished (recorded on `copier`)
@@ -688,7 +744,6 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
         (void)hipStreamSynchronize(db->stream);
         if (copier) (void)hipStreamDestroy(copier);
         copier = nullptr;
-        if (d_raw) (void)dev_free_idle(d_raw);
         if (lost.keys) (void)dev_free_idle(lost.keys);
         if (lost.counts) (void)dev_free_idle(lost.counts);
         if (lost.n) (void)dev_free_idle(lost.n);
@@ -718,22 +773,18 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     const bool cells = (db->fmt == FORMAT_CELLS);
     const bool two_phase = (db->mode == MODE_MINIMIZER);
     // keep every decoded record resident between the phases?
-    size_t free_b = free_device_bytes();
-    // (the table may still be on its way -- table_ready -- and must not be counted as free room: conservative when it has arrived)
     // (the table may still be on its way -- table_ready -- and must not be counted as free room; once its allocation has landed
-    // hipMemGetInfo no longer counts it and subtracting it again -- round 4 did -- left a wheat-scale open no tier that fit)
-    if (db->alloc_thread.joinable() && !db->alloc_landed) free_b -= std::min<size_t>(free_b, (size_t)LINE_BYTES * db->n_lines);
-    const char* raw_env = getenv("KCFX_LOAD_RAW");          // 1: the raw tier whatever fits (test hook); 0: never
-    const bool resident = two_phase && getenv("KCFX_LOAD_STREAM_TWICE") == nullptr && !(raw_env && raw_env[0] == '1') &&
+    // hipMemGetInfo no longer counts it and subtracting it again -- round 4 did -- left a wheat-scale open no tier that fit. `landed`
+    // is read BEFORE the free memory: an allocation that lands between the two reads is then subtracted once too often -- the
+    // conservative side -- never counted as free)
+    const bool landed = db->alloc_landed.load();
+    size_t free_b = free_device_bytes();
+    if (db->alloc_thread.joinable() && !landed) free_b -= std::min<size_t>(free_b, (size_t)LINE_BYTES * db->n_lines);
+    const bool resident = two_phase && hook("KCFX_LOAD_STREAM_TWICE") == nullptr &&
                           (double)h.total * 12.0 + (double)(2 * chunk_bytes) + (double)(64 << 20) < 0.5 * (double)free_b;
-    // Round 5, between "everything decoded stays" and "the file is streamed once per pass": the RECORDS stay, as the file holds them
-    // (record_size bytes each: 8 for k = 31, p = 7, 2-byte counters -- two thirds of the decoded 12, a third of the 21 with the kept
-    // cells), and every pass decodes its chunk again from HBM; they make room for the stash before its pass, which streams the file
-    // once more. Built for the wheat-scale open (8 G k-mers, 65 GB of records beside 192 GiB of lines: two streams of the file instead
-    // of six), measured, and NOT the default: on this platform allocating the 65 GB costs 4 - 5 s (the driver hands memory out
-    // cleared) and a build pass from HBM takes 1.95 s where a streamed one takes 2.5 s -- 20.0 s against 18.7 s for the open
-    // (profiles/r05_notes.md). KCFX_LOAD_RAW=1 selects it (tests/test_gpu_parity.py runs all four tiers against each other).
-    bool raw_tier = two_phase && cells && !resident && raw_env && raw_env[0] == '1' && getenv("KCFX_LOAD_STREAM_TWICE") == nullptr;
+    // (Round 5 built a tier between "everything decoded stays" and "the file is streamed once per pass" -- the RECORDS resident as the
+    // file holds them, decoded again per pass -- and measured it slower than streaming at the size it was meant for: allocating 65 GB
+    // costs 4 - 5 s on this platform, 20.0 s against 18.7 s for the wheat-scale open, profiles/r05_notes.md section 5. Removed in round 6.)
     const int64_t n_chunk_max = std::min<int64_t>(CH, std::max<int64_t>(h.total, 1));
     const int64_t n_keys_buf = resident ? std::max<int64_t>(h.total, 1) : n_chunk_max;
     for (int i = 0; i < 2; ++i) {
@@ -742,28 +793,25 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
         LOAD_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
         LOAD_HIP(hipEventCreateWithFlags(&decoded[i], hipEventDisableTiming));
     }
-    if (getenv("KCFX_LOAD_ONE_STREAM") == nullptr) LOAD_HIP(hipStreamCreateWithFlags(&copier, hipStreamNonBlocking));   // (A/B and test hook)
+    LOAD_HIP(hipStreamCreateWithFlags(&copier, hipStreamNonBlocking));
     LOAD_HIP(dev_alloc(&d_lut, (size_t)std::max<int64_t>(h.lut_entries, 1) * 8));
     LOAD_HIP(dev_alloc(&d_keys, (size_t)n_keys_buf * 8));
     LOAD_HIP(dev_alloc(&d_counts, (size_t)n_keys_buf * 4));
     // cell tables, records resident: 9 more bytes per record buy four of the five passes their ~600 instructions per k-mer
     // (KCFX_LOAD_NO_PROBES=1: every pass derives the cells itself, as a streamed-twice load has to -- A/B and test hook)
-    const bool keep_probes = cells && resident && getenv("KCFX_LOAD_NO_PROBES") == nullptr &&
+    const bool keep_probes = cells && resident && hook("KCFX_LOAD_NO_PROBES") == nullptr &&
                              (double)h.total * 21.0 + (double)(2 * chunk_bytes) + (double)(64 << 20) < 0.5 * (double)free_b;
     if (keep_probes) {
         LOAD_HIP(dev_alloc(&d_pw, (size_t)n_keys_buf * 8));
         LOAD_HIP(dev_alloc(&d_ps, (size_t)n_keys_buf));
     }
-    if (raw_tier) {
-        if (dev_alloc(&d_raw, (size_t)h.total * h.record_size + 64) != hipSuccess) {
-            (void)hipGetLastError();
-            d_raw = nullptr;
-            raw_tier = false;
-        }
-    }
     // (a database that may want an extended table -- ext_auto -- counts its k-mers per minimizer BOTH ways in the first pass, the
     // second way under the file's copies: the choice then costs no pass of its own)
-    const bool early_ext = cells && db->ext_auto && !db->ext && db->pop_bits == 32 && getenv("KCFX_EXT_LATE") == nullptr;
+    const bool early_ext = cells && db->ext_auto && !db->ext && db->pop_bits == 32;
+    // what pass 0 counts its k-mers by (cell_crowd_key): the LOCUS -- except while the choice of an extended table is still to be made,
+    // which is estimated from the k-mers per MINIMIZER; the locus counters are then the second set (d_pop2: the same key as an
+    // extended table's), or counted in a pass of their own once the choice is made
+    int32_t count_by_min = (early_ext || db->crowd_by_minimizer) ? 1 : 0;
     if (early_ext && !resident) {
         if (dev_alloc(&d_pop2, cells_pop_bytes(db->pop_bits)) != hipSuccess) {
             (void)hipGetLastError();
@@ -774,7 +822,7 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     }
     if (h.lut_entries) LOAD_HIP(hipMemcpyAsync(d_lut, h.lut_bytes, (size_t)h.lut_entries * 8, hipMemcpyHostToDevice, db->stream));
     db->alloc_go = true;                                    // (the table's allocation, if it is still to come: from here on)
-    tr.mark(raw_tier ? "buffers + LUT upload (records will stay resident)" : "buffers + LUT upload");
+    tr.mark("buffers + LUT upload");
 
     // One pass of the build over a batch of decoded records. Line tables: 0 = count per home line (minimizer tables only),
     // 1 = insert. Cell tables: 0 = count per minimizer sub-bucket, 1 / 2 = claim the first-choice cells / write the winners' cell words, 3 = settle
@@ -786,14 +834,14 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
             uint64_t* pw = d_pw ? d_pw + (keys - d_keys) : nullptr;
             uint8_t* ps = d_ps ? d_ps + (keys - d_keys) : nullptr;
             if (phase == 0) {
-                if (d_pop2 && !db->ext) {                   // ... and per minimizer of the extended form (see early_ext)
+                if (d_pop2 && !db->ext) {                   // ... and per locus = per minimizer of the extended form (see early_ext)
                     const hipError_t e0 = launch_cells_count(d_pop2, db->pop_bits, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream, 0, 1);
                     if (e0 != hipSuccess) return e0;
                 }
-                return pw ? launch_cells_resolve(db->d_pop, db->pop_bits, kk, db->lbits, db->info.both_strands, keys, counts, n, pw, ps, db->stream, db->ext)
-                          : launch_cells_count(db->d_pop, db->pop_bits, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream, 0, db->ext);
+                return pw ? launch_cells_resolve(db->d_pop, db->pop_bits, kk, db->lbits, db->info.both_strands, keys, counts, n, pw, ps, db->stream, db->ext, count_by_min)
+                          : launch_cells_count(db->d_pop, db->pop_bits, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream, 0, db->ext, count_by_min);
             }
-            if (phase == 1 || phase == 2) return launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, phase == 1 ? 1 : 0, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream, 0, pw, ps, db->ext, db->regions, db->slicing());
+            if (phase == 1 || phase == 2) return launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, phase == 1 ? 1 : 0, kk, db->lbits, db->info.both_strands, keys, counts, n, db->stream, 0, pw, ps, db->ext, db->regions, db->slicing(), db->crowd_by_minimizer);
             if (phase == 3) return launch_cells_settle(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stats, db->stream, 0, pw, ps, db->ext, db->regions, db->slicing(), lost);
             return launch_cells_stash(db->d_lines, kk, db->lbits, db->info.both_strands, keys, counts, n, db->d_stash, db->stash_mask, db->stream, 0, pw, ps, db->ext, db->regions, db->slicing());
         }
@@ -826,8 +874,7 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
                 t_read += t_c - t_b;
             }
             // d_rec[turn] was last read by the decode two chunks ago: before this copy in stream order, or (the copier) waited for
-            // (the raw tier: the chunk lands in its place among the resident records)
-            uint8_t* const rec_at = d_raw ? d_raw + (size_t)first * h.record_size : d_rec[turn];
+            uint8_t* const rec_at = d_rec[turn];
             if (copier && used[turn]) LOAD_HIP(hipStreamWaitEvent(copier, decoded[turn], 0));
             LOAD_HIP(hipMemcpyAsync(rec_at, h_buf[turn], (size_t)bytes, hipMemcpyHostToDevice, up));
             LOAD_HIP(hipEventRecord(done[turn], up));
@@ -857,15 +904,6 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
             }
             return KCFX_OK;
         }
-        if (d_raw) {                                        // the records are resident: decode chunk by chunk from HBM
-            for (int64_t first = 0; first < h.total; first += CH) {
-                const int64_t n = std::min(CH, h.total - first);
-                LOAD_HIP(launch_decode_records(d_raw + (size_t)first * h.record_size, first, n, h.record_size, h.suffix_bytes, h.counter_size, h.p, d_lut,
-                                               h.lut_entries, d_keys, d_counts, db->stream));
-                LOAD_HIP(apply(phase, d_keys, d_counts, n));
-            }
-            return KCFX_OK;
-        }
         LOAD_HIP(hipStreamSynchronize(db->stream));
         return stream_file(phase, false);
     };
@@ -874,9 +912,9 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     // 1.4 s of 12.6). Room for a sixteenth of the database, within a twentieth of the free memory (the stash itself comes out of the
     // same memory next); a list that overflows is ignored. KCFX_LOAD_NO_LOST_LIST=1: never (A/B and test hook).
     auto lost_list_alloc = [&]() {
-        if (!cells || resident || lost.keys || getenv("KCFX_LOAD_NO_LOST_LIST")) return;
+        if (!cells || resident || lost.keys || hook("KCFX_LOAD_NO_LOST_LIST")) return;
         unsigned long long cap = (unsigned long long)std::max<int64_t>(h.total / 16, 1024);
-        if (const char* s = getenv("KCFX_LOAD_LOST_CAP")) cap = std::max(1ull, strtoull(s, nullptr, 10));          // (test hook: an overflowing list)
+        if (const char* s = hook("KCFX_LOAD_LOST_CAP")) cap = std::max(1ull, strtoull(s, nullptr, 10));          // (test hook: an overflowing list)
         else cap = std::min<unsigned long long>(cap, (unsigned long long)(0.05 * (double)free_device_bytes() / 12.0));
         if (cap == 0) return;
         if (dev_alloc(&lost.keys, (size_t)cap * 8) != hipSuccess || dev_alloc(&lost.counts, (size_t)cap * 4) != hipSuccess ||
@@ -919,7 +957,9 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
         // hash to its line and cell: d = k-mers per cell of them on average, and of two runs that contest a line one keeps every
         // cell (cell_bid) -- half of the contested k-mers move (the 2.1 G-k-mer database of random k-mers at 0.33 per cell: 11 %
         // by its own minimizers, 49 % outside their cells in the plain table that round 4 built first)
-        const double d = all / (16.0 * (double)db->n_lines);
+        // (a slice's table has 1 / n_slices of the lines and holds 1 / n_slices of the k-mers the counters saw: the counters are of the
+        // whole database)
+        const double d = all / (double)std::max(1, db->n_slices) / (16.0 * (double)db->n_lines);
         const double own = all > 0 ? moved / all : 0.0;
         *share = own + (1.0 - own) * 0.5 * (1.0 - std::exp(-d));
         return KCFX_OK;
@@ -941,16 +981,18 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
                 double share = 0;
                 if ((rc = ext_by_crowding(&share))) return rc;
                 if (tr.on) fprintf(stderr, "[kcfx load] crowding counters: %.1f %% of the k-mers would sit outside their first-choice cells in a plain table\n", 100.0 * share);
-                if (share > EXT_MOVED_SHARE) {
-                    db->ext = 1;                            // nothing but the counters has been built yet
-                    if (d_pop2) {                           // ... and the extended form's were counted beside them
+                if (share > EXT_MOVED_SHARE) db->ext = 1;   // nothing but the counters has been built yet
+                if (db->ext || !db->crowd_by_minimizer) {
+                    // the bids want the counters per LOCUS (an extended table's own key): counted beside the others, or now
+                    count_by_min = db->crowd_by_minimizer;
+                    if (d_pop2) {
                         LOAD_HIP(hipStreamSynchronize(db->stream));
                         std::swap(db->d_pop, d_pop2);
-                    } else {                                // (records resident, or no room for a second set: once more, per extended minimizer)
+                    } else {                                // (records resident, or no room for a second set: once more)
                         LOAD_HIP(hipMemsetAsync(db->d_pop, 0, cells_pop_bytes(db->pop_bits), db->stream));
                         if ((rc = later_pass(0))) return rc;
                     }
-                    tr.mark("extended table chosen by the crowding counters");
+                    if (db->ext) tr.mark("extended table chosen by the crowding counters");
                 }
                 if (d_pop2) {
                     LOAD_HIP(hipStreamSynchronize(db->stream));
@@ -970,6 +1012,7 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
                 if (tr.on) fprintf(stderr, "[kcfx load] plain table: %.1f %% of the k-mers outside their first-choice cells\n", 100.0 * (double)(st4[0] + st4[3]) / (double)std::max<unsigned long long>(st4[1], 1));
                 if ((double)(st4[0] + st4[3]) > EXT_MOVED_SHARE * (double)std::max<unsigned long long>(st4[1], 1)) {
                     db->ext = 1;                            // start over: lines, counters and statistics cleared, the four passes again
+                    count_by_min = db->crowd_by_minimizer;
                     LOAD_HIP(hipMemsetAsync(db->d_lines, 0, (size_t)LINE_BYTES * db->n_lines, db->stream));
                     LOAD_HIP(hipMemsetAsync(db->d_pop, 0, cells_pop_bytes(db->pop_bits), db->stream));
                     LOAD_HIP(hipMemsetAsync(db->d_stats, 0, 4 * sizeof(unsigned long long), db->stream));
@@ -979,11 +1022,6 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
                         if ((rc = later_pass(phase))) return rc;
                     tr.mark("rebuilt as an extended table");
                 }
-            }
-            if (d_raw) {                                    // the resident records make room for the stash; its pass streams the file once more
-                LOAD_HIP(hipStreamSynchronize(db->stream));
-                (void)dev_free_idle(d_raw);
-                d_raw = nullptr;
             }
             if ((rc = cells_stash_alloc(db))) {
                 cleanup();
@@ -1179,10 +1217,10 @@ int32_t kcfx_db_open_slice(const char* kmc_prefix, int32_t device, const kcfx_db
     const int64_t n_mine = n_slices > 1 ? std::min<int64_t>(h.total, h.total / n_slices + h.total / (50 * n_slices) + 4096) : h.total;
     if (n_slices > 1) {
         const int32_t kk = db->info.kmer_length;
-        if (kk < CELL_K_MIN || kk > CELL_K_MAX || getenv("KCFX_TABLE_FORMAT") || getenv("KCFX_GENERIC_KERNEL") || getenv("KCFX_MM_LEN") || table_mode() != MODE_MINIMIZER)
+        if (kk < CELL_K_MIN || kk > CELL_K_MAX || hook("KCFX_TABLE_FORMAT") || hook("KCFX_GENERIC_KERNEL") || hook("KCFX_MM_LEN") || table_mode() != MODE_MINIMIZER)
             return fail(KCFX_ERR_ARG, "table slices need a cell table (k = 19 .. 31, the default table format)");
     }
-    int32_t rc = table_alloc(db, n_mine, h.counter_size, true, getenv("KCFX_SYNC_ALLOC") == nullptr);
+    int32_t rc = table_alloc(db, n_mine, h.counter_size, true, hook("KCFX_SYNC_ALLOC") == nullptr);
     tr.mark("table alloc (deferred)");
     if (!rc) rc = load_suffix_file(db, std::string(kmc_prefix) + ".kmc_suf", h);
     // (the allocation thread may still be running when the streaming failed first -- an I/O error, or the decoded arrays lost the
@@ -1226,14 +1264,19 @@ int32_t kcfx_db_open_slice(const char* kmc_prefix, int32_t device, const kcfx_db
 } KCFX_CATCH("kcfx_db_open_slice")
 
 int32_t kcfx_table_plan(int64_t total_kmers, int32_t kmer_length, int32_t both_strands, int64_t free_bytes,
-                        int64_t* lines, int32_t* regions) try {
-    if (total_kmers < 0 || free_bytes < 0) return fail(KCFX_ERR_ARG, "kcfx_table_plan: negative argument");
+                        int64_t* lines, int32_t* regions) {
+    return kcfx_table_plan_for(total_kmers, kmer_length, both_strands, free_bytes, 0, lines, regions);
+}
+
+int32_t kcfx_table_plan_for(int64_t total_kmers, int32_t kmer_length, int32_t both_strands, int64_t free_bytes, int64_t expected_queries,
+                            int64_t* lines, int32_t* regions) try {
+    if (total_kmers < 0 || free_bytes < 0 || expected_queries < 0) return fail(KCFX_ERR_ARG, "kcfx_table_plan: negative argument");
     if (kmer_length < 1 || kmer_length > 32) return fail(KCFX_ERR_FORMAT, "unsupported k-mer length (1..32)");
     int64_t n_lines = 0;
     int32_t R = 1;
     const bool both = both_strands != 0;
     if (kmer_length >= CELL_K_MIN && kmer_length <= CELL_K_MAX && total_kmers <= (int64_t)16 << cells_lbits_cap(kmer_length)) {
-        const int32_t L0 = cells_lbits(total_kmers, kmer_length, both, 0, LINE_BYTES, (size_t)free_bytes);
+        const int32_t L0 = cells_lbits(total_kmers, kmer_length, both, expected_queries, LINE_BYTES, (size_t)free_bytes);
         int32_t Lr = L0;
         cells_regions(total_kmers, kmer_length, both, L0, (size_t)free_bytes, &R, &Lr);
         n_lines = (int64_t)R << Lr;
@@ -1245,7 +1288,7 @@ int32_t kcfx_table_plan(int64_t total_kmers, int32_t kmer_length, int32_t both_s
     if (lines) *lines = n_lines;
     if (regions) *regions = R;
     return KCFX_OK;
-} KCFX_CATCH("kcfx_table_plan")
+} KCFX_CATCH("kcfx_table_plan_for")
 
 int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, int32_t kmer_length,
                       int32_t counter_size, int32_t both_strands, int32_t device, kcfx_db** out) try {
@@ -1299,9 +1342,9 @@ int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, 
         int32_t rc = table_alloc(db, n, counter_size, allow_cells);
         if (rc || n == 0) return rc;
         if (db->fmt == FORMAT_CELLS) {
-            if ((e = launch_cells_count(db->d_pop, db->pop_bits, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream, 0, db->ext)) != hipSuccess ||
-                (e = launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, 1, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream, 0, nullptr, nullptr, db->ext, db->regions)) != hipSuccess ||
-                (e = launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, 0, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream, 0, nullptr, nullptr, db->ext, db->regions)) != hipSuccess ||
+            if ((e = launch_cells_count(db->d_pop, db->pop_bits, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream, 0, db->ext, db->crowd_by_minimizer)) != hipSuccess ||
+                (e = launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, 1, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream, 0, nullptr, nullptr, db->ext, db->regions, 0, db->crowd_by_minimizer)) != hipSuccess ||
+                (e = launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, 0, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->stream, 0, nullptr, nullptr, db->ext, db->regions, 0, db->crowd_by_minimizer)) != hipSuccess ||
                 (e = launch_cells_settle(db->d_lines, kmer_length, db->lbits, db->info.both_strands, d_keys, d_counts, n, db->d_stats, db->stream, 0, nullptr, nullptr, db->ext, db->regions)) != hipSuccess)
                 return hip_fail(e, "kcfx_db_build insert");
             if ((rc = cells_stash_alloc(db))) return rc;
@@ -1376,6 +1419,12 @@ int32_t kcfx_release_cached(int32_t device) try {
     return KCFX_OK;
 } KCFX_CATCH("kcfx_release_cached")
 
+double kcfx_set_cache_fraction(double fraction) {
+    const double prev = kcfx::pool_set_fraction(fraction);
+    if (fraction >= 0.0 && fraction < prev) kcfx::pool_trim();
+    return prev;
+}
+
 int32_t kcfx_ref_create(int32_t device, int32_t kmer_length, const uint8_t* text, int64_t text_len,
                         const int64_t* win_begin, const int32_t* win_len, int32_t n_windows, kcfx_ref** out) {
     return kcfx_ref_create_opts(device, kmer_length, text, text_len, win_begin, win_len, n_windows, nullptr, out);
@@ -1395,7 +1444,7 @@ int32_t kcfx_ref_create_opts(int32_t device, int32_t kmer_length, const uint8_t*
     // A reference that ONE database will be screened against (kcfx_ref_opts.expected_screens == 1: one sample per device in the
     // sharded call, the one-shot kcfx_screen) is kept as text only too: the one launch that plans its tiles itself is faster than
     // plan + screen as two (0.095 against 0.027 + 0.078 ms on the bench workload) and needs no plan buffers.
-    const char* plan_env = getenv("KCFX_REF_PLAN");
+    const char* plan_env = hook("KCFX_REF_PLAN");
     const bool cell_k = k >= CELL_K_MIN && k <= CELL_K_MAX;
     bool planned = cell_k && text_len > 0 && !(opts && opts->expected_screens == 1);
     if (plan_env) planned = planned && plan_env[0] != '0';
@@ -1439,6 +1488,14 @@ int32_t kcfx_ref_create_opts(int32_t device, int32_t kmer_length, const uint8_t*
     r->n_tiles = (int32_t)tiles.size();
     r->n_slots = n_slots;
     r->text_len = text_len;
+    {   // (FNV-1a over the window list)
+        uint64_t hsh = 1469598103934665603ull;
+        for (int32_t w = 0; w < n_windows; ++w) {
+            hsh = (hsh ^ (uint64_t)win_begin[w]) * 1099511628211ull;
+            hsh = (hsh ^ (uint64_t)(uint32_t)win_len[w]) * 1099511628211ull;
+        }
+        r->win_hash = hsh;
+    }
     // One block: the text (+ 128 zero bytes: the pack phase reads whole 32-byte chunks) and, for cell tables (k = 19 .. 31), the
     // reference plan behind it -- anchors, then codes, each 256-byte aligned.
     auto up256 = [](size_t n) { return (n + 255) & ~(size_t)255; };
@@ -1527,7 +1584,12 @@ static int32_t screen_ref_launch(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_co
     }
     KCFX_HIP(launch_screen_tiles(ref->d_text, ref->plan(), ref->d_tiles, ref->n_tiles, db->view(), ref->k, db->info.both_strands,
                                  min_kmer_count, ref->d_bits, ref->d_csum, st, ev0, ev1));
-    if (partial) return KCFX_OK;                           // (kcfx_screen_ref_partial_async: the bitmaps stay where they are)
+    if (partial) {                                         // (kcfx_screen_ref_partial_async: the bitmaps stay where they are)
+        // ... and a merge out of this reference (kcfx_ref_merge_from) is ordered behind this launch whatever stream it ran on
+        if (!ref->partial_done) KCFX_HIP(hipEventCreateWithFlags(&ref->partial_done, hipEventDisableTiming));
+        KCFX_HIP(hipEventRecord(ref->partial_done, st));
+        return KCFX_OK;
+    }
     KCFX_HIP(launch_reduce_windows(ref->d_tiles, ref->n_tiles, 1, ref->d_bits, ref->d_csum, ref->d_win_tile0, ref->n_windows,
                                    ref->k, reinterpret_cast<kcfx_result*>(out_device), st));
     return KCFX_OK;
@@ -1580,16 +1642,19 @@ int32_t kcfx_ref_merge_partial_async(kcfx_ref* ref, const void* bitmaps_device, 
 // into a scratch buffer first); synchronous: returns when dst holds the merged results
 int32_t kcfx_ref_merge_from(kcfx_ref* dst, kcfx_ref* src) try {
     if (!dst || !src) return fail(KCFX_ERR_ARG, "null argument");
-    if (dst->n_tiles != src->n_tiles || dst->n_windows != src->n_windows || dst->k != src->k)
+    if (dst->n_tiles != src->n_tiles || dst->n_windows != src->n_windows || dst->k != src->k || dst->text_len != src->text_len || dst->win_hash != src->win_hash)
         return fail(KCFX_ERR_ARG, "kcfx_ref_merge_from: the two references do not describe the same windows");
     if (dst == src || dst->n_tiles == 0) return KCFX_OK;
     int64_t b = 0, c = 0;
     kcfx_ref_partial_bytes(dst, &b, &c);
     {
+        // src's partial screen -- on its own stream or on a caller's (kcfx_screen_ref_partial_async records partial_done there) -- first
         DeviceGuard gs(src->device);
-        KCFX_HIP(hipStreamSynchronize(src->stream));        // (the caller has waited for src's screening launch; its own stream is idle)
+        if (src->partial_done) KCFX_HIP(hipEventSynchronize(src->partial_done));
+        KCFX_HIP(hipStreamSynchronize(src->stream));
     }
     DeviceGuard g(dst->device);
+    if (dst->partial_done) KCFX_HIP(hipStreamWaitEvent(dst->stream, dst->partial_done, 0));    // (dst's own partial screen, wherever it was launched)
     if (dst->device == src->device) {
         KCFX_HIP(launch_merge_partial(dst->d_bits, dst->d_csum, src->d_bits, src->d_csum, dst->n_tiles, dst->stream));
         KCFX_HIP(hipStreamSynchronize(dst->stream));
@@ -1853,7 +1918,7 @@ int32_t kcfx_cohort_open(const char* const* kmc_prefixes, int32_t n_samples, int
     if (db->fmt != FORMAT_CELLS) return fail(KCFX_ERR_ARG, "cohort tables need a cell table (KCFX_TABLE_FORMAT / KCFX_GENERIC_KERNEL / too many k-mers)");
     const int32_t k = hs[0].k, both = db->info.both_strands;
     // the cells of every record once, for the four later passes and the S counter passes (9 bytes per record, if they fit)
-    if (getenv("KCFX_LOAD_NO_PROBES") == nullptr && (double)nn * 9.0 < 0.25 * (double)free_device_bytes()) {
+    if (hook("KCFX_LOAD_NO_PROBES") == nullptr && (double)nn * 9.0 < 0.25 * (double)free_device_bytes()) {
         if (dev_alloc(&hold.d_pw, nn * 8) != hipSuccess || dev_alloc(&hold.d_ps, nn) != hipSuccess) {
             (void)hipGetLastError();
             if (hold.d_pw) (void)dev_free(hold.d_pw);
@@ -1870,9 +1935,9 @@ int32_t kcfx_cohort_open(const char* const* kmc_prefixes, int32_t n_samples, int
             uint8_t* ps = hold.d_ps ? hold.d_ps + first : nullptr;
             hipError_t e2 = hipSuccess;
             if (phase == 0)
-                e2 = pw ? launch_cells_resolve(db->d_pop, db->pop_bits, k, db->lbits, both, kk, cc, n, pw, ps, db->stream, db->ext)
-                        : launch_cells_count(db->d_pop, db->pop_bits, k, db->lbits, both, kk, cc, n, db->stream, 1, db->ext);
-            else if (phase == 1 || phase == 2) e2 = launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, phase == 1 ? 1 : 0, k, db->lbits, both, kk, cc, n, db->stream, 1, pw, ps, db->ext, db->regions);
+                e2 = pw ? launch_cells_resolve(db->d_pop, db->pop_bits, k, db->lbits, both, kk, cc, n, pw, ps, db->stream, db->ext, db->crowd_by_minimizer)
+                        : launch_cells_count(db->d_pop, db->pop_bits, k, db->lbits, both, kk, cc, n, db->stream, 1, db->ext, db->crowd_by_minimizer);
+            else if (phase == 1 || phase == 2) e2 = launch_cells_insert(db->d_lines, db->d_pop, db->pop_bits, phase == 1 ? 1 : 0, k, db->lbits, both, kk, cc, n, db->stream, 1, pw, ps, db->ext, db->regions, 0, db->crowd_by_minimizer);
             else if (phase == 3) e2 = launch_cells_settle(db->d_lines, k, db->lbits, both, kk, cc, n, db->d_stats, db->stream, 1, pw, ps, db->ext, db->regions);
             else e2 = launch_cells_stash(db->d_lines, k, db->lbits, both, kk, cc, n, db->d_stash, db->stash_mask, db->stream, 1, pw, ps, db->ext, db->regions);
             if (e2 != hipSuccess) return e2;

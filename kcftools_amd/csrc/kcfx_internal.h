@@ -283,7 +283,15 @@ hipError_t dev_free(void* p);                // waits for the device first, as h
 hipError_t dev_free_idle(void* p);           // the caller has already waited for every user of the block (its own stream)
 size_t free_device_bytes();                  // hipMemGetInfo's free + what the pool keeps on the current device
 size_t pooled_device_bytes(int dev);
+// Switches that change what the library BUILDS (table size / format / regions, load tiers, kernel selection) are test and A/B
+// hooks, not configuration: they are read only when KCFX_TEST_HOOKS is set in the environment as well, so that a host process (a JVM)
+// that happens to inherit one of them gets the documented behaviour. hook(name) = getenv(name) under that condition, else null.
+// (Always read: KCFX_VERBOSE, KCFX_LOAD_TRACE / KCFX_REF_TRACE / KCFX_CLI_TRACE / KCFX_POOL_TRACE, KCFX_NO_POOL, KCFX_POOL_FRACTION,
+// KCFX_LENIENT_LUT -- they report, or change where memory goes, never what a look-up returns or costs.)
+const char* hook(const char* name);
 void pool_release(int dev);                  // dev < 0: every device
+double pool_set_fraction(double f);          // the bound on what is kept (share of a device); returns the previous one
+void pool_trim();                            // release what is over the bound now
 hipError_t host_alloc(void** p, size_t bytes);    // pinned staging buffers, a few kept
 template <class T> inline hipError_t host_alloc(T** p, size_t bytes) { return host_alloc(reinterpret_cast<void**>(p), bytes); }
 hipError_t host_free(void* p);
@@ -317,13 +325,14 @@ hipError_t launch_pop_histogram(const uint32_t* pop32, int32_t pop_bits, unsigne
 // (both = the database is canonical; see CELL_R_FLIP in kcfx_device.h for what a forward-only one changes)
 // (presence != 0: every non-zero counter is stored as 1 -- the key table of a cohort, kcfx_cohort_open)
 hipError_t launch_cells_count(uint32_t* pop32, int32_t pop_bits, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                              hipStream_t st, int32_t presence = 0, int32_t ext = 0);
+                              hipStream_t st, int32_t presence = 0, int32_t ext = 0, int32_t by_minimizer = 0);
+// (by_minimizer: the crowding counters / the run of a bid keyed by the minimizer alone instead of by the locus -- cell_crowd_key, kcfx_kernels.hip)
 // (pw / ps: the cells of the records as launch_cells_resolve kept them -- 8 + 1 bytes per record, see RecProbes in kcfx_kernels.hip --
 // or null: the pass derives them itself with cells_visit. launch_cells_resolve = launch_cells_count + keeping them.)
 hipError_t launch_cells_resolve(uint32_t* pop32, int32_t pop_bits, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                                uint64_t* pw, uint8_t* ps, hipStream_t st, int32_t ext = 0);
+                                uint64_t* pw, uint8_t* ps, hipStream_t st, int32_t ext = 0, int32_t by_minimizer = 0);
 hipError_t launch_cells_insert(uint8_t* lines, const uint32_t* pop32, int32_t pop_bits, int32_t cls, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys,
-                               const uint32_t* counts, int64_t n, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr, int32_t ext = 0, int32_t regions = 1, int32_t slicing = 0);
+                               const uint32_t* counts, int64_t n, hipStream_t st, int32_t presence = 0, const uint64_t* pw = nullptr, const uint8_t* ps = nullptr, int32_t ext = 0, int32_t regions = 1, int32_t slicing = 0, int32_t by_minimizer = 0);
 // what the settle pass counts for the stash, written down (round 5): keys / counts of `cap` entries and the number appended so far
 // (it keeps counting beyond cap: n > cap = the list is incomplete and the stash is filled from the records instead). keys == null: no list.
 struct LostList {

@@ -225,24 +225,39 @@ __device__ __forceinline__ bool cell_same(uint64_t have, uint64_t mine, uint64_t
 // a bucket is ONE minimizer. With line + 2 bits (round 2) an isolated k-mer that shared the line of a genomic run was classed
 // with the run and, where its counter happened to be the larger, took the genomic k-mer's cell (profiles/r03_notes.md).
 // kcfx_db_open falls back to lbits + 2 when the device cannot spare 4 GiB.
-__device__ __forceinline__ uint64_t cell_sub_bucket(const CellProbe& p, int32_t lbits, int32_t pop_bits) {
+// WHICH k-mers are counted together (round 6): those of one LOCUS, not of one minimizer. The order prefers open syncmers, so the
+// minimizers of any set of k-mers concentrate on ~1 / 11 of the canonical 16-mers -- the 123 M uniformly random k-mers of the bench
+// database share their 16-mer with 0.6 other k-mers each, and a genomic run has as many strangers with ITS minimizer, in its line,
+// with its rest of G32. Counted per minimizer such a stranger is "crowded" like the run, carries the run's own hash, and wins the
+// cell it wants on a coin toss: 3.5 % of the reference's present k-mers sat outside their first-choice cell in the sparsest table
+// (0.66 M of the 0.71 M queued look-ups of a pass were k-mers that ARE in the database; at 0.28 per cell with per-line counters
+// 2.0 M of 2.2 M: profiles/r06_notes.md section 2). The key is the minimizer TOGETHER with the three bases next to it -- the
+// bijection of G32 that an extended table takes its lines from (cell_g32_ext: the bases in front of the minimizer for the
+// thirteen offsets that have them, else those behind it). The k-mers of a run share it (two groups per run at most), a stranger
+// with the same 16-mer has other neighbours 63 times in 64. In an extended table (line, r) already are that key.
+// by_minimizer: the plain G32 -- what the choice of an extended table is estimated from (kcfx_db_open: ext_by_crowding), and the
+// A/B hook KCFX_CROWD_BY_MINIMIZER.
+__device__ __forceinline__ uint32_t cell_crowd_key(const CellProbe& p, int32_t lbits, bool ext, bool by_minimizer) {
     // (r may carry CELL_R_FLIP above its 32 - lbits identifying bits: masked, or a forward-only database's reverse-strand k-mers
     // would be counted in another minimizer's bucket)
     const uint32_t g = (p.line << (32 - lbits)) | (p.r & (0xFFFFFFFFu >> lbits));
-    return (uint64_t)(g >> (32 - pop_bits));
+    return (ext || by_minimizer) ? g : cell_g32_ext(g, p.w & ~CELL_FLAG_MASK, p.sh);
+}
+__device__ __forceinline__ uint64_t cell_sub_bucket(const CellProbe& p, int32_t lbits, int32_t pop_bits, bool ext, bool by_minimizer) {
+    return (uint64_t)(cell_crowd_key(p, lbits, ext, by_minimizer) >> (32 - pop_bits));
 }
 
 // Pass 0: k-mers per sub-bucket, one byte each (a byte that overflows spills into its neighbour: the classes are a
 // heuristic, see above)
 __global__ void cells_count_kernel(uint32_t* pop32, int32_t pop_bits, int32_t k, int32_t lbits, int32_t both, const uint64_t* __restrict__ keys,
-                                   const uint32_t* __restrict__ counts, int64_t n, int32_t presence, int32_t ext) {
+                                   const uint32_t* __restrict__ counts, int64_t n, int32_t presence, int32_t ext, int32_t by_minimizer) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         if (counts[i] == 0) continue;                           // (presence mode: the same test)
         cells_visit(keys[i], k, lbits, both != 0, ext != 0, [&](const CellProbe& p, int a) {
             if (a != 0) return;                                 // the first of its cells names the k-mer's sub-bucket
-            const uint64_t sub = cell_sub_bucket(p, lbits, pop_bits);
+            const uint64_t sub = cell_sub_bucket(p, lbits, pop_bits, ext != 0, by_minimizer != 0);
             atomicAdd(&pop32[sub >> 2], 1u << (8 * (uint32_t)(sub & 3)));
         });
     }
@@ -292,7 +307,7 @@ __device__ __forceinline__ int record_cells(const RecProbes& rp, int64_t i, uint
 
 // Pass 0 when the records stay resident: cells_count_kernel + the probes kept
 __global__ void cells_resolve_kernel(uint32_t* pop32, int32_t pop_bits, int32_t k, int32_t lbits, int32_t both, const uint64_t* __restrict__ keys,
-                                     const uint32_t* __restrict__ counts, int64_t n, uint64_t* __restrict__ pw, uint8_t* __restrict__ ps, int32_t ext) {
+                                     const uint32_t* __restrict__ counts, int64_t n, uint64_t* __restrict__ pw, uint8_t* __restrict__ ps, int32_t ext, int32_t by_minimizer) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
@@ -305,7 +320,7 @@ __global__ void cells_resolve_kernel(uint32_t* pop32, int32_t pop_bits, int32_t 
         const int nc = cells_visit(keys[i], k, lbits, both != 0, ext != 0, [&](const CellProbe& p, int a) {
             if (a == 0) first = p;
         });
-        const uint64_t sub = cell_sub_bucket(first, lbits, pop_bits);
+        const uint64_t sub = cell_sub_bucket(first, lbits, pop_bits, ext != 0, by_minimizer != 0);
         atomicAdd(&pop32[sub >> 2], 1u << (8 * (uint32_t)(sub & 3)));
         const uint32_t g = (first.line << (32 - lbits)) | (first.r & (0xFFFFFFFFu >> lbits));
         pw[i] = (uint64_t)g | ((uint64_t)first.w << 32);
@@ -329,8 +344,11 @@ __global__ void cells_resolve_kernel(uint32_t* pop32, int32_t pop_bits, int32_t 
 // "seen more than once" reads "held by more than one sample": the k-mers the samples share, which are the ones a reference
 // asks for, stay above a run that is private to one sample. With the run directly under the class the bench cohort screened
 // in 0.292 ms instead of 0.217: half of the shared runs lost their contests to private ones.)
-__device__ __forceinline__ unsigned long long cell_bid(const CellProbe& p, uint32_t c, bool crowded, int32_t lbits, int32_t presence) {
-    const uint32_t g = (p.line << (32 - lbits)) | (p.r & (0xFFFFFFFFu >> lbits));
+// (round 6: "the run" is the LOCUS -- cell_crowd_key: the minimizer with the three bases next to it -- so that of two loci that contain
+// the same 16-mer ONE keeps every cell both want, as of two runs that share a line; keyed by the minimizer alone they tied here and
+// split the contested cells by the counter and a hash, k-mer by k-mer: both loci then paid for a second line, in ones and twos)
+__device__ __forceinline__ unsigned long long cell_bid(const CellProbe& p, uint32_t c, bool crowded, int32_t lbits, int32_t presence, bool ext, bool by_minimizer) {
+    const uint32_t g = cell_crowd_key(p, lbits, ext, by_minimizer);
     const uint32_t run = (g * 0x9E3779B1u) >> 18;
     const bool more = presence ? (c >> 12) >= 2u : c >= 2u;
     const uint32_t top = ((crowded ? 1u : 0u) << 15) | ((more ? 1u : 0u) << 14) | run;
@@ -338,7 +356,7 @@ __device__ __forceinline__ unsigned long long cell_bid(const CellProbe& p, uint3
     return ((unsigned long long)top << 48) | ((unsigned long long)(c & 0xFFFFu) << 32) | idh;
 }
 __global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__ pop32, int32_t pop_bits, int32_t cls, int32_t k, int32_t lbits, int32_t both,
-                                    const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, int64_t n, int32_t presence, RecProbes rp) {
+                                    const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, int64_t n, int32_t presence, RecProbes rp, int32_t by_minimizer) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
@@ -348,12 +366,12 @@ __global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__
         bool crowded = false;
         record_cells(rp, i, keys[i], k, lbits, both != 0, [&](const CellProbe& p, int a) {
             if (a == 0) {
-                const uint64_t sub = cell_sub_bucket(p, lbits, pop_bits);
+                const uint64_t sub = cell_sub_bucket(p, lbits, pop_bits, rp.ext != 0, by_minimizer != 0);
                 crowded = ((pop32[sub >> 2] >> (8 * (uint32_t)(sub & 3))) & 0xFFu) >= CELL_CROWD;
             }
             if (!rp.mine(p, lbits)) return;             // (a table slice: the crowding counters are of the whole database, the cells of this slice)
             unsigned long long* cell = reinterpret_cast<unsigned long long*>(lines + cell_byte_at(p, lbits, rp.regions));
-            const unsigned long long bid = cell_bid(p, c, crowded, lbits, presence);
+            const unsigned long long bid = cell_bid(p, c, crowded, lbits, presence, rp.ext != 0, by_minimizer != 0);
             if (cls) atomicMax(cell, bid);
             else if (__atomic_load_n(cell, __ATOMIC_RELAXED) == bid) __atomic_store_n(cell, (unsigned long long)cell_word(p.w, p.r, c), __ATOMIC_RELAXED);
         });
@@ -1684,10 +1702,30 @@ __device__ __forceinline__ CellProbe k31_probe_at(const Lds& sh, int q, uint32_t
     return cell_probe_planned<BOTH>(fm ? rc : fwd, anc & 30u, fm, lbits, ext);
 }
 
+#ifdef KCFX_EXP_STATS
+// experiment build only (make fast FASTFLAGS=-DKCFX_EXP_STATS): what the queued look-ups of a pass are made of
+// [0] k-mers queued  [1] found in their second line  [2] sent on from it  [3] found in their third line  [4] looked up in the stash
+// [5] found there  [6] second-line requests (lanes whose line differs from the lane before)  [7] words with a queued k-mer
+// [8] k-mers found in their first-choice cell  [9] deferred rounds
+__device__ unsigned long long g_exp[16];
+extern "C" int32_t kcfx_exp_stats(unsigned long long* out, int32_t reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_exp), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        const unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_exp), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#define EXP_COUNT(i, pred) do { if (pred) atomicAdd(&g_exp[i], 1ull); } while (0)
+#define EXP_ROUND(i, pred) do { if constexpr (EXPS) { if (pred) atomicAdd(&g_exp[i], 1ull); } } while (0)
+#else
+#define EXP_COUNT(i, pred) do { } while (0)
+#define EXP_ROUND(i, pred) do { } while (0)
+#endif
 // The first min(qn, 64) queued k-mers -- their first-choice cell said "someone who belongs here lives elsewhere", with their filter
 // bit: the same cell of their second line (the losers of a minimizer sit there together: neighbouring lanes, one line), and if
 // that cell sends them on too, the stash. Calls found(id, counter) for the lanes that find theirs; returns the new qn.
-template <int K, bool BOTH, class Lds, class Found>
+template <int K, bool BOTH, bool EXPS = false, class Lds, class Found>
 __device__ __forceinline__ int k31c_deferred_round(const TableView& tv, const Lds& sh, uint32_t* ids, int lane, int qn, int pos0, Found&& found) {
     const int nb = min(qn, 64), rest = qn - nb;
     const uint32_t id = ids[lane];
@@ -1715,6 +1753,20 @@ __device__ __forceinline__ int k31c_deferred_round(const TableView& tv, const Ld
         const bool hit2 = holds(e, q2);
         if (hit2) found(id, e.y >> 16, (uint32_t)cell, false);
         bool on = !hit2 && sends_on(e, q2);
+#ifdef KCFX_EXP_STATS
+        if constexpr (EXPS) {
+            const uint32_t l2 = cell_line_index(q2.line, q2.r, tv.lbits, tv.regions);
+            const uint32_t prev = __shfl_up(l2, 1);
+            EXP_ROUND(0, true);
+            EXP_ROUND(1, hit2);
+            EXP_ROUND(2, on);
+            EXP_ROUND(6, lane == 0 || prev != l2);
+            EXP_ROUND(9, lane == 0);
+        }
+#endif
+#if defined(KCFX_EXP_CUT) && KCFX_EXP_CUT <= 1
+        on = false;                                         // (experiment build: nothing beyond the second line)
+#endif
         if (cell_has_third(tv.lbits, BOTH)) {                // (wave-uniform)
             if (on) {
                 // its third line: the losers of this minimizer's other loci are not here
@@ -1724,11 +1776,17 @@ __device__ __forceinline__ int k31c_deferred_round(const TableView& tv, const Ld
                 const bool hit3 = holds(e3, q3);
                 if (hit3) found(id, e3.y >> 16, (uint32_t)cell3, false);
                 on = !hit3 && sends_on(e3, q3);
+                EXP_ROUND(3, hit3);
             }
         }
+#if defined(KCFX_EXP_CUT) && KCFX_EXP_CUT <= 2
+        on = false;                                         // (experiment build: no stash)
+#endif
         if (on) {
             const uint32_t slot = stash_find_slot(tv, key);
             if (slot != ~0u) found(id, tv.stash[slot].z, slot, true);
+            EXP_ROUND(4, true);
+            EXP_ROUND(5, slot != ~0u);
         }
     }
     wave_lds_fence();
@@ -1825,15 +1883,21 @@ __global__ __launch_bounds__(PLANNED ? CELLS_BLOCK : TEXT_BLOCK) __attribute__((
         }
         // looked up further: flagged cell + filter bit, and not a hit here (a k-mer found below -c is not stored anywhere else
         // either: its look-up would end as the miss it already is -- harmless, and one compare less than "cnt == 0")
+#if defined(KCFX_EXP_CUT) && KCFX_EXP_CUT == 0
+        const uint64_t PM = 0;                              // (experiment build: first-choice cells only)
+#else
         const uint64_t PM = wave_ballot(pend != 0u) & ~H & cw.V;
+#endif
+        EXP_COUNT(8, __builtin_amdgcn_inverse_ballot_w64(M));
         if (PM) {
+            EXP_COUNT(7, lane == 0);
             const bool pending = __builtin_amdgcn_inverse_ballot_w64(PM);
             const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(PM >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)PM, 0u));
             if (pending) q.id[pos] = (uint32_t)(((w - w_begin) << 6) | lane) | ((cw.anc & 31u) << QUEUE_ANCHOR_SHIFT);
             qn += __popcll(PM);
         }
         wave_lds_fence();
-        while (qn >= 64) qn = k31c_deferred_round<K, BOTH>(tv, sh, q.id, lane, qn, pos0, found);
+        while (qn >= 64) qn = k31c_deferred_round<K, BOTH, true>(tv, sh, q.id, lane, qn, pos0, found);
     };
     // D words of cell loads in flight per wave (CELLS_PIPE): a ring of D CellWords in fixed registers -- the loop is unrolled D
     // times -- and no condition around an issue in the steady state (see cells_issue); the first D - 1 issues and the last
@@ -1858,7 +1922,7 @@ __global__ __launch_bounds__(PLANNED ? CELLS_BLOCK : TEXT_BLOCK) __attribute__((
         if (base + i + D - 1 < w_end) issue(base + i + D - 1, cw[(i + D - 1) % D]);
         if (base + i < w_end) retire(base + i, cw[i % D]);
     }
-    while (qn > 0) qn = k31c_deferred_round<K, BOTH>(tv, sh, q.id, lane, qn, pos0, found);
+    while (qn > 0) qn = k31c_deferred_round<K, BOTH, true>(tv, sh, q.id, lane, qn, pos0, found);
     if (lane < w_end - w_begin) {                           // the wave's words of the window's bitmap
         my_bits[w_begin + lane] = q.vw[lane];
         my_bits[TILE_WORDS + w_begin + lane] = q.hit[lane];
@@ -2484,24 +2548,24 @@ hipError_t launch_table_finalize(uint8_t* lines, uint32_t n_lines, int32_t wide,
 }
 
 hipError_t launch_cells_count(uint32_t* pop32, int32_t pop_bits, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                              hipStream_t st, int32_t presence, int32_t ext) {
+                              hipStream_t st, int32_t presence, int32_t ext, int32_t by_minimizer) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(cells_count_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, pop32, pop_bits, k, lbits, both, keys, counts, n, presence, ext);
+    hipLaunchKernelGGL(cells_count_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, pop32, pop_bits, k, lbits, both, keys, counts, n, presence, ext, by_minimizer);
     return hipGetLastError();
 }
 
 hipError_t launch_cells_resolve(uint32_t* pop32, int32_t pop_bits, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys, const uint32_t* counts, int64_t n,
-                                uint64_t* pw, uint8_t* ps, hipStream_t st, int32_t ext) {
+                                uint64_t* pw, uint8_t* ps, hipStream_t st, int32_t ext, int32_t by_minimizer) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(cells_resolve_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, pop32, pop_bits, k, lbits, both, keys, counts, n, pw, ps, ext);
+    hipLaunchKernelGGL(cells_resolve_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, pop32, pop_bits, k, lbits, both, keys, counts, n, pw, ps, ext, by_minimizer);
     return hipGetLastError();
 }
 
 hipError_t launch_cells_insert(uint8_t* lines, const uint32_t* pop32, int32_t pop_bits, int32_t cls, int32_t k, int32_t lbits, int32_t both, const uint64_t* keys,
-                               const uint32_t* counts, int64_t n, hipStream_t st, int32_t presence, const uint64_t* pw, const uint8_t* ps, int32_t ext, int32_t regions, int32_t slicing) {
+                               const uint32_t* counts, int64_t n, hipStream_t st, int32_t presence, const uint64_t* pw, const uint8_t* ps, int32_t ext, int32_t regions, int32_t slicing, int32_t by_minimizer) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(cells_insert_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, lines, pop32, pop_bits, cls, k, lbits, both, keys, counts, n, presence,
-                       RecProbes{pw, ps, ext, regions, slicing});
+                       RecProbes{pw, ps, ext, regions, slicing}, by_minimizer);
     return hipGetLastError();
 }
 

@@ -9,6 +9,7 @@
 // request (kcfx_release_cached), disabled by KCFX_NO_POOL, bounded lower by KCFX_POOL_FRACTION. Memory policies that look at the free device memory count the
 // kept blocks as free (free_device_bytes).
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -19,32 +20,43 @@
 
 namespace kcfx {
 
+const char* hook(const char* name) {
+    static const bool on = getenv("KCFX_TEST_HOOKS") != nullptr;
+    return on ? getenv(name) : nullptr;
+}
+
 namespace {
 
 size_t pool_min_bytes() {                               // smaller requests go straight to hipMalloc (KCFX_POOL_MIN_KB: experiments)
     static const size_t n = [] {
-        const char* e = getenv("KCFX_POOL_MIN_KB");
+        const char* e = hook("KCFX_POOL_MIN_KB");
         return e && atoi(e) > 0 ? (size_t)atoi(e) << 10 : (size_t)8 << 20;
     }();
     return n;
 }
 size_t pool_max_blocks() {                              // kept blocks per device (KCFX_POOL_BLOCKS: experiments)
     static const size_t n = [] {
-        const char* e = getenv("KCFX_POOL_BLOCKS");
+        const char* e = hook("KCFX_POOL_BLOCKS");
         return e && atoi(e) > 0 ? (size_t)atoi(e) : (size_t)16;
     }();
     return n;
 }
-// of the device's memory. (Round 5: 0.4 -> 0.9. A table of 206 GB -- an 8 G-k-mer database -- was over the bound and went back to
-// the driver on close; the next open of the run got the same pages back at once, and its first pass over the file then crept along
-// for six seconds with the GPU idle and the uploads stuck in hipMemcpyAsync -- the driver clears released memory in the background
-// on the engines the uploads use. Kept, the second open of such a database takes 7 s instead of 12.8. What is kept is released
-// when any allocation fails, and counts as free memory in every policy: keeping more costs nothing.)
-double pool_max_fraction() {                            // (KCFX_POOL_FRACTION=<0..1>: a process that shares the device with another allocator)
+// of the device's memory. Round 5 raised the bound from 0.4 to 0.9 for every process: a table of 206 GB -- an 8 G-k-mer database --
+// went back to the driver on close, the next open of the run got the same pages back at once, and its first pass over the file
+// then crept along for six seconds with the GPU idle and the uploads stuck in hipMemcpyAsync -- the driver clears released memory in
+// the background on the engines the uploads use (kept, the second open of such a database takes 7 s instead of 12.8). That is the
+// right bound for a job that opens one large database after the other and a hostile default for a library loaded into a host that
+// shares the device: round 6 -- half of the device by default, kcfx_set_cache_fraction for the jobs that want more
+// (kcfx_screen_sharded raises it to 0.9 for the length of its call and trims when it returns). What is kept is released when any
+// allocation of the library fails and counts as free memory in every policy.
+std::atomic<double> g_fraction{-1.0};
+double pool_max_fraction() {                            // (KCFX_POOL_FRACTION=<0..1>: the process-wide default)
+    const double now = g_fraction.load();
+    if (now >= 0.0) return now;
     static const double f = [] {
         const char* e = getenv("KCFX_POOL_FRACTION");
-        const double v = e ? atof(e) : 0.9;
-        return v >= 0.0 && v <= 1.0 ? v : 0.9;
+        const double v = e ? atof(e) : 0.5;
+        return v >= 0.0 && v <= 1.0 ? v : 0.5;
     }();
     return f;
 }
@@ -91,6 +103,42 @@ size_t pooled_locked(int dev) {
 }
 
 }  // namespace
+
+double pool_set_fraction(double f) {
+    const double prev = pool_max_fraction();
+    if (f >= 0.0 && f <= 1.0) g_fraction.store(f);
+    return prev;
+}
+
+// the oldest kept blocks of every device go until each device is within the bound again (after the bound was lowered)
+void pool_trim() {
+    std::vector<Block> out;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        std::vector<int> devs;
+        for (const Block& b : g_spare)
+            if (std::find(devs.begin(), devs.end(), b.dev) == devs.end()) devs.push_back(b.dev);
+        for (int dev : devs) {
+            size_t total_b = 0, free_b = 0;
+            {
+                OnDevice g(dev);
+                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = (size_t)256 << 30;
+            }
+            while ((double)pooled_locked(dev) > pool_max_fraction() * (double)total_b) {
+                bool dropped = false;
+                for (size_t i = 0; i < g_spare.size(); ++i)
+                    if (g_spare[i].dev == dev) {
+                        out.push_back(g_spare[i]);
+                        g_spare.erase(g_spare.begin() + (long)i);
+                        dropped = true;
+                        break;
+                    }
+                if (!dropped) break;
+            }
+        }
+    }
+    for (const Block& b : out) really_free(b);
+}
 
 size_t pooled_device_bytes(int dev) {
     std::lock_guard<std::mutex> lk(g_mu);

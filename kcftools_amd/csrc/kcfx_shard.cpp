@@ -337,6 +337,16 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
         stats->n_devices = G;
     }
     if (n_samples == 0 || n_windows == 0) return KCFX_OK;
+    // one database after the other on the same devices: a released table stays for the next one whatever its size (a 200 GB table
+    // that went back to the driver made the next open wait for the driver's clearing, kcfx_pool.cpp); the process's own bound
+    // comes back -- and what is over it goes -- when the call returns
+    struct KeepLarge {
+        double prev = kcfx::pool_set_fraction(0.9);
+        ~KeepLarge() {
+            kcfx::pool_set_fraction(prev);
+            kcfx::pool_trim();
+        }
+    } keep_large;
     if (mode == KCFX_SHARD_TABLE) {
         const int32_t rc = screen_table_sharded(ctx->devices, kmc_prefixes, n_samples, kmer_length, text, text_len, win_begin, win_len, n_windows,
                                                 min_kmer_count, out, stats);
@@ -520,7 +530,7 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
             cv.notify_all();
         };
         int n_loaders = 1;
-        if (const char* e = getenv("KCFX_SHARD_LOADERS")) n_loaders = std::max(1, std::min(4, atoi(e)));
+        if (const char* e = kcfx::hook("KCFX_SHARD_LOADERS")) n_loaders = std::max(1, std::min(4, atoi(e)));
         n_loaders = (int)std::min<size_t>((size_t)n_loaders, std::max<size_t>(n_segs, 1));
         std::vector<std::thread> loaders;
         // on every way out of this scope (normal, error, exception): stop the loaders, join them, close what they had ready

@@ -33,7 +33,7 @@ ABI_SYMBOLS = (
     "kcfx_db_open_slice", "kcfx_table_slice_of", "kcfx_screen_ref_partial_async", "kcfx_screen_ref_partial", "kcfx_ref_partial_bytes",
     "kcfx_ref_export_partial_async", "kcfx_ref_merge_partial_async", "kcfx_ref_merge_from", "kcfx_ref_finish_async", "kcfx_ref_finish",
     "kcfx_score", "kcfx_windows",
-    "kcfx_table_plan", "kcfx_prof_enable", "kcfx_prof_read", "kcfx_ref_plan_async", "kcfx_ref_is_planned", "kcfx_prof_read_plan", "kcfx_last_error", "kcfx_device_count", "kcfx_version",
+    "kcfx_table_plan", "kcfx_table_plan_for", "kcfx_set_cache_fraction", "kcfx_prof_enable", "kcfx_prof_read", "kcfx_ref_plan_async", "kcfx_ref_is_planned", "kcfx_prof_read_plan", "kcfx_last_error", "kcfx_device_count", "kcfx_version",
 )
 
 
@@ -143,6 +143,9 @@ def lib() -> C.CDLL:
         L.kcfx_screen_sharded.argtypes = [vp, vp, i32, i32, vp, i64, vp, vp, i32, i32, i32, vp, C.POINTER(ShardStats)]
         L.kcfx_shard_plan.argtypes = [i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, i64, C.POINTER(i64), C.POINTER(i32)]
         L.kcfx_table_plan.argtypes = [i64, i32, i32, i64, C.POINTER(i64), C.POINTER(i32)]
+        L.kcfx_table_plan_for.argtypes = [i64, i32, i32, i64, i64, C.POINTER(i64), C.POINTER(i32)]
+        L.kcfx_set_cache_fraction.argtypes = [C.c_double]
+        L.kcfx_set_cache_fraction.restype = C.c_double
         L.kcfx_db_lookup.argtypes = [vp, vp, i64, vp]
         L.kcfx_db_close.argtypes = [vp]
         L.kcfx_db_close.restype = None
@@ -187,11 +190,17 @@ def release_cached(device: int = -1) -> None:
     _check(lib().kcfx_release_cached(device))
 
 
-def table_plan(total_kmers: int, k: int, both_strands: bool = True, free_bytes: int = 256 << 30) -> tuple[int, int]:
-    """kcfx_table_plan (host only): (lines, regions) of the cell table kcfx_db_open would build; lines = 0: a line table."""
+def table_plan(total_kmers: int, k: int, both_strands: bool = True, free_bytes: int = 256 << 30, expected_queries: int = 0) -> tuple[int, int]:
+    """kcfx_table_plan_for (host only): (lines, regions) of the cell table kcfx_db_open_opts would build for a handle that serves
+    expected_queries look-ups (0 = unknown: kcfx_db_open's table); lines = 0: a line table."""
     n, r = C.c_int64(0), C.c_int32(0)
-    _check(lib().kcfx_table_plan(int(total_kmers), int(k), int(bool(both_strands)), int(free_bytes), C.byref(n), C.byref(r)))
+    _check(lib().kcfx_table_plan_for(int(total_kmers), int(k), int(bool(both_strands)), int(free_bytes), int(expected_queries), C.byref(n), C.byref(r)))
     return n.value, r.value
+
+
+def set_cache_fraction(fraction: float) -> float:
+    """kcfx_set_cache_fraction: the share of a device that released buffers may occupy (default 0.5); returns the previous value."""
+    return float(lib().kcfx_set_cache_fraction(float(fraction)))
 
 
 def table_slice_of(g32: int, lbits: int, n_slices: int) -> int:

@@ -6,6 +6,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the switches that change what the library builds (KCFX_TABLE_*, KCFX_LOAD_*, KCFX_GENERIC_KERNEL, KCFX_REF_PLAN ...) are test
+# hooks: the library reads them only when this is set too (kcfx_internal.h: hook()); the suites force table forms with them
+os.environ.setdefault("KCFX_TEST_HOOKS", "1")
 
 
 def pytest_configure(config):

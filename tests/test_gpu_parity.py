@@ -813,10 +813,12 @@ def test_planned_reference_at_the_text_lengths_where_its_arrays_end(oracle, tmp_
 
 def test_every_load_tier_builds_the_same_table(oracle, tmp_path, monkeypatch):
     """kcfx_db_open keeps between its build passes what fits: the decoded records and their cells (21 B per k-mer), the decoded
-    records (12 B), the records as the file holds them (record_size B, decoded again per pass: round 5, what a wheat-scale
-    database gets), or nothing (the file streamed once per pass). Which tier ran must not show: the same table statistics,
-    KMC.getCount and windows from all four, for a plain table and for a forced extended one, 2- and 4-byte counters (odd record
-    sizes: 7 and 10 bytes per record here)."""
+    records (12 B), or nothing (the file streamed once per pass: what a wheat-scale database gets). Which tier ran must not show:
+    the same table statistics, KMC.getCount and windows from all of them, for a plain table and for a forced extended one, 2- and
+    4-byte counters (odd record sizes: 7 and 10 bytes per record here) -- and, round 6, every tier again with CHUNKS OF 4 099
+    RECORDS (KCFX_LOAD_CHUNK_RECORDS: ~100 chunks per file, so both pinned buffers and both device buffers are reused many times
+    behind the copy stream's done[] / decoded[] events, chunks start at byte offsets that are no multiple of 4, and the settle
+    pass's list of stash k-mers is appended to across chunks)."""
     k = 31
     ref = synth.random_reference(400_000, 77, n_run_every=50_000, max_n_run=600)
     s, e = engine.windows(len(ref), 10_000, 0, k)
@@ -827,15 +829,17 @@ def test_every_load_tier_builds_the_same_table(oracle, tmp_path, monkeypatch):
         for ext in ("0", "1"):
             monkeypatch.setenv("KCFX_TABLE_EXT", ext)
             stats = {}
-            # (round 5, the tiers that keep no decoded records: the uploads ride a stream of their own -- KCFX_LOAD_ONE_STREAM=1 is the
-            # old order -- and the settle pass writes the k-mers of the stash down so that the stash needs no pass of its own:
-            # with the list, without it, and with a list too short to hold them)
-            for tier, env in (("probes", {}), ("decoded", {"KCFX_LOAD_NO_PROBES": "1"}), ("raw", {"KCFX_LOAD_RAW": "1"}),
-                              ("raw, no list", {"KCFX_LOAD_RAW": "1", "KCFX_LOAD_NO_LOST_LIST": "1"}),
+            # (the tiers that keep no decoded records: the uploads ride a stream of their own, and the settle pass writes the k-mers
+            # of the stash down so that the stash needs no pass of its own: with the list, without it, and with a list too short to
+            # hold them)
+            small = {"KCFX_LOAD_CHUNK_RECORDS": "4099"}
+            for tier, env in (("probes", {}), ("decoded", {"KCFX_LOAD_NO_PROBES": "1"}),
                               ("streamed", {"KCFX_LOAD_STREAM_TWICE": "1"}),
-                              ("streamed, one stream", {"KCFX_LOAD_STREAM_TWICE": "1", "KCFX_LOAD_ONE_STREAM": "1"}),
                               ("streamed, no list", {"KCFX_LOAD_STREAM_TWICE": "1", "KCFX_LOAD_NO_LOST_LIST": "1"}),
-                              ("streamed, short list", {"KCFX_LOAD_STREAM_TWICE": "1", "KCFX_LOAD_LOST_CAP": "3"})):
+                              ("streamed, short list", {"KCFX_LOAD_STREAM_TWICE": "1", "KCFX_LOAD_LOST_CAP": "3"}),
+                              ("probes, small chunks", dict(small)), ("decoded, small chunks", {"KCFX_LOAD_NO_PROBES": "1", **small}),
+                              ("streamed, small chunks", {"KCFX_LOAD_STREAM_TWICE": "1", **small}),
+                              ("streamed, no list, small chunks", {"KCFX_LOAD_STREAM_TWICE": "1", "KCFX_LOAD_NO_LOST_LIST": "1", **small})):
                 for kk, v in env.items():
                     monkeypatch.setenv(kk, v)
                 db = engine.KmcDb.open(prefix)

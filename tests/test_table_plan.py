@@ -14,8 +14,16 @@ def per_cell(n, lines):
 
 
 def test_the_sizes_the_profiles_quote():
-    # the bench sample: ~0.075 per cell in a power of two, one region
+    # the bench sample, a handle somebody keeps (expected_queries = 0): ~0.075 per cell in a power of two, one region
     assert engine.table_plan(150_079_223, 31, True, FREE) == (1 << 27, 1)
+    # ... opened for ONE pass of a 30 Mb reference (the command-line driver, kcfx_screen_sharded): the first size at or under 0.3 per
+    # cell -- 4.4 GB instead of 17 -- and so for a hundred passes; the sparse table pays for its allocation past ~4e11 look-ups
+    assert engine.table_plan(150_079_223, 31, True, FREE, expected_queries=30_010_326) == (1 << 25, 1)
+    assert engine.table_plan(150_079_223, 31, True, FREE, expected_queries=100 * 30_010_326) == (1 << 25, 1)
+    assert engine.table_plan(150_079_223, 31, True, FREE, expected_queries=10**12)[0] in (1 << 26, 1 << 27)
+    assert engine.table_plan(150_079_223, 31, True, FREE, expected_queries=10**14) == (1 << 27, 1)
+    # a one-pass table between the powers of two: 2^24 lines would be 0.45 per cell, the region steps stop at 1.5 x 2^24 (0.298)
+    assert engine.table_plan(120_000_000, 31, True, FREE, expected_queries=1) == (3 << 23, 3)
     # the config-5 database: 2^28 lines would be 0.49 per cell; a table under 48 GiB grows up to them in quarters: 3 x 2^27
     assert engine.table_plan(2_110_000_000, 31, True, FREE) == (3 << 27, 3)
     # the wheat-scale database: 2^30 lines (the most a 32-bit mix of the minimizer addresses) = 0.47 per cell; 3 x 2^29 = 192 GiB
@@ -34,6 +42,25 @@ def test_the_sizes_the_profiles_quote():
         engine.table_plan(-1, 31, True, FREE)
     with pytest.raises(engine.KcfxError):
         engine.table_plan(1, 40, True, FREE)
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.integers(0, 16_000_000_000), st.sampled_from([19, 25, 31]), st.booleans(), st.integers(8, 280), st.integers(1, 10**15))
+def test_expected_queries_only_ever_shrink_the_table(n, k, both, free_gib, q):
+    """A stated number of look-ups never gives a larger table than "unknown", more look-ups never a smaller one, and the dense end
+    stays at or under ~0.3 k-mers per cell wherever the unknown-queries policy would have been sparser than that."""
+    free = free_gib * GIB
+    unknown, _ = engine.table_plan(n, k, both, free)
+    stated, regions = engine.table_plan(n, k, both, free, expected_queries=q)
+    more, _ = engine.table_plan(n, k, both, free, expected_queries=min(10**15, 100 * q))
+    if unknown == 0:
+        assert stated == 0
+        return
+    assert 0 < stated <= unknown and 16 * stated >= n
+    assert more >= stated
+    assert regions in (1, 3, 5, 7)
+    if per_cell(n, unknown) <= 0.30 and stated * 128 < 48 * GIB and stated >= (1 << 20):
+        assert per_cell(n, stated) <= 0.30 + 1e-9 or stated == unknown
 
 
 @settings(max_examples=300, deadline=None)

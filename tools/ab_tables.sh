@@ -1,4 +1,5 @@
 #!/bin/bash
+export KCFX_TEST_HOOKS=1    # KCFX_TABLE_* / KCFX_LOAD_* are test hooks (kcfx_internal.h: hook())
 # Same-box A/B of the table policies on the bench workload (run ON THE GPU BOX): the product table (what one pass gets), the sparse
 # one (kcfx_db_open's default) and explicit sizes. Prints one line per configuration.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1

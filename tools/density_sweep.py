@@ -14,6 +14,7 @@ import csv
 import glob
 import json
 import os
+os.environ.setdefault("KCFX_TEST_HOOKS", "1")     # KCFX_TABLE_* / KCFX_LOAD_* are test hooks (kcfx_internal.h: hook())
 import sys
 import time
 

@@ -1,4 +1,5 @@
 #!/bin/bash
+export KCFX_TEST_HOOKS=1    # KCFX_TABLE_* / KCFX_LOAD_* are test hooks (kcfx_internal.h: hook())
 # Where does an end-to-end getVariations run of the bench workload spend its wall time? (run on the GPU box)
 # bench.py leaves the workload's files in $KCFX_BENCH_DIR; the CLI then runs with its phase trace on, and a few times without.
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true

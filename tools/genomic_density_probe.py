@@ -8,6 +8,7 @@ every k-mer is a run of its own.)
 import argparse
 import json
 import os
+os.environ.setdefault("KCFX_TEST_HOOKS", "1")     # KCFX_TABLE_* / KCFX_LOAD_* are test hooks (kcfx_internal.h: hook())
 import shutil
 import subprocess
 import sys

@@ -6,6 +6,7 @@ KCFX_LOAD_TRACE=1 for the phase split.
     python tools/load_overlap_probe.py [--n 8]"""
 import argparse
 import os
+os.environ.setdefault("KCFX_TEST_HOOKS", "1")     # KCFX_TABLE_* / KCFX_LOAD_* are test hooks (kcfx_internal.h: hook())
 import subprocess
 import sys
 import threading

@@ -1,4 +1,5 @@
 import os, sys, time, subprocess
+os.environ.setdefault("KCFX_TEST_HOOKS", "1")     # KCFX_TABLE_* / KCFX_LOAD_* are test hooks (kcfx_internal.h: hook())
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000_000
