@@ -1716,15 +1716,52 @@ int32_t kcfx_screen_ref_multi_async(kcfx_db* const* dbs, int32_t n_db, kcfx_ref*
     DeviceGuard g(ref->device);
     // scratch of the multi-sample kernel: only if some database can take it, sized for the largest batch this call forms
     // (512 B per tile and sample: 29 GB for eight samples of a 14.5 Gb reference -- not to be allocated on spec)
+    // Cell tables (k = 19 .. 31: the BASELINE configuration) take one screening launch per sample -- their probe is one load per k-mer
+    // already -- but their window reduces are batched (round 6): the launches of up to eight consecutive samples write their tiles'
+    // bitmaps side by side into the multi-sample scratch and ONE reduce_windows launch (grid.y = samples) turns them into records, where
+    // every sample used to pay a reduce and the gap in front of it (7 + ~4 us per sample beside a 80 us pass of a 30 Mb reference). The
+    // scratch is bounded at 2 GiB: a 14.5 Gb reference (3.7 GB of bitmaps per sample) keeps the one-by-one form.
+    int32_t cell_batch = 1;
     {
-        int32_t eligible = 0;
-        for (int32_t i = 0; i < n_db; ++i) eligible += screen_multi_supported(dbs[i]->view(), ref->k) ? 1 : 0;
-        if (int32_t rc = kcfx_ref_reserve_multi(ref, eligible)) return rc;
+        int32_t eligible = 0, cells = 0;
+        for (int32_t i = 0; i < n_db; ++i) {
+            eligible += screen_multi_supported(dbs[i]->view(), ref->k) ? 1 : 0;
+            cells += (dbs[i]->fmt == FORMAT_CELLS && dbs[i]->n_slices == 1) ? 1 : 0;
+        }
+        const double per_sample = (double)std::max(ref->n_tiles, 1) * (TILE_BITS_U64 * 8 + 8);
+        if (cells >= 2) cell_batch = (int32_t)std::max(1.0, std::min({(double)SCREEN_MULTI_MAX, (double)cells, std::floor((double)(2ull << 30) / per_sample)}));
+        if (int32_t rc = kcfx_ref_reserve_multi(ref, std::max(eligible, cell_batch >= 2 ? cell_batch : 0))) return rc;
     }
     std::vector<char> done(n_db, 0);
     for (int32_t first = 0; first < n_db; ++first) {
         if (done[first]) continue;
         kcfx_db* d0 = dbs[first];
+        if (cell_batch >= 2 && d0->fmt == FORMAT_CELLS && d0->n_slices == 1) {
+            // the run of consecutive cell tables that starts here, up to cell_batch of them
+            int32_t nb = 0;
+            while (first + nb < n_db && nb < cell_batch && nb < ref->multi_cap && !done[first + nb] && dbs[first + nb]->fmt == FORMAT_CELLS && dbs[first + nb]->n_slices == 1) ++nb;
+            for (int32_t b = 0; b < nb; ++b) {
+                kcfx_db* d = dbs[first + b];
+                hipEvent_t ev0 = nullptr, ev1 = nullptr;
+                if (ref->prof && ref->n_tiles > 0) {
+                    if (ref->events_used == ref->events.size()) {
+                        hipEvent_t ea, eb;
+                        KCFX_HIP(hipEventCreate(&ea));
+                        KCFX_HIP(hipEventCreate(&eb));
+                        ref->events.emplace_back(ea, eb);
+                    }
+                    ev0 = ref->events[ref->events_used].first;
+                    ev1 = ref->events[ref->events_used].second;
+                    ref->events_used++;
+                }
+                KCFX_HIP(launch_screen_tiles(ref->d_text, ref->plan(), ref->d_tiles, ref->n_tiles, d->view(), ref->k, d->info.both_strands, min_kmer_count,
+                                             ref->d_mbits + (size_t)b * ref->n_tiles * TILE_BITS_U64, ref->d_mcsum + (size_t)b * ref->n_tiles, st, ev0, ev1));
+                done[first + b] = 1;
+            }
+            KCFX_HIP(launch_reduce_windows(ref->d_tiles, ref->n_tiles, nb, ref->d_mbits, ref->d_mcsum, ref->d_win_tile0, ref->n_windows, ref->k,
+                                           out + (size_t)first * ref->n_windows, st));
+            continue;
+        }
         if (!screen_multi_supported(d0->view(), ref->k)) {
             if (int32_t rc = kcfx_screen_ref_async(d0, ref, min_kmer_count, out + (size_t)first * ref->n_windows, hip_stream))
                 return rc;

@@ -330,7 +330,7 @@ __global__ void cells_resolve_kernel(uint32_t* pop32, int32_t pop_bits, int32_t 
 
 // Pass 1 (cls = 1: claim) and pass 2 (cls = 0: write, after ALL of pass 1). Claim: every stored k-mer bids for its first-choice
 // cell(s) with a 64-bit atomic max of its RANK -- not of its cell word: [crowded : 1][counter >= 2 : 1][run : 14][counter : 16]
-// [hash of (w, r) : 32]. "run" is a hash of the minimizer (of G32: line and the identifying bits of r), the same for every k-mer of
+// [locus : 8][hash of (w, r) : 24] (round 6; before: [hash : 32]). "run" is a hash of the minimizer (of G32: line and the identifying bits of r), the same for every k-mer of
 // a minimizer run: where two runs share a line the SAME run wins every cell both want, so a screening pass over the winner's locus
 // finds all of its k-mers at home and only the loser's locus pays the request for a second line (with the counter as the rank both
 // runs lost about half of the contested cells and both loci paid: round 4, profiles/r04_notes.md). "Seen more than once" stays
@@ -344,16 +344,21 @@ __global__ void cells_resolve_kernel(uint32_t* pop32, int32_t pop_bits, int32_t 
 // "seen more than once" reads "held by more than one sample": the k-mers the samples share, which are the ones a reference
 // asks for, stay above a run that is private to one sample. With the run directly under the class the bench cohort screened
 // in 0.292 ms instead of 0.217: half of the shared runs lost their contests to private ones.)
-// (round 6: "the run" is the LOCUS -- cell_crowd_key: the minimizer with the three bases next to it -- so that of two loci that contain
-// the same 16-mer ONE keeps every cell both want, as of two runs that share a line; keyed by the minimizer alone they tied here and
-// split the contested cells by the counter and a hash, k-mer by k-mer: both loci then paid for a second line, in ones and twos)
+// (round 6: the crowding class is counted per LOCUS -- cell_crowd_key -- and the locus also breaks the ties that are left when two
+// k-mers of ONE minimizer have the same counter: of two loci that contain the same 16-mer with equally abundant k-mers ONE keeps
+// every cell both want, as of two runs that share a line, instead of splitting them k-mer by k-mer on a hash. It stands BELOW the
+// counter: among the copies of a repeat family the consensus k-mer -- the one most copies carry, the one a reference asks for most
+// often -- must keep its cell against a rare variant whatever the hashes say. With the locus in the run's place the
+// repeat-structured genome of the bench sent 1.6 M k-mers per pass to the stash instead of 0.5 M: profiles/r06_notes.md section 2.)
+// rank = [crowded : 1][counter >= 2 : 1][run : 14] [counter : 16] [locus : 8][hash of (w, r, cell) : 24]
 __device__ __forceinline__ unsigned long long cell_bid(const CellProbe& p, uint32_t c, bool crowded, int32_t lbits, int32_t presence, bool ext, bool by_minimizer) {
-    const uint32_t g = cell_crowd_key(p, lbits, ext, by_minimizer);
+    const uint32_t g = (p.line << (32 - lbits)) | (p.r & (0xFFFFFFFFu >> lbits));
     const uint32_t run = (g * 0x9E3779B1u) >> 18;
     const bool more = presence ? (c >> 12) >= 2u : c >= 2u;
     const uint32_t top = ((crowded ? 1u : 0u) << 15) | ((more ? 1u : 0u) << 14) | run;
+    const uint32_t locus = by_minimizer ? 0u : (cell_crowd_key(p, lbits, ext, false) * 0x85EBCA6Bu) >> 24;
     const uint32_t idh = ((p.w & ~CELL_FLAG_MASK) * 0x85EBCA6Bu) ^ ((p.r & 0xFFFFu) * 0xC2B2AE35u) ^ (p.sh * 0x27D4EB2Fu);
-    return ((unsigned long long)top << 48) | ((unsigned long long)(c & 0xFFFFu) << 32) | idh;
+    return ((unsigned long long)top << 48) | ((unsigned long long)(c & 0xFFFFu) << 32) | ((unsigned long long)locus << 24) | (by_minimizer ? idh : idh >> 8);
 }
 __global__ void cells_insert_kernel(uint8_t* lines, const uint32_t* __restrict__ pop32, int32_t pop_bits, int32_t cls, int32_t k, int32_t lbits, int32_t both,
                                     const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, int64_t n, int32_t presence, RecProbes rp, int32_t by_minimizer) {

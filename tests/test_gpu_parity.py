@@ -414,11 +414,11 @@ def test_stash_budget_and_line_table_fallback(oracle, tmp_path, monkeypatch, cap
 
 
 def test_db_open_opts_size_the_table_for_the_expected_look_ups(oracle, tmp_path, monkeypatch):
-    """kcfx_db_open_opts: since round 4 every handle gets the same table size whatever expected_queries says (a handle that will
-    serve one pass -- the command-line driver, kcfx_screen_sharded's loader -- only keeps the cheaper crowding counters of the
-    build); a denser table (KCFX_TABLE_LBITS) gives the same results; the allocation thread that runs beside the file streaming
-    and the synchronous path (KCFX_SYNC_ALLOC) build the same table; no_fallback turns the silent line-table rebuild into
-    KCFX_ERR_DEVICE."""
+    """kcfx_db_open_opts (round 6): the table follows the look-ups the handle will serve -- one pass (the command-line driver,
+    kcfx_screen_sharded's loader) gets the first size at or under ~0.3 k-mers per cell, an unknown number (0) or 10^15 of them the
+    sparse table (~0.075), as kcfx_table_plan_for says; every size gives the same results; the allocation thread that runs beside
+    the file streaming and the synchronous path (KCFX_SYNC_ALLOC) build the same table; no_fallback turns the silent line-table
+    rebuild into KCFX_ERR_DEVICE."""
     k = 31
     ref = synth.random_reference(600_000, 21)
     prefix, kmers, counts, prm = make_db(tmp_path, "opts", ref, 22, k=31, p=7, cs=2, m=9, bins=32, noise=1_500_000)
@@ -426,9 +426,13 @@ def test_db_open_opts_size_the_table_for_the_expected_look_ups(oracle, tmp_path,
     want = oracle.OracleDb(prefix).screen(ref, s, e - s, 1, threads=8)
     sparse = engine.KmcDb.open(prefix)
     one_pass = engine.KmcDb.open(prefix, expected_queries=int((e - s - k + 1).sum()))
-    many = engine.KmcDb.open(prefix, expected_queries=10**12)
+    many = engine.KmcDb.open(prefix, expected_queries=10**15)
     assert sparse.info.table_format == one_pass.info.table_format == 1
-    assert many.info.table_lines == sparse.info.table_lines == one_pass.info.table_lines
+    assert many.info.table_lines == sparse.info.table_lines
+    n_keys = int(sparse.info.total_kmers)
+    assert one_pass.info.table_lines < sparse.info.table_lines
+    assert 0.15 < n_keys / (16.0 * one_pass.info.table_lines) <= 0.30 and n_keys / (16.0 * sparse.info.table_lines) <= 0.075
+    assert (int(one_pass.info.table_lines), int(one_pass.info.regions)) == engine.table_plan(n_keys, k, True, 200 << 30, expected_queries=int((e - s - k + 1).sum()))
     monkeypatch.setenv("KCFX_TABLE_LBITS", str(int(np.log2(sparse.info.table_lines)) - 2))
     dense = engine.KmcDb.open(prefix, expected_queries=1000)
     monkeypatch.delenv("KCFX_TABLE_LBITS")
