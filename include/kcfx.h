@@ -317,8 +317,8 @@ void kcfx_ctx_destroy(kcfx_ctx* ctx);
                                   min(KCFX_COHORT_MAX, n_samples - seg_sample) samples */
 
 #define KCFX_SHARD_TABLE 5     /* the TABLE of every sample partitioned over the devices (never chosen by AUTO; k = 19 .. 31): device g
-                                  opens slice g of G of the sample's database (kcfx_db_open_slice: 1 / G of the lines, every device
-                                  streams the file), screens the WHOLE window list against it, the tiles' hit bitmaps are OR-ed on
+                                  opens slice g of G of the sample's database (kcfx_db_open_slice: 1 / G of the lines; the G loaders
+                                  share one stream of the file: kcfx_shard_slice_io), screens the WHOLE window list against it, the tiles' hit bitmaps are OR-ed on
                                   the first device and reduced there; sample after sample. For a database that one device holds
                                   only at a density that costs it half its speed (a wheat-scale count: BASELINE configs[4]).
                                   kcfx_shard_plan reports one segment per (device, sample), all windows each */
@@ -352,6 +352,12 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
                             int32_t n_windows, int32_t min_kmer_count, int32_t shard_mode, kcfx_result* out,
                             kcfx_shard_stats* stats);
 
+/* What the slice loaders of this process's most recent kcfx_screen_sharded(KCFX_SHARD_TABLE) call read from the host side: the G
+ * loaders of a sample share ONE stream of its .kmc_suf (every chunk is read into pinned memory once and copied to each device over
+ * that device's own link; KMC.java:84-102,173-189 maps a file once too) -- bytes_read is therefore ~ passes x the file, not G x
+ * that; chunks_shared counts the chunk requests a sibling loader's read served. Outputs may be NULL. */
+int32_t kcfx_shard_slice_io(int64_t* bytes_read, int64_t* chunks_read, int64_t* chunks_shared);
+
 /* ---- the pieces of a pass over a partitioned table (kcfx_db_open_slice) -------------------------------------------------- */
 
 /* The screening kernel alone on the caller's stream: the tiles' bitmaps (validity, and the hits this slice found) and count sums
@@ -362,6 +368,13 @@ int32_t kcfx_screen_ref_partial(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_cou
 int64_t kcfx_ref_partial_bytes(const kcfx_ref* ref, int64_t* bitmap_bytes, int64_t* sum_bytes);
 /* the partial results copied into caller-owned DEVICE buffers (tensors handed to an RCCL gather), on the caller's stream */
 int32_t kcfx_ref_export_partial_async(kcfx_ref* ref, void* bitmaps_device, void* sums_device, void* hip_stream);
+/* ... and back: caller-owned device buffers of that layout INTO the reference's scratch. With kcfx_ref_tile_range (windows
+ * [w_lo, w_hi) of a reference are its tiles [*t_lo, *t_hi): 64 bitmap words and one count sum per tile, in tile order) this is what a
+ * job needs to let the slices' results meet RANGE BY RANGE instead of on one root: rank q owns a window range, receives that range's
+ * tiles from every rank (1 / G of the bitmaps each), imports its own into a reference of just those windows, merges the others and
+ * finishes -- no device carries (G - 1) x the bitmaps of the whole window list (kcftools_amd/shard.py: reduce_scatter_table_partials). */
+int32_t kcfx_ref_import_partial_async(kcfx_ref* ref, const void* bitmaps_device, const void* sums_device, void* hip_stream);
+int32_t kcfx_ref_tile_range(const kcfx_ref* ref, int32_t w_lo, int32_t w_hi, int32_t* t_lo, int32_t* t_hi);
 /* another slice's partial results -- device buffers on the reference's device, same text and windows -- into this reference's:
  * hit words OR-ed, count sums added (every k-mer is looked up on exactly one slice) */
 int32_t kcfx_ref_merge_partial_async(kcfx_ref* ref, const void* bitmaps_device, const void* sums_device, void* hip_stream);

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -698,11 +699,133 @@ struct LoadTrace {
     }
 };
 
+}  // namespace
+
+// ---- one .kmc_suf read ONCE for the slices that a node's devices build at the same time (round 6) --------------------------------
+// kcfx_db_open_slice makes every device walk the whole file in every build pass; G loaders of their own read G x the file through one
+// page cache (46 GB/s on the boxes seen: eight slices of a 65 GB file = 11 s of reading per pass where one device takes 1.4 s).
+// The loaders of one call share this instead: a small cache of pinned (portable) chunk buffers keyed by the chunk's index in the
+// file. The first loader that asks for a chunk reads it (parallel_pread), the others find it there and start their own
+// host-to-device copy from the same buffer -- every device has its own link. A loader holds at most two chunks (its double
+// buffering); a buffer is reused when nobody holds it. Loaders that drift apart by more than the cache holds simply read for
+// themselves again: nothing waits for a loader that never comes (the passes a slice makes may differ from its siblings').
+namespace kcfx {
+struct SuffixCache {
+    struct Buf {
+        uint8_t* p = nullptr;
+        int64_t chunk = -1;
+        int refs = 0;
+        bool ready = false, loading = false;
+        uint64_t stamp = 0;
+    };
+    int fd = -1;
+    size_t cap = 0;                      // bytes per buffer
+    std::vector<Buf> bufs;
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t clock = 0;
+    int64_t reads = 0, hits = 0, bytes_read = 0;
+    // the chunk's bytes in pinned memory, or null on a read error; *slot names the buffer for release()
+    const uint8_t* acquire(int64_t chunk, int64_t offset, int64_t bytes, int* slot) {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            int mine = -1, spare = -1;
+            for (int i = 0; i < (int)bufs.size(); ++i) {
+                if (bufs[i].chunk == chunk && (bufs[i].ready || bufs[i].loading)) mine = i;
+                else if (bufs[i].refs == 0 && !bufs[i].loading && (spare < 0 || bufs[i].stamp < bufs[spare].stamp)) spare = i;
+            }
+            if (mine >= 0) {
+                if (bufs[mine].loading) {
+                    cv.wait(lk);
+                    continue;
+                }
+                bufs[mine].refs++;
+                bufs[mine].stamp = ++clock;
+                ++hits;
+                *slot = mine;
+                return bufs[mine].p;
+            }
+            if (spare < 0) {                               // (every buffer is held: 2 per loader at most, the cache has 2 G + 2)
+                cv.wait(lk);
+                continue;
+            }
+            Buf& b = bufs[spare];
+            b.chunk = chunk;
+            b.ready = false;
+            b.loading = true;
+            lk.unlock();
+            const bool ok = (size_t)bytes <= cap && parallel_pread(fd, b.p, bytes, offset);
+            lk.lock();
+            b.loading = false;
+            if (!ok) {
+                b.chunk = -1;
+                cv.notify_all();
+                return nullptr;
+            }
+            b.ready = true;
+            b.refs = 1;
+            b.stamp = ++clock;
+            ++reads;
+            bytes_read += bytes;
+            *slot = spare;
+            cv.notify_all();
+            return b.p;
+        }
+    }
+    void release(int slot) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (slot >= 0 && slot < (int)bufs.size() && bufs[slot].refs > 0) --bufs[slot].refs;
+        cv.notify_all();
+    }
+};
+
+int64_t load_chunk_records() {
+    // records per chunk (KCFX_LOAD_CHUNK_RECORDS: test hook -- a few thousand records per chunk make a small database take many chunks,
+    // both buffers reused, chunks at byte offsets that are no multiple of 4)
+    int64_t ch = 4ll << 20;
+    if (const char* ce = hook("KCFX_LOAD_CHUNK_RECORDS")) ch = std::max<int64_t>(64, std::min<int64_t>(ch, atoll(ce)));
+    return ch;
+}
+
+SuffixCache* suffix_cache_create(const char* kmc_prefix, int32_t consumers) {
+    KmcHeader h;
+    std::string perr;
+    if (parse_prefix_file(std::string(kmc_prefix) + ".kmc_pre", h, perr) != KCFX_OK) return nullptr;
+    std::unique_ptr<SuffixCache> c(new SuffixCache());
+    c->fd = open((std::string(kmc_prefix) + ".kmc_suf").c_str(), O_RDONLY);
+    if (c->fd < 0) return nullptr;
+    const int64_t ch = load_chunk_records();
+    c->cap = (size_t)std::max<int64_t>(16, std::min<int64_t>(ch, std::max<int64_t>(h.total, 1)) * h.record_size);
+    c->bufs.resize((size_t)(2 * std::max(1, consumers) + 2));
+    for (auto& b : c->bufs)
+        if (hipHostMalloc(reinterpret_cast<void**>(&b.p), c->cap, hipHostMallocPortable) != hipSuccess) {
+            (void)hipGetLastError();
+            suffix_cache_destroy(c.release());
+            return nullptr;
+        }
+    return c.release();
+}
+void suffix_cache_destroy(SuffixCache* c) {
+    if (!c) return;
+    for (auto& b : c->bufs)
+        if (b.p) (void)hipHostFree(b.p);
+    if (c->fd >= 0) close(c->fd);
+    delete c;
+}
+void suffix_cache_stats(const SuffixCache* c, int64_t* reads, int64_t* hits, int64_t* bytes_read) {
+    if (reads) *reads = c ? c->reads : 0;
+    if (hits) *hits = c ? c->hits : 0;
+    if (bytes_read) *bytes_read = c ? c->bytes_read : 0;
+}
+}  // namespace kcfx
+
+namespace {
+
 // Stream the .kmc_suf records through the GPU once: upload -> decode_records -> (key, count) arrays.
 //   minimizer tables need two passes over the k-mers (count per home line, mark heavy homes, insert). When the decoded
 //   records fit beside the table (12 B per k-mer) they stay in HBM between the passes and the file is read once;
 //   otherwise the file is streamed twice.
-int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& h) {
+int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& h, SuffixCache* shared = nullptr) {
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) return fail(KCFX_ERR_IO, "Error reading suffix buffers from file " + path);
     struct stat st;
@@ -716,10 +839,7 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
         return fail(KCFX_ERR_FORMAT, "missing KMCS marker in " + path);
     }
     LoadTrace tr;
-    // records per chunk (KCFX_LOAD_CHUNK_RECORDS: test hook -- a few thousand records per chunk make a small database take many chunks,
-    // both buffers reused, chunks at byte offsets that are no multiple of 4)
-    int64_t CH = 4ll << 20;
-    if (const char* ce = hook("KCFX_LOAD_CHUNK_RECORDS")) CH = std::max<int64_t>(64, std::min<int64_t>(CH, atoll(ce)));
+    const int64_t CH = load_chunk_records();    // records per chunk
     const int64_t chunk_bytes = CH * h.record_size;
     uint8_t* h_buf[2] = {nullptr, nullptr};
     uint8_t* d_rec[2] = {nullptr, nullptr};
@@ -736,12 +856,18 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     // db->stream alone the copy waited for the table pass of the chunk before it, and a streamed pass over a 65 GB file took 2.5 s
     // where the link and the page cache deliver it in 1.5 s (tools: 56 GB/s H2D, 60 GB/s pread, 45 GB/s both at once).
     hipStream_t copier = nullptr;
+    int held[2] = {-1, -1};                        // (shared chunk cache: the buffers this loader's two turns copy from)
     int32_t rc = KCFX_OK;
     auto cleanup = [&]() {
         // the temporaries are used on db->stream and the copier only: wait for those, not for the device (the other worker's
         // screening kernel, the next database's uploads)
         if (copier) (void)hipStreamSynchronize(copier);
         (void)hipStreamSynchronize(db->stream);
+        for (int i = 0; i < 2; ++i)
+            if (shared && held[i] >= 0) {
+                shared->release(held[i]);
+                held[i] = -1;
+            }
         if (copier) (void)hipStreamDestroy(copier);
         copier = nullptr;
         if (lost.keys) (void)dev_free_idle(lost.keys);
@@ -788,7 +914,7 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     const int64_t n_chunk_max = std::min<int64_t>(CH, std::max<int64_t>(h.total, 1));
     const int64_t n_keys_buf = resident ? std::max<int64_t>(h.total, 1) : n_chunk_max;
     for (int i = 0; i < 2; ++i) {
-        LOAD_HIP(host_alloc(&h_buf[i], (size_t)std::min(chunk_bytes, std::max<int64_t>(h.total * h.record_size, 16))));
+        if (!shared) LOAD_HIP(host_alloc(&h_buf[i], (size_t)std::min(chunk_bytes, std::max<int64_t>(h.total * h.record_size, 16))));
         LOAD_HIP(dev_alloc(&d_rec[i], (size_t)n_chunk_max * h.record_size + 16));
         LOAD_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
         LOAD_HIP(hipEventCreateWithFlags(&decoded[i], hipEventDisableTiming));
@@ -864,7 +990,15 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
             const double t_a = tr.on ? now_s() : 0;
             if (used[turn]) LOAD_HIP(hipEventSynchronize(done[turn]));      // the copy out of h_buf[turn] has finished
             const double t_b = tr.on ? now_s() : 0;
-            if (!parallel_pread(fd, h_buf[turn], bytes, 4 + first * h.record_size)) {
+            const uint8_t* src = h_buf[turn];
+            if (shared) {                                   // the chunk from the cache its sibling loaders share (read by whoever asks first)
+                if (held[turn] >= 0) shared->release(held[turn]);
+                held[turn] = -1;
+                src = shared->acquire(first / CH, 4 + first * h.record_size, bytes, &held[turn]);
+            } else if (!parallel_pread(fd, h_buf[turn], bytes, 4 + first * h.record_size)) {
+                src = nullptr;
+            }
+            if (!src) {
                 cleanup();
                 return fail(KCFX_ERR_IO, "short read on " + path);
             }
@@ -876,7 +1010,7 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
             // d_rec[turn] was last read by the decode two chunks ago: before this copy in stream order, or (the copier) waited for
             uint8_t* const rec_at = d_rec[turn];
             if (copier && used[turn]) LOAD_HIP(hipStreamWaitEvent(copier, decoded[turn], 0));
-            LOAD_HIP(hipMemcpyAsync(rec_at, h_buf[turn], (size_t)bytes, hipMemcpyHostToDevice, up));
+            LOAD_HIP(hipMemcpyAsync(rec_at, src, (size_t)bytes, hipMemcpyHostToDevice, up));
             LOAD_HIP(hipEventRecord(done[turn], up));
             if (copier) LOAD_HIP(hipStreamWaitEvent(db->stream, done[turn], 0));
             used[turn] = true;
@@ -890,6 +1024,13 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
             first += n;
             turn ^= 1;
         }
+        if (shared)                                         // (the pass's last two chunks: back to the cache once their copies are done)
+            for (int i = 0; i < 2; ++i)
+                if (held[i] >= 0) {
+                    LOAD_HIP(hipEventSynchronize(done[i]));
+                    shared->release(held[i]);
+                    held[i] = -1;
+                }
         if (tr.on) fprintf(stderr, "[kcfx load]   pass %d over the file: host %.0f ms = %.0f waiting for the upload two chunks back + %.0f reading + %.0f enqueueing the upload + %.0f launching\n", phase,
                            (now_s() - t_pass0) * 1e3, t_wait * 1e3, t_read * 1e3, t_copy * 1e3, (now_s() - t_pass0 - t_wait - t_read - t_copy) * 1e3);
         return KCFX_OK;
@@ -1183,7 +1324,13 @@ int32_t kcfx_table_slice_of(uint32_t g32, int32_t lbits, int32_t n_slices) {
     return (int32_t)cell_slice_of(g32 >> (32 - lbits), g32, lbits, (uint32_t)n_slices);
 }
 
-int32_t kcfx_db_open_slice(const char* kmc_prefix, int32_t device, const kcfx_db_opts* opts, int32_t n_slices, int32_t slice, kcfx_db** out) try {
+int32_t kcfx_db_open_slice(const char* kmc_prefix, int32_t device, const kcfx_db_opts* opts, int32_t n_slices, int32_t slice, kcfx_db** out) {
+    return kcfx::db_open_slice_shared(kmc_prefix, device, opts, n_slices, slice, nullptr, out);
+}
+
+}  // extern "C"
+
+int32_t kcfx::db_open_slice_shared(const char* kmc_prefix, int32_t device, const kcfx_db_opts* opts, int32_t n_slices, int32_t slice, SuffixCache* shared, kcfx_db** out) try {
     if (!kmc_prefix || !out) return fail(KCFX_ERR_ARG, "null argument");
     if (opts && opts->expected_queries < 0) return fail(KCFX_ERR_ARG, "kcfx_db_opts: negative expected_queries");
     if (n_slices < 1 || n_slices > KCFX_SLICES_MAX || slice < 0 || slice >= n_slices) return fail(KCFX_ERR_ARG, "kcfx_db_open_slice: slice out of range (1 .. 64 slices)");
@@ -1222,7 +1369,7 @@ int32_t kcfx_db_open_slice(const char* kmc_prefix, int32_t device, const kcfx_db
     }
     int32_t rc = table_alloc(db, n_mine, h.counter_size, true, hook("KCFX_SYNC_ALLOC") == nullptr);
     tr.mark("table alloc (deferred)");
-    if (!rc) rc = load_suffix_file(db, std::string(kmc_prefix) + ".kmc_suf", h);
+    if (!rc) rc = load_suffix_file(db, std::string(kmc_prefix) + ".kmc_suf", h, shared);
     // (the allocation thread may still be running when the streaming failed first -- an I/O error, or the decoded arrays lost the
     // race for the memory to the table: join it before its outcome is read)
     if (rc) db->alloc_go = true;
@@ -1239,7 +1386,7 @@ int32_t kcfx_db_open_slice(const char* kmc_prefix, int32_t device, const kcfx_db
         table_release(db);
         db->lbits_cap = cap;
         rc = table_alloc(db, n_mine, h.counter_size, true, false);
-        if (!rc) rc = load_suffix_file(db, std::string(kmc_prefix) + ".kmc_suf", h);
+        if (!rc) rc = load_suffix_file(db, std::string(kmc_prefix) + ".kmc_suf", h, shared);
         tr.mark("denser cell table after an out-of-memory");
     }
     if (rc == KCFX_ERR_DEVICE && db->fmt == FORMAT_CELLS && !(opts && opts->no_fallback) && n_slices == 1) {     // (a slice is a cell table or nothing)
@@ -1250,7 +1397,7 @@ int32_t kcfx_db_open_slice(const char* kmc_prefix, int32_t device, const kcfx_db
         // (not an error and not reported on stderr -- this is a library behind a C / JNI ABI: kcfx_db_info's table_format says it)
         if (getenv("KCFX_VERBOSE")) fprintf(stderr, "kcfx: %s: cell table not built (%s); building a line table instead\n", kmc_prefix, why.c_str());
         rc = table_alloc(db, h.total, h.counter_size, false);
-        if (!rc) rc = load_suffix_file(db, std::string(kmc_prefix) + ".kmc_suf", h);
+        if (!rc) rc = load_suffix_file(db, std::string(kmc_prefix) + ".kmc_suf", h, shared);
         tr.mark("rebuilt as a line table");
     }
     if (!rc) rc = table_finish(db);
@@ -1262,6 +1409,8 @@ int32_t kcfx_db_open_slice(const char* kmc_prefix, int32_t device, const kcfx_db
     *out = hold.release();
     return KCFX_OK;
 } KCFX_CATCH("kcfx_db_open_slice")
+
+extern "C" {
 
 int32_t kcfx_table_plan(int64_t total_kmers, int32_t kmer_length, int32_t both_strands, int64_t free_bytes,
                         int64_t* lines, int32_t* regions) {
@@ -1627,6 +1776,35 @@ int32_t kcfx_ref_export_partial_async(kcfx_ref* ref, void* bitmaps_device, void*
     KCFX_HIP(hipMemcpyAsync(sums_device, ref->d_csum, (size_t)c, hipMemcpyDeviceToDevice, st));
     return KCFX_OK;
 } KCFX_CATCH("kcfx_ref_export_partial_async")
+
+// caller-owned device buffers INTO the reference's scratch (the inverse of the export): what a rank that owns a range of the windows
+// starts its merge from, when the slices' results meet range by range instead of on one root (shard.py: reduce_scatter_table_partials)
+int32_t kcfx_ref_import_partial_async(kcfx_ref* ref, const void* bitmaps_device, const void* sums_device, void* hip_stream) try {
+    if (!ref || !bitmaps_device || !sums_device) return fail(KCFX_ERR_ARG, "null argument");
+    int64_t b = 0, c = 0;
+    kcfx_ref_partial_bytes(ref, &b, &c);
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    DeviceGuard g(ref->device);
+    KCFX_HIP(hipMemcpyAsync(ref->d_bits, bitmaps_device, (size_t)b, hipMemcpyDeviceToDevice, st));
+    KCFX_HIP(hipMemcpyAsync(ref->d_csum, sums_device, (size_t)c, hipMemcpyDeviceToDevice, st));
+    return KCFX_OK;
+} KCFX_CATCH("kcfx_ref_import_partial_async")
+
+// the tiles of a window range: windows [w_lo, w_hi) of this reference are its tiles [*t_lo, *t_hi) -- the units a rank exchanges
+int32_t kcfx_ref_tile_range(const kcfx_ref* ref, int32_t w_lo, int32_t w_hi, int32_t* t_lo, int32_t* t_hi) try {
+    if (!ref || !t_lo || !t_hi || w_lo < 0 || w_hi < w_lo || w_hi > ref->n_windows) return fail(KCFX_ERR_ARG, "kcfx_ref_tile_range: bad window range");
+    if (ref->n_windows == 0) {
+        *t_lo = *t_hi = 0;
+        return KCFX_OK;
+    }
+    int32_t v[2] = {0, 0};
+    DeviceGuard g(ref->device);
+    KCFX_HIP(hipMemcpy(&v[0], ref->d_win_tile0 + w_lo, sizeof(int32_t), hipMemcpyDeviceToHost));
+    KCFX_HIP(hipMemcpy(&v[1], ref->d_win_tile0 + w_hi, sizeof(int32_t), hipMemcpyDeviceToHost));
+    *t_lo = v[0];
+    *t_hi = v[1];
+    return KCFX_OK;
+} KCFX_CATCH("kcfx_ref_tile_range")
 
 // another slice's partial results (device buffers on the reference's device, same tile list) into this reference's: hits OR-ed,
 // count sums added; the validity words are the same on every slice

@@ -289,6 +289,12 @@ size_t pooled_device_bytes(int dev);
 // (Always read: KCFX_VERBOSE, KCFX_LOAD_TRACE / KCFX_REF_TRACE / KCFX_CLI_TRACE / KCFX_POOL_TRACE, KCFX_NO_POOL, KCFX_POOL_FRACTION,
 // KCFX_LENIENT_LUT -- they report, or change where memory goes, never what a look-up returns or costs.)
 const char* hook(const char* name);
+// one .kmc_suf read once for the table slices that several devices build at the same time (kcfx_api.cpp: SuffixCache)
+struct SuffixCache;
+SuffixCache* suffix_cache_create(const char* kmc_prefix, int32_t consumers);     // null: the loaders read for themselves
+void suffix_cache_destroy(SuffixCache* c);
+void suffix_cache_stats(const SuffixCache* c, int64_t* reads, int64_t* hits, int64_t* bytes_read);
+int32_t db_open_slice_shared(const char* kmc_prefix, int32_t device, const kcfx_db_opts* opts, int32_t n_slices, int32_t slice, SuffixCache* shared, kcfx_db** out);   // kcfx_db_open_slice with the loaders' shared cache (or null)
 void pool_release(int dev);                  // dev < 0: every device
 double pool_set_fraction(double f);          // the bound on what is kept (share of a device); returns the previous one
 void pool_trim();                            // release what is over the bound now

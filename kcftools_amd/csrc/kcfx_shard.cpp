@@ -153,6 +153,11 @@ std::vector<std::vector<Segment>> plan_segments(int32_t mode, int32_t G, int32_t
     return plan;
 }
 
+// what the slice loaders of the most recent KCFX_SHARD_TABLE call read from the host side: bytes of .kmc_suf, chunks read, chunks that
+// a sibling loader had already read (kcfx_shard_slice_io)
+std::mutex g_slice_io_mu;
+int64_t g_slice_io[3] = {0, 0, 0};
+
 // KCFX_SHARD_TABLE: sample after sample, the sample's table in G slices on the G devices. Each device keeps ONE reference of the
 // whole window list for the call (planned once when several samples follow, text-only for one); per sample a thread per device
 // opens its slice, screens, closes; then the slices' bitmaps meet on the first device and are reduced there.
@@ -202,6 +207,10 @@ int32_t screen_table_sharded(const std::vector<int32_t>& devices, const char* co
     };
     int64_t queries = 0;
     for (int32_t w = 0; w < n_windows; ++w) queries += std::max<int64_t>(0, (int64_t)win_len[w] - kmer_length + 1);
+    {
+        std::lock_guard<std::mutex> lk(g_slice_io_mu);
+        g_slice_io[0] = g_slice_io[1] = g_slice_io[2] = 0;
+    }
     in_parallel([&](int32_t g) {
         Dev& d = dev[(size_t)g];
         const double t = now_s();
@@ -215,6 +224,12 @@ int32_t screen_table_sharded(const std::vector<int32_t>& devices, const char* co
     if (int32_t rc = first_error()) return rc;
     double t_merge = 0;
     for (int32_t s = 0; s < n_samples; ++s) {
+        // the G loaders of this sample walk the same file in the same passes: ONE read of every chunk for all of them (SuffixCache,
+        // kcfx_api.cpp) -- each device then copies it over its own link. Null (no pinned memory to be had): every loader reads for itself.
+        struct CacheHold {
+            kcfx::SuffixCache* c;
+            ~CacheHold() { kcfx::suffix_cache_destroy(c); }
+        } cache{G > 1 ? kcfx::suffix_cache_create(kmc_prefixes[s], G) : nullptr};
         in_parallel([&](int32_t g) {
             Dev& d = dev[(size_t)g];
             kcfx_db_opts opts;
@@ -223,7 +238,7 @@ int32_t screen_table_sharded(const std::vector<int32_t>& devices, const char* co
             opts.reserved = 0;
             kcfx_db* db = nullptr;
             double t = now_s();
-            d.rc = kcfx_db_open_slice(kmc_prefixes[s], devices[(size_t)g], &opts, G, g, &db);
+            d.rc = kcfx::db_open_slice_shared(kmc_prefixes[s], devices[(size_t)g], &opts, G, g, cache.c, &db);
             d.t_open += now_s() - t;
             if (!d.rc) {
                 kcfx_db_info_t info;
@@ -243,6 +258,20 @@ int32_t screen_table_sharded(const std::vector<int32_t>& devices, const char* co
             kcfx_db_close(db);
         });
         if (int32_t rc = first_error()) return rc;
+        if (cache.c && (getenv("KCFX_LOAD_TRACE") || getenv("KCFX_VERBOSE"))) {
+            int64_t reads = 0, hits = 0, bytes = 0;
+            kcfx::suffix_cache_stats(cache.c, &reads, &hits, &bytes);
+            fprintf(stderr, "[kcfx load] %s: %d slice loaders shared one file stream: %lld chunks read (%.2f GB), %lld served from the cache\n", kmc_prefixes[s], G,
+                    (long long)reads, (double)bytes / 1e9, (long long)hits);
+        }
+        {
+            int64_t reads = 0, hits = 0, bytes = 0;
+            kcfx::suffix_cache_stats(cache.c, &reads, &hits, &bytes);
+            std::lock_guard<std::mutex> lk(g_slice_io_mu);
+            g_slice_io[0] += bytes;
+            g_slice_io[1] += reads;
+            g_slice_io[2] += hits;
+        }
         const double t = now_s();
         for (int32_t g = 1; g < G; ++g)
             if (int32_t rc = kcfx_ref_merge_from(dev[0].ref, dev[(size_t)g].ref)) return rc;
@@ -310,6 +339,14 @@ int32_t kcfx_shard_plan(int32_t shard_mode, int32_t n_devices, int32_t n_samples
 } catch (...) { return kcfx::exception_to_status("kcfx_shard_plan"); }
 
 void kcfx_ctx_destroy(kcfx_ctx* ctx) { delete ctx; }
+
+int32_t kcfx_shard_slice_io(int64_t* bytes_read, int64_t* chunks_read, int64_t* chunks_shared) {
+    std::lock_guard<std::mutex> lk(g_slice_io_mu);
+    if (bytes_read) *bytes_read = g_slice_io[0];
+    if (chunks_read) *chunks_read = g_slice_io[1];
+    if (chunks_shared) *chunks_shared = g_slice_io[2];
+    return KCFX_OK;
+}
 
 int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int32_t n_samples, int32_t kmer_length,
                             const uint8_t* text, int64_t text_len, const int64_t* win_begin, const int32_t* win_len,

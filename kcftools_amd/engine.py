@@ -33,7 +33,7 @@ ABI_SYMBOLS = (
     "kcfx_db_open_slice", "kcfx_table_slice_of", "kcfx_screen_ref_partial_async", "kcfx_screen_ref_partial", "kcfx_ref_partial_bytes",
     "kcfx_ref_export_partial_async", "kcfx_ref_merge_partial_async", "kcfx_ref_merge_from", "kcfx_ref_finish_async", "kcfx_ref_finish",
     "kcfx_score", "kcfx_windows",
-    "kcfx_table_plan", "kcfx_table_plan_for", "kcfx_set_cache_fraction", "kcfx_prof_enable", "kcfx_prof_read", "kcfx_ref_plan_async", "kcfx_ref_is_planned", "kcfx_prof_read_plan", "kcfx_last_error", "kcfx_device_count", "kcfx_version",
+    "kcfx_table_plan", "kcfx_table_plan_for", "kcfx_set_cache_fraction", "kcfx_shard_slice_io", "kcfx_ref_import_partial_async", "kcfx_ref_tile_range", "kcfx_prof_enable", "kcfx_prof_read", "kcfx_ref_plan_async", "kcfx_ref_is_planned", "kcfx_prof_read_plan", "kcfx_last_error", "kcfx_device_count", "kcfx_version",
 )
 
 
@@ -130,6 +130,8 @@ def lib() -> C.CDLL:
         L.kcfx_ref_partial_bytes.restype = i64
         L.kcfx_ref_export_partial_async.argtypes = [vp, vp, vp, vp]
         L.kcfx_ref_merge_partial_async.argtypes = [vp, vp, vp, vp]
+        L.kcfx_ref_import_partial_async.argtypes = [vp, vp, vp, vp]
+        L.kcfx_ref_tile_range.argtypes = [vp, i32, i32, C.POINTER(i32), C.POINTER(i32)]
         L.kcfx_ref_merge_from.argtypes = [vp, vp]
         L.kcfx_ref_finish_async.argtypes = [vp, vp, vp]
         L.kcfx_ref_finish.argtypes = [vp, vp]
@@ -146,6 +148,7 @@ def lib() -> C.CDLL:
         L.kcfx_table_plan_for.argtypes = [i64, i32, i32, i64, i64, C.POINTER(i64), C.POINTER(i32)]
         L.kcfx_set_cache_fraction.argtypes = [C.c_double]
         L.kcfx_set_cache_fraction.restype = C.c_double
+        L.kcfx_shard_slice_io.argtypes = [C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
         L.kcfx_db_lookup.argtypes = [vp, vp, i64, vp]
         L.kcfx_db_close.argtypes = [vp]
         L.kcfx_db_close.restype = None
@@ -196,6 +199,14 @@ def table_plan(total_kmers: int, k: int, both_strands: bool = True, free_bytes: 
     n, r = C.c_int64(0), C.c_int32(0)
     _check(lib().kcfx_table_plan_for(int(total_kmers), int(k), int(bool(both_strands)), int(free_bytes), int(expected_queries), C.byref(n), C.byref(r)))
     return n.value, r.value
+
+
+def shard_slice_io() -> tuple[int, int, int]:
+    """kcfx_shard_slice_io: (bytes of .kmc_suf read, chunks read, chunk requests served by a sibling loader's read) of the most recent
+    table-sharded call of this process."""
+    a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    _check(lib().kcfx_shard_slice_io(C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
 
 
 def set_cache_fraction(fraction: float) -> float:
@@ -419,6 +430,16 @@ class Reference:
 
     def merge_partial_async(self, bitmaps_device_ptr: int, sums_device_ptr: int, stream: int = 0) -> None:
         _check(lib().kcfx_ref_merge_partial_async(self._h, C.c_void_p(bitmaps_device_ptr), C.c_void_p(sums_device_ptr), C.c_void_p(stream)))
+
+    def import_partial_async(self, bitmaps_device_ptr: int, sums_device_ptr: int, stream: int = 0) -> None:
+        """device buffers of the export's layout INTO this reference's scratch (a rank that owns a window range starts its merge here)"""
+        _check(lib().kcfx_ref_import_partial_async(self._h, C.c_void_p(bitmaps_device_ptr), C.c_void_p(sums_device_ptr), C.c_void_p(stream)))
+
+    def tile_range(self, w_lo: int, w_hi: int) -> tuple[int, int]:
+        """windows [w_lo, w_hi) of this reference are its tiles [t_lo, t_hi)"""
+        a, b = C.c_int32(0), C.c_int32(0)
+        _check(lib().kcfx_ref_tile_range(self._h, int(w_lo), int(w_hi), C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def finish(self) -> np.ndarray:
         """reduce_windows over what this reference holds now (one slice's results, or the merged ones)"""

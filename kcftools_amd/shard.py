@@ -16,8 +16,11 @@ runs samples in separate processes) -- so there is NO data-path collective. Two 
 
   * table slices    : (on request, round 5) a database too large for one device at a density worth having: its TABLE is cut
                        into one slice per rank by minimizer (kcfx_db_open_slice), every rank screens the whole window list
-                       against its slice, and the tiles' hit bitmaps (512 B per tile) + count sums meet on rank 0 -- the one
-                       data-path exchange of this engine: a gather of the partial results, OR / add, then ONE reduce_windows.
+                       against its slice, and the tiles' hit bitmaps (512 B per tile) + count sums meet -- the one data-path
+                       exchange of this engine -- either on rank 0 (gather_table_partials: a gather of the partial results, OR /
+                       add, then ONE reduce_windows) or, round 6, RANGE BY RANGE (reduce_scatter_table_partials: rank q owns a
+                       window range and receives only that range's tiles from everybody, 1 / W of the bitmaps each -- no rank
+                       carries (W - 1) x the whole; then the ordinary final gather of 40-byte records).
 
 Otherwise the only exchange is the final gather of the 40-byte per-(window, sample) records to rank 0.
 """
@@ -129,3 +132,33 @@ def merge_table_partials(bits, sums, other_bits, other_sums):
     b[:, TILE_WORDS:] |= other_bits.view(-1, 2 * TILE_WORDS)[:, TILE_WORDS:]
     sums += other_sums
     return bits, sums
+
+
+def reduce_scatter_table_partials(bits, sums, tile_cuts, group=None):
+    """The slices' results meet range by range: tile_cuts[q] .. tile_cuts[q + 1] are the tiles of the windows rank q owns
+    (len(tile_cuts) == world + 1; engine.Reference.tile_range of window_range_of_rank). Every rank sends rank q that range of its
+    bitmaps and count sums (W gathers of 1 / W of the data each: the traffic of a reduce-scatter, on backends with and without
+    all_to_all) and merges what it receives for its own range -- hit words OR-ed, count sums added, validity words as they are.
+    Returns (bits, sums) of this rank's tile range, merged; a rank with an empty range gets empty tensors."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    assert len(tile_cuts) == world + 1
+    W2 = 2 * TILE_WORDS
+    mine_b = mine_s = None
+    for q in range(world):
+        lo, hi = int(tile_cuts[q]), int(tile_cuts[q + 1])
+        pb = bits[lo * W2:hi * W2].contiguous()
+        ps = sums[lo:hi].contiguous()
+        gb = [torch.zeros_like(pb) for _ in range(world)] if rank == q else None
+        gs = [torch.zeros_like(ps) for _ in range(world)] if rank == q else None
+        if hi > lo:                                       # (every rank skips an empty range alike)
+            dist.gather(pb, gb, dst=q, group=group)
+            dist.gather(ps, gs, dst=q, group=group)
+        if rank == q:
+            mine_b, mine_s = gb[rank].clone(), gs[rank].clone()
+            for r in range(world):
+                if r != rank and hi > lo:
+                    merge_table_partials(mine_b, mine_s, gb[r], gs[r])
+    return mine_b, mine_s

@@ -189,6 +189,29 @@ def test_table_partitioned_over_devices(oracle, job, devices):
         assert_same(got2[i], engine.KmcDb.open(prefixes[i]).screen(ref, begins, lens, 3), "-c 3")
 
 
+def test_slice_loaders_share_one_file_stream(oracle, job, monkeypatch):
+    """Round 6: the G loaders of a table-sharded sample read the .kmc_suf ONCE between them (a cache of pinned chunks: whoever asks
+    first reads, the siblings copy from the same buffer). With the file streamed once per build pass and chunks of 4 099 records
+    (a few hundred chunks per file) four slices on the one GPU: the same records as the unsharded call, most chunk requests served
+    by a sibling's read, and far fewer bytes read than four loaders of their own would have."""
+    k, ref, prefixes, begins, lens, want = job
+    monkeypatch.setenv("KCFX_LOAD_STREAM_TWICE", "1")          # (the tier of a database that does not fit: the file once per pass)
+    monkeypatch.setenv("KCFX_LOAD_CHUNK_RECORDS", "4099")
+    devices = [0, 0, 0, 0]
+    got, st = engine.screen_sharded(prefixes[:1], k, ref, begins, lens, 1, devices=devices, mode=engine.SHARD_TABLE)
+    assert st.shard_mode_used == engine.SHARD_TABLE
+    assert_same(got[0], want[0], "four slice loaders on one file stream")
+    nbytes, reads, shared = engine.shard_slice_io()
+    suf = os.path.getsize(prefixes[0] + ".kmc_suf")
+    assert reads > 0 and shared > reads, (nbytes, reads, shared)      # most requests found their chunk already read
+    passes = nbytes / suf
+    assert 3.5 <= passes <= 9.0, passes                         # ~4 - 5 passes of ONE stream (count, claim, write, settle [, stash]); 4 loaders alone: 16 - 20
+    # one device: no cache at all
+    got1, _ = engine.screen_sharded(prefixes[:1], k, ref, begins, lens, 1, devices=[0], mode=engine.SHARD_TABLE)
+    assert_same(got1[0], want[0], "one slice")
+    assert engine.shard_slice_io() == (0, 0, 0)
+
+
 def test_table_slices_piece_by_piece(oracle, job, tmp_path):
     """The entry points behind KCFX_SHARD_TABLE one by one: kcfx_db_open_slice (the slices hold every stored k-mer exactly once, up
     to the few with several first-choice cells; a look-up finds a k-mer on the slice that holds it), kcfx_screen_ref_partial on a
@@ -253,6 +276,24 @@ def test_table_slices_piece_by_piece(oracle, job, tmp_path):
             refs[1].merge_partial_async(bufs[0][0].data_ptr(), bufs[0][1].data_ptr(), torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
             assert_same(refs[1].finish(), want[pi], "slices merged from exported buffers")
+            # (d) round 6, range by range: "rank" q owns a window range, takes that range's tiles of every slice's export (what the
+            # W gathers of shard.reduce_scatter_table_partials deliver), imports its own into a reference of JUST those windows,
+            # merges the others and finishes: its windows' records, no buffer of the whole list anywhere
+            st = torch.cuda.current_stream().cuda_stream
+            for q in range(n):
+                lo, hi = shard.window_range_of_rank(lens, k, n, q)
+                t_lo, t_hi = refs[0].tile_range(lo, hi)
+                own = engine.Reference(ref, begins[lo:hi], lens[lo:hi], k, expected_screens=1)
+                assert own.tile_range(0, hi - lo) == (0, t_hi - t_lo)
+                parts = [(b[t_lo * 64:t_hi * 64].contiguous(), c[t_lo:t_hi].contiguous()) for b, c in bufs]
+                own.import_partial_async(parts[q][0].data_ptr(), parts[q][1].data_ptr(), st)
+                for r_ in range(n):
+                    if r_ != q:
+                        own.merge_partial_async(parts[r_][0].data_ptr(), parts[r_][1].data_ptr(), st)
+                torch.cuda.synchronize()
+                if hi > lo:
+                    assert_same(own.finish(), want[pi][lo:hi], f"range {q} of {n} merged range by range")
+                own.close()
         # a slice is not a database: the whole-table entry points say so
         with pytest.raises(engine.KcfxError) as ei:
             refs[0].screen(slices[0], 1)

@@ -164,6 +164,66 @@ def table_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def table_rs_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    valid, hits, per_hits, per_sums = _table_partials(world)
+    n_tiles = valid.shape[0]
+    bits = torch.from_numpy(np.concatenate([valid, per_hits[rank]], axis=1).reshape(-1).copy())
+    sums = torch.from_numpy(per_sums[rank].copy())
+    # uneven ranges, one of them empty when there are three ranks (a rank may own no window)
+    cuts = [0, n_tiles // 3, n_tiles] if world == 2 else [0, n_tiles // 4, n_tiles // 4, n_tiles]
+    mb, mc = shard.reduce_scatter_table_partials(bits, sums, cuts)
+    q.put((rank, cuts, mb.numpy().copy(), mc.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_table_slices_meet_range_by_range(world):
+    """Round 6, the other form of the exchange: rank q owns a range of the tiles (the tiles of a window range) and receives that range
+    from every rank -- 1 / W of the bitmaps each -- instead of rank 0 receiving everything. Every rank ends up with the merged words
+    of its own range: validity as it was, hits OR-ed over the slices, count sums added; the ranges tile the list, one may be empty."""
+    import queue as _queue
+    import time
+    ctx = mp.get_context("spawn")
+    got = {}
+    for attempt in range(2):
+        got = {}
+        q = ctx.Queue()
+        port = free_port()
+        procs = [ctx.Process(target=table_rs_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        deadline = time.time() + 240
+        while len(got) < world and time.time() < deadline:
+            try:
+                r, cuts, mb, mc = q.get(timeout=2)
+                got[r] = (cuts, mb, mc)
+            except _queue.Empty:
+                if any(p.exitcode not in (None, 0) for p in procs):
+                    break
+        for p in procs:
+            p.join(timeout=90 if len(got) == world else 1)
+            if p.is_alive():
+                p.kill()
+                p.join()
+        if len(got) == world:
+            assert all(p.exitcode == 0 for p in procs)
+            break
+    assert len(got) == world, "multi-rank run did not produce a result"
+    valid, hits, per_hits, per_sums = _table_partials(world)
+    W = shard.TILE_WORDS
+    for r in range(world):
+        cuts, mb, mc = got[r]
+        lo, hi = cuts[r], cuts[r + 1]
+        mb = mb.reshape(-1, 2 * W)
+        assert mb.shape[0] == hi - lo == len(mc)
+        assert np.array_equal(mb[:, :W], valid[lo:hi]) and np.array_equal(mb[:, W:], hits[lo:hi])
+        assert np.array_equal(mc, np.sum(per_sums, axis=0)[lo:hi])
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_table_slices_meet_on_rank_zero(world):
     """bench.py --shard table / a job with one process per GPU: every rank screens the whole window list against ITS slice of the
