@@ -372,7 +372,8 @@ int32_t kcfx_ref_export_partial_async(kcfx_ref* ref, void* bitmaps_device, void*
  * [w_lo, w_hi) of a reference are its tiles [*t_lo, *t_hi): 64 bitmap words and one count sum per tile, in tile order) this is what a
  * job needs to let the slices' results meet RANGE BY RANGE instead of on one root: rank q owns a window range, receives that range's
  * tiles from every rank (1 / G of the bitmaps each), imports its own into a reference of just those windows, merges the others and
- * finishes -- no device carries (G - 1) x the bitmaps of the whole window list (kcftools_amd/shard.py: reduce_scatter_table_partials). */
+ * finishes -- no device carries (G - 1) x the bitmaps of the whole window list (kcftools_amd/shard.py: reduce_scatter_table_partials).
+ * Both references must be of the same form (kcfx_ref_opts.expected_screens): a text-only one cuts its tiles at 2 001 k-mers, a planned one at 2 048. */
 int32_t kcfx_ref_import_partial_async(kcfx_ref* ref, const void* bitmaps_device, const void* sums_device, void* hip_stream);
 int32_t kcfx_ref_tile_range(const kcfx_ref* ref, int32_t w_lo, int32_t w_hi, int32_t* t_lo, int32_t* t_hi);
 /* another slice's partial results -- device buffers on the reference's device, same text and windows -- into this reference's:

@@ -714,25 +714,36 @@ struct SuffixCache {
     struct Buf {
         uint8_t* p = nullptr;
         int64_t chunk = -1;
-        int refs = 0;
+        int refs = 0;                    // loaders copying from it now
+        int taken = 0;                   // loaders that have had it since it was read
         bool ready = false, loading = false;
         uint64_t stamp = 0;
     };
     int fd = -1;
     size_t cap = 0;                      // bytes per buffer
+    int consumers = 1;                   // loaders still at work (leave())
     std::vector<Buf> bufs;
     std::mutex mu;
     std::condition_variable cv;
     uint64_t clock = 0;
     int64_t reads = 0, hits = 0, bytes_read = 0;
-    // the chunk's bytes in pinned memory, or null on a read error; *slot names the buffer for release()
+    // the chunk's bytes in pinned memory, or null on a read error; *slot names the buffer for release().
+    // A buffer that not every loader has had yet is given up only after a wait: the loaders walk the file in step (a leader waits
+    // for the others at most a few chunks ahead) instead of reading the same chunks one after the other -- but nobody waits for
+    // a loader that never comes (a slice that makes a pass its siblings do not: it reads for itself, after 50 ms).
     const uint8_t* acquire(int64_t chunk, int64_t offset, int64_t bytes, int* slot) {
         std::unique_lock<std::mutex> lk(mu);
+        int patience = 1;
         for (;;) {
-            int mine = -1, spare = -1;
+            int mine = -1, spare = -1, busy_spare = -1;
             for (int i = 0; i < (int)bufs.size(); ++i) {
-                if (bufs[i].chunk == chunk && (bufs[i].ready || bufs[i].loading)) mine = i;
-                else if (bufs[i].refs == 0 && !bufs[i].loading && (spare < 0 || bufs[i].stamp < bufs[spare].stamp)) spare = i;
+                Buf& b = bufs[i];
+                if (b.chunk == chunk && (b.ready || b.loading)) mine = i;
+                else if (b.refs == 0 && !b.loading) {
+                    if (b.chunk < 0 || b.taken >= consumers) {
+                        if (spare < 0 || b.stamp < bufs[spare].stamp) spare = i;
+                    } else if (busy_spare < 0 || b.stamp < bufs[busy_spare].stamp) busy_spare = i;
+                }
             }
             if (mine >= 0) {
                 if (bufs[mine].loading) {
@@ -740,11 +751,17 @@ struct SuffixCache {
                     continue;
                 }
                 bufs[mine].refs++;
+                bufs[mine].taken++;
                 bufs[mine].stamp = ++clock;
                 ++hits;
                 *slot = mine;
                 return bufs[mine].p;
             }
+            if (spare < 0 && busy_spare >= 0 && patience > 0) {      // (somebody has not had the oldest chunk yet: give them a moment)
+                if (cv.wait_for(lk, std::chrono::milliseconds(50)) == std::cv_status::timeout) --patience;
+                continue;
+            }
+            if (spare < 0) spare = busy_spare;
             if (spare < 0) {                               // (every buffer is held: 2 per loader at most, the cache has 2 G + 2)
                 cv.wait(lk);
                 continue;
@@ -753,6 +770,7 @@ struct SuffixCache {
             b.chunk = chunk;
             b.ready = false;
             b.loading = true;
+            b.taken = 0;
             lk.unlock();
             const bool ok = (size_t)bytes <= cap && parallel_pread(fd, b.p, bytes, offset);
             lk.lock();
@@ -764,6 +782,7 @@ struct SuffixCache {
             }
             b.ready = true;
             b.refs = 1;
+            b.taken = 1;
             b.stamp = ++clock;
             ++reads;
             bytes_read += bytes;
@@ -775,6 +794,11 @@ struct SuffixCache {
     void release(int slot) {
         std::lock_guard<std::mutex> lk(mu);
         if (slot >= 0 && slot < (int)bufs.size() && bufs[slot].refs > 0) --bufs[slot].refs;
+        cv.notify_all();
+    }
+    void leave() {                       // a loader is done (or has failed): the others stop counting on it
+        std::lock_guard<std::mutex> lk(mu);
+        if (consumers > 1) --consumers;
         cv.notify_all();
     }
 };
@@ -796,7 +820,8 @@ SuffixCache* suffix_cache_create(const char* kmc_prefix, int32_t consumers) {
     if (c->fd < 0) return nullptr;
     const int64_t ch = load_chunk_records();
     c->cap = (size_t)std::max<int64_t>(16, std::min<int64_t>(ch, std::max<int64_t>(h.total, 1)) * h.record_size);
-    c->bufs.resize((size_t)(2 * std::max(1, consumers) + 2));
+    c->consumers = std::max(1, consumers);
+    c->bufs.resize((size_t)(2 * std::max(1, consumers) + 4));
     for (auto& b : c->bufs)
         if (hipHostMalloc(reinterpret_cast<void**>(&b.p), c->cap, hipHostMallocPortable) != hipSuccess) {
             (void)hipGetLastError();
@@ -1331,6 +1356,10 @@ int32_t kcfx_db_open_slice(const char* kmc_prefix, int32_t device, const kcfx_db
 }  // extern "C"
 
 int32_t kcfx::db_open_slice_shared(const char* kmc_prefix, int32_t device, const kcfx_db_opts* opts, int32_t n_slices, int32_t slice, SuffixCache* shared, kcfx_db** out) try {
+    struct Leave {                              // (the siblings' shared file stream stops counting on this loader when it is done, or has failed)
+        SuffixCache* c;
+        ~Leave() { if (c) c->leave(); }
+    } leave{shared};
     if (!kmc_prefix || !out) return fail(KCFX_ERR_ARG, "null argument");
     if (opts && opts->expected_queries < 0) return fail(KCFX_ERR_ARG, "kcfx_db_opts: negative expected_queries");
     if (n_slices < 1 || n_slices > KCFX_SLICES_MAX || slice < 0 || slice >= n_slices) return fail(KCFX_ERR_ARG, "kcfx_db_open_slice: slice out of range (1 .. 64 slices)");
