@@ -84,18 +84,42 @@ hipError_t stream_acquire(int device, hipStream_t* out) {
     }
     return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
 }
-// databases only use their stream while loading and in kcfx_db_lookup: one shared stream per device, for the process
-std::vector<std::pair<int, hipStream_t>> g_db_streams;
-hipError_t db_stream(int device, hipStream_t* out) {
+// databases only use their stream while loading and in kcfx_db_lookup: a few shared streams per device, for the process. A load takes
+// one that no other load is running on (round 6: with ONE stream per device two loaders serialised completely -- every wait of one
+// stood behind the other's queued work -- which is what round 4 measured as "two loads do not overlap"); a second stream is created
+// only when two loads really run at the same time, and so is each stream's companion for the uploads (the copier of load_suffix_file).
+struct DbStream {
+    int device;
+    hipStream_t st, copier;
+    bool loading;
+};
+std::vector<DbStream> g_db_streams;
+hipError_t db_stream(int device, hipStream_t* out, hipStream_t* copier_out, bool for_a_load) {
     std::lock_guard<std::mutex> lk(g_stream_mu);
     for (auto& e : g_db_streams)
-        if (e.first == device) {
-            *out = e.second;
+        if (e.device == device && !(for_a_load && e.loading)) {
+            *out = e.st;
+            if (copier_out) *copier_out = e.copier;
+            if (for_a_load) e.loading = true;
             return hipSuccess;
         }
-    const hipError_t e = hipStreamCreateWithFlags(out, hipStreamNonBlocking);
-    if (e == hipSuccess) g_db_streams.emplace_back(device, *out);
+    hipStream_t copier = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&copier, hipStreamNonBlocking);
+    if (e == hipSuccess) g_db_streams.push_back(DbStream{device, *out, copier, for_a_load});
+    if (copier_out) *copier_out = copier;
     return e;
+}
+void db_stream_load_done(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    for (auto& e : g_db_streams)
+        if (e.st == st) e.loading = false;
+}
+hipStream_t db_stream_copier(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    for (auto& e : g_db_streams)
+        if (e.st == st) return e.copier;
+    return nullptr;
 }
 void stream_release(int device, hipStream_t st) {
     if (!st) return;
@@ -893,8 +917,7 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
                 shared->release(held[i]);
                 held[i] = -1;
             }
-        if (copier) (void)hipStreamDestroy(copier);
-        copier = nullptr;
+        copier = nullptr;                                     // (the stream pair stays with the process: db_stream)
         if (lost.keys) (void)dev_free_idle(lost.keys);
         if (lost.counts) (void)dev_free_idle(lost.counts);
         if (lost.n) (void)dev_free_idle(lost.n);
@@ -944,7 +967,7 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
         LOAD_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
         LOAD_HIP(hipEventCreateWithFlags(&decoded[i], hipEventDisableTiming));
     }
-    LOAD_HIP(hipStreamCreateWithFlags(&copier, hipStreamNonBlocking));
+    copier = db_stream_copier(db->stream);                  // (created with the handle's stream; null only if that failed: uploads on db->stream then)
     LOAD_HIP(dev_alloc(&d_lut, (size_t)std::max<int64_t>(h.lut_entries, 1) * 8));
     LOAD_HIP(dev_alloc(&d_keys, (size_t)n_keys_buf * 8));
     LOAD_HIP(dev_alloc(&d_counts, (size_t)n_keys_buf * 4));
@@ -1134,7 +1157,16 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     if (!two_phase) {
         if ((rc = stream_file(1, false))) return rc;
     } else {
-        if ((rc = stream_file(0, resident))) return rc;
+        {
+            // Loaders of one process take turns on the file's way into the device (round 6): page cache -> pinned memory is a memcpy
+            // that the box's cores run at ~48 GB/s in all, so two loads that stream at the same time each take twice as long -- and
+            // stay in step for good, streaming together and then building together. With the turn, B streams while A's build passes
+            // run on the GPU (no host work), and the two alternate: profiles/r06_notes.md section 7.
+            static std::mutex file_turn;
+            std::unique_lock<std::mutex> turn(file_turn, std::defer_lock);
+            if (!shared) turn.lock();                       // (slice loaders share one stream of the file instead: SuffixCache)
+            if ((rc = stream_file(0, resident))) return rc;
+        }
         tr.mark("file -> decode -> first pass (host)");
         if (cells) {
             if ((rc = table_ready(db))) {               // (the lines are first touched by the bids)
@@ -1385,8 +1417,12 @@ int32_t kcfx::db_open_slice_shared(const char* kmc_prefix, int32_t device, const
     db->slice = slice;
     db->info.table_slices = n_slices;
     db->info.table_slice = slice;
-    hipError_t e = db_stream(device, &db->stream);
+    hipError_t e = db_stream(device, &db->stream, nullptr, true);
     if (e != hipSuccess) return hip_fail(e, "hipStreamCreate");
+    struct LoadDone {                           // (the stream is another load's to take again when this one is over, however it ends)
+        hipStream_t st;
+        ~LoadDone() { db_stream_load_done(st); }
+    } load_done{db->stream};
     tr.mark("device + stream");
     // a slice holds 1 / n of the k-mers (a hash of the minimizer decides: + 2 % and a few thousand for the unevenness) -- the table is
     // sized for that many, every pass still walks the whole file
@@ -1498,8 +1534,12 @@ int32_t kcfx_db_build(const uint64_t* kmers, const uint32_t* counts, int64_t n, 
     uint64_t*& d_keys = scratch.keys;
     uint32_t*& d_counts = scratch.counts;
     int32_t rc = KCFX_OK;
-    hipError_t e = db_stream(device, &db->stream);
+    hipError_t e = db_stream(device, &db->stream, nullptr, true);
     if (e != hipSuccess) return hip_fail(e, "hipStreamCreate");
+    struct LoadDone {                           // (the stream is another load's to take again when this one is over, however it ends)
+        hipStream_t st;
+        ~LoadDone() { db_stream_load_done(st); }
+    } load_done{db->stream};
     if (n > 0) {
         // the stored counter is counter_size bytes wide (KMC.java:395-401)
         std::vector<uint32_t> masked;
@@ -2128,8 +2168,12 @@ int32_t kcfx_cohort_open(const char* const* kmc_prefixes, int32_t n_samples, int
     db->info.device = device;
     db->expected_queries = opts ? opts->expected_queries : 0;
     db->line_footprint = LINE_BYTES + 16 * COHORT_STRIDE;           // cells + 8 bytes of counters per cell: the size policy budgets both
-    hipError_t e = db_stream(device, &db->stream);
+    hipError_t e = db_stream(device, &db->stream, nullptr, true);
     if (e != hipSuccess) return hip_fail(e, "hipStreamCreate");
+    struct LoadDone {                           // (the stream is another load's to take again when this one is over, however it ends)
+        hipStream_t st;
+        ~LoadDone() { db_stream_load_done(st); }
+    } load_done{db->stream};
     const size_t nn = (size_t)std::max<int64_t>(N, 1);
     if ((e = dev_alloc(&hold.d_keys, nn * 8)) != hipSuccess || (e = dev_alloc(&hold.d_counts, nn * 4)) != hipSuccess)
         return hip_fail(e, "kcfx_cohort_open: the decoded records of all samples (12 bytes each) must fit the device");

@@ -50,6 +50,18 @@ def test_no_gpu_means_loud_failure_not_fallback():
     assert used == engine.SHARD_GRID and len(plan) >= 4
 
 
+def test_cache_fraction_and_table_plan_are_host_only():
+    """kcfx_set_cache_fraction (the bound on the device memory the library keeps of what it has released: half of the device unless
+    the host says otherwise) and kcfx_table_plan_for (the size policy as arithmetic) touch no GPU."""
+    prev = engine.set_cache_fraction(0.7)
+    assert prev == pytest.approx(float(os.environ.get("KCFX_POOL_FRACTION", 0.5)))
+    assert engine.set_cache_fraction(2.0) == pytest.approx(0.7)          # out of range: unchanged
+    assert engine.set_cache_fraction(prev) == pytest.approx(0.7)
+    lines, regions = engine.table_plan(150_000_000, 31, True, 200 << 30, expected_queries=30_000_000)
+    assert (lines, regions) == (1 << 25, 1)
+    assert engine.shard_slice_io() == (0, 0, 0)
+
+
 def test_db_header_is_host_only(tmp_path):
     """kcfx_db_header reads the KMC header fields (KMC.java:124-139) without a GPU."""
     from kcftools_amd import synth

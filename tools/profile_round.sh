@@ -7,8 +7,8 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 # the same command as the bench line above, minus the CPU legs; enough launches that the cold first ones do not move the average
-P="python3 bench.py --steps 300 --warmup 5 --cpu-baseline-seconds 0 --no-end-to-end --no-realistic --no-cache-state --spin-ms 0"
-Q="python3 bench.py --steps 40 --warmup 3 --cpu-baseline-seconds 0 --no-end-to-end --no-realistic --no-cache-state --spin-ms 0"      # counter passes (slower per launch)
+P="python3 bench.py --steps 300 --warmup 5 --cpu-baseline-seconds 0 --no-end-to-end --no-realistic --no-cache-state --no-resident --spin-ms 0"
+Q="python3 bench.py --steps 40 --warmup 3 --cpu-baseline-seconds 0 --no-end-to-end --no-realistic --no-cache-state --no-resident --spin-ms 0"      # counter passes (slower per launch)
 # per-kernel time (no counters)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $P > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 # HBM traffic: separate --pmc passes (TCC has 4 slots; FETCH_SIZE takes 3, WRITE_SIZE 2)
