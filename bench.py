@@ -906,6 +906,10 @@ def main():
             for d_ in dbs:
                 d_.close()
             ref.close()
+            if "ref_o" in locals():
+                ref_o.close()
+            if cohort is not None:
+                cohort.close()
             engine.release_cached()                  # everything this process held goes back to the driver NOW (tables, pooled blocks)
             runs2, _ = end_to_end_runs(cli, fa, prefix, args.window, args.min_count, local_rank, 2)
             e2e["after_churn"] = {"seconds_wall_all_runs": [r_["seconds_wall"] for r_ in runs2], "runs": runs2,
