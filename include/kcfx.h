@@ -111,9 +111,9 @@ int32_t kcfx_db_open(const char* kmc_prefix, int32_t device, kcfx_db** out);
  *                     reference runs ONE pass per database: GetVariants.java:129-159); 0 = unknown. Sizes the table: memory (and
  *                     the time the driver takes to hand it out on a device other processes have used: 28 - 42 GB/s) against the
  *                     speed of a pass. The size minimises  bytes / 35 GB/s + look-ups x seconds per look-up at that density  over
- *                     the sizes from ~0.3 k-mers per cell (150 M k-mers: 2^25 lines, 4.4 GB, 0.092 ms per pass of a 30 Mb reference)
- *                     to ~0.075 per cell (2^27 lines, 17 GB, 0.080 ms): a one-pass job gets the first, a handle that will serve
- *                     more than ~4 x 10^11 look-ups -- or an unknown number: 0 -- the second (profiles/r06_notes.md section 1; rounds
+ *                     the sizes from ~0.3 k-mers per cell (150 M k-mers: 2^25 lines, 4.4 GB, 0.081 ms per pass of a 30 Mb reference)
+ *                     to ~0.075 per cell (2^27 lines, 17 GB, 0.075 ms): a one-pass job gets the first, a handle that will serve
+ *                     more than ~10^12 look-ups -- or an unknown number: 0 -- the second (profiles/r06_notes.md section 1; rounds
  *                     4 - 5 gave every handle the sparse table, and a one-pass job on a busy device paid 0.5 - 2.5 s for its 13 GB).
  *                     A handle that serves fewer than 10^10 look-ups also builds with the cheaper crowding counters (no 4 GiB scratch).
  *   no_fallback       1: a cell table that does not fit the device fails with KCFX_ERR_DEVICE instead of being rebuilt as

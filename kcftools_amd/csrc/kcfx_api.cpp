@@ -309,11 +309,12 @@ bool cells_eligible(const kcfx_db* db, int32_t counter_size) {
 
 // 2^lbits lines of 16 cells: memory (and the time the driver takes to hand it out) against the speed of a screening pass.
 // A denser table sends more k-mers to second / third lines and the stash, and every such look-up is a random request of its own
-// (profiles/r06_density.csv, bench workload, 150 M k-mers, screening kernel on a planned reference, same box):
-//     2^27 lines  0.070 per cell  17.2 GB   5.6 % outside their first-choice cell  0.03 % in the stash  0.0797 ms per pass
-//     2^26        0.140            8.6 GB   8.7 %                                   0.18 %               0.0833 ms
-//     2^25        0.280            4.4 GB  13.6 %                                   1.08 %               0.0921 ms
-//     2^24        0.559            3.2 GB  18.9 %                                   5.97 % (1 GiB stash) 0.1142 ms
+// (profiles/r06_density.csv, bench workload, 150 M k-mers, screening kernel on a planned reference, same box, the round's final code;
+// the round-5 code on the same workload: 0.0797 / 0.0833 / 0.0921 / 0.1142 ms):
+//     2^27 lines  0.070 per cell  17.2 GB   5.6 % outside their first-choice cell  0.03 % in the stash  0.0750 ms per pass
+//     2^26        0.140            8.6 GB   8.7 %                                   0.19 %               0.0773 ms
+//     2^25        0.280            4.4 GB  13.6 %                                   1.09 %               0.0810 ms
+//     2^24        0.559            3.2 GB  18.9 %                                   6.00 % (1 GiB stash) 0.0973 ms
 // What the memory costs is not the clearing (a few ms of hipMemset) but the ALLOCATION on a device that other processes have used:
 // the driver hands out memory that a finished process has just given back only after clearing it, at 28 - 42 GB/s, and while it
 // does so the uploads of the loading pass stand still (profiles/r06_notes.md section 1: the one-sample job end to end, 2^27 lines:
@@ -323,7 +324,7 @@ bool cells_eligible(const kcfx_db* db, int32_t counter_size) {
 // So the size follows the look-ups the handle will serve (kcfx_db_opts.expected_queries = reference k-mers x passes):
 //     cost(L) = bytes(L) / ALLOC_BYTES_PER_S + expected_queries x seconds_per_query(k-mers per cell at L)
 // minimised over the sizes from "at most ~0.3 per cell" (the density the large databases get as well: cells_regions) to ~0.075 per
-// cell. One pass of a 30 Mb reference: 2^25 lines; the sparse table pays for its 13 GB after ~4 x 10^11 look-ups (a resident engine
+// cell. One pass of a 30 Mb reference: 2^25 lines; the sparse table pays for its 13 GB after ~10^12 look-ups (a resident engine
 // that screens thousands of references, a cohort of hundreds of samples' worth of windows). expected_queries = 0 (unknown: a
 // handle somebody keeps) gets the sparse table, as kcfx_db_open always did. KCFX_TABLE_LBITS overrides.
 constexpr double QUERIES_FOR_SPARSE = 1e10;             // (pop_alloc: below this the build takes the cheaper crowding counters)
@@ -331,7 +332,7 @@ constexpr double ALLOC_BYTES_PER_S = 35e9;              // what a used device ha
 constexpr double DENSITY_DENSE = 0.30, DENSITY_SPARSE = 0.075;
 // seconds per look-up at d k-mers per cell: the table above, linear in log2(d) between its rows (below 0.07 nothing more to gain)
 double seconds_per_query(double d) {
-    static const double dd[4] = {0.070, 0.140, 0.280, 0.559}, tt[4] = {0.0797e-3 / 30.0e6, 0.0833e-3 / 30.0e6, 0.0921e-3 / 30.0e6, 0.1142e-3 / 30.0e6};
+    static const double dd[4] = {0.070, 0.140, 0.280, 0.559}, tt[4] = {0.0750e-3 / 30.0e6, 0.0773e-3 / 30.0e6, 0.0810e-3 / 30.0e6, 0.0973e-3 / 30.0e6};
     if (d <= dd[0]) return tt[0];
     for (int i = 1; i < 4; ++i)
         if (d <= dd[i]) return tt[i - 1] + (tt[i] - tt[i - 1]) * std::log2(d / dd[i - 1]);

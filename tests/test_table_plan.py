@@ -17,7 +17,7 @@ def test_the_sizes_the_profiles_quote():
     # the bench sample, a handle somebody keeps (expected_queries = 0): ~0.075 per cell in a power of two, one region
     assert engine.table_plan(150_079_223, 31, True, FREE) == (1 << 27, 1)
     # ... opened for ONE pass of a 30 Mb reference (the command-line driver, kcfx_screen_sharded): the first size at or under 0.3 per
-    # cell -- 4.4 GB instead of 17 -- and so for a hundred passes; the sparse table pays for its allocation past ~4e11 look-ups
+    # cell -- 4.4 GB instead of 17 -- and so for a hundred passes; the sparser tables pay for their allocation past ~1e12 look-ups
     assert engine.table_plan(150_079_223, 31, True, FREE, expected_queries=30_010_326) == (1 << 25, 1)
     assert engine.table_plan(150_079_223, 31, True, FREE, expected_queries=100 * 30_010_326) == (1 << 25, 1)
     assert engine.table_plan(150_079_223, 31, True, FREE, expected_queries=10**12)[0] in (1 << 26, 1 << 27)
