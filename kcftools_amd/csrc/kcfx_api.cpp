@@ -671,16 +671,20 @@ int32_t table_finish(kcfx_db* db) {
     return KCFX_OK;
 }
 
-void db_free(kcfx_db* db) {
+// idle: the caller has waited for every launch that read the table (kcfx_screen_sharded's worker: its screens are synchronous) --
+// no device-wide synchronisation, which would wait for whatever the NEXT databases' loaders have in flight on the device and kept
+// the worker's "in use" slot taken for the length of their loads: the reason two loaders never overlapped (profiles/r06_notes.md 7)
+void db_free(kcfx_db* db, bool idle = false) {
     if (!db) return;
     db->alloc_go = true;
     if (db->alloc_thread.joinable()) db->alloc_thread.join();
     DeviceGuard g(db->device);
     if (db->stream) (void)hipStreamSynchronize(db->stream);   // shared per device (db_stream), never destroyed
-    if (db->d_lines) (void)dev_free(db->d_lines);
-    if (db->d_stash) (void)dev_free(db->d_stash);
-    if (db->d_stats) (void)dev_free(db->d_stats);
-    if (db->d_pop) (void)dev_free(db->d_pop);
+    auto drop = [&](void* p) { if (p) (void)(idle ? dev_free_idle(p) : dev_free(p)); };
+    drop(db->d_lines);
+    drop(db->d_stash);
+    drop(db->d_stats);
+    drop(db->d_pop);
     delete db;
 }
 
@@ -1088,6 +1092,10 @@ int32_t load_suffix_file(kcfx_db* db, const std::string& path, const KmcHeader& 
     // file is streamed again
     auto later_pass = [&](int phase) -> int32_t {
         if (resident) {
+            // (round 6 tried launches of 8 M records instead of one per pass, so that another load's small per-chunk kernels would not
+            // wait at the boundary of a 5 - 7 ms kernel: two loads on two streams then overlapped a little -- 128 - 166 ms for a pair
+            // against 167 alone -- and a single load got no faster; the timeline says why two loaders gain so little: a load keeps
+            // the copy engine busy for 43 ms and the CUs for 45 ms of its ~75, tools/load_overlap_probe.py, profiles/r06_notes.md 7)
             for (int64_t first = 0; first < h.total; first += (1ll << 30)) {
                 const int64_t n = std::min<int64_t>(1ll << 30, h.total - first);
                 LOAD_HIP(apply(phase, d_keys + first, d_counts + first, n));
@@ -1631,6 +1639,11 @@ int32_t kcfx_db_lookup(kcfx_db* db, const uint64_t* kmers, int64_t n, int32_t* c
 } KCFX_CATCH("kcfx_db_lookup")
 
 void kcfx_db_close(kcfx_db* db) { db_free(db); }
+
+}  // extern "C"
+// kcfx_db_close for a caller that has already waited for every launch that used the table (no device-wide wait: see db_free)
+void kcfx::db_close_idle(kcfx_db* db) { db_free(db, true); }
+extern "C" {
 
 int32_t kcfx_release_cached(int32_t device) try {
     kcfx::pool_release(device);

@@ -294,6 +294,7 @@ struct SuffixCache;
 SuffixCache* suffix_cache_create(const char* kmc_prefix, int32_t consumers);     // null: the loaders read for themselves
 void suffix_cache_destroy(SuffixCache* c);
 void suffix_cache_stats(const SuffixCache* c, int64_t* reads, int64_t* hits, int64_t* bytes_read);
+void db_close_idle(kcfx_db* db);     // kcfx_db_close without the device-wide wait: every launch that read the table has been waited for
 int32_t db_open_slice_shared(const char* kmc_prefix, int32_t device, const kcfx_db_opts* opts, int32_t n_slices, int32_t slice, SuffixCache* shared, kcfx_db** out);   // kcfx_db_open_slice with the loaders' shared cache (or null)
 void pool_release(int dev);                  // dev < 0: every device
 double pool_set_fraction(double f);          // the bound on what is kept (share of a device); returns the previous one

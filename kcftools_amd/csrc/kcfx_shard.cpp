@@ -671,13 +671,13 @@ int32_t kcfx_screen_sharded(kcfx_ctx* ctx, const char* const* kmc_prefixes, int3
                     wk.t_open += now_s() - t2;
                     wk.t_wait += now_s() - t2;
                     screen_one(db, sg.sample + j);
-                    kcfx_db_close(db);
+                    kcfx::db_close_idle(db);
                 }
                 wk.t_screen += now_s() - t1;
             } else {
                 screen_one(ld.db, sg.sample);
                 wk.t_screen += now_s() - t1;
-                kcfx_db_close(ld.db);
+                kcfx::db_close_idle(ld.db);               // (kcfx_screen_ref has returned: nothing in flight reads this table)
             }
             {
                 std::lock_guard<std::mutex> lk(mu);
