@@ -603,10 +603,15 @@ def test_wheat_scale_genomic_database(oracle, monkeypatch, size):
             ms_first = None
             if again:                       # ... and once more in this process: the table's memory is kept between the two (kcfx_pool.cpp)
                 ms_first = pass_ms(db)
+                # (a job that opens one large database after the other says so: since round 6 the library keeps at most half of the
+                # device of what it has released unless asked -- a 206 GB table that goes back to the driver makes the next open wait
+                # for the driver's clearing: 12.7 s instead of 7)
+                prev_fraction = engine.set_cache_fraction(0.9)
                 db.close()
                 t1 = time.time()
                 db = engine.KmcDb.open(prefix, no_fallback=True)
                 t_again = time.time() - t1
+                engine.set_cache_fraction(prev_fraction)
             if lbits:
                 monkeypatch.delenv("KCFX_TABLE_LBITS")
             info = db.info
