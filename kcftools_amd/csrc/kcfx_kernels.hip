@@ -1319,6 +1319,7 @@ static_assert(CELLS_WAVES >= 1 && CELLS_WAVES <= WAVES && CELLS_WORDS_PER_WAVE <
 template <int WPW = CELLS_WORDS_PER_WAVE>
 struct K31CQueueT {
     uint32_t id[K31_QUEUE];                                 // (word of the wave << 6) | lane
+    uint32_t id2[128];                                      // the k-mers their second line sent on (k31c_second_round): third line + stash, once per tile
     unsigned long long hit[WPW];                            // hit ballots of the wave's words
     unsigned long long vw[WPW];                             // their validity ballots (written out with the hits)
 };
@@ -1798,6 +1799,97 @@ __device__ __forceinline__ int k31c_deferred_round(const TableView& tv, const Ld
     return rest;
 }
 
+// Round 6: the same look-ups in two stages. A wave that walks a queued batch through second line -> third line -> stash waits
+// for three to five dependent loads in a row with nothing else of its own in flight, and with one wave per tile (the text-only
+// form) that chain is a fifth of the wave's life at 0.28 k-mers per cell: experiment builds that stop after the second line run
+// the one-pass kernel in 0.080 ms instead of 0.0875 - 0.090, although third lines and stash are 5 % of the requests
+// (profiles/r06_notes.md section 9). So a batch only takes its SECOND-LINE step here; the lanes that are sent on (a fifth of them)
+// are written to a second queue, and that queue is walked ONCE per tile (k31c_rest_round): one third-line load for all of them,
+// then the stash for those still sent on, two slots per lane at once. Same cells, same order per k-mer, same results.
+// Returns the new qn; qn2 = entries in ids2 (<= 128: the caller empties it before a batch of 64 could overflow it).
+template <int K, bool BOTH, class Lds, class Found>
+__device__ __forceinline__ int k31c_second_round(const TableView& tv, const Lds& sh, uint32_t* ids, uint32_t* ids2, int& qn2, int lane, int qn, int pos0, Found&& found) {
+    const int nb = min(qn, 64), rest = qn - nb;
+    const uint32_t id = ids[lane];
+    const uint32_t i2 = ids[64 + lane];
+    wave_lds_fence();
+    if (lane < rest) ids[lane] = i2;                        // the entries behind the batch move to the front
+    bool on = false;
+    if (lane < nb) {
+        uint64_t key;
+        const CellProbe p = k31_probe_at<K, BOTH>(sh, pos0 + (int)(id & 0xFFFFu), id >> QUEUE_ANCHOR_SHIFT, tv.lbits, tv.ext, key);
+        const CellProbe q2 = cell_second_line(p, tv.lbits);
+        const size_t cell = (size_t)cell_line_index(q2.line, q2.r, tv.lbits, tv.regions) * 16 + (q2.sh >> 1);
+        const uint2 e = reinterpret_cast<const uint2*>(tv.lines)[cell];
+        const uint32_t rmask = cell_rmask(tv.lbits, BOTH);
+        const uint32_t nspare = cell_spare_bits(tv.lbits, BOTH);
+        const bool hit2 = (((e.x ^ q2.w) <= CELL_FLAG_MASK) & (((e.y ^ q2.r) & rmask) == 0) & ((e.y >> 16) != 0u)) != 0;
+        if (hit2) found(id, e.y >> 16, (uint32_t)cell, false);
+        const uint32_t bit = nspare == 0 ? 1u : (e.y >> cell_filter_pos(q2.w, e.x, tv.lbits, BOTH)) & 1u;
+        on = !hit2 && (e.x & CELL_FLAG_STASH & bit) != 0u;
+    }
+    const uint64_t ON = wave_ballot(on);
+    if (ON) {
+        const int at = qn2 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ON >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ON, 0u));
+        if (on) ids2[at] = id;
+        qn2 += __popcll(ON);
+    }
+    wave_lds_fence();
+    return rest;
+}
+// the second queue, once per tile (or when a batch could overflow it): third line, then the stash
+template <int K, bool BOTH, class Lds, class Found>
+__device__ __forceinline__ void k31c_rest_round(const TableView& tv, const Lds& sh, const uint32_t* ids2, int qn2, int lane, int pos0, Found&& found) {
+    if (lane < qn2) {
+        const uint32_t id = ids2[lane];
+        uint64_t key;
+        const CellProbe p = k31_probe_at<K, BOTH>(sh, pos0 + (int)(id & 0xFFFFu), id >> QUEUE_ANCHOR_SHIFT, tv.lbits, tv.ext, key);
+        const uint32_t rmask = cell_rmask(tv.lbits, BOTH);
+        const uint32_t nspare = cell_spare_bits(tv.lbits, BOTH);
+        bool on = true;
+        if (cell_has_third(tv.lbits, BOTH)) {               // (wave-uniform)
+            const CellProbe q3 = cell_third_line(p, tv.lbits, BOTH, cell_nw(K));
+            const size_t cell3 = (size_t)cell_line_index(q3.line, q3.r, tv.lbits, tv.regions) * 16 + (q3.sh >> 1);
+            const uint2 e3 = reinterpret_cast<const uint2*>(tv.lines)[cell3];
+            const bool hit3 = (((e3.x ^ q3.w) <= CELL_FLAG_MASK) & (((e3.y ^ q3.r) & rmask) == 0) & ((e3.y >> 16) != 0u)) != 0;
+            if (hit3) found(id, e3.y >> 16, (uint32_t)cell3, false);
+            const uint32_t bit = nspare == 0 ? 1u : (e3.y >> cell_filter_pos(q3.w, e3.x, tv.lbits, BOTH)) & 1u;
+            on = !hit3 && (e3.x & CELL_FLAG_STASH & bit) != 0u;
+        }
+        if (on) {
+            // linear probing at load <= 0.25 (0.8 at worst): the slot and its successor in one round trip, further ones (rare) one by one
+            uint32_t slot = stash_slot(key, tv.stash_mask);
+            const uint4 a = tv.stash[slot], b = tv.stash[(slot + 1) & tv.stash_mask];
+            const uint64_t ka = u64_of(a.x, a.y), kb = u64_of(b.x, b.y);
+            uint32_t got = ~0u, cnt = 0u;
+            if (ka == key) {
+                got = slot;
+                cnt = a.z;
+            } else if (ka != EMPTY_KEY) {
+                if (kb == key) {
+                    got = (slot + 1) & tv.stash_mask;
+                    cnt = b.z;
+                } else if (kb != EMPTY_KEY) {
+                    slot = (slot + 2) & tv.stash_mask;
+                    for (;;) {
+                        const uint4 e = tv.stash[slot];
+                        const uint64_t ek = u64_of(e.x, e.y);
+                        if (ek == key) {
+                            got = slot;
+                            cnt = e.z;
+                            break;
+                        }
+                        if (ek == EMPTY_KEY) break;
+                        slot = (slot + 1) & tv.stash_mask;
+                    }
+                }
+            }
+            if (got != ~0u) found(id, cnt, got, true);
+        }
+    }
+    wave_lds_fence();
+}
+
 template <int K, bool BOTH, bool PLANNED>
 __global__ __launch_bounds__(PLANNED ? CELLS_BLOCK : TEXT_BLOCK) __attribute__((amdgpu_waves_per_eu(PLANNED ? 8 : KCFX_TEXT_WAVES_MIN, 8))) void screen_k31c_kernel(
     const uint8_t* __restrict__ text, RefPlan plan, const TileDesc* __restrict__ tiles, TableView tv, int32_t min_count,
@@ -1836,6 +1928,7 @@ __global__ __launch_bounds__(PLANNED ? CELLS_BLOCK : TEXT_BLOCK) __attribute__((
     const int w_end = min(w_begin + wpw, n_words);
     Queue& q = s_scratch.w.queue[wave];
     int qn = 0;                                             // queued k-mers (wave-uniform)
+    int qn2 = 0;                                            // ... of them, sent on by their second line: third line + stash once per tile
     const int pos0 = off + w_begin * 64;                    // packed position of the wave's first k-mer
 
     uint32_t sum_acc = 0;                                   // per lane; u16 counters: fits (static_assert in screen_k31_kernel)
@@ -1851,6 +1944,11 @@ __global__ __launch_bounds__(PLANNED ? CELLS_BLOCK : TEXT_BLOCK) __attribute__((
         // only a 3- / 4-byte counter (they live in the stash) exceeds 16 bits: its own 64-bit sum (GetVariants.java:226)
         if (cnt > CELL_COUNT_MAX) big_acc += (int64_t)(int32_t)cnt;
         else sum_acc += cnt;
+    };
+    // the second queue: third line, then stash, 64 entries at a time (normally once, at the end of the tile)
+    auto flush_rest = [&]() {
+        for (int off = 0; off < qn2; off += 64) k31c_rest_round<K, BOTH>(tv, sh, q.id2 + off, min(qn2 - off, 64), lane, pos0, found);
+        qn2 = 0;
     };
     // stage A of word w: keys, minimizer, cell, fetches issued
     auto issue = [&](int w, CellWord& cw) {
@@ -1902,7 +2000,10 @@ __global__ __launch_bounds__(PLANNED ? CELLS_BLOCK : TEXT_BLOCK) __attribute__((
             qn += __popcll(PM);
         }
         wave_lds_fence();
-        while (qn >= 64) qn = k31c_deferred_round<K, BOTH, true>(tv, sh, q.id, lane, qn, pos0, found);
+        while (qn >= 64) {
+            if (qn2 > 64) flush_rest();                     // (a batch of 64 may send all of its lanes on: room for them first)
+            qn = k31c_second_round<K, BOTH>(tv, sh, q.id, q.id2, qn2, lane, qn, pos0, found);
+        }
     };
     // D words of cell loads in flight per wave (CELLS_PIPE): a ring of D CellWords in fixed registers -- the loop is unrolled D
     // times -- and no condition around an issue in the steady state (see cells_issue); the first D - 1 issues and the last
@@ -1927,7 +2028,11 @@ __global__ __launch_bounds__(PLANNED ? CELLS_BLOCK : TEXT_BLOCK) __attribute__((
         if (base + i + D - 1 < w_end) issue(base + i + D - 1, cw[(i + D - 1) % D]);
         if (base + i < w_end) retire(base + i, cw[i % D]);
     }
-    while (qn > 0) qn = k31c_deferred_round<K, BOTH, true>(tv, sh, q.id, lane, qn, pos0, found);
+    while (qn > 0) {
+        if (qn2 > 64) flush_rest();
+        qn = k31c_second_round<K, BOTH>(tv, sh, q.id, q.id2, qn2, lane, qn, pos0, found);
+    }
+    flush_rest();
     if (lane < w_end - w_begin) {                           // the wave's words of the window's bitmap
         my_bits[w_begin + lane] = q.vw[lane];
         my_bits[TILE_WORDS + w_begin + lane] = q.hit[lane];

@@ -46,10 +46,11 @@ def test_screening_kernels_do_not_spill_and_fit_their_occupancy(kernels):
         assert m["vgpr_count"] <= (80 if "screen_k31_multi" in name else 72 if text_only(name) else 64), (name, m)
     for name, m in hot.items():
         if "screen_k31c_kernel" in name:
-            # planned reference: two waves per workgroup, 4.8 KB of LDS (codes both ways, anchors, queues) -- 16 workgroups per CU.
-            # text-only: one wave per workgroup, the planner's exchange rows UNDER the codes, anchors and queue: 4.3 KB -- 28
-            # workgroups (7 waves per SIMD) take 120 KB of a CU's 160
-            assert m["group_segment_fixed_size"] <= (4608 if text_only(name) else 5120), (name, m)
+            # planned reference: two waves per workgroup, 5.7 KB of LDS (codes both ways, anchors, the two queues of each wave) -- 16
+            # workgroups per CU. text-only: one wave per workgroup, the planner's exchange rows UNDER the codes, anchors and queues:
+            # 4.7 KB (round 6: + 512 B for the queue of the k-mers their second line sent on) -- 28 workgroups (7 waves per SIMD)
+            # take 132 KB of a CU's 160
+            assert m["group_segment_fixed_size"] <= (4864 if text_only(name) else 5888), (name, m)
         elif "screen_" in name:
             assert m["group_segment_fixed_size"] <= 20480, (name, m)     # 160 KB LDS per CU / 8 workgroups
 
