@@ -65,6 +65,11 @@ JNIEXPORT jint JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_releaseCached(JNIEnv
     return kcfx_release_cached(device);
 }
 
+// double setCacheFraction(double fraction): the share of a device that released buffers may occupy (default 0.5); returns the previous one
+JNIEXPORT jdouble JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_setCacheFraction(JNIEnv*, jclass, jdouble fraction) {
+    return kcfx_set_cache_fraction(fraction);
+}
+
 // void screen(long db, ByteBuffer text, long[] winBegin, int[] winLen, int minKmerCount, ByteBuffer results)
 // `text` and `results` are direct buffers; results receives nWindows * 40 bytes (kcfx_result, little-endian).
 // winBegin and winLen describe the same windows: non-null, equal lengths (else IllegalArgumentException; the C ABI trusts n)
@@ -157,6 +162,20 @@ JNIEXPORT jlongArray JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_tablePlan(JNIE
     int64_t lines = 0;
     int32_t regions = 1;
     const int32_t rc = kcfx_table_plan(totalKmers, k, bothStrands ? 1 : 0, freeBytes, &lines, &regions);
+    if (rc) { throw_kcfx(env, rc); return nullptr; }
+    jlongArray out = env->NewLongArray(2);
+    if (!out) return nullptr;
+    const jlong v[2] = {(jlong)lines, (jlong)regions};
+    env->SetLongArrayRegion(out, 0, 2, v);
+    return out;
+}
+
+// long[] tablePlanFor(long totalKmers, int k, boolean bothStrands, long freeBytes, long expectedQueries): the table dbOpenFor would build
+JNIEXPORT jlongArray JNICALL Java_nl_wur_bis_kcftools_Native_Kcfx_tablePlanFor(JNIEnv* env, jclass, jlong totalKmers, jint k,
+                                                                               jboolean bothStrands, jlong freeBytes, jlong expectedQueries) {
+    int64_t lines = 0;
+    int32_t regions = 1;
+    const int32_t rc = kcfx_table_plan_for(totalKmers, k, bothStrands ? 1 : 0, freeBytes, expectedQueries, &lines, &regions);
     if (rc) { throw_kcfx(env, rc); return nullptr; }
     jlongArray out = env->NewLongArray(2);
     if (!out) return nullptr;

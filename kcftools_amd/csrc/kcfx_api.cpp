@@ -309,8 +309,8 @@ bool cells_eligible(const kcfx_db* db, int32_t counter_size) {
 
 // 2^lbits lines of 16 cells: memory (and the time the driver takes to hand it out) against the speed of a screening pass.
 // A denser table sends more k-mers to second / third lines and the stash, and every such look-up is a random request of its own
-// (profiles/r06_density.csv, bench workload, 150 M k-mers, screening kernel on a planned reference, same box, the round's final code;
-// the round-5 code on the same workload: 0.0797 / 0.0833 / 0.0921 / 0.1142 ms):
+// (bench workload, 150 M k-mers, screening kernel on a planned reference, same box, round 6 -- the committed profiles/r06_density.csv
+// is a later run on another box: 0.0763 / 0.0785 / 0.0819 / 0.0944 ms; the round-5 code: 0.0797 / 0.0833 / 0.0921 / 0.1142 ms):
 //     2^27 lines  0.070 per cell  17.2 GB   5.6 % outside their first-choice cell  0.03 % in the stash  0.0750 ms per pass
 //     2^26        0.140            8.6 GB   8.7 %                                   0.19 %               0.0773 ms
 //     2^25        0.280            4.4 GB  13.6 %                                   1.09 %               0.0810 ms
@@ -1863,7 +1863,9 @@ int32_t kcfx_ref_export_partial_async(kcfx_ref* ref, void* bitmaps_device, void*
 // caller-owned device buffers INTO the reference's scratch (the inverse of the export): what a rank that owns a range of the windows
 // starts its merge from, when the slices' results meet range by range instead of on one root (shard.py: reduce_scatter_table_partials)
 int32_t kcfx_ref_import_partial_async(kcfx_ref* ref, const void* bitmaps_device, const void* sums_device, void* hip_stream) try {
-    if (!ref || !bitmaps_device || !sums_device) return fail(KCFX_ERR_ARG, "null argument");
+    if (!ref) return fail(KCFX_ERR_ARG, "null argument");
+    if (ref->n_tiles == 0) return KCFX_OK;                 // (a rank that owns no window: nothing to bring in, whatever the pointers are)
+    if (!bitmaps_device || !sums_device) return fail(KCFX_ERR_ARG, "null argument");
     int64_t b = 0, c = 0;
     kcfx_ref_partial_bytes(ref, &b, &c);
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
@@ -1892,7 +1894,9 @@ int32_t kcfx_ref_tile_range(const kcfx_ref* ref, int32_t w_lo, int32_t w_hi, int
 // another slice's partial results (device buffers on the reference's device, same tile list) into this reference's: hits OR-ed,
 // count sums added; the validity words are the same on every slice
 int32_t kcfx_ref_merge_partial_async(kcfx_ref* ref, const void* bitmaps_device, const void* sums_device, void* hip_stream) try {
-    if (!ref || !bitmaps_device || !sums_device) return fail(KCFX_ERR_ARG, "null argument");
+    if (!ref) return fail(KCFX_ERR_ARG, "null argument");
+    if (ref->n_tiles == 0) return KCFX_OK;                 // (no tiles: nothing to merge)
+    if (!bitmaps_device || !sums_device) return fail(KCFX_ERR_ARG, "null argument");
     DeviceGuard g(ref->device);
     KCFX_HIP(launch_merge_partial(ref->d_bits, ref->d_csum, reinterpret_cast<const uint64_t*>(bitmaps_device),
                                   reinterpret_cast<const int64_t*>(sums_device), ref->n_tiles, reinterpret_cast<hipStream_t>(hip_stream)));
