@@ -1,4 +1,4 @@
-"""The bench line the driver parses: the committed profile of the last GPU run (profiles/r05_bench.json, written by
+"""The bench line the driver parses: the committed profile of the last GPU run (profiles/r06_bench.json, written by
 tools/profile_round.sh from `python bench.py`) must carry every field of the contract with consistent values. Runs on CPU."""
 import json
 import os
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r06_bench.json")))
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -36,13 +36,13 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r["kernel"] == "screen_k31c_kernel" and (r["traffic"] is None or "not measured in this run" in r["traffic_source"])
     assert d["parity"]["bit_exact"] is True
     # the rocprofv3 summary committed next to it agrees with the HIP-event figure within 10 %
-    s = json.load(open(os.path.join(ROOT, "profiles", "r05_summary.json")))
+    s = json.load(open(os.path.join(ROOT, "profiles", "r06_summary.json")))
     assert abs(s["rocprof_kernel_avg_ms"] - r["kernel_avg_ms"]) < 0.1 * r["kernel_avg_ms"]
     assert r["traffic"] is None or r["traffic"] > alg      # HBM traffic by PMC is above the algorithmic bytes
     # ... and what the memory system really moves while the kernel runs stands beside the algorithmic rate
     assert r["traffic"] is None or abs(r["traffic_GBps"] - r["traffic"] / (r["kernel_avg_ms"] * 1e-3) / 1e9) < 1e-6 * r["traffic_GBps"]
     assert r["traffic"] is None or (r["frac"] < r["traffic_frac_of_peak"] < 1.0)
-    # round 5: the step is the pass the product runs for one sample -- ONE launch on a text-only reference (K1 - K3) + reduce -- at the
+    # since round 5: the step is the pass the product runs for one sample -- ONE launch on a text-only reference (K1 - K3) + reduce -- at the
     # REQUESTED warm-up; plan + screen as two launches and the amortised form are measured beside it and the fractions follow
     assert d["step_form"] == "one-pass" and d["step"].startswith("one pass") and d["warmup"] == 5
     assert r["kernel_instance"] == "screen_k31c_kernel<31, true, false>" and r["kernel_instance"] in s["rocprof_kernel"]
@@ -57,13 +57,31 @@ def test_committed_bench_line_has_the_contract_fields():
     # owed to the previous launch's data beyond what the Infinity Cache serves), a dirty one and the first launch on a fresh handle do
     cs = d["cache_state"]
     assert cs["hot_loop_ms"] < 1.02 * cs["read_swept_ms"] < 1.2 * cs["hot_loop_ms"] and cs["read_swept_ms"] < cs["write_swept_ms"]
-    assert len(cs["first_pass_ms"]) == 5 and cs["first_pass_median_ms"] > 1.5 * cs["second_pass_median_ms"]
-    # inputs that look like data: every window of each against the oracle, both forms of the kernel
+    assert len(cs["first_pass_ms"]) == 5 and cs["first_pass_median_ms"] > 1.2 * cs["second_pass_median_ms"]      # (on the one-pass table; 2.2 x on round 5's 17 GB table)
+    # inputs that look like data: every window of each against the oracle, in both product configurations (round 6): the one-pass job
+    # (text-only reference, the table sized for one pass) and the resident engine (planned reference, the table of a kept handle)
     for name in ("read_error_db", "read_error_depth30", "k25", "repeats"):
         x = d["realistic"][name]
         assert x["parity"]["bit_exact"] is True and x["forms_identical"] is True and x["parity"]["windows_checked"] >= 3000, name
-        assert 0.1 < x["one_pass"]["frac"] < 1.0 and 0.1 < x["amortised"]["frac"] < 1.0
+        assert 0.1 < x["one_pass"]["frac"] < x["resident"]["frac"] < 1.0
+        assert x["one_pass"]["table"]["lines"] < x["resident"]["table"]["lines"] and 0.15 < x["one_pass"]["table"]["kmers_per_cell"] <= 0.30
+    # round 6: the step's table IS the one kcfx_db_open_opts builds for one pass (~0.3 k-mers per cell), the PMC traffic figure is of that
+    # table, and the same kernels against a resident handle's table stand beside it
     assert r["table"]["policy"] == "product" and r["table"]["lines"] == json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["table_lines"]
+    assert 0.15 < r["table"]["kmers_per_cell"] <= 0.30 and r["table"]["expected_queries"] > 0
+    rt = d["resident_table"]
+    assert rt["identical_to_the_step"] is True and rt["table"]["lines"] > r["table"]["lines"] and rt["table"]["kmers_per_cell"] <= 0.075
+    assert abs(r["frac_resident_one_pass"] - rt["one-pass"]["frac"]) < 1e-12 and abs(r["frac_resident_amortised"] - rt["amortised"]["frac"]) < 1e-12
+    assert abs(rt["one-pass"]["frac"] - alg / (rt["one-pass"]["kernel_avg_ms"] * 1e-3) / 1e9 / r["peak"]) < 1e-9
+    # ... the end-to-end leg carries every run with its phases, and two more runs right after the process released its device memory
+    e = d["end_to_end"]
+    assert len(e["runs"]) == 4 and e["seconds_wall_all_runs"] == [x["seconds_wall"] for x in e["runs"]]
+    for run in e["runs"] + e["after_churn"]["runs"]:
+        ph = run["phases_ms"]
+        assert any(k.startswith("cli: kcfx_screen_sharded") for k in ph) and any(k.startswith("load: ") for k in ph)
+        assert abs(sum(v for k, v in ph.items() if k.startswith("cli: ") or k.startswith("process")) - 1e3 * run["seconds_wall"]) < 1.0
+    assert len(e["after_churn"]["runs"]) == 2 and max(e["seconds_wall_all_runs"] + e["after_churn"]["seconds_wall_all_runs"]) < d["cpu_end_to_end"]["seconds_wall"]
+    assert d["setup_seconds"]["db_open"] < 0.3
     # the CPU leg says how many cores it really had
     assert c["host_cores"] <= c["host_cores_logical"] and str(c["host_cores"]) in c["by_threads"]
 
