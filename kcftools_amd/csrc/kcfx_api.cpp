@@ -357,6 +357,9 @@ int32_t cells_lbits(int64_t n_keys, int32_t k, bool both, int64_t expected_queri
         // quarters to the first size at or under 0.3: the dense end of the policy is the same for every database) upwards
         int32_t Ld = lmin;
         while (Ld < L && per_cell(Ld + 1) > DENSITY_DENSE) ++Ld;
+        // (a cohort's key table has no regions to grow in: its dense end is the first power of two at or under ~0.3 per cell -- at the
+        // 0.56 per cell below that the bench cohort kept 6 % of its records in the stash instead of 2 %)
+        if (line_footprint != LINE_BYTES && Ld < L && per_cell(Ld) > DENSITY_DENSE) ++Ld;
         int32_t best = Ld;
         double best_cost = 0;
         for (int32_t l = Ld; l <= L; ++l) {

@@ -8,6 +8,8 @@ import os
 import numpy as np
 import pytest
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 from kcftools_amd import engine, synth
 
 pytestmark = pytest.mark.gpu
@@ -411,6 +413,31 @@ def test_stash_budget_and_line_table_fallback(oracle, tmp_path, monkeypatch, cap
     monkeypatch.setenv("KCFX_VERBOSE", "1")
     assert engine.KmcDb.open(prefix).info.table_format == 0
     assert "building a line table instead" in capfd.readouterr().err
+
+
+def test_structural_switches_need_the_test_hook_gate(tmp_path):
+    """Round 6: the environment switches that change what the library BUILDS (KCFX_TABLE_LBITS, KCFX_TABLE_FORMAT, ...) are test hooks
+    and count only when KCFX_TEST_HOOKS is set as well -- a host process that inherits a stray one gets the documented table. In a
+    process of its own (the gate is read once): the same database with KCFX_TABLE_LBITS=17 / KCFX_TABLE_FORMAT=lines in the environment,
+    without and with the gate."""
+    import json
+    import subprocess
+    import sys
+    k = 31
+    ref = synth.random_reference(300_000, 5)
+    prefix, *_ = make_db(tmp_path, "gate", ref, 6, k=k, p=3, cs=2, m=7, bins=4, noise=400_000)
+    code = ("import json, sys; sys.path.insert(0, %r); from kcftools_amd import engine; d = engine.KmcDb.open(%r); "
+            "print(json.dumps({'lines': int(d.info.table_lines), 'format': int(d.info.table_format)}))" % (ROOT, prefix))
+    seen = {}
+    for gate in (False, True):
+        env = {k_: v for k_, v in os.environ.items() if not k_.startswith("KCFX_")}
+        env.update({"KCFX_TABLE_LBITS": "17", "KCFX_TABLE_FORMAT": "lines"} if gate is False else {"KCFX_TABLE_LBITS": "17", "KCFX_TEST_HOOKS": "1"})
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert out.returncode == 0, out.stderr[-500:]
+        seen[gate] = json.loads(out.stdout.strip().splitlines()[-1])
+    want_lines, _ = engine.table_plan(int(engine.KmcDb.open(prefix).info.total_kmers), k, True, 200 << 30)
+    assert seen[False] == {"lines": want_lines, "format": 1}, seen          # ungated: the policy's cell table, whatever the environment says
+    assert seen[True] == {"lines": 1 << 17, "format": 1}, seen              # gated: the hook counts
 
 
 def test_db_open_opts_size_the_table_for_the_expected_look_ups(oracle, tmp_path, monkeypatch):
