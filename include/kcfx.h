@@ -219,14 +219,16 @@ int32_t kcfx_screen_ref_async(kcfx_db* db, kcfx_ref* ref, int32_t min_kmer_count
 /* Several samples, ONE pass over the reference (SURVEY f-4): what the reference does as S getVariations runs followed by
  * `cohort` (run_kcftools.sh:124-140, Plugins/Cohort.java:71-119). out[s * n_windows + w] = sample s (input order),
  * window w; each slice equals kcfx_screen_ref(dbs[s], ...). Databases must live on ref's device and share its k;
- * cell tables (the default for k = 19 .. 31) are screened and reduced one launch pair per sample, the reference staying resident;
+ * cell tables (the default for k = 19 .. 31) are screened one launch per sample, the reference staying resident, and reduced up to
+ * eight samples per launch (round 6);
  * 12-slot line tables of k = 31 with counters of at most 2 bytes are screened up to 8 at a time by one kernel (same
  * results either way). */
 int32_t kcfx_screen_ref_multi(kcfx_db* const* dbs, int32_t n_db, kcfx_ref* ref, int32_t min_kmer_count, kcfx_result* out);
 /* Same, asynchronous on `hip_stream`, results left in device memory (n_db * n_windows records). Databases that the
  * multi-sample kernel takes (12-slot line tables) need scratch of 512 B per tile and sample on the reference: it is allocated
  * by the first call that needs it, or beforehand by kcfx_ref_reserve_multi -- do that before capturing the call into a HIP
- * graph (an allocation is not capturable). Cell tables (table_format 1) are screened one launch per sample and need none. */
+ * graph (an allocation is not capturable). Two or more cell tables (table_format 1) use the same scratch for their batched window
+ * reduce while 520 B per tile and sample stay under 2 GiB (a 14.5 Gb reference keeps the launch pair per sample and needs none). */
 int32_t kcfx_screen_ref_multi_async(kcfx_db* const* dbs, int32_t n_db, kcfx_ref* ref, int32_t min_kmer_count,
                                     void* out_device, void* hip_stream);
 
