@@ -4,4 +4,4 @@ Only what the path needs lives here: `csrc/` (hand-written HIP kernels + the C A
 include/kcfx.h + the C++ host side mirroring GetVariants), a ctypes binding of that ABI
 (`engine`), and seeded synthetic-input generators (`synth`).
 """
-__version__ = "0.5.0"          # the library says the same: kcfx_version()
+__version__ = "0.6.0"          # the library says the same: kcfx_version()

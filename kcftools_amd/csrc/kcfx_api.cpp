@@ -1369,7 +1369,7 @@ struct RefHold {
 extern "C" {
 
 const char* kcfx_last_error(void) { return g_error.c_str(); }
-const char* kcfx_version(void) { return "kcfx 0.5.0 (gfx950)"; }
+const char* kcfx_version(void) { return "kcfx 0.6.0 (gfx950)"; }
 
 int32_t kcfx_device_count(int32_t* n) {
     if (!n) return fail(KCFX_ERR_ARG, "null argument");
