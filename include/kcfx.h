@@ -131,16 +131,19 @@ int32_t kcfx_db_open_opts(const char* kmc_prefix, int32_t device, const kcfx_db_
  * run stay together); this handle builds the cells of slice `slice` in a table of 1 / n_slices of the size -- n_slices devices hold
  * a database n_slices times as large at the density one device gives a small one. Every handle still streams the whole file.
  * k = 19 .. 31 (cell tables) only, never rebuilt as a line table. Screening: kcfx_screen_ref_partial_async on every slice (each
- * against a reference of the same text and windows on its device: the lanes whose minimizer another slice holds stay idle), the
+ * against a reference of the same text and windows on its device: a planned reference walks the positions whose minimizer can be
+ * this slice's, a text-only one every position with the other slices' lanes idle), the
  * tiles' hit bitmaps and count sums merged (kcfx_ref_merge_from inside a process, kcfx_ref_export_partial_async / an RCCL gather /
  * kcfx_ref_merge_partial_async between processes) and ONE kcfx_ref_finish_async -- or all of it in one call:
  * kcfx_screen_sharded(KCFX_SHARD_TABLE). kcfx_screen_ref* on a slice handle fail with KCFX_ERR_ARG; kcfx_db_lookup returns a
  * k-mer's counter on the slice(s) that hold it and 0 elsewhere. n_slices = 1 is kcfx_db_open_opts. */
 #define KCFX_SLICES_MAX 64
 int32_t kcfx_db_open_slice(const char* kmc_prefix, int32_t device, const kcfx_db_opts* opts, int32_t n_slices, int32_t slice, kcfx_db** out);
-/* which slice holds the cells of a minimizer: g32 = the 32 bits (line : r) of a first-choice cell in a table of 2^lbits lines per
- * region; host arithmetic (the kernels' cell_slice_of), -1 on bad arguments */
-int32_t kcfx_table_slice_of(uint32_t g32, int32_t lbits, int32_t n_slices);
+/* which slice holds the cells of a minimizer: slice_class = two hash bits of the minimizer's order key (0 .. 3; the anchor byte of
+ * every planned reference position carries them, so a pass against a slice walks only the positions that can be its own -- with
+ * 2 or 4 slices the class alone is the slice), g32 = the 32 bits (line : r) of a first-choice cell in a table of 2^lbits lines
+ * per region, which decide among the slices that share a class; host arithmetic (the kernels' cell_slice_of), -1 on bad arguments */
+int32_t kcfx_table_slice_of(uint32_t g32, int32_t lbits, int32_t n_slices, int32_t slice_class);
 
 /* Build the same table from host arrays of distinct k-mer words and counts (no files). `counter_size` in
  * 0..4 selects the stored counter width exactly like the KMC header field. */

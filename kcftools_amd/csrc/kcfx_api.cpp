@@ -1388,9 +1388,9 @@ int32_t kcfx_db_open_opts(const char* kmc_prefix, int32_t device, const kcfx_db_
     return kcfx_db_open_slice(kmc_prefix, device, opts, 1, 0, out);
 }
 
-int32_t kcfx_table_slice_of(uint32_t g32, int32_t lbits, int32_t n_slices) {
-    if (n_slices < 1 || n_slices > KCFX_SLICES_MAX || lbits < CELL_LBITS_MIN || lbits > CELL_LBITS_MAX) return -1;
-    return (int32_t)cell_slice_of(g32 >> (32 - lbits), g32, lbits, (uint32_t)n_slices);
+int32_t kcfx_table_slice_of(uint32_t g32, int32_t lbits, int32_t n_slices, int32_t slice_class) {
+    if (n_slices < 1 || n_slices > KCFX_SLICES_MAX || lbits < CELL_LBITS_MIN || lbits > CELL_LBITS_MAX || slice_class < 0 || slice_class > 3) return -1;
+    return (int32_t)cell_slice_of((uint32_t)slice_class, g32 >> (32 - lbits), g32, lbits, (uint32_t)n_slices);
 }
 
 int32_t kcfx_db_open_slice(const char* kmc_prefix, int32_t device, const kcfx_db_opts* opts, int32_t n_slices, int32_t slice, kcfx_db** out) {

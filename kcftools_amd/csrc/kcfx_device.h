@@ -253,6 +253,12 @@ KCFX_HD uint32_t cell_order27(const uint32_t* u) {
     const uint32_t hx = u[0] ^ u[1] ^ u[2] ^ u[3] ^ u[4] ^ u[5] ^ u[6] ^ u[7] ^ u[8] ^ u[9] ^ u[10];
     return (hx & ORDER_HASH_MASK) | cell_class30(u[0], u[5], u[10], inner);
 }
+// The two lowest hash bits of a minimizer's order key (bits 6..5): its SLICE CLASS. A function of the 16-mer alone, the same for
+// a 16-mer and its reverse complement, and both sides have it for nothing -- the build as the minimum it has just taken
+// (cells_visit), the query in the byte of the tagged minimum that already carries offset and strand (StripPlanner: bits 6..5 of
+// the anchor byte). Which device of a node holds a k-mer (cell_slice_of, kcfx_internal.h) starts from these two bits, so a
+// screening pass against a table slice knows from the anchor bytes alone which positions cannot be its own.
+KCFX_HD uint32_t order_slice_class(uint32_t key) { return (key >> 5) & 3u; }
 // What a position feeds into the sliding minimum: order key | position label (bits 4..1: twice the position mod 16, distinct within
 // any 16 consecutive positions) | strand bit (bit 0: the canonical form is the reverse complement of the 16-mer as the
 // text reads it). The minimum therefore carries where the minimizer sits and which way round it is; with the label
@@ -359,6 +365,7 @@ struct CellProbe {
     uint32_t sh;        // 2 * cell index (the cell is at byte 4 * sh of the line)
     uint32_t w;         // flank bits (flag bits clear)
     uint32_t r;         // low 32 - lbits bits of G32
+    uint32_t cls;       // build side only (cells_visit, record_cells): the slice class of the k-mer's minimizer (order_slice_class)
 };
 
 // Where a k-mer that lost the bid for its first-choice cell may live, in the order a query looks:
@@ -415,6 +422,7 @@ KCFX_HD CellProbe cell_second_line(const CellProbe& p, int32_t lbits) {
     q.sh = p.sh;
     q.w = p.w;
     q.r = (g2 & idm) | CELL_R_ALT | (p.r & CELL_R_FLIP & ~idm);    // (a canonical table of 2^17 lines has a G32 bit where FLIP would be)
+    q.cls = p.cls;
     return q;
 }
 
@@ -434,6 +442,7 @@ KCFX_HD CellProbe cell_third_line(const CellProbe& p, int32_t lbits, bool both, 
     q.sh = p.sh;
     q.w = p.w;
     q.r = (g3 & idm) | CELL_R_ALT | cell_r_third(both) | (p.r & CELL_R_FLIP & ~idm);
+    q.cls = p.cls;
     return q;
 }
 
@@ -503,6 +512,7 @@ KCFX_HD CellProbe cell_probe_of(uint64_t F, uint64_t R, uint32_t mn, uint32_t la
     p.sh = sh;
     p.line = g >> (32 - lbits);
     p.r = (g & (0xFFFFFFFFu >> lbits)) | ((!both && flip) ? CELL_R_FLIP : 0u);     // forward-only: F itself is looked up
+    p.cls = order_slice_class(mn);
     return p;
 }
 
@@ -560,6 +570,7 @@ KCFX_HD int cells_visit(uint64_t C, int32_t k, int32_t lbits, bool both, bool ex
             p.sh = sh;
             p.line = g >> (32 - lbits);
             p.r = (g & (0xFFFFFFFFu >> lbits)) | ((!both && strand == 1) ? CELL_R_FLIP : 0u);
+            p.cls = order_slice_class(best);
             f(ext ? cell_first_ext(p, lbits) : p, n);
             ++n;
         }

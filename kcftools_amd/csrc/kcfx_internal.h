@@ -90,19 +90,33 @@ __host__ __device__ inline uint64_t cell_word(uint32_t w, uint32_t r, uint32_t c
 }
 
 // TABLE SLICES (TableView::slices = S; round 5): a database whose table does not fit one device at a density worth having is
-// partitioned over the S devices of a node BY MINIMIZER -- device s holds the cells of the k-mers whose (line, r) hash to s, in a
-// table of 1 / S of the lines (kcfx_db_open_slice); every device screens the whole reference with the lanes whose minimizer is not
-// its own switched off, and the per-tile hit bitmaps and count sums are OR-ed / added before ONE reduce_windows (kcfx_shard.cpp,
-// KCFX_SHARD_TABLE). A function of the same 32 bits that name the line and r of the FIRST choice, so a k-mer's second and third
-// lines, its filter bits and its stash entry live where its first-choice cell does, and the k-mers of a minimizer run stay
-// together (an extended table cuts a run in two at most, as it does for its lines). A k-mer with several first-choice cells (tied
-// minimizers) is stored per cell, each copy where a query that derives THAT cell will look.
-__host__ __device__ inline uint32_t cell_slice_of_g(uint32_t g, uint32_t n_slices) {        // g = the 32 bits (line : r) themselves
+// partitioned over the S devices of a node BY MINIMIZER -- device s holds the cells of the k-mers whose minimizer belongs to s, in a
+// table of 1 / S of the lines (kcfx_db_open_slice); every device screens the whole reference for the k-mers whose minimizer is its
+// own, and the per-tile hit bitmaps and count sums are OR-ed / added before ONE reduce_windows (kcfx_shard.cpp, KCFX_SHARD_TABLE).
+// Which slice: the top of a 32-bit word whose two leading bits are the minimizer's SLICE CLASS (order_slice_class, kcfx_device.h:
+// two hash bits of its order key, which the anchor byte of every reference position carries) and whose other thirty are a hash of
+// the 32 bits that name the line and r of the FIRST choice. So a k-mer's second and third lines, its filter bits and its stash
+// entry live where its first-choice cell does, the k-mers of a minimizer run stay together (an extended table cuts a run in two
+// at most, as it does for its lines), and a pass knows from the anchor bytes alone which positions cannot be its slice's
+// (cell_slice_classes: with 2 or 4 slices the class IS the slice; with 8, two slices share a class) -- round 6: the planned
+// reference's pass against a slice walks only those (screen_k31c_slice_kernel). A k-mer with several first-choice cells (tied
+// minimizers: same key, same class) is stored per cell, each copy where a query that derives THAT cell will look.
+__host__ __device__ inline uint32_t cell_slice_of_g(uint32_t cls, uint32_t g, uint32_t n_slices) {        // g = the 32 bits (line : r) themselves
     const uint32_t h = (g ^ (g >> 13)) * 0x7FEB352Du;
-    return (uint32_t)(((uint64_t)(h ^ (h >> 15)) * n_slices) >> 32);
+    const uint32_t u = (cls << 30) | ((h ^ (h >> 15)) >> 2);
+    return (uint32_t)(((uint64_t)u * n_slices) >> 32);
 }
-__host__ __device__ inline uint32_t cell_slice_of(uint32_t line, uint32_t r, int32_t lbits, uint32_t n_slices) {
-    return cell_slice_of_g((line << (32 - lbits)) | (r & (0xFFFFFFFFu >> lbits)), n_slices);
+__host__ __device__ inline uint32_t cell_slice_of(uint32_t cls, uint32_t line, uint32_t r, int32_t lbits, uint32_t n_slices) {
+    return cell_slice_of_g(cls, (line << (32 - lbits)) | (r & (0xFFFFFFFFu >> lbits)), n_slices);
+}
+// bit c: a minimizer of slice class c can belong to slice `slice` of n_slices
+__host__ __device__ inline uint32_t cell_slice_classes(uint32_t n_slices, uint32_t slice) {
+    uint32_t m = 0;
+    for (uint32_t c = 0; c < 4; ++c) {
+        const uint32_t lo = (uint32_t)(((uint64_t)(c << 30) * n_slices) >> 32), hi = (uint32_t)(((uint64_t)((c << 30) | 0x3FFFFFFFu) * n_slices) >> 32);
+        if (lo <= slice && slice <= hi) m |= 1u << c;
+    }
+    return m;
 }
 
 struct TableView {

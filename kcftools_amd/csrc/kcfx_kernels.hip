@@ -272,13 +272,13 @@ __global__ void cells_count_kernel(uint32_t* pop32, int32_t pop_bits, int32_t k,
 // minimizers: a few in 10^5) is flagged and walked by cells_visit as before.
 struct RecProbes {
     const uint64_t* pw;     // G32 | flank << 32        (null: nothing was kept -- every pass derives the cells itself)
-    const uint8_t* ps;      // cell index | REC_MULTI | REC_FLIP
+    const uint8_t* ps;      // cell index | REC_MULTI | REC_FLIP | slice class << 6
     int32_t ext;            // the table is an extended one (what is kept is the extended G32: cell_first_ext)
     int32_t regions;        // the table has R regions of 2^lbits lines (cell_line_index): where a probe's line IS
     int32_t slicing;        // 0, or (slices << 8 | slice): the table holds one slice of the database (cell_slice_of) -- a pass acts
                             // on the cells of a record that are this slice's and leaves the others to the devices that hold theirs
     __device__ __forceinline__ bool mine(const CellProbe& p, int32_t lbits) const {
-        return slicing == 0 || cell_slice_of(p.line, p.r, lbits, (uint32_t)slicing >> 8) == ((uint32_t)slicing & 0xFFu);
+        return slicing == 0 || cell_slice_of(p.cls, p.line, p.r, lbits, (uint32_t)slicing >> 8) == ((uint32_t)slicing & 0xFFu);
     }
 };
 // byte address of a probe's cell in the table
@@ -286,6 +286,7 @@ __device__ __forceinline__ size_t cell_byte_at(const CellProbe& p, int32_t lbits
     return (size_t)cell_line_index(p.line, p.r, lbits, regions) * LINE_BYTES + 4 * p.sh;
 }
 constexpr uint8_t REC_MULTI = 0x10, REC_FLIP = 0x20;
+constexpr uint32_t REC_CLASS_SHIFT = 6;                    // bits 7..6: order_slice_class of the minimizer
 template <class F>
 __device__ __forceinline__ int record_cells(const RecProbes& rp, int64_t i, uint64_t key, int32_t k, int32_t lbits, bool both, F&& f) {
     if (rp.pw) {
@@ -298,6 +299,7 @@ __device__ __forceinline__ int record_cells(const RecProbes& rp, int64_t i, uint
             p.r = (g & (0xFFFFFFFFu >> lbits)) | ((s & REC_FLIP) ? CELL_R_FLIP : 0u);
             p.w = (uint32_t)(w >> 32);
             p.sh = 2u * (s & 15u);
+            p.cls = s >> REC_CLASS_SHIFT;
             f(p, 0);
             return 1;
         }
@@ -316,7 +318,7 @@ __global__ void cells_resolve_kernel(uint32_t* pop32, int32_t pop_bits, int32_t 
             ps[i] = 0;
             continue;
         }
-        CellProbe first{0, 0, 0, 0};
+        CellProbe first{0, 0, 0, 0, 0};
         const int nc = cells_visit(keys[i], k, lbits, both != 0, ext != 0, [&](const CellProbe& p, int a) {
             if (a == 0) first = p;
         });
@@ -324,7 +326,8 @@ __global__ void cells_resolve_kernel(uint32_t* pop32, int32_t pop_bits, int32_t 
         atomicAdd(&pop32[sub >> 2], 1u << (8 * (uint32_t)(sub & 3)));
         const uint32_t g = (first.line << (32 - lbits)) | (first.r & (0xFFFFFFFFu >> lbits));
         pw[i] = (uint64_t)g | ((uint64_t)first.w << 32);
-        ps[i] = (uint8_t)((first.sh >> 1) | (nc > 1 ? REC_MULTI : 0) | ((first.r & CELL_R_FLIP & ~(0xFFFFFFFFu >> lbits)) ? REC_FLIP : 0));
+        ps[i] = (uint8_t)((first.sh >> 1) | (nc > 1 ? REC_MULTI : 0) | ((first.r & CELL_R_FLIP & ~(0xFFFFFFFFu >> lbits)) ? REC_FLIP : 0) |
+                          (first.cls << REC_CLASS_SHIFT));
     }
 }
 
@@ -580,7 +583,7 @@ __global__ __launch_bounds__(256) void lookup_cells_kernel(TableView tv, int32_t
         // a both-strands database stores only canonical words; a k-mer word has its low 64 - 2k bits clear
         const bool both = both_i != 0;
         if ((!both || key <= revcomp_word(key, k)) && (key & ~(~0ull << (64 - 2 * k))) == 0) {
-            CellProbe c0{0, 0, 0, 0};                            // any one of its cells decides: the first
+            CellProbe c0{0, 0, 0, 0, 0};                            // any one of its cells decides: the first
             cells_visit(key, k, tv.lbits, both, tv.ext != 0, [&](const CellProbe& p, int a) {
                 if (a == 0) c0 = p;
             });
@@ -1689,6 +1692,7 @@ __device__ __forceinline__ CellProbe cell_probe_planned(uint64_t N, uint32_t sh2
     p.sh = sh2;
     p.line = g >> (32 - lbits);
     p.r = (g & (0xFFFFFFFFu >> lbits)) | (BOTH ? 0u : (fm & CELL_R_FLIP));
+    p.cls = 0;                                              // (the anchor byte carries it: anchor_slice_class)
     return p;
 }
 
@@ -1827,6 +1831,9 @@ __device__ __forceinline__ int k31c_second_round(const TableView& tv, const Lds&
         if (hit2) found(id, e.y >> 16, (uint32_t)cell, false);
         const uint32_t bit = nspare == 0 ? 1u : (e.y >> cell_filter_pos(q2.w, e.x, tv.lbits, BOTH)) & 1u;
         on = !hit2 && (e.x & CELL_FLAG_STASH & bit) != 0u;
+#if defined(KCFX_EXP_CUT) && KCFX_EXP_CUT <= 1
+        on = false;                                         // (experiment build: nothing beyond the second line)
+#endif
     }
     const uint64_t ON = wave_ballot(on);
     if (ON) {
@@ -1960,7 +1967,8 @@ __global__ __launch_bounds__(PLANNED ? CELLS_BLOCK : TEXT_BLOCK) __attribute__((
         cw.Vfull = V;
         // (wave-uniform: the table is one slice of the database -- the k-mers whose minimizer another device holds are that
         // device's to look up: no load, no hit, no queue entry here; the tiles' bitmaps are OR-ed afterwards)
-        if (tv.slices > 1) V &= wave_ballot(cell_slice_of_g(g, (uint32_t)tv.slices) == (uint32_t)tv.slice);
+        // (the text-only form: a planned reference against a slice has its own kernel below, which walks the slice's positions only)
+        if (tv.slices > 1) V &= wave_ballot(cell_slice_of_g((a >> 5) & 3u, g, (uint32_t)tv.slices) == (uint32_t)tv.slice);
         if (tv.regions > 1) p.line |= cell_region_of(g, (uint32_t)tv.regions) << tv.lbits;  // (wave-uniform: cell_line_index; from here on the line is only an address)
         cells_issue<cell_nw(K), BOTH>(tv, V, p, a, cw);          // (the anchor byte whole: masked when -- if -- the k-mer is queued)
     };
@@ -2053,6 +2061,226 @@ __global__ __launch_bounds__(PLANNED ? CELLS_BLOCK : TEXT_BLOCK) __attribute__((
             for (int i = 0; i < WAVES; ++i) t += sh.sum[i];
             count_sums[blockIdx.x] = t;
         }
+    }
+}
+
+// ======================================================================================================
+// screen_k31c_slice: a planned reference against ONE SLICE of a database (round 6)
+// ======================================================================================================
+// Every device of a node walks the whole reference against its slice of the table. In screen_k31c_kernel that walk costs a slice
+// what it costs a whole table -- keys, minimizer, cell address, match and ballots for all 64 lanes of every word, with the 1 / S of
+// them that are this slice's switched on: a pass against one of four slices took 5.0 ms where the whole table's took 9.95
+// (profiles/r05_notes.md section 4), all of it instruction issue. Here the anchor bytes decide first: a wave reads the anchor of
+// every position of its words (one LDS byte each), keeps the positions whose minimizer's slice class this slice can own
+// (cell_slice_classes: exact with 2 or 4 slices) in a list in LDS -- ~10 VALU instructions per word -- and then walks the LIST 64
+// entries at a time with the code of screen_k31c_kernel's word loop (same probe, same cell loads in a ring of CELLS_PIPE, same
+// match, same queue for the k-mers that are looked up further). A lane's k-mer now sits at any position of the wave's words, so
+// it derives its LDS addresses from the position (~12 instructions more per list word) and a hit is one byte in LDS per position,
+// gathered into the tile's hit words at the end; the validity words do not depend on the slice and are written by the first phase.
+constexpr int SLICE_LIST = CELLS_WORDS_PER_WAVE * 64;       // positions of a wave's words
+#ifndef KCFX_SLICE_HIT_BYTES
+#define KCFX_SLICE_HIT_BYTES 0
+#endif
+struct SliceWave {
+    uint16_t list[SLICE_LIST];                              // (word of the wave << 6) | lane of the positions this slice may own, ascending
+#if KCFX_SLICE_HIT_BYTES
+    __attribute__((aligned(16))) uint8_t hit[SLICE_LIST];   // 1: the k-mer at that position is in the slice's table with a counter >= -c
+#endif
+};
+static_assert(SLICE_LIST <= 1024 && SLICE_LIST % 1024 == 0, "a position of the wave in 10 bits (queue ids keep 16); the hit bytes are cleared 16 per lane");
+
+// N, sh2, fm (PlannedWords::next) of the k-mer at packed position q of the tile, from its anchor byte
+template <int K>
+__device__ __forceinline__ uint64_t planned_kmer_at(const K31Plan& sh, int q, uint32_t fm) {
+    typedef const __attribute__((address_space(3))) uint32_t* lds_u32;
+    constexpr uint32_t lo_mask = ~0u << (64 - 2 * K);
+    // the strand the anchor names: position q of fw (lead word in front) or position T - q - K of rw
+    const int qq = fm ? K31Plan::T - q - K : q;
+    const int b = 2 * qq - 1;
+    const uint32_t base = fm ? PlannedWords<K>::lds_address(sh.rw) : PlannedWords<K>::lds_address(sh.fw + 1);
+    const lds_u32 p = (lds_u32)(uintptr_t)(base + 4u * (uint32_t)(b >> 5));
+    const uint32_t sx = 31u - (uint32_t)(b & 31);
+    const uint32_t y0 = p[0], y1 = p[1], y2 = p[2];
+    return u64_of(alignbit32(y1, y2, sx) & lo_mask, alignbit32(y0, y1, sx));
+}
+
+template <int K, bool BOTH>
+__global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void screen_k31c_slice_kernel(
+    RefPlan plan, const TileDesc* __restrict__ tiles, TableView tv, uint32_t classes, int32_t min_count,
+    uint64_t* __restrict__ bits, int64_t* __restrict__ count_sums) {
+    constexpr int WAVES = CELLS_WAVES;
+    using Lds = K31Plan;
+    __shared__ Lds sh;
+    __shared__ K31CQueue s_queue[WAVES];
+    __shared__ SliceWave s_slice[WAVES];
+    const TileDesc td = tiles[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int off = k31_load_plan_tile<CELLS_BLOCK>(sh, plan, td, K, tid);
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_words = (td.n_kmers + 63) >> 6;
+    const int wpw = (n_words + WAVES - 1) / WAVES;
+    const int w_begin = min(wave * wpw, n_words);
+    const int w_end = min(w_begin + wpw, n_words);
+    K31CQueue& q = s_queue[wave];
+    SliceWave& sw = s_slice[wave];
+    const int pos0 = off + w_begin * 64;                    // packed position of the wave's first k-mer
+    const int8_t* const an = reinterpret_cast<const int8_t*>(sh.an) + pos0;
+    uint64_t* my_bits = bits + (size_t)blockIdx.x * TILE_BITS_U64;
+
+    // ---- phase 1: the anchors of the wave's words -> validity words + the list of the positions this slice may own ----
+#if KCFX_SLICE_HIT_BYTES
+#pragma unroll
+    for (int i = 0; i < SLICE_LIST / (64 * 16); ++i) reinterpret_cast<uint4*>(sw.hit)[i * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
+#else
+    if (lane < CELLS_WORDS_PER_WAVE) q.hit[lane] = 0ull;    // the hit words: the lanes that find their k-mer OR their bit in
+#endif
+    int n_list = 0;                                         // (wave-uniform)
+    {
+        // (all the anchor reads first, then the words: one LDS round trip per wave, not one per word; a word behind the wave's
+        // last reads anchors of the next wave's positions or the array's tail -- inside sh.an either way -- and is not looked at)
+        static_assert(sizeof(sh.an) >= 32 + CELLS_WORDS_PER_WAVE * 64 * CELLS_WAVES, "phase 1 reads the anchors of whole words");
+        int32_t a[CELLS_WORDS_PER_WAVE];
+#pragma unroll
+        for (int i = 0; i < CELLS_WORDS_PER_WAVE; ++i) a[i] = (int32_t)an[(i << 6) + lane];     // sign-extended: valid <=> negative
+#pragma unroll
+        for (int i = 0; i < CELLS_WORDS_PER_WAVE; ++i) {
+            if (w_begin + i >= w_end) break;
+            const int rem = td.n_kmers - (w_begin + i) * 64;                                    // >= 1
+            const uint64_t V = (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull)) & wave_ballot(a[i] < 0);
+            if (lane == 0) q.vw[i] = V;
+            const uint32_t cls = __builtin_amdgcn_ubfe((uint32_t)a[i], 5u, 2u);
+            const uint64_t O = V & wave_ballot(__builtin_amdgcn_ubfe(classes, cls, 1u) != 0u);
+            if (O) {
+                const int at = n_list + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(O >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)O, 0u));
+                if (__builtin_amdgcn_inverse_ballot_w64(O)) sw.list[at] = (uint16_t)((i << 6) | lane);
+                n_list += __popcll(O);
+            }
+        }
+    }
+    wave_lds_fence();
+
+    // ---- phase 2: the list, 64 positions per word ----
+    int qn = 0, qn2 = 0;
+    uint32_t sum_acc = 0;
+    int64_t big_acc = 0;
+    auto found = [&](uint32_t id, uint32_t cnt, uint32_t, bool) {
+        if ((int32_t)cnt < min_count) return;               // GetVariants.java:224
+#if KCFX_SLICE_HIT_BYTES
+        sw.hit[id & (SLICE_LIST - 1)] = 1;
+#else
+        atomicOr(&q.hit[(id >> 6) & (uint32_t)(CELLS_WORDS_PER_WAVE - 1)], 1ull << (id & 63));
+#endif
+        if (cnt > CELL_COUNT_MAX) big_acc += (int64_t)(int32_t)cnt;     // GetVariants.java:226
+        else sum_acc += cnt;
+    };
+    auto flush_rest = [&]() {
+        for (int o = 0; o < qn2; o += 64) k31c_rest_round<K, BOTH>(tv, sh, q.id2 + o, min(qn2 - o, 64), lane, pos0, found);
+        qn2 = 0;
+    };
+    const bool by_class = (tv.slices & (tv.slices - 1)) == 0 && tv.slices <= 4;     // the class alone names the slice
+    struct ListWord {
+        CellWord cw;
+        uint32_t id;
+    };
+    auto issue = [&](int c, ListWord& lw) {
+        const int n = min(n_list - 64 * c, 64);
+        uint64_t V = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+        const uint32_t id = sw.list[(64 * c + lane) & (SLICE_LIST - 1)] & (SLICE_LIST - 1);     // (behind the list's end: some position of the wave, masked out of V)
+        const int32_t a = (int32_t)an[id];
+        uint32_t fm;
+        asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(fm) : "v"(a));
+        const uint32_t sh2 = (uint32_t)a & 30u;
+        const uint64_t N = planned_kmer_at<K>(sh, pos0 + (int)id, fm);
+        uint32_t g;
+        CellProbe p = cell_probe_planned<BOTH>(N, sh2, fm, tv.lbits, tv.ext, &g);
+        // (3, 5, 6, 7 or more than 4 slices: some classes are shared by two slices -- the hash of (line : r) decides)
+        if (!by_class) V &= wave_ballot(cell_slice_of_g(((uint32_t)a >> 5) & 3u, g, (uint32_t)tv.slices) == (uint32_t)tv.slice);
+        if (tv.regions > 1) p.line |= cell_region_of(g, (uint32_t)tv.regions) << tv.lbits;
+        lw.id = id;
+        cells_issue<cell_nw(K), BOTH>(tv, V, p, (uint32_t)a, lw.cw);
+    };
+    auto retire = [&](int, const ListWord& lw) {
+        const CellWord& cw = lw.cw;
+        uint32_t cnt = 0, pend = 0;
+        uint64_t M = 0;
+        cells_match<BOTH, cell_nw(K)>(cw, tv.lbits, cnt, pend, &M);
+        const uint64_t H = wave_ballot((int32_t)cnt >= min_count);          // GetVariants.java:224 (cnt is 0 outside cw.V: cells_match)
+#if KCFX_SLICE_HIT_BYTES
+        if (__builtin_amdgcn_inverse_ballot_w64(H)) sw.hit[lw.id] = 1;
+#else
+        if (__builtin_amdgcn_inverse_ballot_w64(H)) atomicOr(&q.hit[lw.id >> 6], 1ull << (lw.id & 63));
+#endif
+        sum_acc += cnt;                                                     // GetVariants.java:226 (see screen_k31c_kernel)
+        if constexpr (cell_nw(K) > CELL_ALT_FREE_MAX_W) {
+            const uint64_t low = M & ~H;
+            if (low) sum_acc -= __builtin_amdgcn_inverse_ballot_w64(low) ? cnt : 0u;
+        } else {
+            sum_acc -= __builtin_amdgcn_inverse_ballot_w64(H) ? 0u : cnt;
+        }
+#if defined(KCFX_EXP_CUT) && KCFX_EXP_CUT == 0
+        const uint64_t PM = 0;                              // (experiment build: first-choice cells only)
+#else
+        const uint64_t PM = wave_ballot(pend != 0u) & ~H & cw.V;
+#endif
+        if (PM) {
+            const bool pending = __builtin_amdgcn_inverse_ballot_w64(PM);
+            const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(PM >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)PM, 0u));
+            if (pending) q.id[pos] = lw.id | ((cw.anc & 31u) << QUEUE_ANCHOR_SHIFT);
+            qn += __popcll(PM);
+        }
+        wave_lds_fence();
+        while (qn >= 64) {
+            if (qn2 > 64) flush_rest();
+            qn = k31c_second_round<K, BOTH>(tv, sh, q.id, q.id2, qn2, lane, qn, pos0, found);
+        }
+    };
+    const int c_end = (n_list + 63) >> 6;
+    constexpr int D = CELLS_PIPE;
+    ListWord lw[D];
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < D - 1; ++i)
+        if (i < c_end) issue(i, lw[i]);
+    for (; base + 2 * D - 2 < c_end; base += D) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            issue(base + i + D - 1, lw[(i + D - 1) % D]);
+            retire(base + i, lw[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * D - 2; ++i) {
+        if (base + i + D - 1 < c_end) issue(base + i + D - 1, lw[(i + D - 1) % D]);
+        if (base + i < c_end) retire(base + i, lw[i % D]);
+    }
+    while (qn > 0) {
+        if (qn2 > 64) flush_rest();
+        qn = k31c_second_round<K, BOTH>(tv, sh, q.id, q.id2, qn2, lane, qn, pos0, found);
+    }
+    flush_rest();
+    wave_lds_fence();
+
+    // ---- phase 3: the hit bytes -> the tile's hit words ----
+#if KCFX_SLICE_HIT_BYTES
+    for (int w = w_begin; w < w_end; ++w) {
+        const uint64_t H = wave_ballot(sw.hit[((w - w_begin) << 6) | lane] != 0);
+        if (lane == 0) q.hit[w - w_begin] = H;
+    }
+    wave_lds_fence();
+#endif
+    if (lane < w_end - w_begin) {
+        my_bits[w_begin + lane] = q.vw[lane];
+        my_bits[TILE_WORDS + w_begin + lane] = q.hit[lane];
+    }
+    int64_t count_sum = (int64_t)wave_sum_u32_dpp(sum_acc);
+    if (wave_ballot(big_acc != 0) != 0) count_sum += wave_sum_i64(big_acc);
+    if (lane == 0) sh.sum[wave] = count_sum;
+    __syncthreads();
+    if (tid == 0) {
+        int64_t t = 0;
+#pragma unroll
+        for (int i = 0; i < WAVES; ++i) t += sh.sum[i];
+        count_sums[blockIdx.x] = t;
     }
 }
 
@@ -2798,6 +3026,9 @@ hipError_t launch_ref_plan(const uint8_t* text, int64_t text_len, int32_t k, uin
     return hipGetLastError();
 }
 
+// KCFX_SLICE_WALK_ALL (test hook): a planned reference against a table slice in screen_k31c_kernel's form -- every position of every
+// word with the foreign lanes switched off, what the text-only reference does -- for the A/B and the parity of the two forms
+static bool slice_walk_all() { return hook("KCFX_SLICE_WALK_ALL") != nullptr; }     // (read per launch: a test switches it inside one process)
 hipError_t launch_screen_tiles(const uint8_t* text, RefPlan plan, const TileDesc* tiles, int32_t n_tiles, TableView tv, int32_t k,
                                int32_t both_strands, int32_t min_count, uint64_t* bits, int64_t* count_sums,
                                hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
@@ -2811,11 +3042,17 @@ hipError_t launch_screen_tiles(const uint8_t* text, RefPlan plan, const TileDesc
     hipExtLaunchKernelGGL((screen_k31_kernel<W, BS>), g, b, 0, st, ev_start, ev_stop, 0, text, tiles, tv, min_count, bits, count_sums)
     const bool generic_only = tv.generic != 0;                                      // A/B and test hook, fixed at kcfx_db_open
     if (tv.fmt == FORMAT_CELLS) {
+        // a planned reference against a table slice: the walk over the slice's positions only (screen_k31c_slice_kernel)
+        const bool by_list = tv.slices > 1 && !slice_walk_all();
+        const uint32_t slice_classes = cell_slice_classes((uint32_t)tv.slices, (uint32_t)tv.slice);
 #define KCFX_LAUNCHC1(KK, BS, PL) \
     hipExtLaunchKernelGGL((screen_k31c_kernel<KK, BS, PL>), g, (PL) ? bc : dim3(TEXT_BLOCK), 0, st, ev_start, ev_stop, 0, text, plan, tiles, tv, min_count, bits, count_sums)
+#define KCFX_LAUNCHS1(KK, BS) \
+    hipExtLaunchKernelGGL((screen_k31c_slice_kernel<KK, BS>), g, bc, 0, st, ev_start, ev_stop, 0, plan, tiles, tv, slice_classes, min_count, bits, count_sums)
 #define KCFX_LAUNCHC(KK)                                                                  \
     do {                                                                                  \
-        if (plan.codes) { if (both_strands) KCFX_LAUNCHC1(KK, true, true); else KCFX_LAUNCHC1(KK, false, true); }   \
+        if (plan.codes && by_list) { if (both_strands) KCFX_LAUNCHS1(KK, true); else KCFX_LAUNCHS1(KK, false); }   \
+        else if (plan.codes) { if (both_strands) KCFX_LAUNCHC1(KK, true, true); else KCFX_LAUNCHC1(KK, false, true); }   \
         else            { if (both_strands) KCFX_LAUNCHC1(KK, true, false); else KCFX_LAUNCHC1(KK, false, false); } \
     } while (0)
         switch (k) {
@@ -2838,6 +3075,7 @@ hipError_t launch_screen_tiles(const uint8_t* text, RefPlan plan, const TileDesc
         }
 #undef KCFX_LAUNCHC
 #undef KCFX_LAUNCHC1
+#undef KCFX_LAUNCHS1
     } else if (tv.mode == MODE_MINIMIZER && k == 31 && tv.mm_len == 16 && !generic_only) {
         if (tv.wide) { if (both_strands) KCFX_LAUNCH31(true, true); else KCFX_LAUNCH31(true, false); }
         else         { if (both_strands) KCFX_LAUNCH31(false, true); else KCFX_LAUNCH31(false, false); }

@@ -194,13 +194,15 @@ struct StripPlanner {
         if constexpr ((VN + 1) * L < 64) V |= (1ull << (64 - (VN + 1) * L)) - 1;
         const uint64_t S = io.all_clean(V == ~0ull) ? ~0ull : valid_starts(V);
 
-        // ---- anchor bytes, four positions per dword: bit 7 valid, bits 4..1 twice the minimizer's offset in N, bit 0 "N is the
-        //      reverse complement of the k-mer as the text reads it" (cell_probe_of's sh and flip) ----
+        // ---- anchor bytes, four positions per dword: bit 7 valid, bits 6..5 the minimizer's slice class, bits 4..1 twice the
+        //      minimizer's offset in N, bit 0 "N is the reverse complement of the k-mer as the text reads it" (cell_probe_of's sh
+        //      and flip) ----
         static_for<0, L / 4>([&](auto qc) {
             constexpr int q = qc;
             constexpr uint32_t c0 = (8u * q) & 31u;         // twice the position label of the dword's first position
             constexpr uint32_t C4 = c0 | (((c0 + 2u) & 31u) << 8) | (((c0 + 4u) & 31u) << 16) | (((c0 + 6u) & 31u) << 24);
             uint32_t d = low_bytes4(mn[4 * q], mn[4 * q + 1], mn[4 * q + 2], mn[4 * q + 3]);
+            const uint32_t cls = d & 0x60606060u;           // bits 6..5 of the minimum: the minimizer's slice class (order_slice_class)
             // label of the minimum - label of the position, mod 32, in every byte at once (bit 5 keeps the borrows apart)
             d = ((d & 0x1F1F1F1Fu) | 0x20202020u) - C4;
             // bytes whose strand bit is set: the minimizer sits at W - 1 - offset of the reverse complement
@@ -208,7 +210,7 @@ struct StripPlanner {
             d ^= fl * 30u;
             if constexpr (W < 16) d -= fl * (uint32_t)(32 - 2 * W);
             const uint32_t nib = (uint32_t)(S >> (60 - 4 * q)) & 0xFu;
-            res.anchors[q] = (d & 0x1F1F1F1Fu) | ((nib * 0x80402010u) & 0x80808080u);
+            res.anchors[q] = (d & 0x1F1F1F1Fu) | cls | ((nib * 0x80402010u) & 0x80808080u);
         });
         return res;
     }

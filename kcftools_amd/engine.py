@@ -123,7 +123,7 @@ def lib() -> C.CDLL:
         L.kcfx_db_open.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
         L.kcfx_db_open_opts.argtypes = [C.c_char_p, i32, C.POINTER(DbOpts), C.POINTER(vp)]
         L.kcfx_db_open_slice.argtypes = [C.c_char_p, i32, C.POINTER(DbOpts), i32, i32, C.POINTER(vp)]
-        L.kcfx_table_slice_of.argtypes = [C.c_uint32, i32, i32]
+        L.kcfx_table_slice_of.argtypes = [C.c_uint32, i32, i32, i32]
         L.kcfx_screen_ref_partial_async.argtypes = [vp, vp, i32, vp]
         L.kcfx_screen_ref_partial.argtypes = [vp, vp, i32]
         L.kcfx_ref_partial_bytes.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
@@ -214,10 +214,11 @@ def set_cache_fraction(fraction: float) -> float:
     return float(lib().kcfx_set_cache_fraction(float(fraction)))
 
 
-def table_slice_of(g32: int, lbits: int, n_slices: int) -> int:
-    """kcfx_table_slice_of (host only): which of n_slices devices holds the cells of the minimizer whose first-choice line and r
-    are the 32 bits g32 in a table of 2^lbits lines per region; -1 on bad arguments."""
-    return int(lib().kcfx_table_slice_of(C.c_uint32(g32 & 0xFFFFFFFF), int(lbits), int(n_slices)))
+def table_slice_of(g32: int, lbits: int, n_slices: int, slice_class: int = 0) -> int:
+    """kcfx_table_slice_of (host only): which of n_slices devices holds the cells of a minimizer of slice class `slice_class`
+    (0 .. 3: two hash bits of its order key) whose first-choice line and r are the 32 bits g32 in a table of 2^lbits lines per
+    region; -1 on bad arguments."""
+    return int(lib().kcfx_table_slice_of(C.c_uint32(g32 & 0xFFFFFFFF), int(lbits), int(n_slices), int(slice_class)))
 
 
 def device_count() -> int:

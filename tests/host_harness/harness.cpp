@@ -358,8 +358,8 @@ int harness_plan_strips(const uint8_t* text, int64_t readable, int64_t origin, i
     if (L == 16) return plan_strips_k<16>(k, text, readable, origin, n_strips, codes_out, anchors_out);
     return 1;
 }
-// what the planner must produce for the k-mer at text position pos, from the definition: bit 7 valid, bits 4..1 = 2 * offset of
-// the minimizer in N, bit 0 = N is the reverse complement. Returns how many anchors are acceptable (cands[0 ..]): more than one
+// what the planner must produce for the k-mer at text position pos, from the definition: bit 7 valid, bits 6..5 = the slice class
+// of the minimizer (two bits of its order key), bits 4..1 = 2 * offset of the minimizer in N, bit 0 = N is the reverse complement. Returns how many anchors are acceptable (cands[0 ..]): more than one
 // when the minimum key is attained at several offsets -- the planner breaks such ties by position labels relative to its
 // origin, and the build side stores the k-mer at every tied offset (cells_visit).
 int harness_anchor_reference(const uint8_t* text, int64_t pos, int k, int* cands) {
@@ -383,7 +383,7 @@ int harness_anchor_reference(const uint8_t* text, int64_t pos, int k, int* cands
         extract_pair(P.fw(), P.cw(), P.off + j, 16, f, r);
         const bool flip = r < f;
         const int off = flip ? W - 1 - j : j;
-        cands[n++] = (valid ? 0x80 : 0) | (2 * off) | (flip ? 1 : 0);
+        cands[n++] = (valid ? 0x80 : 0) | (int)(order_slice_class(best) << 5) | (2 * off) | (flip ? 1 : 0);
     }
     return n;
 }

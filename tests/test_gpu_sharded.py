@@ -189,6 +189,69 @@ def test_table_partitioned_over_devices(oracle, job, devices):
         assert_same(got2[i], engine.KmcDb.open(prefixes[i]).screen(ref, begins, lens, 3), "-c 3")
 
 
+@pytest.mark.parametrize("k,both,cs", [(31, True, 2), (31, False, 2), (25, True, 1), (19, False, 4)])
+def test_a_slice_walks_its_own_positions(oracle, tmp_path, monkeypatch, k, both, cs):
+    """Round 6: which slice holds a k-mer starts from two hash bits of its minimizer's order key (the slice class), and the anchor
+    byte of every planned reference position carries them -- a planned reference's pass against a slice lists the positions whose
+    class the slice can own and walks the list (screen_k31c_slice_kernel) where round 5 walked every position with the other
+    slices' lanes idle (KCFX_SLICE_WALK_ALL, and what a text-only reference still does). The three forms give the same tile
+    bitmaps and count sums for every slice, bit for bit; the slices merged == the whole table == the oracle. 2 / 4 slices (the
+    class is the slice), 8 (two slices per class), 3 and 5 (classes shared unevenly); plain, extended and three-region tables;
+    the build with and without the probes it keeps between its passes (the class rides in their flag byte)."""
+    import torch
+    L = 260_000
+    ref = synth.random_reference(L, 5 + k, n_run_every=50_000, max_n_run=500, lower_frac=0.1, iupac_rate=2e-4)
+    prefix, *_ = make_db(tmp_path, "own", ref, 31 + k, k=k, p={31: 3, 25: 5, 19: 3}[k], cs=cs, m=7, bins=4, both=both, noise=30_000,
+                         sub_rate=5e-3, indel_rate=5e-4)
+    s, e = engine.windows(len(ref), 7_000, 0, k)
+    rng = np.random.default_rng(k)
+    lens = np.concatenate([e - s, rng.integers(0, 5_000, 30), [0, k - 1, k, 2048 + k - 1]]).astype(np.int32)
+    begins = np.concatenate([s, rng.integers(0, L - 5_000, 30), [3, 9, L - k, 1000]]).astype(np.int64)
+    want = oracle.OracleDb(prefix).screen(ref, begins, lens, 1, threads=4)
+    st = torch.cuda.current_stream().cuda_stream
+    planned = engine.Reference(ref, begins, lens, k)
+    text_only = engine.Reference(ref, begins, lens, k, expected_screens=1)
+    assert planned.planned and not text_only.planned
+    nb, ns = planned.partial_bytes()
+
+    def export(r):
+        b = torch.zeros(nb // 8, dtype=torch.int64, device="cuda:0")
+        c = torch.zeros(ns // 8, dtype=torch.int64, device="cuda:0")
+        r.export_partial_async(b.data_ptr(), c.data_ptr(), st)
+        torch.cuda.synchronize()
+        return b, c
+
+    for variant, n_list in (({}, (2, 4, 8, 3)), ({"KCFX_TABLE_EXT": "1", "KCFX_TABLE_REGIONS": "3"}, (4, 5)), ({"KCFX_LOAD_NO_PROBES": "1"}, (8,))):
+        for name, v in variant.items():
+            monkeypatch.setenv(name, v)
+        for n in n_list:
+            total = None
+            sizes = []
+            for i in range(n):
+                db = engine.KmcDb.open(prefix, n_slices=n, slice=i)
+                sizes.append(int(db.info.stored_kmers))
+                planned.screen_partial(db, 1)
+                listed = export(planned)
+                monkeypatch.setenv("KCFX_SLICE_WALK_ALL", "1")
+                planned.screen_partial(db, 1)
+                walked = export(planned)
+                monkeypatch.delenv("KCFX_SLICE_WALK_ALL")
+                assert torch.equal(listed[0], walked[0]) and torch.equal(listed[1], walked[1]), (variant, n, i)
+                text_only.screen_partial(db, 2)
+                t2 = text_only.finish()
+                planned.screen_partial(db, 2)                                       # (-c 2: the counters' side of the match)
+                assert_same(planned.finish(), t2, f"slice {i} of {n} alone, -c 2: planned (listed) vs text-only")
+                planned.import_partial_async(listed[0].data_ptr(), listed[1].data_ptr(), st)
+                if total is not None:
+                    planned.merge_partial_async(total[0].data_ptr(), total[1].data_ptr(), st)
+                total = export(planned)
+                db.close()
+            assert_same(planned.finish(), want, f"{n} slices merged vs oracle ({variant})")
+            assert max(sizes) < (1.0 / n + 0.08) * sum(sizes) + 2_000, (n, sizes)     # the classes are even: no slice much over its share
+        for name in variant:
+            monkeypatch.delenv(name)
+
+
 def test_slice_loaders_share_one_file_stream(oracle, job, monkeypatch):
     """Round 6: the G loaders of a table-sharded sample read the .kmc_suf ONCE between them (a cache of pinned chunks: whoever asks
     first reads, the siblings copy from the same buffer). With the file streamed once per build pass and chunks of 4 099 records

@@ -112,14 +112,25 @@ def test_table_mode_gives_every_device_every_sample_and_the_slices_partition_the
     assert engine.shard_plan(wl, K, 5, 5)[1] != engine.SHARD_TABLE         # never chosen by AUTO
     rng = np.random.default_rng(11)
     g32 = rng.integers(0, 1 << 32, 200_000, dtype=np.uint64)
+    cls = rng.integers(0, 4, 200_000)
     for n in (1, 2, 3, 4, 7, 8, 64):
-        sl = np.array([engine.table_slice_of(int(g), 27, n) for g in g32[:20_000]])
+        sl = np.array([engine.table_slice_of(int(g), 27, n, int(c)) for g, c in zip(g32[:20_000], cls)])
         assert sl.min() >= 0 and sl.max() < n and len(np.unique(sl)) == n
         cnt = np.bincount(sl, minlength=n)
         assert cnt.max() <= 1.25 * cnt.mean() + 40, cnt                     # even within sampling noise
-    # a function of the 32 bits alone, whatever the table's size says about which of them are the line (same bits, same slice)
-    assert all(engine.table_slice_of(int(g), 24, 4) == engine.table_slice_of(int(g), 29, 4) for g in g32[:2000])
-    # the k-mers of one line do not sit on one slice (the line number alone does not decide)
+        # the slice class (two bits of the minimizer's order key, which the anchor bytes of a planned reference carry) leads: a class
+        # belongs to the slices of one contiguous range -- one slice when n is 2 or 4, two of eight -- so a pass against a slice
+        # knows from the anchors alone which positions are not its own
+        for c in range(4):
+            mine = np.unique(sl[cls[:20_000] == c])
+            assert len(mine) == mine.max() - mine.min() + 1 and len(mine) <= (n + 3) // 4 + 1
+            assert mine.min() == (c * n) // 4
+        if n in (2, 4):
+            assert np.array_equal(sl, cls[:20_000] * n // 4)
+    # a function of the class and the 32 bits alone, whatever the table's size says about which of them are the line
+    assert all(engine.table_slice_of(int(g), 24, 8, 2) == engine.table_slice_of(int(g), 29, 8, 2) for g in g32[:2000])
+    # within a class the hash of (line : r) decides, not the line number alone
     line = 0x5A5A5 << 12
-    assert len({engine.table_slice_of(line | r, 20, 4) for r in range(4096)}) == 4
+    assert len({engine.table_slice_of(line | r, 20, 16, 1) for r in range(4096)}) == 4
     assert engine.table_slice_of(1, 27, 0) == -1 and engine.table_slice_of(1, 27, 65) == -1 and engine.table_slice_of(1, 5, 4) == -1
+    assert engine.table_slice_of(1, 27, 4, 4) == -1 and engine.table_slice_of(1, 27, 4, -1) == -1
