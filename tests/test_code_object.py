@@ -53,6 +53,13 @@ def test_screening_kernels_do_not_spill_and_fit_their_occupancy(kernels):
             assert m["group_segment_fixed_size"] <= (4864 if text_only(name) else 5888), (name, m)
         elif "screen_" in name:
             assert m["group_segment_fixed_size"] <= 20480, (name, m)     # 160 KB LDS per CU / 8 workgroups
+    # a planned reference against a table slice (round 6): the list of the slice's positions beside the plan and the queues -- 9.7 KB,
+    # 16 workgroups of two waves per CU = the 8 waves per SIMD its 64 registers allow. With the hits as one byte per position in
+    # LDS (12 KB, 13 workgroups) a pass took 1.12 ms where this form takes 0.90 (profiles/r06_notes.md section 11)
+    sliced = {n: m for n, m in kernels.items() if "screen_k31c_slice_kernel" in n}
+    assert len(sliced) == 26                                             # k = 19 .. 31 x canonical / forward-only
+    for name, m in sliced.items():
+        assert m["private_segment_fixed_size"] == 0 and m["vgpr_count"] <= 64 and m["group_segment_fixed_size"] <= 10240, (name, m)
 
 
 def test_no_kernel_of_the_library_uses_scratch(kernels):
