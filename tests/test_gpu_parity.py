@@ -735,6 +735,28 @@ def test_fuzz_window_geometry_against_oracle(oracle, tmp_path, seed, kernel, mon
         n = 2 + (seed // 2) % 3
         sl, _ = engine.screen_sharded([prefix], k, ref, begins, lens, minc, devices=(0,) * n, mode=engine.SHARD_TABLE)
         assert_same(sl[0], want, f"fuzz seed {seed}: {n} table slices (k={k}, cs={cs}, both={both}, -c {minc}, kernel {kernel})")
+        if kernel == "default":
+            # (one sample: the call above keeps its references text-only.) A PLANNED reference against the slices -- the pass that
+            # lists the positions of the slice's minimizer classes and walks the list (screen_k31c_slice_kernel) -- slice after
+            # slice into one reference's tiles, n and 2 n slices
+            for m in (n, 2 * n):
+                r = engine.Reference(ref, begins, lens, k)
+                assert r.planned
+                import torch
+                st = torch.cuda.current_stream().cuda_stream
+                nb, ns = r.partial_bytes()
+                acc = None
+                for i in range(m):
+                    d = engine.KmcDb.open(prefix, n_slices=m, slice=i)
+                    r.screen_partial(d, minc)
+                    if acc is not None:
+                        r.merge_partial_async(acc[0].data_ptr(), acc[1].data_ptr(), st)
+                    acc = (torch.zeros(nb // 8, dtype=torch.int64, device="cuda:0"), torch.zeros(ns // 8, dtype=torch.int64, device="cuda:0"))
+                    r.export_partial_async(acc[0].data_ptr(), acc[1].data_ptr(), st)
+                    torch.cuda.synchronize()
+                    d.close()
+                assert_same(r.finish(), want, f"fuzz seed {seed}: planned reference, {m} table slices (k={k}, cs={cs}, both={both}, -c {minc})")
+                r.close()
     assert_scores(oracle, got, want)
 
 
