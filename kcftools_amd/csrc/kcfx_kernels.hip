@@ -2069,25 +2069,21 @@ __global__ __launch_bounds__(PLANNED ? CELLS_BLOCK : TEXT_BLOCK) __attribute__((
 // ======================================================================================================
 // Every device of a node walks the whole reference against its slice of the table. In screen_k31c_kernel that walk costs a slice
 // what it costs a whole table -- keys, minimizer, cell address, match and ballots for all 64 lanes of every word, with the 1 / S of
-// them that are this slice's switched on: a pass against one of four slices took 5.0 ms where the whole table's took 9.95
-// (profiles/r05_notes.md section 4), all of it instruction issue. Here the anchor bytes decide first: a wave reads the anchor of
-// every position of its words (one LDS byte each), keeps the positions whose minimizer's slice class this slice can own
-// (cell_slice_classes: exact with 2 or 4 slices) in a list in LDS -- ~10 VALU instructions per word -- and then walks the LIST 64
-// entries at a time with the code of screen_k31c_kernel's word loop (same probe, same cell loads in a ring of CELLS_PIPE, same
-// match, same queue for the k-mers that are looked up further). A lane's k-mer now sits at any position of the wave's words, so
-// it derives its LDS addresses from the position (~12 instructions more per list word) and a hit is one byte in LDS per position,
-// gathered into the tile's hit words at the end; the validity words do not depend on the slice and are written by the first phase.
+// them that are this slice's switched on: a pass against one of four slices took 5.0 - 5.15 ms where the whole table's took 9.9,
+// all of it instruction issue. Here the anchor bytes decide first: a wave reads the anchor of every position of its words (one
+// LDS byte each), keeps the positions whose minimizer's slice class this slice can own (cell_slice_classes: exact with 2 or 4
+// slices) in a list in LDS -- ~10 VALU instructions per word -- and then walks the LIST 64 entries at a time with the code of
+// screen_k31c_kernel's word loop (same probe, same cell loads in a ring of CELLS_PIPE, same match, same queues for the k-mers that
+// are looked up further). A lane's k-mer now sits at any position of the wave's words, so it derives its LDS addresses from the
+// position (~12 instructions more per list word), and a hit is OR-ed into the tile's hit word in LDS (one byte per position,
+// gathered at the end, costs 2 KB more LDS per workgroup = 13 workgroups per CU instead of 16: 1.12 ms where this form takes 0.90);
+// the validity words do not depend on the slice and are written by the first phase. 3.45 ms for that pass (profiles/r06_notes.md
+// section 11): 0.55 x the instructions, and a wave's life is now mostly its waits.
 constexpr int SLICE_LIST = CELLS_WORDS_PER_WAVE * 64;       // positions of a wave's words
-#ifndef KCFX_SLICE_HIT_BYTES
-#define KCFX_SLICE_HIT_BYTES 0
-#endif
 struct SliceWave {
     uint16_t list[SLICE_LIST];                              // (word of the wave << 6) | lane of the positions this slice may own, ascending
-#if KCFX_SLICE_HIT_BYTES
-    __attribute__((aligned(16))) uint8_t hit[SLICE_LIST];   // 1: the k-mer at that position is in the slice's table with a counter >= -c
-#endif
 };
-static_assert(SLICE_LIST <= 1024 && SLICE_LIST % 1024 == 0, "a position of the wave in 10 bits (queue ids keep 16); the hit bytes are cleared 16 per lane");
+static_assert(SLICE_LIST <= 1024, "a position of the wave in 10 bits (queue ids keep 16)");
 
 // N, sh2, fm (PlannedWords::next) of the k-mer at packed position q of the tile, from its anchor byte
 template <int K>
@@ -2128,12 +2124,7 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
     uint64_t* my_bits = bits + (size_t)blockIdx.x * TILE_BITS_U64;
 
     // ---- phase 1: the anchors of the wave's words -> validity words + the list of the positions this slice may own ----
-#if KCFX_SLICE_HIT_BYTES
-#pragma unroll
-    for (int i = 0; i < SLICE_LIST / (64 * 16); ++i) reinterpret_cast<uint4*>(sw.hit)[i * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
-#else
     if (lane < CELLS_WORDS_PER_WAVE) q.hit[lane] = 0ull;    // the hit words: the lanes that find their k-mer OR their bit in
-#endif
     int n_list = 0;                                         // (wave-uniform)
     {
         // (all the anchor reads first, then the words: one LDS round trip per wave, not one per word; a word behind the wave's
@@ -2165,11 +2156,7 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
     int64_t big_acc = 0;
     auto found = [&](uint32_t id, uint32_t cnt, uint32_t, bool) {
         if ((int32_t)cnt < min_count) return;               // GetVariants.java:224
-#if KCFX_SLICE_HIT_BYTES
-        sw.hit[id & (SLICE_LIST - 1)] = 1;
-#else
         atomicOr(&q.hit[(id >> 6) & (uint32_t)(CELLS_WORDS_PER_WAVE - 1)], 1ull << (id & 63));
-#endif
         if (cnt > CELL_COUNT_MAX) big_acc += (int64_t)(int32_t)cnt;     // GetVariants.java:226
         else sum_acc += cnt;
     };
@@ -2205,11 +2192,7 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
         uint64_t M = 0;
         cells_match<BOTH, cell_nw(K)>(cw, tv.lbits, cnt, pend, &M);
         const uint64_t H = wave_ballot((int32_t)cnt >= min_count);          // GetVariants.java:224 (cnt is 0 outside cw.V: cells_match)
-#if KCFX_SLICE_HIT_BYTES
-        if (__builtin_amdgcn_inverse_ballot_w64(H)) sw.hit[lw.id] = 1;
-#else
         if (__builtin_amdgcn_inverse_ballot_w64(H)) atomicOr(&q.hit[lw.id >> 6], 1ull << (lw.id & 63));
-#endif
         sum_acc += cnt;                                                     // GetVariants.java:226 (see screen_k31c_kernel)
         if constexpr (cell_nw(K) > CELL_ALT_FREE_MAX_W) {
             const uint64_t low = M & ~H;
@@ -2260,14 +2243,7 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
     flush_rest();
     wave_lds_fence();
 
-    // ---- phase 3: the hit bytes -> the tile's hit words ----
-#if KCFX_SLICE_HIT_BYTES
-    for (int w = w_begin; w < w_end; ++w) {
-        const uint64_t H = wave_ballot(sw.hit[((w - w_begin) << 6) | lane] != 0);
-        if (lane == 0) q.hit[w - w_begin] = H;
-    }
-    wave_lds_fence();
-#endif
+    // ---- the wave's words of the tile's bitmaps ----
     if (lane < w_end - w_begin) {
         my_bits[w_begin + lane] = q.vw[lane];
         my_bits[TILE_WORDS + w_begin + lane] = q.hit[lane];
