@@ -2077,7 +2077,7 @@ __global__ __launch_bounds__(PLANNED ? CELLS_BLOCK : TEXT_BLOCK) __attribute__((
 // are looked up further). A lane's k-mer now sits at any position of the wave's words, so it derives its LDS addresses from the
 // position (~12 instructions more per list word), and a hit is OR-ed into the tile's hit word in LDS (one byte per position,
 // gathered at the end, costs 2 KB more LDS per workgroup = 13 workgroups per CU instead of 16: 1.12 ms where this form takes 0.90);
-// the validity words do not depend on the slice and are written by the first phase. 3.45 ms for that pass (profiles/r06_notes.md
+// the validity words do not depend on the slice and are written by the first phase. 3.34 ms for that pass (profiles/r06_notes.md
 // section 11): 0.55 x the instructions, and a wave's life is now mostly its waits.
 constexpr int SLICE_LIST = CELLS_WORDS_PER_WAVE * 64;       // positions of a wave's words
 struct SliceWave {
@@ -2169,15 +2169,16 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
         CellWord cw;
         uint32_t id;
     };
-    auto issue = [&](int c, ListWord& lw) {
-        const int n = min(n_list - 64 * c, 64);
+    // a list word in three steps -- its entries, their anchors, their k-mers (three dependent LDS reads) -- and the probe + load
+    auto entry_of = [&](int c) -> uint32_t {                // (behind the list's end: some position of the wave, masked out of V)
+        return sw.list[(64 * c + lane) & (SLICE_LIST - 1)] & (uint32_t)(SLICE_LIST - 1);
+    };
+    auto launch = [&](int c, uint32_t id, int32_t a, uint64_t N, ListWord& lw) {
+        const int n = max(0, min(n_list - 64 * c, 64));
         uint64_t V = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
-        const uint32_t id = sw.list[(64 * c + lane) & (SLICE_LIST - 1)] & (SLICE_LIST - 1);     // (behind the list's end: some position of the wave, masked out of V)
-        const int32_t a = (int32_t)an[id];
         uint32_t fm;
         asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(fm) : "v"(a));
         const uint32_t sh2 = (uint32_t)a & 30u;
-        const uint64_t N = planned_kmer_at<K>(sh, pos0 + (int)id, fm);
         uint32_t g;
         CellProbe p = cell_probe_planned<BOTH>(N, sh2, fm, tv.lbits, tv.ext, &g);
         // (3, 5, 6, 7 or more than 4 slices: some classes are shared by two slices -- the hash of (line : r) decides)
@@ -2185,6 +2186,16 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
         if (tv.regions > 1) p.line |= cell_region_of(g, (uint32_t)tv.regions) << tv.lbits;
         lw.id = id;
         cells_issue<cell_nw(K), BOTH>(tv, V, p, (uint32_t)a, lw.cw);
+    };
+    auto kmer_of = [&](uint32_t id, int32_t a) -> uint64_t {
+        uint32_t fm;
+        asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(fm) : "v"(a));
+        return planned_kmer_at<K>(sh, pos0 + (int)id, fm);
+    };
+    auto issue = [&](int c, ListWord& lw) {
+        const uint32_t id = entry_of(c);
+        const int32_t a = (int32_t)an[id];
+        launch(c, id, a, kmer_of(id, a), lw);
     };
     auto retire = [&](int, const ListWord& lw) {
         const CellWord& cw = lw.cw;
@@ -2218,12 +2229,24 @@ __global__ __launch_bounds__(CELLS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
         }
     };
     const int c_end = (n_list + 63) >> 6;
-    constexpr int D = CELLS_PIPE;
+    constexpr int D = CELLS_PIPE;                           // (5 and 6 list words in flight measure the same: 0.87 / 0.89 ms against 0.88)
     ListWord lw[D];
     int base = 0;
+    {
+        // the first D - 1 list words side by side, no condition between them (one block of code: the three LDS round trips of
+        // each overlap with the others'; a word behind the list's end loads line 0 with every lane masked and is never retired)
+        uint32_t id[D - 1];
+        int32_t a[D - 1];
+        uint64_t N[D - 1];
 #pragma unroll
-    for (int i = 0; i < D - 1; ++i)
-        if (i < c_end) issue(i, lw[i]);
+        for (int i = 0; i < D - 1; ++i) id[i] = entry_of(i);
+#pragma unroll
+        for (int i = 0; i < D - 1; ++i) a[i] = (int32_t)an[id[i]];
+#pragma unroll
+        for (int i = 0; i < D - 1; ++i) N[i] = kmer_of(id[i], a[i]);
+#pragma unroll
+        for (int i = 0; i < D - 1; ++i) launch(i, id[i], a[i], N[i], lw[i]);
+    }
     for (; base + 2 * D - 2 < c_end; base += D) {
 #pragma unroll
         for (int i = 0; i < D; ++i) {
