@@ -1411,14 +1411,34 @@ int32_t kcfx::db_open_slice_shared(const char* kmc_prefix, int32_t device, const
     const double t0 = now_s();
     KmcHeader h;
     LoadTrace tr;
-    {
-        std::string perr;
-        if (int32_t rc = parse_prefix_file(std::string(kmc_prefix) + ".kmc_pre", h, perr)) return fail(rc, perr);
-    }
+    // The first open of a process on a device brings up the device's context and the loads' stream pair: 60 - 70 ms of the
+    // runtime's, none of it this thread's to do -- a helper takes it while the .kmc_pre is read and checked (11 - 17 ms of host work
+    // for the bench database; every later open finds the streams made and the helper returns at once)
+    hipStream_t load_stream = nullptr;
+    hipError_t stream_rc = hipSuccess;
+    bool device_ok = true;
+    std::thread bring_up([&] {
+        DeviceGuard hg(device);
+        device_ok = hg.ok;
+        if (device_ok) stream_rc = db_stream(device, &load_stream, nullptr, true);
+    });
+    struct Joined {                             // (whatever the parse throws)
+        std::thread& t;
+        ~Joined() { if (t.joinable()) t.join(); }
+    } joined{bring_up};
+    std::string perr;
+    const int32_t parse_rc = parse_prefix_file(std::string(kmc_prefix) + ".kmc_pre", h, perr);
     tr.mark("parse .kmc_pre");
+    bring_up.join();
+    struct LoadDone {                           // (the stream is another load's to take again when this one is over, however it ends)
+        hipStream_t st;
+        ~LoadDone() { if (st) db_stream_load_done(st); }
+    } load_done{device_ok && stream_rc == hipSuccess ? load_stream : nullptr};
+    if (parse_rc) return fail(parse_rc, perr);   // (a file that cannot be read is reported before a device that cannot be used)
     if (int32_t rc = check_device(device)) return rc;
     DeviceGuard g(device);
-    if (!g.ok) return fail(KCFX_ERR_DEVICE, "hipSetDevice failed");
+    if (!g.ok || !device_ok) return fail(KCFX_ERR_DEVICE, "hipSetDevice failed");
+    if (stream_rc != hipSuccess) return hip_fail(stream_rc, "hipStreamCreate");
     DbHold hold;
     kcfx_db* db = hold.p = new kcfx_db();
     db->device = device;
@@ -1429,12 +1449,7 @@ int32_t kcfx::db_open_slice_shared(const char* kmc_prefix, int32_t device, const
     db->slice = slice;
     db->info.table_slices = n_slices;
     db->info.table_slice = slice;
-    hipError_t e = db_stream(device, &db->stream, nullptr, true);
-    if (e != hipSuccess) return hip_fail(e, "hipStreamCreate");
-    struct LoadDone {                           // (the stream is another load's to take again when this one is over, however it ends)
-        hipStream_t st;
-        ~LoadDone() { db_stream_load_done(st); }
-    } load_done{db->stream};
+    db->stream = load_stream;
     tr.mark("device + stream");
     // a slice holds 1 / n of the k-mers (a hash of the minimizer decides: + 2 % and a few thousand for the unevenness) -- the table is
     // sized for that many, every pass still walks the whole file
