@@ -23,6 +23,8 @@ class FastaIndex {
     const FaidxEntry* find(const std::string& name) const;
     // FastaIndex.getSequence (:122-182): bases [start, start+length) by (offset, lineBases, lineWidth) arithmetic
     bool get_sequence(const FaidxEntry& e, int64_t start, int64_t length, std::string& out, std::string& err) const;
+    // the same bases appended to `out` (the driver builds one text of all windows: no second copy of a chromosome)
+    bool append_sequence(const FaidxEntry& e, int64_t start, int64_t length, std::string& out, std::string& err) const;
     static bool generate(const std::string& fasta_path, std::vector<FaidxEntry>& out, std::string& err);   // :239-299
     static std::string to_text(const std::vector<FaidxEntry>& entries);
 

@@ -213,6 +213,11 @@ int main(int argc, char** argv) {
     hdr.wr = o.wr;
 
     std::string text;
+    if (!targeted) {                                      // (every contig once: no regrowth while it is assembled)
+        size_t total = 0;
+        for (const auto& e : index.entries()) total += (size_t)e.length;
+        text.reserve(total);
+    }
     std::vector<Win> wins;
     std::vector<std::pair<size_t, size_t>> per_contig;    // [first, last) into wins, in .faidx order
     for (const auto& e : index.entries()) {
@@ -225,11 +230,7 @@ int main(int argc, char** argv) {
             std::vector<int32_t> s((size_t)n), en((size_t)n);
             if (n && kcfx_windows(e.length, o.window, o.step, k, s.data(), en.data(), n, &n)) error(kcfx_last_error());
             const int64_t base = (int64_t)text.size();
-            if (e.length > 0) {
-                std::string seq;
-                if (!index.get_sequence(e, 0, e.length, seq, err)) error(err);
-                text += seq;
-            }
+            if (e.length > 0 && !index.append_sequence(e, 0, e.length, text, err)) error(err);
             for (int64_t i = 0; i < n; ++i)
                 wins.push_back(Win{e.name + "_" + std::to_string(s[(size_t)i]), e.name, s[(size_t)i], en[(size_t)i], base + s[(size_t)i],
                                    en[(size_t)i] - s[(size_t)i], wins.size()});
@@ -313,27 +314,46 @@ int main(int argc, char** argv) {
         if (kcfx_score(res[s], n, o.wi, o.wt, o.wr, score[s].data(), depth[s].data())) error(kcfx_last_error());   // Data.java:101-103
     }
 
-    // sort each contig's windows by start (:169-171); ties keep generation order
     hdr.n_windows = n;
     std::ofstream out(o.out, std::ios::binary);
     if (!out) error("Error writing KCF file: " + o.out);
     info("Writing KCF file: " + o.out);
     out << kcf_header_text(hdr);
+    // the rows in file order: each contig's windows by start (:169-171; ties keep generation order) ...
+    std::vector<size_t> order;
+    order.reserve(wins.size());
     for (const auto& pc : per_contig) {
-        std::vector<size_t> order;
+        const size_t at = order.size();
         for (size_t i = pc.first; i < pc.second; ++i) order.push_back(i);
-        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return wins[a].start < wins[b].start; });
-        for (size_t i : order) {
+        std::stable_sort(order.begin() + (std::ptrdiff_t)at, order.end(), [&](size_t a, size_t b) { return wins[a].start < wins[b].start; });
+    }
+    // ... formatted by a few threads, a contiguous range of rows each (Java's %.2f and Float.toString per sample column are most of
+    // what a multi-sample run does after its last launch), written in order
+    const int T = (int)std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency()), order.size() / 512 + 1}));
+    std::vector<std::string> part((size_t)T);
+    auto format_rows = [&](int t) {
+        const size_t lo = order.size() * (size_t)t / (size_t)T, hi = order.size() * (size_t)(t + 1) / (size_t)T;
+        std::string& dst = part[(size_t)t];
+        dst.reserve((hi - lo) * (64 + 40 * S));
+        for (size_t r = lo; r < hi; ++r) {
+            const size_t i = order[r];
             if (S == 1) {
-                out << kcf_row_text(wins[i].seq, wins[i].start, wins[i].end, wins[i].id, res[0][i], score[0][i], depth[0][i]) << "\n";
+                dst += kcf_row_text(wins[i].seq, wins[i].start, wins[i].end, wins[i].id, res[0][i], score[0][i], depth[0][i]);
             } else {
                 std::vector<SampleCol> cols;
                 for (size_t s = 0; s < S; ++s) cols.push_back(cohort_sample(res[s][i], score[s][i], depth[s][i]));
-                out << kcf_row_text_multi(wins[i].seq, wins[i].start, wins[i].end, wins[i].id, res[0][i].total_kmers,
-                                          res[0][i].eff_length, cols) << "\n";
+                dst += kcf_row_text_multi(wins[i].seq, wins[i].start, wins[i].end, wins[i].id, res[0][i].total_kmers, res[0][i].eff_length, cols);
             }
+            dst += '\n';
         }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back(format_rows, t);
+        format_rows(0);
+        for (auto& x : th) x.join();
     }
+    for (const auto& p : part) out.write(p.data(), (std::streamsize)p.size());
     out.close();
     if (!out) error("Error writing KCF file: " + o.out);
     mark("scores + KCF written");
