@@ -345,6 +345,7 @@ def realistic_leg(engine, torch, synth_bin, workdir, ref_len, window, min_count,
     return out
 
 
+_EPOCH = re.compile(r"^\[kcftools-amd\] epoch (.*?)\s+([0-9]+\.[0-9]+)\s*$", re.M)
 _PHASE = re.compile(r"^\[(kcftools-amd|kcfx \w+)\]\s+(.*?)\s+([0-9.]+) ms\s*$")
 
 
@@ -360,9 +361,11 @@ def end_to_end_runs(cli, fa, prefix, window, min_count, device, n_runs):
     kcf = prefix + ".bench.kcf"
     for _ in range(n_runs):
         t0 = time.perf_counter()
+        e0 = time.time()
         pr = subprocess.run([cli, "getVariations", "-r", fa, "-k", prefix, "-o", kcf, "-s", "bench", "-f", "window",
                              "-w", str(window), "-c", str(min_count), "--device", str(device)], capture_output=True, text=True, env=env)
         wall = time.perf_counter() - t0
+        e1 = time.time()
         if pr.returncode != 0:
             raise RuntimeError(pr.stdout[-500:] + pr.stderr[-500:])
         phases = {}
@@ -373,6 +376,12 @@ def end_to_end_runs(cli, fa, prefix, window, min_count, device, n_runs):
                 phases[key] = round(phases.get(key, 0.0) + float(m.group(3)), 1)
         accounted = sum(v for k_, v in phases.items() if k_.startswith("cli: "))
         phases["process start + exit (wall - the driver's phases)"] = round(wall * 1e3 - accounted, 1)
+        # ... split by the driver's own wall-clock stamps: spawn -> main() (exec, the dynamic linker, the ROCm libraries' initialisers)
+        # and "leaving" -> reaped (the kernel taking the process's device memory and queues down)
+        stamps = dict(_EPOCH.findall(pr.stderr))
+        if "main entered" in stamps and "leaving" in stamps:
+            phases["process start (spawn -> main)"] = round((float(stamps["main entered"]) - e0) * 1e3, 1)
+            phases["process exit (leaving -> reaped)"] = round((e1 - float(stamps["leaving"])) * 1e3, 1)
         split = [ln for ln in pr.stdout.splitlines() if "Screened" in ln]
         runs.append({"seconds_wall": round(wall, 4), "phases_ms": phases, "breakdown": split[-1].split(" - ")[-1] if split else ""})
     rows = sum(1 for ln in open(kcf) if not ln.startswith("#"))

@@ -98,6 +98,13 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "[kcftools-amd] %-34s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
         t_prev = t;
     };
+    auto epoch = [&](const char* what) {      // (KCFX_CLI_TRACE: wall-clock stamps a parent can hold against its own spawn / wait times)
+        if (!trace_on) return;
+        timeval tv;
+        gettimeofday(&tv, nullptr);
+        std::fprintf(stderr, "[kcftools-amd] epoch %-28s %ld.%06ld\n", what, (long)tv.tv_sec, (long)tv.tv_usec);
+    };
+    epoch("main entered");
     Options o;
     std::string cmdline = "kcftools-amd";
     for (int i = 1; i < argc; ++i) cmdline += std::string(" ") + argv[i];
@@ -357,10 +364,6 @@ int main(int argc, char** argv) {
     out.close();
     if (!out) error("Error writing KCF file: " + o.out);
     mark("scores + KCF written");
-    // The file is closed and every handle of the library released: leave without the runtime's exit handlers (unloading the HIP
-    // runtime and its code objects takes tens of milliseconds of a half-second job; the driver reclaims the process's device state
-    // either way). KCFX_CLI_FULL_EXIT=1: return through them.
-    std::fflush(nullptr);                   // (the log lines go through stdio)
-    if (std::getenv("KCFX_CLI_FULL_EXIT") == nullptr) std::_Exit(0);
+    epoch("leaving");
     return 0;
 }
