@@ -79,7 +79,11 @@ def test_committed_bench_line_has_the_contract_fields():
     for run in e["runs"] + e["after_churn"]["runs"]:
         ph = run["phases_ms"]
         assert any(k.startswith("cli: kcfx_screen_sharded") for k in ph) and any(k.startswith("load: ") for k in ph)
-        assert abs(sum(v for k, v in ph.items() if k.startswith("cli: ") or k.startswith("process")) - 1e3 * run["seconds_wall"]) < 1.0
+        rest = "process start + exit (wall - the driver's phases)"
+        assert abs(sum(v for k, v in ph.items() if k.startswith("cli: ") or k == rest) - 1e3 * run["seconds_wall"]) < 1.0
+        # ... and the rest split by the driver's wall-clock stamps: spawn -> main(), the return from main() -> reaped
+        split = [ph[k] for k in ("process start (spawn -> main)", "process exit (leaving -> reaped)")]
+        assert all(v >= 0 for v in split) and abs(sum(split) - ph[rest]) < 5.0
     assert len(e["after_churn"]["runs"]) == 2 and max(e["seconds_wall_all_runs"] + e["after_churn"]["seconds_wall_all_runs"]) < d["cpu_end_to_end"]["seconds_wall"]
     assert d["setup_seconds"]["db_open"] < 0.3
     # the CPU leg says how many cores it really had
