@@ -72,7 +72,7 @@ def test_sharded_run_equals_single_process(tmp_path, world, n_samples, mode):
     import time
     ctx = mp.get_context("spawn")
     parts = None
-    for attempt in range(2):                       # one retry: the rendezvous port can be taken between probe and bind
+    for attempt in range(3):                       # retries: the rendezvous port can be taken between probe and bind
         q = ctx.Queue()
         port = free_port()
         procs = [ctx.Process(target=worker, args=(r, world, port, str(tmp_path), n_samples, mode, q)) for r in range(world)]
