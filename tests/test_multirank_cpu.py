@@ -189,7 +189,7 @@ def test_table_slices_meet_range_by_range(world):
     import time
     ctx = mp.get_context("spawn")
     got = {}
-    for attempt in range(2):
+    for attempt in range(3):
         got = {}
         q = ctx.Queue()
         port = free_port()
@@ -234,7 +234,7 @@ def test_table_slices_meet_on_rank_zero(world):
     import time
     ctx = mp.get_context("spawn")
     got = None
-    for attempt in range(2):
+    for attempt in range(3):
         q = ctx.Queue()
         port = free_port()
         procs = [ctx.Process(target=table_worker, args=(r, world, port, q)) for r in range(world)]
