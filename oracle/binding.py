@@ -34,8 +34,16 @@ def build(force: bool = False) -> str:
         return os.environ["KCF_ORACLE_SO"]
     so = os.path.join(_HERE, "libkcforacle.so")
     src = [os.path.join(_HERE, f) for f in ("kcf_oracle.c", "kcf_oracle.h")]
-    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
-        subprocess.run(["make", "-C", _HERE, "libkcforacle.so"], check=True, capture_output=True)
+    def stale():
+        return not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src)
+    if force or stale():
+        # one builder at a time: the ranks of a multi-process test import this module side by side, and a fresh checkout gives
+        # sources and library timestamps in any order -- a second `make` must not overwrite the file a sibling is loading
+        import fcntl
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if force or stale():
+                subprocess.run(["make", "-C", _HERE, "libkcforacle.so"] + (["-B"] if force else []), check=True, capture_output=True)
     return so
 
 

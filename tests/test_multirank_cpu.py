@@ -23,14 +23,17 @@ def free_port():
     return p
 
 
-def make_inputs(tmpdir, n_samples):
+def make_inputs(tmpdir, n_samples, write=True):
+    """write=True: the parent, ONCE, before the ranks start; a rank passes False and finds the databases written (every rank writing
+    the same files while its siblings read them was a race: a rank now and then opened a half-written .kmc_suf and died)"""
     ref = synth.random_reference(60_000, 7, n_run_every=9000, max_n_run=300)
     prefixes = []
     for s in range(n_samples):
-        prm = synth.KmcParams(k=K, p=3, counter_size=2, sig_len=5, n_bins=4)
-        kmers, counts = synth.build_sample_db(synth.mutate_sample(ref, 100 + s), prm, 200 + s, noise_kmers=500)
         prefix = os.path.join(tmpdir, f"s{s}")
-        synth.write_kmc(prefix, kmers, counts, prm)
+        if write:
+            prm = synth.KmcParams(k=K, p=3, counter_size=2, sig_len=5, n_bins=4)
+            kmers, counts = synth.build_sample_db(synth.mutate_sample(ref, 100 + s), prm, 200 + s, noise_kmers=500)
+            synth.write_kmc(prefix, kmers, counts, prm)
         prefixes.append(prefix)
     starts, ends = synth.tiling_windows(len(ref), 5_000, K)
     return ref, prefixes, starts, ends - starts
@@ -41,7 +44,7 @@ def worker(rank, world, port, tmpdir, n_samples, mode, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import binding as oracle
-    ref, prefixes, wb, wl = make_inputs(tmpdir, n_samples)
+    ref, prefixes, wb, wl = make_inputs(tmpdir, n_samples, write=False)
     if mode == "samples":
         mine = shard.samples_of_rank(n_samples, world, rank)
         recs = [oracle.OracleDb(prefixes[s]).screen(ref, wb, wl, 1) for s in mine]
@@ -71,6 +74,8 @@ def test_sharded_run_equals_single_process(tmp_path, world, n_samples, mode):
     import queue as _queue
     import time
     ctx = mp.get_context("spawn")
+    oracle.build()                                 # (and the oracle's library: the ranks only load it)
+    ref, prefixes, wb, wl = make_inputs(str(tmp_path), n_samples)
     parts = None
     for attempt in range(3):                       # retries: the rendezvous port can be taken between probe and bind
         q = ctx.Queue()
@@ -94,7 +99,6 @@ def test_sharded_run_equals_single_process(tmp_path, world, n_samples, mode):
             assert all(p.exitcode == 0 for p in procs)
             break
     assert parts is not None, "multi-rank run did not produce a result"
-    ref, prefixes, wb, wl = make_inputs(str(tmp_path), n_samples)
     if mode == "samples":
         for r in range(world):
             got = parts[r].view(oracle.RESULT_DTYPE)
