@@ -11,17 +11,24 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES" 
   i=$((i + 1))
   timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc_$i -o p -- python3 tools/table_slices_probe.py "$@" > $OUT/probe_$i.log 2>&1
 done
-python3 - <<PY
+python3 - <<PY > $OUT/summary.log
 import csv, glob, collections
+print("# tools/pmc_slices.sh $TAG $* (one MI355X; rocprofv3 --pmc, one counter group per run of tools/table_slices_probe.py)")
+print("# per launch = one pass of the whole reference against ONE slice (whole_table: against the unsliced table, the probe's first four launches)")
+print("# walk_all = screen_k31c_kernel, every position, the other slices' lanes idle (KCFX_SLICE_WALK_ALL); slice_list = screen_k31c_slice_kernel")
 acc = collections.defaultdict(lambda: [0.0, 0])
-for f in glob.glob("$OUT/pmc_*/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        n = r["Kernel_Name"]
-        kind = "slice_list" if "screen_k31c_slice_kernel" in n else "walk_all_or_whole" if "screen_k31c_kernel" in n else None
-        if kind is None:
-            continue
-        a = acc[(kind, int(r["Grid_Size"]), r["Counter_Name"])]
-        a[0] += float(r["Counter_Value"]); a[1] += 1
-for (kind, grid, name), (v, c) in sorted(acc.items()):
-    print(f"{kind:18s} grid {grid:9d} {name:24s} per launch {v / c:16.0f}  ({c} launches)")
+for f in sorted(glob.glob("$OUT/pmc_*/**/*counter_collection.csv", recursive=True)):
+    rows = list(csv.DictReader(open(f)))
+    whole = sorted({int(r["Dispatch_Id"]) for r in rows if "screen_k31c_kernel" in r["Kernel_Name"]})[:4]
+    for r in rows:
+        n, d = r["Kernel_Name"], int(r["Dispatch_Id"])
+        if "screen_k31c_slice_kernel" in n: kind = "slice_list"
+        elif "screen_k31c_kernel" in n: kind = "whole_table" if d in whole else "walk_all"
+        else: continue
+        a = acc[(kind, r["Counter_Name"])]; a[0] += float(r["Counter_Value"]); a[1] += 1
+print(f"{'counter':24s} {'whole_table':>16s} {'walk_all':>16s} {'slice_list':>16s}   slice_list / walk_all")
+for n in sorted({k[1] for k in acc}):
+    v = [acc[(k, n)][0] / max(1, acc[(k, n)][1]) for k in ("whole_table", "walk_all", "slice_list")]
+    print(f"{n:24s} {v[0]:16.0f} {v[1]:16.0f} {v[2]:16.0f}   {v[2] / v[1] if v[1] else 0:.2f}")
 PY
+cat $OUT/summary.log
